@@ -1,0 +1,322 @@
+/* go2sim.h — C ABI of the MI355X-native vectorised Go2 simulator.
+ *
+ * This is the drop-in boundary for the hot path of wty-yy/go2_rl_gym: it replaces the Isaac Gym
+ * tensor API as the reference uses it (acquire_*_tensor / refresh_*_tensor / simulate /
+ * set_dof_actuation_force_tensor / set_*_state_tensor_indexed; call sites
+ * legged_gym/envs/base/legged_robot.py:82-92,107-109,632-634,705-707,722-724,769-787) AND the
+ * per-env torch code around it (LeggedRobot.step :60-100, post_physics_step :102-142,
+ * reset_idx :180-245, _resample_commands :423-592, _compute_torques :594-618, _push_robots :709-724,
+ * compute_reward :247-274 + _reward_* :1228-1441, Go2Robot.compute_observations go2_env.py:23-53,
+ * RolloutStorage.compute_returns rsl_rl/rsl_rl/storage/rollout_storage.py:123-137).
+ *
+ * Two libraries export exactly this ABI:
+ *   go2_rl_gym_amd/csrc  -> libgo2sim_hip.so   the product: HIP kernels for gfx950; buffers are device
+ *                                              pointers; `stream` is a hipStream_t.
+ *   oracle/              -> libgo2oracle_f32/f64.so   TEST INFRASTRUCTURE ONLY: a plain-C CPU
+ *                                              restatement; buffers are host pointers; `stream` ignored.
+ *
+ * Conventions: all functions return 0 on success, a negative GO2SIM_E* code on failure, and never
+ * throw across the ABI.  One handle = one caller thread at a time; distinct handles are independent.
+ * All calls on the HIP library are asynchronous on the passed stream.  The library owns every buffer
+ * it hands out; pointers stay valid until go2sim_destroy.  Quaternions are (x,y,z,w)
+ * (legged_robot_config.py:91).  All floating point is fp32 (the f64 oracle build widens everything).
+ */
+#ifndef GO2SIM_H
+#define GO2SIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GO2SIM_ABI_VERSION 1
+
+#define GO2SIM_EINVAL   (-1)  /* bad argument / config */
+#define GO2SIM_ENOMEM   (-2)
+#define GO2SIM_EDEVICE  (-3)  /* HIP runtime error (message via go2sim_last_error) */
+#define GO2SIM_ENOTSUP  (-4)
+
+#define GO2_NUM_OBS 45           /* go2_config.py:34 */
+#define GO2_NUM_PRIV_OBS 263     /* go2_config.py:36 */
+#define GO2_NUM_ACTIONS 12
+#define GO2_NUM_BODIES_ABI 19
+#define GO2_NUM_HEIGHT_POINTS 187 /* 17 x 11, legged_robot_config.py:26-27 */
+
+/* Reward terms, in the order the library sums them.  (The reference iterates a Python set,
+ * legged_robot.py:927-936, so its order is not defined; ours is this enum.)  A term is active
+ * iff its scale != 0 (legged_robot.py:914-920). */
+enum {
+  GO2_REW_TRACKING_LIN_VEL = 0, /* :1322 */
+  GO2_REW_TRACKING_ANG_VEL,     /* :1336 */
+  GO2_REW_LIN_VEL_Z,            /* :1228 */
+  GO2_REW_ANG_VEL_XY,           /* :1232 */
+  GO2_REW_ORIENTATION,          /* :1236 */
+  GO2_REW_BASE_HEIGHT,          /* :1245 */
+  GO2_REW_TORQUES,              /* :1261 */
+  GO2_REW_DOF_VEL,              /* :1265 */
+  GO2_REW_DOF_ACC,              /* :1269 */
+  GO2_REW_ACTION_RATE,          /* :1273 */
+  GO2_REW_COLLISION,            /* :1277 */
+  GO2_REW_DOF_POS_LIMITS,       /* :1285 */
+  GO2_REW_DOF_VEL_LIMITS,       /* :1291 */
+  GO2_REW_TORQUE_LIMITS,        /* :1296 */
+  GO2_REW_FEET_AIR_TIME,        /* :1347 */
+  GO2_REW_STUMBLE,              /* :1360 (scale key feet_stumble has no function in the reference; key "stumble") */
+  GO2_REW_STAND_STILL,          /* :1365 */
+  GO2_REW_FEET_CONTACT_FORCES,  /* :1369 */
+  GO2_REW_ACTION_SMOOTHNESS,    /* :1373 */
+  GO2_REW_DOF_POWER,            /* :1381 */
+  GO2_REW_CORRECT_BASE_HEIGHT,  /* :1399 */
+  GO2_REW_FEET_REGULATION,      /* :1404 */
+  GO2_REW_SIMILAR_TO_DEFAULT,   /* :1416 */
+  GO2_REW_UPRIGHT,              /* :1420 */
+  GO2_REW_LEGS_DISTANCE,        /* :1423 */
+  GO2_REW_HIP_TO_DEFAULT,       /* go2_env.py:55 */
+  GO2_REW_X_COMMAND_HIP_REGULAR,/* go2_env.py:62 */
+  GO2_REW_TERMINATION,          /* :1281, added after the positive clip (:271-274) */
+  GO2_NUM_REWARDS
+};
+
+/* Per-env per-step uniform slots.  In normal operation each slot is Philox4x32-10(key = seed,
+ * counter = {global env id, slot/4, step_lo, step_hi})[slot%4] mapped to [0,1); in test mode
+ * (go2sim_inject_uniforms) the caller supplies the [num_envs][GO2_NUM_UNIFORMS] table, which is how
+ * parity with the reference's torch.rand draws is checked. */
+enum {
+  GO2_U_DELAY = 0,            /* legged_robot.py:72   randint(0, decimation+1) */
+  GO2_U_RSA = 1,              /* resample in _post_physics_step_callback: x,y,yaw,prob,comb,ang,dir  (:454-477,509,525,571,575) */
+  GO2_U_RESET_STRENGTH = 8,   /* :197 (12) */
+  GO2_U_RESET_OFFSET = 20,    /* :202 (12) */
+  GO2_U_RESET_KP = 32,        /* :205 (12) */
+  GO2_U_RESET_KD = 44,        /* :206 (12) */
+  GO2_U_RESET_TERRAIN = 56,   /* :1166 */
+  GO2_U_RESET_DOF = 57,       /* :628 (12) */
+  GO2_U_RESET_YAW = 69,       /* :645 */
+  GO2_U_RESET_XY = 70,        /* :698 (2) */
+  GO2_U_RESET_VEL = 72,       /* :703 (6) */
+  GO2_U_RSB = 78,             /* resample inside reset_idx (:227): same 7 slots as RSA */
+  GO2_U_PUSH = 85,            /* :718-719 (2 + 3) */
+  GO2_U_NOISE = 90,           /* go2_env.py:53 (45) */
+  GO2_NUM_UNIFORMS = 136      /* padded to a multiple of 4 */
+};
+
+typedef struct Go2SimCfg {
+  uint32_t struct_size;       /* sizeof(Go2SimCfg), checked */
+  uint32_t abi_version;       /* GO2SIM_ABI_VERSION */
+  int32_t  num_envs;          /* envs in this shard (one shard per process/GPU) */
+  int32_t  env_offset;        /* global index of this shard's env 0 (multi-GPU sharding) */
+  int32_t  num_envs_global;   /* total envs over all shards */
+  int32_t  _pad0;
+  uint64_t seed;
+
+  /* ---- sim: legged_robot_config.py:242-259 ---- */
+  float    sim_dt;            /* 0.005 */
+  int32_t  decimation;        /* 4 (go2_config.py:85) */
+  float    gravity[3];        /* 0,0,-9.81 */
+  int32_t  solver_iterations; /* PGS sweeps per substep */
+  float    contact_offset;    /* 0.01: candidate becomes a constraint when gap < contact_offset */
+  float    erp;               /* fraction of penetration removed per substep */
+  float    max_depenetration_velocity; /* 1.0 */
+  float    bounce_threshold_velocity;  /* 0.5 */
+  float    contact_cfm;       /* relative softness added to the Delassus diagonal */
+  float    joint_armature;    /* 0 (legged_robot_config.py:133) */
+  float    joint_limit_margin;/* rad: joint-limit row active within this distance of a hard limit */
+
+  /* ---- terrain: legged_robot_config.py:15-40 ---- */
+  int32_t  terrain_mode;      /* 0 = plane, 1 = heightfield */
+  float    terrain_friction;  /* 1.0 */
+  float    terrain_restitution; /* 0 */
+  int32_t  hf_rows, hf_cols;  /* height_samples[hf_rows][hf_cols], x -> rows (legged_robot.py:1213-1220) */
+  float    hf_hscale, hf_vscale, hf_border;
+  const int16_t* hf_samples;  /* HOST pointer, copied at create; NULL for plane */
+  int32_t  terrain_num_levels, terrain_num_types; /* 10 x 20 */
+  const float* terrain_origins; /* HOST [levels][types][3]; NULL for plane */
+  const int32_t* terrain_type_id; /* HOST [types] -> terrain kind 0..8 (terrain.cols2id); NULL for plane */
+  int32_t  terrain_curriculum;  /* cfg.terrain.curriculum */
+  int32_t  max_init_terrain_level;
+  int32_t  move_down_by_accumulated_xy_command;
+  float    terrain_length;    /* 8.0: used by the resampler even on a plane (:447) */
+  float    env_spacing;       /* 3.0 (plane grid, :1081-1091) */
+  int32_t  measure_heights;   /* 1 */
+
+  /* ---- control: go2_config.py:77-85 ---- */
+  float    kp[12], kd[12];
+  float    default_dof_pos[12];
+  float    action_scale;      /* 0.25 */
+  float    clip_actions;      /* 100 */
+  float    clip_observations; /* 100 */
+
+  /* ---- init state ---- */
+  float    base_init_state[13]; /* pos(3) quat(4) lin(3) ang(3), :1000-1001 */
+
+  /* ---- domain randomisation: go2_config.py:41-75 ---- */
+  int32_t  randomize_friction;      float friction_range[2];
+  int32_t  randomize_restitution;   float restitution_range[2];
+  int32_t  randomize_base_mass;     float added_mass_range[2];
+  int32_t  randomize_link_mass;     float link_mass_range[2];
+  int32_t  randomize_base_com;      float base_com_range[2];
+  int32_t  randomize_pd_gains;      float stiffness_mult_range[2]; float damping_mult_range[2];
+  int32_t  randomize_motor_zero_offset; float motor_zero_offset_range[2];
+  int32_t  randomize_motor_strength;    float motor_strength_range[2];
+  int32_t  push_robots;             int32_t push_interval; float max_push_vel_xy; float max_push_ang_vel;
+  int32_t  randomize_action_delay;
+
+  /* ---- commands: go2_config.py:97-146 ---- */
+  float    cmd_resampling_time;     /* 5 s */
+  int32_t  heading_command;         /* 0 */
+  int32_t  dynamic_resample_commands; /* 1 */
+  float    limit_vel_prob;          /* 0.2 */
+  int32_t  limit_vel_invert_when_continuous;
+  int32_t  stop_heading_at_limit;
+  float    limit_ang_vel_at_zero_command_prob; /* 0.2 */
+  int32_t  limit_vel_comb_count;    /* rows of product(limit_vel...) = 12 (:827-831) */
+  float    limit_vel_comb[36][3];   /* up to 36 rows of {-1,0,1} */
+  int32_t  zero_cmd_curriculum_enabled; float zero_cmd_curriculum[4]; /* start_iter,end_iter,start_value,end_value (:556-557) */
+  float    cmd_ranges[4][2];        /* lin_vel_x, lin_vel_y, ang_vel_yaw, heading (go2_config.py:142-146) */
+  int32_t  cmd_curriculum_count;    /* command_range_curriculum entries (:433-446) */
+  float    cmd_curriculum[4][9];    /* {iter, x0,x1, y0,y1, yaw0,yaw1, h0,h1} */
+  float    terrain_max_cmd_ranges[9][4][2]; /* per terrain kind (go2_config.py:129-139) */
+
+  /* ---- rewards: go2_config.py:156-205 ---- */
+  float    reward_scales[GO2_NUM_REWARDS]; /* RAW scales (before x dt); 0 = inactive */
+  int32_t  only_positive_rewards;
+  float    tracking_sigma;          /* 0.25 */
+  int32_t  dynamic_sigma_enabled;   float dynamic_sigma_vel[4]; /* min_lin,max_lin,min_ang,max_ang */
+  float    dynamic_sigma_max[9];
+  float    soft_dof_pos_limit;      /* 0.9 */
+  float    soft_dof_vel_limit, soft_torque_limit;
+  float    base_height_target;      /* 0.38 */
+  float    max_contact_force;       /* 147 */
+  float    min_legs_distance;       /* 0.1 */
+  int32_t  reward_curriculum_count; /* curriculum_rewards entries (go2_config.py:161-166) */
+  int32_t  reward_curriculum_term[4]; /* GO2_REW_* index */
+  float    reward_curriculum[4][4]; /* start_iter,end_iter,start_value,end_value */
+
+  /* ---- observations: legged_robot_config.py:214-234 ---- */
+  float    obs_scale_lin_vel, obs_scale_ang_vel, obs_scale_dof_pos, obs_scale_dof_vel, obs_scale_height;
+  int32_t  add_noise; float noise_level;
+  float    noise_dof_pos, noise_dof_vel, noise_lin_vel, noise_ang_vel, noise_gravity, noise_height;
+
+  float    episode_length_s;        /* 25 -> max_episode_length = ceil(25/0.02) = 1250 */
+  int32_t  send_timeouts;
+  int32_t  num_steps_per_env;       /* 24: hard-coded in the env (:58), drives every curriculum */
+} Go2SimCfg;
+
+/* Raw views of the library-owned buffers (device pointers for the HIP library, host pointers for the
+ * oracle).  Shapes are row-major as the reference's torch tensors see them. */
+typedef struct Go2SimBuffers {
+  /* the four Isaac Gym state tensors (legged_robot.py:779-787) */
+  float*   root_states;        /* [N,13] */
+  float*   dof_state;          /* [N,12,2]  (pos, vel) */
+  float*   contact_forces;     /* [N,19,3]  world frame, last substep */
+  float*   rigid_body_states;  /* [N,19,13] pos(3) quat(4) lin(3) ang(3) */
+  /* VecEnv buffers (base_task.py:41-49) */
+  float*   obs_buf;            /* [N,45] */
+  float*   privileged_obs_buf; /* [N,263] */
+  float*   rew_buf;            /* [N] */
+  uint8_t* reset_buf;          /* [N] bool */
+  uint8_t* time_out_buf;       /* [N] bool */
+  int64_t* episode_length_buf; /* [N]  (the runner overwrites it: on_policy_runner.py:118) */
+  /* per-env state the reference keeps as attributes (legged_robot.py:805-859) */
+  float*   torques;            /* [N,12] last substep */
+  float*   actions;            /* [N,12] clipped */
+  float*   last_actions;       /* [N,12] */
+  float*   last_last_actions;  /* [N,12] */
+  float*   last_dof_vel;       /* [N,12] */
+  float*   last_root_vel;      /* [N,6] */
+  float*   commands;           /* [N,4] (writable by the caller: play.py:54-60) */
+  float*   commands_resampling_step; /* [N] */
+  float*   commands_xy_accumulation; /* [N,2] */
+  uint8_t* stop_heading;       /* [N] */
+  uint8_t* last_is_limit_vel;  /* [N] */
+  float*   base_lin_vel;       /* [N,3] */
+  float*   base_ang_vel;       /* [N,3] */
+  float*   projected_gravity;  /* [N,3] */
+  float*   rpy;                /* [N,3] */
+  float*   measured_heights;   /* [N,187] */
+  float*   max_move_distance;  /* [N] */
+  float*   feet_air_time;      /* [N,4] */
+  uint8_t* last_contacts;      /* [N,4] */
+  uint8_t* last_contacts2;     /* [N,4] */
+  float*   motor_strengths;    /* [N,12] */
+  float*   motor_zero_offsets; /* [N,12] */
+  float*   p_gains_multiplier; /* [N,12] */
+  float*   d_gains_multiplier; /* [N,12] */
+  float*   env_origins;        /* [N,3] */
+  int64_t* terrain_levels;     /* [N] */
+  int64_t* terrain_types;      /* [N] */
+  float*   episode_sums;       /* [GO2_NUM_REWARDS,N] */
+  /* per-env physical DR fixed at creation (legged_robot.py:320-402) */
+  float*   friction_coeffs;    /* [N] shape friction */
+  float*   restitution_coeffs; /* [N] */
+  float*   added_base_mass;    /* [N] */
+  float*   added_base_com;     /* [N,3] */
+  float*   link_mass_ratio;    /* [N,18] */
+  /* extras["episode"] (legged_robot.py:229-242): mean over the envs reset in the latest step that
+   * had >= 1 reset, divided by max_episode_length_s; [GO2_NUM_REWARDS + 1] (last = #envs reset). */
+  float*   episode_info;
+  /* warm-start impulses of the 4 foot contacts */
+  float*   foot_impulse;       /* [N,4,3] */
+} Go2SimBuffers;
+
+typedef struct Go2Sim Go2Sim;
+
+/* 1 if this library computes on the GPU (product), 0 if it is the CPU oracle. */
+int go2sim_is_device_library(void);
+const char* go2sim_last_error(void);
+/* Fill `cfg` with the task=go2 defaults (go2_config.py + legged_robot_config.py); plane terrain. */
+void go2sim_default_cfg(Go2SimCfg* cfg);
+
+int  go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out);
+void go2sim_destroy(Go2Sim* h);
+int  go2sim_get_buffers(Go2Sim* h, Go2SimBuffers* out);
+
+/* ---- fused fast path ------------------------------------------------------------------------- */
+/* LeggedRobot.reset_idx(all envs) (base_task.py:82-84) without the following step. */
+int  go2sim_reset_all(Go2Sim* h, void* stream);
+/* LeggedRobot.step (legged_robot.py:60-100): clip actions, `decimation` x {delay select, PD torque,
+ * clip, strength, articulated-body substep with contact}, post_physics_step, clip observations.
+ * `actions` is [N,12] in the library's memory space. */
+int  go2sim_step(Go2Sim* h, const float* actions, void* stream);
+
+/* ---- fine-grained operations (the Isaac Gym tensor API the reference drives) ------------------- */
+/* legged_robot.py:73-92: only the physics loop of step() (actions must be in buffers.actions). */
+int  go2sim_simulate(Go2Sim* h, void* stream);
+/* legged_robot.py:102-142: post_physics_step() on whatever the four state tensors currently hold. */
+int  go2sim_post_physics(Go2Sim* h, void* stream);
+/* gym.set_actor_root_state_tensor_indexed / set_dof_state_tensor_indexed (:632,:705,:722):
+ * commit rows `ids` of the API tensors into the simulator's internal state. ids may be NULL = all. */
+int  go2sim_set_root_state_indexed(Go2Sim* h, const int32_t* ids, int32_t count, void* stream);
+int  go2sim_set_dof_state_indexed(Go2Sim* h, const int32_t* ids, int32_t count, void* stream);
+
+/* ---- host-side scalars the reference keeps in Python ------------------------------------------ */
+int     go2sim_set_common_step_counter(Go2Sim* h, int64_t value);  /* train.py:14 */
+int64_t go2sim_get_common_step_counter(Go2Sim* h);
+/* update_reward_curriculum(force_update) (:144-152) */
+int  go2sim_update_reward_curriculum(Go2Sim* h, int force_update);
+/* current reward_curriculum_scales / command_ranges / zero_command_proba, for inspection */
+int  go2sim_get_curriculum_state(Go2Sim* h, float reward_curriculum_scale[GO2_NUM_REWARDS],
+                                 float cmd_ranges[4][2], float* zero_command_proba);
+
+/* ---- test hooks ------------------------------------------------------------------------------- */
+/* Use the caller's uniforms [N][GO2_NUM_UNIFORMS] for the NEXT step/reset only (NULL = Philox). */
+int  go2sim_inject_uniforms(Go2Sim* h, const float* uniforms, void* stream);
+/* Copy the Philox uniforms the next step would use into `out` [N][GO2_NUM_UNIFORMS]. */
+int  go2sim_peek_uniforms(Go2Sim* h, float* out, void* stream);
+
+/* ---- PPO rollout kernels ---------------------------------------------------------------------- */
+/* RolloutStorage.compute_returns (rollout_storage.py:123-137) for a [T,N] rollout:
+ *   GAE(gamma, lam) reverse scan -> returns, raw advantages; also accumulates
+ *   partials[3] = {sum adv, sum adv^2, count} (float64) for the caller to all-reduce across shards.
+ * rewards/values/returns/advantages: float [T,N]; dones: uint8 [T,N]; last_values: float [N]. */
+int  go2sim_gae(const float* rewards, const uint8_t* dones, const float* values, const float* last_values,
+                float* returns, float* advantages, double* partials, int32_t T, int32_t N,
+                float gamma, float lam, void* stream);
+/* advantages = (advantages - mean) / (std + 1e-8) with mean/std (unbiased) from the (all-reduced)
+ * partials (rollout_storage.py:137). */
+int  go2sim_normalize_advantages(float* advantages, const double* partials, int32_t count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GO2SIM_H */
