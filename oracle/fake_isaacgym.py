@@ -1,0 +1,348 @@
+"""In-memory stand-in for the `isaacgym` python package, so the reference's Python can be IMPORTED in the
+build container (there is no Isaac Gym for ROCm, and no network).  CONTAINER-ONLY TEST TOOLING:
+used by oracle/gen_golden.py to capture golden vectors from /root/reference; never shipped to, or
+imported on, the GPU box, and never imported by the product.
+
+Nothing here simulates anything: `FakeGym` hands the reference four torch tensors (root, dof, net contact
+force, rigid body state) that the harness fills with synthetic numbers, and records the torques the
+reference asks it to apply.  The seven `torch_utils` helpers restate the published semantics listed in
+SURVEY.md App. C (isaacgym itself is absent from /root/reference).
+
+It also provides *uniform injection*: while `INJECT.table` is set, every torch.rand / torch.randint /
+rand_like / randint_like / torch_rand_float call made from a known call site of the reference
+(legged_robot.py / go2_env.py / isaacgym_utils.py line numbers) returns the caller's
+per-env uniforms from the [N, GO2_NUM_UNIFORMS] table instead of fresh random numbers, using the slot
+layout of include/go2sim.h.  Unknown call sites fall through to the real generator.
+"""
+import inspect
+import sys
+import types
+
+import numpy as np
+import torch
+
+BODY_NAMES = ["base", "Head_upper", "Head_lower"] + [f"{l}_{p}" for l in ("FL", "FR", "RL", "RR") for p in ("hip", "thigh", "calf", "foot")]
+DOF_NAMES = [f"{l}_{j}_joint" for l in ("FL", "FR", "RL", "RR") for j in ("hip", "thigh", "calf")]
+# URDF <limit> values (resources/robots/go2/urdf/go2.urdf :170-174, :225-229, :280-284, ...)
+DOF_LOWER = [-1.0472, -1.5708, -2.7227] * 2 + [-1.0472, -0.5236, -2.7227] * 2
+DOF_UPPER = [1.0472, 3.4907, -0.83776] * 2 + [1.0472, 4.5379, -0.83776] * 2
+DOF_EFFORT = [23.7, 23.7, 35.55] * 4
+DOF_VELOCITY = [30.1, 30.1, 20.07] * 4
+
+# slot layout: keep in sync with include/go2sim.h
+U = dict(DELAY=0, RSA=1, RESET_STRENGTH=8, RESET_OFFSET=20, RESET_KP=32, RESET_KD=44, RESET_TERRAIN=56, RESET_DOF=57,
+         RESET_YAW=69, RESET_XY=70, RESET_VEL=72, RSB=78, PUSH=85, NOISE=90, NUM=136)
+
+
+class _Inject:
+    table = None      # torch [N, 136] float32 or None
+    log = []
+
+
+INJECT = _Inject()
+_orig = dict(rand=torch.rand, randint=torch.randint, rand_like=torch.rand_like, randint_like=torch.randint_like)
+
+
+def _site(depth_start=2):
+    """(basename, lineno, frame) of the nearest caller inside the reference tree."""
+    f = sys._getframe(depth_start)
+    while f is not None:
+        fn = f.f_code.co_filename
+        if "/root/reference/" in fn:
+            return fn.rsplit("/", 1)[1], f.f_lineno, f
+        f = f.f_back
+    return None, None, None
+
+
+def _resample_base(frame):
+    """RSA if _resample_commands was called from the post-physics callback, RSB if from reset_idx."""
+    f = frame
+    while f is not None:
+        if f.f_code.co_name == "reset_idx":
+            return U["RSB"]
+        if f.f_code.co_name == "_post_physics_step_callback":
+            return U["RSA"]
+        f = f.f_back
+    return U["RSB"]   # direct call (e.g. from reset())
+
+
+def _frame_named(frame, name):
+    f = frame
+    while f is not None:
+        if f.f_code.co_name == name:
+            return f
+        f = f.f_back
+    return None
+
+
+def _lookup(shape_hint=None):
+    """Return (slot, width, ids) for the current call site, or None."""
+    if INJECT.table is None:
+        return None
+    fname, line, fr = _site(3)
+    if fname is None:
+        return None
+    loc = fr.f_locals
+    if fname == "legged_robot.py":
+        if line == 72: return U["DELAY"], 1, None
+        if 195 <= line <= 199: return U["RESET_STRENGTH"], 12, loc["env_ids"]
+        if line == 202: return U["RESET_OFFSET"], 12, loc["env_ids"]
+        if line == 205: return U["RESET_KP"], 12, loc["env_ids"]
+        if line == 206: return U["RESET_KD"], 12, loc["env_ids"]
+        if line == 628: return U["RESET_DOF"], 12, loc["env_ids"]
+        if line == 645: return U["RESET_YAW"], 1, loc["env_ids"]
+        if line == 698: return U["RESET_XY"], 2, loc["env_ids"]
+        if line == 703: return U["RESET_VEL"], 6, loc["env_ids"]
+        if line == 718: return U["PUSH"], 2, None
+        if line == 719: return U["PUSH"] + 2, 3, None
+        if 1165 <= line <= 1167: return U["RESET_TERRAIN"], 1, loc["env_ids"]
+        if line in (469, 474): return _resample_base(fr) + 2, 1, loc["env_ids"]
+        if line == 509: return _resample_base(fr) + 3, 1, loc["env_ids"]
+        if line == 525: return _resample_base(fr) + 4, 1, loc["change_lim_env_ids"]
+        if line == 571: return _resample_base(fr) + 5, 1, loc["zero_env_ids"]
+        if line == 575: return _resample_base(fr) + 6, 1, loc["add_ang_env_ids"]
+        return None
+    if fname == "isaacgym_utils.py":
+        rs = _frame_named(fr, "_resample_commands")
+        if rs is None:
+            return None
+        l2 = rs.f_lineno
+        base = _resample_base(rs)
+        ids = loc["env_ids"]
+        if 454 <= l2 <= 460 or 479 <= l2 <= 484: return base + 0, 1, ids
+        if 461 <= l2 <= 467 or 485 <= l2 <= 490: return base + 1, 1, ids
+        if 491 <= l2 <= 504: return base + 2, 1, ids
+        return None
+    if fname == "go2_env.py":
+        if line == 53: return U["NOISE"], 45, None
+    return None
+
+
+def _take(slot, width, ids, shape):
+    t = INJECT.table
+    rows = t if ids is None else t[ids.long()]
+    out = rows[:, slot:slot + width]
+    INJECT.log.append((slot, width, None if ids is None else ids.clone()))
+    return out.reshape(shape).clone()
+
+
+def _shape_of(args):
+    if len(args) == 1 and isinstance(args[0], (tuple, list, torch.Size)):
+        return tuple(args[0])
+    return tuple(args)
+
+
+def rand(*size, **kw):
+    hit = _lookup()
+    if hit is None:
+        return _orig["rand"](*size, **kw)
+    return _take(*hit, _shape_of(size))
+
+
+def rand_like(x, **kw):
+    hit = _lookup()
+    if hit is None:
+        return _orig["rand_like"](x, **kw)
+    return _take(*hit, tuple(x.shape))
+
+
+def randint(*args, **kw):
+    hit = _lookup()
+    if hit is None:
+        return _orig["randint"](*args, **kw)
+    if len(args) == 3:
+        low, high, size = args
+    else:
+        (high, size), low = args, 0
+    u = _take(*hit, tuple(size))
+    return torch.clamp(torch.floor(u * (high - low)).long() + low, max=high - 1)
+
+
+def randint_like(x, *args, **kw):
+    hit = _lookup()
+    if hit is None:
+        return _orig["randint_like"](x, *args, **kw)
+    high = args[-1] if args else kw["high"]
+    low = args[0] if len(args) == 2 else 0
+    u = _take(*hit, tuple(x.shape))
+    return torch.clamp(torch.floor(u * (high - low)).to(x.dtype) + low, max=high - 1)
+
+
+def patch_torch():
+    torch.rand, torch.randint, torch.rand_like, torch.randint_like = rand, randint, rand_like, randint_like
+
+
+def unpatch_torch():
+    torch.rand, torch.randint, torch.rand_like, torch.randint_like = _orig["rand"], _orig["randint"], _orig["rand_like"], _orig["randint_like"]
+
+
+# ---- isaacgym.torch_utils (semantics: SURVEY App. C) -------------------------------------------------
+def torch_rand_float(lower, upper, shape, device):
+    return (upper - lower) * torch.rand(*shape, device=device) + lower
+
+
+def quat_rotate_inverse(q, v):
+    q_w = q[:, -1]
+    q_vec = q[:, :3]
+    a = v * (2.0 * q_w ** 2 - 1.0).unsqueeze(-1)
+    b = torch.cross(q_vec, v, dim=-1) * q_w.unsqueeze(-1) * 2.0
+    c = q_vec * torch.bmm(q_vec.view(q.shape[0], 1, 3), v.view(q.shape[0], 3, 1)).squeeze(-1) * 2.0
+    return a - b + c
+
+
+def quat_apply(a, b):
+    shape = b.shape
+    a = a.reshape(-1, 4)
+    b = b.reshape(-1, 3)
+    xyz = a[:, :3]
+    t = xyz.cross(b, dim=-1) * 2
+    return (b + a[:, 3:] * t + xyz.cross(t, dim=-1)).view(shape)
+
+
+def quat_from_euler_xyz(roll, pitch, yaw):
+    cy, sy = torch.cos(yaw * 0.5), torch.sin(yaw * 0.5)
+    cr, sr = torch.cos(roll * 0.5), torch.sin(roll * 0.5)
+    cp, sp = torch.cos(pitch * 0.5), torch.sin(pitch * 0.5)
+    qw = cy * cr * cp + sy * sr * sp
+    qx = cy * sr * cp - sy * cr * sp
+    qy = cy * cr * sp + sy * sr * cp
+    qz = sy * cr * cp - cy * sr * sp
+    return torch.stack([qx, qy, qz, qw], dim=-1)
+
+
+def normalize(x, eps=1e-9):
+    return x / x.norm(p=2, dim=-1).clamp(min=eps, max=None).unsqueeze(-1)
+
+
+def to_torch(x, dtype=torch.float, device="cpu", requires_grad=False):
+    return torch.tensor(x, dtype=dtype, device=device, requires_grad=requires_grad)
+
+
+def get_axis_params(value, axis_idx, x_value=0.0, dtype=float, n_dims=3):
+    zs = np.zeros((n_dims,))
+    zs[axis_idx] = 1.0
+    params = np.where(zs == 1.0, value, zs)
+    params[0] = x_value
+    return list(params.astype(dtype))
+
+
+# ---- gymapi / gymutil / gymtorch ----------------------------------------------------------------------
+class Bag:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class Vec3:
+    def __init__(self, x=0.0, y=0.0, z=0.0):
+        self.x, self.y, self.z = float(x), float(y), float(z)
+
+    def __add__(self, o):
+        return Vec3(self.x + o.x, self.y + o.y, self.z + o.z)
+
+
+class Transform:
+    def __init__(self):
+        self.p = Vec3()
+        self.r = Bag(x=0, y=0, z=0, w=1)
+
+
+class SimParams(Bag):
+    def __init__(self):
+        super().__init__(dt=0.005, substeps=1, use_gpu_pipeline=False, up_axis=1, gravity=Vec3(0, 0, -9.81),
+                         physx=Bag(use_gpu=False, num_subscenes=0, num_threads=10))
+
+
+class FakeGym:
+    def __init__(self):
+        self.N = None
+        self.on_simulate = None
+        self.torque_log = []
+
+    # creation-time no-ops
+    def create_sim(self, *a): return "sim"
+    def add_ground(self, *a): pass
+    def add_heightfield(self, *a): pass
+    def add_triangle_mesh(self, *a): pass
+    def load_asset(self, *a): return "asset"
+    def get_asset_dof_count(self, a): return 12
+    def get_asset_rigid_body_count(self, a): return 19
+    def get_asset_rigid_body_names(self, a): return list(BODY_NAMES)
+    def get_asset_dof_names(self, a): return list(DOF_NAMES)
+    def get_asset_dof_properties(self, a):
+        p = np.zeros(12, dtype=[("lower", "f4"), ("upper", "f4"), ("velocity", "f4"), ("effort", "f4")])
+        p["lower"], p["upper"], p["velocity"], p["effort"] = DOF_LOWER, DOF_UPPER, DOF_VELOCITY, DOF_EFFORT
+        return p
+    def get_asset_rigid_shape_properties(self, a): return [Bag(friction=1.0, restitution=0.0) for _ in range(30)]
+    def set_asset_rigid_shape_properties(self, *a): pass
+    def create_env(self, *a): return 0
+    def create_actor(self, *a): return 0
+    def set_actor_dof_properties(self, *a): pass
+    def get_actor_rigid_body_properties(self, *a): return [Bag(mass=1.0, com=Vec3()) for _ in range(19)]
+    def set_actor_rigid_body_properties(self, *a, **k): pass
+    def find_actor_rigid_body_handle(self, env, actor, name): return BODY_NAMES.index(name)
+    def find_actor_dof_handle(self, env, actor, name): return DOF_NAMES.index(name)
+    def prepare_sim(self, sim): pass
+
+    def alloc(self, N):
+        self.N = N
+        self.root = torch.zeros(N, 13); self.root[:, 6] = 1.0
+        self.dof = torch.zeros(N * 12, 2)
+        self.contact = torch.zeros(N * 19, 3)
+        self.rigid = torch.zeros(N * 19, 13)
+
+    def acquire_actor_root_state_tensor(self, sim): return self.root
+    def acquire_dof_state_tensor(self, sim): return self.dof
+    def acquire_net_contact_force_tensor(self, sim): return self.contact
+    def acquire_rigid_body_state_tensor(self, sim): return self.rigid
+
+    def set_dof_actuation_force_tensor(self, sim, t):
+        self.torque_log.append(t.clone())
+
+    def simulate(self, sim):
+        if self.on_simulate is not None:
+            self.on_simulate()
+
+    def __getattr__(self, name):
+        if name.startswith(("refresh_", "set_", "fetch_", "get_elapsed", "get_sim_time", "viewer", "subscribe", "step_", "draw_", "poll_", "sync_")):
+            return lambda *a, **k: True
+        raise AttributeError(name)
+
+
+GYM = FakeGym()
+
+
+def install():
+    """Register the stub module tree in sys.modules (before importing anything from the reference)."""
+    iso = types.ModuleType("isaacgym")
+    gymapi = types.ModuleType("isaacgym.gymapi")
+    gymutil = types.ModuleType("isaacgym.gymutil")
+    gymtorch = types.ModuleType("isaacgym.gymtorch")
+    tu = types.ModuleType("isaacgym.torch_utils")
+    terr = types.ModuleType("isaacgym.terrain_utils")
+    for n in ("torch_rand_float", "quat_rotate_inverse", "quat_apply", "quat_from_euler_xyz", "normalize", "to_torch", "get_axis_params"):
+        setattr(tu, n, globals()[n])
+    tu.__all__ = ["torch_rand_float", "quat_rotate_inverse", "quat_apply", "quat_from_euler_xyz", "normalize", "to_torch", "get_axis_params"]
+    gymapi.acquire_gym = lambda: GYM
+    gymapi.Vec3, gymapi.Transform, gymapi.SimParams = Vec3, Transform, SimParams
+    gymapi.AssetOptions = lambda: Bag()
+    gymapi.PlaneParams = lambda: Bag(normal=None)
+    gymapi.HeightFieldParams = lambda: Bag(transform=Transform())
+    gymapi.TriangleMeshParams = lambda: Bag(transform=Transform())
+    gymapi.CameraProperties = lambda: Bag()
+    gymapi.SIM_PHYSX, gymapi.SIM_FLEX = 1, 0
+    gymapi.KEY_ESCAPE, gymapi.KEY_V = 0, 1
+    gymutil.parse_device_str = lambda s: (s.split(":")[0], int(s.split(":")[1]) if ":" in s else 0)
+    gymutil.parse_sim_config = lambda cfg, sp: None
+    gymtorch.wrap_tensor = lambda t: t
+    gymtorch.unwrap_tensor = lambda t: t
+    iso.gymapi, iso.gymutil, iso.gymtorch, iso.torch_utils, iso.terrain_utils = gymapi, gymutil, gymtorch, tu, terr
+    for m in (iso, gymapi, gymutil, gymtorch, tu, terr):
+        sys.modules[m.__name__] = m
+    tb = types.ModuleType("torch.utils.tensorboard")
+
+    class SummaryWriter:
+        def __init__(self, *a, **k): pass
+        def add_scalar(self, *a, **k): pass
+    tb.SummaryWriter = SummaryWriter
+    sys.modules["torch.utils.tensorboard"] = tb
+    torch.utils.tensorboard = tb

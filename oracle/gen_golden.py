@@ -1,0 +1,294 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING THE REFERENCE in the build container.
+
+CONTAINER-ONLY (reads /root/reference; the GPU box has no such path and never runs this).
+What it pins: everything of the hot path that lives in the reference's own Python —
+torque computation and action delay, post_physics_step (derived base quantities, command resampling,
+termination, the reward terms, reset_idx, push, observations, last_* bookkeeping), and
+RolloutStorage.compute_returns / one PPO.update.  The physics itself (Isaac Gym) is absent, so the four
+simulator tensors are filled with SYNTHETIC states: the fixtures record those inputs, the per-env uniforms
+injected at each torch.rand call site (oracle/fake_isaacgym.py) and every output the reference computed.
+
+Usage:  python oracle/gen_golden.py            (writes tests/golden/*.npz + MANIFEST.json)
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.dont_write_bytecode = True
+sys.path.insert(0, HERE)
+import fake_isaacgym as fig  # noqa: E402
+
+fig.install()
+sys.path.insert(0, "/root/reference/rsl_rl")
+sys.path.insert(0, "/root/reference")
+import isaacgym  # noqa: E402,F401  (the stub; same import order as legged_gym/scripts/train.py:6-7)
+from legged_gym.envs import *  # noqa: E402,F401,F403
+from legged_gym.utils import task_registry  # noqa: E402
+from legged_gym.utils.helpers import class_to_dict  # noqa: E402
+
+# reward name -> index in the GO2_REW_* enum of include/go2sim.h
+sys.path.insert(0, ROOT)
+from go2_rl_gym_amd._abi import Abi  # noqa: E402
+
+ABI = Abi()
+NU = ABI.GO2_NUM_UNIFORMS
+
+
+def make_env(N, seed=1):
+    env_cfg, train_cfg = task_registry.get_cfgs("go2")
+    env_cfg.env.num_envs = N
+    env_cfg.terrain.mesh_type = "plane"
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    fig.GYM.alloc(N)
+    env = Go2Robot(env_cfg, fig.SimParams(), 1, "cpu", True)  # noqa: F405
+    return env, env_cfg, train_cfg
+
+
+def synth_state(rng, N, env):
+    """One synthetic simulator state (the 'fake physics')."""
+    root = np.zeros((N, 13), np.float32)
+    root[:, 0:2] = env.env_origins[:, :2].numpy() + rng.uniform(-3, 3, (N, 2))
+    root[:, 2] = rng.uniform(0.2, 0.45, N)
+    yaw = rng.uniform(-np.pi, np.pi, N); roll = rng.normal(0, 0.15, N); pitch = rng.normal(0, 0.15, N)
+    q = fig.quat_from_euler_xyz(torch.tensor(roll), torch.tensor(pitch), torch.tensor(yaw)).numpy()
+    root[:, 3:7] = q
+    root[:, 7:10] = rng.uniform(-1.2, 1.2, (N, 3))
+    root[:, 10:13] = rng.uniform(-1.5, 1.5, (N, 3))
+    q0 = env.default_dof_pos.numpy().reshape(1, 12)
+    dof = np.zeros((4, N, 12, 2), np.float32)
+    base = q0 * rng.uniform(0.4, 1.6, (N, 12))
+    # push a few joints past their soft limits
+    far = rng.uniform(size=(N, 12)) < 0.05
+    base = np.where(far, q0 + rng.uniform(-2.0, 2.0, (N, 12)), base)
+    for i in range(4):
+        dof[i, :, :, 0] = base + 0.01 * i * rng.normal(size=(N, 12))
+        dof[i, :, :, 1] = rng.uniform(-8, 8, (N, 12))
+    contact = np.zeros((N, 19, 3), np.float32)
+    feet = [6, 10, 14, 18]
+    on = rng.uniform(size=(N, 4)) < 0.6
+    contact[:, feet, 2] = on * rng.uniform(0, 120, (N, 4))
+    contact[:, feet, 0:2] = on[..., None] * rng.normal(0, 15, (N, 4, 2))
+    pen = [4, 5, 8, 9, 12, 13, 16, 17]
+    hit = rng.uniform(size=(N, 8)) < 0.08
+    contact[:, pen, :] = hit[..., None] * rng.normal(0, 5, (N, 8, 3))
+    small = rng.uniform(size=(N, 8)) < 0.05
+    contact[:, pen, :] += small[..., None] * rng.normal(0, 0.05, (N, 8, 3))
+    base_hit = rng.uniform(size=N) < 0.04
+    contact[:, 0, :] = base_hit[:, None] * rng.normal(0, 4, (N, 3))
+    feet_state = np.zeros((N, 4, 13), np.float32)
+    feet_state[:, :, 0:2] = root[:, None, 0:2] + rng.uniform(-0.3, 0.3, (N, 4, 2))
+    feet_state[:, :, 2] = rng.uniform(0.0, 0.12, (N, 4))
+    feet_state[:, :, 7:10] = rng.uniform(-2, 2, (N, 4, 3))
+    return root, dof, contact.astype(np.float32), feet_state
+
+
+def gen_env_sequence(N=16, T=64, seed=7):
+    rng = np.random.default_rng(seed)
+    env, env_cfg, train_cfg = make_env(N)
+    fig.patch_torch()
+    names_active = list(env.episode_sums.keys())
+    rew_index = {n: ABI.reward_names.index(n) for n in names_active}
+    feet = [6, 10, 14, 18]
+    G = fig.GYM
+    start_counter = 24 * 1000
+    env.common_step_counter = start_counter
+    env.update_reward_curriculum(force_update=True)
+
+    rec = {k: [] for k in ("U", "actions", "root_in", "dof_in", "contact_in", "feet_in", "torques", "obs", "priv", "rew", "reset",
+                           "time_out", "commands", "cmd_timer", "cmd_xy_acc", "last_is_limit_vel", "ep_len", "episode_sums",
+                           "root_out", "dof_out", "last_actions", "last_last_actions", "last_dof_vel", "base_lin_vel", "base_ang_vel",
+                           "projected_gravity", "rpy", "motor_strengths", "motor_zero_offsets", "p_gains_multiplier", "d_gains_multiplier",
+                           "max_move_distance", "episode_info", "episode_info_valid", "ep_len_in", "cmd_timer_in")}
+
+    def snapshot(t_extras_rebuilt):
+        rec["obs"].append(env.obs_buf.numpy().copy()); rec["priv"].append(env.privileged_obs_buf.numpy().copy())
+        rec["rew"].append(env.rew_buf.numpy().copy()); rec["reset"].append(env.reset_buf.numpy().astype(np.uint8))
+        rec["time_out"].append(env.time_out_buf.numpy().astype(np.uint8))
+        rec["commands"].append(env.commands.numpy().copy()); rec["cmd_timer"].append(env.commands_resampling_step.numpy().copy())
+        rec["cmd_xy_acc"].append(env.commands_xy_accumulation.numpy().copy())
+        rec["last_is_limit_vel"].append(env.last_is_limit_vel.numpy().astype(np.uint8)); rec["ep_len"].append(env.episode_length_buf.numpy().copy())
+        es = np.zeros((ABI.GO2_NUM_REWARDS, N), np.float32)
+        for n, i in rew_index.items():
+            es[i] = env.episode_sums[n].numpy()
+        rec["episode_sums"].append(es)
+        rec["root_out"].append(env.root_states.numpy().copy()); rec["dof_out"].append(env.dof_state.numpy().reshape(N, 12, 2).copy())
+        rec["last_actions"].append(env.last_actions.numpy().copy())
+        rec["last_last_actions"].append(env.last_last_actions.numpy().copy() if hasattr(env, "last_last_actions") else np.zeros((N, 12), np.float32))
+        rec["last_dof_vel"].append(env.last_dof_vel.numpy().copy())
+        for k in ("base_lin_vel", "base_ang_vel", "projected_gravity", "rpy", "motor_strengths", "motor_zero_offsets", "p_gains_multiplier", "d_gains_multiplier", "max_move_distance"):
+            rec[k].append(getattr(env, k).numpy().copy())
+        info = np.zeros(ABI.GO2_NUM_REWARDS, np.float32)
+        if t_extras_rebuilt:
+            for n, i in rew_index.items():
+                info[i] = float(env.extras["episode"]["rew_" + n])
+        rec["episode_info"].append(info); rec["episode_info_valid"].append(np.uint8(t_extras_rebuilt))
+
+    def new_table():
+        return rng.uniform(0, 1, (N, NU)).astype(np.float32)
+
+    # ---- reset_idx(all) (base_task.py:82-84) with table 0 ------------------------------------------------
+    U0 = new_table()
+    fig.INJECT.table = torch.from_numpy(U0)
+    env.reset_idx(torch.arange(N))
+    reset_all_out = dict(root=env.root_states.numpy().copy(), dof=env.dof_state.numpy().reshape(N, 12, 2).copy(), commands=env.commands.numpy().copy(),
+                         motor_strengths=env.motor_strengths.numpy().copy(), motor_zero_offsets=env.motor_zero_offsets.numpy().copy(),
+                         p_gains_multiplier=env.p_gains_multiplier.numpy().copy(), d_gains_multiplier=env.d_gains_multiplier.numpy().copy(),
+                         cmd_timer=env.commands_resampling_step.numpy().copy(), cmd_xy_acc=env.commands_xy_accumulation.numpy().copy(),
+                         last_is_limit_vel=env.last_is_limit_vel.numpy().astype(np.uint8))
+
+    counters = dict(resets=0, time_outs=0, pushes=0, resample_cb=0, limit=0, zero=0)
+    for t in range(T):
+        if t == 1:
+            # what OnPolicyRunner.learn(init_at_random_ep_len=True) does (on_policy_runner.py:117-118); a few envs close to time-out
+            el = rng.integers(0, 1250, N)
+            el[: N // 4] = rng.integers(1225, 1251, N // 4)
+            env.episode_length_buf = torch.from_numpy(el.astype(np.int64))
+            # stagger the command timers so the post-physics callback resamples during the sequence (:409-410)
+            env.commands_resampling_step[:] = torch.from_numpy(rng.integers(1, 60, N).astype(np.float32))
+        rec["ep_len_in"].append(env.episode_length_buf.numpy().copy())
+        rec["cmd_timer_in"].append(env.commands_resampling_step.numpy().copy())
+        U = new_table()
+        root, dof, contact, feet_state = synth_state(rng, N, env)
+        actions = rng.normal(0, 1.0, (N, 12)).astype(np.float32)
+        actions[rng.uniform(size=(N, 12)) < 0.01] *= 300.0      # exercise clip_actions
+        if t == 0:
+            actions[:] = 0                                        # reset() steps with zeros (base_task.py:85)
+        sub = {"i": 0}
+
+        def on_sim():
+            i = sub["i"]
+            G.dof[:] = torch.from_numpy(dof[i].reshape(N * 12, 2))
+            if i == 3:
+                G.root[:] = torch.from_numpy(root)
+                G.contact[:] = torch.from_numpy(contact.reshape(N * 19, 3))
+                G.rigid.view(N, 19, 13)[:, feet, :] = torch.from_numpy(feet_state)
+            sub["i"] += 1
+        G.on_simulate = on_sim
+        G.torque_log.clear()
+        fig.INJECT.table = torch.from_numpy(U)
+        fig.INJECT.log.clear()
+        pre_extras = env.extras.get("episode", None)
+        was_limit = env.last_is_limit_vel.clone()
+        env.step(torch.from_numpy(actions))
+        rebuilt = env.extras.get("episode", None) is not pre_extras
+        rec["U"].append(U); rec["actions"].append(actions); rec["root_in"].append(root); rec["dof_in"].append(dof)
+        rec["contact_in"].append(contact); rec["feet_in"].append(feet_state)
+        rec["torques"].append(np.stack([x.numpy() for x in G.torque_log]))
+        snapshot(rebuilt)
+        counters["resets"] += int(env.reset_buf.sum()); counters["time_outs"] += int(env.time_out_buf.sum())
+        counters["pushes"] += int((env.episode_length_buf % 200 == 0).sum())
+        slots = [s for s, _, _ in fig.INJECT.log]
+        counters["resample_cb"] += sum(1 for s in slots if s == fig.U["RSA"] + 3)
+        counters["limit"] += sum(1 for s in slots if s in (fig.U["RSA"] + 4, fig.U["RSB"] + 4))
+        counters["zero"] += sum(1 for s in slots if s in (fig.U["RSA"] + 5, fig.U["RSB"] + 5))
+    fig.INJECT.table = None
+    fig.unpatch_torch()
+    out = {k: np.stack(v) for k, v in rec.items()}
+    out.update({"reset_all_" + k: v for k, v in reset_all_out.items()})
+    out["U_reset_all"] = U0
+    out["start_counter"] = np.int64(start_counter)
+    out["env_origins"] = env.env_origins.numpy().copy()
+    out["dof_pos_limits"] = env.dof_pos_limits.numpy().copy()
+    out["torque_limits"] = env.torque_limits.numpy().copy()
+    out["noise_scale_vec"] = env.noise_scale_vec.numpy().copy()
+    scales = np.zeros(ABI.GO2_NUM_REWARDS, np.float32)
+    for n, i in rew_index.items():
+        scales[i] = env.reward_scales[n]
+    out["reward_scales_dt"] = scales
+    out["height_points"] = env.height_points[0].numpy().copy()
+    out["base_height_scan_mask"] = env.base_height_scan_mask.numpy().copy()
+    out["limit_vel_comb"] = env.limit_vel_comb.numpy().astype(np.float32)
+    print("env sequence: N=%d T=%d events:" % (N, T), counters, "active rewards:", sorted(names_active))
+    return out
+
+
+def gen_gae(seed=3):
+    from rsl_rl.storage import RolloutStorage
+    rng = np.random.default_rng(seed)
+    T, N = 24, 48
+    st = RolloutStorage(N, T, [45], [263], [12], "cpu")
+    st.rewards[:] = torch.from_numpy(rng.normal(0, 0.05, (T, N, 1)).astype(np.float32))
+    st.values[:] = torch.from_numpy(rng.normal(0, 1.0, (T, N, 1)).astype(np.float32))
+    st.dones[:] = torch.from_numpy((rng.uniform(size=(T, N, 1)) < 0.06).astype(np.uint8))
+    last = torch.from_numpy(rng.normal(0, 1.0, (N, 1)).astype(np.float32))
+    st.compute_returns(last, 0.99, 0.95)
+    return dict(rewards=st.rewards.numpy()[..., 0], values=st.values.numpy()[..., 0], dones=st.dones.numpy()[..., 0], last_values=last.numpy()[:, 0],
+                returns=st.returns.numpy()[..., 0], advantages=st.advantages.numpy()[..., 0], gamma=np.float32(0.99), lam=np.float32(0.95))
+
+
+def gen_ppo(seed=5):
+    """One PPO.update (ppo.py:120-187) on a tiny actor-critic; also PPO.act statistics (ppo.py:90-102)."""
+    from rsl_rl.algorithms import PPO
+    from rsl_rl.modules import ActorCritic
+    torch.manual_seed(seed)
+    T, N = 6, 32
+    ac = ActorCritic(45, 263, 12, actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16], activation="elu", init_noise_std=1.0)
+    alg = PPO(ac, num_learning_epochs=2, num_mini_batches=2, clip_param=0.2, gamma=0.99, lam=0.95, value_loss_coef=1.0, entropy_coef=0.01,
+              learning_rate=1e-3, max_grad_norm=1.0, use_clipped_value_loss=True, schedule="adaptive", desired_kl=0.01, device="cpu")
+    alg.init_storage(N, T, [45], [263], [12])
+    sd0 = {k: v.detach().numpy().copy() for k, v in ac.state_dict().items()}
+    g = torch.Generator().manual_seed(seed)
+    obs = torch.randn(T + 1, N, 45, generator=g); cobs = torch.randn(T + 1, N, 263, generator=g)
+    rew = torch.randn(T, N, generator=g) * 0.05; dones = torch.rand(T, N, generator=g) < 0.1; touts = dones & (torch.rand(T, N, generator=g) < 0.5)
+    noise = torch.randn(T, N, 12, generator=g)
+    acts, vals, logps = [], [], []
+    for t in range(T):
+        # PPO.act with the sampled noise made explicit: a = mu + std * eps
+        ac.update_distribution(obs[t])
+        a = (ac.action_mean + ac.action_std * noise[t]).detach()
+        alg.transition.actions = a
+        alg.transition.values = ac.evaluate(cobs[t]).detach()
+        alg.transition.actions_log_prob = ac.get_actions_log_prob(a).detach()
+        alg.transition.action_mean = ac.action_mean.detach(); alg.transition.action_sigma = ac.action_std.detach()
+        alg.transition.observations = obs[t]; alg.transition.critic_observations = cobs[t]
+        acts.append(a.numpy().copy()); vals.append(alg.transition.values.numpy().copy()); logps.append(alg.transition.actions_log_prob.numpy().copy())
+        alg.process_env_step(rew[t], dones[t], {"time_outs": touts[t]})
+    alg.compute_returns(cobs[T])
+    returns = alg.storage.returns.numpy().copy(); adv = alg.storage.advantages.numpy().copy(); srew = alg.storage.rewards.numpy().copy()
+    perm = torch.randperm(T * N, generator=torch.Generator().manual_seed(seed + 1))
+    orig_randperm = torch.randperm
+    torch.randperm = lambda n, **kw: perm
+    try:
+        mvl, msl = alg.update()
+    finally:
+        torch.randperm = orig_randperm
+    sd1 = {k: v.detach().numpy().copy() for k, v in ac.state_dict().items()}
+    out = dict(obs=obs.numpy(), cobs=cobs.numpy(), rew=rew.numpy(), dones=dones.numpy().astype(np.uint8), time_outs=touts.numpy().astype(np.uint8), noise=noise.numpy(),
+               actions=np.stack(acts), values=np.stack(vals), logp=np.stack(logps), returns=returns, advantages=adv, stored_rewards=srew, perm=perm.numpy(),
+               mean_value_loss=np.float64(mvl), mean_surrogate_loss=np.float64(msl), final_lr=np.float64(alg.learning_rate))
+    for k, v in sd0.items(): out["w0_" + k] = v
+    for k, v in sd1.items(): out["w1_" + k] = v
+    return out
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    files = {}
+    seq = gen_env_sequence()
+    np.savez_compressed(os.path.join(OUT, "go2_plane_sequence.npz"), **seq); files["go2_plane_sequence.npz"] = None
+    np.savez_compressed(os.path.join(OUT, "gae.npz"), **gen_gae()); files["gae.npz"] = None
+    np.savez_compressed(os.path.join(OUT, "ppo_update.npz"), **gen_ppo()); files["ppo_update.npz"] = None
+    for f in files:
+        files[f] = hashlib.sha256(open(os.path.join(OUT, f), "rb").read()).hexdigest()
+    try:
+        ref = subprocess.run(["git", "-C", "/root/reference", "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or "snapshot 2026-02-20 (no git metadata)"
+    except Exception:
+        ref = "snapshot 2026-02-20"
+    json.dump({"generator": "oracle/gen_golden.py", "reference": "wty-yy/go2_rl_gym @ " + ref, "torch": torch.__version__, "numpy": np.__version__, "files": files},
+              open(os.path.join(OUT, "MANIFEST.json"), "w"), indent=1)
+    for f in files:
+        print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1107,3 +1107,21 @@ int go2o_pd_torques(Go2Sim* s, const float* act_in, float* out) {
   return 0;
 }
 int go2o_sizeof_real(void) { return (int)sizeof(R); }
+/* Golden test of legged_robot.py:67-81: clip the actions, draw the action delay and, for each substep i,
+ * compute the torques from caller-supplied DOF states dof[D][N][12][2] (the 'fake physics').  Leaves the
+ * clipped actions in buffers.actions and the last substep's torques in buffers.torques, like step(). */
+int go2o_torque_trace(Go2Sim* s, const float* actions_raw, const float* dof, float* out) {
+  const Go2SimCfg* c=&s->cfg; int N=s->N; R cl=(R)c->clip_actions;
+  for (int i=0;i<N*12;++i) { R a=(R)actions_raw[i]; if (a>cl) a=cl; if (a<-cl) a=-cl; s->b.actions[i]=(float)a; }
+  for (int e=0;e<N;++e) {
+    int start=0; if (c->randomize_action_delay) { start=(int)(uni(s,e,GO2_U_DELAY)*(c->decimation+1)); if (start>c->decimation) start=c->decimation; }
+    for (int i=0;i<c->decimation;++i) {
+      R q[12],qd[12],a[12],t[12];
+      for (int j=0;j<12;++j) { const float* d=dof+(((size_t)i*N+e)*12+j)*2; q[j]=(R)d[0]; qd[j]=(R)d[1];
+        a[j] = (c->randomize_action_delay && i<start) ? (R)s->b.last_actions[12*e+j] : (R)s->b.actions[12*e+j]; }
+      pd_torques(s,e,q,qd,a,t);
+      for (int j=0;j<12;++j) { out[((size_t)i*N+e)*12+j]=(float)t[j]; s->b.torques[12*e+j]=(float)t[j]; }
+    }
+  }
+  return 0;
+}
