@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the hot path: task=go2 on flat terrain, 4096 envs per MI355X (BASELINE.json configs[1]).
+
+One "step" = one full PPO iteration exactly as OnPolicyRunner.learn runs it (on_policy_runner.py:113-172):
+24 rollout steps x 4096 envs (policy inference + the fused HIP env step + storage), GAE + advantage normalisation,
+5 epochs x 4 mini-batches of PPO (forward, backward, grad clip, Adam).  Nothing is skipped, fp32 throughout.
+value = num_gpus * 4096 * 24 * K / elapsed  — the reference's own "Computation: N steps/s" definition (:194).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  Extra keys: "roofline" (the fused env-step kernel against HBM), "cpu_baseline" (the
+CPU oracle + torch-CPU PPO on the node's host cores, bounded sample), "collection_only" (24*N/collection_time).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_FLAT = 2936          # algorithmic bytes per env-step on a plane: 778 read + 2158 written
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md)
+NUM_ENVS = 4096
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--num-envs", type=int, default=NUM_ENVS, help="envs PER GPU (weak scaling)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    return p.parse_args()
+
+
+def cpu_baseline(num_envs=512):
+    """The same PPO iteration on the host CPU: the plain-C oracle (OpenMP) as the env + torch-CPU PPO, on a bounded
+    sample (1/8 of the envs, one full iteration after one warm-up).  Test-infrastructure code, timed only here."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import load_oracle
+    from go2_rl_gym_amd.envs import task_registry  # noqa: F401
+    from go2_rl_gym_amd.utils import get_args
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    args = get_args(["--task", "go2_flat", "--num_envs", str(num_envs), "--sim_device", "cpu", "--rl_device", "cpu", "--headless"])
+    env, _ = task_registry.make_env("go2_flat", args, lib=load_oracle())
+    runner, _ = task_registry.make_alg_runner(env, "go2_flat", args, log_root=None)
+    runner.learn(1, init_at_random_ep_len=True)
+    t0 = time.time()
+    runner.learn(1)
+    dt = time.time() - t0
+    env.close()
+    return {"value": num_envs * 24 / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "num_envs=%d (1/%d of the workload), 1 full PPO iteration (24 steps + 5x4 mini-batches) after 1 warm-up; oracle env (OpenMP) + torch-CPU PPO; "
+                      "collection %.2fs, learning %.2fs" % (num_envs, NUM_ENVS // num_envs, runner.last_collection_time, runner.last_learn_time)}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, a.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the product has no CPU path)")
+    torch.cuda.set_device(local)
+    dev = "cuda:%d" % local
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))      # RCCL over xGMI
+
+    from go2_rl_gym_amd.envs import task_registry  # noqa: F401
+    from go2_rl_gym_amd.utils import get_args
+    N = a.num_envs
+    args = get_args(["--task", "go2_flat", "--num_envs", str(N), "--sim_device", dev, "--rl_device", dev, "--headless", "--seed", "1"])
+    env, env_cfg = task_registry.make_env("go2_flat", args, env_offset=rank * N, num_envs_global=world * N)
+    torch.manual_seed(1 + rank)       # policy init is broadcast from rank 0; sampling noise differs per shard
+    runner, train_cfg = task_registry.make_alg_runner(env, "go2_flat", args, log_root=None)
+    env.common_step_counter = 0
+    env.update_reward_curriculum(force_update=True)
+
+    runner.learn(a.warmup, init_at_random_ep_len=True)        # untimed: also brings resets/pushes/resamples to steady state
+
+    env.lib.go2sim_enable_timing(env.handle, 1)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    col = 0.0
+    for _ in range(a.steps):
+        runner.learn(1)
+        col += runner.last_collection_time
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ms, n = C.c_double(), C.c_int64()
+    env.lib.go2sim_kernel_time(env.handle, C.byref(ms), C.byref(n))
+    env.lib.go2sim_enable_timing(env.handle, 0)
+    t = torch.tensor([elapsed, col], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, col = t.tolist()
+
+    if rank == 0:
+        total_steps = world * N * 24 * a.steps
+        k_ms = ms.value / max(n.value, 1)
+        achieved = ALGO_BYTES_FLAT * N / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec at 4096 envs (go2 flat); 1/2/4/8-GPU scaling", "value": total_steps / elapsed, "unit": "env-steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "task=go2 flat terrain (go2_flat), num_envs=%d per GPU, full PPO iteration = 24 rollout steps + GAE + 5 epochs x 4 mini-batches" % N,
+                       "num_envs_per_gpu": N, "num_steps_per_env": 24, "parallelism": "env-sharded dp%d" % world},
+            "collection_only": world * N * 24 * a.steps / col,
+            "roofline": {"bound": "hbm", "kernel": "go2_step_kernel<PHYS|POST>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel_ms": k_ms, "launches": n.value, "algorithmic_bytes_per_env_step": ALGO_BYTES_FLAT,
+                         "note": "latency/occupancy-bound by construction: 4096 envs x 4 lanes = 256 waves for 1024 SIMDs (DESIGN.md 6)"},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:   # never lose the GPU number to a CPU-side problem
+                out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,44 @@
+"""Compile the HIP library (gfx950) in-tree: go2_rl_gym_amd/libgo2sim_hip.so.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the built .so is git-ignored but
+travels with the repo snapshot to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "csrc", "go2sim_impl.cpp")
+OUT = os.path.join(HERE, "libgo2sim_hip.so")
+
+
+def _deps():
+    d = [os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))]
+    d += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
+    return d
+
+
+def hipcc_path():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (need ROCm): the HIP library is the only compute path of this package")
+
+
+def build_hip(force=False, verbose=False):
+    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= max(os.path.getmtime(p) for p in _deps()):
+        return OUT
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", OUT, SRC]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stderr[-4000:])
+    if verbose:
+        print(r.stderr)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build_hip(force=True, verbose=True))

@@ -1,0 +1,184 @@
+// go2_math.h — small fixed-size algebra for the Go2 lane programs (device code; also compiled for the
+// host by the lane-emulation test build, hence the GO2_HD macro).
+//
+// Spatial vectors are pairs (ang, lin) of V3 expressed in ONE frame for the whole robot: the inertial
+// frame instantaneously coincident with the base frame, origin at the base origin.  In that frame every
+// Plücker transform is the identity, a rigid-body inertia is 10 numbers {m, h = m c, J about the origin},
+// and composite inertias / forces of the four legs add with plain sums — which is what makes the
+// 4-lanes-per-env reduction a handful of quad shuffles.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GO2_HD __host__ __device__ __forceinline__
+#else
+#define GO2_HD inline
+#endif
+
+struct V3 { float x, y, z; };
+GO2_HD V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+GO2_HD V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+GO2_HD V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+GO2_HD V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+GO2_HD V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+GO2_HD V3 operator*(V3 a, float s) { return v3(s * a.x, s * a.y, s * a.z); }
+GO2_HD V3& operator+=(V3& a, V3 b) { a.x += b.x; a.y += b.y; a.z += b.z; return a; }
+GO2_HD float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+GO2_HD V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+GO2_HD float comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+// 3x3 matrix by columns (x, y, z): M v = x v.x + y v.y + z v.z
+struct M3 { V3 x, y, z; };
+GO2_HD V3 mul(const M3& M, V3 v) { return M.x * v.x + M.y * v.y + M.z * v.z; }
+GO2_HD V3 mulT(const M3& M, V3 v) { return v3(dot(M.x, v), dot(M.y, v), dot(M.z, v)); }
+GO2_HD M3 quat_to_m3(float qx, float qy, float qz, float qw) {  // world_from_body, columns
+  M3 R;
+  R.x = v3(1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy + qz * qw), 2 * (qx * qz - qy * qw));
+  R.y = v3(2 * (qx * qy - qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz + qx * qw));
+  R.z = v3(2 * (qx * qz + qy * qw), 2 * (qy * qz - qx * qw), 1 - 2 * (qx * qx + qy * qy));
+  return R;
+}
+
+// symmetric 3x3: xx, yy, zz, xy, xz, yz
+struct S3 { float xx, yy, zz, xy, xz, yz; };
+GO2_HD S3 operator+(S3 a, S3 b) { S3 r = {a.xx + b.xx, a.yy + b.yy, a.zz + b.zz, a.xy + b.xy, a.xz + b.xz, a.yz + b.yz}; return r; }
+GO2_HD S3 operator*(float s, S3 a) { S3 r = {s * a.xx, s * a.yy, s * a.zz, s * a.xy, s * a.xz, s * a.yz}; return r; }
+GO2_HD V3 mul(const S3& J, V3 v) { return v3(J.xx * v.x + J.xy * v.y + J.xz * v.z, J.xy * v.x + J.yy * v.y + J.yz * v.z, J.xz * v.x + J.yz * v.y + J.zz * v.z); }
+// R J R^T
+GO2_HD S3 rotate(const M3& R, const S3& J) {
+  V3 c0 = R.x * J.xx + R.y * J.xy + R.z * J.xz;  // (R J) columns
+  V3 c1 = R.x * J.xy + R.y * J.yy + R.z * J.yz;
+  V3 c2 = R.x * J.xz + R.y * J.yz + R.z * J.zz;
+  // (R J) R^T: element (i,j) = c0_i R.x_j + c1_i R.y_j + c2_i R.z_j
+  S3 o;
+  o.xx = c0.x * R.x.x + c1.x * R.y.x + c2.x * R.z.x;
+  o.yy = c0.y * R.x.y + c1.y * R.y.y + c2.y * R.z.y;
+  o.zz = c0.z * R.x.z + c1.z * R.y.z + c2.z * R.z.z;
+  o.xy = c0.x * R.x.y + c1.x * R.y.y + c2.x * R.z.y;
+  o.xz = c0.x * R.x.z + c1.x * R.y.z + c2.x * R.z.z;
+  o.yz = c0.y * R.x.z + c1.y * R.y.z + c2.y * R.z.z;
+  return o;
+}
+
+// spatial motion / force vector
+struct SV { V3 a, l; };
+GO2_HD SV sv(V3 a, V3 l) { SV r; r.a = a; r.l = l; return r; }
+GO2_HD SV operator+(SV p, SV q) { return sv(p.a + q.a, p.l + q.l); }
+GO2_HD SV operator-(SV p, SV q) { return sv(p.a - q.a, p.l - q.l); }
+GO2_HD SV operator*(float s, SV p) { return sv(s * p.a, s * p.l); }
+GO2_HD float dot(SV p, SV q) { return dot(p.a, q.a) + dot(p.l, q.l); }
+GO2_HD SV crm(SV v, SV m) { return sv(cross(v.a, m.a), cross(v.a, m.l) + cross(v.l, m.a)); }   // v x m
+GO2_HD SV crf(SV v, SV f) { return sv(cross(v.a, f.a) + cross(v.l, f.l), cross(v.a, f.l)); }   // v x* f
+GO2_HD float get(const SV& s, int i) { return i < 3 ? comp(s.a, i) : comp(s.l, i - 3); }
+
+// rigid-body inertia about the common origin: m, h = m c, J
+struct RB { float m; V3 h; S3 J; };
+GO2_HD RB operator+(RB a, RB b) { RB r; r.m = a.m + b.m; r.h = a.h + b.h; r.J = a.J + b.J; return r; }
+GO2_HD RB operator*(float s, RB a) { RB r; r.m = s * a.m; r.h = s * a.h; r.J = s * a.J; return r; }
+GO2_HD SV mul(const RB& I, SV v) { return sv(mul(I.J, v.a) + cross(I.h, v.l), I.m * v.l - cross(I.h, v.a)); }
+// move an inertia given in a link frame (about the link origin, link axes) to the common frame:
+// link origin at p, link axes R (columns)
+GO2_HD RB to_common(const RB& L, const M3& R, V3 p) {
+  RB o; o.m = L.m;
+  V3 hr = mul(R, L.h);
+  o.h = hr + L.m * p;
+  S3 J = rotate(R, L.J);
+  float pp = dot(p, p), ph = dot(p, hr);
+  J.xx += L.m * (pp - p.x * p.x) + 2 * ph - 2 * p.x * hr.x;
+  J.yy += L.m * (pp - p.y * p.y) + 2 * ph - 2 * p.y * hr.y;
+  J.zz += L.m * (pp - p.z * p.z) + 2 * ph - 2 * p.z * hr.z;
+  J.xy += -L.m * p.x * p.y - p.x * hr.y - hr.x * p.y;
+  J.xz += -L.m * p.x * p.z - p.x * hr.z - hr.x * p.z;
+  J.yz += -L.m * p.y * p.z - p.y * hr.z - hr.y * p.z;
+  o.J = J; return o;
+}
+// {m, com c, inertia about the COM} -> about the frame origin
+GO2_HD RB rb_from_com(float m, V3 c, S3 Ic) {
+  RB o; o.m = m; o.h = m * c; float cc = dot(c, c);
+  o.J.xx = Ic.xx + m * (cc - c.x * c.x); o.J.yy = Ic.yy + m * (cc - c.y * c.y); o.J.zz = Ic.zz + m * (cc - c.z * c.z);
+  o.J.xy = Ic.xy - m * c.x * c.y; o.J.xz = Ic.xz - m * c.x * c.z; o.J.yz = Ic.yz - m * c.y * c.z;
+  return o;
+}
+
+// ---- 6x6 symmetric positive definite: packed lower triangle, index (i,j), i >= j --------------------
+#define S6(i, j) ((i) * ((i) + 1) / 2 + (j))
+// inverse of an SPD 6x6 given packed (21) -> packed (21); fully unrolled so everything stays in registers
+GO2_HD void spd6_inverse(const float* A, float* Ainv) {
+  float L[21];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float d = A[S6(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= L[S6(j, k)] * L[S6(j, k)];
+    d = sqrtf(fmaxf(d, 1e-20f));
+    float inv = 1.0f / d;
+    L[S6(j, j)] = d;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      float s = A[S6(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s -= L[S6(i, k)] * L[S6(j, k)];
+      L[S6(i, j)] = s * inv;
+    }
+  }
+  // M = L^-1 (lower)
+  float M[21];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    M[S6(j, j)] = 1.0f / L[S6(j, j)];
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      float s = 0;
+#pragma unroll
+      for (int k = j; k < i; ++k) s -= L[S6(i, k)] * M[S6(k, j)];
+      M[S6(i, j)] = s / L[S6(i, i)];
+    }
+  }
+  // Ainv = M^T M
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      float s = 0;
+#pragma unroll
+      for (int k = i; k < 6; ++k) s += M[S6(k, i)] * M[S6(k, j)];
+      Ainv[S6(i, j)] = s;
+    }
+}
+GO2_HD float s6at(const float* A, int i, int j) { return i >= j ? A[S6(i, j)] : A[S6(j, i)]; }
+GO2_HD SV spd6_mul(const float* A, SV v) {
+  float x[6] = {v.a.x, v.a.y, v.a.z, v.l.x, v.l.y, v.l.z}, o[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float s = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) s += s6at(A, i, j) * x[j];
+    o[i] = s;
+  }
+  return sv(v3(o[0], o[1], o[2]), v3(o[3], o[4], o[5]));
+}
+// packed 6x6 of a rigid-body inertia [[J, hx],[hx^T, m 1]]
+GO2_HD void rb_to_s6(const RB& I, float* A) {
+  A[S6(0, 0)] = I.J.xx; A[S6(1, 0)] = I.J.xy; A[S6(1, 1)] = I.J.yy; A[S6(2, 0)] = I.J.xz; A[S6(2, 1)] = I.J.yz; A[S6(2, 2)] = I.J.zz;
+  // rows 3..5 (lin), cols 0..2 (ang): hx^T = -hx ;  hx = [[0,-hz,hy],[hz,0,-hx],[-hy,hx,0]]
+  A[S6(3, 0)] = 0;      A[S6(3, 1)] = I.h.z;  A[S6(3, 2)] = -I.h.y;
+  A[S6(4, 0)] = -I.h.z; A[S6(4, 1)] = 0;      A[S6(4, 2)] = I.h.x;
+  A[S6(5, 0)] = I.h.y;  A[S6(5, 1)] = -I.h.x; A[S6(5, 2)] = 0;
+  A[S6(3, 3)] = I.m; A[S6(4, 3)] = 0; A[S6(4, 4)] = I.m; A[S6(5, 3)] = 0; A[S6(5, 4)] = 0; A[S6(5, 5)] = I.m;
+}
+
+// ---- Philox4x32-10 (Salmon et al. SC'11): the same generator, key and counter layout as the oracle ----
+GO2_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+GO2_HD float u01_from_bits(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }

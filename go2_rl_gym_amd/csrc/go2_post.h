@@ -1,0 +1,439 @@
+// go2_post.h — the per-lane post-physics program (one lane = one (env, leg)).
+//
+// Restates, fused into one pass per env, LeggedRobot.post_physics_step
+// (legged_gym/envs/base/legged_robot.py:102-142): counters, derived base quantities (:119-125),
+// _post_physics_step_callback (:404-421) with _resample_commands (:423-592) and _get_heights (:1188-1224),
+// check_termination (:170-178), compute_reward (:247-274) with every _reward_* (:1228-1441, go2_env.py:55-68),
+// reset_idx (:180-245; _reset_dofs :620, _reset_root_states :635, _update_terrain_curriculum :1143),
+// _push_robots (:709-724), Go2Robot.compute_observations (go2_env.py:23-53) and the obs clip of step()
+// (:96-99), last_* updates (:140-142).  Ordering quirks of the reference are kept.
+//
+// Work split inside a quad: every per-joint quantity (3 of the 12 DOFs), the leg's 4 bodies and a quarter of
+// the 187 height samples belong to the lane; per-env scalar logic (commands, termination, root reset) is
+// computed redundantly by the 4 lanes (identical inputs, identical results) and written by lane 0.
+// One cross-lane step: the quad-sum of GO2_POST_PARTIALS reward partial sums between postA and postB.
+#pragma once
+#include "go2_math.h"
+#include "go2_tables.h"
+
+#define GO2_POST_PARTIALS 24
+
+// field-major (SoA) addressing, see Go2Ptrs
+#define F1D(p, e) (p)[(e)]
+#define F2D(p, a, e) (p)[(size_t)(a) * N + (e)]
+#define F3D(p, A, a, b, e) (p)[((size_t)(b) * (A) + (a)) * N + (e)]
+
+struct PhysOut {
+  V3 pw; float qx, qy, qz, qw; V3 vw, ww;
+  float q[3], qd[3], tau[3];
+  V3 Fhip, Fthigh, Fcalf, Ffoot, Fbase;
+  V3 foot_pos, foot_vel;
+};
+
+GO2_HD V3 quat_rotate_inverse(float qx, float qy, float qz, float qw, V3 v) {
+  V3 qv = v3(qx, qy, qz); V3 c = cross(qv, v); float d = dot(qv, v), a = 2 * qw * qw - 1;
+  return a * v - (2 * qw) * c + (2 * d) * qv;
+}
+GO2_HD V3 quat_apply(float qx, float qy, float qz, float qw, V3 v) {
+  V3 qv = v3(qx, qy, qz); V3 c = cross(qv, v); V3 cc = cross(qv, c);
+  return v + (2 * qw) * c + 2.0f * cc;
+}
+
+// The scalars the reference keeps as Python floats are pure functions of common_step_counter // 24:
+// reward curriculum (legged_robot.py:144-168), command-range curriculum (:433-446), zero-command
+// probability (:556-557).  `csc` = the counter value this step runs under.
+GO2_HD float go2_current_scale(const float* c4, float it) {   // get_current_scale (:154-168)
+  float pct = (it - c4[0]) / (c4[1] - c4[0]); pct = fminf(fmaxf(pct, 0.f), 1.f);
+  return (1.f - pct) * c4[2] + pct * c4[3];
+}
+GO2_HD void go2_step_scalars(const Go2Launch& L, const Go2Dyn& dyn, const float* inj_storage, int64_t csc, int initial_reset, Go2Step* S) {
+  S->step_lo = (uint32_t)dyn.step_count; S->step_hi = (uint32_t)(dyn.step_count >> 32);
+  S->initial_reset = initial_reset; S->injected = dyn.use_injected ? inj_storage : nullptr;
+  float it = (float)(csc / L.num_steps_per_env);
+  for (int t = 0; t < GO2_NUM_REWARDS; ++t) {
+    float sc = L.rew_scale_dt[t];
+    for (int i = 0; i < L.rew_curr_count; ++i) if (L.rew_curr_term[i] == t) sc *= go2_current_scale(L.rew_curr[i], it);
+    S->rew_scale[t] = sc;
+  }
+  int best = -1;
+  for (int i = 0; i < L.cmd_curr_count; ++i) if (it >= L.cmd_curr[i][0] && (best < 0 || L.cmd_curr[i][0] > L.cmd_curr[best][0])) best = i;
+  for (int r = 0; r < 4; ++r) {
+    S->cmd_ranges[r][0] = best < 0 ? L.cmd_ranges0[r][0] : L.cmd_curr[best][1 + 2 * r];
+    S->cmd_ranges[r][1] = best < 0 ? L.cmd_ranges0[r][1] : L.cmd_curr[best][2 + 2 * r];
+  }
+  S->max_lin_vel = fmaxf(fmaxf(fabsf(S->cmd_ranges[0][0]), fabsf(S->cmd_ranges[0][1])), fmaxf(fabsf(S->cmd_ranges[1][0]), fabsf(S->cmd_ranges[1][1])));
+  S->zero_cmd_proba = L.zero_curr_enabled ? go2_current_scale(L.zero_curr, it) : 0.f;
+}
+
+struct LegPost {
+  int e, lane, N;
+  const Go2Ptrs* P; const Go2Launch* L; const Go2Step* S;
+  PhysOut o;
+  // env scalars (replicated)
+  int64_t ep_len; float timer, cmd[4], acc[2]; uint8_t stop_heading, last_limit;
+  V3 blv, bav, pg; float base_height;
+  uint8_t reset, time_out;
+  float act[3], last_act[3], llast_act[3], last_dv[3];
+
+  GO2_HD float uni(int slot) const {
+    if (S->injected) return S->injected[(size_t)e * GO2_NUM_UNIFORMS + slot];
+    uint32_t r[4];
+    philox4x32_10((uint32_t)(L->env_offset + e), (uint32_t)(slot >> 2), S->step_lo, S->step_hi, L->seed_lo, L->seed_hi, r);
+    return u01_from_bits(r[slot & 3]);
+  }
+  GO2_HD static float urange(float u, float lo, float hi) { return (hi - lo) * u + lo; }
+  GO2_HD void cmd_range(int which, float* lo, float* hi) const {  // env_command_ranges (:861-907)
+    *lo = S->cmd_ranges[which][0]; *hi = S->cmd_ranges[which][1];
+    int kind = P->terrain_kind[e];
+    if (kind >= 0 && (which < 3 || L->heading_command)) {
+      *lo = fmaxf(*lo, L->terrain_max_cmd[kind][which][0]); *hi = fminf(*hi, L->terrain_max_cmd[kind][which][1]);
+    }
+  }
+  GO2_HD static float sample_disjoint(float u, float bound, float cmin, float cmax) {  // isaacgym_utils.py:32-47
+    float wn = fmaxf(-bound - cmin, 0.f), wp = fmaxf(cmax - bound, 0.f);
+    float t = u * (wn + wp + 1e-6f);
+    return t < wn ? cmin + t : cmax - wp + (t - wn);
+  }
+  // _resample_commands (:423-592) for this env; U = first of the 7 uniform slots
+  GO2_HD void resample(int U) {
+    stop_heading = 0;
+    float remaining = fmaxf(0.625f * L->terrain_length - sqrtf(acc[0] * acc[0] + acc[1] * acc[1]) * L->resampling_time, 0.f);
+    timer = L->resampling_time / L->dt;
+    float xl, xh, yl, yh, wl, wh, hl, hh; cmd_range(0, &xl, &xh); cmd_range(1, &yl, &yh); cmd_range(2, &wl, &wh); cmd_range(3, &hl, &hh);
+    float epl = (float)ep_len;
+    if (L->dynamic_resample) {
+      float vlow = fmaxf(remaining / ((L->max_episode_length - epl + 1e-9f) * L->dt), 0.f);
+      cmd[0] = sample_disjoint(uni(U + 0), vlow, xl, xh);
+      cmd[1] = sample_disjoint(uni(U + 1), vlow, yl, yh);
+      if (L->heading_command) cmd[3] = urange(uni(U + 2), hl, hh); else cmd[2] = urange(uni(U + 2), wl, wh);
+    } else {
+      cmd[0] = xl + uni(U + 0) * (xh - xl); cmd[1] = yl + uni(U + 1) * (yh - yl);
+      if (L->heading_command) cmd[3] = hl + uni(U + 2) * (hh - hl); else cmd[2] = wl + uni(U + 2) * (wh - wl);
+      if (!(sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]) > 0.2f)) { cmd[0] = 0; cmd[1] = 0; }
+    }
+    float p = uni(U + 3), minp = 0.f, maxp = 0.f;
+    if (L->limit_vel_prob > 0.f) {
+      maxp += L->limit_vel_prob;
+      bool lim = (p >= minp) && (p < maxp);
+      if (lim) {
+        if (L->limit_invert && last_limit) { cmd[0] = -cmd[0]; cmd[1] = -cmd[1]; cmd[2] = -cmd[2]; }
+        else {
+          int idx = (int)(uni(U + 4) * L->comb_count); idx = idx >= L->comb_count ? L->comb_count - 1 : idx;
+          float c0 = L->comb[idx][0], c1 = L->comb[idx][1], c2 = L->comb[idx][2];
+          cmd[0] = c0 == 0.f ? 0.f : (c0 == -1.f ? xl : xh);
+          cmd[1] = c1 == 0.f ? 0.f : (c1 == -1.f ? yl : yh);
+          cmd[2] = c2 == 0.f ? 0.f : (c2 == -1.f ? wl : wh);
+        }
+        if (L->heading_command && L->stop_heading_at_limit) stop_heading = 1;
+      }
+      last_limit = lim ? 1 : 0;
+      minp += L->limit_vel_prob;
+    }
+    if (S->zero_cmd_proba > 0.f) {
+      maxp += S->zero_cmd_proba;
+      float nxt = L->max_episode_length - epl - remaining / (0.8f * S->max_lin_vel * L->dt + 1e-9f);
+      nxt = fminf(fmaxf(nxt, 0.f), L->resampling_time / L->dt);
+      if ((p >= minp) && (p < maxp) && nxt > 0.f) {
+        cmd[0] = 0; cmd[1] = 0; timer = nxt;
+        if (L->limit_ang_zero_prob > 0.f && uni(U + 5) < L->limit_ang_zero_prob) {
+          cmd[2] = uni(U + 6) < 0.5f ? wl : wh;
+          if (L->heading_command) stop_heading = 1;
+        }
+      }
+    }
+    acc[0] += cmd[0]; acc[1] += cmd[1];
+  }
+  GO2_HD float dyn_sigma(float vabs, float vmin, float vmax) const {  // :1300-1320
+    float def = L->tracking_sigma; int kind = P->terrain_kind[e];
+    if (!L->terrain_curriculum || !L->dyn_sigma || kind < 0) return def;
+    float target = L->dyn_sigma_max[kind], sig = def;
+    if (vabs >= vmin && vabs < vmax) sig = def + (vabs - vmin) / (vmax - vmin) * (target - def);
+    if (vabs >= vmax) sig = target;
+    float ls = fminf(expf(((float)tlevel + 1.f) / 10.f) - 1.f, 1.f);
+    return def + ls * (sig - def);
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  GO2_HD void postA(const LegTab& t, float* part) {
+    const Go2Ptrs& p = *P; const Go2Launch& c = *L;
+    ep_len = p.ep_len[e] + 1;                      // :111
+    timer = p.cmd_timer[e] - 1.f;                  // :113
+    for (int k = 0; k < 4; ++k) cmd[k] = F2D(p.commands, k, e);
+    acc[0] = F2D(p.cmd_xy_acc, 0, e); acc[1] = F2D(p.cmd_xy_acc, 1, e);
+    stop_heading = p.stop_heading[e]; last_limit = p.last_is_limit_vel[e];
+    for (int j = 0; j < 3; ++j) {
+      int d = 3 * lane + j;
+      act[j] = F2D(p.actions, d, e); last_act[j] = F2D(p.last_actions, d, e); llast_act[j] = F2D(p.last_last_actions, d, e); last_dv[j] = F2D(p.last_dof_vel, d, e);
+    }
+    // derived base quantities (:119-125); get_euler_xyz (utils/isaacgym_utils.py:11-30)
+    float qx = o.qx, qy = o.qy, qz = o.qz, qw = o.qw;
+    float sr = 2 * (qw * qx + qy * qz), cr = qw * qw - qx * qx - qy * qy + qz * qz;
+    float sp = 2 * (qw * qy - qz * qx);
+    float sy = 2 * (qw * qz + qx * qy), cy = qw * qw + qx * qx - qy * qy - qz * qz;
+    float roll = atan2f(sr, cr), pitch = fabsf(sp) >= 1.f ? copysignf(1.57079632679f, sp) : asinf(sp), yaw = atan2f(sy, cy);
+    blv = quat_rotate_inverse(qx, qy, qz, qw, o.vw); bav = quat_rotate_inverse(qx, qy, qz, qw, o.ww);
+    pg = quat_rotate_inverse(qx, qy, qz, qw, v3(0, 0, -1));
+    load_terrain_fields();
+    float mm = fmaxf(p.max_move[e], sqrtf((o.pw.x - org_x) * (o.pw.x - org_x) + (o.pw.y - org_y) * (o.pw.y - org_y)));
+    // _post_physics_step_callback (:404-421)
+    if (timer <= 0.f && (float)ep_len < c.max_episode_length - 1.f) resample(GO2_U_RSA);
+    if (c.heading_command && !stop_heading) {
+      V3 fw = quat_apply(qx, qy, qz, qw, v3(1, 0, 0)); float heading = atan2f(fw.y, fw.x);
+      float a = fmodf(cmd[3] - heading, 6.28318530718f); if (a < 0) a += 6.28318530718f; if (a > 3.14159265359f) a -= 6.28318530718f;
+      float lo, hi; cmd_range(2, &lo, &hi); cmd[2] = fminf(fmaxf(0.5f * a, lo), hi);
+    }
+    // _get_heights (:1188-1224): this lane samples points lane, lane+4, ...
+    float hsum = 0.f;
+    if (c.measure_heights) {
+      float nn = fmaxf(sqrtf(qz * qz + qw * qw), 1e-9f), yz = qz / nn, yw = qw / nn;  // quat_apply_yaw (utils/math.py:8-12)
+      for (int i = lane; i < GO2_NUM_HEIGHT_POINTS; i += 4) {
+        float hv = 0.f;
+        int ix = i / 11, iy = i - 11 * ix;
+        if (c.terrain_mode != 0) {
+          V3 w = quat_apply(0.f, 0.f, yz, yw, v3((float)(ix - 8) * 0.1f, (float)(iy - 5) * 0.1f, 0.f));
+          float x = (w.x + o.pw.x + c.hf_border) / c.hf_hscale, y = (w.y + o.pw.y + c.hf_border) / c.hf_hscale;
+          int px = (int)x, py = (int)y;
+          px = px < 0 ? 0 : (px > c.hf_rows - 2 ? c.hf_rows - 2 : px); py = py < 0 ? 0 : (py > c.hf_cols - 2 ? c.hf_cols - 2 : py);
+          int h1 = p.hf[px * c.hf_cols + py], h2 = p.hf[(px + 1) * c.hf_cols + py], h3 = p.hf[px * c.hf_cols + py + 1];
+          int hm = h1 < h2 ? h1 : h2; hm = h3 < hm ? h3 : hm;
+          hv = hm * c.hf_vscale;
+        }
+        F2D(p.heights, i, e) = hv;
+        if (ix >= 6 && ix <= 10 && iy >= 4 && iy <= 6) hsum += hv;   // base_height_scan_mask (:790-796)
+      }
+    }
+    // check_termination (:170-178)
+    bool term = sqrtf(dot(o.Fbase, o.Fbase)) > 1.f;
+    time_out = (float)ep_len > c.max_episode_length ? 1 : 0;
+    reset = (term || time_out) ? 1 : 0;
+    // ---- reward partial sums over this lane's joints / bodies ------------------------------------
+    float tq2 = 0, dv2 = 0, dacc = 0, arate = 0, plim = 0, vlim = 0, tlim = 0, still = 0, smooth = 0, power = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      int d = 3 * lane + j;
+      tq2 += o.tau[j] * o.tau[j]; dv2 += o.qd[j] * o.qd[j];
+      float a = (last_dv[j] - o.qd[j]) / c.dt; dacc += a * a;
+      float r = last_act[j] - act[j]; arate += r * r;
+      float lo = o.q[j] - c.soft_limits[d][0]; if (lo < 0) plim -= lo; float hi = o.q[j] - c.soft_limits[d][1]; if (hi > 0) plim += hi;
+      vlim += fminf(fmaxf(fabsf(o.qd[j]) - t.vel_lim[j] * c.soft_vel_limit, 0.f), 1.f);
+      tlim += fmaxf(fabsf(o.tau[j]) - t.eff_lim[j] * c.soft_torque_limit, 0.f);
+      still += fabsf(o.q[j] - c.q0[d]);
+      float s = act[j] - 2 * last_act[j] + llast_act[j]; smooth += s * s;
+      power += fabsf(o.tau[j] * o.qd[j]);
+    }
+    float coll = (sqrtf(dot(o.Fthigh, o.Fthigh)) > 0.1f ? 1.f : 0.f) + (sqrtf(dot(o.Fcalf, o.Fcalf)) > 0.1f ? 1.f : 0.f);
+    float fnorm = sqrtf(dot(o.Ffoot, o.Ffoot));
+    bool contact = o.Ffoot.z > 1.f;
+    // _reward_base_height (:1245-1259)
+    float bh_cnt = 0; V3 bh_pos = v3(0, 0, 0);
+    if (c.rew_scale_dt[GO2_REW_BASE_HEIGHT] != 0.f) {
+      bool filt = contact || F2D(p.last_contacts2, lane, e); F2D(p.last_contacts2, lane, e) = contact ? 1 : 0;
+      if (filt) { bh_cnt = 1; bh_pos = o.foot_pos; }
+    }
+    // _reward_feet_air_time (:1347-1358)
+    float air = 0;
+    if (c.rew_scale_dt[GO2_REW_FEET_AIR_TIME] != 0.f) {
+      bool filt = contact || F2D(p.last_contacts, lane, e); F2D(p.last_contacts, lane, e) = contact ? 1 : 0;
+      float fat = F2D(p.feet_air_time, lane, e); bool first = fat > 0.f && filt; fat += c.dt; air = (fat - 0.5f) * (first ? 1.f : 0.f);
+      F2D(p.feet_air_time, lane, e) = filt ? 0.f : fat;
+    }
+    float stumble = sqrtf(o.Ffoot.x * o.Ffoot.x + o.Ffoot.y * o.Ffoot.y) > 5.f * fabsf(o.Ffoot.z) ? 1.f : 0.f;
+    float fcf = fmaxf(fnorm - c.max_contact_force, 0.f);
+    V3 dfoot = o.foot_pos - o.pw;
+    float f2b = dot(dfoot, pg);                                   // feet_regulation (:1404-1414), finished in postB
+    float fvel2 = o.foot_vel.x * o.foot_vel.x + o.foot_vel.y * o.foot_vel.y;
+    V3 floc = quat_rotate_inverse(qx, qy, qz, qw, dfoot);          // legs_distance (:1423-1441)
+    float hip = o.q[0];
+    part[0] = tq2; part[1] = dv2; part[2] = dacc; part[3] = arate; part[4] = coll; part[5] = plim; part[6] = vlim; part[7] = tlim;
+    part[8] = air; part[9] = stumble; part[10] = still; part[11] = fcf; part[12] = smooth; part[13] = power;
+    part[14] = bh_cnt; part[15] = bh_pos.x; part[16] = bh_pos.y; part[17] = bh_pos.z;
+    part[18] = fabsf(hip - c.q0[3 * lane]);                        // hip_to_default (go2_env.py:55)
+    part[19] = lane < 2 ? hip : 0.f; part[20] = lane >= 2 ? hip : 0.f;   // x_command_hip_regular (go2_env.py:62)
+    part[21] = lane == 0 ? floc.y : (lane == 1 ? -floc.y : 0.f); part[22] = lane == 2 ? floc.y : (lane == 3 ? -floc.y : 0.f);
+    part[23] = hsum;
+    own_f2b = f2b; own_fvel2 = fvel2;
+    rpy[0] = roll; rpy[1] = pitch; rpy[2] = yaw; max_move = mm;
+  }
+  float own_f2b, own_fvel2, rpy[3], max_move, org_x, org_y, org_z; int64_t tlevel, ttype;
+  // replicated fields that lane 0 rewrites in postB: every lane reads them BEFORE any lane writes
+  GO2_HD void load_terrain_fields() {
+    const Go2Ptrs& p = *P;
+    org_x = F2D(p.origins, 0, e); org_y = F2D(p.origins, 1, e); org_z = F2D(p.origins, 2, e);
+    tlevel = p.terrain_levels[e]; ttype = p.terrain_types[e];
+  }
+
+  // feet_regulation needs base_height (a quad quantity) and then a second quad-sum; to keep ONE reduction the
+  // caller passes, besides the summed partials, nothing else: each lane recomputes its own term and the
+  // four terms are summed with a second tiny reduction (1 float) inside postB's caller.  See regulation().
+  GO2_HD float regulation(const float* red) const {
+    float bh = base_height_from(red);
+    float fh = fmaxf(bh - own_f2b, 0.f);
+    return own_fvel2 * expf(-fh / (0.025f * L->base_height_target));
+  }
+  GO2_HD float base_height_from(const float* red) const {        // _get_base_height (:1387-1397)
+    if (!L->measure_heights) return o.pw.z;
+    return o.pw.z - red[23] / 15.0f;
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // red = quad-summed partials; feet_reg = quad-summed regulation()
+  GO2_HD void postB(const LegTab& t, const float* red, float feet_reg) {
+    const Go2Ptrs& p = *P; const Go2Launch& c = *L; const int N_ = N; (void)N_;
+    float raw[GO2_NUM_REWARDS];
+#pragma unroll
+    for (int i = 0; i < GO2_NUM_REWARDS; ++i) raw[i] = 0.f;
+    {
+      float sx = c.tracking_sigma, sy_ = sx, sg = sx;
+      if (c.dyn_sigma) { sx = dyn_sigma(fabsf(cmd[0]), c.dyn_sigma_vel[0], c.dyn_sigma_vel[1]); sy_ = dyn_sigma(fabsf(cmd[1]), c.dyn_sigma_vel[0], c.dyn_sigma_vel[1]);
+                         sg = dyn_sigma(fabsf(cmd[2]), c.dyn_sigma_vel[2], c.dyn_sigma_vel[3]); }
+      float ex = cmd[0] - blv.x, ey = cmd[1] - blv.y, er = cmd[2] - bav.z;
+      raw[GO2_REW_TRACKING_LIN_VEL] = expf(-(ex * ex / sx + ey * ey / sy_));   // :1322
+      raw[GO2_REW_TRACKING_ANG_VEL] = expf(-er * er / sg);                      // :1336
+    }
+    raw[GO2_REW_LIN_VEL_Z] = blv.z * blv.z;                                     // :1228
+    raw[GO2_REW_ANG_VEL_XY] = bav.x * bav.x + bav.y * bav.y;                    // :1232
+    raw[GO2_REW_ORIENTATION] = pg.x * pg.x + pg.y * pg.y;                       // :1236
+    {
+      float nc = red[14], den = fmaxf(nc, 1.f);
+      float bh = (red[15] / den - o.pw.x) * pg.x + (red[16] / den - o.pw.y) * pg.y + (red[17] / den - o.pw.z) * pg.z;
+      float d = bh - c.base_height_target; raw[GO2_REW_BASE_HEIGHT] = d * d * (nc > 0.f ? 1.f : 0.f);
+    }
+    raw[GO2_REW_TORQUES] = red[0]; raw[GO2_REW_DOF_VEL] = red[1]; raw[GO2_REW_DOF_ACC] = red[2]; raw[GO2_REW_ACTION_RATE] = red[3];
+    raw[GO2_REW_COLLISION] = red[4]; raw[GO2_REW_DOF_POS_LIMITS] = red[5]; raw[GO2_REW_DOF_VEL_LIMITS] = red[6]; raw[GO2_REW_TORQUE_LIMITS] = red[7];
+    float cn = sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]);
+    raw[GO2_REW_FEET_AIR_TIME] = red[8] * (cn > 0.1f ? 1.f : 0.f);
+    raw[GO2_REW_STUMBLE] = red[9] > 0.f ? 1.f : 0.f;
+    raw[GO2_REW_STAND_STILL] = red[10] * (cn < 0.1f ? 1.f : 0.f);
+    raw[GO2_REW_FEET_CONTACT_FORCES] = red[11]; raw[GO2_REW_ACTION_SMOOTHNESS] = red[12]; raw[GO2_REW_DOF_POWER] = red[13];
+    { float d = base_height_from(red) - c.base_height_target; raw[GO2_REW_CORRECT_BASE_HEIGHT] = d * d; }   // :1399
+    raw[GO2_REW_FEET_REGULATION] = feet_reg;
+    raw[GO2_REW_SIMILAR_TO_DEFAULT] = red[10];
+    raw[GO2_REW_UPRIGHT] = (-1.f - pg.z) * 0.5f;
+    { float df = fmaxf(c.min_legs_distance - red[21], 0.f), dr = fmaxf(c.min_legs_distance - red[22], 0.f); raw[GO2_REW_LEGS_DISTANCE] = df * df + dr * dr; }
+    raw[GO2_REW_HIP_TO_DEFAULT] = red[18];
+    raw[GO2_REW_X_COMMAND_HIP_REGULAR] = (fabsf(red[19]) + fabsf(red[20])) * fabsf(cmd[0]) / sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1] + cmd[2] * cmd[2]);
+    float total = 0.f;
+    float* es = p.ep_sums;  // [R][N] row-major
+#pragma unroll
+    for (int i = 0; i < GO2_REW_TERMINATION; ++i)
+      if (c.rew_scale_dt[i] != 0.f && !S->initial_reset) { float r = raw[i] * S->rew_scale[i]; total += r; if (lane == 0) es[(size_t)i * N + e] += r; }
+    if (c.only_positive && total < 0.f) total = 0.f;
+    if (c.rew_scale_dt[GO2_REW_TERMINATION] != 0.f && !S->initial_reset) {
+      float r = ((reset && !time_out) ? 1.f : 0.f) * S->rew_scale[GO2_REW_TERMINATION]; total += r; if (lane == 0) es[(size_t)GO2_REW_TERMINATION * N + e] += r;
+    }
+    if (c.rew_scale_dt[GO2_REW_ACTION_SMOOTHNESS] != 0.f)
+      for (int j = 0; j < 3; ++j) llast_act[j] = last_act[j];       // :1378 (not zeroed on reset, App. E.9)
+
+    // ---- reset_idx (:180-245) ---------------------------------------------------------------------
+    float ox = org_x, oy = org_y, oz = org_z;
+    if (reset) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        int d = 3 * lane + j;
+        if (c.rand_strength) F2D(p.strength, d, e) = urange(uni(GO2_U_RESET_STRENGTH + d), c.strength_rng[0], c.strength_rng[1]);
+        if (c.rand_offset) F2D(p.zero_off, d, e) = urange(uni(GO2_U_RESET_OFFSET + d), c.offset_rng[0], c.offset_rng[1]);
+        if (c.rand_pd) { F2D(p.kp_mul, d, e) = urange(uni(GO2_U_RESET_KP + d), c.kp_rng[0], c.kp_rng[1]); F2D(p.kd_mul, d, e) = urange(uni(GO2_U_RESET_KD + d), c.kd_rng[0], c.kd_rng[1]); }
+      }
+      if (c.terrain_curriculum && c.terrain_mode != 0 && !S->initial_reset) {   // _update_terrain_curriculum (:1143-1169)
+        float dist = max_move;
+        bool up = dist > c.terrain_length * 0.5f, down;
+        if (c.move_down_by_acc) down = (dist < sqrtf(acc[0] * acc[0] + acc[1] * acc[1]) * (c.resampling_time * (1.f - S->zero_cmd_proba)) * 0.5f) && !up;
+        else down = (dist < sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]) * c.episode_length_s * 0.5f) && !up;
+        int64_t lv = tlevel + (up ? 1 : 0) - (down ? 1 : 0);
+        if (lv >= c.terrain_num_levels) { int r = (int)(uni(GO2_U_RESET_TERRAIN) * c.terrain_num_levels); lv = r >= c.terrain_num_levels ? c.terrain_num_levels - 1 : r; }
+        else if (lv < 0) lv = 0;
+        const float* og = p.terrain_origins + ((size_t)lv * c.terrain_num_types + ttype) * 3;
+        ox = og[0]; oy = og[1]; oz = og[2]; max_move = 0.f;
+        if (lane == 0) { p.terrain_levels[e] = lv; F2D(p.origins, 0, e) = ox; F2D(p.origins, 1, e) = oy; F2D(p.origins, 2, e) = oz; }
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {   // _reset_dofs (:620-634)
+        int d = 3 * lane + j;
+        o.q[j] = c.q0[d] * urange(uni(GO2_U_RESET_DOF + d), 0.5f, 1.5f); o.qd[j] = 0.f;
+        act[j] = 0.f; last_act[j] = 0.f; last_dv[j] = 0.f;
+      }
+      // _reset_root_states (:635-707)
+      float yaw = urange(uni(GO2_U_RESET_YAW), -3.14159265358979f, 3.14159265358979f);
+      o.pw = v3(c.base_init[0] + ox, c.base_init[1] + oy, c.base_init[2] + oz);
+      if (c.terrain_mode != 0) { o.pw.x += urange(uni(GO2_U_RESET_XY), -1.f, 1.f); o.pw.y += urange(uni(GO2_U_RESET_XY + 1), -1.f, 1.f); }
+      o.qx = 0.f; o.qy = 0.f; o.qz = sinf(0.5f * yaw); o.qw = cosf(0.5f * yaw);
+      o.vw = v3(urange(uni(GO2_U_RESET_VEL), -0.5f, 0.5f), urange(uni(GO2_U_RESET_VEL + 1), -0.5f, 0.5f), urange(uni(GO2_U_RESET_VEL + 2), -0.5f, 0.5f));
+      o.ww = v3(urange(uni(GO2_U_RESET_VEL + 3), -0.5f, 0.5f), urange(uni(GO2_U_RESET_VEL + 4), -0.5f, 0.5f), urange(uni(GO2_U_RESET_VEL + 5), -0.5f, 0.5f));
+      F2D(p.feet_air_time, lane, e) = 0.f;
+      for (int a = 0; a < 3; ++a) F3D(p.foot_impulse, 4, lane, a, e) = 0.f;
+      ep_len = 0;
+      timer = c.resampling_time / c.dt; acc[0] = 0.f; acc[1] = 0.f;
+      resample(GO2_U_RSB);
+      if (lane == 0) {   // extras["episode"] accumulators (:229-242)
+        for (int i = 0; i < GO2_NUM_REWARDS; ++i) if (c.rew_scale_dt[i] != 0.f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+          atomicAdd(&p.ep_accum[i], es[(size_t)i * N + e]);
+#else
+          p.ep_accum[i] += es[(size_t)i * N + e];
+#endif
+          es[(size_t)i * N + e] = 0.f;
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        atomicAdd(&p.ep_accum[GO2_NUM_REWARDS], 1.0f);
+#else
+        p.ep_accum[GO2_NUM_REWARDS] += 1.0f;
+#endif
+      }
+    }
+    // _push_robots (:709-724): episode clock multiple of the push interval (a fresh reset is pushed at once, App. E.4)
+    if (c.push_robots && !S->initial_reset && (ep_len % c.push_interval == 0)) {
+      o.vw.x = urange(uni(GO2_U_PUSH), -c.push_xy, c.push_xy); o.vw.y = urange(uni(GO2_U_PUSH + 1), -c.push_xy, c.push_xy);
+      o.ww = v3(urange(uni(GO2_U_PUSH + 2), -c.push_ang, c.push_ang), urange(uni(GO2_U_PUSH + 3), -c.push_ang, c.push_ang), urange(uni(GO2_U_PUSH + 4), -c.push_ang, c.push_ang));
+    }
+    // ---- Go2Robot.compute_observations (go2_env.py:23-53) + clip (:96-99) -----------------------------
+    float cl = c.clip_obs;
+    float* ob = p.obs + (size_t)e * GO2_NUM_OBS; float* pv = p.priv + (size_t)e * GO2_NUM_PRIV_OBS;
+#define CLIP(x) fminf(fmaxf((x), -cl), cl)
+#define NOISE(i) (c.add_noise ? (2.f * uni(GO2_U_NOISE + (i)) - 1.f) * c.noise_vec[(i)] : 0.f)
+    if (lane == 0) {
+      float s9[9] = {bav.x * c.os_ang, bav.y * c.os_ang, bav.z * c.os_ang, pg.x, pg.y, pg.z, cmd[0] * c.os_lin, cmd[1] * c.os_lin, cmd[2] * c.os_ang};
+      pv[0] = CLIP(blv.x * c.os_lin); pv[1] = CLIP(blv.y * c.os_lin); pv[2] = CLIP(blv.z * c.os_lin);
+      for (int i = 0; i < 9; ++i) { pv[3 + i] = CLIP(s9[i]); ob[i] = CLIP(s9[i] + NOISE(i)); }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      int d = 3 * lane + j;
+      float dp = (o.q[j] - c.q0[d]) * c.os_dof_pos, dv = o.qd[j] * c.os_dof_vel;
+      pv[3 + 9 + d] = CLIP(dp); pv[3 + 21 + d] = CLIP(dv); pv[3 + 33 + d] = CLIP(act[j]);
+      ob[9 + d] = CLIP(dp + NOISE(9 + d)); ob[21 + d] = CLIP(dv + NOISE(21 + d)); ob[33 + d] = CLIP(act[j] + NOISE(33 + d));
+      pv[52 + d] = CLIP(o.tau[j] / t.eff_lim[j]);
+      pv[64 + d] = CLIP((last_dv[j] - o.qd[j]) / c.dt * 1e-4f);
+    }
+    pv[48 + lane] = CLIP(sqrtf(dot(o.Ffoot, o.Ffoot)) * 1e-3f);
+    for (int i = lane; i < GO2_NUM_HEIGHT_POINTS; i += 4) {
+      float hh = fminf(fmaxf(o.pw.z - 0.5f - F2D(p.heights, i, e), -1.f), 1.f);
+      pv[76 + i] = CLIP(hh * c.os_height);
+    }
+#undef CLIP
+#undef NOISE
+    // ---- write back ---------------------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      int d = 3 * lane + j;
+      F2D(p.last_actions, d, e) = act[j];                      // :140 (zero for a reset env)
+      F2D(p.last_last_actions, d, e) = llast_act[j];
+      F2D(p.last_dof_vel, d, e) = o.qd[j];                     // :141
+      F2D(p.actions, d, e) = act[j];
+      F2D(p.dof, d, e) = o.q[j]; F2D(p.dof, 12 + d, e) = o.qd[j];
+    }
+    if (lane == 0) {
+      float r13[13] = {o.pw.x, o.pw.y, o.pw.z, o.qx, o.qy, o.qz, o.qw, o.vw.x, o.vw.y, o.vw.z, o.ww.x, o.ww.y, o.ww.z};
+      for (int k = 0; k < 13; ++k) F2D(p.root, k, e) = r13[k];
+      for (int k = 0; k < 6; ++k) F2D(p.last_root_vel, k, e) = r13[7 + k];   // :142
+      p.ep_len[e] = ep_len; p.cmd_timer[e] = timer;
+      for (int k = 0; k < 4; ++k) F2D(p.commands, k, e) = cmd[k];
+      F2D(p.cmd_xy_acc, 0, e) = acc[0]; F2D(p.cmd_xy_acc, 1, e) = acc[1];
+      p.stop_heading[e] = stop_heading; p.last_is_limit_vel[e] = last_limit;
+      p.reset[e] = reset; p.time_out[e] = time_out; p.rew[e] = total; p.max_move[e] = max_move;
+      F2D(p.base_lin_vel, 0, e) = blv.x; F2D(p.base_lin_vel, 1, e) = blv.y; F2D(p.base_lin_vel, 2, e) = blv.z;
+      F2D(p.base_ang_vel, 0, e) = bav.x; F2D(p.base_ang_vel, 1, e) = bav.y; F2D(p.base_ang_vel, 2, e) = bav.z;
+      F2D(p.proj_gravity, 0, e) = pg.x; F2D(p.proj_gravity, 1, e) = pg.y; F2D(p.proj_gravity, 2, e) = pg.z;
+      F2D(p.rpy, 0, e) = rpy[0]; F2D(p.rpy, 1, e) = rpy[1]; F2D(p.rpy, 2, e) = rpy[2];
+    }
+  }
+};

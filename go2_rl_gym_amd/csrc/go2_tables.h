@@ -1,0 +1,83 @@
+// go2_tables.h — the robot tables the kernels stage into LDS, and the per-launch parameter block.
+// Filled on the host from include/go2_model_data.h (numbers generated from the Go2 URDF).
+#pragma once
+#include <stdint.h>
+#include "../../include/go2sim.h"
+#include "../../include/go2_model_data.h"
+
+#define GO2_NLEG_OTHER GO2_LEG_OTHER_PTS
+#define GO2_LANE_BASE_PTS 3
+
+// per-leg constant table (one per lane index 0..3); plain floats/ints so it can be memcpy'd into LDS
+struct LegTab {
+  float o1[3], o2[3], o3[3];        // joint origins in the parent link frame (hip origin is in the base frame)
+  float body[4][10];                // hip, thigh, calf, foot: {m, h(3), J(6: xx,yy,zz,xy,xz,yz)} about the moving link origin, link axes
+  float lim_lo[3], lim_hi[3], vel_lim[3], eff_lim[3];
+  float foot_pt[4];                 // collision sphere: centre in calf frame, radius
+  float foot_off[4];                // foot body frame origin in the calf frame (+pad)
+  float other_pt[GO2_NLEG_OTHER][4];
+  int32_t other_link[GO2_NLEG_OTHER];   // 1 hip, 2 thigh, 3 calf
+  int32_t other_body[GO2_NLEG_OTHER];   // body index in the 19-body list
+  float base_pt[GO2_LANE_BASE_PTS][4];  // this lane's share of the base-attached candidates (base frame)
+  int32_t base_body[GO2_LANE_BASE_PTS];
+  int32_t n_base;
+  int32_t body_index[4];            // hip, thigh, calf, foot body indices
+  int32_t mass_ratio_index[4];      // index into link_mass_ratio[18] (= body index - 1)
+};
+struct BaseTab {
+  float m0, c0[3], Ic0[6];          // base body: mass, COM, inertia about COM
+  float head[2][10];                // Head_upper, Head_lower about the base origin
+  float body_off[3][4];             // frame origins of base, Head_upper, Head_lower in the base frame
+};
+struct Go2Tables { LegTab leg[4]; BaseTab base; };
+
+// Device/host pointers of every per-env field.  The HIP library stores per-env fields FIELD-MAJOR (SoA):
+// logical [N, a, b] lives at ((b_idx * A + a_idx) * N + env), i.e. C order of the reversed logical dims,
+// so that consecutive lanes (envs) touch consecutive addresses.  obs_buf and privileged_obs_buf are the
+// exception: they are the policy's GEMM inputs and stay row-major [N,45] / [N,263].
+struct Go2Ptrs {
+  float *root, *dof, *contact, *rigid, *obs, *priv, *rew; uint8_t *reset, *time_out; int64_t* ep_len;
+  float *torques, *actions, *last_actions, *last_last_actions, *last_dof_vel, *last_root_vel, *commands, *cmd_timer, *cmd_xy_acc;
+  uint8_t *stop_heading, *last_is_limit_vel; float *base_lin_vel, *base_ang_vel, *proj_gravity, *rpy, *heights, *max_move, *feet_air_time;
+  uint8_t *last_contacts, *last_contacts2; float *strength, *zero_off, *kp_mul, *kd_mul, *origins; int64_t *terrain_levels, *terrain_types;
+  float *ep_sums, *friction, *restitution, *added_mass, *added_com, *mass_ratio, *episode_info, *foot_impulse;
+  // internal
+  int32_t* terrain_kind; float* ep_accum /*[NUM_REWARDS+1]*/; const float* inj_storage; const int16_t* hf; const float* terrain_origins;
+  const Go2Tables* tables;
+};
+
+// everything a launch needs besides pointers: config constants + the host-side scalars of this step
+struct Go2Launch {
+  int32_t N, env_offset, decimation, solver_iterations;
+  uint32_t seed_lo, seed_hi;
+  float sim_dt, dt, gravity[3], contact_offset, erp, max_depen_vel, bounce_thr, cfm, armature, limit_margin;
+  int32_t terrain_mode, hf_rows, hf_cols; float hf_hscale, hf_vscale, hf_border, terrain_friction, terrain_restitution;
+  int32_t terrain_num_levels, terrain_num_types, terrain_curriculum, move_down_by_acc, measure_heights; float terrain_length;
+  float kp[12], kd[12], q0[12], action_scale, clip_actions, clip_obs, base_init[13];
+  int32_t rand_strength, rand_offset, rand_pd, push_robots, push_interval, rand_delay;
+  float strength_rng[2], offset_rng[2], kp_rng[2], kd_rng[2], push_xy, push_ang;
+  float resampling_time; int32_t heading_command, dynamic_resample; float limit_vel_prob; int32_t limit_invert, stop_heading_at_limit;
+  float limit_ang_zero_prob; int32_t comb_count; float comb[36][3];
+  float cmd_ranges0[4][2], terrain_max_cmd[9][4][2];
+  float rew_scale_dt[GO2_NUM_REWARDS];  // raw scale * dt (0 = inactive)
+  int32_t rew_curr_count, rew_curr_term[4]; float rew_curr[4][4];     // curriculum_rewards (start_iter,end_iter,start,end)
+  int32_t cmd_curr_count; float cmd_curr[4][9];                       // command_range_curriculum
+  int32_t zero_curr_enabled; float zero_curr[4]; int32_t num_steps_per_env;
+  int32_t only_positive; float tracking_sigma; int32_t dyn_sigma; float dyn_sigma_vel[4], dyn_sigma_max[9];
+  float soft_vel_limit, soft_torque_limit, base_height_target, max_contact_force, min_legs_distance, soft_limits[12][2];
+  float os_lin, os_ang, os_dof_pos, os_dof_vel, os_height; int32_t add_noise; float noise_vec[GO2_NUM_OBS];
+  float max_episode_length, episode_length_s;
+};
+
+// counters that live in device memory and are advanced by the device itself, so that a step is a pure
+// enqueue (HIP-graph replayable): nothing the host computes per step is baked into kernel arguments
+struct Go2Dyn { uint64_t step_count; int64_t common_step_counter; int32_t use_injected; int32_t pad; };
+
+// per-step scalars (what the reference keeps as Python floats), recomputed by every workgroup from
+// Go2Dyn.common_step_counter into LDS: they are pure functions of counter // num_steps_per_env
+struct Go2Step {
+  uint32_t step_lo, step_hi; int32_t initial_reset; const float* injected;
+  float rew_scale[GO2_NUM_REWARDS];  // scale * dt * curriculum (0 = inactive)
+  float cmd_ranges[4][2], max_lin_vel, zero_cmd_proba;
+};
+struct Go2DevBlock { Go2Ptrs p; Go2Launch L; Go2Dyn dyn; };

@@ -1,0 +1,760 @@
+// go2sim_impl.cpp — the C ABI of include/go2sim.h on top of the lane programs.
+//
+// Built two ways from this one source:
+//   hipcc --offload-arch=gfx950           -> libgo2sim_hip.so : THE PRODUCT.  One HIP kernel per env step
+//       (go2_step_kernel), 64-thread workgroups = 16 envs x 4 leg-lanes, robot tables staged in LDS,
+//       quad reductions with DPP, all per-env state field-major (SoA) in HBM.
+//   g++ -DGO2_EMU                          -> libgo2sim_emu.so : TEST-ONLY host emulation of the very same
+//       lane programs (4 structs per env, reductions as loops), so the kernel arithmetic can be checked
+//       against the oracle on a machine without a GPU.  Never loaded by the product (go2_rl_gym_amd/_lib.py
+//       accepts only a library whose go2sim_is_device_library() is 1).
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/go2sim.h"
+#include "../../include/go2sim_defaults.h"
+#include "go2_lane.h"
+#include "go2_post.h"
+
+#ifndef GO2_EMU
+#include <hip/hip_runtime.h>
+#endif
+
+static thread_local char g_err[512] = "";
+#define FAIL(code, ...) do { snprintf(g_err, sizeof(g_err), __VA_ARGS__); return (code); } while (0)
+
+#ifndef GO2_EMU
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) FAIL(GO2SIM_EDEVICE, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
+#endif
+
+enum { MODE_PHYS = 1, MODE_POST = 2, MODE_RESET_ALL = 4 };
+
+// ------------------------------------------------------------------------------------------------------
+// the per-quad driver shared by the kernel and the emulation: everything except the cross-lane steps
+// ------------------------------------------------------------------------------------------------------
+struct LaneCtx {
+  LegPhys ph; LegPost po; PhysOut out;
+  float kpm[3], kdm[3], zoff[3], strength[3], act_new[3], act_old[3];
+  int start;
+};
+
+GO2_HD void lane_load_phys(LaneCtx& c, const Go2Tables& tab, const Go2Ptrs& p, const Go2Launch& L, const Go2Step& S, const float* actions_in, int e, int lane) {
+  const int N = L.N;
+  const LegTab& t = tab.leg[lane];
+  LegPhys& ph = c.ph;
+  ph.pw = v3(F2D(p.root, 0, e), F2D(p.root, 1, e), F2D(p.root, 2, e));
+  ph.qx = F2D(p.root, 3, e); ph.qy = F2D(p.root, 4, e); ph.qz = F2D(p.root, 5, e); ph.qw = F2D(p.root, 6, e);
+  ph.vw = v3(F2D(p.root, 7, e), F2D(p.root, 8, e), F2D(p.root, 9, e));
+  ph.ww = v3(F2D(p.root, 10, e), F2D(p.root, 11, e), F2D(p.root, 12, e));
+  float cl = L.clip_actions;
+  for (int j = 0; j < 3; ++j) {
+    int d = 3 * lane + j;
+    ph.q[j] = F2D(p.dof, d, e); ph.qd[j] = F2D(p.dof, 12 + d, e);
+    c.kpm[j] = F2D(p.kp_mul, d, e); c.kdm[j] = F2D(p.kd_mul, d, e); c.zoff[j] = F2D(p.zero_off, d, e); c.strength[j] = F2D(p.strength, d, e);
+    float a = actions_in ? actions_in[(size_t)e * 12 + d] : F2D(p.actions, d, e);
+    a = fminf(fmaxf(a, -cl), cl);                  // legged_robot.py:67-68
+    c.act_new[j] = a; F2D(p.actions, d, e) = a;
+    c.act_old[j] = F2D(p.last_actions, d, e);
+    ph.lam_foot[0 + j] = F3D(p.foot_impulse, 4, lane, j, e);
+  }
+  // per-env inertial parameters (legged_robot.py:379-402, recomputeInertia=True modelled as inertia ~ mass)
+  float r_hip = F2D(p.mass_ratio, t.mass_ratio_index[0], e), r_thigh = F2D(p.mass_ratio, t.mass_ratio_index[1], e);
+  float r_calf = F2D(p.mass_ratio, t.mass_ratio_index[2], e), r_foot = F2D(p.mass_ratio, t.mass_ratio_index[3], e);
+  auto rb10 = [](const float* b) { RB r; r.m = b[0]; r.h = v3(b[1], b[2], b[3]); r.J.xx = b[4]; r.J.yy = b[5]; r.J.zz = b[6]; r.J.xy = b[7]; r.J.xz = b[8]; r.J.yz = b[9]; return r; };
+  ph.Lhip = r_hip * rb10(t.body[0]); ph.Lthigh = r_thigh * rb10(t.body[1]);
+  ph.Lcalf = r_calf * rb10(t.body[2]) + r_foot * rb10(t.body[3]);
+  const BaseTab& bt = tab.base;
+  float m = bt.m0 + p.added_mass[e], ratio = m / bt.m0;
+  V3 cc = v3(bt.c0[0] + F2D(p.added_com, 0, e), bt.c0[1] + F2D(p.added_com, 1, e), bt.c0[2] + F2D(p.added_com, 2, e));
+  S3 Ic = {bt.Ic0[0] * ratio, bt.Ic0[1] * ratio, bt.Ic0[2] * ratio, bt.Ic0[3] * ratio, bt.Ic0[4] * ratio, bt.Ic0[5] * ratio};
+  ph.Ibase = rb_from_com(m, cc, Ic) + F2D(p.mass_ratio, 0, e) * rb10(bt.head[0]) + F2D(p.mass_ratio, 1, e) * rb10(bt.head[1]);
+  ph.mu = 0.5f * (L.terrain_friction + p.friction[e]);
+  ph.rest = 0.5f * (L.terrain_restitution + p.restitution[e]);
+  // action delay (legged_robot.py:71-78)
+  c.start = 0;
+  if (L.rand_delay) {
+    float u;
+    if (S.injected) u = S.injected[(size_t)e * GO2_NUM_UNIFORMS + GO2_U_DELAY];
+    else { uint32_t r[4]; philox4x32_10((uint32_t)(L.env_offset + e), 0u, S.step_lo, S.step_hi, L.seed_lo, L.seed_hi, r); u = u01_from_bits(r[GO2_U_DELAY & 3]); }
+    c.start = (int)(u * (float)(L.decimation + 1)); if (c.start > L.decimation) c.start = L.decimation;
+  }
+}
+
+GO2_HD void quat_mul(const float* a, const float* b, float* o) {  // (x,y,z,w)
+  o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  o[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+  o[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+  o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+
+// after the last substep: forward kinematics at the new state, API tensors, PhysOut.  fbase = this lane's
+// contribution to the base / head contact forces (3 bodies x 3), to be quad-summed by the caller.
+GO2_HD void lane_finish_phys(LaneCtx& c, const Go2Tables& tab, const Go2Ptrs& p, const Go2Launch& L, int e, int lane, float* fbase) {
+  const int N = L.N;
+  const LegTab& t = tab.leg[lane];
+  LegPhys& ph = c.ph; PhysOut& o = c.out;
+  M3 Rwb = quat_to_m3(ph.qx, ph.qy, ph.qz, ph.qw);
+  V3 wb = mulT(Rwb, ph.ww), vb = mulT(Rwb, ph.vw);
+  float s1, c1, s2, c2, s3, c3; sincosf(ph.q[0], &s1, &c1); sincosf(ph.q[1], &s2, &c2); sincosf(ph.q[2], &s3, &c3);
+  float c23 = c2 * c3 - s2 * s3, s23 = s2 * c3 + c2 * s3;
+  M3 R1, R2, R3; R1.x = v3(1, 0, 0); R1.y = v3(0, c1, s1); R1.z = v3(0, -s1, c1);
+  R2.x = c2 * R1.x - s2 * R1.z; R2.y = R1.y; R2.z = s2 * R1.x + c2 * R1.z;
+  R3.x = c23 * R1.x - s23 * R1.z; R3.y = R1.y; R3.z = s23 * R1.x + c23 * R1.z;
+  V3 p1 = v3(t.o1[0], t.o1[1], t.o1[2]), p2 = p1 + mul(R1, v3(t.o2[0], t.o2[1], t.o2[2])), p3 = p2 + mul(R2, v3(t.o3[0], t.o3[1], t.o3[2]));
+  V3 a1 = v3(1, 0, 0), a2 = R1.y;
+  // link spatial velocities in the common frame
+  SV V0 = sv(wb, vb);
+  SV V1 = V0 + ph.qd[0] * sv(a1, cross(p1, a1)), V2 = V1 + ph.qd[1] * sv(a2, cross(p2, a2)), V3l = V2 + ph.qd[2] * sv(a2, cross(p3, a2));
+  V3 pf = p3 + mul(R3, v3(t.foot_off[0], t.foot_off[1], t.foot_off[2]));
+  V3 org[4] = {p1, p2, p3, pf}; SV vel[4] = {V1, V2, V3l, V3l};
+  float qb[4] = {ph.qx, ph.qy, ph.qz, ph.qw}, qh[4], qt[4], qc[4];
+  float h1[4] = {sinf(0.5f * ph.q[0]), 0, 0, cosf(0.5f * ph.q[0])}, h2[4] = {0, sinf(0.5f * ph.q[1]), 0, cosf(0.5f * ph.q[1])}, h3[4] = {0, sinf(0.5f * ph.q[2]), 0, cosf(0.5f * ph.q[2])};
+  quat_mul(qb, h1, qh); quat_mul(qh, h2, qt); quat_mul(qt, h3, qc);
+  const float* quats[4] = {qh, qt, qc, qc};
+  for (int k = 0; k < 4; ++k) {
+    int b = t.body_index[k];
+    V3 pos = ph.pw + mul(Rwb, org[k]);
+    V3 lv = mul(Rwb, vel[k].l + cross(vel[k].a, org[k])), av = mul(Rwb, vel[k].a);
+    float r13[13] = {pos.x, pos.y, pos.z, quats[k][0], quats[k][1], quats[k][2], quats[k][3], lv.x, lv.y, lv.z, av.x, av.y, av.z};
+    for (int i = 0; i < 13; ++i) F3D(p.rigid, 19, b, i, e) = r13[i];
+    if (k == 3) { o.foot_pos = pos; o.foot_vel = lv; }
+  }
+  if (lane < 3) {  // base, Head_upper, Head_lower rows
+    V3 off = v3(tab.base.body_off[lane][0], tab.base.body_off[lane][1], tab.base.body_off[lane][2]);
+    V3 pos = ph.pw + mul(Rwb, off); V3 lv = mul(Rwb, vb + cross(wb, off));
+    float r13[13] = {pos.x, pos.y, pos.z, ph.qx, ph.qy, ph.qz, ph.qw, lv.x, lv.y, lv.z, ph.ww.x, ph.ww.y, ph.ww.z};
+    for (int i = 0; i < 13; ++i) F3D(p.rigid, 19, lane, i, e) = r13[i];
+  }
+  // contact forces of this leg's bodies; base/head parts go through the quad sum
+  V3 zero = v3(0, 0, 0);
+  o.Fhip = ph.other_body == t.body_index[0] ? ph.force_other : zero;
+  o.Fthigh = ph.other_body == t.body_index[1] ? ph.force_other : zero;
+  o.Fcalf = ph.other_body == t.body_index[2] ? ph.force_other : zero;
+  o.Ffoot = ph.force_foot;
+  V3 fl[4] = {o.Fhip, o.Fthigh, o.Fcalf, o.Ffoot};
+  for (int k = 0; k < 4; ++k) { int b = t.body_index[k]; F3D(p.contact, 19, b, 0, e) = fl[k].x; F3D(p.contact, 19, b, 1, e) = fl[k].y; F3D(p.contact, 19, b, 2, e) = fl[k].z; }
+  for (int b = 0; b < 3; ++b) { V3 f = ph.other_body == b ? ph.force_other : zero; fbase[3 * b] = f.x; fbase[3 * b + 1] = f.y; fbase[3 * b + 2] = f.z; }
+  o.pw = ph.pw; o.qx = ph.qx; o.qy = ph.qy; o.qz = ph.qz; o.qw = ph.qw; o.vw = ph.vw; o.ww = ph.ww;
+  for (int j = 0; j < 3; ++j) {
+    int d = 3 * lane + j;
+    o.q[j] = ph.q[j]; o.qd[j] = ph.qd[j]; o.tau[j] = ph.tau[j];
+    F2D(p.dof, d, e) = ph.q[j]; F2D(p.dof, 12 + d, e) = ph.qd[j]; F2D(p.torques, d, e) = ph.tau[j];
+    F3D(p.foot_impulse, 4, lane, j, e) = ph.lam_foot[j];
+  }
+  if (lane == 0) {
+    float r13[13] = {o.pw.x, o.pw.y, o.pw.z, o.qx, o.qy, o.qz, o.qw, o.vw.x, o.vw.y, o.vw.z, o.ww.x, o.ww.y, o.ww.z};
+    for (int k = 0; k < 13; ++k) F2D(p.root, k, e) = r13[k];
+  }
+}
+// fbase_sum = quad-summed base/head forces
+GO2_HD void lane_store_base_forces(LaneCtx& c, const Go2Ptrs& p, const Go2Launch& L, int e, int lane, const float* fbase_sum) {
+  const int N = L.N;
+  c.out.Fbase = v3(fbase_sum[0], fbase_sum[1], fbase_sum[2]);
+  if (lane < 3) for (int k = 0; k < 3; ++k) F3D(p.contact, 19, lane, k, e) = fbase_sum[3 * lane + k];
+}
+// post-only entry: rebuild PhysOut from the API tensors
+GO2_HD void lane_load_physout(LaneCtx& c, const Go2Tables& tab, const Go2Ptrs& p, const Go2Launch& L, int e, int lane) {
+  const int N = L.N; const LegTab& t = tab.leg[lane]; PhysOut& o = c.out;
+  o.pw = v3(F2D(p.root, 0, e), F2D(p.root, 1, e), F2D(p.root, 2, e));
+  o.qx = F2D(p.root, 3, e); o.qy = F2D(p.root, 4, e); o.qz = F2D(p.root, 5, e); o.qw = F2D(p.root, 6, e);
+  o.vw = v3(F2D(p.root, 7, e), F2D(p.root, 8, e), F2D(p.root, 9, e)); o.ww = v3(F2D(p.root, 10, e), F2D(p.root, 11, e), F2D(p.root, 12, e));
+  for (int j = 0; j < 3; ++j) { int d = 3 * lane + j; o.q[j] = F2D(p.dof, d, e); o.qd[j] = F2D(p.dof, 12 + d, e); o.tau[j] = F2D(p.torques, d, e); }
+  auto F = [&](int b) { return v3(F3D(p.contact, 19, b, 0, e), F3D(p.contact, 19, b, 1, e), F3D(p.contact, 19, b, 2, e)); };
+  o.Fhip = F(t.body_index[0]); o.Fthigh = F(t.body_index[1]); o.Fcalf = F(t.body_index[2]); o.Ffoot = F(t.body_index[3]); o.Fbase = F(0);
+  int fb = t.body_index[3];
+  o.foot_pos = v3(F3D(p.rigid, 19, fb, 0, e), F3D(p.rigid, 19, fb, 1, e), F3D(p.rigid, 19, fb, 2, e));
+  o.foot_vel = v3(F3D(p.rigid, 19, fb, 7, e), F3D(p.rigid, 19, fb, 8, e), F3D(p.rigid, 19, fb, 9, e));
+}
+GO2_HD void lane_init_post(LaneCtx& c, const Go2Ptrs* p, const Go2Launch* L, const Go2Step* S, int e, int lane) {
+  c.po.e = e; c.po.lane = lane; c.po.N = L->N; c.po.P = p; c.po.L = L; c.po.S = S; c.po.o = c.out;
+}
+// reset_idx(all envs) without a step (base_task.py:82-84): postB's reset branch with reset forced on
+GO2_HD void lane_reset_all(LaneCtx& c, const Go2Tables& tab, const Go2Ptrs& p, const Go2Launch& L, const Go2Step& S, int e, int lane) {
+  const int N = L.N;
+  lane_load_physout(c, tab, p, L, e, lane);
+  lane_init_post(c, &p, &L, &S, e, lane);
+  LegPost& po = c.po;
+  // load what postA would have loaded, without advancing any clock
+  po.ep_len = p.ep_len[e]; po.timer = p.cmd_timer[e];
+  for (int k = 0; k < 4; ++k) po.cmd[k] = F2D(p.commands, k, e);
+  po.acc[0] = F2D(p.cmd_xy_acc, 0, e); po.acc[1] = F2D(p.cmd_xy_acc, 1, e);
+  po.stop_heading = p.stop_heading[e]; po.last_limit = p.last_is_limit_vel[e];
+  for (int j = 0; j < 3; ++j) { int d = 3 * lane + j; po.act[j] = 0; po.last_act[j] = 0; po.llast_act[j] = F2D(p.last_last_actions, d, e); po.last_dv[j] = 0; }
+  po.max_move = p.max_move[e];
+  po.load_terrain_fields();
+}
+
+// ------------------------------------------------------------------------------------------------------
+#ifndef GO2_EMU
+__device__ __forceinline__ float quad_sum(float x) {
+  // DPP quad_perm [1,0,3,2] then [2,3,0,1]: both adds are commutative pairs, so the 4 lanes get bit-identical sums
+  float y = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));
+  return y + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(y), 0x4E, 0xF, 0xF, true));
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(64) go2_step_kernel(const Go2DevBlock* __restrict__ blk, const float* __restrict__ actions_in, int initial_reset) {
+  __shared__ Go2Tables tab;   // robot link / collision tables staged in LDS (per-lane leg index -> ds_read)
+  __shared__ Go2Step S;       // this step's scalars, computed on device from the device-resident counters
+  const Go2Ptrs& p = blk->p; const Go2Launch& L = blk->L;   // uniform addresses -> scalar loads
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.tables); uint32_t* dst = reinterpret_cast<uint32_t*>(&tab);
+    for (int i = threadIdx.x; i < (int)(sizeof(Go2Tables) / 4); i += 64) dst[i] = src[i];
+    if (threadIdx.x == 0) go2_step_scalars(L, blk->dyn, p.inj_storage, blk->dyn.common_step_counter + ((MODE & MODE_POST) ? 1 : 0), initial_reset, &S);
+  }
+  __syncthreads();
+  const int e = blockIdx.x * 16 + (threadIdx.x >> 2), lane = threadIdx.x & 3;
+  if (e >= L.N) return;   // whole quads leave together
+  LaneCtx c;
+  const LegTab& t = tab.leg[lane];
+  if (MODE & MODE_RESET_ALL) {
+    lane_reset_all(c, tab, p, L, S, e, lane);
+    float red[GO2_POST_PARTIALS];
+#pragma unroll
+    for (int i = 0; i < GO2_POST_PARTIALS; ++i) red[i] = 0.f;
+    c.po.reset = 1; c.po.time_out = 0;
+    c.po.blv = v3(0, 0, 0); c.po.bav = v3(0, 0, 0); c.po.pg = v3(0, 0, -1); c.po.rpy[0] = c.po.rpy[1] = c.po.rpy[2] = 0.f;
+    c.po.own_f2b = 0.f; c.po.own_fvel2 = 0.f;
+    c.po.postB(t, red, 0.f);
+    return;
+  }
+  if (MODE & MODE_PHYS) {
+    lane_load_phys(c, tab, p, L, S, actions_in, e, lane);
+    for (int sub = 0; sub < L.decimation; ++sub) {
+      const float* a = (L.rand_delay && sub < c.start) ? c.act_old : c.act_new;
+      c.ph.pd(t, L, lane, a, c.kpm, c.kdm, c.zoff, c.strength);
+      float part[GO2_QUAD_PARTIALS];
+      c.ph.phaseA(t, L, part);
+#pragma unroll
+      for (int i = 0; i < GO2_QUAD_PARTIALS; ++i) part[i] = quad_sum(part[i]);
+      c.ph.phaseB(L, part);
+      float dw[6], tot[6];
+      c.ph.phaseC(t, L, p.hf, dw);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dw[i] = quad_sum(dw[i]);
+      c.ph.set_w(dw);
+      for (int it = 0; it < L.solver_iterations; ++it)
+        for (int turn = 0; turn < 4; ++turn) {
+          c.ph.sweep(lane == turn ? 1.f : 0.f, dw);
+#pragma unroll
+          for (int i = 0; i < 6; ++i) tot[i] = quad_sum(dw[i]);
+          c.ph.add_others(tot, dw);
+        }
+      c.ph.phaseD(t, L);
+    }
+    float fb[9];
+    lane_finish_phys(c, tab, p, L, e, lane, fb);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) fb[i] = quad_sum(fb[i]);
+    lane_store_base_forces(c, p, L, e, lane, fb);
+  } else {
+    lane_load_physout(c, tab, p, L, e, lane);
+  }
+  if (MODE & MODE_POST) {
+    lane_init_post(c, &p, &L, &S, e, lane);
+    float part[GO2_POST_PARTIALS];
+    c.po.postA(t, part);
+#pragma unroll
+    for (int i = 0; i < GO2_POST_PARTIALS; ++i) part[i] = quad_sum(part[i]);
+    float fr = quad_sum(c.po.regulation(part));
+    c.po.postB(t, part, fr);
+  }
+}
+
+// after a step: extras["episode"] means, then advance the device-resident counters
+__global__ void go2_finish_kernel(Go2DevBlock* blk, int counter_inc) {
+  float* accum = blk->p.ep_accum; float* info = blk->p.episode_info;
+  int i = threadIdx.x;
+  float cnt = accum[GO2_NUM_REWARDS];
+  __syncthreads();
+  if (i <= GO2_NUM_REWARDS) {
+    if (cnt > 0.f) info[i] = i < GO2_NUM_REWARDS ? accum[i] / cnt / blk->L.episode_length_s : cnt;
+    accum[i] = 0.f;
+  }
+  if (i == 0) { blk->dyn.common_step_counter += counter_inc; blk->dyn.step_count += 1; blk->dyn.use_injected = 0; }
+}
+__global__ void go2_peek_kernel(float* out, int N, int env_offset, uint32_t s0, uint32_t s1, uint32_t k0, uint32_t k1) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * (GO2_NUM_UNIFORMS / 4)) return;
+  int e = i / (GO2_NUM_UNIFORMS / 4), blk = i % (GO2_NUM_UNIFORMS / 4);
+  uint32_t r[4]; philox4x32_10((uint32_t)(env_offset + e), (uint32_t)blk, s0, s1, k0, k1, r);
+  for (int k = 0; k < 4; ++k) out[(size_t)e * GO2_NUM_UNIFORMS + 4 * blk + k] = u01_from_bits(r[k]);
+}
+// GAE(lambda) reverse scan, one lane per env (rollout_storage.py:123-137); block partials -> fp64 atomics
+__global__ void __launch_bounds__(256) go2_gae_kernel(const float* rew, const uint8_t* dones, const float* val, const float* last, float* ret, float* adv,
+                                                      double* partials, int T, int N, float gamma, float lam) {
+  int e = blockIdx.x * 256 + threadIdx.x;
+  double s1 = 0, s2 = 0;
+  if (e < N) {
+    float a = 0.f;
+    for (int t = T - 1; t >= 0; --t) {
+      float nv = t == T - 1 ? last[e] : val[(size_t)(t + 1) * N + e];
+      float nt = 1.f - (dones[(size_t)t * N + e] ? 1.f : 0.f);
+      float v = val[(size_t)t * N + e];
+      float delta = rew[(size_t)t * N + e] + nt * gamma * nv - v;
+      a = delta + nt * gamma * lam * a;
+      float r = a + v; ret[(size_t)t * N + e] = r;
+      float ad = r - v; adv[(size_t)t * N + e] = ad; s1 += ad; s2 += (double)ad * ad;
+    }
+  }
+  __shared__ double sh1[4], sh2[4];
+  for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
+  if ((threadIdx.x & 63) == 0) { sh1[threadIdx.x >> 6] = s1; sh2[threadIdx.x >> 6] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0 && partials) {
+    atomicAdd(&partials[0], sh1[0] + sh1[1] + sh1[2] + sh1[3]); atomicAdd(&partials[1], sh2[0] + sh2[1] + sh2[2] + sh2[3]);
+    if (blockIdx.x == 0) atomicAdd(&partials[2], (double)T * N);
+  }
+}
+__global__ void go2_normalize_kernel(float* adv, const double* partials, int count) {
+  double n = partials[2], mean = partials[0] / n, var = (partials[1] - n * mean * mean) / (n - 1.0);
+  float sd = (float)sqrt(var > 0 ? var : 0.0), m = (float)mean;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) adv[i] = (adv[i] - m) / (sd + 1e-8f);
+}
+#endif  // !GO2_EMU
+
+// ------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------
+struct Go2Sim {
+  Go2SimCfg cfg; Go2SimBuffers b; int N;
+  Go2DevBlock h;            // host mirror of the device-resident block (pointers, constants, counters)
+  Go2DevBlock* d_blk;       // the block in device memory
+  std::vector<void*> allocs;
+  float dt, max_episode_length;
+  float* inj_storage; Go2Tables* d_tables; int16_t* d_hf; float* d_torigins;
+  int timing; double time_ms; int64_t time_launches;
+#ifndef GO2_EMU
+  std::vector<hipEvent_t> ev; size_t ev_used;
+#endif
+};
+
+static void* dev_alloc(Go2Sim* s, size_t bytes) {
+  void* ptr = nullptr;
+#ifdef GO2_EMU
+  ptr = calloc(1, bytes ? bytes : 1);
+#else
+  if (hipMalloc(&ptr, bytes ? bytes : 1) != hipSuccess) return nullptr;
+  hipMemset(ptr, 0, bytes ? bytes : 1);
+#endif
+  if (ptr) s->allocs.push_back(ptr);
+  return ptr;
+}
+static void dev_upload(void* dst, const void* src, size_t bytes) {
+#ifdef GO2_EMU
+  memcpy(dst, src, bytes);
+#else
+  hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+#endif
+}
+
+static float u01_host(uint64_t seed, uint32_t env, uint32_t slot, uint64_t step) {
+  uint32_t r[4]; philox4x32_10(env, slot >> 2, (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  return u01_from_bits(r[slot & 3]);
+}
+static float urange_h(float u, float lo, float hi) { return (hi - lo) * u + lo; }
+
+static void fill_tables(Go2Tables* T) {
+  static const int kBodyLink[19] = GO2_BODY_LINK_INIT; static const double kOff[19][3] = GO2_BODY_OFFSET_INIT; static const double kMass[19] = GO2_BODY_MASS_INIT;
+  static const double kCom[19][3] = GO2_BODY_COM_INIT; static const double kIn[19][6] = GO2_BODY_INERTIA_INIT; static const double kJO[12][3] = GO2_JOINT_ORIGIN_INIT;
+  static const double kLo[12] = GO2_JOINT_LOWER_INIT, kHi[12] = GO2_JOINT_UPPER_INIT, kEff[12] = GO2_JOINT_EFFORT_INIT, kVel[12] = GO2_JOINT_VELOCITY_INIT;
+  struct Sph { int body, link; double c[3]; double r; };
+  static const Sph kFoot[4] = GO2_FOOT_PTS_INIT; static const Sph kOther[4][GO2_LEG_OTHER_PTS] = GO2_LEG_OTHER_PTS_INIT; static const Sph kBase[GO2_BASE_PTS] = GO2_BASE_PTS_INIT;
+  (void)kBodyLink;
+  memset(T, 0, sizeof(*T));
+  auto body10 = [&](int b, float* out) {   // about the moving-link origin
+    V3 c = v3((float)(kOff[b][0] + kCom[b][0]), (float)(kOff[b][1] + kCom[b][1]), (float)(kOff[b][2] + kCom[b][2]));
+    S3 Ic = {(float)kIn[b][0], (float)kIn[b][1], (float)kIn[b][2], (float)kIn[b][3], (float)kIn[b][4], (float)kIn[b][5]};
+    RB r = rb_from_com((float)kMass[b], c, Ic);
+    out[0] = r.m; out[1] = r.h.x; out[2] = r.h.y; out[3] = r.h.z; out[4] = r.J.xx; out[5] = r.J.yy; out[6] = r.J.zz; out[7] = r.J.xy; out[8] = r.J.xz; out[9] = r.J.yz;
+  };
+  for (int l = 0; l < 4; ++l) {
+    LegTab& t = T->leg[l];
+    for (int k = 0; k < 3; ++k) { t.o1[k] = (float)kJO[3 * l][k]; t.o2[k] = (float)kJO[3 * l + 1][k]; t.o3[k] = (float)kJO[3 * l + 2][k]; }
+    for (int k = 0; k < 4; ++k) { int b = 3 + 4 * l + k; body10(b, t.body[k]); t.body_index[k] = b; t.mass_ratio_index[k] = b - 1; }
+    for (int j = 0; j < 3; ++j) { t.lim_lo[j] = (float)kLo[3 * l + j]; t.lim_hi[j] = (float)kHi[3 * l + j]; t.vel_lim[j] = (float)kVel[3 * l + j]; t.eff_lim[j] = (float)kEff[3 * l + j]; }
+    for (int k = 0; k < 3; ++k) { t.foot_pt[k] = (float)kFoot[l].c[k]; t.foot_off[k] = (float)kOff[3 + 4 * l + 3][k]; }
+    t.foot_pt[3] = (float)kFoot[l].r;
+    for (int i = 0; i < GO2_LEG_OTHER_PTS; ++i) {
+      for (int k = 0; k < 3; ++k) t.other_pt[i][k] = (float)kOther[l][i].c[k];
+      t.other_pt[i][3] = (float)kOther[l][i].r; t.other_link[i] = kOther[l][i].link - 3 * l; t.other_body[i] = kOther[l][i].body;
+    }
+    t.n_base = 0;
+    for (int i = 0; i < GO2_BASE_PTS; ++i) if ((i & 3) == l) {
+      int k = t.n_base++; for (int a = 0; a < 3; ++a) t.base_pt[k][a] = (float)kBase[i].c[a]; t.base_pt[k][3] = (float)kBase[i].r; t.base_body[k] = kBase[i].body;
+    }
+  }
+  T->base.m0 = (float)kMass[0];
+  for (int k = 0; k < 3; ++k) T->base.c0[k] = (float)kCom[0][k];
+  for (int k = 0; k < 6; ++k) T->base.Ic0[k] = (float)kIn[0][k];
+  body10(1, T->base.head[0]); body10(2, T->base.head[1]);
+  for (int b = 0; b < 3; ++b) for (int k = 0; k < 3; ++k) T->base.body_off[b][k] = (float)kOff[b][k];
+}
+
+
+
+static void blk_sync_dyn(Go2Sim* s, void* stream) {   // host mirror -> device counters (rare: create, set_counter, inject)
+#ifdef GO2_EMU
+  (void)stream; s->d_blk->dyn = s->h.dyn;
+#else
+  hipMemcpyAsync(&s->d_blk->dyn, &s->h.dyn, sizeof(Go2Dyn), hipMemcpyHostToDevice, (hipStream_t)stream);
+#endif
+}
+
+extern "C" {
+
+int go2sim_is_device_library(void) {
+#ifdef GO2_EMU
+  return 0;
+#else
+  return 1;
+#endif
+}
+int go2sim_buffer_layout(void) { return 1; }
+const char* go2sim_last_error(void) { return g_err; }
+void go2sim_default_cfg(Go2SimCfg* cfg) { go2sim_fill_default_cfg(cfg); }
+
+void go2sim_destroy(Go2Sim* s) {
+  if (!s) return;
+#ifndef GO2_EMU
+  for (hipEvent_t e : s->ev) hipEventDestroy(e);
+#endif
+  for (void* ptr : s->allocs) {
+#ifdef GO2_EMU
+    free(ptr);
+#else
+    hipFree(ptr);
+#endif
+  }
+  delete s;
+}
+
+int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
+  if (!cfg || !out) FAIL(GO2SIM_EINVAL, "null argument");
+  if (cfg->struct_size != sizeof(Go2SimCfg) || cfg->abi_version != GO2SIM_ABI_VERSION) FAIL(GO2SIM_EINVAL, "cfg size/version mismatch (%u vs %zu)", cfg->struct_size, sizeof(Go2SimCfg));
+  if (cfg->num_envs <= 0 || cfg->decimation <= 0 || cfg->num_envs_global < cfg->env_offset + cfg->num_envs) FAIL(GO2SIM_EINVAL, "bad num_envs/decimation");
+  if (cfg->terrain_mode != 0 && (!cfg->hf_samples || !cfg->terrain_origins || !cfg->terrain_type_id)) FAIL(GO2SIM_EINVAL, "heightfield terrain needs hf_samples, terrain_origins, terrain_type_id");
+  if (cfg->limit_vel_comb_count > 36 || cfg->cmd_curriculum_count > 4 || cfg->reward_curriculum_count > 4) FAIL(GO2SIM_EINVAL, "table sizes out of range");
+#ifndef GO2_EMU
+  HIPCHK(hipSetDevice(device_id));
+#else
+  (void)device_id;
+#endif
+  Go2Sim* s = new Go2Sim();
+  s->cfg = *cfg; const int N = s->N = cfg->num_envs;
+  s->d_hf = nullptr; s->d_torigins = nullptr; s->timing = 0; s->time_ms = 0; s->time_launches = 0;
+#ifndef GO2_EMU
+  s->ev_used = 0;
+#endif
+  memset(&s->b, 0, sizeof(s->b)); memset(&s->h, 0, sizeof(s->h));
+  bool ok = true;
+#define A(field, type, count) do { s->b.field = (type*)dev_alloc(s, sizeof(type) * (size_t)(count)); ok = ok && s->b.field; } while (0)
+  A(root_states, float, N * 13); A(dof_state, float, N * 24); A(contact_forces, float, N * 57); A(rigid_body_states, float, N * 19 * 13);
+  A(obs_buf, float, N * GO2_NUM_OBS); A(privileged_obs_buf, float, N * GO2_NUM_PRIV_OBS); A(rew_buf, float, N); A(reset_buf, uint8_t, N); A(time_out_buf, uint8_t, N);
+  A(episode_length_buf, int64_t, N); A(torques, float, N * 12); A(actions, float, N * 12); A(last_actions, float, N * 12); A(last_last_actions, float, N * 12);
+  A(last_dof_vel, float, N * 12); A(last_root_vel, float, N * 6); A(commands, float, N * 4); A(commands_resampling_step, float, N); A(commands_xy_accumulation, float, N * 2);
+  A(stop_heading, uint8_t, N); A(last_is_limit_vel, uint8_t, N); A(base_lin_vel, float, N * 3); A(base_ang_vel, float, N * 3); A(projected_gravity, float, N * 3); A(rpy, float, N * 3);
+  A(measured_heights, float, N * GO2_NUM_HEIGHT_POINTS); A(max_move_distance, float, N); A(feet_air_time, float, N * 4); A(last_contacts, uint8_t, N * 4); A(last_contacts2, uint8_t, N * 4);
+  A(motor_strengths, float, N * 12); A(motor_zero_offsets, float, N * 12); A(p_gains_multiplier, float, N * 12); A(d_gains_multiplier, float, N * 12);
+  A(env_origins, float, N * 3); A(terrain_levels, int64_t, N); A(terrain_types, int64_t, N); A(episode_sums, float, GO2_NUM_REWARDS * N);
+  A(friction_coeffs, float, N); A(restitution_coeffs, float, N); A(added_base_mass, float, N); A(added_base_com, float, N * 3); A(link_mass_ratio, float, N * 18);
+  A(episode_info, float, GO2_NUM_REWARDS + 1); A(foot_impulse, float, N * 12);
+#undef A
+  Go2Ptrs& p = s->h.p; Go2SimBuffers& b = s->b;
+  p.root = b.root_states; p.dof = b.dof_state; p.contact = b.contact_forces; p.rigid = b.rigid_body_states; p.obs = b.obs_buf; p.priv = b.privileged_obs_buf; p.rew = b.rew_buf;
+  p.reset = b.reset_buf; p.time_out = b.time_out_buf; p.ep_len = b.episode_length_buf; p.torques = b.torques; p.actions = b.actions; p.last_actions = b.last_actions;
+  p.last_last_actions = b.last_last_actions; p.last_dof_vel = b.last_dof_vel; p.last_root_vel = b.last_root_vel; p.commands = b.commands; p.cmd_timer = b.commands_resampling_step;
+  p.cmd_xy_acc = b.commands_xy_accumulation; p.stop_heading = b.stop_heading; p.last_is_limit_vel = b.last_is_limit_vel; p.base_lin_vel = b.base_lin_vel; p.base_ang_vel = b.base_ang_vel;
+  p.proj_gravity = b.projected_gravity; p.rpy = b.rpy; p.heights = b.measured_heights; p.max_move = b.max_move_distance; p.feet_air_time = b.feet_air_time; p.last_contacts = b.last_contacts;
+  p.last_contacts2 = b.last_contacts2; p.strength = b.motor_strengths; p.zero_off = b.motor_zero_offsets; p.kp_mul = b.p_gains_multiplier; p.kd_mul = b.d_gains_multiplier; p.origins = b.env_origins;
+  p.terrain_levels = b.terrain_levels; p.terrain_types = b.terrain_types; p.ep_sums = b.episode_sums; p.friction = b.friction_coeffs; p.restitution = b.restitution_coeffs;
+  p.added_mass = b.added_base_mass; p.added_com = b.added_base_com; p.mass_ratio = b.link_mass_ratio; p.episode_info = b.episode_info; p.foot_impulse = b.foot_impulse;
+  p.terrain_kind = (int32_t*)dev_alloc(s, sizeof(int32_t) * N); p.ep_accum = (float*)dev_alloc(s, sizeof(float) * (GO2_NUM_REWARDS + 1));
+  s->inj_storage = (float*)dev_alloc(s, sizeof(float) * (size_t)N * GO2_NUM_UNIFORMS); p.inj_storage = s->inj_storage;
+  s->d_tables = (Go2Tables*)dev_alloc(s, sizeof(Go2Tables));
+  s->d_blk = (Go2DevBlock*)dev_alloc(s, sizeof(Go2DevBlock));
+  ok = ok && p.terrain_kind && p.ep_accum && s->inj_storage && s->d_tables && s->d_blk;
+  if (!ok) { go2sim_destroy(s); FAIL(GO2SIM_ENOMEM, "allocation failed"); }
+  { Go2Tables T; fill_tables(&T); dev_upload(s->d_tables, &T, sizeof(T)); p.tables = s->d_tables; }
+
+  s->dt = (float)cfg->decimation * cfg->sim_dt;
+  s->max_episode_length = (float)ceil((double)cfg->episode_length_s / (double)s->dt - 1e-3);   // np.ceil(25/0.02) = 1250 (:1104)
+
+  // ---- launch block constants ----
+  Go2Launch& L = s->h.L;
+  L.N = N; L.env_offset = cfg->env_offset; L.decimation = cfg->decimation; L.solver_iterations = cfg->solver_iterations;
+  L.seed_lo = (uint32_t)cfg->seed; L.seed_hi = (uint32_t)(cfg->seed >> 32);
+  L.sim_dt = cfg->sim_dt; L.dt = s->dt; memcpy(L.gravity, cfg->gravity, sizeof(L.gravity));
+  L.contact_offset = cfg->contact_offset; L.erp = cfg->erp; L.max_depen_vel = cfg->max_depenetration_velocity; L.bounce_thr = cfg->bounce_threshold_velocity;
+  L.cfm = cfg->contact_cfm; L.armature = cfg->joint_armature; L.limit_margin = cfg->joint_limit_margin;
+  L.terrain_mode = cfg->terrain_mode; L.hf_rows = cfg->hf_rows; L.hf_cols = cfg->hf_cols; L.hf_hscale = cfg->hf_hscale; L.hf_vscale = cfg->hf_vscale; L.hf_border = cfg->hf_border;
+  L.terrain_friction = cfg->terrain_friction; L.terrain_restitution = cfg->terrain_restitution; L.terrain_num_levels = cfg->terrain_num_levels; L.terrain_num_types = cfg->terrain_num_types;
+  L.terrain_curriculum = cfg->terrain_curriculum; L.move_down_by_acc = cfg->move_down_by_accumulated_xy_command; L.measure_heights = cfg->measure_heights; L.terrain_length = cfg->terrain_length;
+  memcpy(L.kp, cfg->kp, sizeof(L.kp)); memcpy(L.kd, cfg->kd, sizeof(L.kd)); memcpy(L.q0, cfg->default_dof_pos, sizeof(L.q0));
+  L.action_scale = cfg->action_scale; L.clip_actions = cfg->clip_actions; L.clip_obs = cfg->clip_observations; memcpy(L.base_init, cfg->base_init_state, sizeof(L.base_init));
+  L.rand_strength = cfg->randomize_motor_strength; L.rand_offset = cfg->randomize_motor_zero_offset; L.rand_pd = cfg->randomize_pd_gains; L.push_robots = cfg->push_robots;
+  L.push_interval = cfg->push_interval; L.rand_delay = cfg->randomize_action_delay;
+  memcpy(L.strength_rng, cfg->motor_strength_range, 8); memcpy(L.offset_rng, cfg->motor_zero_offset_range, 8); memcpy(L.kp_rng, cfg->stiffness_mult_range, 8); memcpy(L.kd_rng, cfg->damping_mult_range, 8);
+  L.push_xy = cfg->max_push_vel_xy; L.push_ang = cfg->max_push_ang_vel;
+  L.resampling_time = cfg->cmd_resampling_time; L.heading_command = cfg->heading_command; L.dynamic_resample = cfg->dynamic_resample_commands; L.limit_vel_prob = cfg->limit_vel_prob;
+  L.limit_invert = cfg->limit_vel_invert_when_continuous; L.stop_heading_at_limit = cfg->stop_heading_at_limit; L.limit_ang_zero_prob = cfg->limit_ang_vel_at_zero_command_prob;
+  L.comb_count = cfg->limit_vel_comb_count; memcpy(L.comb, cfg->limit_vel_comb, sizeof(L.comb)); memcpy(L.terrain_max_cmd, cfg->terrain_max_cmd_ranges, sizeof(L.terrain_max_cmd));
+  memcpy(L.cmd_ranges0, cfg->cmd_ranges, sizeof(L.cmd_ranges0));
+  for (int t = 0; t < GO2_NUM_REWARDS; ++t) L.rew_scale_dt[t] = cfg->reward_scales[t] * s->dt;   // :914-920
+  L.rew_curr_count = cfg->reward_curriculum_count; memcpy(L.rew_curr_term, cfg->reward_curriculum_term, sizeof(L.rew_curr_term)); memcpy(L.rew_curr, cfg->reward_curriculum, sizeof(L.rew_curr));
+  L.cmd_curr_count = cfg->cmd_curriculum_count; memcpy(L.cmd_curr, cfg->cmd_curriculum, sizeof(L.cmd_curr));
+  L.zero_curr_enabled = cfg->zero_cmd_curriculum_enabled; memcpy(L.zero_curr, cfg->zero_cmd_curriculum, sizeof(L.zero_curr)); L.num_steps_per_env = cfg->num_steps_per_env;
+  L.only_positive = cfg->only_positive_rewards; L.tracking_sigma = cfg->tracking_sigma; L.dyn_sigma = cfg->dynamic_sigma_enabled;
+  memcpy(L.dyn_sigma_vel, cfg->dynamic_sigma_vel, sizeof(L.dyn_sigma_vel)); memcpy(L.dyn_sigma_max, cfg->dynamic_sigma_max, sizeof(L.dyn_sigma_max));
+  L.soft_vel_limit = cfg->soft_dof_vel_limit; L.soft_torque_limit = cfg->soft_torque_limit; L.base_height_target = cfg->base_height_target; L.max_contact_force = cfg->max_contact_force;
+  L.min_legs_distance = cfg->min_legs_distance;
+  {
+    static const double lo[12] = GO2_JOINT_LOWER_INIT, hi[12] = GO2_JOINT_UPPER_INIT;
+    for (int j = 0; j < 12; ++j) { float l = (float)lo[j], h = (float)hi[j], m = (l + h) / 2, r = h - l; L.soft_limits[j][0] = m - 0.5f * r * cfg->soft_dof_pos_limit; L.soft_limits[j][1] = m + 0.5f * r * cfg->soft_dof_pos_limit; }   // :372-375
+  }
+  L.os_lin = cfg->obs_scale_lin_vel; L.os_ang = cfg->obs_scale_ang_vel; L.os_dof_pos = cfg->obs_scale_dof_pos; L.os_dof_vel = cfg->obs_scale_dof_vel; L.os_height = cfg->obs_scale_height;
+  L.add_noise = cfg->add_noise;
+  { float nl = cfg->noise_level;   // Go2Robot._get_noise_scale_vec (go2_env.py:9-21)
+    for (int i = 0; i < 3; ++i) { L.noise_vec[i] = cfg->noise_ang_vel * nl * cfg->obs_scale_ang_vel; L.noise_vec[3 + i] = cfg->noise_gravity * nl; L.noise_vec[6 + i] = 0.f; }
+    for (int j = 0; j < 12; ++j) { L.noise_vec[9 + j] = cfg->noise_dof_pos * nl * cfg->obs_scale_dof_pos; L.noise_vec[21 + j] = cfg->noise_dof_vel * nl * cfg->obs_scale_dof_vel; L.noise_vec[33 + j] = 0.f; } }
+  L.max_episode_length = s->max_episode_length; L.episode_length_s = cfg->episode_length_s;
+
+  // ---- terrain ----
+  std::vector<int32_t> type_id;
+  std::vector<float> torig;
+  if (cfg->terrain_mode != 0) {
+    size_t nh = (size_t)cfg->hf_rows * cfg->hf_cols; s->d_hf = (int16_t*)dev_alloc(s, nh * sizeof(int16_t));
+    size_t no = (size_t)cfg->terrain_num_levels * cfg->terrain_num_types * 3; s->d_torigins = (float*)dev_alloc(s, no * sizeof(float));
+    if (!s->d_hf || !s->d_torigins) { go2sim_destroy(s); FAIL(GO2SIM_ENOMEM, "allocation failed"); }
+    dev_upload(s->d_hf, cfg->hf_samples, nh * sizeof(int16_t)); dev_upload(s->d_torigins, cfg->terrain_origins, no * sizeof(float));
+    p.hf = s->d_hf; p.terrain_origins = s->d_torigins;
+    type_id.assign(cfg->terrain_type_id, cfg->terrain_type_id + cfg->terrain_num_types); torig.assign(cfg->terrain_origins, cfg->terrain_origins + no);
+  }
+  s->cfg.hf_samples = nullptr; s->cfg.terrain_origins = nullptr; s->cfg.terrain_type_id = nullptr;
+
+  // ---- creation-time per-env quantities (legged_robot.py:320-402, :1054-1091), same Philox slots as the oracle ----
+  const uint64_t INIT = 0xFFFFFFFFFFFFFFFFull;
+  float buckets[64];
+  for (int k = 0; k < 64; ++k) buckets[k] = urange_h(u01_host(cfg->seed, 0xFFFFFFFFu, (uint32_t)k, INIT), cfg->friction_range[0], cfg->friction_range[1]);
+  std::vector<float> fr(N), re(N), am(N), ac(3 * N), mr(18 * N), org(3 * N), root(13 * N), dof(24 * N), ones(12 * N, 1.f);
+  std::vector<int64_t> lv(N, 0), ty(N, 0); std::vector<int32_t> kind(N, -1); std::vector<uint8_t> rb(N, 1);
+  const int Ng = cfg->num_envs_global;
+  for (int e = 0; e < N; ++e) {
+    uint32_t ge = (uint32_t)(cfg->env_offset + e);
+    int bucket = (int)(u01_host(cfg->seed, ge, 0, INIT) * 64); bucket = bucket > 63 ? 63 : bucket;
+    fr[e] = cfg->randomize_friction ? buckets[bucket] : 1.0f;
+    re[e] = cfg->randomize_restitution ? urange_h(u01_host(cfg->seed, ge, 1, INIT), cfg->restitution_range[0], cfg->restitution_range[1]) : 0.f;
+    am[e] = cfg->randomize_base_mass ? urange_h(u01_host(cfg->seed, ge, 2, INIT), cfg->added_mass_range[0], cfg->added_mass_range[1]) : 0.f;
+    for (int k = 0; k < 3; ++k) ac[(size_t)k * N + e] = cfg->randomize_base_com ? urange_h(u01_host(cfg->seed, ge, 3 + k, INIT), cfg->base_com_range[0], cfg->base_com_range[1]) : 0.f;
+    for (int k = 0; k < 18; ++k) mr[(size_t)k * N + e] = cfg->randomize_link_mass ? urange_h(u01_host(cfg->seed, ge, 6 + k, INIT), cfg->link_mass_range[0], cfg->link_mass_range[1]) : 1.f;
+    float o3[3];
+    if (cfg->terrain_mode == 0) {
+      int ncols = (int)floor(sqrt((double)Ng)); o3[0] = cfg->env_spacing * (float)(ge / ncols); o3[1] = cfg->env_spacing * (float)(ge % ncols); o3[2] = 0.f;
+    } else {
+      int maxl = cfg->terrain_curriculum ? cfg->max_init_terrain_level : cfg->terrain_num_levels - 1;
+      lv[e] = ge % (uint32_t)(maxl + 1); ty[e] = (int64_t)floor((double)ge / ((double)Ng / cfg->terrain_num_types));
+      const float* o = &torig[((size_t)lv[e] * cfg->terrain_num_types + ty[e]) * 3]; o3[0] = o[0]; o3[1] = o[1]; o3[2] = o[2];
+      kind[e] = type_id[ty[e]];
+    }
+    for (int k = 0; k < 3; ++k) org[(size_t)k * N + e] = o3[k];
+    for (int k = 0; k < 13; ++k) root[(size_t)k * N + e] = cfg->base_init_state[k] + (k < 3 ? o3[k] : 0.f);
+    for (int j = 0; j < 12; ++j) { dof[(size_t)j * N + e] = cfg->default_dof_pos[j]; dof[(size_t)(12 + j) * N + e] = 0.f; }
+  }
+  dev_upload(b.friction_coeffs, fr.data(), 4 * N); dev_upload(b.restitution_coeffs, re.data(), 4 * N); dev_upload(b.added_base_mass, am.data(), 4 * N);
+  dev_upload(b.added_base_com, ac.data(), 12 * N); dev_upload(b.link_mass_ratio, mr.data(), 72 * N); dev_upload(b.env_origins, org.data(), 12 * N);
+  dev_upload(b.root_states, root.data(), 52 * N); dev_upload(b.dof_state, dof.data(), 96 * N); dev_upload(b.terrain_levels, lv.data(), 8 * N); dev_upload(b.terrain_types, ty.data(), 8 * N);
+  dev_upload(p.terrain_kind, kind.data(), 4 * N); dev_upload(b.reset_buf, rb.data(), N);
+  dev_upload(b.motor_strengths, ones.data(), 48 * N); dev_upload(b.p_gains_multiplier, ones.data(), 48 * N); dev_upload(b.d_gains_multiplier, ones.data(), 48 * N);
+  dev_upload(s->d_blk, &s->h, sizeof(Go2DevBlock));
+  *out = s;
+  return 0;
+}
+
+int go2sim_get_buffers(Go2Sim* s, Go2SimBuffers* out) { if (!s || !out) FAIL(GO2SIM_EINVAL, "null argument"); *out = s->b; return 0; }
+
+#ifdef GO2_EMU
+static float quad_sum4(float a, float b, float c, float d) { return (a + b) + (c + d); }
+static void emu_run(Go2Sim* s, int mode, const float* actions_in, int initial_reset, int counter_inc) {
+  Go2DevBlock* blk = s->d_blk;
+  Go2Tables& tab = *s->d_tables; const Go2Ptrs& p = blk->p; const Go2Launch& L = blk->L;
+  Go2Step S; go2_step_scalars(L, blk->dyn, p.inj_storage, blk->dyn.common_step_counter + ((mode & MODE_POST) ? 1 : 0), initial_reset, &S);
+  for (int e = 0; e < L.N; ++e) {
+    static thread_local LaneCtx c[4];
+    if (mode & MODE_RESET_ALL) {
+      float red[GO2_POST_PARTIALS]; for (int i = 0; i < GO2_POST_PARTIALS; ++i) red[i] = 0.f;
+      for (int l = 0; l < 4; ++l) {
+        lane_reset_all(c[l], tab, p, L, S, e, l); c[l].po.reset = 1; c[l].po.time_out = 0; c[l].po.blv = v3(0, 0, 0); c[l].po.bav = v3(0, 0, 0); c[l].po.pg = v3(0, 0, -1);
+        c[l].po.rpy[0] = c[l].po.rpy[1] = c[l].po.rpy[2] = 0.f; c[l].po.own_f2b = 0; c[l].po.own_fvel2 = 0;
+      }
+      for (int l = 0; l < 4; ++l) c[l].po.postB(tab.leg[l], red, 0.f);
+      continue;
+    }
+    if (mode & MODE_PHYS) {
+      for (int l = 0; l < 4; ++l) lane_load_phys(c[l], tab, p, L, S, actions_in, e, l);
+      for (int sub = 0; sub < L.decimation; ++sub) {
+        float part[4][GO2_QUAD_PARTIALS], red[GO2_QUAD_PARTIALS], dw[4][6], tot[6];
+        for (int l = 0; l < 4; ++l) {
+          const float* a = (L.rand_delay && sub < c[l].start) ? c[l].act_old : c[l].act_new;
+          c[l].ph.pd(tab.leg[l], L, l, a, c[l].kpm, c[l].kdm, c[l].zoff, c[l].strength);
+          c[l].ph.phaseA(tab.leg[l], L, part[l]);
+        }
+        for (int i = 0; i < GO2_QUAD_PARTIALS; ++i) red[i] = quad_sum4(part[0][i], part[1][i], part[2][i], part[3][i]);
+        for (int l = 0; l < 4; ++l) { c[l].ph.phaseB(L, red); c[l].ph.phaseC(tab.leg[l], L, p.hf, dw[l]); }
+        for (int i = 0; i < 6; ++i) tot[i] = quad_sum4(dw[0][i], dw[1][i], dw[2][i], dw[3][i]);
+        for (int l = 0; l < 4; ++l) c[l].ph.set_w(tot);
+        for (int it = 0; it < L.solver_iterations; ++it)
+          for (int turn = 0; turn < 4; ++turn) {
+            for (int l = 0; l < 4; ++l) c[l].ph.sweep(l == turn ? 1.f : 0.f, dw[l]);
+            for (int i = 0; i < 6; ++i) tot[i] = quad_sum4(dw[0][i], dw[1][i], dw[2][i], dw[3][i]);
+            for (int l = 0; l < 4; ++l) c[l].ph.add_others(tot, dw[l]);
+          }
+        for (int l = 0; l < 4; ++l) c[l].ph.phaseD(tab.leg[l], L);
+      }
+      float fb[4][9], fbs[9];
+      for (int l = 0; l < 4; ++l) lane_finish_phys(c[l], tab, p, L, e, l, fb[l]);
+      for (int i = 0; i < 9; ++i) fbs[i] = quad_sum4(fb[0][i], fb[1][i], fb[2][i], fb[3][i]);
+      for (int l = 0; l < 4; ++l) lane_store_base_forces(c[l], p, L, e, l, fbs);
+    } else {
+      for (int l = 0; l < 4; ++l) lane_load_physout(c[l], tab, p, L, e, l);
+    }
+    if (mode & MODE_POST) {
+      float part[4][GO2_POST_PARTIALS], red[GO2_POST_PARTIALS], fr[4];
+      for (int l = 0; l < 4; ++l) { lane_init_post(c[l], &p, &L, &S, e, l); c[l].po.postA(tab.leg[l], part[l]); }
+      for (int i = 0; i < GO2_POST_PARTIALS; ++i) red[i] = quad_sum4(part[0][i], part[1][i], part[2][i], part[3][i]);
+      for (int l = 0; l < 4; ++l) fr[l] = c[l].po.regulation(red);
+      float frs = quad_sum4(fr[0], fr[1], fr[2], fr[3]);
+      for (int l = 0; l < 4; ++l) c[l].po.postB(tab.leg[l], red, frs);
+    }
+  }
+  if (mode != MODE_PHYS) {   // == go2_finish_kernel
+    float* acc = p.ep_accum; float cnt = acc[GO2_NUM_REWARDS];
+    for (int i = 0; i <= GO2_NUM_REWARDS; ++i) { if (cnt > 0.f) p.episode_info[i] = i < GO2_NUM_REWARDS ? acc[i] / cnt / L.episode_length_s : cnt; acc[i] = 0.f; }
+    blk->dyn.common_step_counter += counter_inc; blk->dyn.step_count += 1; blk->dyn.use_injected = 0;
+  }
+}
+#endif
+
+// Enqueue one pass.  Nothing computed on the host enters the kernels: the per-step scalars are derived on the
+// device from the device-resident counters, so the same enqueue can be captured in a HIP graph and replayed.
+static int launch(Go2Sim* s, int mode, const float* actions_in, int initial_reset, int counter_inc, void* stream) {
+#ifdef GO2_EMU
+  (void)stream; emu_run(s, mode, actions_in, initial_reset, counter_inc);
+#else
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((s->N + 15) / 16), block(64);
+  bool timed = s->timing && (mode & MODE_PHYS);
+  if (timed) {
+    if (s->ev_used + 2 > s->ev.size()) { size_t n0 = s->ev.size(); s->ev.resize(n0 + 512); for (size_t i = n0; i < s->ev.size(); ++i) HIPCHK(hipEventCreate(&s->ev[i])); }
+    HIPCHK(hipEventRecord(s->ev[s->ev_used], st));
+  }
+  if (mode == MODE_RESET_ALL) hipLaunchKernelGGL(go2_step_kernel<MODE_RESET_ALL>, grid, block, 0, st, s->d_blk, actions_in, initial_reset);
+  else if (mode == (MODE_PHYS | MODE_POST)) hipLaunchKernelGGL(go2_step_kernel<MODE_PHYS | MODE_POST>, grid, block, 0, st, s->d_blk, actions_in, initial_reset);
+  else if (mode == MODE_PHYS) hipLaunchKernelGGL(go2_step_kernel<MODE_PHYS>, grid, block, 0, st, s->d_blk, actions_in, initial_reset);
+  else hipLaunchKernelGGL(go2_step_kernel<MODE_POST>, grid, block, 0, st, s->d_blk, actions_in, initial_reset);
+  if (timed) { HIPCHK(hipEventRecord(s->ev[s->ev_used + 1], st)); s->ev_used += 2; }
+  if (mode != MODE_PHYS) hipLaunchKernelGGL(go2_finish_kernel, dim3(1), dim3(64), 0, st, s->d_blk, counter_inc);
+  HIPCHK(hipGetLastError());
+#endif
+  if (mode != MODE_PHYS) { s->h.dyn.common_step_counter += counter_inc; s->h.dyn.step_count += 1; s->h.dyn.use_injected = 0; }   // host mirror
+  return 0;
+}
+
+int go2sim_enable_timing(Go2Sim* s, int en) {
+  if (!s) return GO2SIM_EINVAL;
+  s->timing = en; s->time_ms = 0; s->time_launches = 0;
+#ifndef GO2_EMU
+  s->ev_used = 0;
+#endif
+  return 0;
+}
+int go2sim_kernel_time(Go2Sim* s, double* ms, int64_t* n) {
+  if (!s || !ms || !n) FAIL(GO2SIM_EINVAL, "null argument");
+#ifndef GO2_EMU
+  for (size_t i = 0; i + 1 < s->ev_used; i += 2) { HIPCHK(hipEventSynchronize(s->ev[i + 1])); float t = 0; HIPCHK(hipEventElapsedTime(&t, s->ev[i], s->ev[i + 1])); s->time_ms += t; s->time_launches++; }
+  s->ev_used = 0;
+#endif
+  *ms = s->time_ms; *n = s->time_launches; s->time_ms = 0; s->time_launches = 0;
+  return 0;
+}
+int go2sim_reset_all(Go2Sim* s, void* stream) { if (!s) FAIL(GO2SIM_EINVAL, "null handle"); return launch(s, MODE_RESET_ALL, nullptr, 1, 0, stream); }
+int go2sim_simulate(Go2Sim* s, void* stream) { if (!s) FAIL(GO2SIM_EINVAL, "null handle"); return launch(s, MODE_PHYS, nullptr, 0, 0, stream); }
+int go2sim_post_physics(Go2Sim* s, void* stream) { if (!s) FAIL(GO2SIM_EINVAL, "null handle"); return launch(s, MODE_POST, nullptr, 0, 1, stream); }
+int go2sim_step(Go2Sim* s, const float* actions, void* stream) {
+  if (!s || !actions) FAIL(GO2SIM_EINVAL, "null argument");
+  return launch(s, MODE_PHYS | MODE_POST, actions, 0, 1, stream);   // counter += 1: legged_robot.py:112
+}
+// The API tensors ARE the simulator state in this library, so a write is committed as soon as it is made.
+int go2sim_set_root_state_indexed(Go2Sim* s, const int32_t*, int32_t, void*) { return s ? 0 : GO2SIM_EINVAL; }
+int go2sim_set_dof_state_indexed(Go2Sim* s, const int32_t*, int32_t, void*) { return s ? 0 : GO2SIM_EINVAL; }
+int go2sim_set_common_step_counter(Go2Sim* s, int64_t v) { if (!s) return GO2SIM_EINVAL; s->h.dyn.common_step_counter = v; blk_sync_dyn(s, nullptr); return 0; }
+int64_t go2sim_get_common_step_counter(Go2Sim* s) { return s ? s->h.dyn.common_step_counter : -1; }
+// The curriculum scales are pure functions of common_step_counter // num_steps_per_env here (the reference
+// refreshes them when counter % 24 == 0 or when forced, legged_robot.py:144-152 — the same values except
+// between a manual counter change and the next refresh), so there is nothing to force.
+int go2sim_update_reward_curriculum(Go2Sim* s, int) { return s ? 0 : GO2SIM_EINVAL; }
+int go2sim_get_curriculum_state(Go2Sim* s, float* rcs, float cr[4][2], float* zp) {
+  if (!s) return GO2SIM_EINVAL;
+  Go2Step S; go2_step_scalars(s->h.L, s->h.dyn, nullptr, s->h.dyn.common_step_counter, 0, &S);
+  if (rcs) for (int t = 0; t < GO2_NUM_REWARDS; ++t) rcs[t] = s->h.L.rew_scale_dt[t] != 0.f ? S.rew_scale[t] / s->h.L.rew_scale_dt[t] : 1.f;
+  if (cr) for (int r = 0; r < 4; ++r) { cr[r][0] = S.cmd_ranges[r][0]; cr[r][1] = S.cmd_ranges[r][1]; }
+  if (zp) *zp = S.zero_cmd_proba;
+  return 0;
+}
+int go2sim_inject_uniforms(Go2Sim* s, const float* u, void* stream) {
+  if (!s) FAIL(GO2SIM_EINVAL, "null handle");
+  if (!u) { s->h.dyn.use_injected = 0; blk_sync_dyn(s, stream); return 0; }
+#ifdef GO2_EMU
+  memcpy(s->inj_storage, u, sizeof(float) * (size_t)s->N * GO2_NUM_UNIFORMS);
+#else
+  HIPCHK(hipMemcpyAsync(s->inj_storage, u, sizeof(float) * (size_t)s->N * GO2_NUM_UNIFORMS, hipMemcpyDefault, (hipStream_t)stream));
+#endif
+  s->h.dyn.use_injected = 1; blk_sync_dyn(s, stream);
+  return 0;
+}
+int go2sim_peek_uniforms(Go2Sim* s, float* out, void* stream) {
+  if (!s || !out) FAIL(GO2SIM_EINVAL, "null argument");
+  uint64_t sc = s->h.dyn.step_count;
+#ifdef GO2_EMU
+  (void)stream;
+  for (int e = 0; e < s->N; ++e) for (int k = 0; k < GO2_NUM_UNIFORMS; ++k) out[(size_t)e * GO2_NUM_UNIFORMS + k] = u01_host(s->cfg.seed, (uint32_t)(s->cfg.env_offset + e), (uint32_t)k, sc);
+#else
+  int n = s->N * (GO2_NUM_UNIFORMS / 4);
+  hipLaunchKernelGGL(go2_peek_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, s->N, s->cfg.env_offset, (uint32_t)sc, (uint32_t)(sc >> 32), (uint32_t)s->cfg.seed, (uint32_t)(s->cfg.seed >> 32));
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+int go2sim_gae(const float* rewards, const uint8_t* dones, const float* values, const float* last_values, float* returns, float* advantages, double* partials,
+               int32_t T, int32_t N, float gamma, float lam, void* stream) {
+  if (!rewards || !dones || !values || !last_values || !returns || !advantages || T <= 0 || N <= 0) FAIL(GO2SIM_EINVAL, "bad argument");
+#ifdef GO2_EMU
+  (void)stream; double s1 = 0, s2 = 0;
+  for (int e = 0; e < N; ++e) { float a = 0.f;
+    for (int t = T - 1; t >= 0; --t) { float nv = t == T - 1 ? last_values[e] : values[(size_t)(t + 1) * N + e]; float nt = 1.f - (dones[(size_t)t * N + e] ? 1.f : 0.f); float v = values[(size_t)t * N + e];
+      float delta = rewards[(size_t)t * N + e] + nt * gamma * nv - v; a = delta + nt * gamma * lam * a; float r = a + v; returns[(size_t)t * N + e] = r; float ad = r - v; advantages[(size_t)t * N + e] = ad; s1 += ad; s2 += (double)ad * ad; } }
+  if (partials) { partials[0] += s1; partials[1] += s2; partials[2] += (double)T * N; }
+#else
+  hipLaunchKernelGGL(go2_gae_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, rewards, dones, values, last_values, returns, advantages, partials, T, N, gamma, lam);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+int go2sim_normalize_advantages(float* adv, const double* partials, int32_t count, void* stream) {
+  if (!adv || !partials || count <= 0) FAIL(GO2SIM_EINVAL, "bad argument");
+#ifdef GO2_EMU
+  (void)stream; double n = partials[2], mean = partials[0] / n, var = (partials[1] - n * mean * mean) / (n - 1.0); float sd = (float)sqrt(var > 0 ? var : 0.0), m = (float)mean;
+  for (int i = 0; i < count; ++i) adv[i] = (adv[i] - m) / (sd + 1e-8f);
+#else
+  int blocks = (count + 255) / 256; blocks = blocks > 2048 ? 2048 : blocks;
+  hipLaunchKernelGGL(go2_normalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, adv, partials, count);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+}  // extern "C"

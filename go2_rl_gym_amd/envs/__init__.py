@@ -1,0 +1,9 @@
+"""Task registration (legged_gym/envs/__init__.py).  `go2` keeps the reference's terrain default (trimesh curriculum,
+scope row f1/f4); `go2_flat` is the BASELINE workload: the same robot on a plane."""
+from ..utils.task_registry import task_registry
+from .base.legged_robot import LeggedRobot  # noqa: F401
+from .go2.go2_config import GO2Cfg, GO2CfgPPO, GO2FlatCfg, GO2FlatCfgPPO
+from .go2.go2_env import Go2Robot
+
+task_registry.register("go2", Go2Robot, GO2Cfg(), GO2CfgPPO())
+task_registry.register("go2_flat", Go2Robot, GO2FlatCfg(), GO2FlatCfgPPO())

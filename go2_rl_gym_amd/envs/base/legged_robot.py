@@ -1,0 +1,329 @@
+"""LeggedRobot — the reference's vectorised environment surface (legged_gym/envs/base/legged_robot.py) as a thin
+host layer over the go2sim C ABI.
+
+Everything the reference computes per env in ~300 eager torch launches per step (torque loop :73-92,
+post_physics_step :102-142 and all it calls) happens inside ONE HIP kernel launch per step
+(go2_rl_gym_amd/csrc); this class only translates the config, owns the handle, exposes the library's buffers
+under the attribute names the reference uses and keeps the Python-visible scalars
+(common_step_counter, curricula) in sync.
+"""
+import ctypes as C
+import math
+from itertools import product
+
+import numpy as np
+import torch
+
+from ... import _abi
+from ...utils.helpers import class_to_dict
+from .base_task import BaseTask, wrap_buffers
+from .legged_robot_config import LeggedRobotCfg
+
+_DOF_NAMES = [f"{l}_{j}_joint" for l in ("FL", "FR", "RL", "RR") for j in ("hip", "thigh", "calf")]
+_BODY_NAMES = ["base", "Head_upper", "Head_lower"] + [f"{l}_{p}" for l in ("FL", "FR", "RL", "RR") for p in ("hip", "thigh", "calf", "foot")]
+# reference reward-scale keys that differ from the enum spelling
+_REWARD_KEY_ALIASES = {"feet_stumble": "stumble"}
+
+
+class LeggedRobot(BaseTask):
+    def __init__(self, cfg: LeggedRobotCfg, sim_params, physics_engine, sim_device, headless, lib=None, env_offset=0, num_envs_global=None):
+        self.cfg = cfg
+        self.sim_params = sim_params
+        self.height_samples = None
+        self.debug_viz = False
+        self.init_done = False
+        self._env_offset = int(env_offset)
+        self._num_envs_global = num_envs_global
+        self._parse_cfg(self.cfg)
+        super().__init__(self.cfg, sim_params, physics_engine, sim_device, headless, lib=lib)
+        self._init_buffers()
+        self.init_done = True
+        self.num_steps_per_env = 24          # hard-coded in the reference env (:58)
+        self.reward_curriculum_configs = list(getattr(self.cfg.rewards, "curriculum_rewards", None) or [])
+
+    # ------------------------------------------------------------------ config -> Go2SimCfg
+    def _parse_cfg(self, cfg):
+        sim_dt = self.sim_params.dt if hasattr(self.sim_params, "dt") else self.sim_params["sim"]["dt"]
+        self.dt = cfg.control.decimation * sim_dt                                  # :1094
+        self.obs_scales = cfg.normalization.obs_scales
+        self.reward_scales = class_to_dict(cfg.rewards.scales)
+        self.command_ranges = class_to_dict(cfg.commands.ranges)
+        self.max_episode_length_s = cfg.env.episode_length_s
+        self.max_episode_length = np.ceil(self.max_episode_length_s / self.dt)     # :1104
+        cfg.domain_rand.push_interval = np.ceil(cfg.domain_rand.push_interval_s / self.dt)   # :1106
+        self._sim_dt = sim_dt
+
+    def _fill_cfg(self):
+        cfg, abi = self.cfg, self.abi
+        c = abi.Cfg()
+        self.lib.go2sim_default_cfg(C.byref(c))
+        N = cfg.env.num_envs
+        c.num_envs, c.env_offset = N, self._env_offset
+        c.num_envs_global = self._num_envs_global if self._num_envs_global is not None else self._env_offset + N
+        c.seed = int(getattr(cfg, "seed", 1)) & 0xFFFFFFFFFFFFFFFF
+        c.sim_dt, c.decimation = self._sim_dt, cfg.control.decimation
+        g = cfg.sim.gravity
+        for i in range(3):
+            c.gravity[i] = g[i]
+        sol = getattr(cfg.sim, "solver", None)
+        if sol is not None:
+            c.solver_iterations, c.erp, c.contact_cfm, c.joint_limit_margin = sol.iterations, sol.erp, sol.cfm, sol.joint_limit_margin
+        px = cfg.sim.physx
+        c.contact_offset, c.max_depenetration_velocity, c.bounce_threshold_velocity = px.contact_offset, px.max_depenetration_velocity, px.bounce_threshold_velocity
+        c.joint_armature = cfg.asset.armature
+        mesh = cfg.terrain.mesh_type
+        if mesh == "plane":
+            c.terrain_mode = 0
+        elif mesh in ("heightfield", "trimesh"):
+            raise NotImplementedError("terrain.mesh_type=%r: the heightfield terrain generator is the next scope row (SURVEY 8 f1); "
+                                      "use task go2_flat (mesh_type='plane')" % mesh)
+        else:
+            raise ValueError("Terrain mesh type not recognised. Allowed types are [plane, heightfield, trimesh]")
+        t = cfg.terrain
+        c.terrain_friction, c.terrain_restitution = t.static_friction, t.restitution
+        c.hf_hscale, c.hf_vscale, c.hf_border = t.horizontal_scale, t.vertical_scale, t.border_size
+        c.terrain_num_levels, c.terrain_num_types = t.num_rows, t.num_cols
+        c.terrain_curriculum, c.max_init_terrain_level = int(t.curriculum), t.max_init_terrain_level
+        c.move_down_by_accumulated_xy_command = int(t.move_down_by_accumulated_xy_command)
+        c.terrain_length, c.env_spacing, c.measure_heights = t.terrain_length, cfg.env.env_spacing, int(t.measure_heights)
+        # PD gains / default pose by substring match of the joint name (:843-859)
+        for i, name in enumerate(_DOF_NAMES):
+            c.default_dof_pos[i] = cfg.init_state.default_joint_angles[name]
+            c.kp[i] = c.kd[i] = 0.0
+            for key in cfg.control.stiffness:
+                if key in name:
+                    c.kp[i], c.kd[i] = cfg.control.stiffness[key], cfg.control.damping[key]
+        if cfg.control.control_type != "P":
+            raise NotImplementedError("only control_type 'P' (the go2 tasks) is implemented")
+        c.action_scale, c.clip_actions, c.clip_observations = cfg.control.action_scale, cfg.normalization.clip_actions, cfg.normalization.clip_observations
+        init = cfg.init_state.pos + cfg.init_state.rot + cfg.init_state.lin_vel + cfg.init_state.ang_vel      # :1000
+        for i in range(13):
+            c.base_init_state[i] = init[i]
+        if getattr(cfg.init_state, "turn_over", False):
+            raise NotImplementedError("init_state.turn_over (off in every registered task) is scope row f4")
+        d = cfg.domain_rand
+        for flag, rng, src in (("randomize_friction", "friction_range", d.friction_range), ("randomize_restitution", "restitution_range", d.restitution_range),
+                               ("randomize_base_mass", "added_mass_range", d.added_mass_range), ("randomize_link_mass", "link_mass_range", d.multiplied_link_mass_range),
+                               ("randomize_base_com", "base_com_range", d.added_base_com_range), ("randomize_motor_zero_offset", "motor_zero_offset_range", d.motor_zero_offset_range),
+                               ("randomize_motor_strength", "motor_strength_range", d.motor_strength_range)):
+            setattr(c, flag, int(getattr(d, flag)))
+            getattr(c, rng)[0], getattr(c, rng)[1] = src[0], src[1]
+        c.randomize_pd_gains = int(d.randomize_pd_gains)
+        c.stiffness_mult_range[0], c.stiffness_mult_range[1] = d.stiffness_multiplier_range
+        c.damping_mult_range[0], c.damping_mult_range[1] = d.damping_multiplier_range
+        c.push_robots, c.push_interval, c.max_push_vel_xy, c.max_push_ang_vel = int(d.push_robots), int(d.push_interval), d.max_push_vel_xy, d.max_push_ang_vel
+        c.randomize_action_delay = int(d.randomize_action_delay)
+        cm = cfg.commands
+        c.cmd_resampling_time, c.heading_command, c.dynamic_resample_commands = cm.resampling_time, int(cm.heading_command), int(cm.dynamic_resample_commands)
+        c.limit_vel_prob, c.limit_vel_invert_when_continuous, c.stop_heading_at_limit = cm.limit_vel_prob, int(cm.limit_vel_invert_when_continuous), int(cm.stop_heading_at_limit)
+        c.limit_ang_vel_at_zero_command_prob = cm.limit_ang_vel_at_zero_command_prob
+        comb = list(product(cm.limit_vel["lin_vel_x"], cm.limit_vel["lin_vel_y"], cm.limit_vel["ang_vel_yaw"]))     # :827-831
+        c.limit_vel_comb_count = len(comb)
+        for i, row in enumerate(comb):
+            for k in range(3):
+                c.limit_vel_comb[i][k] = row[k]
+        z = cm.zero_command_curriculum
+        c.zero_cmd_curriculum_enabled = int(z is not None)
+        if z is not None:
+            for k, key in enumerate(("start_iter", "end_iter", "start_value", "end_value")):
+                c.zero_cmd_curriculum[k] = z[key]
+        for r, key in enumerate(("lin_vel_x", "lin_vel_y", "ang_vel_yaw", "heading")):
+            c.cmd_ranges[r][0], c.cmd_ranges[r][1] = self.command_ranges[key]
+        cur = sorted(cm.command_range_curriculum, key=lambda x: x["iter"])
+        c.cmd_curriculum_count = len(cur)
+        for i, ent in enumerate(cur):
+            vals = [ent["iter"]] + [v for key in ("lin_vel_x", "lin_vel_y", "ang_vel_yaw", "heading") for v in ent[key]]
+            for k in range(9):
+                c.cmd_curriculum[i][k] = vals[k]
+        for kidx, ent in enumerate(cm.terrain_max_command_ranges):
+            for r, key in enumerate(("lin_vel_x", "lin_vel_y", "ang_vel_yaw", "heading")):
+                c.terrain_max_cmd_ranges[kidx][r][0], c.terrain_max_cmd_ranges[kidx][r][1] = ent[key]
+        rw = cfg.rewards
+        names = abi.reward_names
+        for i in range(len(names)):
+            c.reward_scales[i] = 0.0
+        for key, val in self.reward_scales.items():
+            k = _REWARD_KEY_ALIASES.get(key, key)
+            if val == 0:
+                continue                                                                                     # zero scales are dropped (:914-920)
+            if k not in names:
+                raise ValueError("reward %r has no kernel implementation" % key)
+            c.reward_scales[names.index(k)] = val
+        c.only_positive_rewards, c.tracking_sigma = int(rw.only_positive_rewards), rw.tracking_sigma
+        ds = rw.dynamic_sigma
+        c.dynamic_sigma_enabled = int(ds is not None)
+        if ds is not None:
+            for k, key in enumerate(("min_lin_vel", "max_lin_vel", "min_ang_vel", "max_ang_vel")):
+                c.dynamic_sigma_vel[k] = ds[key]
+            for k in range(9):
+                c.dynamic_sigma_max[k] = ds["max_sigma"][k]
+        c.soft_dof_pos_limit, c.soft_dof_vel_limit, c.soft_torque_limit = rw.soft_dof_pos_limit, rw.soft_dof_vel_limit, rw.soft_torque_limit
+        c.base_height_target, c.max_contact_force, c.min_legs_distance = rw.base_height_target, rw.max_contact_force, rw.min_legs_distance
+        cr = list(getattr(rw, "curriculum_rewards", None) or [])
+        c.reward_curriculum_count = len(cr)
+        for i, ent in enumerate(cr):
+            c.reward_curriculum_term[i] = names.index(ent["reward_name"])
+            for k, key in enumerate(("start_iter", "end_iter", "start_value", "end_value")):
+                c.reward_curriculum[i][k] = ent[key]
+        o = cfg.normalization.obs_scales
+        c.obs_scale_lin_vel, c.obs_scale_ang_vel, c.obs_scale_dof_pos, c.obs_scale_dof_vel, c.obs_scale_height = o.lin_vel, o.ang_vel, o.dof_pos, o.dof_vel, o.height_measurements
+        n = cfg.noise
+        c.add_noise, c.noise_level = int(n.add_noise), n.noise_level
+        ns = n.noise_scales
+        c.noise_dof_pos, c.noise_dof_vel, c.noise_lin_vel, c.noise_ang_vel, c.noise_gravity, c.noise_height = ns.dof_pos, ns.dof_vel, ns.lin_vel, ns.ang_vel, ns.gravity, ns.height_measurements
+        c.episode_length_s, c.send_timeouts, c.num_steps_per_env = cfg.env.episode_length_s, int(cfg.env.send_timeouts), 24
+        return c
+
+    def create_sim(self):
+        """Creates the simulator handle (the reference's create_sim/_create_envs, :292-310,952-1052)."""
+        self._c = self._fill_cfg()
+        dev_id = 0
+        if self.lib.go2sim_is_device_library() == 1:
+            dev_id = torch.device(self.device).index or 0
+        h = C.c_void_p()
+        _abi.check(self.lib, self.lib.go2sim_create(C.byref(self._c), dev_id, C.byref(h)), "go2sim_create")
+        self.handle = h
+        self.num_dof = self.num_dofs = 12
+        self.num_bodies = 19
+        self.dof_names = list(_DOF_NAMES)
+        self.body_names = list(_BODY_NAMES)
+
+    # ------------------------------------------------------------------ buffers
+    def _init_buffers(self):
+        dev = self.device
+        b = wrap_buffers(self.lib, self.handle, self.num_envs, dev)
+        self._buf = b
+        # the four Isaac Gym tensors and their views (:779-787)
+        self.root_states, self.dof_state = b["root_states"], b["dof_state"]
+        self.dof_pos, self.dof_vel = self.dof_state[..., 0], self.dof_state[..., 1]
+        self.base_quat, self.base_pos = self.root_states[:, 3:7], self.root_states[:, 0:3]
+        self.contact_forces, self.rigid_body_states = b["contact_forces"], b["rigid_body_states"]
+        # VecEnv buffers (base_task.py:41-49)
+        self.obs_buf, self.privileged_obs_buf, self.rew_buf = b["obs_buf"], b["privileged_obs_buf"], b["rew_buf"]
+        if self.num_privileged_obs is None:
+            self.privileged_obs_buf = None
+        self.reset_buf, self.time_out_buf = b["reset_buf"].view(torch.bool), b["time_out_buf"].view(torch.bool)
+        self._episode_length_buf = b["episode_length_buf"]
+        for src, dst in (("torques", "torques"), ("actions", "actions"), ("last_actions", "last_actions"), ("last_last_actions", "last_last_actions"),
+                         ("last_dof_vel", "last_dof_vel"), ("last_root_vel", "last_root_vel"), ("commands", "commands"),
+                         ("commands_resampling_step", "commands_resampling_step"), ("commands_xy_accumulation", "commands_xy_accumulation"),
+                         ("base_lin_vel", "base_lin_vel"), ("base_ang_vel", "base_ang_vel"), ("projected_gravity", "projected_gravity"), ("rpy", "rpy"),
+                         ("measured_heights", "measured_heights"), ("max_move_distance", "max_move_distance"), ("feet_air_time", "feet_air_time"),
+                         ("motor_strengths", "motor_strengths"), ("motor_zero_offsets", "motor_zero_offsets"), ("p_gains_multiplier", "p_gains_multiplier"),
+                         ("d_gains_multiplier", "d_gains_multiplier"), ("env_origins", "env_origins"), ("terrain_levels", "terrain_levels"),
+                         ("terrain_types", "terrain_types"), ("friction_coeffs", "friction_coeffs")):
+            setattr(self, dst, b[src])
+        self.stop_heading, self.last_is_limit_vel = b["stop_heading"].view(torch.bool), b["last_is_limit_vel"].view(torch.bool)
+        self.last_contacts = b["last_contacts"].view(torch.bool)
+        names = self.abi.reward_names
+        active = [i for i in range(len(names)) if self._c.reward_scales[i] != 0]
+        self.reward_names = [names[i] for i in active if names[i] != "termination"]
+        self.episode_sums = {names[i]: b["episode_sums"][i] for i in active}
+        self.reward_scales = {names[i]: self._c.reward_scales[i] * self.dt for i in active}
+        # extras["episode"]: 0-d views of a per-step snapshot ring of the library's episode_info vector
+        self._episode_info = b["episode_info"]
+        self._info_ring = torch.zeros(32, self._episode_info.shape[0], device=dev)
+        self._info_slot = 0
+        self._active_idx = active
+        self.extras = {}
+        f32 = dict(dtype=torch.float, device=dev)
+        self.p_gains = torch.tensor([self._c.kp[i] for i in range(12)], **f32)
+        self.d_gains = torch.tensor([self._c.kd[i] for i in range(12)], **f32)
+        self.default_dof_pos = torch.tensor([self._c.default_dof_pos[i] for i in range(12)], **f32).unsqueeze(0)
+        lo = torch.tensor([-1.0472, -1.5708, -2.7227] * 2 + [-1.0472, -0.5236, -2.7227] * 2, **f32)
+        hi = torch.tensor([1.0472, 3.4907, -0.83776] * 2 + [1.0472, 4.5379, -0.83776] * 2, **f32)
+        m, r = (lo + hi) / 2, hi - lo                                                # soft limits (:372-375)
+        self.dof_pos_limits = torch.stack([m - 0.5 * r * self.cfg.rewards.soft_dof_pos_limit, m + 0.5 * r * self.cfg.rewards.soft_dof_pos_limit], dim=1)
+        self.torque_limits = torch.tensor([23.7, 23.7, 35.55] * 4, **f32)
+        self.dof_vel_limits = torch.tensor([30.1, 30.1, 20.07] * 4, **f32)
+        self.feet_indices = torch.tensor([6, 10, 14, 18], dtype=torch.long, device=dev)
+        self.penalised_contact_indices = torch.tensor([4, 5, 8, 9, 12, 13, 16, 17], dtype=torch.long, device=dev)
+        self.termination_contact_indices = torch.tensor([0], dtype=torch.long, device=dev)
+        self.commands_scale = torch.tensor([self.obs_scales.lin_vel, self.obs_scales.lin_vel, self.obs_scales.ang_vel], **f32)
+        self.gravity_vec = torch.tensor([0.0, 0.0, -1.0], **f32).repeat(self.num_envs, 1)
+        self.custom_origins = self.cfg.terrain.mesh_type in ("heightfield", "trimesh")
+        self.add_noise = self.cfg.noise.add_noise
+
+    # the runner REPLACES this attribute (on_policy_runner.py:118): copy into the library's buffer instead
+    @property
+    def episode_length_buf(self):
+        return self._episode_length_buf
+
+    @episode_length_buf.setter
+    def episode_length_buf(self, value):
+        self._episode_length_buf.copy_(value)
+
+    @property
+    def common_step_counter(self):
+        return int(self.lib.go2sim_get_common_step_counter(self.handle))
+
+    @common_step_counter.setter
+    def common_step_counter(self, value):                       # train.py:14
+        _abi.check(self.lib, self.lib.go2sim_set_common_step_counter(self.handle, int(value)), "set_common_step_counter")
+
+    def update_reward_curriculum(self, force_update: bool = False):   # :144-152
+        _abi.check(self.lib, self.lib.go2sim_update_reward_curriculum(self.handle, int(force_update)), "update_reward_curriculum")
+
+    def _curriculum_state(self):
+        R = self.abi.real
+        rcs = (R * self.abi.GO2_NUM_REWARDS)()
+        cr = (R * 8)()
+        zp = R()
+        self.lib.go2sim_get_curriculum_state(self.handle, rcs, cr, C.byref(zp))
+        return list(rcs), [[cr[2 * i], cr[2 * i + 1]] for i in range(4)], zp.value
+
+    @property
+    def reward_curriculum_scales(self):
+        rcs, _, _ = self._curriculum_state()
+        return {c["reward_name"]: rcs[self.abi.reward_names.index(c["reward_name"])] for c in self.reward_curriculum_configs}
+
+    @property
+    def zero_command_proba(self):
+        return self._curriculum_state()[2]
+
+    # ------------------------------------------------------------------ the hot path
+    def step(self, actions):
+        """LeggedRobot.step (:60-100): one library call = one fused kernel launch."""
+        a = actions
+        if a.dtype != torch.float32 or not a.is_contiguous() or str(a.device) != str(self.obs_buf.device):
+            a = a.to(device=self.obs_buf.device, dtype=torch.float32).contiguous()
+        _abi.check(self.lib, self.lib.go2sim_step(self.handle, C.c_void_p(a.data_ptr()), self._stream()), "go2sim_step")
+        self._publish_extras()
+        return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def reset_idx(self, env_ids):
+        """Only the all-envs form is exposed (base_task.py:82-84 is the reference's sole external caller); per-env resets
+        happen inside the step kernel exactly where post_physics_step does them (:132-133)."""
+        if len(env_ids) == 0:
+            return
+        if len(env_ids) != self.num_envs:
+            raise NotImplementedError("reset_idx(subset) from Python: resets are fused into the step kernel")
+        _abi.check(self.lib, self.lib.go2sim_reset_all(self.handle, self._stream()), "go2sim_reset_all")
+        self._publish_extras()
+
+    def _publish_extras(self):
+        """extras['episode'] / extras['time_outs'] (:229-245) without a host sync: the kernel keeps the means of the
+        latest step that reset >= 1 env; each step snapshots them into a ring slot so earlier dicts stay intact."""
+        slot = self._info_ring[self._info_slot]
+        slot.copy_(self._episode_info)
+        self._info_slot = (self._info_slot + 1) % self._info_ring.shape[0]
+        names = self.abi.reward_names
+        ep = {"terrain_level_all": 0.0}
+        for i in self._active_idx:
+            ep["rew_" + names[i]] = slot[i]
+        if self.cfg.commands.curriculum:
+            ep["max_command_x"] = self.command_ranges["lin_vel_x"][1]
+        self.extras["episode"] = ep
+        if self.cfg.env.send_timeouts:
+            self.extras["time_outs"] = self.time_out_buf
+
+    def post_physics_step(self):
+        """For harnesses that drive the four simulator tensors themselves (the golden-vector tests)."""
+        _abi.check(self.lib, self.lib.go2sim_post_physics(self.handle, self._stream()), "go2sim_post_physics")
+        self._publish_extras()
+
+    def get_current_scale(self, config):                        # :154-168
+        it = self.common_step_counter // self.num_steps_per_env
+        pct = (it - config["start_iter"]) / (config["end_iter"] - config["start_iter"])
+        pct = max(min(pct, 1.0), 0.0)
+        return (1.0 - pct) * config["start_value"] + pct * config["end_value"]

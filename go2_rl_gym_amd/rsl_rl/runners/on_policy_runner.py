@@ -1,0 +1,208 @@
+"""OnPolicyRunner with the reference's interface and semantics (rsl_rl/rsl_rl/runners/on_policy_runner.py:60-309):
+24-step rollout -> GAE + advantage normalisation -> 5 epochs x 4 mini-batches of PPO; same checkpoint keys, same
+console / scalar names, fps = num_steps_per_env * num_envs / (collection_time + learn_time) (:194).
+
+Differences that do not change results: the per-step `.cpu()` bookkeeping of the reference (:143-153, a host sync every
+env step) is replaced by device-side buffers read once per iteration; RoboGauge (:103-111,252-295, an external HTTP
+service) is out of scope; with torch.distributed initialised only rank 0 logs and saves.
+"""
+import os
+import statistics
+import time
+from collections import deque
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import yaml
+
+from ...utils.helpers import class_to_dict
+from ..algorithms import PPO
+from ..modules import ActorCritic
+
+_POLICIES = {"ActorCritic": ActorCritic}
+_ALGS = {"PPO": PPO}
+
+for _t, _f in ((np.float32, float), (np.float64, float), (np.int32, int), (np.int64, int)):
+    yaml.add_representer(_t, (lambda f: (lambda dumper, data: dumper.represent_float(float(data)) if f is float else dumper.represent_int(int(data))))(_f), Dumper=yaml.SafeDumper)
+
+
+def _rank():
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
+def _world():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+class _NullWriter:
+    def add_scalar(self, *a, **k):
+        pass
+
+
+def _make_writer(log_dir):
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+        return SummaryWriter(log_dir=log_dir, flush_secs=10)
+    except Exception:
+        return _NullWriter()
+
+
+class OnPolicyRunner:
+    def __init__(self, env, train_cfg, log_dir=None, device="cpu"):
+        self.cfg = train_cfg["runner"]
+        self.alg_cfg = train_cfg["algorithm"]
+        self.policy_cfg = train_cfg["policy"]
+        self.device = device
+        self.env = env
+        num_critic_obs = self.env.num_privileged_obs if self.env.num_privileged_obs is not None else self.env.num_obs
+        actor_critic = _POLICIES[self.cfg["policy_class_name"]](self.env.num_obs, num_critic_obs, self.env.num_actions, **self.policy_cfg).to(self.device)
+        self.alg = _ALGS[self.cfg["algorithm_class_name"]](actor_critic, device=self.device, lib=getattr(env, "lib", None), **self.alg_cfg)
+        self.num_steps_per_env = self.cfg["num_steps_per_env"]
+        self.save_interval = self.cfg["save_interval"]
+        self.alg.init_storage(self.env.num_envs, self.num_steps_per_env, [self.env.num_obs], [self.env.num_privileged_obs], [self.env.num_actions])
+        self.log_dir = log_dir if _rank() == 0 else None
+        self.writer = None
+        self.tot_timesteps = 0
+        self.tot_time = 0
+        self.current_learning_iteration = 0
+        self.last_fps = None
+        self.last_collection_time = self.last_learn_time = None
+        _, _ = self.env.reset()
+        if self.log_dir is not None and self.env.cfg.env.test is False:
+            Path(self.log_dir).mkdir(parents=True, exist_ok=True)
+            all_cfg = {"train_cfg": train_cfg, "env_cfg": class_to_dict(self.env.cfg)}
+            yaml.safe_dump(all_cfg, open(os.path.join(self.log_dir, "config.yaml"), "w"))
+
+    def _sync(self):
+        if str(self.device).startswith("cuda"):
+            torch.cuda.synchronize(self.device)
+
+    def learn(self, num_learning_iterations, init_at_random_ep_len=False):
+        if self.log_dir is not None and self.writer is None:
+            self.writer = _make_writer(self.log_dir)
+        if init_at_random_ep_len:
+            self.env.episode_length_buf = torch.randint_like(self.env.episode_length_buf, high=int(self.env.max_episode_length))
+        obs = self.env.get_observations()
+        privileged_obs = self.env.get_privileged_observations()
+        critic_obs = privileged_obs if privileged_obs is not None else obs
+        obs, critic_obs = obs.to(self.device), critic_obs.to(self.device)
+        self.alg.actor_critic.train()
+        ep_infos = []
+        rewbuffer, lenbuffer = deque(maxlen=100), deque(maxlen=100)
+        N, T = self.env.num_envs, self.num_steps_per_env
+        cur_reward_sum = torch.zeros(N, dtype=torch.float, device=self.device)
+        cur_episode_length = torch.zeros(N, dtype=torch.float, device=self.device)
+        fin_rew = torch.zeros(T, N, device=self.device)
+        fin_len = torch.zeros(T, N, device=self.device)
+        fin_mask = torch.zeros(T, N, dtype=torch.bool, device=self.device)
+        tot_iter = self.current_learning_iteration + num_learning_iterations
+        it = self.current_learning_iteration
+        for it in range(self.current_learning_iteration, tot_iter):
+            self._sync()
+            start = time.time()
+            with torch.inference_mode():
+                for i in range(T):
+                    actions = self.alg.act(obs, critic_obs)
+                    obs, privileged_obs, rewards, dones, infos = self.env.step(actions)
+                    critic_obs = privileged_obs if privileged_obs is not None else obs
+                    obs, critic_obs, rewards, dones = obs.to(self.device), critic_obs.to(self.device), rewards.to(self.device), dones.to(self.device)
+                    self.alg.process_env_step(rewards, dones, infos)
+                    if self.log_dir is not None:
+                        if "episode" in infos:
+                            ep_infos.append(infos["episode"])
+                        cur_reward_sum += rewards
+                        cur_episode_length += 1
+                        fin_mask[i] = dones
+                        fin_rew[i] = cur_reward_sum
+                        fin_len[i] = cur_episode_length
+                        keep = (~dones).float()
+                        cur_reward_sum *= keep
+                        cur_episode_length *= keep
+                self._sync()
+                stop = time.time()
+                collection_time = stop - start
+                start = stop
+                self.alg.compute_returns(critic_obs)
+            mean_value_loss, mean_surrogate_loss = self.alg.update()
+            self._sync()
+            stop = time.time()
+            learn_time = stop - start
+            if self.log_dir is not None:
+                m = fin_mask.cpu().numpy()   # one device->host read per iteration, same deque order as the reference (step-major)
+                rewbuffer.extend(fin_rew.cpu().numpy()[m].tolist())
+                lenbuffer.extend(fin_len.cpu().numpy()[m].tolist())
+                self.log(locals())
+            self.last_collection_time, self.last_learn_time = collection_time, learn_time
+            self.last_fps = T * N * _world() / (collection_time + learn_time)
+            if self.log_dir is not None and it % self.save_interval == 0:
+                self.save(os.path.join(self.log_dir, "model_{}.pt".format(it)), it, False)
+            ep_infos.clear()
+        self.current_learning_iteration += num_learning_iterations
+        if self.log_dir is not None:
+            self.save(os.path.join(self.log_dir, "model_{}.pt".format(self.current_learning_iteration)), it, True)
+
+    def log(self, locs, width=80, pad=35):
+        self.tot_timesteps += self.num_steps_per_env * self.env.num_envs
+        self.tot_time += locs["collection_time"] + locs["learn_time"]
+        iteration_time = locs["collection_time"] + locs["learn_time"]
+        ep_string = ""
+        if locs["ep_infos"]:
+            for key in locs["ep_infos"][0]:
+                vals = []
+                for ep_info in locs["ep_infos"]:
+                    v = ep_info[key]
+                    v = torch.as_tensor(v, dtype=torch.float, device=self.device).reshape(-1)
+                    vals.append(v)
+                value = torch.mean(torch.cat(vals))
+                self.writer.add_scalar("Episode/" + key, value, locs["it"])
+                ep_string += f"""{f'Mean episode {key}:':>{pad}} {value:.4f}\n"""
+        mean_std = self.alg.actor_critic.std.mean()
+        fps = int(self.num_steps_per_env * self.env.num_envs / (locs["collection_time"] + locs["learn_time"]))
+        w = self.writer
+        w.add_scalar("Loss/value_function", locs["mean_value_loss"], locs["it"])
+        w.add_scalar("Loss/surrogate", locs["mean_surrogate_loss"], locs["it"])
+        w.add_scalar("Loss/learning_rate", self.alg.learning_rate, locs["it"])
+        w.add_scalar("Policy/mean_noise_std", mean_std.item(), locs["it"])
+        w.add_scalar("Perf/total_fps", fps, locs["it"])
+        w.add_scalar("Perf/collection time", locs["collection_time"], locs["it"])
+        w.add_scalar("Perf/learning_time", locs["learn_time"], locs["it"])
+        have = len(locs["rewbuffer"]) > 0
+        if have:
+            w.add_scalar("Train/mean_reward", statistics.mean(locs["rewbuffer"]), locs["it"])
+            w.add_scalar("Train/mean_episode_length", statistics.mean(locs["lenbuffer"]), locs["it"])
+            w.add_scalar("Train/mean_reward/time", statistics.mean(locs["rewbuffer"]), self.tot_time)
+            w.add_scalar("Train/mean_episode_length/time", statistics.mean(locs["lenbuffer"]), self.tot_time)
+        head = f" \033[1m Learning iteration {locs['it']}/{self.current_learning_iteration + locs['num_learning_iterations']} \033[0m "
+        s = (f"""{'#' * width}\n{head.center(width, ' ')}\n\n"""
+             f"""{'Computation:':>{pad}} {fps:.0f} steps/s (collection: {locs['collection_time']:.3f}s, learning {locs['learn_time']:.3f}s)\n"""
+             f"""{'Value function loss:':>{pad}} {locs['mean_value_loss']:.4f}\n"""
+             f"""{'Surrogate loss:':>{pad}} {locs['mean_surrogate_loss']:.4f}\n"""
+             f"""{'Mean action noise std:':>{pad}} {mean_std.item():.2f}\n""")
+        if have:
+            s += (f"""{'Mean reward:':>{pad}} {statistics.mean(locs['rewbuffer']):.2f}\n"""
+                  f"""{'Mean episode length:':>{pad}} {statistics.mean(locs['lenbuffer']):.2f}\n""")
+        s += ep_string
+        s += (f"""{'-' * width}\n{'Total timesteps:':>{pad}} {self.tot_timesteps}\n{'Iteration time:':>{pad}} {iteration_time:.2f}s\n"""
+              f"""{'Total time:':>{pad}} {self.tot_time:.2f}s\n"""
+              f"""{'ETA:':>{pad}} {self.tot_time / (locs['it'] + 1) * (locs['num_learning_iterations'] - locs['it']):.1f}s\n""")
+        print(s)
+
+    def save(self, path, it=None, last_model=False, infos=None):
+        torch.save({"model_state_dict": self.alg.actor_critic.state_dict(), "optimizer_state_dict": self.alg.optimizer.state_dict(),
+                    "iter": self.current_learning_iteration, "infos": infos}, path)
+
+    def load(self, path, load_optimizer=True):
+        d = torch.load(path, map_location=self.device)
+        self.alg.actor_critic.load_state_dict(d["model_state_dict"])
+        if load_optimizer:
+            self.alg.optimizer.load_state_dict(d["optimizer_state_dict"])
+        self.current_learning_iteration = d["iter"]
+        return d["infos"]
+
+    def get_inference_policy(self, device=None):
+        self.alg.actor_critic.eval()
+        if device is not None:
+            self.alg.actor_critic.to(device)
+        return self.alg.actor_critic.act_inference

@@ -263,6 +263,12 @@ typedef struct Go2Sim Go2Sim;
 
 /* 1 if this library computes on the GPU (product), 0 if it is the CPU oracle. */
 int go2sim_is_device_library(void);
+/* Memory layout of the per-env buffers of Go2SimBuffers: 0 = row-major as documented (oracle);
+ * 1 = field-major / SoA (HIP library): logical [N,a,b] is stored in C order of the REVERSED dims, element
+ * (e,i,j) at ((j*a + i)*N + e), so consecutive envs are consecutive addresses.  In both layouts
+ * obs_buf [N,45], privileged_obs_buf [N,263] (the policy's GEMM inputs) and episode_sums [R,N] are
+ * row-major exactly as documented. */
+int go2sim_buffer_layout(void);
 const char* go2sim_last_error(void);
 /* Fill `cfg` with the task=go2 defaults (go2_config.py + legged_robot_config.py); plane terrain. */
 void go2sim_default_cfg(Go2SimCfg* cfg);
@@ -303,6 +309,13 @@ int  go2sim_get_curriculum_state(Go2Sim* h, float reward_curriculum_scale[GO2_NU
 int  go2sim_inject_uniforms(Go2Sim* h, const float* uniforms, void* stream);
 /* Copy the Philox uniforms the next step would use into `out` [N][GO2_NUM_UNIFORMS]. */
 int  go2sim_peek_uniforms(Go2Sim* h, float* out, void* stream);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+/* While enabled, every go2sim_step / go2sim_simulate brackets its main kernel with events ON THE STREAM IT
+ * IS LAUNCHED ON; go2sim_kernel_time synchronises, returns the summed kernel time [ms] and the number of
+ * launches since the last call, and resets both.  (The oracle reports host wall-clock.) */
+int  go2sim_enable_timing(Go2Sim* h, int enable);
+int  go2sim_kernel_time(Go2Sim* h, double* total_ms, int64_t* launches);
 
 /* ---- PPO rollout kernels ---------------------------------------------------------------------- */
 /* RolloutStorage.compute_returns (rollout_storage.py:123-137) for a [T,N] rollout:

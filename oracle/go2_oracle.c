@@ -230,6 +230,7 @@ struct Go2Sim {
   R height_pts[GO2_NUM_HEIGHT_POINTS][2];
   /* episode info accumulators */
   double ep_sum[GO2_NUM_REWARDS]; int ep_count;
+  int timing; double time_ms; int64_t time_launches;
 };
 
 /* ---------------- per-env inertial model (legged_robot.py:379-402 + recomputeInertia=True) ------ */
@@ -884,6 +885,7 @@ static void finish_episode_info(Go2Sim* s) { /* extras["episode"] (:229-242) */
  * ABI
  * ---------------------------------------------------------------------------------------------- */
 int go2sim_is_device_library(void) { return 0; }
+int go2sim_buffer_layout(void) { return 0; }
 const char* go2sim_last_error(void) { return g_err; }
 void go2sim_default_cfg(Go2SimCfg* cfg) { go2sim_fill_default_cfg(cfg); }
 
@@ -997,12 +999,18 @@ static void simulate_env(Go2Sim* s, int e) {
   write_body_states(s,e,&k);
 }
 
+#include <time.h>
+static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec*1e3 + t.tv_nsec*1e-6; }
 int go2sim_simulate(Go2Sim* s, void* stream) {
   (void)stream; if (!s) return GO2SIM_EINVAL;
+  double t0 = now_ms();
   #pragma omp parallel for schedule(static)
   for (int e=0;e<s->N;++e) simulate_env(s,e);
+  if (s->timing) { s->time_ms += now_ms()-t0; s->time_launches++; }
   return 0;
 }
+int go2sim_enable_timing(Go2Sim* s, int en) { if (!s) return GO2SIM_EINVAL; s->timing=en; s->time_ms=0; s->time_launches=0; return 0; }
+int go2sim_kernel_time(Go2Sim* s, double* ms, int64_t* n) { if (!s||!ms||!n) return GO2SIM_EINVAL; *ms=s->time_ms; *n=s->time_launches; s->time_ms=0; s->time_launches=0; return 0; }
 int go2sim_post_physics(Go2Sim* s, void* stream) {
   (void)stream; if (!s) return GO2SIM_EINVAL;
   s->common_step_counter += 1;            /* :112 */

@@ -18,6 +18,23 @@ def build_oracle():
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
 
 
+def build_emu():
+    out = os.path.join(ROOT, "tests", "emu", "libgo2sim_emu.so")
+    src = os.path.join(ROOT, "go2_rl_gym_amd", "csrc")
+    deps = [os.path.join(src, f) for f in os.listdir(src)] + [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-DGO2_EMU", "-w", "-o", out, os.path.join(src, "go2sim_impl.cpp")], check=True)
+    return out
+
+
+def load_emu():
+    """Host emulation of the HIP lane programs (TEST ONLY: same source as the kernels, compiled by g++)."""
+    lib = _abi.bind(build_emu(), C.c_float)
+    assert lib.go2sim_is_device_library() == 0 and lib.go2sim_buffer_layout() == 1
+    return lib
+
+
 def load_oracle(f64=False):
     path = os.path.join(ROOT, "oracle", "libgo2oracle_f64.so" if f64 else "libgo2oracle_f32.so")
     if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(ROOT, "oracle", "go2_oracle.c")):
@@ -50,10 +67,15 @@ class HostSim:
         b = self.abi.Buffers()
         _abi.check(lib, lib.go2sim_get_buffers(h, C.byref(b)), "go2sim_get_buffers")
         shapes = _abi.buffer_shapes(self.abi, self.N)
+        self.layout = lib.go2sim_buffer_layout()
         self.buf = {}
         for name, ctype in self.abi.buffer_fields:
             ptr = getattr(b, name)
-            arr = np.ctypeslib.as_array(ptr, shape=shapes[name])
+            shp = shapes[name]
+            if self.layout == 1 and name not in _abi.ROW_MAJOR_ALWAYS and len(shp) > 1:
+                arr = np.ctypeslib.as_array(ptr, shape=tuple(reversed(shp))).transpose()   # field-major storage, logical view
+            else:
+                arr = np.ctypeslib.as_array(ptr, shape=shp)
             self.buf[name] = arr
             setattr(self, name, arr)
 
@@ -107,3 +129,107 @@ class HostSim:
         a1 = np.zeros(18, self.real); a2 = np.zeros(18, self.real); M = np.zeros((18, 18), self.real); en = np.zeros(6, self.real)
         self.lib.go2o_debug_dynamics(self.h, e, tau.ctypes.data, a1.ctypes.data, a2.ctypes.data, M.ctypes.data, en.ctypes.data)
         return a1, a2, M, en
+
+
+# ---- device-memory libraries (the HIP product) -------------------------------------------------------------
+class _Proxy:
+    """numpy-flavoured access to a torch tensor living in device memory, so the golden/parity tests written for
+    HostSim run unchanged on the GPU: `sim.root_states[:] = ndarray`, `np.asarray(sim.obs_buf)`, slicing -> ndarray."""
+
+    def __init__(self, t):
+        self.t = t
+
+    def __setitem__(self, idx, val):
+        import torch
+        self.t[idx] = torch.as_tensor(np.asarray(val), device=self.t.device).to(self.t.dtype)
+
+    def __getitem__(self, idx):
+        return self.t[idx].cpu().numpy()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.t.cpu().numpy()
+        return a.astype(dtype) if dtype is not None else a
+
+    def any(self):
+        return bool(self.t.any().item())
+
+    def sum(self, *a, **k):
+        return self.__array__().sum(*a, **k)
+
+    @property
+    def shape(self):
+        return tuple(self.t.shape)
+
+
+class DeviceSim:
+    """Same interface as HostSim for a device-memory library (go2_rl_gym_amd/libgo2sim_hip.so)."""
+
+    def __init__(self, lib, device="cuda:0", **overrides):
+        import torch
+        from go2_rl_gym_amd.envs.base.base_task import wrap_buffers
+        self.lib, self.abi, self.device = lib, lib.abi, device
+        self.real = np.float32
+        cfg = self.abi.Cfg()
+        lib.go2sim_default_cfg(C.byref(cfg))
+        self._keep = []
+        for k, v in overrides.items():
+            HostSim.set_cfg(self, cfg, k, v)
+        if "num_envs_global" not in overrides:
+            cfg.num_envs_global = cfg.env_offset + cfg.num_envs
+        self.cfg = cfg
+        h = C.c_void_p()
+        _abi.check(lib, lib.go2sim_create(C.byref(cfg), torch.device(device).index or 0, C.byref(h)), "go2sim_create")
+        self.h, self.N = h, cfg.num_envs
+        self.t = wrap_buffers(lib, h, self.N, device)
+        self.buf = {k: _Proxy(v) for k, v in self.t.items()}
+        for k, v in self.buf.items():
+            setattr(self, k, v)
+        self.torch = torch
+
+    def _st(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if self.h:
+            self.torch.cuda.synchronize()
+            self.lib.go2sim_destroy(self.h)
+            self.h = None
+
+    __del__ = HostSim.__del__
+
+    def reset_all(self):
+        _abi.check(self.lib, self.lib.go2sim_reset_all(self.h, self._st()), "reset_all")
+
+    def step(self, actions):
+        a = self.torch.as_tensor(np.ascontiguousarray(actions, dtype=np.float32), device=self.device)
+        _abi.check(self.lib, self.lib.go2sim_step(self.h, C.c_void_p(a.data_ptr()), self._st()), "step")
+        self.torch.cuda.synchronize()
+
+    def simulate(self):
+        _abi.check(self.lib, self.lib.go2sim_simulate(self.h, self._st()), "simulate")
+
+    def post_physics(self):
+        _abi.check(self.lib, self.lib.go2sim_post_physics(self.h, self._st()), "post_physics")
+
+    def inject(self, u):
+        u = self.torch.as_tensor(np.ascontiguousarray(u, dtype=np.float32), device=self.device)
+        assert tuple(u.shape) == (self.N, self.abi.GO2_NUM_UNIFORMS)
+        _abi.check(self.lib, self.lib.go2sim_inject_uniforms(self.h, C.c_void_p(u.data_ptr()), self._st()), "inject")
+        self.torch.cuda.synchronize()
+
+    def peek(self):
+        out = self.torch.zeros(self.N, self.abi.GO2_NUM_UNIFORMS, device=self.device)
+        _abi.check(self.lib, self.lib.go2sim_peek_uniforms(self.h, C.c_void_p(out.data_ptr()), self._st()), "peek")
+        return out.cpu().numpy()
+
+
+def load_hip():
+    from go2_rl_gym_amd import _lib
+    return _lib.load_hip()
+
+
+# state that fully determines the next step (copied oracle -> device before a one-step comparison)
+STEP_STATE = ["root_states", "dof_state", "last_actions", "last_last_actions", "last_dof_vel", "commands", "commands_resampling_step",
+              "commands_xy_accumulation", "episode_length_buf", "motor_strengths", "motor_zero_offsets", "p_gains_multiplier", "d_gains_multiplier",
+              "foot_impulse", "last_is_limit_vel", "max_move_distance", "episode_sums", "feet_air_time", "last_contacts", "last_contacts2",
+              "friction_coeffs", "restitution_coeffs", "added_base_mass", "added_base_com", "link_mass_ratio", "env_origins"]

@@ -1,0 +1,69 @@
+"""The HIP lane programs (go2_rl_gym_amd/csrc/go2_lane.h, go2_post.h), compiled for the host, against the oracle.
+
+CPU only.  The two sides derive the same physical model differently (oracle: Featherstone ABA in link coordinates +
+dense CRBA/Cholesky contact problem; lanes: single-frame spatial algebra, per-leg 3x3 block elimination onto the base,
+operational-space rows from Ainv / N / Phi), so agreement to fp32 round-off checks both.
+"""
+import numpy as np
+import pytest
+
+from helpers import STEP_STATE, HostSim, load_emu, load_oracle
+
+N = 48
+
+
+def _pair(**kw):
+    return HostSim(load_oracle(), num_envs=N, **kw), HostSim(load_emu(), num_envs=N, **kw)
+
+
+def test_creation_and_reset_identical():
+    so, se = _pair()
+    for k in ("friction_coeffs", "restitution_coeffs", "added_base_mass", "added_base_com", "link_mass_ratio", "env_origins"):
+        np.testing.assert_array_equal(np.asarray(getattr(so, k)), np.asarray(getattr(se, k)), err_msg=k)
+    np.testing.assert_array_equal(so.peek(), se.peek())      # same Philox stream
+    so.reset_all(); se.reset_all()
+    for k in ("root_states", "dof_state", "commands", "motor_strengths", "motor_zero_offsets", "p_gains_multiplier", "d_gains_multiplier"):
+        np.testing.assert_allclose(np.asarray(getattr(so, k)), np.asarray(getattr(se, k)), atol=1e-6, err_msg=k)
+
+
+def test_one_step_parity_through_landing_and_stance():
+    """120 steps of random actions; before every step the emulation is synced to the oracle's state, so each comparison
+    is ONE step (4 substeps incl. contact solve + post-physics) from identical inputs."""
+    so, se = _pair()
+    so.reset_all(); se.reset_all()
+    rng = np.random.default_rng(0)
+    worst = {}
+    contact_seen = 0
+    for it in range(120):
+        a = rng.normal(0, 1, (N, 12)).astype(np.float32)
+        for k in STEP_STATE:
+            getattr(se, k)[...] = getattr(so, k)
+        so.step(a); se.step(a)
+        contact_seen += int((so.contact_forces[:, [6, 10, 14, 18], 2] > 1).sum())
+        for k, tol in (("root_states", 2e-4), ("dof_state", 2e-3), ("torques", 2e-3), ("obs_buf", 2e-4), ("privileged_obs_buf", 2e-4), ("rew_buf", 5e-6)):
+            d = np.sort(np.abs(np.asarray(getattr(so, k), np.float64) - np.asarray(getattr(se, k), np.float64)).reshape(N, -1).max(1))
+            worst[k] = max(worst.get(k, 0.0), d[-2])
+            # all envs but at most one within tol; an env sitting exactly on a contact-activation / friction-cone
+            # boundary may take the other branch in fp32 and is allowed a larger (still small) difference
+            assert d[-2] < tol and d[-1] < 50 * tol, (k, it, d[-3:])
+        # forces are impulse / 0.005 s: fp32 noise is amplified 200x, compare relative to the force scale
+        fo, fe = np.asarray(so.contact_forces, np.float64), np.asarray(se.contact_forces, np.float64)
+        de = np.abs(fo - fe).reshape(N, -1).max(1)
+        assert np.median(de) < 5e-3, (it, np.median(de))
+        # an env sitting exactly on a friction-cone / contact-activation boundary may take the other branch
+        assert (de > 1e-3 * max(1.0, np.abs(fo).max()) + 5e-2).sum() <= 1, (it, np.sort(de)[-3:])
+        np.testing.assert_array_equal(np.asarray(so.reset_buf), np.asarray(se.reset_buf))
+    assert contact_seen > 1000          # the robots did land and stand
+    print("worst one-step differences:", worst)
+
+
+def test_free_trajectory_stays_statistically_close():
+    """Without re-syncing, fp32 round-off grows chaotically once contacts switch; the ensembles must still agree."""
+    so, se = _pair(push_robots=0)
+    so.reset_all(); se.reset_all()
+    a = np.zeros((N, 12), np.float32)
+    for _ in range(100):
+        so.step(a); se.step(a)
+    zo, ze = np.asarray(so.root_states)[:, 2], np.asarray(se.root_states)[:, 2]
+    assert abs(zo.mean() - ze.mean()) < 0.01 and 0.15 < ze.mean() < 0.40
+    assert abs(np.asarray(so.rew_buf).mean() - np.asarray(se.rew_buf).mean()) < 5e-3

@@ -41,8 +41,9 @@ def test_static_tables(seq):
     s.close()
 
 
-def test_reset_all_matches_reference(seq):
-    lib = load_oracle()
+@pytest.mark.parametrize("which", ["oracle", "lane_emulation"])
+def test_reset_all_matches_reference(seq, which):
+    lib = _libs()[which]()
     s = _mk(lib, seq)
     s.inject(seq["U_reset_all"])
     s.reset_all()
@@ -62,18 +63,32 @@ def run_sequence(s, lib, g, check):
     T, N = g["actions"].shape[:2]
     s.inject(g["U_reset_all"])
     s.reset_all()
-    lib.go2o_torque_trace.argtypes = [C.c_void_p] * 4
+    has_trace = hasattr(lib, "go2o_torque_trace")
+    if has_trace:
+        lib.go2o_torque_trace.argtypes = [C.c_void_p] * 4
     for t in range(T):
         s.episode_length_buf[:] = g["ep_len_in"][t]
         s.commands_resampling_step[:] = g["cmd_timer_in"][t]
         s.inject(g["U"][t])
+        if not has_trace:
+            # libraries without the torque-trace hook (the lane emulation): take the reference's own clipped
+            # actions / last-substep torques as inputs of post_physics_step; their PD path is covered by the
+            # physics parity tests against the oracle
+            s.actions[:] = np.clip(g["actions"][t], -100.0, 100.0)
+            s.torques[:] = g["torques"][t][3]
+            s.root_states[:] = g["root_in"][t]; s.dof_state[:] = g["dof_in"][t][3]; s.contact_forces[:] = g["contact_in"][t]
+            s.rigid_body_states[:] = 0; s.rigid_body_states[:, FEET, :] = g["feet_in"][t]
+            s.post_physics()
+            yield t
+            continue
         tq = np.zeros((4, N, 12), np.float32)
         # substep i computes its torques from the DOF state left by simulate i-1 (legged_robot.py:79-92):
         # the library's own current state for i = 0, then the injected states
         acts = np.ascontiguousarray(g["actions"][t])
         dof = np.ascontiguousarray(np.concatenate([np.asarray(s.dof_state, np.float32)[None], g["dof_in"][t][:3]], 0))
         lib.go2o_torque_trace(s.h, acts.ctypes.data, dof.ctypes.data, tq.ctypes.data)
-        check("torques", t, tq, g["torques"][t])
+        if check is not None:
+            check("torques", t, tq, g["torques"][t])
         s.root_states[:] = g["root_in"][t]
         s.dof_state[:] = g["dof_in"][t][3]
         s.contact_forces[:] = g["contact_in"][t]
@@ -110,8 +125,16 @@ def compare_step(s, g, t):
         np.testing.assert_allclose(s.episode_info[:n], g["episode_info"][t], atol=1e-6, rtol=1e-4)
 
 
-def test_sequence_matches_reference(seq):
-    lib = load_oracle()
+def _libs():
+    from helpers import load_emu
+    return {"oracle": load_oracle, "lane_emulation": load_emu}
+
+
+@pytest.mark.parametrize("which", ["oracle", "lane_emulation"])
+def test_sequence_matches_reference(seq, which):
+    """oracle: pins the checker.  lane_emulation: the HIP lane programs (go2_post.h), compiled for the host,
+    against the same reference vectors — the GPU run of the same check is tests/test_gpu_parity.py."""
+    lib = _libs()[which]()
     s = _mk(lib, seq)
 
     def check(name, t, got, want):
