@@ -224,7 +224,7 @@ class DeviceSim:
 
 
 def load_hip():
-    from go2_rl_gym_amd import _lib
+    from go2_rl_gym_amd import _lib      # imports torch first: one HIP runtime per process (see _lib.py)
     return _lib.load_hip()
 
 
