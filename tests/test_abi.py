@@ -1,0 +1,53 @@
+"""The C-ABI libraries export every symbol include/go2sim.h declares, and the structs agree with the header.  CPU only:
+no compute call is made on the HIP library here."""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+
+from helpers import ROOT, load_emu, load_oracle
+from go2_rl_gym_amd import _abi, build
+
+
+def test_header_parses_and_lists_every_function():
+    abi = _abi.Abi()
+    assert sorted(set(abi.exported)) == sorted(_abi._REQUIRED)
+    assert C.sizeof(abi.Cfg) > 1000 and abi.GO2_NUM_UNIFORMS == 136 and abi.GO2_NUM_REWARDS == 28
+    assert abi.reward_names[abi.GO2_REW_HIP_TO_DEFAULT] == "hip_to_default"
+
+
+@pytest.mark.parametrize("which", ["oracle_f32", "oracle_f64", "lane_emulation"])
+def test_host_libraries_export_abi_and_check_struct_size(which):
+    lib = {"oracle_f32": lambda: load_oracle(False), "oracle_f64": lambda: load_oracle(True), "lane_emulation": load_emu}[which]()
+    cfg = lib.abi.Cfg()
+    lib.go2sim_default_cfg(C.byref(cfg))
+    assert cfg.struct_size == C.sizeof(lib.abi.Cfg) and cfg.num_envs == 4096 and cfg.decimation == 4
+    h = C.c_void_p()
+    cfg.struct_size += 4                       # a drifted caller is rejected, never silently accepted
+    assert lib.go2sim_create(C.byref(cfg), 0, C.byref(h)) == lib.abi.GO2SIM_EINVAL
+    assert b"mismatch" in lib.go2sim_last_error()
+
+
+def test_hip_library_builds_for_gfx950_and_exports_every_symbol():
+    out = build.build_hip()
+    syms = subprocess.run(["nm", "-D", "--defined-only", out], capture_output=True, text=True, check=True).stdout
+    for f in _abi._REQUIRED:
+        assert (" T " + f) in syms, f
+    # the fat binary really carries gfx950 code objects
+    blob = open(out, "rb").read()
+    assert b"gfx950" in blob
+
+
+def test_product_refuses_to_run_without_the_gpu_library(monkeypatch, tmp_path):
+    """No CPU fallback: a missing HIP library, or a CPU sim_device, raises."""
+    from go2_rl_gym_amd import _lib
+    monkeypatch.setattr(_lib, "HIP_LIB", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(_lib, "_cached", None)
+    with pytest.raises(RuntimeError, match="no CPU fallback|missing"):
+        _lib.load_hip()
+    from go2_rl_gym_amd.envs import task_registry  # noqa: F401
+    from go2_rl_gym_amd.utils import get_args
+    args = get_args(["--task", "go2_flat", "--num_envs", "8", "--sim_device", "cpu", "--rl_device", "cpu", "--headless"])
+    with pytest.raises(RuntimeError, match="GPU only"):
+        task_registry.make_env("go2_flat", args)

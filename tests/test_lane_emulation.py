@@ -40,7 +40,7 @@ def test_one_step_parity_through_landing_and_stance():
             getattr(se, k)[...] = getattr(so, k)
         so.step(a); se.step(a)
         contact_seen += int((so.contact_forces[:, [6, 10, 14, 18], 2] > 1).sum())
-        for k, tol in (("root_states", 2e-4), ("dof_state", 2e-3), ("torques", 2e-3), ("obs_buf", 2e-4), ("privileged_obs_buf", 2e-4), ("rew_buf", 5e-6)):
+        for k, tol in (("root_states", 5e-4), ("dof_state", 2e-3), ("torques", 2e-3), ("obs_buf", 2e-4), ("privileged_obs_buf", 2e-4), ("rew_buf", 5e-6)):
             d = np.sort(np.abs(np.asarray(getattr(so, k), np.float64) - np.asarray(getattr(se, k), np.float64)).reshape(N, -1).max(1))
             worst[k] = max(worst.get(k, 0.0), d[-2])
             # all envs but at most one within tol; an env sitting exactly on a contact-activation / friction-cone
