@@ -1,0 +1,88 @@
+"""world_size-2 checks of the multi-GPU path on CPU (gloo): env sharding by global index, the advantage-statistics
+all-reduce (the one data-path collective of the rollout), gradient/KL averaging for one coherent policy."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import ROOT, HostSim, load_oracle
+
+T, N = 24, 32
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _rollout_data(seed=0):
+    rng = np.random.default_rng(seed)
+    return (rng.normal(0, 0.05, (T, N, 1)).astype(np.float32), rng.normal(0, 1, (T, N, 1)).astype(np.float32),
+            (rng.uniform(size=(T, N, 1)) < 0.05).astype(np.uint8), rng.normal(0, 1, (N, 1)).astype(np.float32))
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from go2_rl_gym_amd.rsl_rl.storage import RolloutStorage
+    from go2_rl_gym_amd.rsl_rl.algorithms import PPO
+    from go2_rl_gym_amd.rsl_rl.modules import ActorCritic
+    lib = load_oracle()
+    rew, val, done, last = _rollout_data()
+    n = N // world
+    sl = slice(rank * n, (rank + 1) * n)
+    st = RolloutStorage(n, T, [45], [263], [12], "cpu", lib=lib)
+    st.rewards[:] = torch.from_numpy(rew[:, sl]); st.values[:] = torch.from_numpy(val[:, sl]); st.dones[:] = torch.from_numpy(done[:, sl])
+    st.compute_returns(torch.from_numpy(last[sl]), 0.99, 0.95)
+    res = {"adv": st.advantages.numpy().copy(), "ret": st.returns.numpy().copy()}
+    # one PPO update on different shard data: replicas must stay identical
+    torch.manual_seed(100 + rank)     # different init on purpose: PPO broadcasts rank 0's parameters
+    ac = ActorCritic(45, 263, 12, actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16])
+    alg = PPO(ac, num_learning_epochs=2, num_mini_batches=2, entropy_coef=0.01, schedule="adaptive", device="cpu", lib=lib)
+    alg.init_storage(n, T, [45], [263], [12])
+    g = torch.Generator().manual_seed(7 + rank)
+    for t in range(T):
+        obs, cobs = torch.randn(n, 45, generator=g), torch.randn(n, 263, generator=g)
+        alg.act(obs, cobs)
+        alg.process_env_step(torch.randn(n, generator=g) * 0.05, torch.rand(n, generator=g) < 0.05, {"time_outs": torch.zeros(n, dtype=torch.bool)})
+    alg.compute_returns(torch.randn(n, 263, generator=g))
+    alg.update()
+    res["params"] = torch.cat([p.detach().reshape(-1) for p in ac.parameters()]).numpy().copy()
+    res["lr"] = alg.learning_rate
+    # env sharding: shard r of a 2-shard sim equals envs [r*n, (r+1)*n) of the single sim (same global Philox keys / origins)
+    s = HostSim(lib, num_envs=8, env_offset=rank * 8, num_envs_global=16, seed=3)
+    s.reset_all()
+    res["shard_root"], res["shard_ratio"], res["shard_origin"] = s.root_states.copy(), s.link_mass_ratio.copy(), s.env_origins.copy()
+    s.close()
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_world_size_2_matches_single_process():
+    world, port = 2, _free_port()
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    # single-process reference on the concatenated data
+    from go2_rl_gym_amd.rsl_rl.storage import RolloutStorage
+    lib = load_oracle()
+    rew, val, done, last = _rollout_data()
+    st = RolloutStorage(N, T, [45], [263], [12], "cpu", lib=lib)
+    st.rewards[:] = torch.from_numpy(rew); st.values[:] = torch.from_numpy(val); st.dones[:] = torch.from_numpy(done)
+    st.compute_returns(torch.from_numpy(last), 0.99, 0.95)
+    adv = np.concatenate([out[0]["adv"], out[1]["adv"]], axis=1)
+    np.testing.assert_allclose(adv, st.advantages.numpy(), atol=1e-6)          # statistics were global, not per shard
+    assert abs(adv.mean()) < 1e-6 and abs(adv.std(ddof=1) - 1.0) < 1e-5
+    np.testing.assert_allclose(np.concatenate([out[0]["ret"], out[1]["ret"]], axis=1), st.returns.numpy(), atol=1e-6)
+    np.testing.assert_array_equal(out[0]["params"], out[1]["params"])           # one coherent policy
+    assert out[0]["lr"] == out[1]["lr"]
+    s = HostSim(lib, num_envs=16, seed=3); s.reset_all()
+    for r in range(2):
+        np.testing.assert_array_equal(out[r]["shard_root"], s.root_states[8 * r:8 * r + 8])
+        np.testing.assert_array_equal(out[r]["shard_ratio"], s.link_mass_ratio[8 * r:8 * r + 8])
+        np.testing.assert_array_equal(out[r]["shard_origin"], s.env_origins[8 * r:8 * r + 8])
+    s.close()
