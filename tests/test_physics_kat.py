@@ -1,0 +1,116 @@
+"""Known-answer tests of the physics model (the part of the path the reference delegates to Isaac Gym, so nothing of
+the reference can pin it).  fp64 oracle build unless stated."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import HostSim, load_oracle
+
+N = 8
+
+
+def _randomise(s, rng, scale_v=1.0):
+    s.reset_all()
+    s.dof_state[:, :, 1] = rng.uniform(-3, 3, (s.N, 12)) * scale_v
+    s.root_states[:, 7:13] = rng.uniform(-1, 1, (s.N, 6)) * scale_v
+    q = rng.normal(size=(s.N, 4)); s.root_states[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+
+
+def test_aba_equals_dense_inverse_dynamics_fp64():
+    """Featherstone's floating-base ABA (RBDA table 9.4) vs M^-1 (tau - C) from CRBA + RNEA + Cholesky: two derivations."""
+    s = HostSim(load_oracle(f64=True), num_envs=N)
+    rng = np.random.default_rng(1)
+    _randomise(s, rng)
+    for e in range(N):
+        a1, a2, M, en = s.debug_dynamics(e, rng.uniform(-20, 20, 12))
+        np.testing.assert_allclose(a1, a2, atol=1e-9, rtol=1e-10)
+        np.testing.assert_allclose(M, M.T, atol=1e-14)
+        assert np.linalg.eigvalsh(M).min() > 0
+        assert abs(en[5] - (15.019 + s.added_base_mass[e] + (s.link_mass_ratio[e] - 1) @ np.array([0.001, 0.001] + [0.678, 1.152, 0.154, 0.04] * 4))) < 1e-9
+    s.close()
+
+
+def _free_flight_drift(dt, steps):
+    s = HostSim(load_oracle(f64=True), num_envs=N, gravity=[0, 0, 0], kp=[0] * 12, kd=[0] * 12, push_robots=0, randomize_action_delay=0,
+                joint_limit_margin=-10.0, sim_dt=dt, decimation=1)
+    rng = np.random.default_rng(2)
+    _randomise(s, rng, 0.5)
+    s.root_states[:, 2] = 5.0
+    e0 = np.array([s.debug_dynamics(e, np.zeros(12))[3] for e in range(N)])
+    for _ in range(steps):
+        s.simulate()
+    e1 = np.array([s.debug_dynamics(e, np.zeros(12))[3] for e in range(N)])
+    s.close()
+    mom = np.abs(e1[:, 2:5] - e0[:, 2:5]).max() / np.abs(e0[:, 2:5]).max()
+    ke = np.abs(e1[:, 0] / e0[:, 0] - 1).max()
+    return mom, ke
+
+
+def test_free_flight_conserves_momentum_and_energy_fp64():
+    """No gravity, no contact, zero gains, tumbling base and swinging legs for 0.2 s: world linear momentum and kinetic
+    energy are conserved up to the integrator's error, which must be small and shrink ~linearly with dt (first order)."""
+    m1, k1 = _free_flight_drift(1e-3, 200)
+    m2, k2 = _free_flight_drift(5e-4, 400)
+    assert m1 < 2e-3 and k1 < 0.05, (m1, k1)
+    assert m2 < 0.65 * m1 and k2 < 0.65 * k1, (m1, m2, k1, k2)
+
+
+def test_free_fall_is_exact():
+    s = HostSim(load_oracle(f64=True), num_envs=N, kp=[0] * 12, kd=[0] * 12, push_robots=0, randomize_action_delay=0, joint_limit_margin=-10.0)
+    s.reset_all()
+    s.root_states[:, 2] = 10.0; s.root_states[:, 7:13] = 0; s.dof_state[:, :, 1] = 0
+    z0 = s.root_states[:, 2].copy()
+    for _ in range(5):
+        s.simulate()                       # 20 substeps of 5 ms
+    # the system COM falls with g; with all joints free and started at rest the base follows to first order
+    vz = s.root_states[:, 9]
+    assert np.all(np.abs(vz + 9.81 * 0.1) < 0.25)
+    s.close()
+
+
+def test_standing_robot_carries_its_weight():
+    """PD at the default pose on the plane: after settling, sum of vertical contact forces = m g within 3 %, base height
+    in the standing range, nothing explodes (fp32 build, the one compared with the GPU)."""
+    s = HostSim(load_oracle(), num_envs=32, push_robots=0, add_noise=0)
+    s.reset_all()
+    a = np.zeros((32, 12), np.float32)
+    fz = []
+    for i in range(150):
+        s.step(a)
+        if i >= 100:
+            fz.append(s.contact_forces[:, :, 2].sum(1).copy())
+    alive = ~np.asarray(s.reset_buf).astype(bool)
+    w = (15.019 + s.added_base_mass + (s.link_mass_ratio - 1) @ np.array([0.001, 0.001] + [0.678, 1.152, 0.154, 0.04] * 4)) * 9.81
+    ratio = (np.mean(fz, axis=0) / w)[alive]
+    assert np.abs(np.median(ratio) - 1.0) < 0.03, np.median(ratio)
+    z = s.root_states[:, 2][alive]
+    assert 0.15 < np.median(z) < 0.40 and np.isfinite(np.asarray(s.obs_buf)).all()
+    assert np.abs(s.dof_state[:, :, 1]).max() < 25.0
+    s.close()
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/deploy/pre_train/go2/go2_cts_150k.pt"), reason="container-only: needs the reference's pretrained policy")
+def test_reference_pretrained_policy_walks_in_this_simulator():
+    """Behavioural check of the contact model: the policy the reference ships (trained in PhysX, README.md:101-120 says it
+    also walks in MuJoCo) tracks a 1 m/s forward command here without falling for 10 s.  The .pt is read in place, never copied."""
+    import torch
+    lib = load_oracle()
+    speeds = []
+    for trial in range(2):
+        pol = torch.jit.load("/root/reference/deploy/pre_train/go2/go2_cts_150k.pt")
+        s = HostSim(lib, num_envs=1, push_robots=0, add_noise=0, seed=trial + 1, randomize_friction=0, randomize_action_delay=0)
+        s.reset_all()
+        s.step(np.zeros((1, 12), np.float32))
+        for i in range(500):
+            s.commands[:, :3] = [1.0, 0, 0]
+            obs = s.obs_buf.copy(); obs[:, 6:9] = s.commands[:, :3] * np.array([2, 2, 0.25], np.float32)
+            with torch.no_grad():
+                act = pol(torch.from_numpy(obs)).numpy()
+            s.step(act)
+            assert not s.reset_buf.any(), "fell at step %d" % i
+            if i >= 100:
+                speeds.append(float(s.base_lin_vel[0, 0]))
+        assert 0.30 < s.root_states[0, 2] < 0.42
+        s.close()
+    assert 0.8 < np.mean(speeds) < 1.1, np.mean(speeds)
