@@ -149,9 +149,10 @@ struct LegPhys {
     s.t1w = t1; s.t2w = cross(nw, t1);
     V3 dirs[3] = {mulT(Rwb, s.nw), mulT(Rwb, s.t1w), mulT(Rwb, s.t2w)};
     V3 rb = cb - rad * dirs[0];
-    V3 col1 = link >= 1 ? cross(v3(1, 0, 0), rb - p1) : v3(0, 0, 0);
-    V3 col2 = link >= 2 ? cross(a2, rb - p2) : v3(0, 0, 0);
-    V3 col3 = link >= 3 ? cross(a2, rb - p3) : v3(0, 0, 0);
+    V3 zero3 = v3(0, 0, 0);
+    V3 col1 = sel(link >= 1, cross(v3(1, 0, 0), rb - p1), zero3);
+    V3 col2 = sel(link >= 2, cross(a2, rb - p2), zero3);
+    V3 col3 = sel(link >= 3, cross(a2, rb - p3), zero3);
     float cfm1 = 1.0f + L.cfm;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -198,7 +199,7 @@ struct LegPhys {
           int k = i - GO2_NLEG_OTHER; if (k >= t.n_base) continue;
           c = v3(t.base_pt[k][0], t.base_pt[k][1], t.base_pt[k][2]); rad = t.base_pt[k][3]; link = 0; body = t.base_body[k];
         }
-        V3 cb = link == 0 ? c : (link == 1 ? p1 + mul(R1, c) : (link == 2 ? p2 + mul(R2, c) : p3 + mul(R3, c)));
+        V3 cb = sel(link == 0, c, sel(link == 1, p1 + mul(R1, c), sel(link == 2, p2 + mul(R2, c), p3 + mul(R3, c))));
         V3 cw = pw + mul(Rwb, cb); float hh; V3 n; terrain(L, hf, cw.x, cw.y, &hh, &n);
         float gap = (cw.z - hh) * n.z - rad;
         if (gap < best) { best = gap; bcb = cb; bn = n; brad = rad; blink = link; bbody = body; }
@@ -215,7 +216,7 @@ struct LegPhys {
       LimitRow& r = lr[j];
       r.active = sgn != 0.f ? 1.f : 0.f; r.lam = 0.f; r.sgn = sgn;
       r.Z[0] = sgn * ainv(0, j); r.Z[1] = sgn * ainv(1, j); r.Z[2] = sgn * ainv(2, j);
-      SV Tj = j == 0 ? T1 : (j == 1 ? T2 : T3);
+      SV Tj = sv(sel(j == 0, T1.a, sel(j == 1, T2.a, T3.a)), sel(j == 0, T1.l, sel(j == 1, T2.l, T3.l)));
       r.G = (-sgn) * Tj;
       r.H = spd6_mul(Phi, r.G);
       float d_ = (sgn * r.Z[j] + dot(r.G, r.H)) * cfm1;

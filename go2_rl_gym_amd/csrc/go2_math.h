@@ -28,6 +28,9 @@ GO2_HD V3& operator+=(V3& a, V3 b) { a.x += b.x; a.y += b.y; a.z += b.z; return 
 GO2_HD float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 GO2_HD V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 GO2_HD float comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+// component-wise select.  NEVER write `cond ? structA : structB` on aggregates in lane code: clang lowers it to a
+// select of ADDRESSES, which pins both objects (and the whole lane context they live in) in scratch memory.
+GO2_HD V3 sel(bool c, V3 a, V3 b) { return v3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
 
 // 3x3 matrix by columns (x, y, z): M v = x v.x + y v.y + z v.z
 struct M3 { V3 x, y, z; };
@@ -182,3 +185,10 @@ GO2_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 GO2_HD float u01_from_bits(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+// word k (0..3) of a Philox block without indexing a private array dynamically (that would live in scratch memory)
+GO2_HD float philox_u01(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, int k) {
+  uint32_t r[4];
+  philox4x32_10(c0, c1, c2, c3, k0, k1, r);
+  uint32_t x = k == 0 ? r[0] : (k == 1 ? r[1] : (k == 2 ? r[2] : r[3]));
+  return u01_from_bits(x);
+}

@@ -50,14 +50,14 @@ GO2_HD void go2_step_scalars(const Go2Launch& L, const Go2Dyn& dyn, const float*
   S->step_lo = (uint32_t)dyn.step_count; S->step_hi = (uint32_t)(dyn.step_count >> 32);
   S->initial_reset = initial_reset; S->injected = dyn.use_injected ? inj_storage : nullptr;
   float it = (float)(csc / L.num_steps_per_env);
-  for (int t = 0; t < GO2_NUM_REWARDS; ++t) {
+  _Pragma("unroll") for (int t = 0; t < GO2_NUM_REWARDS; ++t) {
     float sc = L.rew_scale_dt[t];
     for (int i = 0; i < L.rew_curr_count; ++i) if (L.rew_curr_term[i] == t) sc *= go2_current_scale(L.rew_curr[i], it);
     S->rew_scale[t] = sc;
   }
   int best = -1;
   for (int i = 0; i < L.cmd_curr_count; ++i) if (it >= L.cmd_curr[i][0] && (best < 0 || L.cmd_curr[i][0] > L.cmd_curr[best][0])) best = i;
-  for (int r = 0; r < 4; ++r) {
+  _Pragma("unroll") for (int r = 0; r < 4; ++r) {
     S->cmd_ranges[r][0] = best < 0 ? L.cmd_ranges0[r][0] : L.cmd_curr[best][1 + 2 * r];
     S->cmd_ranges[r][1] = best < 0 ? L.cmd_ranges0[r][1] : L.cmd_curr[best][2 + 2 * r];
   }
@@ -77,9 +77,7 @@ struct LegPost {
 
   GO2_HD float uni(int slot) const {
     if (S->injected) return S->injected[(size_t)e * GO2_NUM_UNIFORMS + slot];
-    uint32_t r[4];
-    philox4x32_10((uint32_t)(L->env_offset + e), (uint32_t)(slot >> 2), S->step_lo, S->step_hi, L->seed_lo, L->seed_hi, r);
-    return u01_from_bits(r[slot & 3]);
+    return philox_u01((uint32_t)(L->env_offset + e), (uint32_t)(slot >> 2), S->step_lo, S->step_hi, L->seed_lo, L->seed_hi, slot & 3);
   }
   GO2_HD static float urange(float u, float lo, float hi) { return (hi - lo) * u + lo; }
   GO2_HD void cmd_range(int which, float* lo, float* hi) const {  // env_command_ranges (:861-907)
@@ -158,10 +156,10 @@ struct LegPost {
     const Go2Ptrs& p = *P; const Go2Launch& c = *L;
     ep_len = p.ep_len[e] + 1;                      // :111
     timer = p.cmd_timer[e] - 1.f;                  // :113
-    for (int k = 0; k < 4; ++k) cmd[k] = F2D(p.commands, k, e);
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) cmd[k] = F2D(p.commands, k, e);
     acc[0] = F2D(p.cmd_xy_acc, 0, e); acc[1] = F2D(p.cmd_xy_acc, 1, e);
     stop_heading = p.stop_heading[e]; last_limit = p.last_is_limit_vel[e];
-    for (int j = 0; j < 3; ++j) {
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) {
       int d = 3 * lane + j;
       act[j] = F2D(p.actions, d, e); last_act[j] = F2D(p.last_actions, d, e); llast_act[j] = F2D(p.last_last_actions, d, e); last_dv[j] = F2D(p.last_dof_vel, d, e);
     }
@@ -322,7 +320,7 @@ struct LegPost {
       float r = ((reset && !time_out) ? 1.f : 0.f) * S->rew_scale[GO2_REW_TERMINATION]; total += r; if (lane == 0) es[(size_t)GO2_REW_TERMINATION * N + e] += r;
     }
     if (c.rew_scale_dt[GO2_REW_ACTION_SMOOTHNESS] != 0.f)
-      for (int j = 0; j < 3; ++j) llast_act[j] = last_act[j];       // :1378 (not zeroed on reset, App. E.9)
+      _Pragma("unroll") for (int j = 0; j < 3; ++j) llast_act[j] = last_act[j];       // :1378 (not zeroed on reset, App. E.9)
 
     // ---- reset_idx (:180-245) ---------------------------------------------------------------------
     float ox = org_x, oy = org_y, oz = org_z;
@@ -360,12 +358,12 @@ struct LegPost {
       o.vw = v3(urange(uni(GO2_U_RESET_VEL), -0.5f, 0.5f), urange(uni(GO2_U_RESET_VEL + 1), -0.5f, 0.5f), urange(uni(GO2_U_RESET_VEL + 2), -0.5f, 0.5f));
       o.ww = v3(urange(uni(GO2_U_RESET_VEL + 3), -0.5f, 0.5f), urange(uni(GO2_U_RESET_VEL + 4), -0.5f, 0.5f), urange(uni(GO2_U_RESET_VEL + 5), -0.5f, 0.5f));
       F2D(p.feet_air_time, lane, e) = 0.f;
-      for (int a = 0; a < 3; ++a) F3D(p.foot_impulse, 4, lane, a, e) = 0.f;
+      _Pragma("unroll") for (int a = 0; a < 3; ++a) F3D(p.foot_impulse, 4, lane, a, e) = 0.f;
       ep_len = 0;
       timer = c.resampling_time / c.dt; acc[0] = 0.f; acc[1] = 0.f;
       resample(GO2_U_RSB);
       if (lane == 0) {   // extras["episode"] accumulators (:229-242)
-        for (int i = 0; i < GO2_NUM_REWARDS; ++i) if (c.rew_scale_dt[i] != 0.f) {
+        _Pragma("unroll") for (int i = 0; i < GO2_NUM_REWARDS; ++i) if (c.rew_scale_dt[i] != 0.f) {
 #if defined(__HIP_DEVICE_COMPILE__)
           atomicAdd(&p.ep_accum[i], es[(size_t)i * N + e]);
 #else
@@ -393,7 +391,7 @@ struct LegPost {
     if (lane == 0) {
       float s9[9] = {bav.x * c.os_ang, bav.y * c.os_ang, bav.z * c.os_ang, pg.x, pg.y, pg.z, cmd[0] * c.os_lin, cmd[1] * c.os_lin, cmd[2] * c.os_ang};
       pv[0] = CLIP(blv.x * c.os_lin); pv[1] = CLIP(blv.y * c.os_lin); pv[2] = CLIP(blv.z * c.os_lin);
-      for (int i = 0; i < 9; ++i) { pv[3 + i] = CLIP(s9[i]); ob[i] = CLIP(s9[i] + NOISE(i)); }
+      _Pragma("unroll") for (int i = 0; i < 9; ++i) { pv[3 + i] = CLIP(s9[i]); ob[i] = CLIP(s9[i] + NOISE(i)); }
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -423,10 +421,10 @@ struct LegPost {
     }
     if (lane == 0) {
       float r13[13] = {o.pw.x, o.pw.y, o.pw.z, o.qx, o.qy, o.qz, o.qw, o.vw.x, o.vw.y, o.vw.z, o.ww.x, o.ww.y, o.ww.z};
-      for (int k = 0; k < 13; ++k) F2D(p.root, k, e) = r13[k];
-      for (int k = 0; k < 6; ++k) F2D(p.last_root_vel, k, e) = r13[7 + k];   // :142
+      _Pragma("unroll") for (int k = 0; k < 13; ++k) F2D(p.root, k, e) = r13[k];
+      _Pragma("unroll") for (int k = 0; k < 6; ++k) F2D(p.last_root_vel, k, e) = r13[7 + k];   // :142
       p.ep_len[e] = ep_len; p.cmd_timer[e] = timer;
-      for (int k = 0; k < 4; ++k) F2D(p.commands, k, e) = cmd[k];
+      _Pragma("unroll") for (int k = 0; k < 4; ++k) F2D(p.commands, k, e) = cmd[k];
       F2D(p.cmd_xy_acc, 0, e) = acc[0]; F2D(p.cmd_xy_acc, 1, e) = acc[1];
       p.stop_heading[e] = stop_heading; p.last_is_limit_vel[e] = last_limit;
       p.reset[e] = reset; p.time_out[e] = time_out; p.rew[e] = total; p.max_move[e] = max_move;

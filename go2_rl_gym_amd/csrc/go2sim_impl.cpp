@@ -36,29 +36,29 @@ enum { MODE_PHYS = 1, MODE_POST = 2, MODE_RESET_ALL = 4 };
 // ------------------------------------------------------------------------------------------------------
 // the per-quad driver shared by the kernel and the emulation: everything except the cross-lane steps
 // ------------------------------------------------------------------------------------------------------
-struct LaneCtx {
-  LegPhys ph; LegPost po; PhysOut out;
-  float kpm[3], kdm[3], zoff[3], strength[3], act_new[3], act_old[3];
-  int start;
-};
+// The lane context is kept as THREE separate objects (not one struct): the compiler's scalar-replacement pass gives up on a
+// single 2.4 KB aggregate with thousands of uses and would leave all of it in scratch memory.
+struct LaneAux { float kpm[3], kdm[3], zoff[3], strength[3], act_new[3], act_old[3]; int start; };
+#define LANE_PARAMS LegPhys& ph_, LegPost& po_, LaneAux& ax
+#define LANE_ARGS(i) c_ph[i], c_po[i], c_ax[i]
 
-GO2_HD void lane_load_phys(LaneCtx& c, const Go2Tables& tab, const Go2Ptrs& p, const Go2Launch& L, const Go2Step& S, const float* actions_in, int e, int lane) {
+GO2_HD void lane_load_phys(LANE_PARAMS, const Go2Tables& tab, const Go2Ptrs& p, const Go2Launch& L, const Go2Step& S, const float* actions_in, int e, int lane) {
   const int N = L.N;
   const LegTab& t = tab.leg[lane];
-  LegPhys& ph = c.ph;
+  LegPhys& ph = ph_;
   ph.pw = v3(F2D(p.root, 0, e), F2D(p.root, 1, e), F2D(p.root, 2, e));
   ph.qx = F2D(p.root, 3, e); ph.qy = F2D(p.root, 4, e); ph.qz = F2D(p.root, 5, e); ph.qw = F2D(p.root, 6, e);
   ph.vw = v3(F2D(p.root, 7, e), F2D(p.root, 8, e), F2D(p.root, 9, e));
   ph.ww = v3(F2D(p.root, 10, e), F2D(p.root, 11, e), F2D(p.root, 12, e));
   float cl = L.clip_actions;
-  for (int j = 0; j < 3; ++j) {
+  _Pragma("unroll") for (int j = 0; j < 3; ++j) {
     int d = 3 * lane + j;
     ph.q[j] = F2D(p.dof, d, e); ph.qd[j] = F2D(p.dof, 12 + d, e);
-    c.kpm[j] = F2D(p.kp_mul, d, e); c.kdm[j] = F2D(p.kd_mul, d, e); c.zoff[j] = F2D(p.zero_off, d, e); c.strength[j] = F2D(p.strength, d, e);
+    ax.kpm[j] = F2D(p.kp_mul, d, e); ax.kdm[j] = F2D(p.kd_mul, d, e); ax.zoff[j] = F2D(p.zero_off, d, e); ax.strength[j] = F2D(p.strength, d, e);
     float a = actions_in ? actions_in[(size_t)e * 12 + d] : F2D(p.actions, d, e);
     a = fminf(fmaxf(a, -cl), cl);                  // legged_robot.py:67-68
-    c.act_new[j] = a; F2D(p.actions, d, e) = a;
-    c.act_old[j] = F2D(p.last_actions, d, e);
+    ax.act_new[j] = a; F2D(p.actions, d, e) = a;
+    ax.act_old[j] = F2D(p.last_actions, d, e);
     ph.lam_foot[0 + j] = F3D(p.foot_impulse, 4, lane, j, e);
   }
   // per-env inertial parameters (legged_robot.py:379-402, recomputeInertia=True modelled as inertia ~ mass)
@@ -75,12 +75,12 @@ GO2_HD void lane_load_phys(LaneCtx& c, const Go2Tables& tab, const Go2Ptrs& p, c
   ph.mu = 0.5f * (L.terrain_friction + p.friction[e]);
   ph.rest = 0.5f * (L.terrain_restitution + p.restitution[e]);
   // action delay (legged_robot.py:71-78)
-  c.start = 0;
+  ax.start = 0;
   if (L.rand_delay) {
     float u;
     if (S.injected) u = S.injected[(size_t)e * GO2_NUM_UNIFORMS + GO2_U_DELAY];
-    else { uint32_t r[4]; philox4x32_10((uint32_t)(L.env_offset + e), 0u, S.step_lo, S.step_hi, L.seed_lo, L.seed_hi, r); u = u01_from_bits(r[GO2_U_DELAY & 3]); }
-    c.start = (int)(u * (float)(L.decimation + 1)); if (c.start > L.decimation) c.start = L.decimation;
+    else u = philox_u01((uint32_t)(L.env_offset + e), 0u, S.step_lo, S.step_hi, L.seed_lo, L.seed_hi, GO2_U_DELAY & 3);
+    ax.start = (int)(u * (float)(L.decimation + 1)); if (ax.start > L.decimation) ax.start = L.decimation;
   }
 }
 
@@ -93,10 +93,10 @@ GO2_HD void quat_mul(const float* a, const float* b, float* o) {  // (x,y,z,w)
 
 // after the last substep: forward kinematics at the new state, API tensors, PhysOut.  fbase = this lane's
 // contribution to the base / head contact forces (3 bodies x 3), to be quad-summed by the caller.
-GO2_HD void lane_finish_phys(LaneCtx& c, const Go2Tables& tab, const Go2Ptrs& p, const Go2Launch& L, int e, int lane, float* fbase) {
+GO2_HD void lane_finish_phys(LANE_PARAMS, const Go2Tables& tab, const Go2Ptrs& p, const Go2Launch& L, int e, int lane, float* fbase) {
   const int N = L.N;
   const LegTab& t = tab.leg[lane];
-  LegPhys& ph = c.ph; PhysOut& o = c.out;
+  LegPhys& ph = ph_; PhysOut& o = po_.o;
   M3 Rwb = quat_to_m3(ph.qx, ph.qy, ph.qz, ph.qw);
   V3 wb = mulT(Rwb, ph.ww), vb = mulT(Rwb, ph.vw);
   float s1, c1, s2, c2, s3, c3; sincosf(ph.q[0], &s1, &c1); sincosf(ph.q[1], &s2, &c2); sincosf(ph.q[2], &s3, &c3);
@@ -115,31 +115,31 @@ GO2_HD void lane_finish_phys(LaneCtx& c, const Go2Tables& tab, const Go2Ptrs& p,
   float h1[4] = {sinf(0.5f * ph.q[0]), 0, 0, cosf(0.5f * ph.q[0])}, h2[4] = {0, sinf(0.5f * ph.q[1]), 0, cosf(0.5f * ph.q[1])}, h3[4] = {0, sinf(0.5f * ph.q[2]), 0, cosf(0.5f * ph.q[2])};
   quat_mul(qb, h1, qh); quat_mul(qh, h2, qt); quat_mul(qt, h3, qc);
   const float* quats[4] = {qh, qt, qc, qc};
-  for (int k = 0; k < 4; ++k) {
+  _Pragma("unroll") for (int k = 0; k < 4; ++k) {
     int b = t.body_index[k];
     V3 pos = ph.pw + mul(Rwb, org[k]);
     V3 lv = mul(Rwb, vel[k].l + cross(vel[k].a, org[k])), av = mul(Rwb, vel[k].a);
     float r13[13] = {pos.x, pos.y, pos.z, quats[k][0], quats[k][1], quats[k][2], quats[k][3], lv.x, lv.y, lv.z, av.x, av.y, av.z};
-    for (int i = 0; i < 13; ++i) F3D(p.rigid, 19, b, i, e) = r13[i];
+    _Pragma("unroll") for (int i = 0; i < 13; ++i) F3D(p.rigid, 19, b, i, e) = r13[i];
     if (k == 3) { o.foot_pos = pos; o.foot_vel = lv; }
   }
   if (lane < 3) {  // base, Head_upper, Head_lower rows
     V3 off = v3(tab.base.body_off[lane][0], tab.base.body_off[lane][1], tab.base.body_off[lane][2]);
     V3 pos = ph.pw + mul(Rwb, off); V3 lv = mul(Rwb, vb + cross(wb, off));
     float r13[13] = {pos.x, pos.y, pos.z, ph.qx, ph.qy, ph.qz, ph.qw, lv.x, lv.y, lv.z, ph.ww.x, ph.ww.y, ph.ww.z};
-    for (int i = 0; i < 13; ++i) F3D(p.rigid, 19, lane, i, e) = r13[i];
+    _Pragma("unroll") for (int i = 0; i < 13; ++i) F3D(p.rigid, 19, lane, i, e) = r13[i];
   }
   // contact forces of this leg's bodies; base/head parts go through the quad sum
   V3 zero = v3(0, 0, 0);
-  o.Fhip = ph.other_body == t.body_index[0] ? ph.force_other : zero;
-  o.Fthigh = ph.other_body == t.body_index[1] ? ph.force_other : zero;
-  o.Fcalf = ph.other_body == t.body_index[2] ? ph.force_other : zero;
+  o.Fhip = sel(ph.other_body == t.body_index[0], ph.force_other, zero);
+  o.Fthigh = sel(ph.other_body == t.body_index[1], ph.force_other, zero);
+  o.Fcalf = sel(ph.other_body == t.body_index[2], ph.force_other, zero);
   o.Ffoot = ph.force_foot;
   V3 fl[4] = {o.Fhip, o.Fthigh, o.Fcalf, o.Ffoot};
-  for (int k = 0; k < 4; ++k) { int b = t.body_index[k]; F3D(p.contact, 19, b, 0, e) = fl[k].x; F3D(p.contact, 19, b, 1, e) = fl[k].y; F3D(p.contact, 19, b, 2, e) = fl[k].z; }
-  for (int b = 0; b < 3; ++b) { V3 f = ph.other_body == b ? ph.force_other : zero; fbase[3 * b] = f.x; fbase[3 * b + 1] = f.y; fbase[3 * b + 2] = f.z; }
+  _Pragma("unroll") for (int k = 0; k < 4; ++k) { int b = t.body_index[k]; F3D(p.contact, 19, b, 0, e) = fl[k].x; F3D(p.contact, 19, b, 1, e) = fl[k].y; F3D(p.contact, 19, b, 2, e) = fl[k].z; }
+  _Pragma("unroll") for (int b = 0; b < 3; ++b) { V3 f = sel(ph.other_body == b, ph.force_other, zero); fbase[3 * b] = f.x; fbase[3 * b + 1] = f.y; fbase[3 * b + 2] = f.z; }
   o.pw = ph.pw; o.qx = ph.qx; o.qy = ph.qy; o.qz = ph.qz; o.qw = ph.qw; o.vw = ph.vw; o.ww = ph.ww;
-  for (int j = 0; j < 3; ++j) {
+  _Pragma("unroll") for (int j = 0; j < 3; ++j) {
     int d = 3 * lane + j;
     o.q[j] = ph.q[j]; o.qd[j] = ph.qd[j]; o.tau[j] = ph.tau[j];
     F2D(p.dof, d, e) = ph.q[j]; F2D(p.dof, 12 + d, e) = ph.qd[j]; F2D(p.torques, d, e) = ph.tau[j];
@@ -147,43 +147,43 @@ GO2_HD void lane_finish_phys(LaneCtx& c, const Go2Tables& tab, const Go2Ptrs& p,
   }
   if (lane == 0) {
     float r13[13] = {o.pw.x, o.pw.y, o.pw.z, o.qx, o.qy, o.qz, o.qw, o.vw.x, o.vw.y, o.vw.z, o.ww.x, o.ww.y, o.ww.z};
-    for (int k = 0; k < 13; ++k) F2D(p.root, k, e) = r13[k];
+    _Pragma("unroll") for (int k = 0; k < 13; ++k) F2D(p.root, k, e) = r13[k];
   }
 }
 // fbase_sum = quad-summed base/head forces
-GO2_HD void lane_store_base_forces(LaneCtx& c, const Go2Ptrs& p, const Go2Launch& L, int e, int lane, const float* fbase_sum) {
+GO2_HD void lane_store_base_forces(LANE_PARAMS, const Go2Ptrs& p, const Go2Launch& L, int e, int lane, const float* fbase_sum) {
   const int N = L.N;
-  c.out.Fbase = v3(fbase_sum[0], fbase_sum[1], fbase_sum[2]);
+  po_.o.Fbase = v3(fbase_sum[0], fbase_sum[1], fbase_sum[2]);
   if (lane < 3) for (int k = 0; k < 3; ++k) F3D(p.contact, 19, lane, k, e) = fbase_sum[3 * lane + k];
 }
 // post-only entry: rebuild PhysOut from the API tensors
-GO2_HD void lane_load_physout(LaneCtx& c, const Go2Tables& tab, const Go2Ptrs& p, const Go2Launch& L, int e, int lane) {
-  const int N = L.N; const LegTab& t = tab.leg[lane]; PhysOut& o = c.out;
+GO2_HD void lane_load_physout(LANE_PARAMS, const Go2Tables& tab, const Go2Ptrs& p, const Go2Launch& L, int e, int lane) {
+  const int N = L.N; const LegTab& t = tab.leg[lane]; PhysOut& o = po_.o;
   o.pw = v3(F2D(p.root, 0, e), F2D(p.root, 1, e), F2D(p.root, 2, e));
   o.qx = F2D(p.root, 3, e); o.qy = F2D(p.root, 4, e); o.qz = F2D(p.root, 5, e); o.qw = F2D(p.root, 6, e);
   o.vw = v3(F2D(p.root, 7, e), F2D(p.root, 8, e), F2D(p.root, 9, e)); o.ww = v3(F2D(p.root, 10, e), F2D(p.root, 11, e), F2D(p.root, 12, e));
-  for (int j = 0; j < 3; ++j) { int d = 3 * lane + j; o.q[j] = F2D(p.dof, d, e); o.qd[j] = F2D(p.dof, 12 + d, e); o.tau[j] = F2D(p.torques, d, e); }
+  _Pragma("unroll") for (int j = 0; j < 3; ++j) { int d = 3 * lane + j; o.q[j] = F2D(p.dof, d, e); o.qd[j] = F2D(p.dof, 12 + d, e); o.tau[j] = F2D(p.torques, d, e); }
   auto F = [&](int b) { return v3(F3D(p.contact, 19, b, 0, e), F3D(p.contact, 19, b, 1, e), F3D(p.contact, 19, b, 2, e)); };
   o.Fhip = F(t.body_index[0]); o.Fthigh = F(t.body_index[1]); o.Fcalf = F(t.body_index[2]); o.Ffoot = F(t.body_index[3]); o.Fbase = F(0);
   int fb = t.body_index[3];
   o.foot_pos = v3(F3D(p.rigid, 19, fb, 0, e), F3D(p.rigid, 19, fb, 1, e), F3D(p.rigid, 19, fb, 2, e));
   o.foot_vel = v3(F3D(p.rigid, 19, fb, 7, e), F3D(p.rigid, 19, fb, 8, e), F3D(p.rigid, 19, fb, 9, e));
 }
-GO2_HD void lane_init_post(LaneCtx& c, const Go2Ptrs* p, const Go2Launch* L, const Go2Step* S, int e, int lane) {
-  c.po.e = e; c.po.lane = lane; c.po.N = L->N; c.po.P = p; c.po.L = L; c.po.S = S; c.po.o = c.out;
+GO2_HD void lane_init_post(LANE_PARAMS, const Go2Ptrs* p, const Go2Launch* L, const Go2Step* S, int e, int lane) {
+  po_.e = e; po_.lane = lane; po_.N = L->N; po_.P = p; po_.L = L; po_.S = S;
 }
 // reset_idx(all envs) without a step (base_task.py:82-84): postB's reset branch with reset forced on
-GO2_HD void lane_reset_all(LaneCtx& c, const Go2Tables& tab, const Go2Ptrs& p, const Go2Launch& L, const Go2Step& S, int e, int lane) {
+GO2_HD void lane_reset_all(LANE_PARAMS, const Go2Tables& tab, const Go2Ptrs& p, const Go2Launch& L, const Go2Step& S, int e, int lane) {
   const int N = L.N;
-  lane_load_physout(c, tab, p, L, e, lane);
-  lane_init_post(c, &p, &L, &S, e, lane);
-  LegPost& po = c.po;
+  lane_load_physout(ph_, po_, ax, tab, p, L, e, lane);
+  lane_init_post(ph_, po_, ax, &p, &L, &S, e, lane);
+  LegPost& po = po_;
   // load what postA would have loaded, without advancing any clock
   po.ep_len = p.ep_len[e]; po.timer = p.cmd_timer[e];
-  for (int k = 0; k < 4; ++k) po.cmd[k] = F2D(p.commands, k, e);
+  _Pragma("unroll") for (int k = 0; k < 4; ++k) po.cmd[k] = F2D(p.commands, k, e);
   po.acc[0] = F2D(p.cmd_xy_acc, 0, e); po.acc[1] = F2D(p.cmd_xy_acc, 1, e);
   po.stop_heading = p.stop_heading[e]; po.last_limit = p.last_is_limit_vel[e];
-  for (int j = 0; j < 3; ++j) { int d = 3 * lane + j; po.act[j] = 0; po.last_act[j] = 0; po.llast_act[j] = F2D(p.last_last_actions, d, e); po.last_dv[j] = 0; }
+  _Pragma("unroll") for (int j = 0; j < 3; ++j) { int d = 3 * lane + j; po.act[j] = 0; po.last_act[j] = 0; po.llast_act[j] = F2D(p.last_last_actions, d, e); po.last_dv[j] = 0; }
   po.max_move = p.max_move[e];
   po.load_terrain_fields();
 }
@@ -209,59 +209,60 @@ __global__ void __launch_bounds__(64) go2_step_kernel(const Go2DevBlock* __restr
   __syncthreads();
   const int e = blockIdx.x * 16 + (threadIdx.x >> 2), lane = threadIdx.x & 3;
   if (e >= L.N) return;   // whole quads leave together
-  LaneCtx c;
+  LegPhys ph_; LegPost po_; LaneAux ax;
   const LegTab& t = tab.leg[lane];
   if (MODE & MODE_RESET_ALL) {
-    lane_reset_all(c, tab, p, L, S, e, lane);
+    lane_reset_all(ph_, po_, ax, tab, p, L, S, e, lane);
     float red[GO2_POST_PARTIALS];
 #pragma unroll
     for (int i = 0; i < GO2_POST_PARTIALS; ++i) red[i] = 0.f;
-    c.po.reset = 1; c.po.time_out = 0;
-    c.po.blv = v3(0, 0, 0); c.po.bav = v3(0, 0, 0); c.po.pg = v3(0, 0, -1); c.po.rpy[0] = c.po.rpy[1] = c.po.rpy[2] = 0.f;
-    c.po.own_f2b = 0.f; c.po.own_fvel2 = 0.f;
-    c.po.postB(t, red, 0.f);
+    po_.reset = 1; po_.time_out = 0;
+    po_.blv = v3(0, 0, 0); po_.bav = v3(0, 0, 0); po_.pg = v3(0, 0, -1); po_.rpy[0] = po_.rpy[1] = po_.rpy[2] = 0.f;
+    po_.own_f2b = 0.f; po_.own_fvel2 = 0.f;
+    po_.postB(t, red, 0.f);
     return;
   }
   if (MODE & MODE_PHYS) {
-    lane_load_phys(c, tab, p, L, S, actions_in, e, lane);
+    lane_load_phys(ph_, po_, ax, tab, p, L, S, actions_in, e, lane);
     for (int sub = 0; sub < L.decimation; ++sub) {
-      const float* a = (L.rand_delay && sub < c.start) ? c.act_old : c.act_new;
-      c.ph.pd(t, L, lane, a, c.kpm, c.kdm, c.zoff, c.strength);
+      const bool old = L.rand_delay && sub < ax.start;
+      const float a[3] = {old ? ax.act_old[0] : ax.act_new[0], old ? ax.act_old[1] : ax.act_new[1], old ? ax.act_old[2] : ax.act_new[2]};
+      ph_.pd(t, L, lane, a, ax.kpm, ax.kdm, ax.zoff, ax.strength);
       float part[GO2_QUAD_PARTIALS];
-      c.ph.phaseA(t, L, part);
+      ph_.phaseA(t, L, part);
 #pragma unroll
       for (int i = 0; i < GO2_QUAD_PARTIALS; ++i) part[i] = quad_sum(part[i]);
-      c.ph.phaseB(L, part);
+      ph_.phaseB(L, part);
       float dw[6], tot[6];
-      c.ph.phaseC(t, L, p.hf, dw);
+      ph_.phaseC(t, L, p.hf, dw);
 #pragma unroll
       for (int i = 0; i < 6; ++i) dw[i] = quad_sum(dw[i]);
-      c.ph.set_w(dw);
+      ph_.set_w(dw);
       for (int it = 0; it < L.solver_iterations; ++it)
         for (int turn = 0; turn < 4; ++turn) {
-          c.ph.sweep(lane == turn ? 1.f : 0.f, dw);
+          ph_.sweep(lane == turn ? 1.f : 0.f, dw);
 #pragma unroll
           for (int i = 0; i < 6; ++i) tot[i] = quad_sum(dw[i]);
-          c.ph.add_others(tot, dw);
+          ph_.add_others(tot, dw);
         }
-      c.ph.phaseD(t, L);
+      ph_.phaseD(t, L);
     }
     float fb[9];
-    lane_finish_phys(c, tab, p, L, e, lane, fb);
+    lane_finish_phys(ph_, po_, ax, tab, p, L, e, lane, fb);
 #pragma unroll
     for (int i = 0; i < 9; ++i) fb[i] = quad_sum(fb[i]);
-    lane_store_base_forces(c, p, L, e, lane, fb);
+    lane_store_base_forces(ph_, po_, ax, p, L, e, lane, fb);
   } else {
-    lane_load_physout(c, tab, p, L, e, lane);
+    lane_load_physout(ph_, po_, ax, tab, p, L, e, lane);
   }
   if (MODE & MODE_POST) {
-    lane_init_post(c, &p, &L, &S, e, lane);
+    lane_init_post(ph_, po_, ax, &p, &L, &S, e, lane);
     float part[GO2_POST_PARTIALS];
-    c.po.postA(t, part);
+    po_.postA(t, part);
 #pragma unroll
     for (int i = 0; i < GO2_POST_PARTIALS; ++i) part[i] = quad_sum(part[i]);
-    float fr = quad_sum(c.po.regulation(part));
-    c.po.postB(t, part, fr);
+    float fr = quad_sum(po_.regulation(part));
+    po_.postB(t, part, fr);
   }
 }
 
@@ -583,51 +584,52 @@ static void emu_run(Go2Sim* s, int mode, const float* actions_in, int initial_re
   Go2Tables& tab = *s->d_tables; const Go2Ptrs& p = blk->p; const Go2Launch& L = blk->L;
   Go2Step S; go2_step_scalars(L, blk->dyn, p.inj_storage, blk->dyn.common_step_counter + ((mode & MODE_POST) ? 1 : 0), initial_reset, &S);
   for (int e = 0; e < L.N; ++e) {
-    static thread_local LaneCtx c[4];
+    static thread_local LegPhys c_ph[4]; static thread_local LegPost c_po[4]; static thread_local LaneAux c_ax[4];
     if (mode & MODE_RESET_ALL) {
       float red[GO2_POST_PARTIALS]; for (int i = 0; i < GO2_POST_PARTIALS; ++i) red[i] = 0.f;
       for (int l = 0; l < 4; ++l) {
-        lane_reset_all(c[l], tab, p, L, S, e, l); c[l].po.reset = 1; c[l].po.time_out = 0; c[l].po.blv = v3(0, 0, 0); c[l].po.bav = v3(0, 0, 0); c[l].po.pg = v3(0, 0, -1);
-        c[l].po.rpy[0] = c[l].po.rpy[1] = c[l].po.rpy[2] = 0.f; c[l].po.own_f2b = 0; c[l].po.own_fvel2 = 0;
+        lane_reset_all(LANE_ARGS(l), tab, p, L, S, e, l); c_po[l].reset = 1; c_po[l].time_out = 0; c_po[l].blv = v3(0, 0, 0); c_po[l].bav = v3(0, 0, 0); c_po[l].pg = v3(0, 0, -1);
+        c_po[l].rpy[0] = c_po[l].rpy[1] = c_po[l].rpy[2] = 0.f; c_po[l].own_f2b = 0; c_po[l].own_fvel2 = 0;
       }
-      for (int l = 0; l < 4; ++l) c[l].po.postB(tab.leg[l], red, 0.f);
+      for (int l = 0; l < 4; ++l) c_po[l].postB(tab.leg[l], red, 0.f);
       continue;
     }
     if (mode & MODE_PHYS) {
-      for (int l = 0; l < 4; ++l) lane_load_phys(c[l], tab, p, L, S, actions_in, e, l);
+      for (int l = 0; l < 4; ++l) lane_load_phys(LANE_ARGS(l), tab, p, L, S, actions_in, e, l);
       for (int sub = 0; sub < L.decimation; ++sub) {
         float part[4][GO2_QUAD_PARTIALS], red[GO2_QUAD_PARTIALS], dw[4][6], tot[6];
         for (int l = 0; l < 4; ++l) {
-          const float* a = (L.rand_delay && sub < c[l].start) ? c[l].act_old : c[l].act_new;
-          c[l].ph.pd(tab.leg[l], L, l, a, c[l].kpm, c[l].kdm, c[l].zoff, c[l].strength);
-          c[l].ph.phaseA(tab.leg[l], L, part[l]);
+          const bool old = L.rand_delay && sub < c_ax[l].start;
+          const float a[3] = {old ? c_ax[l].act_old[0] : c_ax[l].act_new[0], old ? c_ax[l].act_old[1] : c_ax[l].act_new[1], old ? c_ax[l].act_old[2] : c_ax[l].act_new[2]};
+          c_ph[l].pd(tab.leg[l], L, l, a, c_ax[l].kpm, c_ax[l].kdm, c_ax[l].zoff, c_ax[l].strength);
+          c_ph[l].phaseA(tab.leg[l], L, part[l]);
         }
         for (int i = 0; i < GO2_QUAD_PARTIALS; ++i) red[i] = quad_sum4(part[0][i], part[1][i], part[2][i], part[3][i]);
-        for (int l = 0; l < 4; ++l) { c[l].ph.phaseB(L, red); c[l].ph.phaseC(tab.leg[l], L, p.hf, dw[l]); }
+        for (int l = 0; l < 4; ++l) { c_ph[l].phaseB(L, red); c_ph[l].phaseC(tab.leg[l], L, p.hf, dw[l]); }
         for (int i = 0; i < 6; ++i) tot[i] = quad_sum4(dw[0][i], dw[1][i], dw[2][i], dw[3][i]);
-        for (int l = 0; l < 4; ++l) c[l].ph.set_w(tot);
+        for (int l = 0; l < 4; ++l) c_ph[l].set_w(tot);
         for (int it = 0; it < L.solver_iterations; ++it)
           for (int turn = 0; turn < 4; ++turn) {
-            for (int l = 0; l < 4; ++l) c[l].ph.sweep(l == turn ? 1.f : 0.f, dw[l]);
+            for (int l = 0; l < 4; ++l) c_ph[l].sweep(l == turn ? 1.f : 0.f, dw[l]);
             for (int i = 0; i < 6; ++i) tot[i] = quad_sum4(dw[0][i], dw[1][i], dw[2][i], dw[3][i]);
-            for (int l = 0; l < 4; ++l) c[l].ph.add_others(tot, dw[l]);
+            for (int l = 0; l < 4; ++l) c_ph[l].add_others(tot, dw[l]);
           }
-        for (int l = 0; l < 4; ++l) c[l].ph.phaseD(tab.leg[l], L);
+        for (int l = 0; l < 4; ++l) c_ph[l].phaseD(tab.leg[l], L);
       }
       float fb[4][9], fbs[9];
-      for (int l = 0; l < 4; ++l) lane_finish_phys(c[l], tab, p, L, e, l, fb[l]);
+      for (int l = 0; l < 4; ++l) lane_finish_phys(LANE_ARGS(l), tab, p, L, e, l, fb[l]);
       for (int i = 0; i < 9; ++i) fbs[i] = quad_sum4(fb[0][i], fb[1][i], fb[2][i], fb[3][i]);
-      for (int l = 0; l < 4; ++l) lane_store_base_forces(c[l], p, L, e, l, fbs);
+      for (int l = 0; l < 4; ++l) lane_store_base_forces(LANE_ARGS(l), p, L, e, l, fbs);
     } else {
-      for (int l = 0; l < 4; ++l) lane_load_physout(c[l], tab, p, L, e, l);
+      for (int l = 0; l < 4; ++l) lane_load_physout(LANE_ARGS(l), tab, p, L, e, l);
     }
     if (mode & MODE_POST) {
       float part[4][GO2_POST_PARTIALS], red[GO2_POST_PARTIALS], fr[4];
-      for (int l = 0; l < 4; ++l) { lane_init_post(c[l], &p, &L, &S, e, l); c[l].po.postA(tab.leg[l], part[l]); }
+      for (int l = 0; l < 4; ++l) { lane_init_post(LANE_ARGS(l), &p, &L, &S, e, l); c_po[l].postA(tab.leg[l], part[l]); }
       for (int i = 0; i < GO2_POST_PARTIALS; ++i) red[i] = quad_sum4(part[0][i], part[1][i], part[2][i], part[3][i]);
-      for (int l = 0; l < 4; ++l) fr[l] = c[l].po.regulation(red);
+      for (int l = 0; l < 4; ++l) fr[l] = c_po[l].regulation(red);
       float frs = quad_sum4(fr[0], fr[1], fr[2], fr[3]);
-      for (int l = 0; l < 4; ++l) c[l].po.postB(tab.leg[l], red, frs);
+      for (int l = 0; l < 4; ++l) c_po[l].postB(tab.leg[l], red, frs);
     }
   }
   if (mode != MODE_PHYS) {   // == go2_finish_kernel
@@ -646,7 +648,7 @@ static int launch(Go2Sim* s, int mode, const float* actions_in, int initial_rese
 #else
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((s->N + 15) / 16), block(64);
-  bool timed = s->timing && (mode & MODE_PHYS);
+  bool timed = s->timing != 0;
   if (timed) {
     if (s->ev_used + 2 > s->ev.size()) { size_t n0 = s->ev.size(); s->ev.resize(n0 + 512); for (size_t i = n0; i < s->ev.size(); ++i) HIPCHK(hipEventCreate(&s->ev[i])); }
     HIPCHK(hipEventRecord(s->ev[s->ev_used], st));
