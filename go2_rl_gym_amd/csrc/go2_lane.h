@@ -234,13 +234,19 @@ struct LegPhys {
     }
     dw_out[0] = dw.a.x; dw_out[1] = dw.a.y; dw_out[2] = dw.a.z; dw_out[3] = dw.l.x; dw_out[4] = dw.l.y; dw_out[5] = dw.l.z;
   }
+  GO2_HD bool has_foot() const { return cs[0].active > 0.f; }
+  GO2_HD bool has_other() const { return cs[1].active > 0.f; }
+  GO2_HD bool has_limit() const { return (lr[0].active + lr[1].active + lr[2].active) > 0.f; }
   GO2_HD void set_w(const float* wsum) { w = sv(v3(wsum[0], wsum[1], wsum[2]), v3(wsum[3], wsum[4], wsum[5])); }
 
-  // one Gauss-Seidel sweep over this lane's rows; `on` = 1 for the lane whose turn it is, else 0
-  GO2_HD void sweep(float on, float* dw_out) {
+  // one Gauss-Seidel sweep over this lane's rows; `on` = 1 for the lane whose turn it is, else 0.
+  // do_slot[s] / do_lim are WAVE-UNIFORM hints: false means no lane of the wave has such a row active this substep, so the
+  // group is skipped as a whole (an inactive row contributes exactly +0, so skipping changes no bit of the result).
+  GO2_HD void sweep(float on, float* dw_out, bool do_foot = true, bool do_other = true, bool do_lim = true) {
     SV dw = sv(v3(0, 0, 0), v3(0, 0, 0));
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
+      if (!(s == 0 ? do_foot : do_other)) continue;
       ContactSlot& c = cs[s];
       float m = on * c.active;
       {
@@ -261,6 +267,7 @@ struct LegPhys {
         SV d = d1 * c.H[1] + d2 * c.H[2]; w = w + d; dw = dw + d;
       }
     }
+    if (do_lim)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       LimitRow& r = lr[j];

@@ -75,9 +75,19 @@ struct LegPost {
   uint8_t reset, time_out;
   float act[3], last_act[3], llast_act[3], last_dv[3];
 
-  GO2_HD float uni(int slot) const {
+  // Uniform `slot` of this env-step (contract: include/go2sim_rng.h).  Slots a lane consumes together share a Philox group and
+  // are requested back to back, so a one-entry group cache turns ~10 Philox calls into ~2-4; the hit/miss pattern is the same
+  // in every lane of the wave (the group index differs per lane, the sequence does not), so the refill branch is uniform.
+  const uint8_t* codes; int cg; uint32_t cw0, cw1, cw2, cw3;
+  GO2_HD float uni(int slot) {
     if (S->injected) return S->injected[(size_t)e * GO2_NUM_UNIFORMS + slot];
-    return philox_u01((uint32_t)(L->env_offset + e), (uint32_t)(slot >> 2), S->step_lo, S->step_hi, L->seed_lo, L->seed_hi, slot & 3);
+    const int code = codes[slot], g = code >> 2, w = code & 3;
+    if (g != cg) {
+      uint32_t r[4];
+      philox4x32_10((uint32_t)(L->env_offset + e), (uint32_t)g, S->step_lo, S->step_hi, L->seed_lo, L->seed_hi, r);
+      cg = g; cw0 = r[0]; cw1 = r[1]; cw2 = r[2]; cw3 = r[3];
+    }
+    return u01_from_bits(w == 0 ? cw0 : (w == 1 ? cw1 : (w == 2 ? cw2 : cw3)));
   }
   GO2_HD static float urange(float u, float lo, float hi) { return (hi - lo) * u + lo; }
   GO2_HD void cmd_range(int which, float* lo, float* hi) const {  // env_command_ranges (:861-907)
@@ -141,6 +151,20 @@ struct LegPost {
     }
     acc[0] += cmd[0]; acc[1] += cmd[1];
   }
+  // one sample of _get_heights (:1188-1224) around base (bx, by) with yaw quaternion (0,0,yz,yw)
+  float hq_z, hq_w, hpx, hpy;
+  GO2_HD float height_at(int i, float yz, float yw, float bx, float by) const {
+    const Go2Launch& c = *L;
+    if (c.terrain_mode == 0) return 0.f;
+    const int ix = i / 11, iy = i - 11 * ix;
+    V3 w = quat_apply(0.f, 0.f, yz, yw, v3((float)(ix - 8) * 0.1f, (float)(iy - 5) * 0.1f, 0.f));
+    float x = (w.x + bx + c.hf_border) / c.hf_hscale, y = (w.y + by + c.hf_border) / c.hf_hscale;
+    int px = (int)x, py = (int)y;
+    px = px < 0 ? 0 : (px > c.hf_rows - 2 ? c.hf_rows - 2 : px); py = py < 0 ? 0 : (py > c.hf_cols - 2 ? c.hf_cols - 2 : py);
+    int h1 = P->hf[px * c.hf_cols + py], h2 = P->hf[(px + 1) * c.hf_cols + py], h3 = P->hf[px * c.hf_cols + py + 1];
+    int hm = h1 < h2 ? h1 : h2; hm = h3 < hm ? h3 : hm;
+    return hm * c.hf_vscale;
+  }
   GO2_HD float dyn_sigma(float vabs, float vmin, float vmax) const {  // :1300-1320
     float def = L->tracking_sigma; int kind = P->terrain_kind[e];
     if (!L->terrain_curriculum || !L->dyn_sigma || kind < 0) return def;
@@ -184,18 +208,10 @@ struct LegPost {
     float hsum = 0.f;
     if (c.measure_heights) {
       float nn = fmaxf(sqrtf(qz * qz + qw * qw), 1e-9f), yz = qz / nn, yw = qw / nn;  // quat_apply_yaw (utils/math.py:8-12)
+      hq_z = yz; hq_w = yw; hpx = o.pw.x; hpy = o.pw.y;
       for (int i = lane; i < GO2_NUM_HEIGHT_POINTS; i += 4) {
-        float hv = 0.f;
-        int ix = i / 11, iy = i - 11 * ix;
-        if (c.terrain_mode != 0) {
-          V3 w = quat_apply(0.f, 0.f, yz, yw, v3((float)(ix - 8) * 0.1f, (float)(iy - 5) * 0.1f, 0.f));
-          float x = (w.x + o.pw.x + c.hf_border) / c.hf_hscale, y = (w.y + o.pw.y + c.hf_border) / c.hf_hscale;
-          int px = (int)x, py = (int)y;
-          px = px < 0 ? 0 : (px > c.hf_rows - 2 ? c.hf_rows - 2 : px); py = py < 0 ? 0 : (py > c.hf_cols - 2 ? c.hf_cols - 2 : py);
-          int h1 = p.hf[px * c.hf_cols + py], h2 = p.hf[(px + 1) * c.hf_cols + py], h3 = p.hf[px * c.hf_cols + py + 1];
-          int hm = h1 < h2 ? h1 : h2; hm = h3 < hm ? h3 : hm;
-          hv = hm * c.hf_vscale;
-        }
+        const float hv = height_at(i, yz, yw, o.pw.x, o.pw.y);
+        const int ix = i / 11, iy = i - 11 * ix;
         F2D(p.heights, i, e) = hv;
         if (ix >= 6 && ix <= 10 && iy >= 4 && iy <= 6) hsum += hv;   // base_height_scan_mask (:790-796)
       }
@@ -325,12 +341,12 @@ struct LegPost {
     // ---- reset_idx (:180-245) ---------------------------------------------------------------------
     float ox = org_x, oy = org_y, oz = org_z;
     if (reset) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        int d = 3 * lane + j;
-        if (c.rand_strength) F2D(p.strength, d, e) = urange(uni(GO2_U_RESET_STRENGTH + d), c.strength_rng[0], c.strength_rng[1]);
-        if (c.rand_offset) F2D(p.zero_off, d, e) = urange(uni(GO2_U_RESET_OFFSET + d), c.offset_rng[0], c.offset_rng[1]);
-        if (c.rand_pd) { F2D(p.kp_mul, d, e) = urange(uni(GO2_U_RESET_KP + d), c.kp_rng[0], c.kp_rng[1]); F2D(p.kd_mul, d, e) = urange(uni(GO2_U_RESET_KD + d), c.kd_rng[0], c.kd_rng[1]); }
+      // field-major request order (strength x3, offset x3, kp x3, kd x3): 3 Philox groups per lane (go2sim_rng.h)
+      if (c.rand_strength) _Pragma("unroll") for (int j = 0; j < 3; ++j) F2D(p.strength, 3 * lane + j, e) = urange(uni(GO2_U_RESET_STRENGTH + 3 * lane + j), c.strength_rng[0], c.strength_rng[1]);
+      if (c.rand_offset) _Pragma("unroll") for (int j = 0; j < 3; ++j) F2D(p.zero_off, 3 * lane + j, e) = urange(uni(GO2_U_RESET_OFFSET + 3 * lane + j), c.offset_rng[0], c.offset_rng[1]);
+      if (c.rand_pd) {
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) F2D(p.kp_mul, 3 * lane + j, e) = urange(uni(GO2_U_RESET_KP + 3 * lane + j), c.kp_rng[0], c.kp_rng[1]);
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) F2D(p.kd_mul, 3 * lane + j, e) = urange(uni(GO2_U_RESET_KD + 3 * lane + j), c.kd_rng[0], c.kd_rng[1]);
       }
       if (c.terrain_curriculum && c.terrain_mode != 0 && !S->initial_reset) {   // _update_terrain_curriculum (:1143-1169)
         float dist = max_move;
@@ -387,25 +403,33 @@ struct LegPost {
     float cl = c.clip_obs;
     float* ob = p.obs + (size_t)e * GO2_NUM_OBS; float* pv = p.priv + (size_t)e * GO2_NUM_PRIV_OBS;
 #define CLIP(x) fminf(fmaxf((x), -cl), cl)
-#define NOISE(i) (c.add_noise ? (2.f * uni(GO2_U_NOISE + (i)) - 1.f) * c.noise_vec[(i)] : 0.f)
+#define NOISE(i) ((c.add_noise && c.noise_vec[(i)] != 0.f) ? (2.f * uni(GO2_U_NOISE + (i)) - 1.f) * c.noise_vec[(i)] : 0.f)
     if (lane == 0) {
       float s9[9] = {bav.x * c.os_ang, bav.y * c.os_ang, bav.z * c.os_ang, pg.x, pg.y, pg.z, cmd[0] * c.os_lin, cmd[1] * c.os_lin, cmd[2] * c.os_ang};
       pv[0] = CLIP(blv.x * c.os_lin); pv[1] = CLIP(blv.y * c.os_lin); pv[2] = CLIP(blv.z * c.os_lin);
       _Pragma("unroll") for (int i = 0; i < 9; ++i) { pv[3 + i] = CLIP(s9[i]); ob[i] = CLIP(s9[i] + NOISE(i)); }
     }
+    float ndp[3], ndv[3];   // noise of this leg's joints: 3 + 3 requests = 2 Philox groups
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) ndp[j] = NOISE(9 + 3 * lane + j);
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) ndv[j] = NOISE(21 + 3 * lane + j);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       int d = 3 * lane + j;
       float dp = (o.q[j] - c.q0[d]) * c.os_dof_pos, dv = o.qd[j] * c.os_dof_vel;
       pv[3 + 9 + d] = CLIP(dp); pv[3 + 21 + d] = CLIP(dv); pv[3 + 33 + d] = CLIP(act[j]);
-      ob[9 + d] = CLIP(dp + NOISE(9 + d)); ob[21 + d] = CLIP(dv + NOISE(21 + d)); ob[33 + d] = CLIP(act[j] + NOISE(33 + d));
+      ob[9 + d] = CLIP(dp + ndp[j]); ob[21 + d] = CLIP(dv + ndv[j]); ob[33 + d] = CLIP(act[j] + NOISE(33 + d));
       pv[52 + d] = CLIP(o.tau[j] / t.eff_lim[j]);
       pv[64 + d] = CLIP((last_dv[j] - o.qd[j]) / c.dt * 1e-4f);
     }
     pv[48 + lane] = CLIP(sqrtf(dot(o.Ffoot, o.Ffoot)) * 1e-3f);
-    for (int i = lane; i < GO2_NUM_HEIGHT_POINTS; i += 4) {
-      float hh = fminf(fmaxf(o.pw.z - 0.5f - F2D(p.heights, i, e), -1.f), 1.f);
-      pv[76 + i] = CLIP(hh * c.os_height);
+    if (c.terrain_mode == 0 || !c.measure_heights) {      // plane: every sample is 0 (:1201-1202), nothing to read back
+      const float hv = CLIP(fminf(fmaxf(o.pw.z - 0.5f, -1.f), 1.f) * c.os_height);
+      for (int i = lane; i < GO2_NUM_HEIGHT_POINTS; i += 4) pv[76 + i] = hv;
+    } else {
+      for (int i = lane; i < GO2_NUM_HEIGHT_POINTS; i += 4) {
+        float hh = fminf(fmaxf(o.pw.z - 0.5f - height_at(i, hq_z, hq_w, hpx, hpy), -1.f), 1.f);   // same samples as postA (pre-reset pose, App. E.3)
+        pv[76 + i] = CLIP(hh * c.os_height);
+      }
     }
 #undef CLIP
 #undef NOISE

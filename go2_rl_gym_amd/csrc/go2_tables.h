@@ -29,7 +29,7 @@ struct BaseTab {
   float head[2][10];                // Head_upper, Head_lower about the base origin
   float body_off[3][4];             // frame origins of base, Head_upper, Head_lower in the base frame
 };
-struct Go2Tables { LegTab leg[4]; BaseTab base; };
+struct Go2Tables { LegTab leg[4]; BaseTab base; uint8_t slot_code[GO2_NUM_UNIFORMS]; /* include/go2sim_rng.h */ };
 
 // Device/host pointers of every per-env field.  The HIP library stores per-env fields FIELD-MAJOR (SoA):
 // logical [N, a, b] lives at ((b_idx * A + a_idx) * N + env), i.e. C order of the reversed logical dims,
@@ -43,7 +43,7 @@ struct Go2Ptrs {
   float *ep_sums, *friction, *restitution, *added_mass, *added_com, *mass_ratio, *episode_info, *foot_impulse;
   // internal
   int32_t* terrain_kind; float* ep_accum /*[NUM_REWARDS+1]*/; const float* inj_storage; const int16_t* hf; const float* terrain_origins;
-  const Go2Tables* tables;
+  const Go2Tables* tables; long long* dbg_clock;
 };
 
 // everything a launch needs besides pointers: config constants + the host-side scalars of this step

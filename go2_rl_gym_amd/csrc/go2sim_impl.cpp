@@ -17,6 +17,7 @@
 
 #include "../../include/go2sim.h"
 #include "../../include/go2sim_defaults.h"
+#include "../../include/go2sim_rng.h"
 #include "go2_lane.h"
 #include "go2_post.h"
 
@@ -169,14 +170,15 @@ GO2_HD void lane_load_physout(LANE_PARAMS, const Go2Tables& tab, const Go2Ptrs& 
   o.foot_pos = v3(F3D(p.rigid, 19, fb, 0, e), F3D(p.rigid, 19, fb, 1, e), F3D(p.rigid, 19, fb, 2, e));
   o.foot_vel = v3(F3D(p.rigid, 19, fb, 7, e), F3D(p.rigid, 19, fb, 8, e), F3D(p.rigid, 19, fb, 9, e));
 }
-GO2_HD void lane_init_post(LANE_PARAMS, const Go2Ptrs* p, const Go2Launch* L, const Go2Step* S, int e, int lane) {
+GO2_HD void lane_init_post(LANE_PARAMS, const uint8_t* codes, const Go2Ptrs* p, const Go2Launch* L, const Go2Step* S, int e, int lane) {
+  po_.codes = codes; po_.cg = -1; po_.cw0 = po_.cw1 = po_.cw2 = po_.cw3 = 0u;
   po_.e = e; po_.lane = lane; po_.N = L->N; po_.P = p; po_.L = L; po_.S = S;
 }
 // reset_idx(all envs) without a step (base_task.py:82-84): postB's reset branch with reset forced on
 GO2_HD void lane_reset_all(LANE_PARAMS, const Go2Tables& tab, const Go2Ptrs& p, const Go2Launch& L, const Go2Step& S, int e, int lane) {
   const int N = L.N;
   lane_load_physout(ph_, po_, ax, tab, p, L, e, lane);
-  lane_init_post(ph_, po_, ax, &p, &L, &S, e, lane);
+  lane_init_post(ph_, po_, ax, tab.slot_code, &p, &L, &S, e, lane);
   LegPost& po = po_;
   // load what postA would have loaded, without advancing any clock
   po.ep_len = p.ep_len[e]; po.timer = p.cmd_timer[e];
@@ -209,6 +211,9 @@ __global__ void __launch_bounds__(64) go2_step_kernel(const Go2DevBlock* __restr
   __syncthreads();
   const int e = blockIdx.x * 16 + (threadIdx.x >> 2), lane = threadIdx.x & 3;
   if (e >= L.N) return;   // whole quads leave together
+  long long* dbg = p.dbg_clock ? p.dbg_clock + (size_t)blockIdx.x * 16 : nullptr;   // optional phase timestamps (tools/kbench.py)
+#define STAMP(k) do { if (dbg && threadIdx.x == 0) dbg[k] = wall_clock64(); } while (0)
+  STAMP(0);
   LegPhys ph_; LegPost po_; LaneAux ax;
   const LegTab& t = tab.leg[lane];
   if (MODE & MODE_RESET_ALL) {
@@ -224,6 +229,7 @@ __global__ void __launch_bounds__(64) go2_step_kernel(const Go2DevBlock* __restr
   }
   if (MODE & MODE_PHYS) {
     lane_load_phys(ph_, po_, ax, tab, p, L, S, actions_in, e, lane);
+    STAMP(1);
     for (int sub = 0; sub < L.decimation; ++sub) {
       const bool old = L.rand_delay && sub < ax.start;
       const float a[3] = {old ? ax.act_old[0] : ax.act_new[0], old ? ax.act_old[1] : ax.act_new[1], old ? ax.act_old[2] : ax.act_new[2]};
@@ -238,15 +244,18 @@ __global__ void __launch_bounds__(64) go2_step_kernel(const Go2DevBlock* __restr
 #pragma unroll
       for (int i = 0; i < 6; ++i) dw[i] = quad_sum(dw[i]);
       ph_.set_w(dw);
+      // wave-wide row-group activity (ballots -> scalar branches): typically only the foot contacts are live
+      const bool any_foot = __any(ph_.has_foot()), any_other = __any(ph_.has_other()), any_lim = __any(ph_.has_limit());
       for (int it = 0; it < L.solver_iterations; ++it)
         for (int turn = 0; turn < 4; ++turn) {
-          ph_.sweep(lane == turn ? 1.f : 0.f, dw);
+          ph_.sweep(lane == turn ? 1.f : 0.f, dw, any_foot, any_other, any_lim);
 #pragma unroll
           for (int i = 0; i < 6; ++i) tot[i] = quad_sum(dw[i]);
           ph_.add_others(tot, dw);
         }
       ph_.phaseD(t, L);
     }
+    STAMP(2);
     float fb[9];
     lane_finish_phys(ph_, po_, ax, tab, p, L, e, lane, fb);
 #pragma unroll
@@ -255,14 +264,17 @@ __global__ void __launch_bounds__(64) go2_step_kernel(const Go2DevBlock* __restr
   } else {
     lane_load_physout(ph_, po_, ax, tab, p, L, e, lane);
   }
+  STAMP(3);
   if (MODE & MODE_POST) {
-    lane_init_post(ph_, po_, ax, &p, &L, &S, e, lane);
+    lane_init_post(ph_, po_, ax, tab.slot_code, &p, &L, &S, e, lane);
     float part[GO2_POST_PARTIALS];
     po_.postA(t, part);
+    STAMP(4);
 #pragma unroll
     for (int i = 0; i < GO2_POST_PARTIALS; ++i) part[i] = quad_sum(part[i]);
     float fr = quad_sum(po_.regulation(part));
     po_.postB(t, part, fr);
+    STAMP(5);
   }
 }
 
@@ -278,12 +290,11 @@ __global__ void go2_finish_kernel(Go2DevBlock* blk, int counter_inc) {
   }
   if (i == 0) { blk->dyn.common_step_counter += counter_inc; blk->dyn.step_count += 1; blk->dyn.use_injected = 0; }
 }
-__global__ void go2_peek_kernel(float* out, int N, int env_offset, uint32_t s0, uint32_t s1, uint32_t k0, uint32_t k1) {
+__global__ void go2_peek_kernel(float* out, const Go2Tables* tab, int N, int env_offset, uint32_t s0, uint32_t s1, uint32_t k0, uint32_t k1) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N * (GO2_NUM_UNIFORMS / 4)) return;
-  int e = i / (GO2_NUM_UNIFORMS / 4), blk = i % (GO2_NUM_UNIFORMS / 4);
-  uint32_t r[4]; philox4x32_10((uint32_t)(env_offset + e), (uint32_t)blk, s0, s1, k0, k1, r);
-  for (int k = 0; k < 4; ++k) out[(size_t)e * GO2_NUM_UNIFORMS + 4 * blk + k] = u01_from_bits(r[k]);
+  if (i >= N * GO2_NUM_UNIFORMS) return;
+  int e = i / GO2_NUM_UNIFORMS, slot = i % GO2_NUM_UNIFORMS, code = tab->slot_code[slot];
+  out[i] = philox_u01((uint32_t)(env_offset + e), (uint32_t)(code >> 2), s0, s1, k0, k1, code & 3);
 }
 // GAE(lambda) reverse scan, one lane per env (rollout_storage.py:123-137); block partials -> fp64 atomics
 __global__ void __launch_bounds__(256) go2_gae_kernel(const float* rew, const uint8_t* dones, const float* val, const float* last, float* ret, float* adv,
@@ -394,6 +405,7 @@ static void fill_tables(Go2Tables* T) {
   for (int k = 0; k < 6; ++k) T->base.Ic0[k] = (float)kIn[0][k];
   body10(1, T->base.head[0]); body10(2, T->base.head[1]);
   for (int b = 0; b < 3; ++b) for (int k = 0; k < 3; ++k) T->base.body_off[b][k] = (float)kOff[b][k];
+  go2_fill_slot_codes(T->slot_code);
 }
 
 
@@ -625,7 +637,7 @@ static void emu_run(Go2Sim* s, int mode, const float* actions_in, int initial_re
     }
     if (mode & MODE_POST) {
       float part[4][GO2_POST_PARTIALS], red[GO2_POST_PARTIALS], fr[4];
-      for (int l = 0; l < 4; ++l) { lane_init_post(LANE_ARGS(l), &p, &L, &S, e, l); c_po[l].postA(tab.leg[l], part[l]); }
+      for (int l = 0; l < 4; ++l) { lane_init_post(LANE_ARGS(l), tab.slot_code, &p, &L, &S, e, l); c_po[l].postA(tab.leg[l], part[l]); }
       for (int i = 0; i < GO2_POST_PARTIALS; ++i) red[i] = quad_sum4(part[0][i], part[1][i], part[2][i], part[3][i]);
       for (int l = 0; l < 4; ++l) fr[l] = c_po[l].regulation(red);
       float frs = quad_sum4(fr[0], fr[1], fr[2], fr[3]);
@@ -665,6 +677,13 @@ static int launch(Go2Sim* s, int mode, const float* actions_in, int initial_rese
   return 0;
 }
 
+// oracle-less debugging aid used by tools/kbench.py (not part of include/go2sim.h): per-workgroup phase timestamps
+int go2sim_debug_clock(Go2Sim* s, long long* dev_buf) {
+  if (!s) return GO2SIM_EINVAL;
+  s->h.p.dbg_clock = dev_buf;
+  dev_upload(&s->d_blk->p, &s->h.p, sizeof(Go2Ptrs));
+  return 0;
+}
 int go2sim_enable_timing(Go2Sim* s, int en) {
   if (!s) return GO2SIM_EINVAL;
   s->timing = en; s->time_ms = 0; s->time_launches = 0;
@@ -722,10 +741,10 @@ int go2sim_peek_uniforms(Go2Sim* s, float* out, void* stream) {
   uint64_t sc = s->h.dyn.step_count;
 #ifdef GO2_EMU
   (void)stream;
-  for (int e = 0; e < s->N; ++e) for (int k = 0; k < GO2_NUM_UNIFORMS; ++k) out[(size_t)e * GO2_NUM_UNIFORMS + k] = u01_host(s->cfg.seed, (uint32_t)(s->cfg.env_offset + e), (uint32_t)k, sc);
+  for (int e = 0; e < s->N; ++e) for (int k = 0; k < GO2_NUM_UNIFORMS; ++k) out[(size_t)e * GO2_NUM_UNIFORMS + k] = u01_host(s->cfg.seed, (uint32_t)(s->cfg.env_offset + e), (uint32_t)s->d_tables->slot_code[k], sc);
 #else
-  int n = s->N * (GO2_NUM_UNIFORMS / 4);
-  hipLaunchKernelGGL(go2_peek_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, s->N, s->cfg.env_offset, (uint32_t)sc, (uint32_t)(sc >> 32), (uint32_t)s->cfg.seed, (uint32_t)(s->cfg.seed >> 32));
+  int n = s->N * GO2_NUM_UNIFORMS;
+  hipLaunchKernelGGL(go2_peek_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, s->d_tables, s->N, s->cfg.env_offset, (uint32_t)sc, (uint32_t)(sc >> 32), (uint32_t)s->cfg.seed, (uint32_t)(s->cfg.seed >> 32));
   HIPCHK(hipGetLastError());
 #endif
   return 0;

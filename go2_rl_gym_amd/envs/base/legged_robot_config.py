@@ -215,7 +215,7 @@ class LeggedRobotCfg(BaseConfig):
             contact_collection = 2
 
         class solver:                      # parameters of this build's own contact solver
-            iterations = 8
+            iterations = 4                 # = physx.num_position_iterations
             erp = 0.5
             cfm = 1e-3
             joint_limit_margin = 0.05

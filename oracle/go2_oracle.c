@@ -110,6 +110,13 @@ static float u01(uint64_t seed, uint32_t env_global, uint32_t slot, uint64_t ste
   philox4x32_10(ctr, key, o);
   return (float)((o[slot & 3] >> 8) * (1.0 / 16777216.0));
 }
+/* per-step uniforms: slot -> (group, word) by the shared contract table (include/go2sim_rng.h) */
+#include "../include/go2sim_rng.h"
+static float u01_step(uint64_t seed, uint32_t env_global, uint32_t slot, uint64_t step) {
+  static uint8_t code[GO2_NUM_UNIFORMS]; static int init = 0;
+  if (!init) { go2_fill_slot_codes(code); init = 1; }
+  return u01(seed, env_global, (uint32_t)code[slot], step);   /* code = group*4 + word: u01 splits it as >>2, &3 */
+}
 
 /* ------------------------------------------------------------------------------------------------
  * small linear algebra
@@ -601,7 +608,7 @@ static void env_cmd_range(const Go2Sim* s, int e, int which, R* lo, R* hi) {
 
 static inline R uni(const Go2Sim* s, int e, int slot) {
   if (s->injected) return (R)s->injected[(size_t)e*GO2_NUM_UNIFORMS + slot];
-  return (R)u01(s->cfg.seed, (uint32_t)(s->cfg.env_offset + e), (uint32_t)slot, s->step_count);
+  return (R)u01_step(s->cfg.seed, (uint32_t)(s->cfg.env_offset + e), (uint32_t)slot, s->step_count);
 }
 static inline R urange(R u, R lo, R hi) { return (hi-lo)*u + lo; } /* torch_rand_float */
 
@@ -1048,7 +1055,7 @@ int go2sim_inject_uniforms(Go2Sim* s, const float* u, void* stream) {
 }
 int go2sim_peek_uniforms(Go2Sim* s, float* out, void* stream) {
   (void)stream; if (!s||!out) return GO2SIM_EINVAL;
-  for (int e=0;e<s->N;++e) for (int k=0;k<GO2_NUM_UNIFORMS;++k) out[(size_t)e*GO2_NUM_UNIFORMS+k]=u01(s->cfg.seed,(uint32_t)(s->cfg.env_offset+e),(uint32_t)k,s->step_count);
+  for (int e=0;e<s->N;++e) for (int k=0;k<GO2_NUM_UNIFORMS;++k) out[(size_t)e*GO2_NUM_UNIFORMS+k]=u01_step(s->cfg.seed,(uint32_t)(s->cfg.env_offset+e),(uint32_t)k,s->step_count);
   return 0;
 }
 
