@@ -94,7 +94,6 @@ def main():
 
     runner.learn(a.warmup, init_at_random_ep_len=True)        # untimed: also brings resets/pushes/resamples to steady state
 
-    env.lib.go2sim_enable_timing(env.handle, 1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -107,6 +106,13 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    # The rollout is replayed from a HIP graph, where per-launch events cannot be recorded; so the dominant kernel is timed
+    # right after the timed region, live, with HIP events on the stream it is launched on: 48 eager env steps from the same
+    # (steady-state) simulator state under the current policy.  profiles/*kernel_stats.csv of the same command must agree.
+    env.lib.go2sim_enable_timing(env.handle, 1)
+    with torch.inference_mode():
+        for _ in range(48):
+            env.step(runner.alg.actor_critic.act(env.get_observations()))
     ms, n = C.c_double(), C.c_int64()
     env.lib.go2sim_kernel_time(env.handle, C.byref(ms), C.byref(n))
     env.lib.go2sim_enable_timing(env.handle, 0)

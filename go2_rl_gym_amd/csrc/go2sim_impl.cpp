@@ -661,6 +661,7 @@ static int launch(Go2Sim* s, int mode, const float* actions_in, int initial_rese
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((s->N + 15) / 16), block(64);
   bool timed = s->timing != 0;
+  { hipStreamCaptureStatus cs = hipStreamCaptureStatusNone; if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) timed = false; }
   if (timed) {
     if (s->ev_used + 2 > s->ev.size()) { size_t n0 = s->ev.size(); s->ev.resize(n0 + 512); for (size_t i = n0; i < s->ev.size(); ++i) HIPCHK(hipEventCreate(&s->ev[i])); }
     HIPCHK(hipEventRecord(s->ev[s->ev_used], st));
@@ -699,6 +700,11 @@ int go2sim_kernel_time(Go2Sim* s, double* ms, int64_t* n) {
   s->ev_used = 0;
 #endif
   *ms = s->time_ms; *n = s->time_launches; s->time_ms = 0; s->time_launches = 0;
+  return 0;
+}
+int go2sim_notify_replayed(Go2Sim* s, int32_t steps) {
+  if (!s || steps < 0) return GO2SIM_EINVAL;
+  s->h.dyn.common_step_counter += steps; s->h.dyn.step_count += (uint64_t)steps; s->h.dyn.use_injected = 0;
   return 0;
 }
 int go2sim_reset_all(Go2Sim* s, void* stream) { if (!s) FAIL(GO2SIM_EINVAL, "null handle"); return launch(s, MODE_RESET_ALL, nullptr, 1, 0, stream); }

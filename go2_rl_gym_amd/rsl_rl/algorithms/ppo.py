@@ -1,9 +1,19 @@
 """PPO with clipped surrogate / clipped value loss / adaptive-KL learning rate (rsl_rl/rsl_rl/algorithms/ppo.py:38-187).
 
-Multi-GPU (one process per GPU, torch.distributed backend 'nccl' = RCCL): each rank owns an env shard and a full
-policy replica.  To train ONE coherent policy the gradients are averaged across ranks before the clip/step and the
-mean KL is averaged before the learning-rate decision, so every rank takes the same branch; the
-advantage statistics are all-reduced in RolloutStorage.compute_returns.  With world_size 1 none of this runs.
+Two execution modes with identical arithmetic:
+  * eager  — the reference's control flow, Python-side learning-rate decision (`.item()` syncs); used on CPU and as the
+             numerical reference (tests/test_ppo_golden.py pins it against the reference's own update).
+  * graphs — on a GPU: one mini-batch update (gather, forward, losses, backward, gradient clip, Adam step, KL -> learning
+             rate) is captured once into a HIP graph and replayed 20x per iteration; the learning rate lives in a device
+             tensor, so there is no host sync and no per-op launch overhead inside the update.
+
+Multi-GPU (one process per GPU, torch.distributed backend 'nccl' = RCCL): each rank owns an env shard and a full policy
+replica; gradients are averaged across ranks before the clip/step and the mean KL before the learning-rate decision, so
+every rank takes the same branch; advantage statistics are all-reduced in RolloutStorage.compute_returns.
+
+The env's observation buffers are persistent device buffers that the step kernel overwrites IN PLACE (the reference
+rebinds `obs_buf` to fresh tensors every step), so `act()` copies the observations into the rollout storage immediately
+instead of keeping a reference until `process_env_step`.
 """
 import torch
 import torch.distributed as dist
@@ -20,18 +30,26 @@ def _world():
 class PPO:
     def __init__(self, actor_critic, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95, value_loss_coef=1.0,
                  entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0, use_clipped_value_loss=True, schedule="fixed", desired_kl=0.01,
-                 device="cpu", lib=None):
+                 device="cpu", lib=None, use_graphs=None):
         self.device = device
         self.lib = lib
         self.desired_kl, self.schedule, self.learning_rate = desired_kl, schedule, learning_rate
         self.actor_critic = actor_critic
         self.actor_critic.to(self.device)
         self.storage = None
-        self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=learning_rate)
+        on_gpu = str(device).startswith("cuda")
+        self.use_graphs = (on_gpu and _world() == 1) if use_graphs is None else bool(use_graphs and on_gpu)
+        if self.use_graphs:
+            self._lr_t = torch.tensor(float(learning_rate), device=device)
+            self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=self._lr_t, capturable=True, foreach=True)
+        else:
+            self._lr_t = None
+            self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=learning_rate)
         self.transition = RolloutStorage.Transition()
         self.clip_param, self.num_learning_epochs, self.num_mini_batches = clip_param, num_learning_epochs, num_mini_batches
         self.value_loss_coef, self.entropy_coef, self.gamma, self.lam = value_loss_coef, entropy_coef, gamma, lam
         self.max_grad_norm, self.use_clipped_value_loss = max_grad_norm, use_clipped_value_loss
+        self._graph = None
         if _world() > 1:   # identical initial replicas
             for p in self.actor_critic.parameters():
                 dist.broadcast(p.data, src=0)
@@ -45,23 +63,37 @@ class PPO:
     def train_mode(self):
         self.actor_critic.train()
 
+    # ------------------------------------------------------------------ rollout half (ppo.py:90-118)
     def act(self, obs, critic_obs):
-        t = self.transition
-        t.actions = self.actor_critic.act(obs).detach()
-        t.values = self.actor_critic.evaluate(critic_obs).detach()
-        t.actions_log_prob = self.actor_critic.get_actions_log_prob(t.actions).detach()
-        t.action_mean = self.actor_critic.action_mean.detach()
-        t.action_sigma = self.actor_critic.action_std.detach()
+        st, t, ac = self.storage, self.transition, self.actor_critic
+        s = st.step
+        if s >= st.num_transitions_per_env:
+            raise AssertionError("Rollout buffer overflow")
+        t.actions = ac.act(obs).detach()
+        t.values = ac.evaluate(critic_obs).detach()
+        t.actions_log_prob = ac.get_actions_log_prob(t.actions).detach()
+        t.action_mean, t.action_sigma = ac.action_mean.detach(), ac.action_std.detach()
         t.observations, t.critic_observations = obs, critic_obs
+        # record everything that env.step() is about to overwrite or that belongs to this step
+        st.observations[s].copy_(obs)
+        if st.privileged_observations is not None:
+            st.privileged_observations[s].copy_(critic_obs)
+        st.actions[s].copy_(t.actions)
+        st.values[s].copy_(t.values)
+        st.actions_log_prob[s].copy_(t.actions_log_prob.view(-1, 1))
+        st.mu[s].copy_(t.action_mean)
+        st.sigma[s].copy_(t.action_sigma)
         return t.actions
 
     def process_env_step(self, rewards, dones, infos):
-        t = self.transition
-        t.rewards = rewards.clone()
-        t.dones = dones
+        st, t = self.storage, self.transition
+        s = st.step
+        r = rewards.clone()
         if "time_outs" in infos:   # bootstrap on time-outs (ppo.py:107-108)
-            t.rewards += self.gamma * torch.squeeze(t.values * infos["time_outs"].unsqueeze(1).to(self.device), 1)
-        self.storage.add_transitions(t)
+            r += self.gamma * torch.squeeze(st.values[s] * infos["time_outs"].unsqueeze(1).to(self.device), 1)
+        st.rewards[s].copy_(r.view(-1, 1))
+        st.dones[s].copy_(dones.view(-1, 1))
+        st.step += 1
         t.clear()
         self.actor_critic.reset(dones)
 
@@ -69,52 +101,137 @@ class PPO:
         last_values = self.actor_critic.evaluate(last_critic_obs).detach()
         self.storage.compute_returns(last_values, self.gamma, self.lam)
 
-    def update(self):
+    # ------------------------------------------------------------------ update half (ppo.py:120-187)
+    def _losses(self, obs_b, cobs_b, act_b, tv_b, adv_b, ret_b, old_lp_b, old_mu_b, old_sig_b):
+        ac = self.actor_critic
+        ac.act(obs_b)
+        lp_b = ac.get_actions_log_prob(act_b)
+        val_b = ac.evaluate(cobs_b)
+        mu_b, sig_b, ent_b = ac.action_mean, ac.action_std, ac.entropy
+        with torch.no_grad():
+            kl = torch.sum(torch.log(sig_b / old_sig_b + 1.0e-5) + (torch.square(old_sig_b) + torch.square(old_mu_b - mu_b)) / (2.0 * torch.square(sig_b)) - 0.5, axis=-1)
+            kl_mean = torch.mean(kl)
+        ratio = torch.exp(lp_b - torch.squeeze(old_lp_b))
+        sur = -torch.squeeze(adv_b) * ratio
+        sur_clip = -torch.squeeze(adv_b) * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)
+        surrogate_loss = torch.max(sur, sur_clip).mean()
+        if self.use_clipped_value_loss:
+            v_clip = tv_b + (val_b - tv_b).clamp(-self.clip_param, self.clip_param)
+            value_loss = torch.max((val_b - ret_b).pow(2), (v_clip - ret_b).pow(2)).mean()
+        else:
+            value_loss = (ret_b - val_b).pow(2).mean()
+        loss = surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * ent_b.mean()
+        return loss, value_loss, surrogate_loss, kl_mean
+
+    def _allreduce_grads(self, world):
+        grads = [p.grad for p in self.actor_critic.parameters() if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads])     # one flat bucket: 1.96 MB of fp32 gradients, latency-bound on xGMI
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat /= world
+        off = 0
+        for g in grads:
+            n = g.numel(); g.copy_(flat[off:off + n].view_as(g)); off += n
+
+    def _update_eager(self):
         mean_value_loss, mean_surrogate_loss = 0.0, 0.0
         world = _world()
-        gen = self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs)
-        for obs_b, cobs_b, act_b, tv_b, adv_b, ret_b, old_lp_b, old_mu_b, old_sig_b, _, _ in gen:
-            self.actor_critic.act(obs_b)
-            lp_b = self.actor_critic.get_actions_log_prob(act_b)
-            val_b = self.actor_critic.evaluate(cobs_b)
-            mu_b, sig_b, ent_b = self.actor_critic.action_mean, self.actor_critic.action_std, self.actor_critic.entropy
-            if self.desired_kl is not None and self.schedule == "adaptive":
-                with torch.inference_mode():
-                    kl = torch.sum(torch.log(sig_b / old_sig_b + 1.0e-5) + (torch.square(old_sig_b) + torch.square(old_mu_b - mu_b)) / (2.0 * torch.square(sig_b)) - 0.5, axis=-1)
-                    kl_mean = torch.mean(kl)
-                    if world > 1:
-                        dist.all_reduce(kl_mean, op=dist.ReduceOp.SUM)
-                        kl_mean /= world
-                    if kl_mean > self.desired_kl * 2.0:
-                        self.learning_rate = max(1e-5, self.learning_rate / 1.5)
-                    elif kl_mean < self.desired_kl / 2.0 and kl_mean > 0.0:
-                        self.learning_rate = min(1e-2, self.learning_rate * 1.5)
-                    for g in self.optimizer.param_groups:
+        adaptive = self.desired_kl is not None and self.schedule == "adaptive"
+        for batch in self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
+            loss, value_loss, surrogate_loss, kl_mean = self._losses(*batch[:9])
+            if adaptive:
+                if world > 1:
+                    dist.all_reduce(kl_mean, op=dist.ReduceOp.SUM)
+                    kl_mean /= world
+                if kl_mean > self.desired_kl * 2.0:
+                    self.learning_rate = max(1e-5, self.learning_rate / 1.5)
+                elif kl_mean < self.desired_kl / 2.0 and kl_mean > 0.0:
+                    self.learning_rate = min(1e-2, self.learning_rate * 1.5)
+                for g in self.optimizer.param_groups:
+                    if torch.is_tensor(g["lr"]):
+                        g["lr"].fill_(self.learning_rate)
+                    else:
                         g["lr"] = self.learning_rate
-            ratio = torch.exp(lp_b - torch.squeeze(old_lp_b))
-            sur = -torch.squeeze(adv_b) * ratio
-            sur_clip = -torch.squeeze(adv_b) * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)
-            surrogate_loss = torch.max(sur, sur_clip).mean()
-            if self.use_clipped_value_loss:
-                v_clip = tv_b + (val_b - tv_b).clamp(-self.clip_param, self.clip_param)
-                value_loss = torch.max((val_b - ret_b).pow(2), (v_clip - ret_b).pow(2)).mean()
-            else:
-                value_loss = (ret_b - val_b).pow(2).mean()
-            loss = surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * ent_b.mean()
             self.optimizer.zero_grad()
             loss.backward()
-            if world > 1:   # one flat bucket: 1.96 MB of fp32 gradients, latency-bound on xGMI
-                grads = [p.grad for p in self.actor_critic.parameters() if p.grad is not None]
-                flat = torch.cat([g.reshape(-1) for g in grads])
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-                flat /= world
-                off = 0
-                for g in grads:
-                    n = g.numel(); g.copy_(flat[off:off + n].view_as(g)); off += n
+            if world > 1:
+                self._allreduce_grads(world)
             nn.utils.clip_grad_norm_(self.actor_critic.parameters(), self.max_grad_norm)
             self.optimizer.step()
             mean_value_loss += value_loss.item()
             mean_surrogate_loss += surrogate_loss.item()
         n = self.num_learning_epochs * self.num_mini_batches
-        self.storage.clear()
         return mean_value_loss / n, mean_surrogate_loss / n
+
+    # ---- graph mode -------------------------------------------------------------------------------------------
+    def _minibatch_from_idx(self):
+        f = self._flat
+        b = self._idx
+        return tuple(t[b] for t in (f["obs"], f["cobs"], f["act"], f["val"], f["adv"], f["ret"], f["logp"], f["mu"], f["sig"]))
+
+    def _graph_step(self):
+        """One mini-batch update with every decision on the device (same arithmetic as _update_eager)."""
+        loss, value_loss, surrogate_loss, kl_mean = self._losses(*self._minibatch_from_idx())
+        if self.desired_kl is not None and self.schedule == "adaptive":
+            lr = self._lr_t
+            up = torch.clamp(lr * 1.5, max=1e-2)
+            down = torch.clamp(lr / 1.5, min=1e-5)
+            new_lr = torch.where(kl_mean > self.desired_kl * 2.0, down, torch.where((kl_mean < self.desired_kl / 2.0) & (kl_mean > 0.0), up, lr))
+            lr.copy_(new_lr)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        nn.utils.clip_grad_norm_(self.actor_critic.parameters(), self.max_grad_norm, foreach=True)
+        self.optimizer.step()
+        self._acc.add_(torch.stack([value_loss.detach(), surrogate_loss.detach()]))
+
+    def _build_graph(self):
+        st = self.storage
+        mb = (st.num_envs * st.num_transitions_per_env) // self.num_mini_batches
+        flat = lambda t: t.flatten(0, 1)
+        self._flat = {"obs": flat(st.observations), "cobs": flat(st.privileged_observations) if st.privileged_observations is not None else flat(st.observations),
+                      "act": flat(st.actions), "val": flat(st.values), "ret": flat(st.returns), "logp": flat(st.actions_log_prob), "adv": flat(st.advantages),
+                      "mu": flat(st.mu), "sig": flat(st.sigma)}
+        self._idx = torch.zeros(mb, dtype=torch.int64, device=self.device)
+        self._acc = torch.zeros(2, device=self.device)
+        # warm-up on a side stream (allocator / lazy initialisation), restoring parameters and optimizer state afterwards is not
+        # needed: the warm-up steps are real PPO steps of the first update
+        self._graph = torch.cuda.CUDAGraph()
+        self._pending_capture = True
+
+    def _update_graphs(self):
+        st = self.storage
+        nmb, mb = self.num_mini_batches, (st.num_envs * st.num_transitions_per_env) // self.num_mini_batches
+        if self._graph is None:
+            self._build_graph()
+        self._acc.zero_()
+        # ONE permutation for the whole update, reused by every epoch, as in the reference (rollout_storage.py:150)
+        indices = torch.randperm(nmb * mb, requires_grad=False, device=self.device)
+        k = 0
+        for _ in range(self.num_learning_epochs):
+            for i in range(nmb):
+                self._idx.copy_(indices[i * mb:(i + 1) * mb])
+                if self._pending_capture and k >= 3:
+                    torch.cuda.synchronize()
+                    with torch.cuda.graph(self._graph):
+                        self._graph_step()
+                    self._pending_capture = False      # the capture itself executes nothing: replay below does this mini-batch
+                if self._pending_capture:
+                    s = torch.cuda.Stream()
+                    s.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(s):
+                        self._graph_step()
+                    torch.cuda.current_stream().wait_stream(s)
+                else:
+                    self._graph.replay()
+                k += 1
+        n = self.num_learning_epochs * nmb
+        acc = (self._acc / n).tolist()
+        self.learning_rate = float(self._lr_t.item())
+        return acc[0], acc[1]
+
+    def update(self):
+        if self.use_graphs:
+            out = self._update_graphs()
+        else:
+            out = self._update_eager()
+        self.storage.clear()
+        return out

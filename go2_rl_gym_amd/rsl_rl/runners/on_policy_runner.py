@@ -50,7 +50,7 @@ def _make_writer(log_dir):
 
 
 class OnPolicyRunner:
-    def __init__(self, env, train_cfg, log_dir=None, device="cpu"):
+    def __init__(self, env, train_cfg, log_dir=None, device="cpu", use_graphs=None):
         self.cfg = train_cfg["runner"]
         self.alg_cfg = train_cfg["algorithm"]
         self.policy_cfg = train_cfg["policy"]
@@ -58,7 +58,7 @@ class OnPolicyRunner:
         self.env = env
         num_critic_obs = self.env.num_privileged_obs if self.env.num_privileged_obs is not None else self.env.num_obs
         actor_critic = _POLICIES[self.cfg["policy_class_name"]](self.env.num_obs, num_critic_obs, self.env.num_actions, **self.policy_cfg).to(self.device)
-        self.alg = _ALGS[self.cfg["algorithm_class_name"]](actor_critic, device=self.device, lib=getattr(env, "lib", None), **self.alg_cfg)
+        self.alg = _ALGS[self.cfg["algorithm_class_name"]](actor_critic, device=self.device, lib=getattr(env, "lib", None), use_graphs=use_graphs, **self.alg_cfg)
         self.num_steps_per_env = self.cfg["num_steps_per_env"]
         self.save_interval = self.cfg["save_interval"]
         self.alg.init_storage(self.env.num_envs, self.num_steps_per_env, [self.env.num_obs], [self.env.num_privileged_obs], [self.env.num_actions])
@@ -69,6 +69,13 @@ class OnPolicyRunner:
         self.current_learning_iteration = 0
         self.last_fps = None
         self.last_collection_time = self.last_learn_time = None
+        on_gpu = str(device).startswith("cuda") and getattr(getattr(env, "lib", None), "go2sim_is_device_library", lambda: 0)() == 1
+        self.use_graphs = bool(on_gpu and _world() == 1 and self.alg.use_graphs) if use_graphs is None else bool(use_graphs and on_gpu)
+        self._rollout_graph, self._graph_ep_infos, self._eager_rollouts = None, None, 0
+        N, T = self.env.num_envs, self.num_steps_per_env
+        self._rewbuffer, self._lenbuffer = deque(maxlen=100), deque(maxlen=100)
+        z = lambda *s_, **k: torch.zeros(*s_, device=self.device, **k)
+        self._bk = {"cur_rew": z(N), "cur_len": z(N), "fin_rew": z(T, N), "fin_len": z(T, N), "fin_mask": z(T, N, dtype=torch.bool)}
         _, _ = self.env.reset()
         if self.log_dir is not None and self.env.cfg.env.test is False:
             Path(self.log_dir).mkdir(parents=True, exist_ok=True)
@@ -79,66 +86,89 @@ class OnPolicyRunner:
         if str(self.device).startswith("cuda"):
             torch.cuda.synchronize(self.device)
 
+    # ---- the 24-step rollout body (on_policy_runner.py:135-153); pure enqueue, no host sync ----
+    def _rollout(self, bk):
+        env, alg, T = self.env, self.alg, self.num_steps_per_env
+        obs = env.get_observations()
+        privileged_obs = env.get_privileged_observations()
+        critic_obs = privileged_obs if privileged_obs is not None else obs
+        ep_infos = []
+        if hasattr(env, "_info_slot"):
+            env._info_slot = 0          # same extras ring slots every iteration (needed for graph replay, harmless otherwise)
+        for i in range(T):
+            actions = alg.act(obs.to(self.device), critic_obs.to(self.device))
+            obs, privileged_obs, rewards, dones, infos = env.step(actions)
+            critic_obs = privileged_obs if privileged_obs is not None else obs
+            rewards, dones = rewards.to(self.device), dones.to(self.device)
+            alg.process_env_step(rewards, dones, infos)
+            if bk is not None:
+                if "episode" in infos:
+                    ep_infos.append(infos["episode"])
+                bk["cur_rew"] += rewards
+                bk["cur_len"] += 1
+                bk["fin_mask"][i] = dones
+                bk["fin_rew"][i] = bk["cur_rew"]
+                bk["fin_len"][i] = bk["cur_len"]
+                keep = (~dones).float()
+                bk["cur_rew"] *= keep
+                bk["cur_len"] *= keep
+        return ep_infos
+
     def learn(self, num_learning_iterations, init_at_random_ep_len=False):
         if self.log_dir is not None and self.writer is None:
             self.writer = _make_writer(self.log_dir)
         if init_at_random_ep_len:
             self.env.episode_length_buf = torch.randint_like(self.env.episode_length_buf, high=int(self.env.max_episode_length))
-        obs = self.env.get_observations()
-        privileged_obs = self.env.get_privileged_observations()
-        critic_obs = privileged_obs if privileged_obs is not None else obs
-        obs, critic_obs = obs.to(self.device), critic_obs.to(self.device)
         self.alg.actor_critic.train()
-        ep_infos = []
-        rewbuffer, lenbuffer = deque(maxlen=100), deque(maxlen=100)
+        rewbuffer, lenbuffer = self._rewbuffer, self._lenbuffer
         N, T = self.env.num_envs, self.num_steps_per_env
-        cur_reward_sum = torch.zeros(N, dtype=torch.float, device=self.device)
-        cur_episode_length = torch.zeros(N, dtype=torch.float, device=self.device)
-        fin_rew = torch.zeros(T, N, device=self.device)
-        fin_len = torch.zeros(T, N, device=self.device)
-        fin_mask = torch.zeros(T, N, dtype=torch.bool, device=self.device)
+        bk = self._bk if self.log_dir is not None else None
         tot_iter = self.current_learning_iteration + num_learning_iterations
         it = self.current_learning_iteration
         for it in range(self.current_learning_iteration, tot_iter):
             self._sync()
             start = time.time()
             with torch.inference_mode():
-                for i in range(T):
-                    actions = self.alg.act(obs, critic_obs)
-                    obs, privileged_obs, rewards, dones, infos = self.env.step(actions)
-                    critic_obs = privileged_obs if privileged_obs is not None else obs
-                    obs, critic_obs, rewards, dones = obs.to(self.device), critic_obs.to(self.device), rewards.to(self.device), dones.to(self.device)
-                    self.alg.process_env_step(rewards, dones, infos)
-                    if self.log_dir is not None:
-                        if "episode" in infos:
-                            ep_infos.append(infos["episode"])
-                        cur_reward_sum += rewards
-                        cur_episode_length += 1
-                        fin_mask[i] = dones
-                        fin_rew[i] = cur_reward_sum
-                        fin_len[i] = cur_episode_length
-                        keep = (~dones).float()
-                        cur_reward_sum *= keep
-                        cur_episode_length *= keep
+                if self._rollout_graph is not None:
+                    self._rollout_graph.replay()                       # 24 x (policy, env step kernel, storage) in ONE launch
+                    self.env.lib.go2sim_notify_replayed(self.env.handle, T)
+                    self.alg.storage.step = T
+                    ep_infos = self._graph_ep_infos
+                elif self.use_graphs and self._eager_rollouts >= 2:
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._graph_ep_infos = self._rollout(bk)
+                    self._rollout_graph = g                            # capture executes nothing ...
+                    self.alg.storage.step = 0
+                    g.replay()                                         # ... so run this iteration's rollout from the graph
+                    self.env.lib.go2sim_notify_replayed(self.env.handle, T)
+                    self.alg.storage.step = T
+                    ep_infos = self._graph_ep_infos
+                else:
+                    ep_infos = self._rollout(bk)
+                    self._eager_rollouts += 1
                 self._sync()
                 stop = time.time()
                 collection_time = stop - start
                 start = stop
+                obs = self.env.get_observations()
+                privileged_obs = self.env.get_privileged_observations()
+                critic_obs = (privileged_obs if privileged_obs is not None else obs).to(self.device)
                 self.alg.compute_returns(critic_obs)
             mean_value_loss, mean_surrogate_loss = self.alg.update()
             self._sync()
             stop = time.time()
             learn_time = stop - start
             if self.log_dir is not None:
-                m = fin_mask.cpu().numpy()   # one device->host read per iteration, same deque order as the reference (step-major)
-                rewbuffer.extend(fin_rew.cpu().numpy()[m].tolist())
-                lenbuffer.extend(fin_len.cpu().numpy()[m].tolist())
+                m = bk["fin_mask"].cpu().numpy()   # one device->host read per iteration, same deque order as the reference (step-major)
+                rewbuffer.extend(bk["fin_rew"].cpu().numpy()[m].tolist())
+                lenbuffer.extend(bk["fin_len"].cpu().numpy()[m].tolist())
                 self.log(locals())
             self.last_collection_time, self.last_learn_time = collection_time, learn_time
             self.last_fps = T * N * _world() / (collection_time + learn_time)
             if self.log_dir is not None and it % self.save_interval == 0:
                 self.save(os.path.join(self.log_dir, "model_{}.pt".format(it)), it, False)
-            ep_infos.clear()
         self.current_learning_iteration += num_learning_iterations
         if self.log_dir is not None:
             self.save(os.path.join(self.log_dir, "model_{}.pt".format(self.current_learning_iteration)), it, True)

@@ -304,6 +304,11 @@ int  go2sim_update_reward_curriculum(Go2Sim* h, int force_update);
 int  go2sim_get_curriculum_state(Go2Sim* h, float reward_curriculum_scale[GO2_NUM_REWARDS],
                                  float cmd_ranges[4][2], float* zero_command_proba);
 
+/* A go2sim_step enqueue captured in a HIP graph advances the DEVICE-resident counters when replayed, but not the
+ * library's host mirror (go2sim_get_common_step_counter, go2sim_peek_uniforms): tell it that `steps` captured
+ * steps were replayed. */
+int  go2sim_notify_replayed(Go2Sim* h, int32_t steps);
+
 /* ---- test hooks ------------------------------------------------------------------------------- */
 /* Use the caller's uniforms [N][GO2_NUM_UNIFORMS] for the NEXT step/reset only (NULL = Philox). */
 int  go2sim_inject_uniforms(Go2Sim* h, const float* uniforms, void* stream);

@@ -1016,6 +1016,7 @@ int go2sim_simulate(Go2Sim* s, void* stream) {
   if (s->timing) { s->time_ms += now_ms()-t0; s->time_launches++; }
   return 0;
 }
+int go2sim_notify_replayed(Go2Sim* s, int32_t steps) { (void)steps; return s ? 0 : GO2SIM_EINVAL; }   /* host library: nothing is replayed */
 int go2sim_enable_timing(Go2Sim* s, int en) { if (!s) return GO2SIM_EINVAL; s->timing=en; s->time_ms=0; s->time_launches=0; return 0; }
 int go2sim_kernel_time(Go2Sim* s, double* ms, int64_t* n) { if (!s||!ms||!n) return GO2SIM_EINVAL; *ms=s->time_ms; *n=s->time_launches; s->time_ms=0; s->time_launches=0; return 0; }
 int go2sim_post_physics(Go2Sim* s, void* stream) {
