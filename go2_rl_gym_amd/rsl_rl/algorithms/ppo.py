@@ -104,7 +104,7 @@ class PPO:
     # ------------------------------------------------------------------ update half (ppo.py:120-187)
     def _losses(self, obs_b, cobs_b, act_b, tv_b, adv_b, ret_b, old_lp_b, old_mu_b, old_sig_b):
         ac = self.actor_critic
-        ac.act(obs_b)
+        ac.update_distribution(obs_b)     # the reference calls act() here and discards the sample (ppo.py:131)
         lp_b = ac.get_actions_log_prob(act_b)
         val_b = ac.evaluate(cobs_b)
         mu_b, sig_b, ent_b = ac.action_mean, ac.action_std, ac.entropy

@@ -58,11 +58,19 @@ class ActorCritic(nn.Module):
 
     def update_distribution(self, observations):
         mean = self.actor(observations)
-        self.distribution = Normal(mean, mean * 0.0 + self.std)
+        # validate_args=False: the argument check is a host sync (torch._is_all_true) per call and cannot be captured in a HIP graph;
+        # the reference intends the same (`Normal.set_default_validate_args = False`, actor_critic.py:92)
+        self.distribution = Normal(mean, mean * 0.0 + self.std, validate_args=False)
+
+    def _noise(self, like):
+        return torch.randn_like(like)
 
     def act(self, observations, **kwargs):
         self.update_distribution(observations)
-        return self.distribution.sample()
+        # mean + std * eps  ==  Normal(mean, std).sample() in law (actor_critic.py:123-125); written out because torch.normal
+        # checks std >= 0 with a host sync, which a HIP-graph capture of the rollout does not allow
+        d = self.distribution
+        return (d.mean + d.stddev * self._noise(d.mean)).detach()
 
     def get_actions_log_prob(self, actions):
         return self.distribution.log_prob(actions).sum(dim=-1)
