@@ -327,6 +327,67 @@ __global__ void go2_normalize_kernel(float* adv, const double* partials, int cou
   float sd = (float)sqrt(var > 0 ? var : 0.0), m = (float)mean;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) adv[i] = (adv[i] - m) / (sd + 1e-8f);
 }
+
+// ---- fused PPO loss head (ppo.py:131-170): one lane per sample, A <= 16 actions in registers ------------------------------
+#define PPO_NSTAT 24   // per-block partials: [0..3] surrogate, value loss, kl, entropy ; [4..4+A) grad_std
+__global__ void __launch_bounds__(256) go2_ppo_loss_kernel(const float* __restrict__ mu, const float* __restrict__ std_, const float* __restrict__ value,
+    const float* __restrict__ actions, const float* __restrict__ old_mu, const float* __restrict__ old_sigma, const float* __restrict__ old_logp,
+    const float* __restrict__ adv, const float* __restrict__ tv, const float* __restrict__ ret, float* __restrict__ gmu, float* __restrict__ gval,
+    float* __restrict__ part, int B, int A, float clip, float vcoef, int use_clip_v) {
+  __shared__ float sh[4][PPO_NSTAT];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float acc[PPO_NSTAT];
+#pragma unroll
+  for (int k = 0; k < PPO_NSTAT; ++k) acc[k] = 0.f;
+  if (i < B) {
+    const float LOG2PI = 1.8378770664093453f;
+    float lp = 0.f, kl = 0.f, ent = 0.f;
+    for (int j = 0; j < A; ++j) {
+      float sg = std_[j], d = actions[(size_t)i * A + j] - mu[(size_t)i * A + j], ls = logf(sg);
+      lp += -d * d / (2.f * sg * sg) - ls - 0.5f * LOG2PI;
+      ent += 0.5f + 0.5f * LOG2PI + ls;
+      float so = old_sigma[(size_t)i * A + j], dm = old_mu[(size_t)i * A + j] - mu[(size_t)i * A + j];
+      kl += logf(sg / so + 1e-5f) + (so * so + dm * dm) / (2.f * sg * sg) - 0.5f;
+    }
+    float ratio = expf(lp - old_logp[i]), a = adv[i];
+    float lo = 1.f - clip, hi = 1.f + clip, rc = fminf(fmaxf(ratio, lo), hi); float in = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
+    float s1 = -a * ratio, s2 = -a * rc, sur = fmaxf(s1, s2);
+    float w = s1 > s2 ? 1.f : (s1 < s2 ? in : 0.5f + 0.5f * in);     // torch.max splits ties evenly; clamp passes gradient inside [lo, hi]
+    float g_lp = -a * w * ratio / (float)B;
+    float v = value[i], dv = v - tv[i], vl, gv;
+    if (use_clip_v) {
+      float dc = fminf(fmaxf(dv, -clip), clip), vin = (dv >= -clip && dv <= clip) ? 1.f : 0.f, vc = tv[i] + dc;
+      float l1 = (v - ret[i]) * (v - ret[i]), l2 = (vc - ret[i]) * (vc - ret[i]); vl = fmaxf(l1, l2);
+      float g1 = 2.f * (v - ret[i]), g2 = 2.f * (vc - ret[i]) * vin; gv = l1 > l2 ? g1 : (l1 < l2 ? g2 : 0.5f * g1 + 0.5f * g2);
+    } else { vl = (ret[i] - v) * (ret[i] - v); gv = 2.f * (v - ret[i]); }
+    gval[i] = vcoef * gv / (float)B;
+    for (int j = 0; j < A; ++j) {
+      float sg = std_[j], d = actions[(size_t)i * A + j] - mu[(size_t)i * A + j];
+      gmu[(size_t)i * A + j] = g_lp * d / (sg * sg);
+      if (j < PPO_NSTAT - 4) acc[4 + j] = g_lp * (d * d / (sg * sg * sg) - 1.f / sg);
+    }
+    acc[0] = sur; acc[1] = vl; acc[2] = kl; acc[3] = ent;
+  }
+#pragma unroll
+  for (int k = 0; k < PPO_NSTAT; ++k) {
+    float x = acc[k];
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < PPO_NSTAT) part[(size_t)blockIdx.x * PPO_NSTAT + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+__global__ void go2_ppo_loss_finish_kernel(const float* __restrict__ part, const float* __restrict__ std_, float* __restrict__ gstd, float* __restrict__ stats,
+                                           int nblocks, int B, int A, float vcoef, float ecoef) {
+  const int k = threadIdx.x;
+  if (k >= PPO_NSTAT) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * PPO_NSTAT + k];      // fixed order: deterministic
+  if (k < 4) { stats[k] = s / (float)B; }
+  else if (k - 4 < A) gstd[k - 4] = s - ecoef / std_[k - 4];
+  __syncthreads();
+  if (k == 0) stats[4] = stats[0] + vcoef * stats[1] - ecoef * stats[3];
+}
 #endif  // !GO2_EMU
 
 // ------------------------------------------------------------------------------------------------------
@@ -779,6 +840,41 @@ int go2sim_normalize_advantages(float* adv, const double* partials, int32_t coun
 #else
   int blocks = (count + 255) / 256; blocks = blocks > 2048 ? 2048 : blocks;
   hipLaunchKernelGGL(go2_normalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, adv, partials, count);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+int go2sim_ppo_loss(const float* mu, const float* std_, const float* value, const float* actions, const float* old_mu, const float* old_sigma,
+                    const float* old_logp, const float* adv, const float* tv, const float* ret, float* gmu, float* gstd, float* gval, float* stats,
+                    float* workspace, int32_t B, int32_t A, float clip, float vcoef, float ecoef, int32_t use_clip_v, void* stream) {
+  if (!mu || !std_ || !value || !actions || !old_mu || !old_sigma || !old_logp || !adv || !tv || !ret || !gmu || !gstd || !gval || !stats || !workspace || B <= 0 || A <= 0 || A > 20)
+    FAIL(GO2SIM_EINVAL, "bad argument");
+#ifdef GO2_EMU
+  (void)stream; (void)workspace;
+  double s_sur = 0, s_vl = 0, s_kl = 0, s_ent = 0; double gs[20]; for (int j = 0; j < A; ++j) gs[j] = 0;
+  const float LOG2PI = 1.8378770664093453f;
+  for (int i = 0; i < B; ++i) {
+    float lp = 0.f, kl = 0.f, ent = 0.f;
+    for (int j = 0; j < A; ++j) { float sg = std_[j], d = actions[(size_t)i * A + j] - mu[(size_t)i * A + j], ls = logf(sg);
+      lp += -d * d / (2.f * sg * sg) - ls - 0.5f * LOG2PI; ent += 0.5f + 0.5f * LOG2PI + ls;
+      float so = old_sigma[(size_t)i * A + j], dm = old_mu[(size_t)i * A + j] - mu[(size_t)i * A + j]; kl += logf(sg / so + 1e-5f) + (so * so + dm * dm) / (2.f * sg * sg) - 0.5f; }
+    float ratio = expf(lp - old_logp[i]), a = adv[i], lo = 1.f - clip, hi = 1.f + clip, rc = fminf(fmaxf(ratio, lo), hi), in = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
+    float s1 = -a * ratio, s2 = -a * rc, sur = fmaxf(s1, s2), w = s1 > s2 ? 1.f : (s1 < s2 ? in : 0.5f + 0.5f * in), g_lp = -a * w * ratio / (float)B;
+    float v = value[i], dv = v - tv[i], vl, gv;
+    if (use_clip_v) { float dc = fminf(fmaxf(dv, -clip), clip), vin = (dv >= -clip && dv <= clip) ? 1.f : 0.f, vc = tv[i] + dc, l1 = (v - ret[i]) * (v - ret[i]), l2 = (vc - ret[i]) * (vc - ret[i]);
+      vl = fmaxf(l1, l2); float g1 = 2.f * (v - ret[i]), g2 = 2.f * (vc - ret[i]) * vin; gv = l1 > l2 ? g1 : (l1 < l2 ? g2 : 0.5f * g1 + 0.5f * g2); }
+    else { vl = (ret[i] - v) * (ret[i] - v); gv = 2.f * (v - ret[i]); }
+    gval[i] = vcoef * gv / (float)B;
+    for (int j = 0; j < A; ++j) { float sg = std_[j], d = actions[(size_t)i * A + j] - mu[(size_t)i * A + j]; gmu[(size_t)i * A + j] = g_lp * d / (sg * sg); gs[j] += g_lp * (d * d / (sg * sg * sg) - 1.f / sg); }
+    s_sur += sur; s_vl += vl; s_kl += kl; s_ent += ent;
+  }
+  for (int j = 0; j < A; ++j) gstd[j] = (float)(gs[j] - ecoef / std_[j]);
+  stats[0] = (float)(s_sur / B); stats[1] = (float)(s_vl / B); stats[2] = (float)(s_kl / B); stats[3] = (float)(s_ent / B); stats[4] = stats[0] + vcoef * stats[1] - ecoef * stats[3];
+#else
+  int nb = (B + 255) / 256;
+  hipLaunchKernelGGL(go2_ppo_loss_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, mu, std_, value, actions, old_mu, old_sigma, old_logp, adv, tv, ret, gmu, gval, workspace, B, A, clip, vcoef, use_clip_v);
+  hipLaunchKernelGGL(go2_ppo_loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, workspace, std_, gstd, stats, nb, B, A, vcoef, ecoef);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

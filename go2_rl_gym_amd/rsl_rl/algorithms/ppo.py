@@ -27,10 +27,42 @@ def _world():
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 
+class _FusedPPOLoss(torch.autograd.Function):
+    """loss = surrogate + c_v * value_loss - c_e * entropy through ONE library kernel (go2sim_ppo_loss) that also returns the
+    analytic gradients w.r.t. mu, std and value; autograd then continues into the actor / critic MLPs.  Replaces ~150
+    element-wise launches of the eager formulation per mini-batch with 2."""
+
+    @staticmethod
+    def forward(ctx, mu, std, value, alg, act_b, tv_b, adv_b, ret_b, old_lp_b, old_mu_b, old_sig_b):
+        import ctypes as C
+        B, A = mu.shape
+        c = lambda t: t.detach().contiguous().float()
+        mu_c, std_c, val_c = c(mu), c(std), c(value).view(-1)
+        args = [mu_c, std_c, val_c, c(act_b), c(old_mu_b), c(old_sig_b), c(old_lp_b).view(-1), c(adv_b).view(-1), c(tv_b).view(-1), c(ret_b).view(-1)]
+        gmu, gstd, gval = torch.empty_like(mu_c), torch.empty_like(std_c), torch.empty_like(val_c)
+        stats = torch.empty(5, device=mu.device)
+        ws = torch.empty(24 * ((B + 255) // 256), device=mu.device)
+        lib = alg.lib
+        stream = C.c_void_p(torch.cuda.current_stream(mu.device).cuda_stream) if mu.is_cuda else None
+        p = lambda t: C.c_void_p(t.data_ptr())
+        rc = lib.go2sim_ppo_loss(*[p(t) for t in args], p(gmu), p(gstd), p(gval), p(stats), p(ws), B, A, float(alg.clip_param), float(alg.value_loss_coef),
+                                 float(alg.entropy_coef), int(alg.use_clipped_value_loss), stream)
+        if rc != 0:
+            raise RuntimeError("go2sim_ppo_loss failed: %s" % lib.go2sim_last_error().decode())
+        ctx.save_for_backward(gmu, gstd, gval.view_as(value))
+        ctx.mark_non_differentiable(stats)
+        return stats[4].clone(), stats
+
+    @staticmethod
+    def backward(ctx, g_loss, g_stats):
+        gmu, gstd, gval = ctx.saved_tensors
+        return gmu * g_loss, gstd * g_loss, gval * g_loss, None, None, None, None, None, None, None, None
+
+
 class PPO:
     def __init__(self, actor_critic, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95, value_loss_coef=1.0,
                  entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0, use_clipped_value_loss=True, schedule="fixed", desired_kl=0.01,
-                 device="cpu", lib=None, use_graphs=None):
+                 device="cpu", lib=None, use_graphs=None, fused_loss=None):
         self.device = device
         self.lib = lib
         self.desired_kl, self.schedule, self.learning_rate = desired_kl, schedule, learning_rate
@@ -50,6 +82,8 @@ class PPO:
         self.value_loss_coef, self.entropy_coef, self.gamma, self.lam = value_loss_coef, entropy_coef, gamma, lam
         self.max_grad_norm, self.use_clipped_value_loss = max_grad_norm, use_clipped_value_loss
         self._graph = None
+        # the fused loss kernel is the default on the GPU; on the CPU it is opt-in (tests compare it with the eager formulation)
+        self.fused_loss = (on_gpu and lib is not None) if fused_loss is None else bool(fused_loss and lib is not None)
         if _world() > 1:   # identical initial replicas
             for p in self.actor_critic.parameters():
                 dist.broadcast(p.data, src=0)
@@ -104,6 +138,11 @@ class PPO:
     # ------------------------------------------------------------------ update half (ppo.py:120-187)
     def _losses(self, obs_b, cobs_b, act_b, tv_b, adv_b, ret_b, old_lp_b, old_mu_b, old_sig_b):
         ac = self.actor_critic
+        if self.fused_loss:
+            mu_b = ac.actor(obs_b)
+            val_b = ac.evaluate(cobs_b)
+            loss, stats = _FusedPPOLoss.apply(mu_b, ac.std, val_b, self, act_b, tv_b, adv_b, ret_b, old_lp_b, old_mu_b, old_sig_b)
+            return loss, stats[1], stats[0], stats[2]
         ac.update_distribution(obs_b)     # the reference calls act() here and discards the sample (ppo.py:131)
         lp_b = ac.get_actions_log_prob(act_b)
         val_b = ac.evaluate(cobs_b)

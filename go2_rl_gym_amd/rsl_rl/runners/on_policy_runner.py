@@ -36,6 +36,33 @@ def _world():
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 
+def _enable_tuned_gemms():
+    """Use PyTorch TunableOp with the shipped selection table (go2_rl_gym_amd/tuning/tunableop_gfx950.csv): for the fp32 GEMM
+    shapes of this workload (4096-row rollout, 24576-row mini-batches) it picks the fastest hipBLASLt / rocBLAS solution
+    (measured 1.6 -> 2.2 M env-steps/s).  Same fp32 arithmetic.  Set PYTORCH_TUNABLEOP_ENABLED yourself to override; set
+    GO2_TUNE_GEMM=1 to (re)tune online for other sizes."""
+    if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") is not None:
+        return
+    try:
+        import torch.cuda.tunable as tn
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tuning", "tunableop_gfx950.csv")
+        tune = os.environ.get("GO2_TUNE_GEMM", "0") == "1"
+        if not tune and not os.path.exists(path):
+            return
+        tn.enable(True)
+        tn.tuning_enable(tune)
+        tn.record_untuned_enable(False)
+        if tune:
+            tn.set_max_tuning_duration(50)
+            tn.set_filename(os.path.join(os.getcwd(), "tunableop_results.csv"))
+        else:
+            tn.write_file_on_exit(False)
+            if not tn.read_file(path):
+                tn.enable(False)       # validators (torch / hipBLASLt / arch) do not match this table
+    except Exception as e:             # never fail the run over an optional speed-up
+        print("[go2_rl_gym_amd] TunableOp not enabled:", e)
+
+
 class _NullWriter:
     def add_scalar(self, *a, **k):
         pass
@@ -70,6 +97,8 @@ class OnPolicyRunner:
         self.last_fps = None
         self.last_collection_time = self.last_learn_time = None
         on_gpu = str(device).startswith("cuda") and getattr(getattr(env, "lib", None), "go2sim_is_device_library", lambda: 0)() == 1
+        if on_gpu:
+            _enable_tuned_gemms()
         self.use_graphs = bool(on_gpu and _world() == 1 and self.alg.use_graphs) if use_graphs is None else bool(use_graphs and on_gpu)
         self._rollout_graph, self._graph_ep_infos, self._eager_rollouts = None, None, 0
         N, T = self.env.num_envs, self.num_steps_per_env

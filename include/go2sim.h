@@ -334,6 +334,18 @@ int  go2sim_gae(const float* rewards, const uint8_t* dones, const float* values,
  * partials (rollout_storage.py:137). */
 int  go2sim_normalize_advantages(float* advantages, const double* partials, int32_t count, void* stream);
 
+/* Fused PPO loss head (rsl_rl/rsl_rl/algorithms/ppo.py:131-170 + Normal.log_prob/entropy of modules/actor_critic.py:101-127):
+ * per-sample log-prob, ratio, clipped surrogate, clipped value loss, entropy, KL(old || new), and the ANALYTIC gradients
+ * of   loss = mean(surrogate) + value_coef * mean(value_loss) - entropy_coef * mean(entropy)
+ * w.r.t. mu [B,A], the state-independent std [A] and value [B] in one pass (what autograd spreads over ~150 launches).
+ * stats[5] = {surrogate_loss, value_loss, kl_mean, entropy_mean, loss}.  workspace: >= 24*ceil(B/256) floats.
+ * Deterministic: block partials are combined in a fixed order by a second tiny kernel. */
+int  go2sim_ppo_loss(const float* mu, const float* std, const float* value, const float* actions, const float* old_mu,
+                     const float* old_sigma, const float* old_log_prob, const float* advantages, const float* target_values,
+                     const float* returns, float* grad_mu, float* grad_std, float* grad_value, float* stats, float* workspace,
+                     int32_t B, int32_t A, float clip_param, float value_loss_coef, float entropy_coef,
+                     int32_t use_clipped_value_loss, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,3 +41,55 @@ def test_one_update_matches_reference(monkeypatch):
     assert abs(alg.learning_rate - float(g["final_lr"])) < 1e-12
     for k, v in ac.state_dict().items():
         np.testing.assert_allclose(v.numpy(), g["w1_" + k], atol=2e-6, rtol=1e-5, err_msg=k)
+
+
+def test_fused_loss_kernel_matches_autograd():
+    """go2sim_ppo_loss (oracle build; the HIP kernel is checked in tests/test_gpu_parity.py) against torch autograd of the
+    eager formulation: loss terms, KL and the gradients w.r.t. every parameter."""
+    torch.manual_seed(0)
+    lib = load_oracle()
+    B = 700
+    for clipv in (True, False):
+        ac = ActorCritic(45, 263, 12, actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16])
+        with torch.no_grad():
+            ac.std.mul_(0.7)
+        obs, cobs = torch.randn(B, 45), torch.randn(B, 263)
+        with torch.no_grad():
+            mu0 = ac.actor(obs); acts = mu0 + 0.8 * torch.randn(B, 12)
+            old_mu = mu0 + 0.1 * torch.randn(B, 12); old_sig = 0.8 * torch.ones(B, 12) + 0.05 * torch.rand(B, 12)
+            old_lp = torch.distributions.Normal(old_mu, old_sig).log_prob(acts).sum(-1, keepdim=True) + 0.3 * torch.randn(B, 1)
+            tv = ac.critic(cobs) + 0.3 * torch.randn(B, 1); ret = tv + torch.randn(B, 1); adv = torch.randn(B, 1)
+        grads = []
+        for fused in (False, True):
+            alg = PPO(ac, clip_param=0.2, value_loss_coef=1.0, entropy_coef=0.01, use_clipped_value_loss=clipv, schedule="adaptive", device="cpu", lib=lib, fused_loss=fused)
+            ac.zero_grad()
+            loss, vl, sl, kl = alg._losses(obs, cobs, acts, tv, adv, ret, old_lp, old_mu, old_sig)
+            loss.backward()
+            grads.append((loss.item(), vl.item(), sl.item(), kl.item(), [p.grad.clone() for p in ac.parameters()]))
+        (l0, v0, s0, k0, g0), (l1, v1, s1, k1, g1) = grads
+        assert abs(l0 - l1) < 2e-6 and abs(v0 - v1) < 2e-6 and abs(s0 - s1) < 2e-6 and abs(k0 - k1) < 2e-6
+        for a, b in zip(g0, g1):
+            np.testing.assert_allclose(b.numpy(), a.numpy(), atol=2e-7, rtol=2e-4)
+
+
+def test_update_with_fused_loss_matches_reference(monkeypatch):
+    """The same golden update as above, but through the fused loss kernel: identical final weights within fp32 noise."""
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "ppo_update.npz")))
+    T, N = g["rew"].shape
+    ac = ActorCritic(45, 263, 12, actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16], activation="elu", init_noise_std=1.0)
+    ac.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w0_")})
+    alg = PPO(ac, num_learning_epochs=2, num_mini_batches=2, clip_param=0.2, gamma=0.99, lam=0.95, value_loss_coef=1.0, entropy_coef=0.01,
+              learning_rate=1e-3, max_grad_norm=1.0, use_clipped_value_loss=True, schedule="adaptive", desired_kl=0.01, device="cpu", lib=load_oracle(), fused_loss=True)
+    alg.init_storage(N, T, [45], [263], [12])
+    noise = torch.from_numpy(g["noise"])
+    for t in range(T):
+        monkeypatch.setattr(ActorCritic, "_noise", lambda self, like, _t=t: noise[_t])
+        alg.act(torch.from_numpy(g["obs"][t]), torch.from_numpy(g["cobs"][t]))
+        alg.process_env_step(torch.from_numpy(g["rew"][t]), torch.from_numpy(g["dones"][t]).bool(), {"time_outs": torch.from_numpy(g["time_outs"][t]).bool()})
+    alg.compute_returns(torch.from_numpy(g["cobs"][T]))
+    perm = torch.from_numpy(g["perm"])
+    monkeypatch.setattr(torch, "randperm", lambda n, **kw: perm)
+    alg.update()
+    assert abs(alg.learning_rate - float(g["final_lr"])) < 1e-12
+    for k, v in ac.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), g["w1_" + k], atol=5e-6, rtol=5e-5, err_msg=k)
