@@ -716,13 +716,14 @@ static void emu_run(Go2Sim* s, int mode, const float* actions_in, int initial_re
 // Enqueue one pass.  Nothing computed on the host enters the kernels: the per-step scalars are derived on the
 // device from the device-resident counters, so the same enqueue can be captured in a HIP graph and replayed.
 static int launch(Go2Sim* s, int mode, const float* actions_in, int initial_reset, int counter_inc, void* stream) {
+  bool capturing = false;   // a captured enqueue executes nothing now: the host mirror advances on go2sim_notify_replayed instead
 #ifdef GO2_EMU
   (void)stream; emu_run(s, mode, actions_in, initial_reset, counter_inc);
 #else
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((s->N + 15) / 16), block(64);
   bool timed = s->timing != 0;
-  { hipStreamCaptureStatus cs = hipStreamCaptureStatusNone; if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) timed = false; }
+  { hipStreamCaptureStatus cs = hipStreamCaptureStatusNone; if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) { timed = false; capturing = true; } }
   if (timed) {
     if (s->ev_used + 2 > s->ev.size()) { size_t n0 = s->ev.size(); s->ev.resize(n0 + 512); for (size_t i = n0; i < s->ev.size(); ++i) HIPCHK(hipEventCreate(&s->ev[i])); }
     HIPCHK(hipEventRecord(s->ev[s->ev_used], st));
@@ -735,7 +736,7 @@ static int launch(Go2Sim* s, int mode, const float* actions_in, int initial_rese
   if (mode != MODE_PHYS) hipLaunchKernelGGL(go2_finish_kernel, dim3(1), dim3(64), 0, st, s->d_blk, counter_inc);
   HIPCHK(hipGetLastError());
 #endif
-  if (mode != MODE_PHYS) { s->h.dyn.common_step_counter += counter_inc; s->h.dyn.step_count += 1; s->h.dyn.use_injected = 0; }   // host mirror
+  if (mode != MODE_PHYS && !capturing) { s->h.dyn.common_step_counter += counter_inc; s->h.dyn.step_count += 1; s->h.dyn.use_injected = 0; }   // host mirror
   return 0;
 }
 

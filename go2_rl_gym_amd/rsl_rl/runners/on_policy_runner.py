@@ -8,6 +8,7 @@ service) is out of scope; with torch.distributed initialised only rank 0 logs an
 """
 import os
 import statistics
+import tempfile
 import time
 from collections import deque
 from pathlib import Path
@@ -56,8 +57,9 @@ def _enable_tuned_gemms():
             tn.set_max_tuning_duration(50)
             tn.set_filename(os.path.join(os.getcwd(), "tunableop_results.csv"))
         else:
-            tn.write_file_on_exit(False)
-            if not tn.read_file(path):
+            ok = tn.read_file(path)
+            tn.set_filename(os.path.join(tempfile.gettempdir(), "go2_tunableop_unused.csv"))   # never write over the shipped table
+            if not ok:
                 tn.enable(False)       # validators (torch / hipBLASLt / arch) do not match this table
     except Exception as e:             # never fail the run over an optional speed-up
         print("[go2_rl_gym_amd] TunableOp not enabled:", e)
