@@ -78,8 +78,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X (the product has no CPU path)")
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
-    if world > 1:
+    if world > 1 or os.environ.get("GO2_FORCE_COLLECTIVES", "0") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device(dev))      # RCCL over xGMI
 
     from go2_rl_gym_amd.envs import task_registry  # noqa: F401
@@ -125,6 +126,15 @@ def main():
         total_steps = world * N * 24 * a.steps
         k_ms = ms.value / max(n.value, 1)
         achieved = ALGO_BYTES_FLAT * N / (k_ms * 1e-3) / 1e9
+        # HBM traffic per launch from the rocprofv3 PMC passes (tools/pmc_pass.sh -> profiles/*_pmc_step_kernel.json; bench.py cannot
+        # collect counters on itself).  Only quoted when the profiled launch shape is the benchmarked one.
+        traffic, traffic_src = None, None
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_step_kernel.json")))[::-1]:
+            pm = json.load(open(f))
+            if pm.get("num_envs") == N:
+                traffic, traffic_src = pm["hbm_bytes_per_launch_corrected"], os.path.relpath(f, ROOT)
+                break
         out = {
             "metric": "env-steps/sec at 4096 envs (go2 flat); 1/2/4/8-GPU scaling", "value": total_steps / elapsed, "unit": "env-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
@@ -133,7 +143,7 @@ def main():
                        "num_envs_per_gpu": N, "num_steps_per_env": 24, "parallelism": "env-sharded dp%d" % world},
             "collection_only": world * N * 24 * a.steps / col,
             "roofline": {"bound": "hbm", "kernel": "go2_step_kernel<PHYS|POST>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel_ms": k_ms, "launches": n.value, "algorithmic_bytes_per_env_step": ALGO_BYTES_FLAT,
+                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": ALGO_BYTES_FLAT * N, "kernel_ms": k_ms, "launches": n.value, "algorithmic_bytes_per_env_step": ALGO_BYTES_FLAT,
                          "note": "latency/occupancy-bound by construction: 4096 envs x 4 lanes = 256 waves for 1024 SIMDs (DESIGN.md 6)"},
         }
         if world == 1 and not a.no_cpu_baseline:
@@ -143,7 +153,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out))
     env.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

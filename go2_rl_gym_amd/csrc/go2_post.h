@@ -206,7 +206,7 @@ struct LegPost {
     }
     // _get_heights (:1188-1224): this lane samples points lane, lane+4, ...
     float hsum = 0.f;
-    if (c.measure_heights) {
+    if (c.measure_heights && c.terrain_mode != 0) {   // on a plane measured_heights stays the all-zero buffer it was created as (:1201-1202)
       float nn = fmaxf(sqrtf(qz * qz + qw * qw), 1e-9f), yz = qz / nn, yw = qw / nn;  // quat_apply_yaw (utils/math.py:8-12)
       hq_z = yz; hq_w = yw; hpx = o.pw.x; hpy = o.pw.y;
       for (int i = lane; i < GO2_NUM_HEIGHT_POINTS; i += 4) {

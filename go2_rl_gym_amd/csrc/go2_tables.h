@@ -52,7 +52,7 @@ struct Go2Launch {
   uint32_t seed_lo, seed_hi;
   float sim_dt, dt, gravity[3], contact_offset, erp, max_depen_vel, bounce_thr, cfm, armature, limit_margin;
   int32_t terrain_mode, hf_rows, hf_cols; float hf_hscale, hf_vscale, hf_border, terrain_friction, terrain_restitution;
-  int32_t terrain_num_levels, terrain_num_types, terrain_curriculum, move_down_by_acc, measure_heights; float terrain_length;
+  int32_t terrain_num_levels, terrain_num_types, terrain_curriculum, move_down_by_acc, measure_heights, full_body_states; float terrain_length;
   float kp[12], kd[12], q0[12], action_scale, clip_actions, clip_obs, base_init[13];
   int32_t rand_strength, rand_offset, rand_pd, push_robots, push_interval, rand_delay;
   float strength_rng[2], offset_rng[2], kp_rng[2], kd_rng[2], push_xy, push_ang;

@@ -121,10 +121,10 @@ GO2_HD void lane_finish_phys(LANE_PARAMS, const Go2Tables& tab, const Go2Ptrs& p
     V3 pos = ph.pw + mul(Rwb, org[k]);
     V3 lv = mul(Rwb, vel[k].l + cross(vel[k].a, org[k])), av = mul(Rwb, vel[k].a);
     float r13[13] = {pos.x, pos.y, pos.z, quats[k][0], quats[k][1], quats[k][2], quats[k][3], lv.x, lv.y, lv.z, av.x, av.y, av.z};
-    _Pragma("unroll") for (int i = 0; i < 13; ++i) F3D(p.rigid, 19, b, i, e) = r13[i];
+    if (k == 3 || L.full_body_states) _Pragma("unroll") for (int i = 0; i < 13; ++i) F3D(p.rigid, 19, b, i, e) = r13[i];
     if (k == 3) { o.foot_pos = pos; o.foot_vel = lv; }
   }
-  if (lane < 3) {  // base, Head_upper, Head_lower rows
+  if (lane < 3 && L.full_body_states) {  // base, Head_upper, Head_lower rows
     V3 off = v3(tab.base.body_off[lane][0], tab.base.body_off[lane][1], tab.base.body_off[lane][2]);
     V3 pos = ph.pw + mul(Rwb, off); V3 lv = mul(Rwb, vb + cross(wb, off));
     float r13[13] = {pos.x, pos.y, pos.z, ph.qx, ph.qy, ph.qz, ph.qw, lv.x, lv.y, lv.z, ph.ww.x, ph.ww.y, ph.ww.z};
@@ -199,7 +199,7 @@ __device__ __forceinline__ float quad_sum(float x) {
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(64) go2_step_kernel(const Go2DevBlock* __restrict__ blk, const float* __restrict__ actions_in, int initial_reset) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) go2_step_kernel(const Go2DevBlock* __restrict__ blk, const float* __restrict__ actions_in, int initial_reset) {
   __shared__ Go2Tables tab;   // robot link / collision tables staged in LDS (per-lane leg index -> ds_read)
   __shared__ Go2Step S;       // this step's scalars, computed on device from the device-resident counters
   const Go2Ptrs& p = blk->p; const Go2Launch& L = blk->L;   // uniform addresses -> scalar loads
@@ -567,7 +567,7 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
   L.cfm = cfg->contact_cfm; L.armature = cfg->joint_armature; L.limit_margin = cfg->joint_limit_margin;
   L.terrain_mode = cfg->terrain_mode; L.hf_rows = cfg->hf_rows; L.hf_cols = cfg->hf_cols; L.hf_hscale = cfg->hf_hscale; L.hf_vscale = cfg->hf_vscale; L.hf_border = cfg->hf_border;
   L.terrain_friction = cfg->terrain_friction; L.terrain_restitution = cfg->terrain_restitution; L.terrain_num_levels = cfg->terrain_num_levels; L.terrain_num_types = cfg->terrain_num_types;
-  L.terrain_curriculum = cfg->terrain_curriculum; L.move_down_by_acc = cfg->move_down_by_accumulated_xy_command; L.measure_heights = cfg->measure_heights; L.terrain_length = cfg->terrain_length;
+  L.terrain_curriculum = cfg->terrain_curriculum; L.move_down_by_acc = cfg->move_down_by_accumulated_xy_command; L.measure_heights = cfg->measure_heights; L.full_body_states = cfg->full_body_states; L.terrain_length = cfg->terrain_length;
   memcpy(L.kp, cfg->kp, sizeof(L.kp)); memcpy(L.kd, cfg->kd, sizeof(L.kd)); memcpy(L.q0, cfg->default_dof_pos, sizeof(L.q0));
   L.action_scale = cfg->action_scale; L.clip_actions = cfg->clip_actions; L.clip_obs = cfg->clip_observations; memcpy(L.base_init, cfg->base_init_state, sizeof(L.base_init));
   L.rand_strength = cfg->randomize_motor_strength; L.rand_offset = cfg->randomize_motor_zero_offset; L.rand_pd = cfg->randomize_pd_gains; L.push_robots = cfg->push_robots;

@@ -15,6 +15,8 @@ The env's observation buffers are persistent device buffers that the step kernel
 rebinds `obs_buf` to fresh tensors every step), so `act()` copies the observations into the rollout storage immediately
 instead of keeping a reference until `process_env_step`.
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -25,6 +27,14 @@ from ..storage import RolloutStorage
 
 def _world():
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def _collectives_on():
+    """True when the cross-rank averaging must run: more than one rank, or GO2_FORCE_COLLECTIVES=1 with an initialised process
+    group of any size (lets a 1-GPU box exercise the RCCL-inside-HIP-graph path)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("GO2_FORCE_COLLECTIVES", "0") == "1"
 
 
 class _FusedPPOLoss(torch.autograd.Function):
@@ -70,7 +80,7 @@ class PPO:
         self.actor_critic.to(self.device)
         self.storage = None
         on_gpu = str(device).startswith("cuda")
-        self.use_graphs = (on_gpu and _world() == 1) if use_graphs is None else bool(use_graphs and on_gpu)
+        self.use_graphs = on_gpu if use_graphs is None else bool(use_graphs and on_gpu)
         if self.use_graphs:
             self._lr_t = torch.tensor(float(learning_rate), device=device)
             self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=self._lr_t, capturable=True, foreach=True)
@@ -178,7 +188,7 @@ class PPO:
         for batch in self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
             loss, value_loss, surrogate_loss, kl_mean = self._losses(*batch[:9])
             if adaptive:
-                if world > 1:
+                if _collectives_on():
                     dist.all_reduce(kl_mean, op=dist.ReduceOp.SUM)
                     kl_mean /= world
                 if kl_mean > self.desired_kl * 2.0:
@@ -192,7 +202,7 @@ class PPO:
                         g["lr"] = self.learning_rate
             self.optimizer.zero_grad()
             loss.backward()
-            if world > 1:
+            if _collectives_on():
                 self._allreduce_grads(world)
             nn.utils.clip_grad_norm_(self.actor_critic.parameters(), self.max_grad_norm)
             self.optimizer.step()
@@ -211,6 +221,9 @@ class PPO:
         """One mini-batch update with every decision on the device (same arithmetic as _update_eager)."""
         loss, value_loss, surrogate_loss, kl_mean = self._losses(*self._minibatch_from_idx())
         if self.desired_kl is not None and self.schedule == "adaptive":
+            if _collectives_on():          # RCCL all-reduce captured inside the graph: every rank takes the same LR branch
+                dist.all_reduce(kl_mean, op=dist.ReduceOp.SUM)
+                kl_mean = kl_mean / _world()
             lr = self._lr_t
             up = torch.clamp(lr * 1.5, max=1e-2)
             down = torch.clamp(lr / 1.5, min=1e-5)
@@ -218,6 +231,8 @@ class PPO:
             lr.copy_(new_lr)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
+        if _collectives_on():
+            self._allreduce_grads(_world())
         nn.utils.clip_grad_norm_(self.actor_critic.parameters(), self.max_grad_norm, foreach=True)
         self.optimizer.step()
         self._acc.add_(torch.stack([value_loss.detach(), surrogate_loss.detach()]))

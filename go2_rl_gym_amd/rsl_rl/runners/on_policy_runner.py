@@ -101,7 +101,7 @@ class OnPolicyRunner:
         on_gpu = str(device).startswith("cuda") and getattr(getattr(env, "lib", None), "go2sim_is_device_library", lambda: 0)() == 1
         if on_gpu:
             _enable_tuned_gemms()
-        self.use_graphs = bool(on_gpu and _world() == 1 and self.alg.use_graphs) if use_graphs is None else bool(use_graphs and on_gpu)
+        self.use_graphs = bool(on_gpu and self.alg.use_graphs) if use_graphs is None else bool(use_graphs and on_gpu)
         self._rollout_graph, self._graph_ep_infos, self._eager_rollouts = None, None, 0
         N, T = self.env.num_envs, self.num_steps_per_env
         self._rewbuffer, self._lenbuffer = deque(maxlen=100), deque(maxlen=100)

@@ -6,6 +6,7 @@ mean / unbiased std of ALL advantages of ALL shards: the fp64 partial sums {sum 
 torch.distributed (RCCL over xGMI on a multi-GPU node) — the one data-path collective of the rollout.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -79,7 +80,7 @@ class RolloutStorage:
                                  T, N, float(gamma), float(lam), self._stream())
         if rc != 0:
             raise RuntimeError("go2sim_gae failed: %s" % self.lib.go2sim_last_error().decode())
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("GO2_FORCE_COLLECTIVES", "0") == "1"):
             dist.all_reduce(self._partials, op=dist.ReduceOp.SUM)       # {sum adv, sum adv^2, count}: 24 bytes over RCCL
         rc = self.lib.go2sim_normalize_advantages(p(self.advantages), p(self._partials), T * N, self._stream())
         if rc != 0:

@@ -138,6 +138,8 @@ typedef struct Go2SimCfg {
   float    terrain_length;    /* 8.0: used by the resampler even on a plane (:447) */
   float    env_spacing;       /* 3.0 (plane grid, :1081-1091) */
   int32_t  measure_heights;   /* 1 */
+  int32_t  full_body_states;  /* 0: rigid_body_states is filled for the 4 feet only — the only rows the reference reads
+                               * (legged_robot.py:1252,1407-1408,1426); 1: all 19 bodies (3.7x the bytes of that tensor) */
 
   /* ---- control: go2_config.py:77-85 ---- */
   float    kp[12], kd[12];

@@ -557,6 +557,7 @@ static void physics_substep(Go2Sim* s, int e, R* root, R* q, R* qd, const R* tau
 /* write rigid_body_states[e] from kinematics at the current state */
 static void write_body_states(Go2Sim* s, int e, const Kin* k) {
   for (int b=0;b<NB;++b) {
+    if (!s->cfg.full_body_states && !(b==6||b==10||b==14||b==18)) continue;   /* feet rows only unless asked (go2sim.h) */
     int l = kBodyLink[b]; float* o = s->b.rigid_body_states + (size_t)(e*NB+b)*13;
     R off[3] = {(R)kBodyOffset[b][0], (R)kBodyOffset[b][1], (R)kBodyOffset[b][2]}, t[3]; mat3_vec(k->Rw[l], off, t);
     R qq[4]; mat_to_quat(k->Rw[l], qq);
