@@ -134,8 +134,10 @@ struct LegPhys {
     float h00 = hf[i * L.hf_cols + j] * L.hf_vscale, h10 = hf[(i + 1) * L.hf_cols + j] * L.hf_vscale;
     float h01 = hf[i * L.hf_cols + j + 1] * L.hf_vscale, h11 = hf[(i + 1) * L.hf_cols + j + 1] * L.hf_vscale;
     float dx, dy;
-    if (uu + vv <= 1.f) { dx = h10 - h00; dy = h01 - h00; *hgt = h00 + uu * dx + vv * dy; }
-    else { dx = h11 - h01; dy = h11 - h10; *hgt = h11 - (1 - uu) * dx - (1 - vv) * dy; }
+    // two triangles per cell split along (i,j)-(i+1,j+1), the diagonal of the reference's trimesh (terrain_utils triangles (0,3,1),(0,2,3))
+    if (uu >= vv) { dx = h10 - h00; dy = h11 - h10; }
+    else { dx = h11 - h01; dy = h01 - h00; }
+    *hgt = h00 + uu * dx + vv * dy;
     float nx = -dx / L.hf_hscale, ny = -dy / L.hf_hscale, inv = 1.0f / sqrtf(nx * nx + ny * ny + 1.f);
     *n = v3(nx * inv, ny * inv, inv);
   }

@@ -507,6 +507,16 @@ void go2sim_destroy(Go2Sim* s) {
   delete s;
 }
 
+// terrain_types = torch.div(arange(N), N / num_cols, rounding_mode="floor") (legged_robot.py:1072): an int64 tensor over a Python
+// float computes in fp32, and torch's floor-division is fmod-based — so 3 / (12/20) is 4, not 5.  Restated exactly.
+static int64_t terrain_type_of(uint32_t ge, int Ng, int num_types) {
+  float a = (float)ge, b = (float)((double)Ng / (double)num_types);
+  float mod = fmodf(a, b), div = (a - mod) / b;
+  if (mod != 0.f && ((b < 0.f) != (mod < 0.f))) div -= 1.f;
+  float fl = 0.f;
+  if (div != 0.f) { fl = floorf(div); if (div - fl > 0.5f) fl += 1.f; }
+  return (int64_t)fl;
+}
 int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
   if (!cfg || !out) FAIL(GO2SIM_EINVAL, "null argument");
   if (cfg->struct_size != sizeof(Go2SimCfg) || cfg->abi_version != GO2SIM_ABI_VERSION) FAIL(GO2SIM_EINVAL, "cfg size/version mismatch (%u vs %zu)", cfg->struct_size, sizeof(Go2SimCfg));
@@ -630,7 +640,7 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
       int ncols = (int)floor(sqrt((double)Ng)); o3[0] = cfg->env_spacing * (float)(ge / ncols); o3[1] = cfg->env_spacing * (float)(ge % ncols); o3[2] = 0.f;
     } else {
       int maxl = cfg->terrain_curriculum ? cfg->max_init_terrain_level : cfg->terrain_num_levels - 1;
-      lv[e] = ge % (uint32_t)(maxl + 1); ty[e] = (int64_t)floor((double)ge / ((double)Ng / cfg->terrain_num_types));
+      lv[e] = ge % (uint32_t)(maxl + 1); ty[e] = terrain_type_of(ge, Ng, cfg->terrain_num_types);
       const float* o = &torig[((size_t)lv[e] * cfg->terrain_num_types + ty[e]) * 3]; o3[0] = o[0]; o3[1] = o[1]; o3[2] = o[2];
       kind[e] = type_id[ty[e]];
     }

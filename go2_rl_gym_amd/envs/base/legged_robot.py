@@ -75,13 +75,27 @@ class LeggedRobot(BaseTask):
         if mesh == "plane":
             c.terrain_mode = 0
         elif mesh in ("heightfield", "trimesh"):
-            raise NotImplementedError("terrain.mesh_type=%r: the heightfield terrain generator is the next scope row (SURVEY 8 f1); "
-                                      "use task go2_flat (mesh_type='plane')" % mesh)
+            # create_sim (:292-310): the Terrain is built on the host; the library copies the int16 samples to HBM at create.
+            # 'trimesh' collides against the same triangulated grid (the slope_treshold wall correction of
+            # convert_heightfield_to_trimesh is not applied: DESIGN.md "terrain").
+            from ...utils.terrain import Terrain
+            self.terrain = Terrain(cfg.terrain, c.num_envs_global)
+            hs = np.ascontiguousarray(self.terrain.heightsamples, dtype=np.int16)
+            org = np.ascontiguousarray(self.terrain.env_origins, dtype=np.float32)
+            ids = np.ascontiguousarray(self.terrain.cols2id, dtype=np.int32)
+            if ids.shape[0] != cfg.terrain.num_cols:
+                raise ValueError("terrain.cols2id has %d entries for %d columns" % (ids.shape[0], cfg.terrain.num_cols))
+            self._terrain_host = (hs, org, ids)                                    # keep alive until go2sim_create has copied them
+            c.terrain_mode = 1
+            c.hf_rows, c.hf_cols = self.terrain.tot_rows, self.terrain.tot_cols
+            c.hf_samples = hs.ctypes.data_as(type(c.hf_samples))
+            c.terrain_origins = org.ctypes.data_as(type(c.terrain_origins))
+            c.terrain_type_id = ids.ctypes.data_as(type(c.terrain_type_id))
         else:
             raise ValueError("Terrain mesh type not recognised. Allowed types are [plane, heightfield, trimesh]")
         t = cfg.terrain
         c.terrain_friction, c.terrain_restitution = t.static_friction, t.restitution
-        c.hf_hscale, c.hf_vscale, c.hf_border = t.horizontal_scale, t.vertical_scale, t.border_size
+        c.hf_hscale, c.hf_vscale, c.hf_border = t.horizontal_scale, t.vertical_scale, (t.border_size if mesh != "plane" else 0.0)
         c.terrain_num_levels, c.terrain_num_types = t.num_rows, t.num_cols
         c.terrain_curriculum, c.max_init_terrain_level = int(t.curriculum), t.max_init_terrain_level
         c.move_down_by_accumulated_xy_command = int(t.move_down_by_accumulated_xy_command)
@@ -242,6 +256,22 @@ class LeggedRobot(BaseTask):
         self.commands_scale = torch.tensor([self.obs_scales.lin_vel, self.obs_scales.lin_vel, self.obs_scales.ang_vel], **f32)
         self.gravity_vec = torch.tensor([0.0, 0.0, -1.0], **f32).repeat(self.num_envs, 1)
         self.custom_origins = self.cfg.terrain.mesh_type in ("heightfield", "trimesh")
+        self._level_groups = None
+        if self.custom_origins:                                                      # _create_heightfield/_get_env_origins (:964-1079)
+            hs, org, ids = self._terrain_host
+            self.height_samples = torch.from_numpy(hs).view(self.terrain.tot_rows, self.terrain.tot_cols).to(dev)
+            self.terrain_cols2id = torch.from_numpy(ids).to(dev).long()
+            self.terrain_ids = self.terrain_cols2id[self.terrain_types]
+            self.max_terrain_level = self.cfg.terrain.num_rows
+            self.terrain_origins = torch.from_numpy(org).to(dev)
+            # extras terrain_level_<name> (:230-235): one [groups, N] membership matrix, applied to terrain_levels per step
+            names = list(self.terrain.name2cols)
+            member = torch.zeros(len(names) + 1, self.num_envs, **f32)
+            member[0] = 1.0
+            for k, name in enumerate(names):
+                cols = torch.tensor(sorted(self.terrain.name2cols[name]), dtype=torch.long, device=dev)
+                member[k + 1] = torch.isin(self.terrain_types, cols).float()
+            self._level_groups = (["all"] + names, member / member.sum(dim=1, keepdim=True))     # 0/0 -> nan like the reference's empty mean
         self.add_noise = self.cfg.noise.add_noise
 
     # the runner REPLACES this attribute (on_policy_runner.py:118): copy into the library's buffer instead
@@ -308,7 +338,12 @@ class LeggedRobot(BaseTask):
         slot.copy_(self._episode_info)
         self._info_slot = (self._info_slot + 1) % self._info_ring.shape[0]
         names = self.abi.reward_names
-        ep = {"terrain_level_all": 0.0}
+        if self._level_groups is None:
+            ep = {"terrain_level_all": 0.0}
+        else:
+            names_l, member = self._level_groups
+            lv = torch.mv(member.nan_to_num(0.0), self.terrain_levels.float()) + (member[:, 0] * 0.0)   # nan rows stay nan
+            ep = {"terrain_level_" + n: lv[k] for k, n in enumerate(names_l)}
         for i in self._active_idx:
             ep["rew_" + names[i]] = slot[i]
         if self.cfg.commands.curriculum:

@@ -335,6 +335,14 @@ def install():
     gymutil.parse_sim_config = lambda cfg, sp: None
     gymtorch.wrap_tensor = lambda t: t
     gymtorch.unwrap_tensor = lambda t: t
+    # isaacgym.terrain_utils is third-party and absent: the reference's Terrain class is run on THIS build's generators
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from go2_rl_gym_amd.utils import terrain as _gen
+    for n in ("SubTerrain", "random_uniform_terrain", "pyramid_sloped_terrain", "pyramid_stairs_terrain", "discrete_obstacles_terrain",
+              "wave_terrain", "stepping_stones_terrain"):
+        setattr(terr, n, getattr(_gen, n))
+    terr.convert_heightfield_to_trimesh = lambda hf, hs, vs, thr: (np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint32))
     iso.gymapi, iso.gymutil, iso.gymtorch, iso.torch_utils, iso.terrain_utils = gymapi, gymutil, gymtorch, tu, terr
     for m in (iso, gymapi, gymutil, gymtorch, tu, terr):
         sys.modules[m.__name__] = m

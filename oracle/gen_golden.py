@@ -43,12 +43,15 @@ ABI = Abi()
 NU = ABI.GO2_NUM_UNIFORMS
 
 
-def make_env(N, seed=1):
+TERRAIN_SEED = 11
+
+
+def make_env(N, seed=1, mesh_type="plane"):
     env_cfg, train_cfg = task_registry.get_cfgs("go2")
     env_cfg.env.num_envs = N
-    env_cfg.terrain.mesh_type = "plane"
+    env_cfg.terrain.mesh_type = mesh_type
     torch.manual_seed(seed)
-    np.random.seed(seed)
+    np.random.seed(TERRAIN_SEED if mesh_type != "plane" else seed)
     fig.GYM.alloc(N)
     env = Go2Robot(env_cfg, fig.SimParams(), 1, "cpu", True)  # noqa: F405
     return env, env_cfg, train_cfg
@@ -58,7 +61,7 @@ def synth_state(rng, N, env):
     """One synthetic simulator state (the 'fake physics')."""
     root = np.zeros((N, 13), np.float32)
     root[:, 0:2] = env.env_origins[:, :2].numpy() + rng.uniform(-3, 3, (N, 2))
-    root[:, 2] = rng.uniform(0.2, 0.45, N)
+    root[:, 2] = env.env_origins[:, 2].numpy() + rng.uniform(0.2, 0.45, N)
     yaw = rng.uniform(-np.pi, np.pi, N); roll = rng.normal(0, 0.15, N); pitch = rng.normal(0, 0.15, N)
     q = fig.quat_from_euler_xyz(torch.tensor(roll), torch.tensor(pitch), torch.tensor(yaw)).numpy()
     root[:, 3:7] = q
@@ -92,9 +95,10 @@ def synth_state(rng, N, env):
     return root, dof, contact.astype(np.float32), feet_state
 
 
-def gen_env_sequence(N=16, T=64, seed=7):
+def gen_env_sequence(N=16, T=64, seed=7, mesh_type="plane"):
     rng = np.random.default_rng(seed)
-    env, env_cfg, train_cfg = make_env(N)
+    env, env_cfg, train_cfg = make_env(N, mesh_type=mesh_type)
+    hf = mesh_type != "plane"
     fig.patch_torch()
     names_active = list(env.episode_sums.keys())
     rew_index = {n: ABI.reward_names.index(n) for n in names_active}
@@ -108,7 +112,7 @@ def gen_env_sequence(N=16, T=64, seed=7):
                            "time_out", "commands", "cmd_timer", "cmd_xy_acc", "last_is_limit_vel", "ep_len", "episode_sums",
                            "root_out", "dof_out", "last_actions", "last_last_actions", "last_dof_vel", "base_lin_vel", "base_ang_vel",
                            "projected_gravity", "rpy", "motor_strengths", "motor_zero_offsets", "p_gains_multiplier", "d_gains_multiplier",
-                           "max_move_distance", "episode_info", "episode_info_valid", "ep_len_in", "cmd_timer_in")}
+                           "max_move_distance", "episode_info", "episode_info_valid", "ep_len_in", "cmd_timer_in", "max_move_in", "terrain_levels", "env_origins_out", "measured_heights")}
 
     def snapshot(t_extras_rebuilt):
         rec["obs"].append(env.obs_buf.numpy().copy()); rec["priv"].append(env.privileged_obs_buf.numpy().copy())
@@ -127,6 +131,10 @@ def gen_env_sequence(N=16, T=64, seed=7):
         rec["last_dof_vel"].append(env.last_dof_vel.numpy().copy())
         for k in ("base_lin_vel", "base_ang_vel", "projected_gravity", "rpy", "motor_strengths", "motor_zero_offsets", "p_gains_multiplier", "d_gains_multiplier", "max_move_distance"):
             rec[k].append(getattr(env, k).numpy().copy())
+        rec["terrain_levels"].append(env.terrain_levels.numpy().copy() if hf else np.zeros(N, np.int64))
+        rec["env_origins_out"].append(env.env_origins.numpy().copy())
+        mh = env.measured_heights
+        rec["measured_heights"].append(mh.numpy().copy() if torch.is_tensor(mh) else np.zeros((N, 187), np.float32))
         info = np.zeros(ABI.GO2_NUM_REWARDS, np.float32)
         if t_extras_rebuilt:
             for n, i in rew_index.items():
@@ -136,6 +144,8 @@ def gen_env_sequence(N=16, T=64, seed=7):
     def new_table():
         return rng.uniform(0, 1, (N, NU)).astype(np.float32)
 
+    rec_levels0 = env.terrain_levels.numpy().copy() if hf else None
+    origins0 = env.env_origins.numpy().copy()
     # ---- reset_idx(all) (base_task.py:82-84) with table 0 ------------------------------------------------
     U0 = new_table()
     fig.INJECT.table = torch.from_numpy(U0)
@@ -155,8 +165,11 @@ def gen_env_sequence(N=16, T=64, seed=7):
             env.episode_length_buf = torch.from_numpy(el.astype(np.int64))
             # stagger the command timers so the post-physics callback resamples during the sequence (:409-410)
             env.commands_resampling_step[:] = torch.from_numpy(rng.integers(1, 60, N).astype(np.float32))
+            if hf:   # spread the walked distances so the terrain curriculum moves envs up and down (:1154-1169)
+                env.max_move_distance[:] = torch.from_numpy(rng.uniform(0, 7, N).astype(np.float32))
         rec["ep_len_in"].append(env.episode_length_buf.numpy().copy())
         rec["cmd_timer_in"].append(env.commands_resampling_step.numpy().copy())
+        rec["max_move_in"].append(env.max_move_distance.numpy().copy())
         U = new_table()
         root, dof, contact, feet_state = synth_state(rng, N, env)
         actions = rng.normal(0, 1.0, (N, 12)).astype(np.float32)
@@ -197,7 +210,7 @@ def gen_env_sequence(N=16, T=64, seed=7):
     out.update({"reset_all_" + k: v for k, v in reset_all_out.items()})
     out["U_reset_all"] = U0
     out["start_counter"] = np.int64(start_counter)
-    out["env_origins"] = env.env_origins.numpy().copy()
+    out["env_origins"] = origins0
     out["dof_pos_limits"] = env.dof_pos_limits.numpy().copy()
     out["torque_limits"] = env.torque_limits.numpy().copy()
     out["noise_scale_vec"] = env.noise_scale_vec.numpy().copy()
@@ -208,8 +221,30 @@ def gen_env_sequence(N=16, T=64, seed=7):
     out["height_points"] = env.height_points[0].numpy().copy()
     out["base_height_scan_mask"] = env.base_height_scan_mask.numpy().copy()
     out["limit_vel_comb"] = env.limit_vel_comb.numpy().astype(np.float32)
-    print("env sequence: N=%d T=%d events:" % (N, T), counters, "active rewards:", sorted(names_active))
+    if hf:
+        out["terrain_levels0"] = rec_levels0; out["terrain_types"] = env.terrain_types.numpy().copy()
+        out["hf_sha256"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(env.terrain.height_field_raw).tobytes()).digest(), np.uint8)
+        out["terrain_seed"] = np.int64(TERRAIN_SEED)
+    if hf:
+        lv = np.stack(rec["terrain_levels"])
+        counters["level_changes"] = int((np.diff(np.concatenate([rec_levels0[None], lv]), axis=0) != 0).sum())
+        counters["nonzero_heights"] = float((np.abs(np.stack(rec["measured_heights"])) > 0).mean())
+    print("env sequence (%s): N=%d T=%d events:" % (mesh_type, N, T), counters, "active rewards:", sorted(names_active))
     return out
+
+
+def gen_terrain():
+    """legged_gym/utils/terrain.py:9-174 run on this build's generators: layout, per-column kinds, origins, placed height field."""
+    from legged_gym.utils.terrain import Terrain
+    env_cfg, _ = task_registry.get_cfgs("go2")
+    env_cfg.terrain.mesh_type = "heightfield"
+    np.random.seed(TERRAIN_SEED)
+    t = Terrain(env_cfg.terrain, 64)
+    hfr = np.ascontiguousarray(t.height_field_raw)
+    return dict(seed=np.int64(TERRAIN_SEED), shape=np.array(hfr.shape), sha256=np.frombuffer(hashlib.sha256(hfr.tobytes()).digest(), np.uint8),
+                env_origins=t.env_origins.copy(), cols2id=np.array(t.cols2id), tot_rows=np.int64(t.tot_rows), tot_cols=np.int64(t.tot_cols),
+                tile_wave=hfr[250:330, 250:330].copy(), tile_stairs=hfr[250 + 9 * 85:330 + 9 * 85, 250 + 8 * 85:330 + 8 * 85].copy(),
+                tile_obstacles=hfr[250 + 5 * 85:330 + 5 * 85, 250 + 14 * 85:330 + 14 * 85].copy(), col_sums=hfr.astype(np.int64).sum(0), row_sums=hfr.astype(np.int64).sum(1))
 
 
 def gen_gae(seed=3):
@@ -276,6 +311,9 @@ def main():
     files = {}
     seq = gen_env_sequence()
     np.savez_compressed(os.path.join(OUT, "go2_plane_sequence.npz"), **seq); files["go2_plane_sequence.npz"] = None
+    hfseq = gen_env_sequence(N=12, T=40, seed=9, mesh_type="heightfield")
+    np.savez_compressed(os.path.join(OUT, "go2_heightfield_sequence.npz"), **hfseq); files["go2_heightfield_sequence.npz"] = None
+    np.savez_compressed(os.path.join(OUT, "terrain.npz"), **gen_terrain()); files["terrain.npz"] = None
     np.savez_compressed(os.path.join(OUT, "gae.npz"), **gen_gae()); files["gae.npz"] = None
     np.savez_compressed(os.path.join(OUT, "ppo_update.npz"), **gen_ppo()); files["ppo_update.npz"] = None
     for f in files:

@@ -384,8 +384,10 @@ static void terrain_query(const Go2Sim* s, R x, R y, R* h, R* n) {
   R u = fx - i, v = fy - j; if (u<0) u=0; if (u>1) u=1; if (v<0) v=0; if (v>1) v=1;
   R h00 = s->hf[i*cols+j]*vs, h10 = s->hf[(i+1)*cols+j]*vs, h01 = s->hf[i*cols+j+1]*vs, h11 = s->hf[(i+1)*cols+j+1]*vs;
   R dx, dy;
-  if (u + v <= 1) { dx = h10-h00; dy = h01-h00; *h = h00 + u*dx + v*dy; }
-  else { dx = h11-h01; dy = h11-h10; *h = h11 - (1-u)*dx - (1-v)*dy; }
+  /* two triangles per cell, split along (i,j)-(i+1,j+1): the diagonal isaacgym.terrain_utils.convert_heightfield_to_trimesh uses */
+  if (u >= v) { dx = h10-h00; dy = h11-h10; }
+  else { dx = h11-h01; dy = h01-h00; }
+  *h = h00 + u*dx + v*dy;
   R nx = -dx/hs, ny = -dy/hs, inv = 1/SQRT(nx*nx+ny*ny+1);
   n[0]=nx*inv; n[1]=ny*inv; n[2]=inv;
 }
@@ -899,6 +901,14 @@ void go2sim_default_cfg(Go2SimCfg* cfg) { go2sim_fill_default_cfg(cfg); }
 
 #define ALLOC(field, type, count) do { s->b.field = (type*)calloc((size_t)(count), sizeof(type)); if (!s->b.field) { go2sim_destroy(s); return GO2SIM_ENOMEM; } } while (0)
 
+/* torch.div(int64 tensor, python float, rounding_mode="floor") (:1072): fp32 arithmetic, c10::div_floor_floating
+   (fmod, exact quotient, floor, round-to-nearest guard).  Matters: env 3 of 12 over 20 columns is column 4, not 5. */
+static int64_t div_floor_f32(float a, float b) {
+  float m = fmodf(a,b), d = (a-m)/b, f = 0;
+  if (m != 0 && ((b<0) != (m<0))) d -= 1;
+  if (d != 0) { f = floorf(d); if (d-f > 0.5f) f += 1; }
+  return (int64_t)f;
+}
 int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
   (void)device_id;
   if (!cfg || !out) { snprintf(g_err,sizeof(g_err),"null argument"); return GO2SIM_EINVAL; }
@@ -958,7 +968,7 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
     } else { /* round robin (:1071-1079) */
       int maxl = cfg->terrain_curriculum ? cfg->max_init_terrain_level : cfg->terrain_num_levels-1;
       s->b.terrain_levels[e] = ge % (uint32_t)(maxl+1);
-      s->b.terrain_types[e] = (int64_t)floor((double)ge/((double)Ng/cfg->terrain_num_types));
+      s->b.terrain_types[e] = div_floor_f32((float)ge, (float)((double)Ng/(double)cfg->terrain_num_types));
       const float* o = s->terrain_origins + ((size_t)s->b.terrain_levels[e]*cfg->terrain_num_types + s->b.terrain_types[e])*3;
       for (int i=0;i<3;++i) s->b.env_origins[3*e+i]=o[i];
       s->terrain_kind[e] = s->terrain_type_id[s->b.terrain_types[e]];

@@ -232,4 +232,22 @@ def load_hip():
 STEP_STATE = ["root_states", "dof_state", "last_actions", "last_last_actions", "last_dof_vel", "commands", "commands_resampling_step",
               "commands_xy_accumulation", "episode_length_buf", "motor_strengths", "motor_zero_offsets", "p_gains_multiplier", "d_gains_multiplier",
               "foot_impulse", "last_is_limit_vel", "max_move_distance", "episode_sums", "feet_air_time", "last_contacts", "last_contacts2",
-              "friction_coeffs", "restitution_coeffs", "added_base_mass", "added_base_com", "link_mass_ratio", "env_origins"]
+              "friction_coeffs", "restitution_coeffs", "added_base_mass", "added_base_com", "link_mass_ratio", "env_origins", "terrain_levels"]
+
+
+def heightfield_overrides(num_envs_global, seed=11, **terrain_kw):
+    """Go2SimCfg overrides for the task=go2 rough terrain, built the way LeggedRobot._fill_cfg does (utils/terrain.py on the host)."""
+    from go2_rl_gym_amd.envs.go2.go2_config import GO2Cfg
+    from go2_rl_gym_amd.utils.terrain import Terrain
+    tc = GO2Cfg().terrain
+    tc.mesh_type = "heightfield"
+    for k, v in terrain_kw.items():
+        setattr(tc, k, v)
+    np.random.seed(seed)
+    t = Terrain(tc, num_envs_global)
+    ov = dict(terrain_mode=1, hf_rows=int(t.tot_rows), hf_cols=int(t.tot_cols), hf_hscale=tc.horizontal_scale, hf_vscale=tc.vertical_scale,
+              hf_border=tc.border_size, hf_samples=np.ascontiguousarray(t.heightsamples, np.int16),
+              terrain_origins=np.ascontiguousarray(t.env_origins, np.float32), terrain_type_id=np.ascontiguousarray(t.cols2id, np.int32),
+              terrain_num_levels=tc.num_rows, terrain_num_types=tc.num_cols, terrain_curriculum=int(tc.curriculum),
+              max_init_terrain_level=tc.max_init_terrain_level, measure_heights=int(tc.measure_heights))
+    return t, ov
