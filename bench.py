@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALGO_BYTES_FLAT = 2936          # algorithmic bytes per env-step on a plane: 778 read + 2158 written
+ALGO_BYTES_ROUGH = 2936 + 187 * 4 + 187 * 3 * 2 + 27 * 4 * 2     # + measured_heights written, 3 int16 samples per scan point, 4 per contact candidate
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md)
 NUM_ENVS = 4096
 
@@ -35,13 +36,14 @@ def parse():
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--num-envs", type=int, default=NUM_ENVS, help="envs PER GPU (weak scaling)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--task", default="go2_flat", choices=["go2_flat", "go2"], help="go2_flat is the BASELINE workload; go2 = the rough curriculum terrain (extra line, not the headline)")
     return p.parse_args()
 
 
 CPU_THREADS = 16
 
 
-def cpu_baseline(num_envs=512):
+def cpu_baseline(num_envs=512, task="go2_flat"):
     """The same PPO iteration on the host CPU: the plain-C oracle (OpenMP) as the env + torch-CPU PPO, on a bounded
     sample (1/8 of the envs, one full iteration after one warm-up).  Test-infrastructure code, timed only here."""
     import torch
@@ -51,9 +53,9 @@ def cpu_baseline(num_envs=512):
     from go2_rl_gym_amd.utils import get_args
     cores = min(os.cpu_count() or 1, CPU_THREADS)     # threads actually used: more only oversubscribes these small problems
     torch.set_num_threads(cores)
-    args = get_args(["--task", "go2_flat", "--num_envs", str(num_envs), "--sim_device", "cpu", "--rl_device", "cpu", "--headless"])
-    env, _ = task_registry.make_env("go2_flat", args, lib=load_oracle())
-    runner, _ = task_registry.make_alg_runner(env, "go2_flat", args, log_root=None)
+    args = get_args(["--task", task, "--num_envs", str(num_envs), "--sim_device", "cpu", "--rl_device", "cpu", "--headless"])
+    env, _ = task_registry.make_env(task, args, lib=load_oracle())
+    runner, _ = task_registry.make_alg_runner(env, task, args, log_root=None)
     runner.learn(1, init_at_random_ep_len=True)
     t0 = time.time()
     runner.learn(1)
@@ -86,10 +88,10 @@ def main():
     from go2_rl_gym_amd.envs import task_registry  # noqa: F401
     from go2_rl_gym_amd.utils import get_args
     N = a.num_envs
-    args = get_args(["--task", "go2_flat", "--num_envs", str(N), "--sim_device", dev, "--rl_device", dev, "--headless", "--seed", "1"])
-    env, env_cfg = task_registry.make_env("go2_flat", args, env_offset=rank * N, num_envs_global=world * N)
+    args = get_args(["--task", a.task, "--num_envs", str(N), "--sim_device", dev, "--rl_device", dev, "--headless", "--seed", "1"])
+    env, env_cfg = task_registry.make_env(a.task, args, env_offset=rank * N, num_envs_global=world * N)
     torch.manual_seed(1 + rank)       # policy init is broadcast from rank 0; sampling noise differs per shard
-    runner, train_cfg = task_registry.make_alg_runner(env, "go2_flat", args, log_root=None)
+    runner, train_cfg = task_registry.make_alg_runner(env, a.task, args, log_root=None)
     env.common_step_counter = 0
     env.update_reward_curriculum(force_update=True)
 
@@ -125,30 +127,32 @@ def main():
     if rank == 0:
         total_steps = world * N * 24 * a.steps
         k_ms = ms.value / max(n.value, 1)
-        achieved = ALGO_BYTES_FLAT * N / (k_ms * 1e-3) / 1e9
+        algo = ALGO_BYTES_FLAT if a.task == "go2_flat" else ALGO_BYTES_ROUGH
+        achieved = algo * N / (k_ms * 1e-3) / 1e9
         # HBM traffic per launch from the rocprofv3 PMC passes (tools/pmc_pass.sh -> profiles/*_pmc_step_kernel.json; bench.py cannot
         # collect counters on itself).  Only quoted when the profiled launch shape is the benchmarked one.
         traffic, traffic_src = None, None
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_step_kernel.json")))[::-1]:
             pm = json.load(open(f))
-            if pm.get("num_envs") == N:
+            if pm.get("num_envs") == N and pm.get("task", "go2_flat") == a.task:
                 traffic, traffic_src = pm["hbm_bytes_per_launch_corrected"], os.path.relpath(f, ROOT)
                 break
         out = {
             "metric": "env-steps/sec at 4096 envs (go2 flat); 1/2/4/8-GPU scaling", "value": total_steps / elapsed, "unit": "env-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "task=go2 flat terrain (go2_flat), num_envs=%d per GPU, full PPO iteration = 24 rollout steps + GAE + 5 epochs x 4 mini-batches" % N,
+            "config": {"workload": "task=%s, num_envs=%d per GPU, full PPO iteration = 24 rollout steps + GAE + 5 epochs x 4 mini-batches"
+                                   % ("go2 flat terrain (go2_flat)" if a.task == "go2_flat" else "go2 rough curriculum terrain (go2; NOT the BASELINE workload)", N),
                        "num_envs_per_gpu": N, "num_steps_per_env": 24, "parallelism": "env-sharded dp%d" % world},
             "collection_only": world * N * 24 * a.steps / col,
             "roofline": {"bound": "hbm", "kernel": "go2_step_kernel<PHYS|POST>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": ALGO_BYTES_FLAT * N, "kernel_ms": k_ms, "launches": n.value, "algorithmic_bytes_per_env_step": ALGO_BYTES_FLAT,
+                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo * N, "kernel_ms": k_ms, "launches": n.value, "algorithmic_bytes_per_env_step": algo,
                          "note": "latency/occupancy-bound by construction: 4096 envs x 4 lanes = 256 waves for 1024 SIMDs (DESIGN.md 6)"},
         }
         if world == 1 and not a.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline()
+                out["cpu_baseline"] = cpu_baseline(task=a.task)
             except Exception as e:   # never lose the GPU number to a CPU-side problem
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out))

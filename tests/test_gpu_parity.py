@@ -21,13 +21,13 @@ def hip():
     return lib
 
 
-def test_golden_sequence_on_gpu(hip):
+@pytest.mark.parametrize("terrain", ["plane", "heightfield"])
+def test_golden_sequence_on_gpu(hip, terrain):
     """post_physics_step of the reference (golden vectors, injected uniforms) reproduced by the HIP kernel:
-    obs / priv obs <= 2e-5, rewards <= 2e-6 (fp32, tolerances in test_oracle_golden.TOL)."""
-    g = dict(np.load(os.path.join(G, "go2_plane_sequence.npz")))
-    N = g["actions"].shape[1]
-    s = DeviceSim(hip, num_envs=N)
-    hip.go2sim_set_common_step_counter(s.h, int(g["start_counter"]))
+    obs / priv obs <= 2e-5, rewards <= 2e-6 (fp32, tolerances in test_oracle_golden.TOL).  heightfield: + the 187-point
+    height scan, terrain curriculum and per-terrain-kind command ranges."""
+    g = dict(np.load(os.path.join(G, "go2_%s_sequence.npz" % terrain)))
+    s = tg._mk(hip, g, sim=DeviceSim)
     n = 0
     for t in tg.run_sequence(s, hip, g, None):
         s.torch.cuda.synchronize()
@@ -78,6 +78,51 @@ def test_one_step_parity_vs_oracle(hip):
         assert d[int(0.95 * N)] < 2e-3, (it, d[-3:])
     assert contact_seen > 1000
     so.close(); sd.close()
+
+
+def test_heightfield_one_step_parity_vs_oracle(hip):
+    """Same protocol on the rough curriculum map (all 20 terrain columns): contact against sloped / stepped facets,
+    height scan, terrain curriculum."""
+    from helpers import heightfield_overrides
+    N = 80
+    t, ov = heightfield_overrides(N)
+    so = HostSim(load_oracle(), num_envs=N, **ov)
+    sd = DeviceSim(hip, num_envs=N, **ov)
+    so.reset_all(); sd.reset_all()
+    rng = np.random.default_rng(2)
+    contact_seen = 0
+    for it in range(100):
+        a = rng.normal(0, 0.6, (N, 12)).astype(np.float32)
+        for k in STEP_STATE:
+            getattr(sd, k)[...] = np.asarray(getattr(so, k))
+        so.step(a); sd.step(a)
+        contact_seen += int((so.contact_forces[:, [6, 10, 14, 18], 2] > 1).sum())
+        for k, tol in (("root_states", 5e-4), ("dof_state", 2e-3), ("torques", 2e-3), ("obs_buf", 2e-4), ("privileged_obs_buf", 2e-4), ("rew_buf", 5e-6),
+                       ("measured_heights", 1e-6)):
+            d = np.sort(np.abs(np.asarray(getattr(so, k), np.float64) - np.asarray(getattr(sd, k), np.float64)).reshape(N, -1).max(1))
+            assert d[int(0.9 * N)] < tol and d[-1] < 100 * tol, (k, it, d[-4:])
+        np.testing.assert_array_equal(np.asarray(so.reset_buf), np.asarray(sd.reset_buf))
+        np.testing.assert_array_equal(np.asarray(so.terrain_levels), np.asarray(sd.terrain_levels))
+    assert contact_seen > 2000 and np.abs(np.asarray(so.measured_heights)).max() > 0.05
+    so.close(); sd.close()
+
+
+def test_train_rough_terrain_on_gpu(hip):
+    """task=go2 (trimesh -> height field, terrain curriculum, height scan in the privileged obs) through the product path."""
+    import tempfile
+    import torch
+    from go2_rl_gym_amd.envs import task_registry  # noqa: F401
+    from go2_rl_gym_amd.utils import get_args
+    args = get_args(["--task", "go2", "--num_envs", "400", "--headless", "--max_iterations", "3"])
+    env, _ = task_registry.make_env("go2", args)
+    assert env.height_samples.shape == (1345, 2195) and env.custom_origins and env.terrain_ids.shape == (400,)
+    runner, _ = task_registry.make_alg_runner(env, "go2", args, log_root=tempfile.mkdtemp())
+    env.common_step_counter = 0
+    runner.learn(3, init_at_random_ep_len=True)
+    assert torch.isfinite(env.obs_buf).all() and torch.isfinite(env.privileged_obs_buf).all() and runner.last_fps > 0
+    assert env.measured_heights.abs().max() > 0.02 and "terrain_level_all" in env.extras["episode"]
+    assert any(k.startswith("terrain_level_") and k != "terrain_level_all" for k in env.extras["episode"])
+    env.close()
 
 
 def test_full_size_properties(hip):

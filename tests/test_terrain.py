@@ -155,3 +155,27 @@ def test_robots_stand_on_every_terrain_kind(which):
     assert (hgt > 0.12).mean() > 0.9 and (hgt < 0.6).all(), np.sort(hgt)
     assert np.abs(root[:, 7:10]).max() < 3.0
     assert resets <= N // 4
+
+
+def test_rough_task_through_the_host_layer():
+    """task=go2 (mesh_type trimesh -> height field) through LeggedRobot/task_registry, on the host build of the lane programs
+    (the GPU run of the same path is tests/test_gpu_parity.py::test_train_rough_terrain_on_gpu)."""
+    import torch
+    from go2_rl_gym_amd.envs import task_registry
+    from go2_rl_gym_amd.utils import get_args
+    args = get_args(["--task", "go2", "--num_envs", "40", "--headless", "--sim_device", "cpu", "--rl_device", "cpu"])
+    env, cfg = task_registry.make_env("go2", args, lib=load_emu())
+    assert cfg.terrain.mesh_type == "trimesh" and env.custom_origins
+    assert tuple(env.height_samples.shape) == (1345, 2195) and env.height_samples.dtype == torch.int16
+    np.testing.assert_array_equal(env.terrain_ids.numpy(), np.array(env.terrain.cols2id)[env.terrain_types.numpy()])
+    np.testing.assert_allclose(env.env_origins.numpy(), env.terrain_origins.numpy()[env.terrain_levels.numpy(), env.terrain_types.numpy()])
+    a = torch.zeros(40, 12)
+    for _ in range(5):
+        obs, priv, rew, done, extras = env.step(a)
+    ep = extras["episode"]
+    assert abs(float(ep["terrain_level_all"]) - float(env.terrain_levels.float().mean())) < 1e-6
+    for name, cols in env.terrain.name2cols.items():
+        m = torch.isin(env.terrain_types, torch.tensor(sorted(cols)))
+        assert abs(float(ep["terrain_level_" + name]) - float(env.terrain_levels[m].float().mean())) < 1e-5
+    assert priv.shape == (40, 263) and float(env.measured_heights.abs().max()) > 0.02
+    env.close()
