@@ -36,19 +36,20 @@ def wrap_buffers(lib, handle, N, device):
         base = ctype._type_
         shp = shapes[name]
         itemsize = C.sizeof(base)
-        phys = tuple(reversed(shp)) if (layout == 1 and name not in _abi.ROW_MAJOR_ALWAYS and len(shp) > 1) else shp
+        transposed = layout == 1 and name not in _abi.ROW_MAJOR_ALWAYS and len(shp) > 1
+        phys = tuple(reversed(shp)) if transposed else shp
         # C-order strides of the physical array, then permuted back to the logical order
         st = [itemsize] * len(phys)
         for i in range(len(phys) - 2, -1, -1):
             st[i] = st[i + 1] * phys[i + 1]
-        if phys != shp:
+        if transposed:                       # NOT `phys != shp`: a (12, 12) buffer (num_envs == 12) is transposed too
             st = list(reversed(st))
         if on_device:
             addr = C.cast(ptr, C.c_void_p).value
             t = torch.as_tensor(_DeviceArray(addr, shp, _TYPESTR[base], st), device=device)
         else:
             arr = np.ctypeslib.as_array(ptr, shape=phys)
-            if phys != shp:
+            if transposed:
                 arr = arr.transpose()
             t = torch.from_numpy(arr)
         out[name] = t

@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 from helpers import ROOT, load_emu, load_oracle
@@ -51,3 +52,17 @@ def test_product_refuses_to_run_without_the_gpu_library(monkeypatch, tmp_path):
     args = get_args(["--task", "go2_flat", "--num_envs", "8", "--sim_device", "cpu", "--rl_device", "cpu", "--headless"])
     with pytest.raises(RuntimeError, match="GPU only"):
         task_registry.make_env("go2_flat", args)
+
+
+def test_wrap_buffers_square_shapes():
+    """num_envs == 12 makes the [N, 12] buffers square: their field-major storage must still be viewed transposed."""
+    import torch
+    from helpers import HostSim, load_emu
+    from go2_rl_gym_amd.envs.base.base_task import wrap_buffers
+    lib = load_emu()
+    s = HostSim(lib, num_envs=12)
+    t = wrap_buffers(lib, s.h, 12, "cpu")
+    s.actions[:] = np.arange(144, dtype=np.float32).reshape(12, 12)
+    np.testing.assert_array_equal(t["actions"].numpy(), np.asarray(s.actions))
+    assert t["actions"].stride() == (1, 12)
+    s.close()
