@@ -36,7 +36,8 @@ def parse():
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--num-envs", type=int, default=NUM_ENVS, help="envs PER GPU (weak scaling)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--task", default="go2_flat", choices=["go2_flat", "go2"], help="go2_flat is the BASELINE workload; go2 = the rough curriculum terrain (extra line, not the headline)")
+    p.add_argument("--task", default="go2_flat", choices=["go2_flat", "go2", "go2_flat_cts", "go2_flat_moe_cts", "go2_cts", "go2_moe_cts"],
+                   help="go2_flat is the BASELINE workload; the others are extra lines (rough curriculum terrain, CTS / MoE-CTS algorithms), never the headline")
     return p.parse_args()
 
 
@@ -115,7 +116,8 @@ def main():
     env.lib.go2sim_enable_timing(env.handle, 1)
     with torch.inference_mode():
         for _ in range(48):
-            env.step(runner.alg.actor_critic.act(env.get_observations()))
+            ac = runner.alg.actor_critic
+            env.step(ac.act(env.get_observations()) if a.task in ("go2_flat", "go2") else ac.act_inference(env.get_observations()))
     ms, n = C.c_double(), C.c_int64()
     env.lib.go2sim_kernel_time(env.handle, C.byref(ms), C.byref(n))
     env.lib.go2sim_enable_timing(env.handle, 0)
@@ -127,7 +129,7 @@ def main():
     if rank == 0:
         total_steps = world * N * 24 * a.steps
         k_ms = ms.value / max(n.value, 1)
-        algo = ALGO_BYTES_FLAT if a.task == "go2_flat" else ALGO_BYTES_ROUGH
+        algo = ALGO_BYTES_FLAT if "flat" in a.task else ALGO_BYTES_ROUGH
         achieved = algo * N / (k_ms * 1e-3) / 1e9
         # HBM traffic per launch from the rocprofv3 PMC passes (tools/pmc_pass.sh -> profiles/*_pmc_step_kernel.json; bench.py cannot
         # collect counters on itself).  Only quoted when the profiled launch shape is the benchmarked one.
@@ -143,7 +145,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "task=%s, num_envs=%d per GPU, full PPO iteration = 24 rollout steps + GAE + 5 epochs x 4 mini-batches"
-                                   % ("go2 flat terrain (go2_flat)" if a.task == "go2_flat" else "go2 rough curriculum terrain (go2; NOT the BASELINE workload)", N),
+                                   % ("go2 flat terrain (go2_flat)" if a.task == "go2_flat" else a.task + " (NOT the BASELINE workload)", N),
                        "num_envs_per_gpu": N, "num_steps_per_env": 24, "parallelism": "env-sharded dp%d" % world},
             "collection_only": world * N * 24 * a.steps / col,
             "roofline": {"bound": "hbm", "kernel": "go2_step_kernel<PHYS|POST>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

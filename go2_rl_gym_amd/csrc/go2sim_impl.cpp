@@ -333,7 +333,7 @@ __global__ void go2_normalize_kernel(float* adv, const double* partials, int cou
 __global__ void __launch_bounds__(256) go2_ppo_loss_kernel(const float* __restrict__ mu, const float* __restrict__ std_, const float* __restrict__ value,
     const float* __restrict__ actions, const float* __restrict__ old_mu, const float* __restrict__ old_sigma, const float* __restrict__ old_logp,
     const float* __restrict__ adv, const float* __restrict__ tv, const float* __restrict__ ret, float* __restrict__ gmu, float* __restrict__ gval,
-    float* __restrict__ part, int B, int A, float clip, float vcoef, int use_clip_v) {
+    float* __restrict__ part, int B, int A, float clip, float vcoef, int use_clip_v, int split, float w_head, float w_tail) {
   __shared__ float sh[4][PPO_NSTAT];
   const int i = blockIdx.x * 256 + threadIdx.x;
   float acc[PPO_NSTAT];
@@ -353,7 +353,8 @@ __global__ void __launch_bounds__(256) go2_ppo_loss_kernel(const float* __restri
     float lo = 1.f - clip, hi = 1.f + clip, rc = fminf(fmaxf(ratio, lo), hi); float in = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
     float s1 = -a * ratio, s2 = -a * rc, sur = fmaxf(s1, s2);
     float w = s1 > s2 ? 1.f : (s1 < s2 ? in : 0.5f + 0.5f * in);     // torch.max splits ties evenly; clamp passes gradient inside [lo, hi]
-    float g_lp = -a * w * ratio / (float)B;
+    const float wr = i < split ? w_head : w_tail;     // plain PPO: 1/B for every row; CTS: 1/teacher rows, 1/student rows
+    float g_lp = -a * w * ratio * wr;
     float v = value[i], dv = v - tv[i], vl, gv;
     if (use_clip_v) {
       float dc = fminf(fmaxf(dv, -clip), clip), vin = (dv >= -clip && dv <= clip) ? 1.f : 0.f, vc = tv[i] + dc;
@@ -366,7 +367,7 @@ __global__ void __launch_bounds__(256) go2_ppo_loss_kernel(const float* __restri
       gmu[(size_t)i * A + j] = g_lp * d / (sg * sg);
       if (j < PPO_NSTAT - 4) acc[4 + j] = g_lp * (d * d / (sg * sg * sg) - 1.f / sg);
     }
-    acc[0] = sur; acc[1] = vl; acc[2] = kl; acc[3] = ent;
+    acc[0] = sur * wr; acc[1] = vl; acc[2] = kl; acc[3] = ent;
   }
 #pragma unroll
   for (int k = 0; k < PPO_NSTAT; ++k) {
@@ -383,10 +384,20 @@ __global__ void go2_ppo_loss_finish_kernel(const float* __restrict__ part, const
   if (k >= PPO_NSTAT) return;
   float s = 0.f;
   for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * PPO_NSTAT + k];      // fixed order: deterministic
-  if (k < 4) { stats[k] = s / (float)B; }
+  if (k < 4) { stats[k] = k == 0 ? s : s / (float)B; }      // the surrogate partials are already weighted
   else if (k - 4 < A) gstd[k - 4] = s - ecoef / std_[k - 4];
   __syncthreads();
   if (k == 0) stats[4] = stats[0] + vcoef * stats[1] - ecoef * stats[3];
+}
+// ---- CTS observation-history ring (on_policy_runner_cts.py:155-156): one thread per (env, feature), H values in flight ------
+__global__ void __launch_bounds__(256) go2_history_push_kernel(float* __restrict__ hist, const float* __restrict__ obs, const uint8_t* __restrict__ dones, int N, int H, int D) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * D) return;
+  const int e = i / D, d = i - e * D;
+  const bool z = dones != nullptr && dones[e] != 0;
+  float* h = hist + (size_t)e * H * D + d;
+  for (int k = 0; k + 1 < H; ++k) h[(size_t)k * D] = z ? 0.f : h[(size_t)(k + 1) * D];
+  h[(size_t)(H - 1) * D] = obs[i];
 }
 #endif  // !GO2_EMU
 
@@ -858,7 +869,10 @@ int go2sim_normalize_advantages(float* adv, const double* partials, int32_t coun
 
 int go2sim_ppo_loss(const float* mu, const float* std_, const float* value, const float* actions, const float* old_mu, const float* old_sigma,
                     const float* old_logp, const float* adv, const float* tv, const float* ret, float* gmu, float* gstd, float* gval, float* stats,
-                    float* workspace, int32_t B, int32_t A, float clip, float vcoef, float ecoef, int32_t use_clip_v, void* stream) {
+                    float* workspace, int32_t B, int32_t A, float clip, float vcoef, float ecoef, int32_t use_clip_v, int32_t split, void* stream) {
+  if (split < 0 || split >= B) split = 0;
+  const float w_head = split ? 1.f / (float)split : 1.f / (float)B, w_tail = split ? 1.f / (float)(B - split) : 1.f / (float)B;
+  if (!split) split = B;
   if (!mu || !std_ || !value || !actions || !old_mu || !old_sigma || !old_logp || !adv || !tv || !ret || !gmu || !gstd || !gval || !stats || !workspace || B <= 0 || A <= 0 || A > 20)
     FAIL(GO2SIM_EINVAL, "bad argument");
 #ifdef GO2_EMU
@@ -871,21 +885,38 @@ int go2sim_ppo_loss(const float* mu, const float* std_, const float* value, cons
       lp += -d * d / (2.f * sg * sg) - ls - 0.5f * LOG2PI; ent += 0.5f + 0.5f * LOG2PI + ls;
       float so = old_sigma[(size_t)i * A + j], dm = old_mu[(size_t)i * A + j] - mu[(size_t)i * A + j]; kl += logf(sg / so + 1e-5f) + (so * so + dm * dm) / (2.f * sg * sg) - 0.5f; }
     float ratio = expf(lp - old_logp[i]), a = adv[i], lo = 1.f - clip, hi = 1.f + clip, rc = fminf(fmaxf(ratio, lo), hi), in = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
-    float s1 = -a * ratio, s2 = -a * rc, sur = fmaxf(s1, s2), w = s1 > s2 ? 1.f : (s1 < s2 ? in : 0.5f + 0.5f * in), g_lp = -a * w * ratio / (float)B;
+    float s1 = -a * ratio, s2 = -a * rc, sur = fmaxf(s1, s2), w = s1 > s2 ? 1.f : (s1 < s2 ? in : 0.5f + 0.5f * in), wr = i < split ? w_head : w_tail, g_lp = -a * w * ratio * wr;
     float v = value[i], dv = v - tv[i], vl, gv;
     if (use_clip_v) { float dc = fminf(fmaxf(dv, -clip), clip), vin = (dv >= -clip && dv <= clip) ? 1.f : 0.f, vc = tv[i] + dc, l1 = (v - ret[i]) * (v - ret[i]), l2 = (vc - ret[i]) * (vc - ret[i]);
       vl = fmaxf(l1, l2); float g1 = 2.f * (v - ret[i]), g2 = 2.f * (vc - ret[i]) * vin; gv = l1 > l2 ? g1 : (l1 < l2 ? g2 : 0.5f * g1 + 0.5f * g2); }
     else { vl = (ret[i] - v) * (ret[i] - v); gv = 2.f * (v - ret[i]); }
     gval[i] = vcoef * gv / (float)B;
     for (int j = 0; j < A; ++j) { float sg = std_[j], d = actions[(size_t)i * A + j] - mu[(size_t)i * A + j]; gmu[(size_t)i * A + j] = g_lp * d / (sg * sg); gs[j] += g_lp * (d * d / (sg * sg * sg) - 1.f / sg); }
-    s_sur += sur; s_vl += vl; s_kl += kl; s_ent += ent;
+    s_sur += sur * wr; s_vl += vl; s_kl += kl; s_ent += ent;
   }
   for (int j = 0; j < A; ++j) gstd[j] = (float)(gs[j] - ecoef / std_[j]);
-  stats[0] = (float)(s_sur / B); stats[1] = (float)(s_vl / B); stats[2] = (float)(s_kl / B); stats[3] = (float)(s_ent / B); stats[4] = stats[0] + vcoef * stats[1] - ecoef * stats[3];
+  stats[0] = (float)s_sur; stats[1] = (float)(s_vl / B); stats[2] = (float)(s_kl / B); stats[3] = (float)(s_ent / B); stats[4] = stats[0] + vcoef * stats[1] - ecoef * stats[3];
 #else
   int nb = (B + 255) / 256;
-  hipLaunchKernelGGL(go2_ppo_loss_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, mu, std_, value, actions, old_mu, old_sigma, old_logp, adv, tv, ret, gmu, gval, workspace, B, A, clip, vcoef, use_clip_v);
+  hipLaunchKernelGGL(go2_ppo_loss_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, mu, std_, value, actions, old_mu, old_sigma, old_logp, adv, tv, ret, gmu, gval, workspace, B, A, clip, vcoef, use_clip_v, split, w_head, w_tail);
   hipLaunchKernelGGL(go2_ppo_loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, workspace, std_, gstd, stats, nb, B, A, vcoef, ecoef);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+int go2sim_history_push(float* history, const float* obs, const uint8_t* dones, int32_t N, int32_t H, int32_t D, void* stream) {
+  if (!history || !obs || N <= 0 || H <= 0 || D <= 0) FAIL(GO2SIM_EINVAL, "bad argument");
+#ifdef GO2_EMU
+  (void)stream;
+  for (int e = 0; e < N; ++e) for (int d = 0; d < D; ++d) {
+    const bool z = dones && dones[e];
+    float* h = history + (size_t)e * H * D + d;
+    for (int k = 0; k + 1 < H; ++k) h[(size_t)k * D] = z ? 0.f : h[(size_t)(k + 1) * D];
+    h[(size_t)(H - 1) * D] = obs[(size_t)e * D + d];
+  }
+#else
+  hipLaunchKernelGGL(go2_history_push_kernel, dim3((N * D + 255) / 256), dim3(256), 0, (hipStream_t)stream, history, obs, dones, N, H, D);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

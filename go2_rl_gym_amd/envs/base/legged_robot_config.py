@@ -261,3 +261,68 @@ class LeggedRobotCfgPPO(BaseConfig):
     class robogauge:
         enabled = False
         port = 9973
+
+
+class LeggedRobotCfgCTS(BaseConfig):
+    """Concurrent Teacher-Student training (legged_robot_config.py:309-359)."""
+    seed = 0
+    runner_class_name = "OnPolicyRunnerCTS"
+    history_length = 5
+
+    class policy:
+        init_noise_std = 1.0
+        actor_hidden_dims = [512, 256, 128]
+        critic_hidden_dims = [512, 256, 128]
+        teacher_encoder_hidden_dims = [512, 256]
+        student_encoder_hidden_dims = [512, 256]
+        activation = "elu"
+        latent_dim = 32
+        norm_type = "l2norm"
+
+    class algorithm:
+        value_loss_coef = 1.0
+        use_clipped_value_loss = True
+        clip_param = 0.2
+        entropy_coef = 0.01
+        num_learning_epochs = 5
+        num_mini_batches = 4
+        learning_rate = 1.0e-3
+        student_encoder_learning_rate = 1.0e-3
+        schedule = "adaptive"
+        gamma = 0.99
+        lam = 0.95
+        desired_kl = 0.01
+        max_grad_norm = 1.0
+        teacher_env_ratio = 0.75
+
+    class runner:
+        policy_class_name = "ActorCriticCTS"
+        algorithm_class_name = "CTS"
+        num_steps_per_env = 24
+        max_iterations = 1500
+        save_interval = 50
+        experiment_name = "test"
+        run_name = ""
+        resume = False
+        load_run = -1
+        checkpoint = -1
+        resume_path = None
+
+    class robogauge:
+        enabled = False
+        port = 9973
+
+
+class LeggedRobotCfgMoECTS(LeggedRobotCfgCTS):
+    """MoE student encoder (legged_robot_config.py:399-409)."""
+
+    class policy(LeggedRobotCfgCTS.policy):
+        expert_num = 8
+        student_encoder_hidden_dims = [512, 256, 256]
+
+    class algorithm(LeggedRobotCfgCTS.algorithm):
+        load_balance_coef = 0.01
+
+    class runner(LeggedRobotCfgCTS.runner):
+        policy_class_name = "ActorCriticMoECTS"
+        algorithm_class_name = "MoECTS"

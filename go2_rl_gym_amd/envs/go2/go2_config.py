@@ -3,7 +3,7 @@
 (legged_gym/envs/go2/go2_config_fast_flat_move.py:98; the BASELINE workload "task=go2 flat terrain")."""
 import math
 
-from ..base.legged_robot_config import LeggedRobotCfg, LeggedRobotCfgPPO, _max_cmd_table
+from ..base.legged_robot_config import LeggedRobotCfg, LeggedRobotCfgCTS, LeggedRobotCfgMoECTS, LeggedRobotCfgPPO, _max_cmd_table
 
 _LEGS = ("FL", "FR", "RL", "RR")
 
@@ -153,3 +153,37 @@ class GO2CfgPPO(LeggedRobotCfgPPO):
 class GO2FlatCfgPPO(GO2CfgPPO):
     class runner(GO2CfgPPO.runner):
         experiment_name = "go2_flat_ppo"
+
+
+class GO2CfgCTS(LeggedRobotCfgCTS):                 # go2_config.py:219-229
+    class runner(LeggedRobotCfgCTS.runner):
+        num_steps_per_env = 24
+        run_name = ""
+        experiment_name = "go2_cts"
+        max_iterations = 150000
+        save_interval = 500
+
+    class policy(LeggedRobotCfgCTS.policy):
+        latent_dim = 32
+        norm_type = "l2norm"
+
+
+class GO2CfgMoECTS(LeggedRobotCfgMoECTS):           # go2_config.py:276-284
+    class policy(LeggedRobotCfgMoECTS.policy):
+        expert_num = 8
+
+    class runner(LeggedRobotCfgMoECTS.runner):
+        run_name = ""
+        experiment_name = "go2_moe_cts"
+        max_iterations = 150000
+        save_interval = 500
+
+
+class GO2FlatCfgCTS(GO2CfgCTS):
+    class runner(GO2CfgCTS.runner):
+        experiment_name = "go2_flat_cts"
+
+
+class GO2FlatCfgMoECTS(GO2CfgMoECTS):
+    class runner(GO2CfgMoECTS.runner):
+        experiment_name = "go2_flat_moe_cts"

@@ -1,1 +1,3 @@
 from .ppo import PPO
+from .cts import CTS
+from .moe_cts import MoECTS

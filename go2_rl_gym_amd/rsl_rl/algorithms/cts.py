@@ -1,0 +1,285 @@
+"""Concurrent Teacher-Student PPO (rsl_rl/rsl_rl/algorithms/cts.py:39-286; CTS, arXiv 2405.10830).
+
+75 % of the envs act through the teacher encoder (privileged obs -> latent), 25 % through the student encoder (5-frame
+history -> latent); both share the actor and the critic.  optimizer1 (teacher encoder, critic, actor, std) takes the PPO
+loss with   surrogate = mean(teacher rows) + mean(student rows)   (:228-231); optimizer2 trains the student encoder to
+reproduce the teacher's latent on the student rows (:259-275), after the policy epochs, on the same mini-batches.
+
+Re-designed for the GPU: the rollout stays in env order (storage/rollout_storage_cts.py); each group's latent is computed
+once and ONE actor pass and ONE critic pass serve all rows, in the rollout and in the update; the loss head is the fused
+library kernel (go2sim_ppo_loss, surrogate_split = teacher rows); the policy step and the student step are each captured
+into a HIP graph and replayed 20x per iteration with the learning rate in a device tensor.  The eager mode keeps the
+reference's control flow and is what tests/test_cts_golden.py pins against the reference's own update."""
+import itertools
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.optim as optim
+
+from ..storage import RolloutStorageCTS
+from ._graph import CapturedStep
+from .ppo import _collectives_on, _FusedPPOLoss, _world
+
+
+def _allreduce_mean_grads(params, world):
+    grads = [p.grad for p in params if p.grad is not None]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= world
+    off = 0
+    for g in grads:
+        n = g.numel(); g.copy_(flat[off:off + n].view_as(g)); off += n
+
+
+class CTS:
+    def __init__(self, model, num_envs, history_length, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95,
+                 value_loss_coef=1.0, entropy_coef=0.0, learning_rate=1e-3, student_encoder_learning_rate=1e-3, max_grad_norm=1.0,
+                 use_clipped_value_loss=True, schedule="fixed", desired_kl=0.01, teacher_env_ratio=0.75, device="cpu", lib=None,
+                 use_graphs=None, fused_loss=None):
+        self.device, self.lib = device, lib
+        self.desired_kl, self.schedule, self.learning_rate = desired_kl, schedule, learning_rate
+        self.history_length = history_length
+        self.model = model
+        self.model.to(self.device)
+        self.storage = None
+        on_gpu = str(device).startswith("cuda")
+        self.use_graphs = on_gpu if use_graphs is None else bool(use_graphs and on_gpu)
+        self.fused_loss = (on_gpu and lib is not None) if fused_loss is None else bool(fused_loss and lib is not None)
+        groups1 = [{"params": list(self.model.teacher_encoder.parameters())}, {"params": list(self.model.critic.parameters())},
+                   {"params": list(self.model.actor.parameters())}, {"params": [self.model.std]}]           # same 4 groups as the reference (:72-77)
+        self._params1 = list(itertools.chain.from_iterable(g["params"] for g in groups1))
+        self._params2 = list(self.model.student_parameters())
+        if self.use_graphs:
+            self._lr_t = torch.tensor(float(learning_rate), device=device)
+            self.optimizer1 = optim.Adam(groups1, lr=self._lr_t, capturable=True, foreach=True)
+            self.optimizer2 = optim.Adam(self._params2, lr=torch.tensor(float(student_encoder_learning_rate), device=device), capturable=True, foreach=True)
+        else:
+            self._lr_t = None
+            self.optimizer1 = optim.Adam(groups1, lr=learning_rate)
+            self.optimizer2 = optim.Adam(self._params2, lr=student_encoder_learning_rate)
+        self.transition = RolloutStorageCTS.Transition()
+        self.clip_param, self.num_learning_epochs, self.num_mini_batches = clip_param, num_learning_epochs, num_mini_batches
+        self.value_loss_coef, self.entropy_coef, self.gamma, self.lam = value_loss_coef, entropy_coef, gamma, lam
+        self.max_grad_norm, self.use_clipped_value_loss = max_grad_norm, use_clipped_value_loss
+        # teacher / student split (:90-101): with ratio 0.75 every 4th env is a student
+        self.teacher_num_envs = max(int(num_envs * teacher_env_ratio), 1)
+        self.student_num_envs = num_envs - self.teacher_num_envs
+        every = int(1 / (1 - teacher_env_ratio))
+        ids = torch.arange(num_envs, device=self.device)
+        self.teacher_env_idxs, self.student_env_idxs = ids[ids % every != 0], ids[ids % every == 0]
+        assert len(self.teacher_env_idxs) == self.teacher_num_envs, f"{len(self.teacher_env_idxs)=} != {self.teacher_num_envs=}"
+        assert len(self.student_env_idxs) == self.student_num_envs, f"{len(self.student_env_idxs)=} != {self.student_num_envs=}"
+        self.surrogate_split = 0            # set per update: teacher rows of a mini-batch (read by _FusedPPOLoss)
+        self._steps = None
+        if _world() > 1:
+            for p in self.model.parameters():
+                dist.broadcast(p.data, src=0)
+
+    # the runner reaches the networks through either name
+    @property
+    def actor_critic(self):
+        return self.model
+
+    def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape):
+        self.storage = RolloutStorageCTS(num_envs, self.teacher_env_idxs, self.student_env_idxs, self.history_length, num_transitions_per_env,
+                                         actor_obs_shape, critic_obs_shape, action_shape, self.device, lib=self.lib)
+
+    def test_mode(self):
+        self.model.eval()
+
+    def train_mode(self):
+        self.model.train()
+
+    # ------------------------------------------------------------------ rollout half (:112-166), env order
+    def _latent_env_order(self, privileged_obs, history):
+        m, ti, si = self.model, self.teacher_env_idxs, self.student_env_idxs
+        lt = m.teacher_encoder(privileged_obs[ti])
+        ls = m.student_latent(history[si])[0]
+        latent = torch.empty(privileged_obs.shape[0], lt.shape[1], device=lt.device, dtype=lt.dtype)
+        latent.index_copy_(0, ti, lt.detach())
+        latent.index_copy_(0, si, ls.detach())
+        return latent
+
+    def act(self, obs, privileged_obs, history):
+        st, t, m = self.storage, self.transition, self.model
+        s = st.step
+        if s >= st.num_transitions_per_env:
+            raise AssertionError("Rollout buffer overflow")
+        # record what env.step() is about to overwrite (the env's buffers and the runner's history ring are updated in place)
+        st.observations[s].copy_(obs)
+        st.privileged_observations[s].copy_(privileged_obs)
+        st.history[s].copy_(history)
+        latent = self._latent_env_order(privileged_obs, history)
+        t.actions = m.act_joint(obs, latent).detach()
+        t.values = m.evaluate_joint(privileged_obs, latent).detach()
+        t.actions_log_prob = m.get_actions_log_prob(t.actions).detach()
+        t.action_mean, t.action_sigma = m.action_mean.detach(), m.action_std.detach()
+        st.actions[s].copy_(t.actions)
+        st.values[s].copy_(t.values)
+        st.actions_log_prob[s].copy_(t.actions_log_prob.view(-1, 1))
+        st.mu[s].copy_(t.action_mean)
+        st.sigma[s].copy_(t.action_sigma)
+        return t.actions
+
+    def process_env_step(self, rewards, dones, infos):
+        st = self.storage
+        s = st.step
+        r = rewards.clone()
+        if "time_outs" in infos:   # bootstrap on time-outs (:156-158)
+            r += self.gamma * torch.squeeze(st.values[s] * infos["time_outs"].unsqueeze(1).to(self.device), 1)
+        st.rewards[s].copy_(r.view(-1, 1))
+        st.dones[s].copy_(dones.view(-1, 1))
+        st.step += 1
+        self.transition.clear()
+        self.model.history.masked_fill_(dones.view(-1, 1, 1) > 0, 0.0)          # model.reset(dones) (:163) without a boolean-index sync
+
+    def compute_returns(self, last_privileged_obs, last_history):
+        latent = self._latent_env_order(last_privileged_obs, last_history)
+        last_values = self.model.evaluate_joint(last_privileged_obs, latent).detach()
+        self.storage.compute_returns(last_values, self.gamma, self.lam)
+
+    # ------------------------------------------------------------------ update half (:167-286)
+    def _policy_losses(self, obs_b, priv_b, hist_b, act_b, tv_b, adv_b, ret_b, old_lp_b, old_mu_b, old_sig_b, n_t):
+        """-> loss, value_loss, surrogate_loss, entropy_mean, kl_mean   (rows [0,n_t) teacher, the rest student)"""
+        m = self.model
+        latent = m.latents(priv_b, hist_b, n_t)
+        if self.fused_loss:
+            mu_b = m.actor(torch.cat([latent, obs_b], dim=1))
+            val_b = m.evaluate_joint(priv_b, latent)
+            self.surrogate_split = n_t
+            loss, stats = _FusedPPOLoss.apply(mu_b, m.std, val_b, self, act_b, tv_b, adv_b, ret_b, old_lp_b, old_mu_b, old_sig_b)
+            return loss, stats[1], stats[0], stats[3], stats[2]
+        m.update_distribution(torch.cat([latent, obs_b], dim=1))
+        lp_b = m.get_actions_log_prob(act_b)
+        val_b = m.evaluate_joint(priv_b, latent)
+        mu_b, sig_b, ent_b = m.action_mean, m.action_std, m.entropy
+        with torch.no_grad():
+            kl = torch.sum(torch.log(sig_b / old_sig_b + 1.0e-5) + (torch.square(old_sig_b) + torch.square(old_mu_b - mu_b)) / (2.0 * torch.square(sig_b)) - 0.5, axis=-1)
+            kl_mean = torch.mean(kl)
+        ratio = torch.exp(lp_b - torch.squeeze(old_lp_b))
+        sur = -torch.squeeze(adv_b) * ratio
+        sur_clip = -torch.squeeze(adv_b) * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)
+        sl = torch.max(sur, sur_clip)
+        surrogate_loss = sl[:n_t].mean() + sl[n_t:].mean()
+        if self.use_clipped_value_loss:
+            v_clip = tv_b + (val_b - tv_b).clamp(-self.clip_param, self.clip_param)
+            value_loss = torch.max((val_b - ret_b).pow(2), (v_clip - ret_b).pow(2)).mean()
+        else:
+            value_loss = (ret_b - val_b).pow(2).mean()
+        ent = ent_b.mean()
+        loss = surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * ent
+        return loss, value_loss, surrogate_loss, ent, kl_mean
+
+    def _student_losses(self, hist_s, priv_s):
+        """-> total loss, (latent_loss, ...) for the log    (student rows only)"""
+        student_latent, _ = self.model.student_latent(hist_s)
+        with torch.no_grad():
+            teacher_latent = self.model.teacher_encoder(priv_s)
+        latent_loss = (teacher_latent - student_latent).pow(2).mean()
+        return latent_loss, (latent_loss,)
+
+    _NUM_STUDENT_LOGS = 1
+
+    def _gather(self, fl, b):
+        return tuple(fl[k][b] for k in ("obs", "cobs", "hist", "act", "val", "adv", "ret", "logp", "mu", "sig"))
+
+    def _teacher_rows(self):
+        return self.teacher_num_envs * self.storage.num_transitions_per_env // self.num_mini_batches
+
+    def _update_eager(self):
+        fl, n_t = self.storage.flat(), self._teacher_rows()
+        idx = self.storage.mini_batch_indices(self.num_mini_batches)
+        world, sync = _world(), _collectives_on()
+        acc = [0.0] * (3 + self._NUM_STUDENT_LOGS)
+        for _ in range(self.num_learning_epochs):
+            for b in idx:
+                loss, value_loss, surrogate_loss, ent, kl_mean = self._policy_losses(*self._gather(fl, b), n_t)
+                if self.desired_kl is not None and self.schedule == "adaptive":
+                    if sync:
+                        dist.all_reduce(kl_mean, op=dist.ReduceOp.SUM)
+                        kl_mean /= world
+                    if kl_mean > self.desired_kl * 2.0:
+                        self.learning_rate = max(1e-5, self.learning_rate / 1.5)
+                    elif kl_mean < self.desired_kl / 2.0 and kl_mean > 0.0:
+                        self.learning_rate = min(1e-2, self.learning_rate * 1.5)
+                    for g in self.optimizer1.param_groups:
+                        if torch.is_tensor(g["lr"]):
+                            g["lr"].fill_(self.learning_rate)
+                        else:
+                            g["lr"] = self.learning_rate
+                self.optimizer1.zero_grad()
+                loss.backward()
+                if sync:
+                    _allreduce_mean_grads(self._params1, world)
+                nn.utils.clip_grad_norm_(self._params1, self.max_grad_norm)
+                self.optimizer1.step()
+                acc[0] += value_loss.item(); acc[1] += surrogate_loss.item(); acc[2] += ent.item()
+        for _ in range(self.num_learning_epochs):
+            for b in idx:
+                bs = b[n_t:]
+                loss, logs = self._student_losses(fl["hist"][bs], fl["cobs"][bs])
+                self.optimizer2.zero_grad()
+                loss.backward()
+                if sync:
+                    _allreduce_mean_grads(self._params2, world)
+                nn.utils.clip_grad_norm_(self._params2, self.max_grad_norm)
+                self.optimizer2.step()
+                for i, v in enumerate(logs):
+                    acc[3 + i] += v.item()
+        n = self.num_learning_epochs * self.num_mini_batches
+        return tuple(a / n for a in acc)
+
+    # ---- graph mode: every decision on the device, two captured steps ----------------------------------------
+    def _policy_step(self):
+        loss, value_loss, surrogate_loss, ent, kl_mean = self._policy_losses(*self._gather(self._flat, self._idx), self._teacher_rows())
+        if self.desired_kl is not None and self.schedule == "adaptive":
+            if _collectives_on():
+                dist.all_reduce(kl_mean, op=dist.ReduceOp.SUM)
+                kl_mean = kl_mean / _world()
+            lr = self._lr_t
+            up, down = torch.clamp(lr * 1.5, max=1e-2), torch.clamp(lr / 1.5, min=1e-5)
+            lr.copy_(torch.where(kl_mean > self.desired_kl * 2.0, down, torch.where((kl_mean < self.desired_kl / 2.0) & (kl_mean > 0.0), up, lr)))
+        self.optimizer1.zero_grad(set_to_none=True)
+        loss.backward()
+        if _collectives_on():
+            _allreduce_mean_grads(self._params1, _world())
+        nn.utils.clip_grad_norm_(self._params1, self.max_grad_norm, foreach=True)
+        self.optimizer1.step()
+        self._acc[:3].add_(torch.stack([value_loss.detach(), surrogate_loss.detach(), ent.detach()]))
+
+    def _student_step(self):
+        bs = self._idx[self._teacher_rows():]
+        loss, logs = self._student_losses(self._flat["hist"][bs], self._flat["cobs"][bs])
+        self.optimizer2.zero_grad(set_to_none=True)
+        loss.backward()
+        if _collectives_on():
+            _allreduce_mean_grads(self._params2, _world())
+        nn.utils.clip_grad_norm_(self._params2, self.max_grad_norm, foreach=True)
+        self.optimizer2.step()
+        self._acc[3:].add_(torch.stack([v.detach() for v in logs]))
+
+    def _update_graphs(self):
+        st = self.storage
+        if self._steps is None:
+            self._flat = st.flat()
+            mb = (st.teacher_num_envs * st.num_transitions_per_env) // self.num_mini_batches + (st.student_num_envs * st.num_transitions_per_env) // self.num_mini_batches
+            self._idx = torch.zeros(mb, dtype=torch.int64, device=self.device)
+            self._acc = torch.zeros(3 + self._NUM_STUDENT_LOGS, device=self.device)
+            self._steps = (CapturedStep(self._policy_step, name="CTS policy step"), CapturedStep(self._student_step, name="CTS student step"))
+        self._acc.zero_()
+        idx = st.mini_batch_indices(self.num_mini_batches)
+        for step in self._steps:
+            for _ in range(self.num_learning_epochs):
+                for b in idx:
+                    self._idx.copy_(b)
+                    step()
+        n = self.num_learning_epochs * self.num_mini_batches
+        out = (self._acc / n).tolist()
+        self.learning_rate = float(self._lr_t.item())
+        return tuple(out)
+
+    def update(self):
+        out = self._update_graphs() if self.use_graphs else self._update_eager()
+        self.storage.clear()
+        return out

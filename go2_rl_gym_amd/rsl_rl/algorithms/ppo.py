@@ -56,7 +56,7 @@ class _FusedPPOLoss(torch.autograd.Function):
         stream = C.c_void_p(torch.cuda.current_stream(mu.device).cuda_stream) if mu.is_cuda else None
         p = lambda t: C.c_void_p(t.data_ptr())
         rc = lib.go2sim_ppo_loss(*[p(t) for t in args], p(gmu), p(gstd), p(gval), p(stats), p(ws), B, A, float(alg.clip_param), float(alg.value_loss_coef),
-                                 float(alg.entropy_coef), int(alg.use_clipped_value_loss), stream)
+                                 float(alg.entropy_coef), int(alg.use_clipped_value_loss), int(getattr(alg, "surrogate_split", 0)), stream)
         if rc != 0:
             raise RuntimeError("go2sim_ppo_loss failed: %s" % lib.go2sim_last_error().decode())
         ctx.save_for_backward(gmu, gstd, gval.view_as(value))

@@ -1,1 +1,3 @@
 from .actor_critic import ActorCritic, get_activation
+from .actor_critic_cts import ActorCriticCTS
+from .actor_critic_moe_cts import ActorCriticMoECTS

@@ -1,1 +1,2 @@
 from .on_policy_runner import OnPolicyRunner
+from .on_policy_runner_cts import OnPolicyRunnerCTS

@@ -85,9 +85,8 @@ class OnPolicyRunner:
         self.policy_cfg = train_cfg["policy"]
         self.device = device
         self.env = env
-        num_critic_obs = self.env.num_privileged_obs if self.env.num_privileged_obs is not None else self.env.num_obs
-        actor_critic = _POLICIES[self.cfg["policy_class_name"]](self.env.num_obs, num_critic_obs, self.env.num_actions, **self.policy_cfg).to(self.device)
-        self.alg = _ALGS[self.cfg["algorithm_class_name"]](actor_critic, device=self.device, lib=getattr(env, "lib", None), use_graphs=use_graphs, **self.alg_cfg)
+        self.lib = getattr(env, "lib", None)
+        self._build_algorithm(train_cfg, use_graphs)
         self.num_steps_per_env = self.cfg["num_steps_per_env"]
         self.save_interval = self.cfg["save_interval"]
         self.alg.init_storage(self.env.num_envs, self.num_steps_per_env, [self.env.num_obs], [self.env.num_privileged_obs], [self.env.num_actions])
@@ -112,6 +111,23 @@ class OnPolicyRunner:
             Path(self.log_dir).mkdir(parents=True, exist_ok=True)
             all_cfg = {"train_cfg": train_cfg, "env_cfg": class_to_dict(self.env.cfg)}
             yaml.safe_dump(all_cfg, open(os.path.join(self.log_dir, "config.yaml"), "w"))
+
+    # ---- hooks the CTS runner overrides ----
+    _LOSS_NAMES = (("mean_value_loss", "Loss/value_function", "Value function loss:"), ("mean_surrogate_loss", "Loss/surrogate", "Surrogate loss:"))
+
+    def _build_algorithm(self, train_cfg, use_graphs):
+        num_critic_obs = self.env.num_privileged_obs if self.env.num_privileged_obs is not None else self.env.num_obs
+        actor_critic = _POLICIES[self.cfg["policy_class_name"]](self.env.num_obs, num_critic_obs, self.env.num_actions, **self.policy_cfg).to(self.device)
+        self.alg = _ALGS[self.cfg["algorithm_class_name"]](actor_critic, device=self.device, lib=self.lib, use_graphs=use_graphs, **self.alg_cfg)
+
+    def _begin_learn(self):
+        pass
+
+    def _compute_returns(self):
+        obs = self.env.get_observations()
+        privileged_obs = self.env.get_privileged_observations()
+        critic_obs = (privileged_obs if privileged_obs is not None else obs).to(self.device)
+        self.alg.compute_returns(critic_obs)
 
     def _sync(self):
         if str(self.device).startswith("cuda"):
@@ -151,6 +167,7 @@ class OnPolicyRunner:
         if init_at_random_ep_len:
             self.env.episode_length_buf = torch.randint_like(self.env.episode_length_buf, high=int(self.env.max_episode_length))
         self.alg.actor_critic.train()
+        self._begin_learn()
         rewbuffer, lenbuffer = self._rewbuffer, self._lenbuffer
         N, T = self.env.num_envs, self.num_steps_per_env
         bk = self._bk if self.log_dir is not None else None
@@ -183,18 +200,14 @@ class OnPolicyRunner:
                 stop = time.time()
                 collection_time = stop - start
                 start = stop
-                obs = self.env.get_observations()
-                privileged_obs = self.env.get_privileged_observations()
-                critic_obs = (privileged_obs if privileged_obs is not None else obs).to(self.device)
-                self.alg.compute_returns(critic_obs)
-            mean_value_loss, mean_surrogate_loss = self.alg.update()
+                self._compute_returns()
+            losses = self.alg.update()
+            mean_value_loss, mean_surrogate_loss = losses[0], losses[1]
             self._sync()
             stop = time.time()
             learn_time = stop - start
             if self.log_dir is not None:
-                m = bk["fin_mask"].cpu().numpy()   # one device->host read per iteration, same deque order as the reference (step-major)
-                rewbuffer.extend(bk["fin_rew"].cpu().numpy()[m].tolist())
-                lenbuffer.extend(bk["fin_len"].cpu().numpy()[m].tolist())
+                self._collect_episode_stats(bk)
                 self.log(locals())
             self.last_collection_time, self.last_learn_time = collection_time, learn_time
             self.last_fps = T * N * _world() / (collection_time + learn_time)
@@ -203,6 +216,15 @@ class OnPolicyRunner:
         self.current_learning_iteration += num_learning_iterations
         if self.log_dir is not None:
             self.save(os.path.join(self.log_dir, "model_{}.pt".format(self.current_learning_iteration)), it, True)
+
+    def _collect_episode_stats(self, bk):
+        m = bk["fin_mask"].cpu().numpy()   # one device->host read per iteration, same deque order as the reference (step-major)
+        self._rewbuffer.extend(bk["fin_rew"].cpu().numpy()[m].tolist())
+        self._lenbuffer.extend(bk["fin_len"].cpu().numpy()[m].tolist())
+
+    def _reward_stats(self):
+        """-> [(tensorboard suffix, console label, rewards deque, lengths deque)]"""
+        return [("", "", self._rewbuffer, self._lenbuffer)]
 
     def log(self, locs, width=80, pad=35):
         self.tot_timesteps += self.num_steps_per_env * self.env.num_envs
@@ -217,33 +239,34 @@ class OnPolicyRunner:
                     v = torch.as_tensor(v, dtype=torch.float, device=self.device).reshape(-1)
                     vals.append(v)
                 value = torch.mean(torch.cat(vals))
-                self.writer.add_scalar("Episode/" + key, value, locs["it"])
+                self.writer.add_scalar(("Terrain/" if "terrain" in key else "Episode/") + key, value, locs["it"])
                 ep_string += f"""{f'Mean episode {key}:':>{pad}} {value:.4f}\n"""
         mean_std = self.alg.actor_critic.std.mean()
         fps = int(self.num_steps_per_env * self.env.num_envs / (locs["collection_time"] + locs["learn_time"]))
         w = self.writer
-        w.add_scalar("Loss/value_function", locs["mean_value_loss"], locs["it"])
-        w.add_scalar("Loss/surrogate", locs["mean_surrogate_loss"], locs["it"])
+        for (name, tag, _), v in zip(self._LOSS_NAMES, locs["losses"]):
+            w.add_scalar(tag, v, locs["it"])
         w.add_scalar("Loss/learning_rate", self.alg.learning_rate, locs["it"])
         w.add_scalar("Policy/mean_noise_std", mean_std.item(), locs["it"])
         w.add_scalar("Perf/total_fps", fps, locs["it"])
         w.add_scalar("Perf/collection time", locs["collection_time"], locs["it"])
         w.add_scalar("Perf/learning_time", locs["learn_time"], locs["it"])
-        have = len(locs["rewbuffer"]) > 0
-        if have:
-            w.add_scalar("Train/mean_reward", statistics.mean(locs["rewbuffer"]), locs["it"])
-            w.add_scalar("Train/mean_episode_length", statistics.mean(locs["lenbuffer"]), locs["it"])
-            w.add_scalar("Train/mean_reward/time", statistics.mean(locs["rewbuffer"]), self.tot_time)
-            w.add_scalar("Train/mean_episode_length/time", statistics.mean(locs["lenbuffer"]), self.tot_time)
+        groups = [g for g in self._reward_stats() if len(g[2]) > 0]
+        for sfx, _, rb, lb in groups:
+            w.add_scalar("Train/mean_%sreward" % sfx, statistics.mean(rb), locs["it"])
+            w.add_scalar("Train/mean_%sepisode_length" % sfx, statistics.mean(lb), locs["it"])
+            w.add_scalar("Train/mean_%sreward/time" % sfx, statistics.mean(rb), self.tot_time)
+            w.add_scalar("Train/mean_%sepisode_length/time" % sfx, statistics.mean(lb), self.tot_time)
         head = f" \033[1m Learning iteration {locs['it']}/{self.current_learning_iteration + locs['num_learning_iterations']} \033[0m "
         s = (f"""{'#' * width}\n{head.center(width, ' ')}\n\n"""
              f"""{'Computation:':>{pad}} {fps:.0f} steps/s (collection: {locs['collection_time']:.3f}s, learning {locs['learn_time']:.3f}s)\n"""
-             f"""{'Value function loss:':>{pad}} {locs['mean_value_loss']:.4f}\n"""
-             f"""{'Surrogate loss:':>{pad}} {locs['mean_surrogate_loss']:.4f}\n"""
-             f"""{'Mean action noise std:':>{pad}} {mean_std.item():.2f}\n""")
-        if have:
-            s += (f"""{'Mean reward:':>{pad}} {statistics.mean(locs['rewbuffer']):.2f}\n"""
-                  f"""{'Mean episode length:':>{pad}} {statistics.mean(locs['lenbuffer']):.2f}\n""")
+             )
+        for (_, _, label), v in zip(self._LOSS_NAMES, locs["losses"]):
+            s += f"""{label:>{pad}} {v:.4f}\n"""
+        s += f"""{'Mean action noise std:':>{pad}} {mean_std.item():.2f}\n"""
+        for _, label, rb, lb in groups:
+            s += (f"""{'Mean %sreward:' % label:>{pad}} {statistics.mean(rb):.2f}\n"""
+                  f"""{'Mean %sepisode length:' % label:>{pad}} {statistics.mean(lb):.2f}\n""")
         s += ep_string
         s += (f"""{'-' * width}\n{'Total timesteps:':>{pad}} {self.tot_timesteps}\n{'Iteration time:':>{pad}} {iteration_time:.2f}s\n"""
               f"""{'Total time:':>{pad}} {self.tot_time:.2f}s\n"""

@@ -2,11 +2,11 @@
 import os
 from datetime import datetime
 
-from ..rsl_rl.runners import OnPolicyRunner  # noqa: F401  (resolved by name below)
+from ..rsl_rl.runners import OnPolicyRunner, OnPolicyRunnerCTS
 from .helpers import class_to_dict, get_args, get_load_path, parse_sim_params, set_seed, update_cfg_from_args
 
 ROOT_DIR = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-_RUNNERS = {"OnPolicyRunner": OnPolicyRunner}
+_RUNNERS = {"OnPolicyRunner": OnPolicyRunner, "OnPolicyRunnerCTS": OnPolicyRunnerCTS}
 
 
 class TaskRegistry:

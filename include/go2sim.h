@@ -341,12 +341,20 @@ int  go2sim_normalize_advantages(float* advantages, const double* partials, int3
  * of   loss = mean(surrogate) + value_coef * mean(value_loss) - entropy_coef * mean(entropy)
  * w.r.t. mu [B,A], the state-independent std [A] and value [B] in one pass (what autograd spreads over ~150 launches).
  * stats[5] = {surrogate_loss, value_loss, kl_mean, entropy_mean, loss}.  workspace: >= 24*ceil(B/256) floats.
+ * surrogate_split: 0 = plain PPO.  0 < split < B = the Concurrent-Teacher-Student surrogate (algorithms/cts.py:228-231):
+ *   mean(surrogate[:split]) + mean(surrogate[split:]) — teacher rows first, student rows after; value loss / entropy / KL
+ *   stay means over all B rows.
  * Deterministic: block partials are combined in a fixed order by a second tiny kernel. */
 int  go2sim_ppo_loss(const float* mu, const float* std, const float* value, const float* actions, const float* old_mu,
                      const float* old_sigma, const float* old_log_prob, const float* advantages, const float* target_values,
                      const float* returns, float* grad_mu, float* grad_std, float* grad_value, float* stats, float* workspace,
                      int32_t B, int32_t A, float clip_param, float value_loss_coef, float entropy_coef,
-                     int32_t use_clipped_value_loss, void* stream);
+                     int32_t use_clipped_value_loss, int32_t surrogate_split, void* stream);
+
+/* Observation-history ring of the CTS runner (on_policy_runner_cts.py:155-156), in place:
+ *   history[dones > 0] = 0;  history = cat(history[:, 1:], obs[:, None])      history: float [N,H,D], obs: float [N,D],
+ * dones: uint8 [N] or NULL (no zeroing: the push before the first step, :129). */
+int  go2sim_history_push(float* history, const float* obs, const uint8_t* dones, int32_t N, int32_t H, int32_t D, void* stream);
 
 #ifdef __cplusplus
 }

@@ -306,6 +306,126 @@ def gen_ppo(seed=5):
     return out
 
 
+class _ScriptedEnv:
+    """The VecEnv surface OnPolicyRunnerCTS consumes (rsl_rl/env/vec_env.py), replaying pre-generated tensors: the runner-level
+    fixtures need the reference's RUNNER + ALGORITHM + STORAGE + MODULES, not its simulator."""
+
+    class _Cfg:
+        class env:
+            test = True
+
+    def __init__(self, obs, priv, rew, dones, touts):
+        self.obs_seq, self.priv_seq, self.rew_seq, self.done_seq, self.tout_seq = obs, priv, rew, dones, touts
+        self.num_envs, self.num_obs, self.num_privileged_obs, self.num_actions = obs.shape[1], obs.shape[2], priv.shape[2], 12
+        self.max_episode_length = 1000
+        self.episode_length_buf = torch.zeros(self.num_envs, dtype=torch.long)
+        self.cfg = self._Cfg()
+        self.t = 0
+        self.actions = []
+
+    def reset(self):
+        return self.obs_seq[0], self.priv_seq[0]
+
+    def get_observations(self):
+        return self.obs_seq[self.t]
+
+    def get_privileged_observations(self):
+        return self.priv_seq[self.t]
+
+    def step(self, actions):
+        self.actions.append(actions.clone().numpy())
+        t = self.t
+        self.t += 1
+        return self.obs_seq[t + 1], self.priv_seq[t + 1], self.rew_seq[t], self.done_seq[t], {"time_outs": self.tout_seq[t]}
+
+
+def gen_cts(kind, seed=21):
+    """ONE iteration of the reference's OnPolicyRunnerCTS.learn (on_policy_runner_cts.py:123-202) on a scripted env with a small
+    network: history ring, CTS.act / process_env_step, compute_returns, the two update loops, checkpoint keys."""
+    import tempfile
+    from rsl_rl.runners import OnPolicyRunnerCTS
+    import rsl_rl.modules.actor_critic_cts as ref_ac_cts
+    torch.manual_seed(seed)
+    T, N, H = 6, 32, 5
+    g = torch.Generator().manual_seed(seed)
+    obs = torch.randn(T + 1, N, 45, generator=g); priv = torch.randn(T + 1, N, 263, generator=g)
+    rew = torch.randn(T, N, generator=g) * 0.05; dones = torch.rand(T, N, generator=g) < 0.12; touts = dones & (torch.rand(T, N, generator=g) < 0.5)
+    noise = torch.randn(T, N, 12, generator=g)
+    env = _ScriptedEnv(obs, priv, rew, dones, touts)
+    policy = dict(init_noise_std=1.0, actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16], teacher_encoder_hidden_dims=[32, 16],
+                  student_encoder_hidden_dims=[32, 16] if kind == "CTS" else [32, 16, 8], activation="elu", latent_dim=8, norm_type="l2norm")
+    algorithm = dict(value_loss_coef=1.0, use_clipped_value_loss=True, clip_param=0.2, entropy_coef=0.01, num_learning_epochs=2, num_mini_batches=2,
+                     learning_rate=1e-3, student_encoder_learning_rate=1e-3, schedule="adaptive", gamma=0.99, lam=0.95, desired_kl=0.01, max_grad_norm=1.0,
+                     teacher_env_ratio=0.75)
+    if kind == "MoECTS":
+        policy["expert_num"] = 4
+        algorithm["load_balance_coef"] = 0.01
+    train_cfg = {"runner": dict(policy_class_name="ActorCritic" + kind, algorithm_class_name=kind, num_steps_per_env=T, max_iterations=1, save_interval=1000,
+                                experiment_name="golden", run_name=""),
+                 "algorithm": algorithm, "policy": policy, "history_length": H, "robogauge": {"enabled": False, "port": 0}}
+    # the reference allocates the model's deployment history on 'cuda' unconditionally (actor_critic_cts.py:48): run it on the CPU
+    real_zeros = torch.zeros
+    ref_ac_cts.torch.zeros = lambda *a, **k: real_zeros(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})
+    try:
+        runner = OnPolicyRunnerCTS(env, train_cfg, log_dir=tempfile.mkdtemp(), device="cpu")
+    finally:
+        ref_ac_cts.torch.zeros = real_zeros
+    alg = runner.alg
+    ti, si = alg.teacher_env_idxs, alg.student_env_idxs
+    sd0 = {k: v.detach().numpy().copy() for k, v in alg.model.state_dict().items()}
+    # sampling noise made explicit: a = mu + std * eps with eps in ENV order; the reference samples teacher rows, then student rows
+    state = {"t": 0, "rollout": True}
+    from torch.distributions import Normal
+    real_sample = Normal.sample
+
+    def sample(self, sample_shape=torch.Size()):
+        if not state["rollout"]:
+            return self.mean.detach()
+        rows = ti if self.mean.shape[0] == len(ti) else si
+        eps = noise[state["t"]][rows]
+        if rows is si:
+            state["t"] += 1
+        return (self.mean + self.stddev * eps).detach()
+
+    perms = {len(ti) * T: torch.randperm(len(ti) * T, generator=torch.Generator().manual_seed(seed + 1)),
+             len(si) * T: torch.randperm(len(si) * T, generator=torch.Generator().manual_seed(seed + 2))}
+    real_randperm, real_update = torch.randperm, alg.update
+    rec = {}
+
+    def update():
+        state["rollout"] = False
+        st = alg.storage
+        order = torch.cat([ti, si])
+        inv = torch.empty_like(order); inv[order] = torch.arange(N)
+        for k in ("returns", "advantages", "values", "rewards", "actions_log_prob", "history", "observations", "mu"):
+            rec["storage_" + k] = getattr(st, k)[:, inv].numpy().copy()                 # back to env order
+        rec["history_after_rollout"] = runner.history.numpy().copy()
+        return real_update()
+
+    Normal.sample = sample
+    torch.randperm = lambda n, **kw: perms[n]
+    alg.update = update
+    try:
+        runner.learn(1, init_at_random_ep_len=False)
+    finally:
+        Normal.sample, torch.randperm = real_sample, real_randperm
+    sd1 = {k: v.detach().numpy().copy() for k, v in alg.model.state_dict().items()}
+    ckpt = torch.load(os.path.join(runner.log_dir, "model_1.pt"), weights_only=False)
+    out = dict(obs=obs.numpy(), priv=priv.numpy(), rew=rew.numpy(), dones=dones.numpy().astype(np.uint8), time_outs=touts.numpy().astype(np.uint8), noise=noise.numpy(),
+               actions=np.stack(env.actions), perm_teacher=perms[len(ti) * T].numpy(), perm_student=perms[len(si) * T].numpy(),
+               teacher_env_idxs=ti.numpy(), student_env_idxs=si.numpy(), final_lr=np.float64(alg.learning_rate),
+               checkpoint_keys=np.array(sorted(ckpt.keys())), optimizer1_groups=np.array([len(g["params"]) for g in ckpt["optimizer1_state_dict"]["param_groups"]]),
+               optimizer2_groups=np.array([len(g["params"]) for g in ckpt["optimizer2_state_dict"]["param_groups"]]), **rec)
+    # act_inference on a fresh model copy state: deployment path (history shift inside the module)
+    alg.model.history[:] = 0
+    inf = [alg.model.act_inference(obs[t]).detach().numpy().copy() for t in range(3)]
+    out["act_inference"] = np.stack(inf)
+    for k, v in sd0.items(): out["w0_" + k] = v
+    for k, v in sd1.items(): out["w1_" + k] = v
+    print("cts golden (%s): dones=%d, lr=%g, params=%d" % (kind, int(dones.sum()), alg.learning_rate, sum(v.size for v in sd0.values())))
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     files = {}
@@ -316,6 +436,8 @@ def main():
     np.savez_compressed(os.path.join(OUT, "terrain.npz"), **gen_terrain()); files["terrain.npz"] = None
     np.savez_compressed(os.path.join(OUT, "gae.npz"), **gen_gae()); files["gae.npz"] = None
     np.savez_compressed(os.path.join(OUT, "ppo_update.npz"), **gen_ppo()); files["ppo_update.npz"] = None
+    np.savez_compressed(os.path.join(OUT, "cts_iteration.npz"), **gen_cts("CTS")); files["cts_iteration.npz"] = None
+    np.savez_compressed(os.path.join(OUT, "moe_cts_iteration.npz"), **gen_cts("MoECTS")); files["moe_cts_iteration.npz"] = None
     for f in files:
         files[f] = hashlib.sha256(open(os.path.join(OUT, f), "rb").read()).hexdigest()
     try:

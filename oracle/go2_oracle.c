@@ -1156,8 +1156,9 @@ int go2o_torque_trace(Go2Sim* s, const float* actions_raw, const float* dof, flo
 /* Fused PPO loss head, CPU restatement (ppo.py:131-170).  Same contract as the HIP kernel. */
 int go2sim_ppo_loss(const float* mu, const float* std, const float* value, const float* actions, const float* old_mu, const float* old_sigma,
                     const float* old_logp, const float* adv, const float* tv, const float* ret, float* gmu, float* gstd, float* gval, float* stats,
-                    float* workspace, int32_t B, int32_t A, float clip, float vcoef, float ecoef, int32_t use_clip_v, void* stream) {
+                    float* workspace, int32_t B, int32_t A, float clip, float vcoef, float ecoef, int32_t use_clip_v, int32_t split, void* stream) {
   (void)stream; (void)workspace;
+  if (split <= 0 || split >= B) split = 0;   /* plain PPO */
   if (!mu||!std||!value||!actions||!old_mu||!old_sigma||!old_logp||!adv||!tv||!ret||!gmu||!gstd||!gval||!stats||B<=0||A<=0||A>64) return GO2SIM_EINVAL;
   double s_sur=0, s_vl=0, s_kl=0, s_ent=0; double gs[64]; for (int j=0;j<A;++j) gs[j]=0;
   const R LOG2PI = RC(1.8378770664093453);
@@ -1172,7 +1173,9 @@ int go2sim_ppo_loss(const float* mu, const float* std, const float* value, const
     R lo=1-(R)clip, hi=1+(R)clip, rc = ratio<lo?lo:(ratio>hi?hi:ratio); int in = ratio>=lo && ratio<=hi;
     R s1=-a*ratio, s2=-a*rc, sur = s1>s2?s1:s2;
     R w = s1>s2 ? 1 : (s1<s2 ? (R)in : RC(0.5)+RC(0.5)*(R)in);
-    R g_lp = -a*w*ratio/(R)B;
+    /* cts.py:228-231: mean over the teacher rows + mean over the student rows */
+    R wr = split ? (i < split ? 1/(R)split : 1/(R)(B-split)) : 1/(R)B;
+    R g_lp = -a*w*ratio*wr;
     R v=(R)value[i], dv=v-(R)tv[i], vl, gv;
     if (use_clip_v) { R dc = dv<-(R)clip?-(R)clip:(dv>(R)clip?(R)clip:dv); int vin = dv>=-(R)clip && dv<=(R)clip; R vc=(R)tv[i]+dc;
       R l1=(v-(R)ret[i])*(v-(R)ret[i]), l2=(vc-(R)ret[i])*(vc-(R)ret[i]); vl = l1>l2?l1:l2;
@@ -1182,10 +1185,23 @@ int go2sim_ppo_loss(const float* mu, const float* std, const float* value, const
     for (int j=0;j<A;++j) { R sg=(R)std[j], d=(R)actions[(size_t)i*A+j]-(R)mu[(size_t)i*A+j];
       gmu[(size_t)i*A+j] = (float)(g_lp*d/(sg*sg));
       gs[j] += (double)(g_lp*(d*d/(sg*sg*sg) - 1/sg)); }
-    s_sur += sur; s_vl += vl; s_kl += kl; s_ent += ent;
+    s_sur += sur*wr; s_vl += vl; s_kl += kl; s_ent += ent;
   }
   for (int j=0;j<A;++j) gstd[j] = (float)(gs[j] - (double)ecoef/(double)std[j]);
-  stats[0]=(float)(s_sur/B); stats[1]=(float)(s_vl/B); stats[2]=(float)(s_kl/B); stats[3]=(float)(s_ent/B);
-  stats[4]=(float)(s_sur/B + (double)vcoef*s_vl/B - (double)ecoef*s_ent/B);
+  stats[0]=(float)(s_sur); stats[1]=(float)(s_vl/B); stats[2]=(float)(s_kl/B); stats[3]=(float)(s_ent/B);
+  stats[4]=(float)(s_sur + (double)vcoef*s_vl/B - (double)ecoef*s_ent/B);
+  return 0;
+}
+
+/* on_policy_runner_cts.py:155-156 restated: zero the rows of finished envs, drop the oldest frame, append obs. */
+int go2sim_history_push(float* history, const float* obs, const uint8_t* dones, int32_t N, int32_t H, int32_t D, void* stream) {
+  (void)stream;
+  if (!history || !obs || N<=0 || H<=0 || D<=0) return GO2SIM_EINVAL;
+  for (int e=0;e<N;++e) {
+    float* h = history + (size_t)e*H*D;
+    if (dones && dones[e]) memset(h, 0, sizeof(float)*(size_t)H*D);
+    memmove(h, h+D, sizeof(float)*(size_t)(H-1)*D);
+    memcpy(h+(size_t)(H-1)*D, obs+(size_t)e*D, sizeof(float)*D);
+  }
   return 0;
 }

@@ -206,7 +206,7 @@ def test_fused_ppo_loss_kernel_on_gpu(hip):
         gmu, gstd, gval, stats, ws = (torch.zeros(B, A, device=dev), torch.zeros(A, device=dev), torch.zeros(B, device=dev), torch.zeros(5, device=dev), torch.zeros(24 * 96, device=dev))
         p = lambda x: C.c_void_p(x.data_ptr())
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream) if dev != "cpu" else None
-        assert lib.go2sim_ppo_loss(*[p(x) for x in t], p(gmu), p(gstd), p(gval), p(stats), p(ws), B, A, 0.2, 1.0, 0.01, 1, st) == 0
+        assert lib.go2sim_ppo_loss(*[p(x) for x in t], p(gmu), p(gstd), p(gval), p(stats), p(ws), B, A, 0.2, 1.0, 0.01, 1, 0, st) == 0
         if dev != "cpu":
             torch.cuda.synchronize()
         res[name] = [x.cpu().numpy() for x in (gmu, gstd, gval, stats)]
@@ -237,5 +237,73 @@ def test_graph_rollout_and_update_match_eager(hip):
     assert out[True][2] == out[False][2] == 5 * 24              # host mirror of the device-resident counter follows the replays
     assert np.isfinite(out[True][1]).all()
     # sampling noise differs between the modes (different RNG consumption), so compare behaviour, not bits
+    assert 0.2 < out[True][0] / out[False][0] < 5.0
+    assert abs(out[True][3] - out[False][3]) < 0.05
+
+
+def test_cts_kernels_on_gpu(hip):
+    """go2sim_history_push and the split-surrogate loss head: HIP kernels vs numpy / the oracle."""
+    import torch
+    rng = np.random.default_rng(0)
+    N, H, D = 4096, 5, 45
+    hist = rng.normal(size=(N, H, D)).astype(np.float32)
+    want = hist.copy()
+    dh = torch.as_tensor(hist, device="cuda:0")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for it in range(5):
+        obs = rng.normal(size=(N, D)).astype(np.float32)
+        dones = (rng.uniform(size=N) < 0.2).astype(np.uint8) if it else None
+        if dones is not None:
+            want[dones > 0] = 0.0
+        want = np.concatenate([want[:, 1:], obs[:, None]], axis=1)
+        do, dd = torch.as_tensor(obs, device="cuda:0"), (torch.as_tensor(dones, device="cuda:0") if dones is not None else None)
+        assert hip.go2sim_history_push(C.c_void_p(dh.data_ptr()), C.c_void_p(do.data_ptr()), C.c_void_p(dd.data_ptr()) if dd is not None else None, N, H, D, st) == 0
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(dh.cpu().numpy(), want)
+    B, A, split = 24576, 12, 18432
+    f = lambda *s: rng.normal(size=s).astype(np.float32)
+    mu, std, value, acts = f(B, A), (0.6 + 0.3 * rng.uniform(size=A)).astype(np.float32), f(B), f(B, A)
+    old_mu, old_sig = mu + 0.1 * f(B, A), (0.7 + 0.2 * rng.uniform(size=(B, A))).astype(np.float32)
+    lp = (-((acts - mu) ** 2) / (2 * std ** 2) - np.log(std) - 0.9189385).sum(1).astype(np.float32)
+    ins = [mu, std, value, acts, old_mu, old_sig, lp + 0.3 * f(B), f(B), value + 0.3 * f(B), value + f(B)]
+    res = {}
+    for name, lib, dev in (("oracle", load_oracle(), "cpu"), ("hip", hip, "cuda:0")):
+        t = [torch.as_tensor(np.ascontiguousarray(x), device=dev) for x in ins]
+        gmu, gstd, gval, stats, ws = (torch.zeros(B, A, device=dev), torch.zeros(A, device=dev), torch.zeros(B, device=dev), torch.zeros(5, device=dev), torch.zeros(24 * 96, device=dev))
+        p = lambda x: C.c_void_p(x.data_ptr())
+        assert lib.go2sim_ppo_loss(*[p(x) for x in t], p(gmu), p(gstd), p(gval), p(stats), p(ws), B, A, 0.2, 1.0, 0.01, 1, split, st if dev != "cpu" else None) == 0
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        res[name] = [x.cpu().numpy() for x in (gmu, gstd, gval, stats)]
+    for a, b, tol in zip(res["oracle"], res["hip"], (2e-8, 2e-6, 2e-9, 2e-5)):
+        np.testing.assert_allclose(b, a, atol=tol, rtol=2e-3)
+    # teacher rows weigh 1/split, student rows 1/(B-split): 3x larger gradients per student row at this 75/25 split
+    assert abs(np.abs(res["hip"][0][split:]).mean() / np.abs(res["hip"][0][:split]).mean() - 3.0) < 0.5
+
+
+@pytest.mark.parametrize("task", ["go2_flat_cts", "go2_moe_cts"])
+def test_cts_training_graph_vs_eager_on_gpu(hip, task):
+    """CTS / MoE-CTS through the product path, HIP-graph mode against eager mode from the same seeds (the eager arithmetic is
+    pinned to the reference in tests/test_cts_golden.py)."""
+    import torch
+    from go2_rl_gym_amd.envs import task_registry  # noqa: F401
+    from go2_rl_gym_amd.utils import get_args
+    out = {}
+    for mode in (False, True):
+        args = get_args(["--task", task, "--num_envs", "512", "--headless", "--seed", "3"])
+        env, _ = task_registry.make_env(task, args)
+        torch.manual_seed(3)
+        runner, _ = task_registry.make_alg_runner(env, task, args, log_root=None, use_graphs=mode)
+        assert runner.use_graphs == mode and runner.alg.use_graphs == mode and runner.alg.fused_loss
+        env.common_step_counter = 0
+        runner.learn(5, init_at_random_ep_len=True)
+        torch.cuda.synchronize()
+        if mode:
+            assert runner._rollout_graph is not None and all(s.graph is not None for s in runner.alg._steps)
+        out[mode] = (runner.alg.learning_rate, torch.cat([p.detach().reshape(-1) for p in runner.alg.model.parameters()]).cpu().numpy(),
+                     env.common_step_counter, float(env.rew_buf.mean()), runner.history.abs().mean().item())
+        env.close()
+    assert out[True][2] == out[False][2] == 5 * 24
+    assert np.isfinite(out[True][1]).all() and out[True][4] > 0
     assert 0.2 < out[True][0] / out[False][0] < 5.0
     assert abs(out[True][3] - out[False][3]) < 0.05
