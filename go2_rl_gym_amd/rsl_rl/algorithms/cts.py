@@ -81,6 +81,17 @@ class CTS:
     def actor_critic(self):
         return self.model
 
+    def rebind_lr(self):
+        """See PPO.rebind_lr; optimizer2's rate is fixed but must be a device tensor again for the captured step."""
+        self.learning_rate = float(self.optimizer1.param_groups[0]["lr"])
+        if self._lr_t is not None:
+            self._lr_t.fill_(self.learning_rate)
+            for g in self.optimizer1.param_groups:
+                g["lr"] = self._lr_t
+            for g in self.optimizer2.param_groups:
+                if not torch.is_tensor(g["lr"]):
+                    g["lr"] = torch.tensor(float(g["lr"]), device=self.device)
+
     def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape):
         self.storage = RolloutStorageCTS(num_envs, self.teacher_env_idxs, self.student_env_idxs, self.history_length, num_transitions_per_env,
                                          actor_obs_shape, critic_obs_shape, action_shape, self.device, lib=self.lib)

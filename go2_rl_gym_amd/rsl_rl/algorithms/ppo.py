@@ -98,6 +98,16 @@ class PPO:
             for p in self.actor_critic.parameters():
                 dist.broadcast(p.data, src=0)
 
+    def rebind_lr(self):
+        """After optimizer.load_state_dict (which may bring a float lr, e.g. from a reference checkpoint): put the device-resident
+        learning-rate tensor the captured graph reads and writes back into the param groups."""
+        lr = self.optimizer.param_groups[0]["lr"]
+        self.learning_rate = float(lr)
+        if self._lr_t is not None:
+            self._lr_t.fill_(self.learning_rate)
+            for g in self.optimizer.param_groups:
+                g["lr"] = self._lr_t
+
     def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape):
         self.storage = RolloutStorage(num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape, self.device, lib=self.lib)
 

@@ -163,6 +163,7 @@ class OnPolicyRunner:
 
     def learn(self, num_learning_iterations, init_at_random_ep_len=False):
         if self.log_dir is not None and self.writer is None:
+            Path(self.log_dir).mkdir(parents=True, exist_ok=True)     # (the reference relies on SummaryWriter to create it)
             self.writer = _make_writer(self.log_dir)
         if init_at_random_ep_len:
             self.env.episode_length_buf = torch.randint_like(self.env.episode_length_buf, high=int(self.env.max_episode_length))
@@ -282,6 +283,7 @@ class OnPolicyRunner:
         self.alg.actor_critic.load_state_dict(d["model_state_dict"])
         if load_optimizer:
             self.alg.optimizer.load_state_dict(d["optimizer_state_dict"])
+            self.alg.rebind_lr()
         self.current_learning_iteration = d["iter"]
         return d["infos"]
 

@@ -103,6 +103,7 @@ class OnPolicyRunnerCTS(OnPolicyRunner):
         if load_optimizer:
             self.alg.optimizer1.load_state_dict(d["optimizer1_state_dict"])
             self.alg.optimizer2.load_state_dict(d["optimizer2_state_dict"])
+            self.alg.rebind_lr()
         self.current_learning_iteration = d["iter"]
         return d["infos"]
 

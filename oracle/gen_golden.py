@@ -303,6 +303,36 @@ def gen_ppo(seed=5):
                mean_value_loss=np.float64(mvl), mean_surrogate_loss=np.float64(msl), final_lr=np.float64(alg.learning_rate))
     for k, v in sd0.items(): out["w0_" + k] = v
     for k, v in sd1.items(): out["w1_" + k] = v
+    import tempfile
+    from legged_gym.utils.exporter import export_policy_as_jit
+    d = tempfile.mkdtemp()
+    export_policy_as_jit(ac, d, filename="p.pt")
+    jit = torch.jit.load(os.path.join(d, "p.pt"))
+    out["jit_actions"] = jit(obs[0][:3]).detach().numpy().copy()
+    return out
+
+
+def gen_pretrained(seed=31):
+    """I/O vectors of the reference's own pretrained deployment policy (deploy/pre_train/go2/go2_cts_150k.pt, a TorchScript export of
+    a CTS student) plus its tensors, so the build's loader/exporter and the behavioural walking test can run where the reference
+    tree is absent.  DATA of the reference (weights + input/output vectors), not source."""
+    path = "/root/reference/deploy/pre_train/go2/go2_cts_150k.pt"
+    jit = torch.jit.load(path)
+    sd = {k: v.detach().cpu().numpy().copy() for k, v in jit.state_dict().items()}
+    g = torch.Generator().manual_seed(seed)
+    obs = torch.randn(12, 1, 45, generator=g) * 0.5
+    acts, lats = [], []
+    for t in list(range(8)) + ["reset"] + list(range(8, 12)):
+        if t == "reset":
+            jit.reset()
+            continue
+        o = jit(obs[t])
+        a, l = (o[0], o[1][1]) if isinstance(o, tuple) else (o, torch.zeros(1, 0))
+        acts.append(a.detach().numpy().copy()); lats.append(l.detach().numpy().copy())
+    out = dict(obs=obs.numpy(), actions=np.stack(acts), latent=np.stack(lats), sha256=np.frombuffer(hashlib.sha256(open(path, "rb").read()).digest(), np.uint8))
+    for k, v in sd.items():
+        out["w_" + k] = v
+    print("pretrained:", {k: v.shape for k, v in sd.items()})
     return out
 
 
@@ -420,24 +450,54 @@ def gen_cts(kind, seed=21):
     alg.model.history[:] = 0
     inf = [alg.model.act_inference(obs[t]).detach().numpy().copy() for t in range(3)]
     out["act_inference"] = np.stack(inf)
+    # deployment export through the reference's exporter (legged_gym/utils/exporter.py:13-23,67-193)
+    from legged_gym.utils.exporter import export_policy_as_jit
+    d = tempfile.mkdtemp()
+    export_policy_as_jit(alg.model, d, filename="p.pt")
+    jit = torch.jit.load(os.path.join(d, "p.pt"))
+    acts, lats, wts = [], [], []
+    for t in list(range(4)) + ["reset", 0, 1]:
+        if t == "reset":
+            jit.reset()
+            continue
+        a, (w, l) = jit(obs[t][:1])
+        acts.append(a.detach().numpy().copy()); lats.append(l.detach().numpy().copy())
+        if w is not None:
+            wts.append(w.detach().numpy().copy())
+    out["jit_actions"], out["jit_latent"] = np.stack(acts), np.stack(lats)
+    if wts:
+        out["jit_weights"] = np.stack(wts)
     for k, v in sd0.items(): out["w0_" + k] = v
     for k, v in sd1.items(): out["w1_" + k] = v
     print("cts golden (%s): dones=%d, lr=%g, params=%d" % (kind, int(dones.sum()), alg.learning_rate, sum(v.size for v in sd0.values())))
     return out
 
 
+def _save(files, name, data):
+    """Write tests/golden/<name> unless it already holds exactly these arrays (zip timestamps would churn the git history)."""
+    path = os.path.join(OUT, name)
+    files[name] = None
+    if os.path.exists(path):
+        old = dict(np.load(path))
+        same = lambda a, b: a.shape == b.shape and (np.allclose(a, b, atol=4e-6, rtol=0) if a.dtype.kind == "f" else np.array_equal(a, b))
+        if set(old) == set(data) and all(same(old[k], np.asarray(data[k])) for k in data):
+            return          # (torch's threaded CPU reductions make the last bit of a few float outputs vary from run to run)
+    np.savez_compressed(path, **data)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     files = {}
     seq = gen_env_sequence()
-    np.savez_compressed(os.path.join(OUT, "go2_plane_sequence.npz"), **seq); files["go2_plane_sequence.npz"] = None
+    _save(files, "go2_plane_sequence.npz", seq)
     hfseq = gen_env_sequence(N=12, T=40, seed=9, mesh_type="heightfield")
-    np.savez_compressed(os.path.join(OUT, "go2_heightfield_sequence.npz"), **hfseq); files["go2_heightfield_sequence.npz"] = None
-    np.savez_compressed(os.path.join(OUT, "terrain.npz"), **gen_terrain()); files["terrain.npz"] = None
-    np.savez_compressed(os.path.join(OUT, "gae.npz"), **gen_gae()); files["gae.npz"] = None
-    np.savez_compressed(os.path.join(OUT, "ppo_update.npz"), **gen_ppo()); files["ppo_update.npz"] = None
-    np.savez_compressed(os.path.join(OUT, "cts_iteration.npz"), **gen_cts("CTS")); files["cts_iteration.npz"] = None
-    np.savez_compressed(os.path.join(OUT, "moe_cts_iteration.npz"), **gen_cts("MoECTS")); files["moe_cts_iteration.npz"] = None
+    _save(files, "go2_heightfield_sequence.npz", hfseq)
+    _save(files, "terrain.npz", gen_terrain())
+    _save(files, "gae.npz", gen_gae())
+    _save(files, "ppo_update.npz", gen_ppo())
+    _save(files, "pretrained_go2_cts_150k.npz", gen_pretrained())
+    _save(files, "cts_iteration.npz", gen_cts("CTS"))
+    _save(files, "moe_cts_iteration.npz", gen_cts("MoECTS"))
     for f in files:
         files[f] = hashlib.sha256(open(os.path.join(OUT, f), "rb").read()).hexdigest()
     try:

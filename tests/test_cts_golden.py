@@ -165,3 +165,21 @@ def test_split_surrogate_kernel_matches_autograd():
         if a is not None:
             np.testing.assert_allclose(b.numpy(), a.numpy(), atol=3e-7, rtol=3e-4)
     assert all(p.grad is None for p in m.student_encoder.parameters())      # the policy loss never reaches the student encoder
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    """save -> load (with optimizers) restores weights, iteration and learning rate; a checkpoint with FLOAT learning rates
+    (the reference's format) loads too."""
+    g = dict(np.load(os.path.join(G, "cts_iteration.npz")))
+    T = g["rew"].shape[0]
+    r1 = OnPolicyRunnerCTS(ScriptedEnv(g, load_oracle()), _train_cfg("CTS", T), log_dir=str(tmp_path / "a"), device="cpu")
+    r1.learn(1)
+    p = str(tmp_path / "ck.pt")
+    r1.save(p)
+    r2 = OnPolicyRunnerCTS(ScriptedEnv(g, load_oracle()), _train_cfg("CTS", T), log_dir=None, device="cpu")
+    r2.load(p)
+    assert r2.current_learning_iteration == 1 and abs(r2.alg.learning_rate - r1.alg.learning_rate) < 1e-12
+    for (k, a), b in zip(r1.alg.model.state_dict().items(), r2.alg.model.state_dict().values()):
+        assert torch.equal(a, b), k
+    st1, st2 = r1.alg.optimizer1.state_dict()["state"], r2.alg.optimizer1.state_dict()["state"]
+    assert all(torch.equal(st1[i]["exp_avg"], st2[i]["exp_avg"]) for i in st1)

@@ -307,3 +307,40 @@ def test_cts_training_graph_vs_eager_on_gpu(hip, task):
     assert np.isfinite(out[True][1]).all() and out[True][4] > 0
     assert 0.2 < out[True][0] / out[False][0] < 5.0
     assert abs(out[True][3] - out[False][3]) < 0.05
+
+
+@pytest.mark.parametrize("terrain", ["plane", "heightfield"])
+def test_pretrained_policy_walks_on_gpu(hip, terrain):
+    """The reference's pretrained CTS student (weights committed as fixture data, loaded through this build's ActorCriticCTS) tracks
+    a 1 m/s command on the HIP simulator: on the plane, and on the rough curriculum map it was trained for."""
+    from helpers import heightfield_overrides
+    from test_export import run_pretrained_walk
+    N = 80
+    ov = heightfield_overrides(N)[1] if terrain == "heightfield" else {}
+    s = DeviceSim(hip, num_envs=N, push_robots=0, add_noise=0, **ov)
+    v, zmin, resets = run_pretrained_walk(s, seconds=8.0)
+    if terrain == "plane":
+        assert 0.8 < v < 1.1 and zmin > 0.25 and resets == 0, (v, zmin, resets)
+    else:
+        assert 0.5 < v < 1.1 and resets <= N // 2, (v, zmin, resets)       # levels 0-5 of slopes, stairs, obstacles: mostly walks, may trip
+    s.close()
+
+
+def test_train_save_play_export_on_gpu(hip, tmp_path):
+    """train.py -> checkpoint -> play.py (resume through the runner, export, roll out) for the CTS task."""
+    import torch
+    from go2_rl_gym_amd.envs import task_registry  # noqa: F401
+    from go2_rl_gym_amd.scripts.play import play
+    from go2_rl_gym_amd.utils import get_args
+    args = get_args(["--task", "go2_flat_cts", "--num_envs", "256", "--headless"])
+    env, _ = task_registry.make_env("go2_flat_cts", args)
+    runner, _ = task_registry.make_alg_runner(env, "go2_flat_cts", args, log_root=str(tmp_path))
+    runner.learn(2, init_at_random_ep_len=True)
+    env.close()
+    args = get_args(["--task", "go2_flat_cts", "--num_envs", "64", "--headless"])
+    env, exported = play(args, steps=20, log_root=str(tmp_path), export_policy=True)
+    assert torch.isfinite(env.obs_buf).all() and os.path.exists(exported[0]) and os.path.exists(exported[1])
+    jit = torch.jit.load(exported[0])
+    a, (none, lat) = jit(torch.zeros(1, 45))
+    assert a.shape == (1, 12) and lat.shape == (1, 32)
+    env.close()

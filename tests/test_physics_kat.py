@@ -90,27 +90,5 @@ def test_standing_robot_carries_its_weight():
     s.close()
 
 
-@pytest.mark.skipif(not os.path.exists("/root/reference/deploy/pre_train/go2/go2_cts_150k.pt"), reason="container-only: needs the reference's pretrained policy")
-def test_reference_pretrained_policy_walks_in_this_simulator():
-    """Behavioural check of the contact model: the policy the reference ships (trained in PhysX, README.md:101-120 says it
-    also walks in MuJoCo) tracks a 1 m/s forward command here without falling for 10 s.  The .pt is read in place, never copied."""
-    import torch
-    lib = load_oracle()
-    speeds = []
-    for trial in range(2):
-        pol = torch.jit.load("/root/reference/deploy/pre_train/go2/go2_cts_150k.pt")
-        s = HostSim(lib, num_envs=1, push_robots=0, add_noise=0, seed=trial + 1, randomize_friction=0, randomize_action_delay=0)
-        s.reset_all()
-        s.step(np.zeros((1, 12), np.float32))
-        for i in range(500):
-            s.commands[:, :3] = [1.0, 0, 0]
-            obs = s.obs_buf.copy(); obs[:, 6:9] = s.commands[:, :3] * np.array([2, 2, 0.25], np.float32)
-            with torch.no_grad():
-                act = pol(torch.from_numpy(obs)).numpy()
-            s.step(act)
-            assert not s.reset_buf.any(), "fell at step %d" % i
-            if i >= 100:
-                speeds.append(float(s.base_lin_vel[0, 0]))
-        assert 0.30 < s.root_states[0, 2] < 0.42
-        s.close()
-    assert 0.8 < np.mean(speeds) < 1.1, np.mean(speeds)
+# The behavioural test with the reference's pretrained policy lives in tests/test_export.py (it runs from committed fixtures,
+# through this build's own loader, on the oracle here and on the HIP kernels on the GPU box).
