@@ -19,7 +19,7 @@ import torch.optim as optim
 
 from ..storage import RolloutStorageCTS
 from ._graph import CapturedStep
-from .ppo import _collectives_on, _FusedPPOLoss, _world
+from .ppo import _ADAM_IMPL, _collectives_on, _FusedPPOLoss, _world
 
 
 def _allreduce_mean_grads(params, world):
@@ -52,8 +52,8 @@ class CTS:
         self._params2 = list(self.model.student_parameters())
         if self.use_graphs:
             self._lr_t = torch.tensor(float(learning_rate), device=device)
-            self.optimizer1 = optim.Adam(groups1, lr=self._lr_t, capturable=True, foreach=True)
-            self.optimizer2 = optim.Adam(self._params2, lr=torch.tensor(float(student_encoder_learning_rate), device=device), capturable=True, foreach=True)
+            self.optimizer1 = optim.Adam(groups1, lr=self._lr_t, capturable=True, **_ADAM_IMPL)
+            self.optimizer2 = optim.Adam(self._params2, lr=torch.tensor(float(student_encoder_learning_rate), device=device), capturable=True, **_ADAM_IMPL)
         else:
             self._lr_t = None
             self.optimizer1 = optim.Adam(groups1, lr=learning_rate)

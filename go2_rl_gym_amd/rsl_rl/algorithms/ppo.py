@@ -25,6 +25,10 @@ import torch.optim as optim
 from ..storage import RolloutStorage
 
 
+# Adam as ONE multi-tensor kernel per param group (fused) instead of ~6 foreach launches; GO2_ADAM=foreach restores the latter
+_ADAM_IMPL = {"foreach": True} if os.environ.get("GO2_ADAM", "fused") == "foreach" else {"fused": True}
+
+
 def _world():
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
@@ -83,7 +87,7 @@ class PPO:
         self.use_graphs = on_gpu if use_graphs is None else bool(use_graphs and on_gpu)
         if self.use_graphs:
             self._lr_t = torch.tensor(float(learning_rate), device=device)
-            self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=self._lr_t, capturable=True, foreach=True)
+            self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=self._lr_t, capturable=True, **_ADAM_IMPL)
         else:
             self._lr_t = None
             self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=learning_rate)
