@@ -389,6 +389,34 @@ __global__ void go2_ppo_loss_finish_kernel(const float* __restrict__ part, const
   __syncthreads();
   if (k == 0) stats[4] = stats[0] + vcoef * stats[1] - ecoef * stats[3];
 }
+// ---- rollout heads: PPO.act sampling + storage rows, PPO.process_env_step (one thread per env) ----------------------------
+__global__ void __launch_bounds__(256) go2_act_head_kernel(const float* __restrict__ mu, const float* __restrict__ std_, const float* __restrict__ eps, const float* __restrict__ value,
+    float* __restrict__ a_out, float* __restrict__ a_st, float* __restrict__ mu_st, float* __restrict__ sig_st, float* __restrict__ lp_st, float* __restrict__ v_st, int N, int A) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= N) return;
+  const float HALF_LOG2PI = 0.9189385332046727f;
+  float lp = 0.f;
+  for (int j = 0; j < A; ++j) {
+    const size_t k = (size_t)e * A + j;
+    const float m = mu[k], sg = std_[j], a = m + sg * eps[k], d = a - m;
+    lp += -(d * d) / (2.f * sg * sg) - logf(sg) - HALF_LOG2PI;
+    a_out[k] = a;
+    if (a_st) a_st[k] = a;
+    if (mu_st) mu_st[k] = m;
+    if (sig_st) sig_st[k] = sg;
+  }
+  if (lp_st) lp_st[e] = lp;
+  if (v_st) v_st[e] = value[e];
+}
+__global__ void __launch_bounds__(256) go2_store_transition_kernel(const float* __restrict__ rew, const uint8_t* __restrict__ dones, const uint8_t* __restrict__ touts,
+    const float* __restrict__ v_st, float* __restrict__ rew_st, uint8_t* __restrict__ dones_st, float gamma, int N) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= N) return;
+  float r = rew[e];
+  if (touts) r += gamma * (v_st[e] * (touts[e] ? 1.f : 0.f));
+  rew_st[e] = r; dones_st[e] = dones[e];
+}
+
 // ---- CTS observation-history ring (on_policy_runner_cts.py:155-156): one thread per (env, feature), H values in flight ------
 __global__ void __launch_bounds__(256) go2_history_push_kernel(float* __restrict__ hist, const float* __restrict__ obs, const uint8_t* __restrict__ dones, int N, int H, int D) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -900,6 +928,40 @@ int go2sim_ppo_loss(const float* mu, const float* std_, const float* value, cons
   int nb = (B + 255) / 256;
   hipLaunchKernelGGL(go2_ppo_loss_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, mu, std_, value, actions, old_mu, old_sigma, old_logp, adv, tv, ret, gmu, gval, workspace, B, A, clip, vcoef, use_clip_v, split, w_head, w_tail);
   hipLaunchKernelGGL(go2_ppo_loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, workspace, std_, gstd, stats, nb, B, A, vcoef, ecoef);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+int go2sim_act_head(const float* mu, const float* std_, const float* eps, const float* value, float* a_out, float* a_st, float* mu_st, float* sig_st, float* lp_st,
+                    float* v_st, int32_t N, int32_t A, void* stream) {
+  if (!mu || !std_ || !eps || !a_out || (v_st && !value) || N <= 0 || A <= 0) FAIL(GO2SIM_EINVAL, "bad argument");
+#ifdef GO2_EMU
+  (void)stream;
+  for (int e = 0; e < N; ++e) {
+    float lp = 0.f;
+    for (int j = 0; j < A; ++j) {
+      const size_t k = (size_t)e * A + j; const float m = mu[k], sg = std_[j], a = m + sg * eps[k], d = a - m;
+      lp += -(d * d) / (2.f * sg * sg) - logf(sg) - 0.9189385332046727f;
+      a_out[k] = a; if (a_st) a_st[k] = a; if (mu_st) mu_st[k] = m; if (sig_st) sig_st[k] = sg;
+    }
+    if (lp_st) lp_st[e] = lp;
+    if (v_st) v_st[e] = value[e];
+  }
+#else
+  hipLaunchKernelGGL(go2_act_head_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, mu, std_, eps, value, a_out, a_st, mu_st, sig_st, lp_st, v_st, N, A);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+int go2sim_store_transition(const float* rew, const uint8_t* dones, const uint8_t* touts, const float* v_st, float* rew_st, uint8_t* dones_st, float gamma, int32_t N, void* stream) {
+  if (!rew || !dones || !rew_st || !dones_st || (touts && !v_st) || N <= 0) FAIL(GO2SIM_EINVAL, "bad argument");
+#ifdef GO2_EMU
+  (void)stream;
+  for (int e = 0; e < N; ++e) { float r = rew[e]; if (touts) r += gamma * (v_st[e] * (touts[e] ? 1.f : 0.f)); rew_st[e] = r; dones_st[e] = dones[e]; }
+#else
+  hipLaunchKernelGGL(go2_store_transition_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, rew, dones, touts, v_st, rew_st, dones_st, gamma, N);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

@@ -19,7 +19,7 @@ import torch.optim as optim
 
 from ..storage import RolloutStorageCTS
 from ._graph import CapturedStep
-from .ppo import _ADAM_IMPL, _collectives_on, _FusedPPOLoss, _world
+from .ppo import _ADAM_IMPL, _collectives_on, _FusedPPOLoss, _RolloutHeads, _world
 
 
 def _allreduce_mean_grads(params, world):
@@ -32,11 +32,11 @@ def _allreduce_mean_grads(params, world):
         n = g.numel(); g.copy_(flat[off:off + n].view_as(g)); off += n
 
 
-class CTS:
+class CTS(_RolloutHeads):
     def __init__(self, model, num_envs, history_length, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95,
                  value_loss_coef=1.0, entropy_coef=0.0, learning_rate=1e-3, student_encoder_learning_rate=1e-3, max_grad_norm=1.0,
                  use_clipped_value_loss=True, schedule="fixed", desired_kl=0.01, teacher_env_ratio=0.75, device="cpu", lib=None,
-                 use_graphs=None, fused_loss=None):
+                 use_graphs=None, fused_loss=None, fused_rollout=None):
         self.device, self.lib = device, lib
         self.desired_kl, self.schedule, self.learning_rate = desired_kl, schedule, learning_rate
         self.history_length = history_length
@@ -46,6 +46,7 @@ class CTS:
         on_gpu = str(device).startswith("cuda")
         self.use_graphs = on_gpu if use_graphs is None else bool(use_graphs and on_gpu)
         self.fused_loss = (on_gpu and lib is not None) if fused_loss is None else bool(fused_loss and lib is not None)
+        self.fused_rollout = (on_gpu and lib is not None) if fused_rollout is None else bool(fused_rollout and lib is not None)
         groups1 = [{"params": list(self.model.teacher_encoder.parameters())}, {"params": list(self.model.critic.parameters())},
                    {"params": list(self.model.actor.parameters())}, {"params": [self.model.std]}]           # same 4 groups as the reference (:72-77)
         self._params1 = list(itertools.chain.from_iterable(g["params"] for g in groups1))
@@ -122,6 +123,9 @@ class CTS:
         st.privileged_observations[s].copy_(privileged_obs)
         st.history[s].copy_(history)
         latent = self._latent_env_order(privileged_obs, history)
+        if self.fused_rollout:
+            mu = m.actor(torch.cat([latent, obs], dim=1))
+            return self._act_head(mu, m.std, m._noise(mu), m.evaluate_joint(privileged_obs, latent), s)
         t.actions = m.act_joint(obs, latent).detach()
         t.values = m.evaluate_joint(privileged_obs, latent).detach()
         t.actions_log_prob = m.get_actions_log_prob(t.actions).detach()
@@ -136,11 +140,14 @@ class CTS:
     def process_env_step(self, rewards, dones, infos):
         st = self.storage
         s = st.step
-        r = rewards.clone()
-        if "time_outs" in infos:   # bootstrap on time-outs (:156-158)
-            r += self.gamma * torch.squeeze(st.values[s] * infos["time_outs"].unsqueeze(1).to(self.device), 1)
-        st.rewards[s].copy_(r.view(-1, 1))
-        st.dones[s].copy_(dones.view(-1, 1))
+        if self.fused_rollout:
+            self._store_transition(rewards, dones, infos, s)
+        else:
+            r = rewards.clone()
+            if "time_outs" in infos:   # bootstrap on time-outs (:156-158)
+                r += self.gamma * torch.squeeze(st.values[s] * infos["time_outs"].unsqueeze(1).to(self.device), 1)
+            st.rewards[s].copy_(r.view(-1, 1))
+            st.dones[s].copy_(dones.view(-1, 1))
         st.step += 1
         self.transition.clear()
         self.model.history.masked_fill_(dones.view(-1, 1, 1) > 0, 0.0)          # model.reset(dones) (:163) without a boolean-index sync

@@ -41,6 +41,43 @@ def _collectives_on():
     return dist.get_world_size() > 1 or os.environ.get("GO2_FORCE_COLLECTIVES", "0") == "1"
 
 
+class _RolloutHeads:
+    """The two per-step element-wise heads of the rollout as library kernels (go2sim_act_head, go2sim_store_transition): sampling +
+    log-prob + the storage rows in one launch, reward bootstrap + done copy in another, instead of ~23 small launches."""
+
+    def _ptr(self, t):
+        import ctypes as C
+        return C.c_void_p(t.data_ptr()) if t is not None else None
+
+    def _stream(self, t):
+        import ctypes as C
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream) if t.is_cuda else None
+
+    def _act_head(self, mu, std, eps, value, s):
+        st, t = self.storage, self.transition
+        mu, eps, value = mu.detach().contiguous(), eps.contiguous(), value.detach().contiguous()
+        actions = torch.empty_like(mu)
+        p = self._ptr
+        rc = self.lib.go2sim_act_head(p(mu), p(std.detach()), p(eps), p(value), p(actions), p(st.actions[s]), p(st.mu[s]), p(st.sigma[s]),
+                                      p(st.actions_log_prob[s]), p(st.values[s]), mu.shape[0], mu.shape[1], self._stream(mu))
+        if rc != 0:
+            raise RuntimeError("go2sim_act_head failed: %s" % self.lib.go2sim_last_error().decode())
+        t.actions, t.values, t.actions_log_prob = actions, st.values[s], st.actions_log_prob[s].view(-1)
+        t.action_mean, t.action_sigma = st.mu[s], st.sigma[s]
+        return actions
+
+    def _store_transition(self, rewards, dones, infos, s):
+        st = self.storage
+        touts = infos.get("time_outs") if isinstance(infos, dict) else None
+        rewards = rewards.contiguous().float()
+        as_u8 = lambda x: None if x is None else (x if x.dtype == torch.uint8 else x.contiguous().view(torch.uint8) if x.dtype == torch.bool else x.to(torch.uint8))
+        d, to = as_u8(dones), as_u8(touts.to(self.device) if touts is not None else None)
+        p = self._ptr
+        rc = self.lib.go2sim_store_transition(p(rewards), p(d), p(to), p(st.values[s]), p(st.rewards[s]), p(st.dones[s]), float(self.gamma), rewards.shape[0], self._stream(rewards))
+        if rc != 0:
+            raise RuntimeError("go2sim_store_transition failed: %s" % self.lib.go2sim_last_error().decode())
+
+
 class _FusedPPOLoss(torch.autograd.Function):
     """loss = surrogate + c_v * value_loss - c_e * entropy through ONE library kernel (go2sim_ppo_loss) that also returns the
     analytic gradients w.r.t. mu, std and value; autograd then continues into the actor / critic MLPs.  Replaces ~150
@@ -73,10 +110,10 @@ class _FusedPPOLoss(torch.autograd.Function):
         return gmu * g_loss, gstd * g_loss, gval * g_loss, None, None, None, None, None, None, None, None
 
 
-class PPO:
+class PPO(_RolloutHeads):
     def __init__(self, actor_critic, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95, value_loss_coef=1.0,
                  entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0, use_clipped_value_loss=True, schedule="fixed", desired_kl=0.01,
-                 device="cpu", lib=None, use_graphs=None, fused_loss=None):
+                 device="cpu", lib=None, use_graphs=None, fused_loss=None, fused_rollout=None):
         self.device = device
         self.lib = lib
         self.desired_kl, self.schedule, self.learning_rate = desired_kl, schedule, learning_rate
@@ -98,6 +135,7 @@ class PPO:
         self._graph = None
         # the fused loss kernel is the default on the GPU; on the CPU it is opt-in (tests compare it with the eager formulation)
         self.fused_loss = (on_gpu and lib is not None) if fused_loss is None else bool(fused_loss and lib is not None)
+        self.fused_rollout = (on_gpu and lib is not None) if fused_rollout is None else bool(fused_rollout and lib is not None)
         if _world() > 1:   # identical initial replicas
             for p in self.actor_critic.parameters():
                 dist.broadcast(p.data, src=0)
@@ -127,6 +165,13 @@ class PPO:
         s = st.step
         if s >= st.num_transitions_per_env:
             raise AssertionError("Rollout buffer overflow")
+        if self.fused_rollout:
+            st.observations[s].copy_(obs)
+            if st.privileged_observations is not None:
+                st.privileged_observations[s].copy_(critic_obs)
+            t.observations, t.critic_observations = obs, critic_obs
+            mu = ac.actor(obs)
+            return self._act_head(mu, ac.std, ac._noise(mu), ac.evaluate(critic_obs), s)
         t.actions = ac.act(obs).detach()
         t.values = ac.evaluate(critic_obs).detach()
         t.actions_log_prob = ac.get_actions_log_prob(t.actions).detach()
@@ -146,6 +191,12 @@ class PPO:
     def process_env_step(self, rewards, dones, infos):
         st, t = self.storage, self.transition
         s = st.step
+        if self.fused_rollout:
+            self._store_transition(rewards, dones, infos, s)
+            st.step += 1
+            t.clear()
+            self.actor_critic.reset(dones)
+            return
         r = rewards.clone()
         if "time_outs" in infos:   # bootstrap on time-outs (ppo.py:107-108)
             r += self.gamma * torch.squeeze(st.values[s] * infos["time_outs"].unsqueeze(1).to(self.device), 1)

@@ -351,6 +351,21 @@ int  go2sim_ppo_loss(const float* mu, const float* std, const float* value, cons
                      int32_t B, int32_t A, float clip_param, float value_loss_coef, float entropy_coef,
                      int32_t use_clipped_value_loss, int32_t surrogate_split, void* stream);
 
+/* Sampling head of PPO.act / CTS.act + its storage writes for ONE rollout step (rsl_rl/algorithms/ppo.py:90-102,
+ * modules/actor_critic.py:101-127), replacing ~17 element-wise launches:
+ *   a = mu + std * eps                         (Normal(mu, std).sample() with the noise made explicit)
+ *   log_prob = sum_j [ -(a_j - mu_j)^2 / (2 std_j^2) - log std_j - log sqrt(2 pi) ]
+ * mu, eps: float [N,A]; std: float [A] (state-independent); value: float [N].
+ * Writes actions_out [N,A] (handed to env.step) and the rollout-storage rows of this step: actions_st, mu_st,
+ * sigma_st [N,A] (sigma = std broadcast), log_prob_st [N], values_st [N].  Any *_st pointer may be NULL. */
+int  go2sim_act_head(const float* mu, const float* std, const float* eps, const float* value, float* actions_out,
+                     float* actions_st, float* mu_st, float* sigma_st, float* log_prob_st, float* values_st,
+                     int32_t N, int32_t A, void* stream);
+/* PPO.process_env_step (ppo.py:104-114): rewards_st = rewards + gamma * values_st * time_outs (bootstrap on time-outs; time_outs
+ * may be NULL), dones_st = dones.  rewards/values_st/rewards_st: float [N]; dones/time_outs/dones_st: uint8 [N]. */
+int  go2sim_store_transition(const float* rewards, const uint8_t* dones, const uint8_t* time_outs, const float* values_st,
+                             float* rewards_st, uint8_t* dones_st, float gamma, int32_t N, void* stream);
+
 /* Observation-history ring of the CTS runner (on_policy_runner_cts.py:155-156), in place:
  *   history[dones > 0] = 0;  history = cat(history[:, 1:], obs[:, None])      history: float [N,H,D], obs: float [N,D],
  * dones: uint8 [N] or NULL (no zeroing: the push before the first step, :129). */

@@ -1193,6 +1193,33 @@ int go2sim_ppo_loss(const float* mu, const float* std, const float* value, const
   return 0;
 }
 
+/* PPO.act's sampling head (ppo.py:90-102; torch.distributions.Normal.log_prob: -((x-mu)^2)/(2 var) - log(scale) - log(sqrt(2 pi))) */
+int go2sim_act_head(const float* mu, const float* std, const float* eps, const float* value, float* a_out, float* a_st, float* mu_st, float* sig_st, float* lp_st,
+                    float* v_st, int32_t N, int32_t A, void* stream) {
+  (void)stream;
+  if (!mu || !std || !eps || !a_out || (v_st && !value) || N<=0 || A<=0) return GO2SIM_EINVAL;
+  for (int e=0;e<N;++e) {
+    R lp=0;
+    for (int j=0;j<A;++j) {
+      size_t k=(size_t)e*A+j;
+      float a = mu[k] + std[j]*eps[k];              /* the sample is formed in fp32, as torch forms it */
+      R d=(R)a-(R)mu[k], sg=(R)std[j];
+      lp += -(d*d)/(2*sg*sg) - (R)log((double)sg) - RC(0.9189385332046727);
+      a_out[k]=a; if (a_st) a_st[k]=a; if (mu_st) mu_st[k]=mu[k]; if (sig_st) sig_st[k]=std[j];
+    }
+    if (lp_st) lp_st[e]=(float)lp;
+    if (v_st) v_st[e]=value[e];
+  }
+  return 0;
+}
+/* PPO.process_env_step (ppo.py:104-114) */
+int go2sim_store_transition(const float* rew, const uint8_t* dones, const uint8_t* touts, const float* v_st, float* rew_st, uint8_t* dones_st, float gamma, int32_t N, void* stream) {
+  (void)stream;
+  if (!rew || !dones || !rew_st || !dones_st || (touts && !v_st) || N<=0) return GO2SIM_EINVAL;
+  for (int e=0;e<N;++e) { float r=rew[e]; if (touts) r += gamma*(v_st[e]*(touts[e]?1.0f:0.0f)); rew_st[e]=r; dones_st[e]=dones[e]; }
+  return 0;
+}
+
 /* on_policy_runner_cts.py:155-156 restated: zero the rows of finished envs, drop the oldest frame, append obs. */
 int go2sim_history_push(float* history, const float* obs, const uint8_t* dones, int32_t N, int32_t H, int32_t D, void* stream) {
   (void)stream;

@@ -68,7 +68,7 @@ def test_one_iteration_matches_reference(kind, fixture, fused, monkeypatch, tmp_
     env = ScriptedEnv(g, load_oracle())
     runner = OnPolicyRunnerCTS(env, _train_cfg(kind, T), log_dir=str(tmp_path), device="cpu")
     alg, model = runner.alg, runner.alg.model
-    alg.fused_loss = fused
+    alg.fused_loss = alg.fused_rollout = fused
     np.testing.assert_array_equal(alg.teacher_env_idxs.numpy(), g["teacher_env_idxs"])
     np.testing.assert_array_equal(alg.student_env_idxs.numpy(), g["student_env_idxs"])
     sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w0_")}

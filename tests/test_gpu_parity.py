@@ -344,3 +344,32 @@ def test_train_save_play_export_on_gpu(hip, tmp_path):
     a, (none, lat) = jit(torch.zeros(1, 45))
     assert a.shape == (1, 12) and lat.shape == (1, 32)
     env.close()
+
+
+def test_rollout_head_kernels_on_gpu(hip):
+    """go2sim_act_head / go2sim_store_transition: HIP vs torch's own formulation (Normal.log_prob, ppo.py:104-114) at 4096 x 12."""
+    import torch
+    torch.manual_seed(0)
+    N, A = 4096, 12
+    dev = "cuda:0"
+    mu, eps, value = torch.randn(N, A, device=dev), torch.randn(N, A, device=dev), torch.randn(N, 1, device=dev)
+    std = (0.3 + torch.rand(A, device=dev))
+    out = [torch.zeros(N, A, device=dev) for _ in range(4)] + [torch.zeros(N, 1, device=dev), torch.zeros(N, 1, device=dev)]
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert hip.go2sim_act_head(p(mu), p(std), p(eps), p(value), *[p(o) for o in out], N, A, st) == 0
+    torch.cuda.synchronize()
+    a = mu + std * eps
+    d = torch.distributions.Normal(mu, mu * 0 + std)
+    assert torch.equal(out[0], a) and torch.equal(out[1], a) and torch.equal(out[2], mu) and torch.equal(out[3], (mu * 0 + std)) and torch.equal(out[5], value)
+    np.testing.assert_allclose(out[4].view(-1).cpu().numpy(), d.log_prob(a).sum(-1).cpu().numpy(), atol=2e-5, rtol=1e-5)
+    rew, dones, touts = torch.randn(N, device=dev), torch.rand(N, device=dev) < 0.1, torch.rand(N, device=dev) < 0.05
+    rst, dst = torch.zeros(N, 1, device=dev), torch.zeros(N, 1, device=dev, dtype=torch.uint8)
+    assert hip.go2sim_store_transition(p(rew), p(dones.view(torch.uint8)), p(touts.view(torch.uint8)), p(value), p(rst), p(dst), 0.99, N, st) == 0
+    torch.cuda.synchronize()
+    want = rew + 0.99 * torch.squeeze(value * touts.unsqueeze(1), 1)
+    np.testing.assert_allclose(rst.view(-1).cpu().numpy(), want.cpu().numpy(), atol=1e-6)
+    assert torch.equal(dst.view(-1).bool(), dones)
+    assert hip.go2sim_store_transition(p(rew), p(dones.view(torch.uint8)), None, None, p(rst), p(dst), 0.99, N, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(rst.view(-1), rew)
