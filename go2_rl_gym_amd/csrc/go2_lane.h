@@ -190,22 +190,34 @@ struct LegPhys {
       float gap = (cw.z - hh) * n.z - t.foot_pt[3];
       build_slot(cs[0], L, gap, cb, t.foot_pt[3], 3, t.body_index[3], n, true);
     }
-    // deepest of the other candidates
+    // deepest of the other candidates.  They are tabulated per link in a fixed order (hip, thigh, calf, then this lane's share of
+    // the base points), so each link's world pose is formed once and a candidate costs one 3x3 transform; only the winner's
+    // base-frame position is reconstructed afterwards.
     {
-      float best = 1e30f; V3 bcb = v3(0, 0, 0), bn = v3(0, 0, 1); float brad = 0; int blink = 0, bbody = 0;
-      for (int i = 0; i < GO2_NLEG_OTHER + GO2_LANE_BASE_PTS; ++i) {
-        V3 c; float rad; int link, body;
-        if (i < GO2_NLEG_OTHER) {
-          c = v3(t.other_pt[i][0], t.other_pt[i][1], t.other_pt[i][2]); rad = t.other_pt[i][3]; link = t.other_link[i]; body = t.other_body[i];
-        } else {
-          int k = i - GO2_NLEG_OTHER; if (k >= t.n_base) continue;
-          c = v3(t.base_pt[k][0], t.base_pt[k][1], t.base_pt[k][2]); rad = t.base_pt[k][3]; link = 0; body = t.base_body[k];
-        }
-        V3 cb = sel(link == 0, c, sel(link == 1, p1 + mul(R1, c), sel(link == 2, p2 + mul(R2, c), p3 + mul(R3, c))));
-        V3 cw = pw + mul(Rwb, cb); float hh; V3 n; terrain(L, hf, cw.x, cw.y, &hh, &n);
-        float gap = (cw.z - hh) * n.z - rad;
-        if (gap < best) { best = gap; bcb = cb; bn = n; brad = rad; blink = link; bbody = body; }
-      }
+      float best = 1e30f; int bi = 0; V3 bn = v3(0, 0, 1);
+      const M3 Rw1 = {mul(Rwb, R1.x), mul(Rwb, R1.y), mul(Rwb, R1.z)}, Rw2 = {mul(Rwb, R2.x), mul(Rwb, R2.y), mul(Rwb, R2.z)}, Rw3 = {mul(Rwb, R3.x), mul(Rwb, R3.y), mul(Rwb, R3.z)};
+      const V3 o1 = pw + mul(Rwb, p1), o2 = pw + mul(Rwb, p2), o3 = pw + mul(Rwb, p3);
+#define GO2_CAND(idx, PT, RW, OW) { \
+        const V3 cw = OW + mul(RW, v3(PT[0], PT[1], PT[2])); float hh; V3 n; terrain(L, hf, cw.x, cw.y, &hh, &n); \
+        const float gap = (cw.z - hh) * n.z - PT[3]; \
+        if (gap < best) { best = gap; bi = (idx); bn = n; } }
+#define GO2_CAND_UNROLL 1     // rolled: unrolling the 19 candidates raises register pressure into scratch (124 vs 117 us, measured)
+#pragma unroll GO2_CAND_UNROLL
+      for (int i = 0; i < GO2_N_HIP_PTS; ++i) GO2_CAND(i, t.other_pt[i], Rw1, o1)
+#pragma unroll GO2_CAND_UNROLL
+      for (int i = GO2_N_HIP_PTS; i < GO2_N_HIP_PTS + GO2_N_THIGH_PTS; ++i) GO2_CAND(i, t.other_pt[i], Rw2, o2)
+#pragma unroll GO2_CAND_UNROLL
+      for (int i = GO2_N_HIP_PTS + GO2_N_THIGH_PTS; i < GO2_NLEG_OTHER; ++i) GO2_CAND(i, t.other_pt[i], Rw3, o3)
+#pragma unroll GO2_CAND_UNROLL
+      for (int k = 0; k < GO2_LANE_BASE_PTS; ++k) if (k < t.n_base) GO2_CAND(GO2_NLEG_OTHER + k, t.base_pt[k], Rwb, pw)
+#undef GO2_CAND
+      const bool isb = bi >= GO2_NLEG_OTHER;
+      const int kb = isb ? bi - GO2_NLEG_OTHER : 0, ko = isb ? 0 : bi;
+      const V3 c = isb ? v3(t.base_pt[kb][0], t.base_pt[kb][1], t.base_pt[kb][2]) : v3(t.other_pt[ko][0], t.other_pt[ko][1], t.other_pt[ko][2]);
+      const float brad = isb ? t.base_pt[kb][3] : t.other_pt[ko][3];
+      const int bbody = isb ? t.base_body[kb] : t.other_body[ko];
+      const int blink = isb ? 0 : (bi < GO2_N_HIP_PTS ? 1 : (bi < GO2_N_HIP_PTS + GO2_N_THIGH_PTS ? 2 : 3));
+      const V3 bcb = sel(blink == 0, c, sel(blink == 1, p1 + mul(R1, c), sel(blink == 2, p2 + mul(R2, c), p3 + mul(R3, c))));
       build_slot(cs[1], L, best, bcb, brad, blink, bbody, bn, false);
     }
     // joint limits
@@ -281,6 +293,9 @@ struct LegPhys {
     }
     dw_out[0] = dw.a.x; dw_out[1] = dw.a.y; dw_out[2] = dw.a.z; dw_out[3] = dw.l.x; dw_out[4] = dw.l.y; dw_out[5] = dw.l.z;
   }
+  GO2_HD void add_delta(const float* d) {
+    w.a.x += d[0]; w.a.y += d[1]; w.a.z += d[2]; w.l.x += d[3]; w.l.y += d[4]; w.l.z += d[5];
+  }
   // after a turn: add what the other lanes contributed (total - own)
   GO2_HD void add_others(const float* tot, const float* own) {
     w.a.x += tot[0] - own[0]; w.a.y += tot[1] - own[1]; w.a.z += tot[2] - own[2];
@@ -315,12 +330,12 @@ struct LegPhys {
   }
 
   // _compute_torques (legged_robot.py:594-618, control_type 'P') then *= motor_strengths (:80-81)
-  GO2_HD void pd(const LegTab& t, const Go2Launch& L, int lane, const float* act, const float* kpm, const float* kdm, const float* off, const float* strength) {
+  // kp/kd arrive already multiplied by the per-env gain multipliers, q0 = default angle of this leg's joints (hoisted out of the substep loop)
+  GO2_HD void pd(const LegTab& t, const Go2Launch& L, const float* act, const float* kp_, const float* kd_, const float* q0, const float* off, const float* strength) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      int d = 3 * lane + j;
-      float kp = L.kp[d] * kpm[j], kd = L.kd[d] * kdm[j];
-      float tq = kp * (act[j] * L.action_scale + L.q0[d] - q[j] + off[j]) - kd * qd[j];
+      float kp = kp_[j], kd = kd_[j];
+      float tq = kp * (act[j] * L.action_scale + q0[j] - q[j] + off[j]) - kd * qd[j];
       tq = fminf(fmaxf(tq, -t.eff_lim[j]), t.eff_lim[j]);
       if (L.rand_strength) tq *= strength[j];
       tau[j] = tq;

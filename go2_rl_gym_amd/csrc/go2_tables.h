@@ -7,6 +7,11 @@
 
 #define GO2_NLEG_OTHER GO2_LEG_OTHER_PTS
 #define GO2_LANE_BASE_PTS 3
+// the per-leg candidates are tabulated link by link (gen_go2_model.py emits hip, thigh, calf in this order; checked at create)
+#define GO2_N_HIP_PTS 2
+#define GO2_N_THIGH_PTS 8
+#define GO2_N_CALF_PTS 6
+static_assert(GO2_N_HIP_PTS + GO2_N_THIGH_PTS + GO2_N_CALF_PTS == GO2_NLEG_OTHER, "candidate layout");
 
 // per-leg constant table (one per lane index 0..3); plain floats/ints so it can be memcpy'd into LDS
 struct LegTab {
@@ -29,7 +34,7 @@ struct BaseTab {
   float head[2][10];                // Head_upper, Head_lower about the base origin
   float body_off[3][4];             // frame origins of base, Head_upper, Head_lower in the base frame
 };
-struct Go2Tables { LegTab leg[4]; BaseTab base; uint8_t slot_code[GO2_NUM_UNIFORMS]; /* include/go2sim_rng.h */ };
+struct Go2Tables { LegTab leg[4]; BaseTab base; uint8_t slot_code[GO2_NUM_UNIFORMS]; /* include/go2sim_rng.h */ int32_t layout_ok; };
 
 // Device/host pointers of every per-env field.  The HIP library stores per-env fields FIELD-MAJOR (SoA):
 // logical [N, a, b] lives at ((b_idx * A + a_idx) * N + env), i.e. C order of the reversed logical dims,

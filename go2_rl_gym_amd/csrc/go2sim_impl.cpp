@@ -39,7 +39,7 @@ enum { MODE_PHYS = 1, MODE_POST = 2, MODE_RESET_ALL = 4 };
 // ------------------------------------------------------------------------------------------------------
 // The lane context is kept as THREE separate objects (not one struct): the compiler's scalar-replacement pass gives up on a
 // single 2.4 KB aggregate with thousands of uses and would leave all of it in scratch memory.
-struct LaneAux { float kpm[3], kdm[3], zoff[3], strength[3], act_new[3], act_old[3]; int start; };
+struct LaneAux { float kp[3], kd[3], q0[3], zoff[3], strength[3], act_new[3], act_old[3]; int start; };   // kp/kd: gain x per-env multiplier (loaded once, not per substep)
 #define LANE_PARAMS LegPhys& ph_, LegPost& po_, LaneAux& ax
 #define LANE_ARGS(i) c_ph[i], c_po[i], c_ax[i]
 
@@ -55,7 +55,8 @@ GO2_HD void lane_load_phys(LANE_PARAMS, const Go2Tables& tab, const Go2Ptrs& p, 
   _Pragma("unroll") for (int j = 0; j < 3; ++j) {
     int d = 3 * lane + j;
     ph.q[j] = F2D(p.dof, d, e); ph.qd[j] = F2D(p.dof, 12 + d, e);
-    ax.kpm[j] = F2D(p.kp_mul, d, e); ax.kdm[j] = F2D(p.kd_mul, d, e); ax.zoff[j] = F2D(p.zero_off, d, e); ax.strength[j] = F2D(p.strength, d, e);
+    ax.kp[j] = L.kp[d] * F2D(p.kp_mul, d, e); ax.kd[j] = L.kd[d] * F2D(p.kd_mul, d, e); ax.q0[j] = L.q0[d];
+    ax.zoff[j] = F2D(p.zero_off, d, e); ax.strength[j] = F2D(p.strength, d, e);
     float a = actions_in ? actions_in[(size_t)e * 12 + d] : F2D(p.actions, d, e);
     a = fminf(fmaxf(a, -cl), cl);                  // legged_robot.py:67-68
     ax.act_new[j] = a; F2D(p.actions, d, e) = a;
@@ -198,6 +199,23 @@ __device__ __forceinline__ float quad_sum(float x) {
   return y + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(y), 0x4E, 0xF, 0xF, true));
 }
 
+// value of quad lane T in all 4 lanes of the quad (one DPP quad_perm move)
+template <int T>
+__device__ __forceinline__ float quad_bcast(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), T | (T << 2) | (T << 4) | (T << 6), 0xF, 0xF, true));
+}
+// one Gauss-Seidel turn: leg T of every quad sweeps its rows; its base-velocity delta reaches the other three legs by a quad
+// broadcast (they contributed exactly zero, so this equals the quad sum the oracle's formulation implies)
+template <int T>
+__device__ __forceinline__ void gs_turn(LegPhys& ph, int lane, bool any_foot, bool any_other, bool any_lim) {
+  float dw[6];
+  ph.sweep(lane == T ? 1.f : 0.f, dw, any_foot, any_other, any_lim);
+  const float others = lane == T ? 0.f : 1.f;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dw[i] = others * quad_bcast<T>(dw[i]);
+  ph.add_delta(dw);
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) go2_step_kernel(const Go2DevBlock* __restrict__ blk, const float* __restrict__ actions_in, int initial_reset) {
   __shared__ Go2Tables tab;   // robot link / collision tables staged in LDS (per-lane leg index -> ds_read)
@@ -233,26 +251,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     for (int sub = 0; sub < L.decimation; ++sub) {
       const bool old = L.rand_delay && sub < ax.start;
       const float a[3] = {old ? ax.act_old[0] : ax.act_new[0], old ? ax.act_old[1] : ax.act_new[1], old ? ax.act_old[2] : ax.act_new[2]};
-      ph_.pd(t, L, lane, a, ax.kpm, ax.kdm, ax.zoff, ax.strength);
+      ph_.pd(t, L, a, ax.kp, ax.kd, ax.q0, ax.zoff, ax.strength);
       float part[GO2_QUAD_PARTIALS];
       ph_.phaseA(t, L, part);
 #pragma unroll
       for (int i = 0; i < GO2_QUAD_PARTIALS; ++i) part[i] = quad_sum(part[i]);
       ph_.phaseB(L, part);
-      float dw[6], tot[6];
+      float dw[6];
       ph_.phaseC(t, L, p.hf, dw);
 #pragma unroll
       for (int i = 0; i < 6; ++i) dw[i] = quad_sum(dw[i]);
       ph_.set_w(dw);
       // wave-wide row-group activity (ballots -> scalar branches): typically only the foot contacts are live
       const bool any_foot = __any(ph_.has_foot()), any_other = __any(ph_.has_other()), any_lim = __any(ph_.has_limit());
-      for (int it = 0; it < L.solver_iterations; ++it)
-        for (int turn = 0; turn < 4; ++turn) {
-          ph_.sweep(lane == turn ? 1.f : 0.f, dw, any_foot, any_other, any_lim);
-#pragma unroll
-          for (int i = 0; i < 6; ++i) tot[i] = quad_sum(dw[i]);
-          ph_.add_others(tot, dw);
-        }
+      for (int it = 0; it < L.solver_iterations; ++it) {
+        gs_turn<0>(ph_, lane, any_foot, any_other, any_lim); gs_turn<1>(ph_, lane, any_foot, any_other, any_lim);
+        gs_turn<2>(ph_, lane, any_foot, any_other, any_lim); gs_turn<3>(ph_, lane, any_foot, any_other, any_lim);
+      }
       ph_.phaseD(t, L);
     }
     STAMP(2);
@@ -478,6 +493,7 @@ static void fill_tables(Go2Tables* T) {
   static const Sph kFoot[4] = GO2_FOOT_PTS_INIT; static const Sph kOther[4][GO2_LEG_OTHER_PTS] = GO2_LEG_OTHER_PTS_INIT; static const Sph kBase[GO2_BASE_PTS] = GO2_BASE_PTS_INIT;
   (void)kBodyLink;
   memset(T, 0, sizeof(*T));
+  T->layout_ok = 1;
   auto body10 = [&](int b, float* out) {   // about the moving-link origin
     V3 c = v3((float)(kOff[b][0] + kCom[b][0]), (float)(kOff[b][1] + kCom[b][1]), (float)(kOff[b][2] + kCom[b][2]));
     S3 Ic = {(float)kIn[b][0], (float)kIn[b][1], (float)kIn[b][2], (float)kIn[b][3], (float)kIn[b][4], (float)kIn[b][5]};
@@ -494,6 +510,8 @@ static void fill_tables(Go2Tables* T) {
     for (int i = 0; i < GO2_LEG_OTHER_PTS; ++i) {
       for (int k = 0; k < 3; ++k) t.other_pt[i][k] = (float)kOther[l][i].c[k];
       t.other_pt[i][3] = (float)kOther[l][i].r; t.other_link[i] = kOther[l][i].link - 3 * l; t.other_body[i] = kOther[l][i].body;
+      const int want = i < GO2_N_HIP_PTS ? 1 : (i < GO2_N_HIP_PTS + GO2_N_THIGH_PTS ? 2 : 3);
+      if (t.other_link[i] != want) T->layout_ok = 0;      // go2_lane.h phaseC relies on the per-link order of the candidates
     }
     t.n_base = 0;
     for (int i = 0; i < GO2_BASE_PTS; ++i) if ((i & 3) == l) {
@@ -602,7 +620,8 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
   s->d_blk = (Go2DevBlock*)dev_alloc(s, sizeof(Go2DevBlock));
   ok = ok && p.terrain_kind && p.ep_accum && s->inj_storage && s->d_tables && s->d_blk;
   if (!ok) { go2sim_destroy(s); FAIL(GO2SIM_ENOMEM, "allocation failed"); }
-  { Go2Tables T; fill_tables(&T); dev_upload(s->d_tables, &T, sizeof(T)); p.tables = s->d_tables; }
+  { Go2Tables T; fill_tables(&T); if (!T.layout_ok) FAIL(GO2SIM_EINVAL, "collision candidates are not tabulated hip/thigh/calf (include/go2_model_data.h vs go2_tables.h)");
+    dev_upload(s->d_tables, &T, sizeof(T)); p.tables = s->d_tables; }
 
   s->dt = (float)cfg->decimation * cfg->sim_dt;
   s->max_episode_length = (float)ceil((double)cfg->episode_length_s / (double)s->dt - 1e-3);   // np.ceil(25/0.02) = 1250 (:1104)
@@ -723,7 +742,7 @@ static void emu_run(Go2Sim* s, int mode, const float* actions_in, int initial_re
         for (int l = 0; l < 4; ++l) {
           const bool old = L.rand_delay && sub < c_ax[l].start;
           const float a[3] = {old ? c_ax[l].act_old[0] : c_ax[l].act_new[0], old ? c_ax[l].act_old[1] : c_ax[l].act_new[1], old ? c_ax[l].act_old[2] : c_ax[l].act_new[2]};
-          c_ph[l].pd(tab.leg[l], L, l, a, c_ax[l].kpm, c_ax[l].kdm, c_ax[l].zoff, c_ax[l].strength);
+          c_ph[l].pd(tab.leg[l], L, a, c_ax[l].kp, c_ax[l].kd, c_ax[l].q0, c_ax[l].zoff, c_ax[l].strength);
           c_ph[l].phaseA(tab.leg[l], L, part[l]);
         }
         for (int i = 0; i < GO2_QUAD_PARTIALS; ++i) red[i] = quad_sum4(part[0][i], part[1][i], part[2][i], part[3][i]);
