@@ -150,7 +150,11 @@ def main():
             "collection_only": world * N * 24 * a.steps / col,
             "roofline": {"bound": "hbm", "kernel": "go2_step_kernel<PHYS|POST>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo * N, "kernel_ms": k_ms, "launches": n.value, "algorithmic_bytes_per_env_step": algo,
-                         "note": "latency/occupancy-bound by construction: 4096 envs x 4 lanes = 256 waves for 1024 SIMDs (DESIGN.md 6)"},
+                         "note": "latency/occupancy-bound by construction: 4096 envs x 4 lanes = 256 waves for 1024 SIMDs; the binding resource is VALU issue, "
+                                 "not HBM: 35.7k VALU instr per wave per step at 1 wave/SIMD (profiles/r1_sq_step_kernel.json); kernel-only throughput scales "
+                                 "3.5x from 4096 to 32768 envs at constant latency (profiles/r1_kernel_scaling.txt, DESIGN.md 6)",
+                         "valu_issue": {"lane_instr_per_env_step": 35663 * 64 * 256 / 4096, "achieved_Tlane_ops": 35663 * 64 * 256 / 4096 * N / (k_ms * 1e-3) / 1e12,
+                                        "peak_Tlane_ops": 1024 * 16 * 2.4e9 / 1e12, "frac": 35663 * 64 * 256 / 4096 * N / (k_ms * 1e-3) / (1024 * 16 * 2.4e9)}},
         }
         if world == 1 and not a.no_cpu_baseline:
             try:

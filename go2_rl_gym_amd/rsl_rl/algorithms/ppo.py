@@ -23,6 +23,7 @@ import torch.nn as nn
 import torch.optim as optim
 
 from ..storage import RolloutStorage
+from ._graph import CapturedStep
 
 
 # Adam as ONE multi-tensor kernel per param group (fused) instead of ~6 foreach launches; GO2_ADAM=foreach restores the latter
@@ -302,46 +303,26 @@ class PPO(_RolloutHeads):
         self.optimizer.step()
         self._acc.add_(torch.stack([value_loss.detach(), surrogate_loss.detach()]))
 
-    def _build_graph(self):
-        st = self.storage
-        mb = (st.num_envs * st.num_transitions_per_env) // self.num_mini_batches
-        flat = lambda t: t.flatten(0, 1)
-        self._flat = {"obs": flat(st.observations), "cobs": flat(st.privileged_observations) if st.privileged_observations is not None else flat(st.observations),
-                      "act": flat(st.actions), "val": flat(st.values), "ret": flat(st.returns), "logp": flat(st.actions_log_prob), "adv": flat(st.advantages),
-                      "mu": flat(st.mu), "sig": flat(st.sigma)}
-        self._idx = torch.zeros(mb, dtype=torch.int64, device=self.device)
-        self._acc = torch.zeros(2, device=self.device)
-        # warm-up on a side stream (allocator / lazy initialisation), restoring parameters and optimizer state afterwards is not
-        # needed: the warm-up steps are real PPO steps of the first update
-        self._graph = torch.cuda.CUDAGraph()
-        self._pending_capture = True
-
     def _update_graphs(self):
         st = self.storage
         nmb, mb = self.num_mini_batches, (st.num_envs * st.num_transitions_per_env) // self.num_mini_batches
         if self._graph is None:
-            self._build_graph()
+            flat = lambda t: t.flatten(0, 1)
+            self._flat = {"obs": flat(st.observations), "cobs": flat(st.privileged_observations) if st.privileged_observations is not None else flat(st.observations),
+                          "act": flat(st.actions), "val": flat(st.values), "ret": flat(st.returns), "logp": flat(st.actions_log_prob), "adv": flat(st.advantages),
+                          "mu": flat(st.mu), "sig": flat(st.sigma)}
+            self._idx = torch.zeros(mb, dtype=torch.int64, device=self.device)
+            self._acc = torch.zeros(2, device=self.device)
+            # the first 3 mini-batch steps run eagerly on a side stream (allocator / lazy initialisation settle; they are real PPO
+            # steps of the first update), the 4th is captured, every later one is a replay; a failed capture degrades to eager
+            self._graph = CapturedStep(self._graph_step, name="PPO mini-batch step")
         self._acc.zero_()
         # ONE permutation for the whole update, reused by every epoch, as in the reference (rollout_storage.py:150)
         indices = torch.randperm(nmb * mb, requires_grad=False, device=self.device)
-        k = 0
         for _ in range(self.num_learning_epochs):
             for i in range(nmb):
                 self._idx.copy_(indices[i * mb:(i + 1) * mb])
-                if self._pending_capture and k >= 3:
-                    torch.cuda.synchronize()
-                    with torch.cuda.graph(self._graph):
-                        self._graph_step()
-                    self._pending_capture = False      # the capture itself executes nothing: replay below does this mini-batch
-                if self._pending_capture:
-                    s = torch.cuda.Stream()
-                    s.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(s):
-                        self._graph_step()
-                    torch.cuda.current_stream().wait_stream(s)
-                else:
-                    self._graph.replay()
-                k += 1
+                self._graph()
         n = self.num_learning_epochs * nmb
         acc = (self._acc / n).tolist()
         self.learning_rate = float(self._lr_t.item())

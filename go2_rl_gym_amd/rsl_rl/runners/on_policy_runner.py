@@ -186,14 +186,22 @@ class OnPolicyRunner:
                 elif self.use_graphs and self._eager_rollouts >= 2:
                     torch.cuda.synchronize()
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        self._graph_ep_infos = self._rollout(bk)
-                    self._rollout_graph = g                            # capture executes nothing ...
-                    self.alg.storage.step = 0
-                    g.replay()                                         # ... so run this iteration's rollout from the graph
-                    self.env.lib.go2sim_notify_replayed(self.env.handle, T)
-                    self.alg.storage.step = T
-                    ep_infos = self._graph_ep_infos
+                    try:
+                        with torch.cuda.graph(g):
+                            self._graph_ep_infos = self._rollout(bk)
+                    except Exception as e:     # noqa: BLE001 — a capture problem must never stop training: fall back to the eager rollout
+                        print("[go2_rl_gym_amd] HIP-graph capture of the rollout failed (%s: %s); continuing eagerly" % (type(e).__name__, e))
+                        self.use_graphs = False
+                        torch.cuda.synchronize()
+                        self.alg.storage.step = 0
+                        ep_infos = self._rollout(bk)
+                    else:
+                        self._rollout_graph = g                        # capture executes nothing ...
+                        self.alg.storage.step = 0
+                        g.replay()                                     # ... so run this iteration's rollout from the graph
+                        self.env.lib.go2sim_notify_replayed(self.env.handle, T)
+                        self.alg.storage.step = T
+                        ep_infos = self._graph_ep_infos
                 else:
                     ep_infos = self._rollout(bk)
                     self._eager_rollouts += 1
