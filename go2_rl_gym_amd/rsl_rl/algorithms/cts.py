@@ -124,8 +124,8 @@ class CTS(_RolloutHeads):
         st.history[s].copy_(history)
         latent = self._latent_env_order(privileged_obs, history)
         if self.fused_rollout:
-            mu = m.actor(torch.cat([latent, obs], dim=1))
-            return self._act_head(mu, m.std, m._noise(mu), m.evaluate_joint(privileged_obs, latent), s)
+            mu, value = self._pair(lambda: m.actor(torch.cat([latent, obs], dim=1)), lambda: m.evaluate_joint(privileged_obs, latent), enabled=self.use_graphs)
+            return self._act_head(mu, m.std, m._noise(mu), value, s)
         t.actions = m.act_joint(obs, latent).detach()
         t.values = m.evaluate_joint(privileged_obs, latent).detach()
         t.actions_log_prob = m.get_actions_log_prob(t.actions).detach()
@@ -163,8 +163,7 @@ class CTS(_RolloutHeads):
         m = self.model
         latent = m.latents(priv_b, hist_b, n_t)
         if self.fused_loss:
-            mu_b = m.actor(torch.cat([latent, obs_b], dim=1))
-            val_b = m.evaluate_joint(priv_b, latent)
+            mu_b, val_b = self._pair(lambda: m.actor(torch.cat([latent, obs_b], dim=1)), lambda: m.evaluate_joint(priv_b, latent), enabled=self.use_graphs)
             self.surrogate_split = n_t
             loss, stats = _FusedPPOLoss.apply(mu_b, m.std, val_b, self, act_b, tv_b, adv_b, ret_b, old_lp_b, old_mu_b, old_sig_b)
             return loss, stats[1], stats[0], stats[3], stats[2]
