@@ -404,6 +404,41 @@ __global__ void go2_ppo_loss_finish_kernel(const float* __restrict__ part, const
   __syncthreads();
   if (k == 0) stats[4] = stats[0] + vcoef * stats[1] - ecoef * stats[3];
 }
+// ---- ELU backward + bias gradient in one pass.  Block = 64 column-quads (float4) x 4 row lanes over a 256-col x 128-row tile --------
+#define EB_ROWS 128
+__global__ void __launch_bounds__(256) go2_elu_bwd_bias_kernel(const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ gz, float* __restrict__ part, int B, int C) {
+  __shared__ float4 sh[4][64];
+  const int cq = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c0 = (blockIdx.x * 64 + cq) * 4, r0 = blockIdx.y * EB_ROWS;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c0 < C) {
+    const int r1 = min(r0 + EB_ROWS, B);
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const size_t k = (size_t)r * C + c0;
+      const float4 g = *reinterpret_cast<const float4*>(gy + k), v = *reinterpret_cast<const float4*>(y + k);
+      float4 o;
+      o.x = g.x * (v.x > 0.f ? 1.f : v.x + 1.f); o.y = g.y * (v.y > 0.f ? 1.f : v.y + 1.f);
+      o.z = g.z * (v.z > 0.f ? 1.f : v.z + 1.f); o.w = g.w * (v.w > 0.f ? 1.f : v.w + 1.f);
+      *reinterpret_cast<float4*>(gz + k) = o;
+      acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+    }
+  }
+  sh[rl][cq] = acc;
+  __syncthreads();
+  if (rl == 0 && c0 < C) {
+    const float4 a = sh[0][cq], b = sh[1][cq], c = sh[2][cq], d = sh[3][cq];
+    float4 o; o.x = (a.x + b.x) + (c.x + d.x); o.y = (a.y + b.y) + (c.y + d.y); o.z = (a.z + b.z) + (c.z + d.z); o.w = (a.w + b.w) + (c.w + d.w);
+    *reinterpret_cast<float4*>(part + (size_t)blockIdx.y * C + c0) = o;
+  }
+}
+__global__ void __launch_bounds__(256) go2_colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ gb, int nrows, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int r = 0; r < nrows; ++r) s += part[(size_t)r * C + c];     // fixed order: deterministic
+  gb[c] = s;
+}
+
 // ---- rollout heads: PPO.act sampling + storage rows, PPO.process_env_step (one thread per env) ----------------------------
 __global__ void __launch_bounds__(256) go2_act_head_kernel(const float* __restrict__ mu, const float* __restrict__ std_, const float* __restrict__ eps, const float* __restrict__ value,
     float* __restrict__ a_out, float* __restrict__ a_st, float* __restrict__ mu_st, float* __restrict__ sig_st, float* __restrict__ lp_st, float* __restrict__ v_st, int N, int A) {
@@ -947,6 +982,21 @@ int go2sim_ppo_loss(const float* mu, const float* std_, const float* value, cons
   int nb = (B + 255) / 256;
   hipLaunchKernelGGL(go2_ppo_loss_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, mu, std_, value, actions, old_mu, old_sigma, old_logp, adv, tv, ret, gmu, gval, workspace, B, A, clip, vcoef, use_clip_v, split, w_head, w_tail);
   hipLaunchKernelGGL(go2_ppo_loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, workspace, std_, gstd, stats, nb, B, A, vcoef, ecoef);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+int go2sim_elu_backward_bias(const float* gy, const float* y, float* gz, float* gb, float* workspace, int32_t B, int32_t C, void* stream) {
+  if (!gy || !y || !gz || !gb || !workspace || B <= 0 || C <= 0 || (C & 3)) FAIL(GO2SIM_EINVAL, "bad argument (C must be a multiple of 4)");
+#ifdef GO2_EMU
+  (void)stream; (void)workspace;
+  for (int c = 0; c < C; ++c) gb[c] = 0.f;
+  for (int r = 0; r < B; ++r) for (int c = 0; c < C; ++c) { const size_t k = (size_t)r * C + c; const float o = gy[k] * (y[k] > 0.f ? 1.f : y[k] + 1.f); gz[k] = o; gb[c] += o; }
+#else
+  const int nr = (B + EB_ROWS - 1) / EB_ROWS;
+  hipLaunchKernelGGL(go2_elu_bwd_bias_kernel, dim3((C / 4 + 63) / 64, nr), dim3(256), 0, (hipStream_t)stream, gy, y, gz, workspace, B, C);
+  hipLaunchKernelGGL(go2_colsum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace, gb, nr, C);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

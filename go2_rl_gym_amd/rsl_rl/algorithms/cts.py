@@ -11,6 +11,7 @@ library kernel (go2sim_ppo_loss, surrogate_split = teacher rows); the policy ste
 into a HIP graph and replayed 20x per iteration with the learning rate in a device tensor.  The eager mode keeps the
 reference's control flow and is what tests/test_cts_golden.py pins against the reference's own update."""
 import itertools
+import os
 
 import torch
 import torch.distributed as dist
@@ -47,6 +48,9 @@ class CTS(_RolloutHeads):
         self.use_graphs = on_gpu if use_graphs is None else bool(use_graphs and on_gpu)
         self.fused_loss = (on_gpu and lib is not None) if fused_loss is None else bool(fused_loss and lib is not None)
         self.fused_rollout = (on_gpu and lib is not None) if fused_rollout is None else bool(fused_rollout and lib is not None)
+        if on_gpu and lib is not None and os.environ.get("GO2_FUSED_MLP", "1") == "1":
+            from ..modules import fused
+            fused.set_library(lib)
         groups1 = [{"params": list(self.model.teacher_encoder.parameters())}, {"params": list(self.model.critic.parameters())},
                    {"params": list(self.model.actor.parameters())}, {"params": [self.model.std]}]           # same 4 groups as the reference (:72-77)
         self._params1 = list(itertools.chain.from_iterable(g["params"] for g in groups1))

@@ -5,6 +5,8 @@ import torch
 import torch.nn as nn
 from torch.distributions import Normal
 
+from .fused import FusedSequential
+
 _ACT = {"elu": nn.ELU, "selu": nn.SELU, "relu": nn.ReLU, "crelu": nn.ReLU, "lrelu": nn.LeakyReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid}
 
 
@@ -21,7 +23,7 @@ def _mlp(n_in, hidden, n_out, act):
     for a, b in zip(dims[:-1], dims[1:]):
         layers += [nn.Linear(a, b), get_activation(act)]
     layers.append(nn.Linear(dims[-1], n_out))
-    return nn.Sequential(*layers)
+    return FusedSequential(*layers)
 
 
 class ActorCritic(nn.Module):

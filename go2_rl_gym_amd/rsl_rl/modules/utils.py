@@ -12,6 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .actor_critic import get_activation
+from .fused import FusedSequential
 
 
 class L2Norm(nn.Module):
@@ -50,7 +51,7 @@ class MLP(nn.Module):
         layers.append(nn.Linear(dims[-2], dims[-1]))
         if last_activation:
             layers.append(get_activation(activation))
-        self.network = nn.Sequential(*layers)
+        self.network = FusedSequential(*layers)
 
     def forward(self, x):
         return self.network(x)

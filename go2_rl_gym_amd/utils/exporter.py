@@ -67,8 +67,17 @@ class _MoECTSPolicy(nn.Module):
         self.history = torch.zeros_like(self.history)
 
 
+def _plain(m):
+    """The training-time containers route Linear->ELU pairs through a fused backward (modules/fused.py); a deployment module is plain
+    nn.Sequential again (same children, same parameter names) so TorchScript / ONNX see only stock modules."""
+    from ..rsl_rl.modules.fused import FusedSequential
+    for name, child in list(m.named_children()):
+        m._modules[name] = _plain(child)
+    return nn.Sequential(*m.children()) if isinstance(m, FusedSequential) else m
+
+
 def _cpu_copy(m):
-    return copy.deepcopy(m).cpu()
+    return _plain(copy.deepcopy(m).cpu())
 
 
 def _deployment_module(policy, normalizer=None):

@@ -366,6 +366,13 @@ int  go2sim_act_head(const float* mu, const float* std, const float* eps, const 
 int  go2sim_store_transition(const float* rewards, const uint8_t* dones, const uint8_t* time_outs, const float* values_st,
                              float* rewards_st, uint8_t* dones_st, float gamma, int32_t N, void* stream);
 
+/* Backward of a hidden layer's activation fused with its bias gradient (the policy MLPs are Linear -> ELU stacks,
+ * modules/actor_critic.py:60-90): given the upstream gradient gy [B,C] and the layer OUTPUT y = elu(z) [B,C] (alpha = 1),
+ *   gz = gy * (y > 0 ? 1 : y + 1)            (= torch's elu_backward with is_result=True)
+ *   gb[c] = sum_b gz[b,c]                    (the Linear's bias gradient; deterministic two-stage reduction)
+ * in one pass over the activations instead of two.  workspace: >= C * ceil(B/128) floats.  gz may alias gy. */
+int  go2sim_elu_backward_bias(const float* gy, const float* y, float* gz, float* gb, float* workspace, int32_t B, int32_t C, void* stream);
+
 /* Observation-history ring of the CTS runner (on_policy_runner_cts.py:155-156), in place:
  *   history[dones > 0] = 0;  history = cat(history[:, 1:], obs[:, None])      history: float [N,H,D], obs: float [N,D],
  * dones: uint8 [N] or NULL (no zeroing: the push before the first step, :129). */

@@ -1193,6 +1193,17 @@ int go2sim_ppo_loss(const float* mu, const float* std, const float* value, const
   return 0;
 }
 
+/* elu_backward (result form, alpha = 1) + column sum = the bias gradient of the preceding Linear */
+int go2sim_elu_backward_bias(const float* gy, const float* y, float* gz, float* gb, float* workspace, int32_t B, int32_t C, void* stream) {
+  (void)stream; (void)workspace;
+  if (!gy || !y || !gz || !gb || B<=0 || C<=0 || (C&3)) return GO2SIM_EINVAL;
+  double* acc = (double*)calloc((size_t)C, sizeof(double));
+  for (int r=0;r<B;++r) for (int c=0;c<C;++c) { size_t k=(size_t)r*C+c; float o = gy[k]*(y[k] > 0 ? 1.0f : y[k]+1.0f); gz[k]=o; acc[c]+=o; }
+  for (int c=0;c<C;++c) gb[c]=(float)acc[c];
+  free(acc);
+  return 0;
+}
+
 /* PPO.act's sampling head (ppo.py:90-102; torch.distributions.Normal.log_prob: -((x-mu)^2)/(2 var) - log(scale) - log(sqrt(2 pi))) */
 int go2sim_act_head(const float* mu, const float* std, const float* eps, const float* value, float* a_out, float* a_st, float* mu_st, float* sig_st, float* lp_st,
                     float* v_st, int32_t N, int32_t A, void* stream) {

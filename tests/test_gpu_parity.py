@@ -373,3 +373,27 @@ def test_rollout_head_kernels_on_gpu(hip):
     assert hip.go2sim_store_transition(p(rew), p(dones.view(torch.uint8)), None, None, p(rst), p(dst), 0.99, N, st) == 0
     torch.cuda.synchronize()
     assert torch.equal(rst.view(-1), rew)
+
+
+def test_fused_linear_elu_on_gpu(hip):
+    """go2sim_elu_backward_bias (HIP) inside modules/fused.py against plain autograd on the GPU at the real mini-batch shape."""
+    import torch
+    from go2_rl_gym_amd.rsl_rl.modules import fused
+    from go2_rl_gym_amd.rsl_rl.modules.actor_critic import _mlp
+    torch.manual_seed(0)
+    net = _mlp(263, [512, 256, 128], 1, "elu").cuda()
+    x, tgt = torch.randn(24576, 263, device="cuda:0"), torch.randn(24576, 1, device="cuda:0")
+    res = []
+    for lib in (None, hip):
+        fused.set_library(lib)
+        try:
+            net.zero_grad()
+            out = net(x)
+            ((out - tgt) ** 2).mean().backward()
+            torch.cuda.synchronize()
+            res.append((out.detach().clone(), [p.grad.clone() for p in net.parameters()]))
+        finally:
+            fused.set_library(None)
+    np.testing.assert_allclose(res[1][0].cpu().numpy(), res[0][0].cpu().numpy(), atol=1e-5)
+    for a, b in zip(res[0][1], res[1][1]):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), atol=2e-6, rtol=2e-3)

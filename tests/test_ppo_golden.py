@@ -98,3 +98,36 @@ def test_update_with_fused_loss_matches_reference(monkeypatch):
     assert abs(alg.learning_rate - float(g["final_lr"])) < 1e-12
     for k, v in ac.state_dict().items():
         np.testing.assert_allclose(v.numpy(), g["w1_" + k], atol=5e-6, rtol=5e-5, err_msg=k)
+
+
+def test_fused_linear_elu_backward_matches_autograd():
+    """modules/fused.py (go2sim_elu_backward_bias through the oracle build) against plain autograd on the same MLP: outputs and all
+    parameter / input gradients; and the state-dict layout is the plain nn.Sequential one."""
+    from go2_rl_gym_amd.rsl_rl.modules import fused
+    from go2_rl_gym_amd.rsl_rl.modules.actor_critic import _mlp
+    torch.manual_seed(0)
+    net = _mlp(45, [64, 32, 16], 12, "elu")
+    assert list(net.state_dict()) == ["0.weight", "0.bias", "2.weight", "2.bias", "4.weight", "4.bias", "6.weight", "6.bias"]
+    x = torch.randn(300, 45, requires_grad=True)
+    tgt = torch.randn(300, 12)
+    res = []
+    for lib in (None, load_oracle()):
+        fused.set_library(lib)
+        try:
+            net.zero_grad(); x.grad = None
+            out = net(x)
+            ((out - tgt) ** 2).mean().backward()
+            res.append((out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in net.parameters()]))
+        finally:
+            fused.set_library(None)
+    (o0, gx0, gp0), (o1, gx1, gp1) = res
+    np.testing.assert_allclose(o1.numpy(), o0.numpy(), atol=1e-6)
+    np.testing.assert_allclose(gx1.numpy(), gx0.numpy(), atol=1e-7, rtol=1e-4)
+    for a, b in zip(gp0, gp1):
+        np.testing.assert_allclose(b.numpy(), a.numpy(), atol=1e-7, rtol=1e-4)
+    with torch.no_grad():       # inference takes the plain path
+        fused.set_library(load_oracle())
+        try:
+            np.testing.assert_allclose(net(x).numpy(), o0.numpy(), atol=1e-6)
+        finally:
+            fused.set_library(None)
