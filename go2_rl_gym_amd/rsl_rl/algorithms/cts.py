@@ -48,7 +48,7 @@ class CTS(_RolloutHeads):
         self.use_graphs = on_gpu if use_graphs is None else bool(use_graphs and on_gpu)
         self.fused_loss = (on_gpu and lib is not None) if fused_loss is None else bool(fused_loss and lib is not None)
         self.fused_rollout = (on_gpu and lib is not None) if fused_rollout is None else bool(fused_rollout and lib is not None)
-        if on_gpu and lib is not None and os.environ.get("GO2_FUSED_MLP", "1") == "1":
+        if on_gpu and lib is not None and os.environ.get("GO2_FUSED_MLP", "0") == "1":
             from ..modules import fused
             fused.set_library(lib)
         groups1 = [{"params": list(self.model.teacher_encoder.parameters())}, {"params": list(self.model.critic.parameters())},
@@ -251,9 +251,12 @@ class CTS(_RolloutHeads):
         n = self.num_learning_epochs * self.num_mini_batches
         return tuple(a / n for a in acc)
 
-    # ---- graph mode: every decision on the device, two captured steps ----------------------------------------
-    def _policy_step(self):
-        loss, value_loss, surrogate_loss, ent, kl_mean = self._policy_losses(*self._gather(self._flat, self._idx), self._teacher_rows())
+    # ---- graph mode: every decision on the device; one captured policy step and one captured student step per mini-batch slot ----
+    _KEYS = ("obs", "cobs", "hist", "act", "val", "adv", "ret", "logp", "mu", "sig")
+
+    def _policy_step(self, i):
+        mb = self._mb
+        loss, value_loss, surrogate_loss, ent, kl_mean = self._policy_losses(*(self._perm[k][i * mb:(i + 1) * mb] for k in self._KEYS), self._teacher_rows())
         if self.desired_kl is not None and self.schedule == "adaptive":
             if _collectives_on():
                 dist.all_reduce(kl_mean, op=dist.ReduceOp.SUM)
@@ -269,9 +272,9 @@ class CTS(_RolloutHeads):
         self.optimizer1.step()
         self._acc[:3].add_(torch.stack([value_loss.detach(), surrogate_loss.detach(), ent.detach()]))
 
-    def _student_step(self):
-        bs = self._idx[self._teacher_rows():]
-        loss, logs = self._student_losses(self._flat["hist"][bs], self._flat["cobs"][bs])
+    def _student_step(self, i):
+        mb, n_t = self._mb, self._teacher_rows()
+        loss, logs = self._student_losses(self._perm["hist"][i * mb + n_t:(i + 1) * mb], self._perm["cobs"][i * mb + n_t:(i + 1) * mb])
         self.optimizer2.zero_grad(set_to_none=True)
         loss.backward()
         if _collectives_on():
@@ -281,21 +284,25 @@ class CTS(_RolloutHeads):
         self._acc[3:].add_(torch.stack([v.detach() for v in logs]))
 
     def _update_graphs(self):
-        st = self.storage
+        st, nmb = self.storage, self.num_mini_batches
         if self._steps is None:
             self._flat = st.flat()
-            mb = (st.teacher_num_envs * st.num_transitions_per_env) // self.num_mini_batches + (st.student_num_envs * st.num_transitions_per_env) // self.num_mini_batches
-            self._idx = torch.zeros(mb, dtype=torch.int64, device=self.device)
+            self._mb = (st.teacher_num_envs * st.num_transitions_per_env) // nmb + (st.student_num_envs * st.num_transitions_per_env) // nmb
+            self._perm = {k: torch.empty((nmb * self._mb,) + tuple(self._flat[k].shape[1:]), device=self.device, dtype=self._flat[k].dtype) for k in self._KEYS}
             self._acc = torch.zeros(3 + self._NUM_STUDENT_LOGS, device=self.device)
-            self._steps = (CapturedStep(self._policy_step, name="CTS policy step"), CapturedStep(self._student_step, name="CTS student step"))
+            mk = lambda fn, name: [CapturedStep((lambda i=i: fn(i)), warmup=3 if i == 0 else 1, name="CTS %s step %d" % (name, i)) for i in range(nmb)]
+            self._steps = (mk(self._policy_step, "policy"), mk(self._student_step, "student"))
         self._acc.zero_()
-        idx = st.mini_batch_indices(self.num_mini_batches)
-        for step in self._steps:
+        # the rollout is gathered ONCE per update into mini-batch order ([teacher rows | student rows] per mini-batch; every epoch
+        # reuses the same permutation, rollout_storage_cts.py:152-160), so each captured step reads a contiguous chunk
+        order = torch.cat(st.mini_batch_indices(nmb))
+        for k in self._KEYS:
+            torch.index_select(self._flat[k], 0, order, out=self._perm[k])
+        for steps in self._steps:
             for _ in range(self.num_learning_epochs):
-                for b in idx:
-                    self._idx.copy_(b)
-                    step()
-        n = self.num_learning_epochs * self.num_mini_batches
+                for i in range(nmb):
+                    steps[i]()
+        n = self.num_learning_epochs * nmb
         out = (self._acc / n).tolist()
         self.learning_rate = float(self._lr_t.item())
         return tuple(out)

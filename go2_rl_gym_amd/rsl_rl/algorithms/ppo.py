@@ -157,9 +157,10 @@ class PPO(_RolloutHeads):
         # the fused loss kernel is the default on the GPU; on the CPU it is opt-in (tests compare it with the eager formulation)
         self.fused_loss = (on_gpu and lib is not None) if fused_loss is None else bool(fused_loss and lib is not None)
         self.fused_rollout = (on_gpu and lib is not None) if fused_rollout is None else bool(fused_rollout and lib is not None)
-        if on_gpu and lib is not None and os.environ.get("GO2_FUSED_MLP", "1") == "1":
+        if on_gpu and lib is not None and os.environ.get("GO2_FUSED_MLP", "0") == "1":
             from ..modules import fused
-            fused.set_library(lib)         # Linear->ELU pairs: activation + bias gradients in one pass
+            fused.set_library(lib)         # opt-in: Linear->ELU pairs with activation + bias gradients in one pass (no measured gain once the
+                                           # two chains overlap on two streams, so off by default)
         if _world() > 1:   # identical initial replicas
             for p in self.actor_critic.parameters():
                 dist.broadcast(p.data, src=0)
@@ -300,14 +301,14 @@ class PPO(_RolloutHeads):
         return mean_value_loss / n, mean_surrogate_loss / n
 
     # ---- graph mode -------------------------------------------------------------------------------------------
-    def _minibatch_from_idx(self):
-        f = self._flat
-        b = self._idx
-        return tuple(t[b] for t in (f["obs"], f["cobs"], f["act"], f["val"], f["adv"], f["ret"], f["logp"], f["mu"], f["sig"]))
+    _KEYS = ("obs", "cobs", "act", "val", "adv", "ret", "logp", "mu", "sig")
 
-    def _graph_step(self):
-        """One mini-batch update with every decision on the device (same arithmetic as _update_eager)."""
-        loss, value_loss, surrogate_loss, kl_mean = self._losses(*self._minibatch_from_idx())
+    def _graph_step(self, i):
+        """One mini-batch update with every decision on the device (same arithmetic as _update_eager).  Mini-batch i is the i-th
+        contiguous chunk of the rollout permuted ONCE per update (the reference reuses one permutation for all epochs,
+        rollout_storage.py:150): 4 chunk gathers per iteration instead of 20 mini-batch gathers."""
+        mb = self._mb
+        loss, value_loss, surrogate_loss, kl_mean = self._losses(*(self._perm[k][i * mb:(i + 1) * mb] for k in self._KEYS))
         if self.desired_kl is not None and self.schedule == "adaptive":
             if _collectives_on():          # RCCL all-reduce captured inside the graph: every rank takes the same LR branch
                 dist.all_reduce(kl_mean, op=dist.ReduceOp.SUM)
@@ -333,18 +334,21 @@ class PPO(_RolloutHeads):
             self._flat = {"obs": flat(st.observations), "cobs": flat(st.privileged_observations) if st.privileged_observations is not None else flat(st.observations),
                           "act": flat(st.actions), "val": flat(st.values), "ret": flat(st.returns), "logp": flat(st.actions_log_prob), "adv": flat(st.advantages),
                           "mu": flat(st.mu), "sig": flat(st.sigma)}
-            self._idx = torch.zeros(mb, dtype=torch.int64, device=self.device)
+            self._mb = mb
+            self._perm = {k: torch.empty((nmb * mb,) + tuple(v.shape[1:]), device=self.device, dtype=v.dtype) for k, v in self._flat.items()}
             self._acc = torch.zeros(2, device=self.device)
-            # the first 3 mini-batch steps run eagerly on a side stream (allocator / lazy initialisation settle; they are real PPO
-            # steps of the first update), the 4th is captured, every later one is a replay; a failed capture degrades to eager
-            self._graph = CapturedStep(self._graph_step, name="PPO mini-batch step")
+            # one captured step per mini-batch slot (each reads its own chunk of the permuted rollout).  Slot 0 runs 3 eager steps on
+            # a side stream first (allocator / lazy initialisation settle; they are real PPO steps of the first update), the others
+            # one; then each is captured once and replayed.  A failed capture degrades that slot to eager execution.
+            self._graph = [CapturedStep((lambda i=i: self._graph_step(i)), warmup=3 if i == 0 else 1, name="PPO mini-batch step %d" % i) for i in range(nmb)]
         self._acc.zero_()
         # ONE permutation for the whole update, reused by every epoch, as in the reference (rollout_storage.py:150)
         indices = torch.randperm(nmb * mb, requires_grad=False, device=self.device)
+        for k in self._KEYS:
+            torch.index_select(self._flat[k], 0, indices, out=self._perm[k])
         for _ in range(self.num_learning_epochs):
             for i in range(nmb):
-                self._idx.copy_(indices[i * mb:(i + 1) * mb])
-                self._graph()
+                self._graph[i]()
         n = self.num_learning_epochs * nmb
         acc = (self._acc / n).tolist()
         self.learning_rate = float(self._lr_t.item())

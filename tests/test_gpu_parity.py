@@ -299,7 +299,7 @@ def test_cts_training_graph_vs_eager_on_gpu(hip, task):
         runner.learn(5, init_at_random_ep_len=True)
         torch.cuda.synchronize()
         if mode:
-            assert runner._rollout_graph is not None and all(s.graph is not None for s in runner.alg._steps)
+            assert runner._rollout_graph is not None and all(s.graph is not None for grp in runner.alg._steps for s in grp)
         out[mode] = (runner.alg.learning_rate, torch.cat([p.detach().reshape(-1) for p in runner.alg.model.parameters()]).cpu().numpy(),
                      env.common_step_counter, float(env.rew_buf.mean()), runner.history.abs().mean().item())
         env.close()
