@@ -54,6 +54,21 @@ def _worker(rank, world, port, out):
     alg.update()
     res["params"] = torch.cat([p.detach().reshape(-1) for p in ac.parameters()]).numpy().copy()
     res["lr"] = alg.learning_rate
+    # the same for CTS (two optimizers: policy group and student encoder)
+    from go2_rl_gym_amd.rsl_rl.algorithms import CTS
+    from go2_rl_gym_amd.rsl_rl.modules import ActorCriticCTS
+    torch.manual_seed(200 + rank)
+    m = ActorCriticCTS(45, 263, 12, n, 5, actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16], teacher_encoder_hidden_dims=[32], student_encoder_hidden_dims=[32], latent_dim=8)
+    cts = CTS(m, n, 5, num_learning_epochs=2, num_mini_batches=2, entropy_coef=0.01, schedule="adaptive", device="cpu", lib=lib)
+    cts.init_storage(n, T, [45], [263], [12])
+    for t in range(T):
+        obs, cobs, hist = torch.randn(n, 45, generator=g), torch.randn(n, 263, generator=g), torch.randn(n, 225, generator=g)
+        cts.act(obs, cobs, hist)
+        cts.process_env_step(torch.randn(n, generator=g) * 0.05, torch.rand(n, generator=g) < 0.05, {"time_outs": torch.zeros(n, dtype=torch.bool)})
+    cts.compute_returns(torch.randn(n, 263, generator=g), torch.randn(n, 225, generator=g))
+    cts.update()
+    res["cts_params"] = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).numpy().copy()
+    res["cts_lr"] = cts.learning_rate
     # env sharding: shard r of a 2-shard sim equals envs [r*n, (r+1)*n) of the single sim (same global Philox keys / origins)
     s = HostSim(lib, num_envs=8, env_offset=rank * 8, num_envs_global=16, seed=3)
     s.reset_all()
@@ -80,6 +95,8 @@ def test_world_size_2_matches_single_process():
     np.testing.assert_allclose(np.concatenate([out[0]["ret"], out[1]["ret"]], axis=1), st.returns.numpy(), atol=1e-6)
     np.testing.assert_array_equal(out[0]["params"], out[1]["params"])           # one coherent policy
     assert out[0]["lr"] == out[1]["lr"]
+    np.testing.assert_array_equal(out[0]["cts_params"], out[1]["cts_params"])
+    assert out[0]["cts_lr"] == out[1]["cts_lr"] and np.isfinite(out[0]["cts_params"]).all()
     s = HostSim(lib, num_envs=16, seed=3); s.reset_all()
     for r in range(2):
         np.testing.assert_array_equal(out[r]["shard_root"], s.root_states[8 * r:8 * r + 8])
