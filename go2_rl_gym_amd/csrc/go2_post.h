@@ -51,9 +51,9 @@ GO2_HD void go2_step_scalars(const Go2Launch& L, const Go2Dyn& dyn, const float*
   S->initial_reset = initial_reset; S->injected = dyn.use_injected ? inj_storage : nullptr;
   float it = (float)(csc / L.num_steps_per_env);
   _Pragma("unroll") for (int t = 0; t < GO2_NUM_REWARDS; ++t) {
-    float sc = L.rew_scale_dt[t];
-    for (int i = 0; i < L.rew_curr_count; ++i) if (L.rew_curr_term[i] == t) sc *= go2_current_scale(L.rew_curr[i], it);
-    S->rew_scale[t] = sc;
+    float sc = L.rew_scale_dt[t], sct = L.rew_to_scale_dt[t];
+    for (int i = 0; i < L.rew_curr_count; ++i) if (L.rew_curr_term[i] == t) { const float k = go2_current_scale(L.rew_curr[i], it); sc *= k; sct *= k; }
+    S->rew_scale[t] = sc; S->rew_to_scale[t] = sct;
   }
   int best = -1;
   for (int i = 0; i < L.cmd_curr_count; ++i) if (it >= L.cmd_curr[i][0] && (best < 0 || L.cmd_curr[i][0] > L.cmd_curr[best][0])) best = i;
@@ -149,8 +149,10 @@ struct LegPost {
         }
       }
     }
+    if (L->turn_over && to_timer > 0.f) { cmd[0] = 0.f; cmd[1] = 0.f; cmd[2] = 0.f; stop_heading = 1; }   // :586-590
     acc[0] += cmd[0]; acc[1] += cmd[1];
   }
+  float to_timer;
   // one sample of _get_heights (:1188-1224) around base (bx, by) with yaw quaternion (0,0,yz,yw)
   float hq_z, hq_w, hpx, hpy;
   GO2_HD float height_at(int i, float yz, float yw, float bx, float by) const {
@@ -180,6 +182,7 @@ struct LegPost {
     const Go2Ptrs& p = *P; const Go2Launch& c = *L;
     ep_len = p.ep_len[e] + 1;                      // :111
     timer = p.cmd_timer[e] - 1.f;                  // :113
+    to_timer = c.turn_over ? fmaxf(p.to_timer[e] - c.dt, 0.f) : 0.f;     // :114-115
     _Pragma("unroll") for (int k = 0; k < 4; ++k) cmd[k] = F2D(p.commands, k, e);
     acc[0] = F2D(p.cmd_xy_acc, 0, e); acc[1] = F2D(p.cmd_xy_acc, 1, e);
     stop_heading = p.stop_heading[e]; last_limit = p.last_is_limit_vel[e];
@@ -217,7 +220,7 @@ struct LegPost {
       }
     }
     // check_termination (:170-178)
-    bool term = sqrtf(dot(o.Fbase, o.Fbase)) > 1.f;
+    bool term = !c.turn_over && sqrtf(dot(o.Fbase, o.Fbase)) > 1.f;      // :174
     time_out = (float)ep_len > c.max_episode_length ? 1 : 0;
     reset = (term || time_out) ? 1 : 0;
     // ---- reward partial sums over this lane's joints / bodies ------------------------------------
@@ -240,13 +243,13 @@ struct LegPost {
     bool contact = o.Ffoot.z > 1.f;
     // _reward_base_height (:1245-1259)
     float bh_cnt = 0; V3 bh_pos = v3(0, 0, 0);
-    if (c.rew_scale_dt[GO2_REW_BASE_HEIGHT] != 0.f) {
+    if (c.rew_on[GO2_REW_BASE_HEIGHT]) {
       bool filt = contact || F2D(p.last_contacts2, lane, e); F2D(p.last_contacts2, lane, e) = contact ? 1 : 0;
       if (filt) { bh_cnt = 1; bh_pos = o.foot_pos; }
     }
     // _reward_feet_air_time (:1347-1358)
     float air = 0;
-    if (c.rew_scale_dt[GO2_REW_FEET_AIR_TIME] != 0.f) {
+    if (c.rew_on[GO2_REW_FEET_AIR_TIME]) {
       bool filt = contact || F2D(p.last_contacts, lane, e); F2D(p.last_contacts, lane, e) = contact ? 1 : 0;
       float fat = F2D(p.feet_air_time, lane, e); bool first = fat > 0.f && filt; fat += c.dt; air = (fat - 0.5f) * (first ? 1.f : 0.f);
       F2D(p.feet_air_time, lane, e) = filt ? 0.f : fat;
@@ -328,14 +331,15 @@ struct LegPost {
     raw[GO2_REW_X_COMMAND_HIP_REGULAR] = (fabsf(red[19]) + fabsf(red[20])) * fabsf(cmd[0]) / sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1] + cmd[2] * cmd[2]);
     float total = 0.f;
     float* es = p.ep_sums;  // [R][N] row-major
+    const bool need_to = c.turn_over && fabsf(rpy[0]) > c.to_roll_thr;      // :263-265
 #pragma unroll
     for (int i = 0; i < GO2_REW_TERMINATION; ++i)
-      if (c.rew_scale_dt[i] != 0.f && !S->initial_reset) { float r = raw[i] * S->rew_scale[i]; total += r; if (lane == 0) es[(size_t)i * N + e] += r; }
+      if (c.rew_on[i] && !S->initial_reset) { float r = raw[i] * (need_to ? S->rew_to_scale[i] : S->rew_scale[i]); total += r; if (lane == 0) es[(size_t)i * N + e] += r; }
     if (c.only_positive && total < 0.f) total = 0.f;
-    if (c.rew_scale_dt[GO2_REW_TERMINATION] != 0.f && !S->initial_reset) {
+    if (c.rew_on[GO2_REW_TERMINATION] && !S->initial_reset) {
       float r = ((reset && !time_out) ? 1.f : 0.f) * S->rew_scale[GO2_REW_TERMINATION]; total += r; if (lane == 0) es[(size_t)GO2_REW_TERMINATION * N + e] += r;
     }
-    if (c.rew_scale_dt[GO2_REW_ACTION_SMOOTHNESS] != 0.f)
+    if (c.rew_on[GO2_REW_ACTION_SMOOTHNESS])
       _Pragma("unroll") for (int j = 0; j < 3; ++j) llast_act[j] = last_act[j];       // :1378 (not zeroed on reset, App. E.9)
 
     // ---- reset_idx (:180-245) ---------------------------------------------------------------------
@@ -368,9 +372,18 @@ struct LegPost {
       }
       // _reset_root_states (:635-707)
       float yaw = urange(uni(GO2_U_RESET_YAW), -3.14159265358979f, 3.14159265358979f);
-      o.pw = v3(c.base_init[0] + ox, c.base_init[1] + oy, c.base_init[2] + oz);
+      float zinit = c.base_init[2], roll = 0.f;
+      if (c.turn_over) {   // :642-684: a share of the resets starts on the back (roll pi) or on a side (roll +-pi/2)
+        to_timer = 0.f;
+        const float pr = uni(GO2_U_TURN), p0 = c.to_prop[0], p1 = p0 + c.to_prop[1];
+        if (pr >= 0.f && pr < p0) { zinit = urange(uni(GO2_U_TURN + 1), c.to_height[0][0], c.to_height[0][1]); roll = 3.14159265358979f; to_timer = c.to_zero_time[0]; }
+        else if (pr >= p0 && pr < p1) { zinit = urange(uni(GO2_U_TURN + 2), c.to_height[1][0], c.to_height[1][1]);
+          roll = uni(GO2_U_TURN + 3) < 0.5f ? 1.57079632679490f : -1.57079632679490f; to_timer = c.to_zero_time[1]; }
+      }
+      o.pw = v3(c.base_init[0] + ox, c.base_init[1] + oy, zinit + oz);
       if (c.terrain_mode != 0) { o.pw.x += urange(uni(GO2_U_RESET_XY), -1.f, 1.f); o.pw.y += urange(uni(GO2_U_RESET_XY + 1), -1.f, 1.f); }
-      o.qx = 0.f; o.qy = 0.f; o.qz = sinf(0.5f * yaw); o.qw = cosf(0.5f * yaw);
+      { const float cy = cosf(0.5f * yaw), sy = sinf(0.5f * yaw), cr = cosf(0.5f * roll), sr = sinf(0.5f * roll);   // quat_from_euler_xyz(roll, 0, yaw)
+        o.qx = cy * sr; o.qy = sy * sr; o.qz = sy * cr; o.qw = cy * cr; }
       o.vw = v3(urange(uni(GO2_U_RESET_VEL), -0.5f, 0.5f), urange(uni(GO2_U_RESET_VEL + 1), -0.5f, 0.5f), urange(uni(GO2_U_RESET_VEL + 2), -0.5f, 0.5f));
       o.ww = v3(urange(uni(GO2_U_RESET_VEL + 3), -0.5f, 0.5f), urange(uni(GO2_U_RESET_VEL + 4), -0.5f, 0.5f), urange(uni(GO2_U_RESET_VEL + 5), -0.5f, 0.5f));
       F2D(p.feet_air_time, lane, e) = 0.f;
@@ -379,7 +392,7 @@ struct LegPost {
       timer = c.resampling_time / c.dt; acc[0] = 0.f; acc[1] = 0.f;
       resample(GO2_U_RSB);
       if (lane == 0) {   // extras["episode"] accumulators (:229-242)
-        _Pragma("unroll") for (int i = 0; i < GO2_NUM_REWARDS; ++i) if (c.rew_scale_dt[i] != 0.f) {
+        _Pragma("unroll") for (int i = 0; i < GO2_NUM_REWARDS; ++i) if (c.rew_on[i]) {
 #if defined(__HIP_DEVICE_COMPILE__)
           atomicAdd(&p.ep_accum[i], es[(size_t)i * N + e]);
 #else
@@ -452,6 +465,7 @@ struct LegPost {
       F2D(p.cmd_xy_acc, 0, e) = acc[0]; F2D(p.cmd_xy_acc, 1, e) = acc[1];
       p.stop_heading[e] = stop_heading; p.last_is_limit_vel[e] = last_limit;
       p.reset[e] = reset; p.time_out[e] = time_out; p.rew[e] = total; p.max_move[e] = max_move;
+      if (c.turn_over) p.to_timer[e] = to_timer;
       F2D(p.base_lin_vel, 0, e) = blv.x; F2D(p.base_lin_vel, 1, e) = blv.y; F2D(p.base_lin_vel, 2, e) = blv.z;
       F2D(p.base_ang_vel, 0, e) = bav.x; F2D(p.base_ang_vel, 1, e) = bav.y; F2D(p.base_ang_vel, 2, e) = bav.z;
       F2D(p.proj_gravity, 0, e) = pg.x; F2D(p.proj_gravity, 1, e) = pg.y; F2D(p.proj_gravity, 2, e) = pg.z;

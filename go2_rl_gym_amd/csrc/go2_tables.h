@@ -43,7 +43,7 @@ struct Go2Tables { LegTab leg[4]; BaseTab base; uint8_t slot_code[GO2_NUM_UNIFOR
 struct Go2Ptrs {
   float *root, *dof, *contact, *rigid, *obs, *priv, *rew; uint8_t *reset, *time_out; int64_t* ep_len;
   float *torques, *actions, *last_actions, *last_last_actions, *last_dof_vel, *last_root_vel, *commands, *cmd_timer, *cmd_xy_acc;
-  uint8_t *stop_heading, *last_is_limit_vel; float *base_lin_vel, *base_ang_vel, *proj_gravity, *rpy, *heights, *max_move, *feet_air_time;
+  uint8_t *stop_heading, *last_is_limit_vel; float *base_lin_vel, *base_ang_vel, *proj_gravity, *rpy, *heights, *max_move, *to_timer, *feet_air_time;
   uint8_t *last_contacts, *last_contacts2; float *strength, *zero_off, *kp_mul, *kd_mul, *origins; int64_t *terrain_levels, *terrain_types;
   float *ep_sums, *friction, *restitution, *added_mass, *added_com, *mass_ratio, *episode_info, *foot_impulse;
   // internal
@@ -64,7 +64,10 @@ struct Go2Launch {
   float resampling_time; int32_t heading_command, dynamic_resample; float limit_vel_prob; int32_t limit_invert, stop_heading_at_limit;
   float limit_ang_zero_prob; int32_t comb_count; float comb[36][3];
   float cmd_ranges0[4][2], terrain_max_cmd[9][4][2];
-  float rew_scale_dt[GO2_NUM_REWARDS];  // raw scale * dt (0 = inactive)
+  float rew_scale_dt[GO2_NUM_REWARDS];  // raw scale * dt
+  float rew_to_scale_dt[GO2_NUM_REWARDS];   // turn_over_scales * dt (all 0 unless init_state.turn_over)
+  int32_t rew_on[GO2_NUM_REWARDS];      // term computed: non-zero in either table (legged_robot.py:927-930)
+  int32_t turn_over; float to_prop[3], to_height[2][2], to_zero_time[2], to_roll_thr;
   int32_t rew_curr_count, rew_curr_term[4]; float rew_curr[4][4];     // curriculum_rewards (start_iter,end_iter,start,end)
   int32_t cmd_curr_count; float cmd_curr[4][9];                       // command_range_curriculum
   int32_t zero_curr_enabled; float zero_curr[4]; int32_t num_steps_per_env;
@@ -82,7 +85,8 @@ struct Go2Dyn { uint64_t step_count; int64_t common_step_counter; int32_t use_in
 // Go2Dyn.common_step_counter into LDS: they are pure functions of counter // num_steps_per_env
 struct Go2Step {
   uint32_t step_lo, step_hi; int32_t initial_reset; const float* injected;
-  float rew_scale[GO2_NUM_REWARDS];  // scale * dt * curriculum (0 = inactive)
+  float rew_scale[GO2_NUM_REWARDS];  // scale * dt * curriculum
+  float rew_to_scale[GO2_NUM_REWARDS];   // turn_over scale * dt * curriculum
   float cmd_ranges[4][2], max_lin_vel, zero_cmd_proba;
 };
 struct Go2DevBlock { Go2Ptrs p; Go2Launch L; Go2Dyn dyn; };

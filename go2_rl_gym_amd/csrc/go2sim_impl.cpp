@@ -634,7 +634,7 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
   A(episode_length_buf, int64_t, N); A(torques, float, N * 12); A(actions, float, N * 12); A(last_actions, float, N * 12); A(last_last_actions, float, N * 12);
   A(last_dof_vel, float, N * 12); A(last_root_vel, float, N * 6); A(commands, float, N * 4); A(commands_resampling_step, float, N); A(commands_xy_accumulation, float, N * 2);
   A(stop_heading, uint8_t, N); A(last_is_limit_vel, uint8_t, N); A(base_lin_vel, float, N * 3); A(base_ang_vel, float, N * 3); A(projected_gravity, float, N * 3); A(rpy, float, N * 3);
-  A(measured_heights, float, N * GO2_NUM_HEIGHT_POINTS); A(max_move_distance, float, N); A(feet_air_time, float, N * 4); A(last_contacts, uint8_t, N * 4); A(last_contacts2, uint8_t, N * 4);
+  A(measured_heights, float, N * GO2_NUM_HEIGHT_POINTS); A(max_move_distance, float, N); A(turn_over_timer, float, N); A(feet_air_time, float, N * 4); A(last_contacts, uint8_t, N * 4); A(last_contacts2, uint8_t, N * 4);
   A(motor_strengths, float, N * 12); A(motor_zero_offsets, float, N * 12); A(p_gains_multiplier, float, N * 12); A(d_gains_multiplier, float, N * 12);
   A(env_origins, float, N * 3); A(terrain_levels, int64_t, N); A(terrain_types, int64_t, N); A(episode_sums, float, GO2_NUM_REWARDS * N);
   A(friction_coeffs, float, N); A(restitution_coeffs, float, N); A(added_base_mass, float, N); A(added_base_com, float, N * 3); A(link_mass_ratio, float, N * 18);
@@ -645,7 +645,7 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
   p.reset = b.reset_buf; p.time_out = b.time_out_buf; p.ep_len = b.episode_length_buf; p.torques = b.torques; p.actions = b.actions; p.last_actions = b.last_actions;
   p.last_last_actions = b.last_last_actions; p.last_dof_vel = b.last_dof_vel; p.last_root_vel = b.last_root_vel; p.commands = b.commands; p.cmd_timer = b.commands_resampling_step;
   p.cmd_xy_acc = b.commands_xy_accumulation; p.stop_heading = b.stop_heading; p.last_is_limit_vel = b.last_is_limit_vel; p.base_lin_vel = b.base_lin_vel; p.base_ang_vel = b.base_ang_vel;
-  p.proj_gravity = b.projected_gravity; p.rpy = b.rpy; p.heights = b.measured_heights; p.max_move = b.max_move_distance; p.feet_air_time = b.feet_air_time; p.last_contacts = b.last_contacts;
+  p.proj_gravity = b.projected_gravity; p.rpy = b.rpy; p.heights = b.measured_heights; p.max_move = b.max_move_distance; p.to_timer = b.turn_over_timer; p.feet_air_time = b.feet_air_time; p.last_contacts = b.last_contacts;
   p.last_contacts2 = b.last_contacts2; p.strength = b.motor_strengths; p.zero_off = b.motor_zero_offsets; p.kp_mul = b.p_gains_multiplier; p.kd_mul = b.d_gains_multiplier; p.origins = b.env_origins;
   p.terrain_levels = b.terrain_levels; p.terrain_types = b.terrain_types; p.ep_sums = b.episode_sums; p.friction = b.friction_coeffs; p.restitution = b.restitution_coeffs;
   p.added_mass = b.added_base_mass; p.added_com = b.added_base_com; p.mass_ratio = b.link_mass_ratio; p.episode_info = b.episode_info; p.foot_impulse = b.foot_impulse;
@@ -681,7 +681,13 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
   L.limit_invert = cfg->limit_vel_invert_when_continuous; L.stop_heading_at_limit = cfg->stop_heading_at_limit; L.limit_ang_zero_prob = cfg->limit_ang_vel_at_zero_command_prob;
   L.comb_count = cfg->limit_vel_comb_count; memcpy(L.comb, cfg->limit_vel_comb, sizeof(L.comb)); memcpy(L.terrain_max_cmd, cfg->terrain_max_cmd_ranges, sizeof(L.terrain_max_cmd));
   memcpy(L.cmd_ranges0, cfg->cmd_ranges, sizeof(L.cmd_ranges0));
-  for (int t = 0; t < GO2_NUM_REWARDS; ++t) L.rew_scale_dt[t] = cfg->reward_scales[t] * s->dt;   // :914-920
+  for (int t = 0; t < GO2_NUM_REWARDS; ++t) {   // :914-930
+    L.rew_scale_dt[t] = cfg->reward_scales[t] * s->dt; L.rew_to_scale_dt[t] = cfg->turn_over ? cfg->turn_over_scales[t] * s->dt : 0.f;
+    L.rew_on[t] = (L.rew_scale_dt[t] != 0.f || L.rew_to_scale_dt[t] != 0.f) ? 1 : 0;
+  }
+  L.turn_over = cfg->turn_over; L.to_roll_thr = cfg->turn_over_roll_threshold;
+  for (int k = 0; k < 3; ++k) L.to_prop[k] = cfg->turn_over_proportions[k];
+  for (int k = 0; k < 2; ++k) { L.to_zero_time[k] = cfg->turn_over_zero_time[k]; L.to_height[k][0] = cfg->turn_over_init_heights[k][0]; L.to_height[k][1] = cfg->turn_over_init_heights[k][1]; }
   L.rew_curr_count = cfg->reward_curriculum_count; memcpy(L.rew_curr_term, cfg->reward_curriculum_term, sizeof(L.rew_curr_term)); memcpy(L.rew_curr, cfg->reward_curriculum, sizeof(L.rew_curr));
   L.cmd_curr_count = cfg->cmd_curriculum_count; memcpy(L.cmd_curr, cfg->cmd_curriculum, sizeof(L.cmd_curr));
   L.zero_curr_enabled = cfg->zero_cmd_curriculum_enabled; memcpy(L.zero_curr, cfg->zero_cmd_curriculum, sizeof(L.zero_curr)); L.num_steps_per_env = cfg->num_steps_per_env;

@@ -113,8 +113,15 @@ class LeggedRobot(BaseTask):
         init = cfg.init_state.pos + cfg.init_state.rot + cfg.init_state.lin_vel + cfg.init_state.ang_vel      # :1000
         for i in range(13):
             c.base_init_state[i] = init[i]
-        if getattr(cfg.init_state, "turn_over", False):
-            raise NotImplementedError("init_state.turn_over (off in every registered task) is scope row f4")
+        ist = cfg.init_state                                                                                   # turn_over (:642-684)
+        c.turn_over = int(bool(getattr(ist, "turn_over", False)))
+        if c.turn_over:
+            for k in range(3):
+                c.turn_over_proportions[k] = ist.turn_over_proportions[k]
+            for k, key in enumerate(("backflip", "sideflip")):
+                c.turn_over_init_heights[k][0], c.turn_over_init_heights[k][1] = ist.turn_over_init_heights[key]
+                c.turn_over_zero_time[k] = cfg.commands.turn_over_zero_time[key]
+            c.turn_over_roll_threshold = cfg.rewards.turn_over_roll_threshold
         d = cfg.domain_rand
         for flag, rng, src in (("randomize_friction", "friction_range", d.friction_range), ("randomize_restitution", "restitution_range", d.restitution_range),
                                ("randomize_base_mass", "added_mass_range", d.added_mass_range), ("randomize_link_mass", "link_mass_range", d.multiplied_link_mass_range),
@@ -163,6 +170,15 @@ class LeggedRobot(BaseTask):
             if k not in names:
                 raise ValueError("reward %r has no kernel implementation" % key)
             c.reward_scales[names.index(k)] = val
+        self.reward_turn_over_scales = class_to_dict(rw.turn_over_scales) if c.turn_over else {}                   # :1097, :922-930
+        for i in range(len(names)):
+            c.turn_over_scales[i] = 0.0
+        for key, val in self.reward_turn_over_scales.items():
+            k = _REWARD_KEY_ALIASES.get(key, key)
+            if val != 0:
+                if k not in names:
+                    raise ValueError("turn-over reward %r has no kernel implementation" % key)
+                c.turn_over_scales[names.index(k)] = val
         c.only_positive_rewards, c.tracking_sigma = int(rw.only_positive_rewards), rw.tracking_sigma
         ds = rw.dynamic_sigma
         c.dynamic_sigma_enabled = int(ds is not None)
@@ -222,7 +238,7 @@ class LeggedRobot(BaseTask):
                          ("last_dof_vel", "last_dof_vel"), ("last_root_vel", "last_root_vel"), ("commands", "commands"),
                          ("commands_resampling_step", "commands_resampling_step"), ("commands_xy_accumulation", "commands_xy_accumulation"),
                          ("base_lin_vel", "base_lin_vel"), ("base_ang_vel", "base_ang_vel"), ("projected_gravity", "projected_gravity"), ("rpy", "rpy"),
-                         ("measured_heights", "measured_heights"), ("max_move_distance", "max_move_distance"), ("feet_air_time", "feet_air_time"),
+                         ("measured_heights", "measured_heights"), ("max_move_distance", "max_move_distance"), ("turn_over_timer", "turn_over_timer"), ("feet_air_time", "feet_air_time"),
                          ("motor_strengths", "motor_strengths"), ("motor_zero_offsets", "motor_zero_offsets"), ("p_gains_multiplier", "p_gains_multiplier"),
                          ("d_gains_multiplier", "d_gains_multiplier"), ("env_origins", "env_origins"), ("terrain_levels", "terrain_levels"),
                          ("terrain_types", "terrain_types"), ("friction_coeffs", "friction_coeffs")):
@@ -230,7 +246,7 @@ class LeggedRobot(BaseTask):
         self.stop_heading, self.last_is_limit_vel = b["stop_heading"].view(torch.bool), b["last_is_limit_vel"].view(torch.bool)
         self.last_contacts = b["last_contacts"].view(torch.bool)
         names = self.abi.reward_names
-        active = [i for i in range(len(names)) if self._c.reward_scales[i] != 0]
+        active = [i for i in range(len(names)) if self._c.reward_scales[i] != 0 or (self._c.turn_over and self._c.turn_over_scales[i] != 0)]
         self.reward_names = [names[i] for i in active if names[i] != "termination"]
         self.episode_sums = {names[i]: b["episode_sums"][i] for i in active}
         self.reward_scales = {names[i]: self._c.reward_scales[i] * self.dt for i in active}

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GO2SIM_ABI_VERSION 1
+#define GO2SIM_ABI_VERSION 2
 
 #define GO2SIM_EINVAL   (-1)  /* bad argument / config */
 #define GO2SIM_ENOMEM   (-2)
@@ -97,7 +97,8 @@ enum {
   GO2_U_RSB = 78,             /* resample inside reset_idx (:227): same 7 slots as RSA */
   GO2_U_PUSH = 85,            /* :718-719 (2 + 3) */
   GO2_U_NOISE = 90,           /* go2_env.py:53 (45) */
-  GO2_NUM_UNIFORMS = 136      /* padded to a multiple of 4 */
+  GO2_U_TURN = 135,           /* init_state.turn_over (:654,661,672,674): category, backflip height, sideflip height, side sign */
+  GO2_NUM_UNIFORMS = 140      /* padded to a multiple of 4 */
 };
 
 typedef struct Go2SimCfg {
@@ -190,6 +191,16 @@ typedef struct Go2SimCfg {
   float    base_height_target;      /* 0.38 */
   float    max_contact_force;       /* 147 */
   float    min_legs_distance;       /* 0.1 */
+  /* init_state.turn_over (legged_robot_config.py:97-102, commands.turn_over_zero_time :66-69, rewards.turn_over_* :193-212):
+   * resets start a share of the robots on their back / side; while |roll| > threshold the turn_over_scales replace
+   * reward_scales (legged_robot.py:257-265); base-contact termination is off (:174); commands stay zero for zero_time after
+   * such a reset (:586-590) */
+  int32_t  turn_over;
+  float    turn_over_proportions[3];        /* backflip, sideflip, no flip */
+  float    turn_over_init_heights[2][2];    /* [backflip|sideflip][lo|hi] */
+  float    turn_over_zero_time[2];          /* [backflip|sideflip] seconds */
+  float    turn_over_roll_threshold;        /* pi/4 */
+  float    turn_over_scales[GO2_NUM_REWARDS];
   int32_t  reward_curriculum_count; /* curriculum_rewards entries (go2_config.py:161-166) */
   int32_t  reward_curriculum_term[4]; /* GO2_REW_* index */
   float    reward_curriculum[4][4]; /* start_iter,end_iter,start_value,end_value */
@@ -237,6 +248,7 @@ typedef struct Go2SimBuffers {
   float*   rpy;                /* [N,3] */
   float*   measured_heights;   /* [N,187] */
   float*   max_move_distance;  /* [N] */
+  float*   turn_over_timer;    /* [N] */
   float*   feet_air_time;      /* [N,4] */
   uint8_t* last_contacts;      /* [N,4] */
   uint8_t* last_contacts2;     /* [N,4] */

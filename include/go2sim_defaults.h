@@ -126,6 +126,14 @@ static inline void go2sim_fill_default_cfg(Go2SimCfg* c) {
   c->base_height_target = 0.38f;                 /* :158 */
   c->max_contact_force = 147.f;                  /* :160 */
   c->min_legs_distance = 0.1f;                   /* :177 */
+  c->turn_over = 0;                                /* go2_config.py:23 */
+  c->turn_over_proportions[0] = 0.0f; c->turn_over_proportions[1] = 0.2f; c->turn_over_proportions[2] = 0.8f;     /* :25 */
+  c->turn_over_init_heights[0][0] = 0.10f; c->turn_over_init_heights[0][1] = 0.15f;                                /* :26-29 */
+  c->turn_over_init_heights[1][0] = 0.16f; c->turn_over_init_heights[1][1] = 0.21f;
+  c->turn_over_zero_time[0] = 5.0f; c->turn_over_zero_time[1] = 3.0f;                                              /* :125-128 */
+  c->turn_over_roll_threshold = 0.78539816339744830962f;                                                           /* :199 */
+  for (int i = 0; i < GO2_NUM_REWARDS; ++i) c->turn_over_scales[i] = 0.0f;
+  c->turn_over_scales[GO2_REW_UPRIGHT] = 1.0f;                                                                     /* :200-201 */
   c->reward_curriculum_count = 2;                /* :161-166 */
   c->reward_curriculum_term[0] = GO2_REW_LIN_VEL_Z;
   c->reward_curriculum[0][0] = 0.f; c->reward_curriculum[0][1] = 1500.f; c->reward_curriculum[0][2] = 1.f; c->reward_curriculum[0][3] = 0.f;

@@ -11,7 +11,8 @@
  *   group 22, 23   RSB                            group 24, 25   PUSH(5)
  *   group 26,27,28 NOISE ang_vel(3) | gravity(3) | commands(3)
  *   group 29+l, 33+l, 37+l   NOISE dof_pos / dof_vel / actions of leg l (3 each)
- *   group 41       padding slot
+ *   group 41       TURN category, backflip height, sideflip height, side sign (init_state.turn_over)
+ *   group 42       padding slot
  */
 #ifndef GO2SIM_RNG_H
 #define GO2SIM_RNG_H
@@ -20,7 +21,8 @@
 
 static inline void go2_fill_slot_codes(uint8_t* code /*[GO2_NUM_UNIFORMS]*/) {
   int s, k, d;
-  for (s = 0; s < GO2_NUM_UNIFORMS; ++s) code[s] = (uint8_t)(41 * 4);
+  for (s = 0; s < GO2_NUM_UNIFORMS; ++s) code[s] = (uint8_t)(42 * 4);
+  for (s = 0; s < 4; ++s) code[GO2_U_TURN + s] = (uint8_t)(41 * 4 + s);
   code[GO2_U_DELAY] = 0;
   for (s = 0; s < 4; ++s) { code[GO2_U_RSA + s] = (uint8_t)(1 * 4 + s); code[GO2_U_RSB + s] = (uint8_t)(22 * 4 + s); }
   for (s = 0; s < 3; ++s) { code[GO2_U_RSA + 4 + s] = (uint8_t)(2 * 4 + s); code[GO2_U_RSB + 4 + s] = (uint8_t)(23 * 4 + s); }

@@ -31,7 +31,7 @@ DOF_VELOCITY = [30.1, 30.1, 20.07] * 4
 
 # slot layout: keep in sync with include/go2sim.h
 U = dict(DELAY=0, RSA=1, RESET_STRENGTH=8, RESET_OFFSET=20, RESET_KP=32, RESET_KD=44, RESET_TERRAIN=56, RESET_DOF=57,
-         RESET_YAW=69, RESET_XY=70, RESET_VEL=72, RSB=78, PUSH=85, NOISE=90, NUM=136)
+         RESET_YAW=69, RESET_XY=70, RESET_VEL=72, RSB=78, PUSH=85, NOISE=90, TURN=135, NUM=140)
 
 
 class _Inject:
@@ -91,6 +91,11 @@ def _lookup(shape_hint=None):
         if line == 206: return U["RESET_KD"], 12, loc["env_ids"]
         if line == 628: return U["RESET_DOF"], 12, loc["env_ids"]
         if line == 645: return U["RESET_YAW"], 1, loc["env_ids"]
+        # init_state.turn_over branch of _reset_root_states (:654-674): category, backflip height, sideflip height, side sign
+        if line == 654: return U["TURN"], 1, loc["env_ids"]
+        if line == 661: return U["TURN"] + 1, 1, loc["env_ids"][loc["back_mask"]]
+        if line == 672: return U["TURN"] + 2, 1, loc["env_ids"][loc["side_ids"]]
+        if line == 674: return U["TURN"] + 3, 1, loc["env_ids"][loc["side_ids"]]
         if line == 698: return U["RESET_XY"], 2, loc["env_ids"]
         if line == 703: return U["RESET_VEL"], 6, loc["env_ids"]
         if line == 718: return U["PUSH"], 2, None

@@ -46,10 +46,14 @@ NU = ABI.GO2_NUM_UNIFORMS
 TERRAIN_SEED = 11
 
 
-def make_env(N, seed=1, mesh_type="plane"):
+def make_env(N, seed=1, mesh_type="plane", turn_over=False):
     env_cfg, train_cfg = task_registry.get_cfgs("go2")
     env_cfg.env.num_envs = N
     env_cfg.terrain.mesh_type = mesh_type
+    env_cfg.init_state.turn_over = turn_over
+    if turn_over:
+        env_cfg.init_state.turn_over_proportions = [0.25, 0.35, 0.4]      # every branch of :654-684 gets exercised
+        env_cfg.rewards.turn_over_scales.dof_power = -2e-5                  # a term present in both scale tables, besides `upright`
     torch.manual_seed(seed)
     np.random.seed(TERRAIN_SEED if mesh_type != "plane" else seed)
     fig.GYM.alloc(N)
@@ -57,12 +61,15 @@ def make_env(N, seed=1, mesh_type="plane"):
     return env, env_cfg, train_cfg
 
 
-def synth_state(rng, N, env):
+def synth_state(rng, N, env, wide_roll=False):
     """One synthetic simulator state (the 'fake physics')."""
     root = np.zeros((N, 13), np.float32)
     root[:, 0:2] = env.env_origins[:, :2].numpy() + rng.uniform(-3, 3, (N, 2))
     root[:, 2] = env.env_origins[:, 2].numpy() + rng.uniform(0.2, 0.45, N)
     yaw = rng.uniform(-np.pi, np.pi, N); roll = rng.normal(0, 0.15, N); pitch = rng.normal(0, 0.15, N)
+    if wide_roll:   # robots lying on their side / back: |roll| > turn_over_roll_threshold for about a third of the envs
+        lying = rng.uniform(size=N) < 0.35
+        roll = np.where(lying, rng.uniform(-np.pi, np.pi, N), roll)
     q = fig.quat_from_euler_xyz(torch.tensor(roll), torch.tensor(pitch), torch.tensor(yaw)).numpy()
     root[:, 3:7] = q
     root[:, 7:10] = rng.uniform(-1.2, 1.2, (N, 3))
@@ -95,9 +102,9 @@ def synth_state(rng, N, env):
     return root, dof, contact.astype(np.float32), feet_state
 
 
-def gen_env_sequence(N=16, T=64, seed=7, mesh_type="plane"):
+def gen_env_sequence(N=16, T=64, seed=7, mesh_type="plane", turn_over=False):
     rng = np.random.default_rng(seed)
-    env, env_cfg, train_cfg = make_env(N, mesh_type=mesh_type)
+    env, env_cfg, train_cfg = make_env(N, mesh_type=mesh_type, turn_over=turn_over)
     hf = mesh_type != "plane"
     fig.patch_torch()
     names_active = list(env.episode_sums.keys())
@@ -112,7 +119,7 @@ def gen_env_sequence(N=16, T=64, seed=7, mesh_type="plane"):
                            "time_out", "commands", "cmd_timer", "cmd_xy_acc", "last_is_limit_vel", "ep_len", "episode_sums",
                            "root_out", "dof_out", "last_actions", "last_last_actions", "last_dof_vel", "base_lin_vel", "base_ang_vel",
                            "projected_gravity", "rpy", "motor_strengths", "motor_zero_offsets", "p_gains_multiplier", "d_gains_multiplier",
-                           "max_move_distance", "episode_info", "episode_info_valid", "ep_len_in", "cmd_timer_in", "max_move_in", "terrain_levels", "env_origins_out", "measured_heights")}
+                           "max_move_distance", "episode_info", "episode_info_valid", "ep_len_in", "cmd_timer_in", "max_move_in", "terrain_levels", "env_origins_out", "measured_heights", "turn_over_timer")}
 
     def snapshot(t_extras_rebuilt):
         rec["obs"].append(env.obs_buf.numpy().copy()); rec["priv"].append(env.privileged_obs_buf.numpy().copy())
@@ -133,6 +140,7 @@ def gen_env_sequence(N=16, T=64, seed=7, mesh_type="plane"):
             rec[k].append(getattr(env, k).numpy().copy())
         rec["terrain_levels"].append(env.terrain_levels.numpy().copy() if hf else np.zeros(N, np.int64))
         rec["env_origins_out"].append(env.env_origins.numpy().copy())
+        rec["turn_over_timer"].append(env.turn_over_timer.numpy().copy())
         mh = env.measured_heights
         rec["measured_heights"].append(mh.numpy().copy() if torch.is_tensor(mh) else np.zeros((N, 187), np.float32))
         info = np.zeros(ABI.GO2_NUM_REWARDS, np.float32)
@@ -162,6 +170,8 @@ def gen_env_sequence(N=16, T=64, seed=7, mesh_type="plane"):
             # what OnPolicyRunner.learn(init_at_random_ep_len=True) does (on_policy_runner.py:117-118); a few envs close to time-out
             el = rng.integers(0, 1250, N)
             el[: N // 4] = rng.integers(1225, 1251, N // 4)
+            if turn_over:   # time-outs are the only resets in this mode (:174): bring half of the envs close to one
+                el[: N // 2] = rng.integers(1215, 1251, N // 2)
             env.episode_length_buf = torch.from_numpy(el.astype(np.int64))
             # stagger the command timers so the post-physics callback resamples during the sequence (:409-410)
             env.commands_resampling_step[:] = torch.from_numpy(rng.integers(1, 60, N).astype(np.float32))
@@ -171,7 +181,7 @@ def gen_env_sequence(N=16, T=64, seed=7, mesh_type="plane"):
         rec["cmd_timer_in"].append(env.commands_resampling_step.numpy().copy())
         rec["max_move_in"].append(env.max_move_distance.numpy().copy())
         U = new_table()
-        root, dof, contact, feet_state = synth_state(rng, N, env)
+        root, dof, contact, feet_state = synth_state(rng, N, env, wide_roll=turn_over)
         actions = rng.normal(0, 1.0, (N, 12)).astype(np.float32)
         actions[rng.uniform(size=(N, 12)) < 0.01] *= 300.0      # exercise clip_actions
         if t == 0:
@@ -216,8 +226,13 @@ def gen_env_sequence(N=16, T=64, seed=7, mesh_type="plane"):
     out["noise_scale_vec"] = env.noise_scale_vec.numpy().copy()
     scales = np.zeros(ABI.GO2_NUM_REWARDS, np.float32)
     for n, i in rew_index.items():
-        scales[i] = env.reward_scales[n]
+        scales[i] = env.reward_scales.get(n, 0.0)
     out["reward_scales_dt"] = scales
+    if turn_over:
+        ts = np.zeros(ABI.GO2_NUM_REWARDS, np.float32)
+        for n, i in rew_index.items():
+            ts[i] = env.reward_turn_over_scales.get(n, 0.0)
+        out["turn_over_scales_dt"] = ts
     out["height_points"] = env.height_points[0].numpy().copy()
     out["base_height_scan_mask"] = env.base_height_scan_mask.numpy().copy()
     out["limit_vel_comb"] = env.limit_vel_comb.numpy().astype(np.float32)
@@ -229,7 +244,11 @@ def gen_env_sequence(N=16, T=64, seed=7, mesh_type="plane"):
         lv = np.stack(rec["terrain_levels"])
         counters["level_changes"] = int((np.diff(np.concatenate([rec_levels0[None], lv]), axis=0) != 0).sum())
         counters["nonzero_heights"] = float((np.abs(np.stack(rec["measured_heights"])) > 0).mean())
-    print("env sequence (%s): N=%d T=%d events:" % (mesh_type, N, T), counters, "active rewards:", sorted(names_active))
+    if turn_over:
+        tt = np.stack(rec["turn_over_timer"])
+        counters["timer_running"] = int((tt > 0).sum()); counters["rolled"] = int((np.abs(np.stack(rec["rpy"])[..., 0]) > np.pi / 4).sum())
+        out["turn_over"] = np.int64(1)
+    print("env sequence (%s%s): N=%d T=%d events:" % (mesh_type, ", turn_over" if turn_over else "", N, T), counters, "active rewards:", sorted(names_active))
     return out
 
 
@@ -492,6 +511,7 @@ def main():
     _save(files, "go2_plane_sequence.npz", seq)
     hfseq = gen_env_sequence(N=12, T=40, seed=9, mesh_type="heightfield")
     _save(files, "go2_heightfield_sequence.npz", hfseq)
+    _save(files, "go2_turn_over_sequence.npz", gen_env_sequence(N=12, T=40, seed=13, turn_over=True))
     _save(files, "terrain.npz", gen_terrain())
     _save(files, "gae.npz", gen_gae())
     _save(files, "ppo_update.npz", gen_ppo())

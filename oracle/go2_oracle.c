@@ -226,6 +226,7 @@ struct Go2Sim {
   R dt;                    /* policy dt = decimation * sim_dt (legged_robot.py:1094) */
   R max_episode_length;    /* ceil(episode_length_s / dt) (:1104) */
   R reward_scale_dt[GO2_NUM_REWARDS];  /* scale * dt (:914-920) */
+  R turn_over_scale_dt[GO2_NUM_REWARDS]; /* turn_over_scales * dt (:922-923) */
   R reward_curr_scale[GO2_NUM_REWARDS];/* reward_curriculum_scales (:52-57), 1 if none */
   int reward_has_curr[GO2_NUM_REWARDS];
   R cmd_ranges[4][2]; R max_lin_vel; R zero_command_proba;
@@ -673,6 +674,7 @@ static void resample_commands(Go2Sim* s, int e, int U) {
     }
     minp += s->zero_command_proba;
   }
+  if (c->turn_over && b->turn_over_timer[e] > 0) { cmd[0]=0; cmd[1]=0; cmd[2]=0; b->stop_heading[e]=1; } /* :586-590 */
   b->commands_xy_accumulation[2*e] += cmd[0]; b->commands_xy_accumulation[2*e+1] += cmd[1];
 }
 
@@ -721,7 +723,7 @@ static void compute_reward(Go2Sim* s, int e) {
   float* lla = b->last_last_actions+12*e; const float* ldv = b->last_dof_vel+12*e;
   static const int feet[4] = {6,10,14,18}; static const int pen[8] = {4,5,8,9,12,13,16,17};
   R raw[GO2_NUM_REWARDS]; memset(raw,0,sizeof(raw));
-#define ACTIVE(t) (s->reward_scale_dt[t] != 0)
+#define ACTIVE(t) (s->reward_scale_dt[t] != 0 || s->turn_over_scale_dt[t] != 0)   /* names = union of both scale tables (:927-930) */
   if (ACTIVE(GO2_REW_TRACKING_LIN_VEL)) { /* :1322 */
     R sx = (R)c->tracking_sigma, sy = sx;
     if (c->dynamic_sigma_enabled) { sx = dynamic_sigma(s,e,FABS((R)cmd[0]),(R)c->dynamic_sigma_vel[0],(R)c->dynamic_sigma_vel[1]); sy = dynamic_sigma(s,e,FABS((R)cmd[1]),(R)c->dynamic_sigma_vel[0],(R)c->dynamic_sigma_vel[1]); }
@@ -772,8 +774,9 @@ static void compute_reward(Go2Sim* s, int e) {
     R ratio = FABS((R)cmd[0])/SQRT((R)cmd[0]*cmd[0]+(R)cmd[1]*cmd[1]+(R)cmd[2]*cmd[2]);
     raw[GO2_REW_X_COMMAND_HIP_REGULAR] = (FABS((R)ds[0]+(R)ds[6]) + FABS((R)ds[12]+(R)ds[18]))*ratio; }
   R total = 0;
+  const int need_turn_over = c->turn_over && FABS((R)b->rpy[3*e]) > (R)c->turn_over_roll_threshold;   /* :263-265 */
   for (int t=0;t<GO2_REW_TERMINATION;++t) if (ACTIVE(t)) {
-    R r = raw[t]*s->reward_scale_dt[t]; if (s->reward_has_curr[t]) r *= s->reward_curr_scale[t];
+    R r = raw[t]*(need_turn_over ? s->turn_over_scale_dt[t] : s->reward_scale_dt[t]); if (s->reward_has_curr[t]) r *= s->reward_curr_scale[t];
     total += r; b->episode_sums[(size_t)t*s->N+e] += (float)r;
   }
   if (c->only_positive_rewards && total < 0) total = 0;
@@ -811,7 +814,17 @@ static void reset_env(Go2Sim* s, int e, int initial) {
   float* root = b->root_states+13*e;
   R yaw = urange(uni(s,e,GO2_U_RESET_YAW), -(R)M_PI, (R)M_PI);
   for (int i=0;i<13;++i) root[i] = c->base_init_state[i];
-  root[3]=0; root[4]=0; root[5]=(float)SIN(yaw/2); root[6]=(float)COS(yaw/2); /* quat_from_euler_xyz(0,0,yaw) */
+  R roll = 0;
+  if (c->turn_over) { /* :642-684: a share of the resets starts on the back (roll pi) or on a side (roll +-pi/2) */
+    b->turn_over_timer[e] = 0;
+    R pr = uni(s,e,GO2_U_TURN), p0 = (R)c->turn_over_proportions[0], p1 = p0 + (R)c->turn_over_proportions[1];
+    if (pr >= 0 && pr < p0) { root[2] = (float)urange(uni(s,e,GO2_U_TURN+1),(R)c->turn_over_init_heights[0][0],(R)c->turn_over_init_heights[0][1]); roll = (R)M_PI; b->turn_over_timer[e] = c->turn_over_zero_time[0]; }
+    else if (pr >= p0 && pr < p1) { root[2] = (float)urange(uni(s,e,GO2_U_TURN+2),(R)c->turn_over_init_heights[1][0],(R)c->turn_over_init_heights[1][1]);
+      roll = uni(s,e,GO2_U_TURN+3) < RC(0.5) ? (R)M_PI/2 : -(R)M_PI/2; b->turn_over_timer[e] = c->turn_over_zero_time[1]; }
+  }
+  { /* quat_from_euler_xyz(roll, 0, yaw) (isaacgym torch_utils) */
+    R cy=COS(yaw/2), sy=SIN(yaw/2), cr=COS(roll/2), sr=SIN(roll/2);
+    root[3]=(float)(cy*sr); root[4]=(float)(sy*sr); root[5]=(float)(sy*cr); root[6]=(float)(cy*cr); }
   for (int i=0;i<3;++i) root[i] += b->env_origins[3*e+i];
   if (c->terrain_mode != 0) { root[0] += (float)urange(uni(s,e,GO2_U_RESET_XY),-1,1); root[1] += (float)urange(uni(s,e,GO2_U_RESET_XY+1),-1,1); }
   for (int i=0;i<6;++i) root[7+i] = (float)urange(uni(s,e,GO2_U_RESET_VEL+i),RC(-0.5),RC(0.5));
@@ -850,6 +863,7 @@ static void post_physics_env(Go2Sim* s, int e) {
   const Go2SimCfg* c = &s->cfg; Go2SimBuffers* b = &s->b;
   float* root = b->root_states+13*e;
   b->episode_length_buf[e] += 1; b->commands_resampling_step[e] -= 1;
+  if (c->turn_over) { R tt = (R)b->turn_over_timer[e] - s->dt; b->turn_over_timer[e] = (float)(tt < 0 ? 0 : tt); }   /* :114-115 */
   R q[4]={(R)root[3],(R)root[4],(R)root[5],(R)root[6]};
   { /* get_euler_xyz (utils/isaacgym_utils.py:11-30) */
     R sr = 2*(q[3]*q[0]+q[1]*q[2]), cr = q[3]*q[3]-q[0]*q[0]-q[1]*q[1]+q[2]*q[2];
@@ -871,7 +885,7 @@ static void post_physics_env(Go2Sim* s, int e) {
     R lo,hi; env_cmd_range(s,e,2,&lo,&hi); R y=RC(0.5)*a; if (y<lo) y=lo; if (y>hi) y=hi; b->commands[4*e+2]=(float)y; }
   if (c->measure_heights) get_heights(s, e);
   /* check_termination (:170-178): termination body = base (index 0) */
-  { const float* F=b->contact_forces+(size_t)e*NB*3; int r = SQRT((R)F[0]*F[0]+(R)F[1]*F[1]+(R)F[2]*F[2]) > 1;
+  { const float* F=b->contact_forces+(size_t)e*NB*3; int r = !c->turn_over && SQRT((R)F[0]*F[0]+(R)F[1]*F[1]+(R)F[2]*F[2]) > 1;   /* :174 */
     int to = (R)b->episode_length_buf[e] > s->max_episode_length; b->time_out_buf[e]=(uint8_t)to; b->reset_buf[e]=(uint8_t)(r||to); }
   compute_reward(s, e);
   if (b->reset_buf[e]) reset_env(s, e, 0);
@@ -926,11 +940,12 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
   ALLOC(motor_strengths,float,N*12); ALLOC(motor_zero_offsets,float,N*12); ALLOC(p_gains_multiplier,float,N*12); ALLOC(d_gains_multiplier,float,N*12);
   ALLOC(env_origins,float,N*3); ALLOC(terrain_levels,int64_t,N); ALLOC(terrain_types,int64_t,N); ALLOC(episode_sums,float,GO2_NUM_REWARDS*N);
   ALLOC(friction_coeffs,float,N); ALLOC(restitution_coeffs,float,N); ALLOC(added_base_mass,float,N); ALLOC(added_base_com,float,N*3); ALLOC(link_mass_ratio,float,N*18);
-  ALLOC(episode_info,float,GO2_NUM_REWARDS+1); ALLOC(foot_impulse,float,N*12);
+  ALLOC(turn_over_timer,float,N); ALLOC(episode_info,float,GO2_NUM_REWARDS+1); ALLOC(foot_impulse,float,N*12);
   s->terrain_kind = (int32_t*)malloc(sizeof(int32_t)*N); s->inj_storage = (float*)malloc(sizeof(float)*(size_t)N*GO2_NUM_UNIFORMS);
   s->dt = (R)cfg->decimation*(R)cfg->sim_dt;
   s->max_episode_length = (R)ceil((double)cfg->episode_length_s/(double)s->dt - 1e-3); /* np.ceil(25/0.02) = 1250 (:1104); the slack absorbs fp32 dt */
-  for (int t=0;t<GO2_NUM_REWARDS;++t) { s->reward_scale_dt[t] = (R)cfg->reward_scales[t]*s->dt; s->reward_curr_scale[t]=1; }
+  for (int t=0;t<GO2_NUM_REWARDS;++t) { s->reward_scale_dt[t] = (R)cfg->reward_scales[t]*s->dt; s->reward_curr_scale[t]=1;
+    s->turn_over_scale_dt[t] = cfg->turn_over ? (R)cfg->turn_over_scales[t]*s->dt : 0; }
   for (int i=0;i<cfg->reward_curriculum_count;++i) { int t=cfg->reward_curriculum_term[i]; s->reward_has_curr[t]=1; s->reward_curr_scale[t]=(R)cfg->reward_curriculum[i][2]; }
   for (int r=0;r<4;++r) { s->cmd_ranges[r][0]=(R)cfg->cmd_ranges[r][0]; s->cmd_ranges[r][1]=(R)cfg->cmd_ranges[r][1]; }
   for (int j=0;j<12;++j) { /* soft limits (:372-375), computed in fp32 like the reference's torch tensors */

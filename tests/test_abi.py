@@ -14,7 +14,7 @@ from go2_rl_gym_amd import _abi, build
 def test_header_parses_and_lists_every_function():
     abi = _abi.Abi()
     assert sorted(set(abi.exported)) == sorted(_abi._REQUIRED)
-    assert C.sizeof(abi.Cfg) > 1000 and abi.GO2_NUM_UNIFORMS == 136 and abi.GO2_NUM_REWARDS == 28
+    assert C.sizeof(abi.Cfg) > 1000 and abi.GO2_NUM_UNIFORMS == 140 and abi.GO2_NUM_REWARDS == 28
     assert abi.reward_names[abi.GO2_REW_HIP_TO_DEFAULT] == "hip_to_default"
 
 

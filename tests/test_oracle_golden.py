@@ -14,7 +14,7 @@ G = os.path.join(ROOT, "tests", "golden")
 FEET = [6, 10, 14, 18]
 
 
-@pytest.fixture(scope="module", params=["plane", "heightfield"])
+@pytest.fixture(scope="module", params=["plane", "heightfield", "turn_over"])
 def seq(request):
     return dict(np.load(os.path.join(G, "go2_%s_sequence.npz" % request.param)))
 
@@ -27,6 +27,11 @@ def _mk(lib, g, sim=HostSim, **kw):
         t, ov = heightfield_overrides(N, seed=int(g["terrain_seed"]))
         assert hashlib.sha256(np.ascontiguousarray(t.height_field_raw).tobytes()).digest() == g["hf_sha256"].tobytes()
         kw.update(ov)
+    if "turn_over" in g:      # init_state.turn_over with the proportions / scales the generator used (oracle/gen_golden.py make_env)
+        ts = np.zeros(len(g["turn_over_scales_dt"]), np.float32)
+        nz = g["turn_over_scales_dt"] != 0
+        ts[nz] = g["turn_over_scales_dt"][nz] / np.float32(0.02)
+        kw.update(turn_over=1, turn_over_proportions=np.array([0.25, 0.35, 0.4], np.float32), turn_over_scales=ts)
     s = sim(lib, num_envs=N, **kw)
     if "hf_sha256" in g:
         np.testing.assert_array_equal(np.asarray(s.terrain_levels), g["terrain_levels0"])      # round robin (:1071-1079)
@@ -45,6 +50,8 @@ def test_static_tables(seq):
     cfg_scales = np.array(list(s.cfg.reward_scales), np.float32) * np.float32(0.02)
     np.testing.assert_allclose(cfg_scales, seq["reward_scales_dt"], rtol=1e-6)
     assert int((seq["reward_scales_dt"] != 0).sum()) == 14
+    if "turn_over" in seq:
+        np.testing.assert_allclose(np.array(list(s.cfg.turn_over_scales), np.float32) * np.float32(0.02), seq["turn_over_scales_dt"], rtol=1e-6)
     comb = np.array([list(r) for r in s.cfg.limit_vel_comb], np.float32)[: s.cfg.limit_vel_comb_count]
     np.testing.assert_array_equal(comb, seq["limit_vel_comb"])
     s.close()
@@ -131,6 +138,8 @@ def compare_step(s, g, t):
     np.testing.assert_allclose(s.root_states[pushed, 7:], g["root_out"][t][pushed, 7:], atol=1e-6)
     np.testing.assert_allclose(s.root_states[:, 9], g["root_out"][t][:, 9], atol=1e-6)
     np.testing.assert_allclose(s.env_origins, g["env_origins_out"][t], atol=1e-6)
+    if "turn_over" in g:
+        np.testing.assert_allclose(s.turn_over_timer, g["turn_over_timer"][t], atol=1e-5)
     if "hf_sha256" in g:
         np.testing.assert_array_equal(s.terrain_levels, g["terrain_levels"][t])
         np.testing.assert_allclose(s.measured_heights, g["measured_heights"][t], atol=1e-6)
@@ -159,7 +168,7 @@ def test_sequence_matches_reference(seq, which):
         n += 1
     assert n == seq["actions"].shape[0]
     # the sequence exercised every branch we claim to pin
-    assert seq["reset"].sum() >= 20 and seq["time_out"].sum() >= 1
+    assert seq["reset"].sum() >= (6 if "turn_over" in seq else 18) and seq["time_out"].sum() >= 1
     s.close()
 
 

@@ -92,3 +92,27 @@ def test_standing_robot_carries_its_weight():
 
 # The behavioural test with the reference's pretrained policy lives in tests/test_export.py (it runs from committed fixtures,
 # through this build's own loader, on the oracle here and on the HIP kernels on the GPU box).
+
+
+@pytest.mark.parametrize("which", ["oracle", "lane_emulation"])
+def test_flipped_robots_settle(which):
+    """init_state.turn_over: robots dropped on their back / side from 10-21 cm come to rest on the base, head and hip geometry:
+    finite state, small velocities, base stays above the ground and below its drop height; nobody is reset (:174)."""
+    from helpers import load_emu
+    lib = load_oracle() if which == "oracle" else load_emu()
+    N = 24
+    s = HostSim(lib, num_envs=N, turn_over=1, turn_over_proportions=np.array([0.5, 0.5, 0.0], np.float32), push_robots=0, seed=5)
+    s.reset_all()
+    roll0 = np.abs(2 * np.arctan2(np.linalg.norm(np.asarray(s.root_states)[:, 3:5], axis=1), np.abs(np.asarray(s.root_states)[:, 6]) + 1e-9))
+    assert (np.asarray(s.turn_over_timer) > 0).all() and (roll0 > 1.0).all()
+    a = np.zeros((N, 12), np.float32)
+    for _ in range(100):
+        s.step(a)
+        assert not np.asarray(s.reset_buf).any()
+    root = np.asarray(s.root_states)
+    assert np.isfinite(root).all() and np.isfinite(np.asarray(s.obs_buf)).all()
+    assert (root[:, 2] > 0.02).all() and (root[:, 2] < 0.45).all(), np.sort(root[:, 2])
+    assert np.abs(root[:, 7:10]).max() < 2.0
+    assert (np.asarray(s.commands)[:, :3] == 0).all()                       # zero commands while the turn-over timer runs (:586-590)
+    assert (np.asarray(s.turn_over_timer) > 0).all() and (np.asarray(s.turn_over_timer) <= 3.0 + 1e-3).all()     # 5 s (back) or 3 s (side) minus the 2 s simulated
+    s.close()
