@@ -66,3 +66,49 @@ def test_wrap_buffers_square_shapes():
     np.testing.assert_array_equal(t["actions"].numpy(), np.asarray(s.actions))
     assert t["actions"].stride() == (1, 12)
     s.close()
+
+
+@pytest.mark.parametrize("which", ["oracle_f32", "lane_emulation"])
+def test_error_behaviour_and_edge_sizes(which):
+    """Bad arguments are refused with GO2SIM_E* + a message (nothing throws across the ABI); the smallest and a ragged batch
+    (not a multiple of the 16-env workgroup) run; a heightfield without its arrays is refused."""
+    from helpers import HostSim
+    lib = {"oracle_f32": lambda: load_oracle(False), "lane_emulation": load_emu}[which]()
+    abi = lib.abi
+    cfg = abi.Cfg(); lib.go2sim_default_cfg(C.byref(cfg))
+    h = C.c_void_p()
+    cfg.num_envs = 0
+    assert lib.go2sim_create(C.byref(cfg), 0, C.byref(h)) == abi.GO2SIM_EINVAL and not h.value
+    cfg.num_envs = 4; cfg.terrain_mode = 1            # heightfield requested, no samples given
+    assert lib.go2sim_create(C.byref(cfg), 0, C.byref(h)) == abi.GO2SIM_EINVAL and b"heightfield" in lib.go2sim_last_error()
+    assert lib.go2sim_create(None, 0, C.byref(h)) == abi.GO2SIM_EINVAL
+    assert lib.go2sim_step(None, None, None) != 0 and lib.go2sim_get_buffers(None, None) != 0
+    for f, args in (("go2sim_gae", [None] * 7 + [24, 8, 0.99, 0.95, None]), ("go2sim_normalize_advantages", [None, None, 8, None]),
+                    ("go2sim_history_push", [None, None, None, 4, 5, 45, None]), ("go2sim_act_head", [None] * 10 + [4, 12, None]),
+                    ("go2sim_store_transition", [None] * 6 + [0.99, 4, None]), ("go2sim_elu_backward_bias", [None] * 5 + [8, 8, None])):
+        assert getattr(lib, f)(*args) != 0, f
+    for n in (1, 17):
+        s = HostSim(lib, num_envs=n, push_robots=0)
+        s.reset_all()
+        for _ in range(30):
+            s.step(np.zeros((n, 12), np.float32))
+        root = np.asarray(s.root_states)
+        assert root.shape == (n, 13) and np.isfinite(root).all() and np.isfinite(np.asarray(s.obs_buf)).all()
+        assert (root[:, 2] > 0.15).all() and (root[:, 2] < 0.45).all()
+        s.close()
+
+
+def test_ragged_batch_matches_oracle_lane_for_lane():
+    """17 envs = one full 16-env workgroup + 1 env in a second one: the lane programs (host build) against the oracle, env by env."""
+    from helpers import STEP_STATE, HostSim
+    so, se = HostSim(load_oracle(), num_envs=17, seed=9), HostSim(load_emu(), num_envs=17, seed=9)
+    so.reset_all(); se.reset_all()
+    rng = np.random.default_rng(4)
+    for it in range(25):
+        a = rng.normal(0, 1, (17, 12)).astype(np.float32)
+        for k in STEP_STATE:
+            getattr(se, k)[...] = getattr(so, k)
+        so.step(a); se.step(a)
+        d = np.abs(np.asarray(so.obs_buf, np.float64) - np.asarray(se.obs_buf, np.float64)).max(1)
+        assert np.sort(d)[-2] < 2e-4 and d.max() < 2e-2, (it, np.sort(d)[-3:])
+    so.close(); se.close()

@@ -397,3 +397,35 @@ def test_fused_linear_elu_on_gpu(hip):
     np.testing.assert_allclose(res[1][0].cpu().numpy(), res[0][0].cpu().numpy(), atol=1e-5)
     for a, b in zip(res[0][1], res[1][1]):
         np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), atol=2e-6, rtol=2e-3)
+
+
+@pytest.mark.parametrize("N", [1, 17, 4097])
+def test_ragged_batches_on_gpu(hip, N):
+    """Smallest, ragged (one full 16-env workgroup + 1) and just-over-BASELINE batches: the partially filled last workgroup
+    computes the same as the oracle, env by env, and touches nothing outside its N envs."""
+    so = HostSim(load_oracle(), num_envs=N, seed=9)
+    sd = DeviceSim(hip, num_envs=N, seed=9)
+    so.reset_all(); sd.reset_all()
+    rng = np.random.default_rng(4)
+    for it in range(6 if N > 1000 else 20):
+        a = rng.normal(0, 1, (N, 12)).astype(np.float32)
+        for k in STEP_STATE:
+            getattr(sd, k)[...] = np.asarray(getattr(so, k))
+        so.step(a); sd.step(a)
+        d = np.abs(np.asarray(so.obs_buf, np.float64) - np.asarray(sd.obs_buf, np.float64)).max(1)
+        assert np.sort(d)[int(0.98 * (N - 1))] < 2e-4 and d.max() < 5e-2, (it, np.sort(d)[-3:])
+        np.testing.assert_array_equal(np.asarray(so.reset_buf), np.asarray(sd.reset_buf))
+    so.close(); sd.close()
+
+
+def test_error_codes_on_gpu(hip):
+    abi = hip.abi
+    cfg = abi.Cfg(); hip.go2sim_default_cfg(C.byref(cfg))
+    h = C.c_void_p()
+    cfg.num_envs = 0
+    assert hip.go2sim_create(C.byref(cfg), 0, C.byref(h)) == abi.GO2SIM_EINVAL
+    cfg.num_envs = 16; cfg.terrain_mode = 1
+    assert hip.go2sim_create(C.byref(cfg), 0, C.byref(h)) == abi.GO2SIM_EINVAL and b"heightfield" in hip.go2sim_last_error()
+    cfg.terrain_mode = 0; cfg.struct_size += 8
+    assert hip.go2sim_create(C.byref(cfg), 0, C.byref(h)) == abi.GO2SIM_EINVAL and b"mismatch" in hip.go2sim_last_error()
+    assert hip.go2sim_step(None, None, None) != 0 and hip.go2sim_act_head(*([None] * 10), 4, 12, None) != 0
