@@ -103,3 +103,35 @@ def test_world_size_2_matches_single_process():
         np.testing.assert_array_equal(out[r]["shard_ratio"], s.link_mass_ratio[8 * r:8 * r + 8])
         np.testing.assert_array_equal(out[r]["shard_origin"], s.env_origins[8 * r:8 * r + 8])
     s.close()
+
+
+def _runner_worker(rank, world, port, out, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from go2_rl_gym_amd.envs import task_registry
+    from go2_rl_gym_amd.utils import get_args
+    n = 16
+    args = get_args(["--task", "go2_flat", "--num_envs", str(n), "--headless", "--sim_device", "cpu", "--rl_device", "cpu", "--seed", "2"])
+    env, _ = task_registry.make_env("go2_flat", args, lib=load_oracle(), env_offset=rank * n, num_envs_global=world * n)
+    torch.manual_seed(50 + rank)
+    runner, _ = task_registry.make_alg_runner(env, "go2_flat", args, log_root=tmp)
+    runner.learn(2, init_at_random_ep_len=True)
+    out[rank] = {"params": torch.cat([p.detach().reshape(-1) for p in runner.alg.actor_critic.parameters()]).numpy().copy(), "lr": runner.alg.learning_rate,
+                 "log_dir": runner.log_dir, "fps": runner.last_fps, "origin": env.env_origins.numpy().copy()}
+    env.close()
+    dist.destroy_process_group()
+
+
+def test_sharded_runner_world_size_2(tmp_path):
+    """The launch shape bench.py / train.py use on a multi-GPU node, on CPU: one process per shard, env_offset = rank * N, one coherent
+    policy after two full iterations (gradient + KL + advantage-statistics collectives), only rank 0 logs and saves."""
+    world, port = 2, _free_port()
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_runner_worker, args=(world, port, out, str(tmp_path)), nprocs=world, join=True)
+    np.testing.assert_array_equal(out[0]["params"], out[1]["params"])
+    assert out[0]["lr"] == out[1]["lr"] and np.isfinite(out[0]["params"]).all()
+    assert out[0]["log_dir"] is not None and out[1]["log_dir"] is None
+    assert out[0]["fps"] > 0 and not np.array_equal(out[0]["origin"], out[1]["origin"])     # different shards of one global grid
+    runs = [d for d in os.listdir(tmp_path)]
+    assert len(runs) == 1 and any(f.startswith("model_") for f in os.listdir(os.path.join(tmp_path, runs[0])))
