@@ -20,17 +20,11 @@ import torch.optim as optim
 
 from ..storage import RolloutStorageCTS
 from ._graph import CapturedStep
-from .ppo import _ADAM_IMPL, _collectives_on, _FusedPPOLoss, _RolloutHeads, _world
+from .ppo import _ADAM_IMPL, _collectives_on, _FusedPPOLoss, _RolloutHeads, _world, allreduce_mean_bucket
 
 
-def _allreduce_mean_grads(params, world):
-    grads = [p.grad for p in params if p.grad is not None]
-    flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat /= world
-    off = 0
-    for g in grads:
-        n = g.numel(); g.copy_(flat[off:off + n].view_as(g)); off += n
+def _allreduce_mean_grads(params, world, extra=None):
+    return allreduce_mean_bucket([p.grad for p in params if p.grad is not None], world, extra)
 
 
 class CTS(_RolloutHeads):
@@ -216,10 +210,12 @@ class CTS(_RolloutHeads):
         for _ in range(self.num_learning_epochs):
             for b in idx:
                 loss, value_loss, surrogate_loss, ent, kl_mean = self._policy_losses(*self._gather(fl, b), n_t)
-                if self.desired_kl is not None and self.schedule == "adaptive":
-                    if sync:
-                        dist.all_reduce(kl_mean, op=dist.ReduceOp.SUM)
-                        kl_mean /= world
+                adaptive = self.desired_kl is not None and self.schedule == "adaptive"
+                self.optimizer1.zero_grad()
+                loss.backward()
+                if sync:
+                    kl_mean = _allreduce_mean_grads(self._params1, world, kl_mean if adaptive else None)
+                if adaptive:     # decided after backward (the rate is only read by optimizer1.step()) so the KL shares the gradient all-reduce
                     if kl_mean > self.desired_kl * 2.0:
                         self.learning_rate = max(1e-5, self.learning_rate / 1.5)
                     elif kl_mean < self.desired_kl / 2.0 and kl_mean > 0.0:
@@ -229,10 +225,6 @@ class CTS(_RolloutHeads):
                             g["lr"].fill_(self.learning_rate)
                         else:
                             g["lr"] = self.learning_rate
-                self.optimizer1.zero_grad()
-                loss.backward()
-                if sync:
-                    _allreduce_mean_grads(self._params1, world)
                 nn.utils.clip_grad_norm_(self._params1, self.max_grad_norm)
                 self.optimizer1.step()
                 acc[0] += value_loss.item(); acc[1] += surrogate_loss.item(); acc[2] += ent.item()
@@ -257,17 +249,15 @@ class CTS(_RolloutHeads):
     def _policy_step(self, i):
         mb = self._mb
         loss, value_loss, surrogate_loss, ent, kl_mean = self._policy_losses(*(self._perm[k][i * mb:(i + 1) * mb] for k in self._KEYS), self._teacher_rows())
-        if self.desired_kl is not None and self.schedule == "adaptive":
-            if _collectives_on():
-                dist.all_reduce(kl_mean, op=dist.ReduceOp.SUM)
-                kl_mean = kl_mean / _world()
-            lr = self._lr_t
-            up, down = torch.clamp(lr * 1.5, max=1e-2), torch.clamp(lr / 1.5, min=1e-5)
-            lr.copy_(torch.where(kl_mean > self.desired_kl * 2.0, down, torch.where((kl_mean < self.desired_kl / 2.0) & (kl_mean > 0.0), up, lr)))
+        adaptive = self.desired_kl is not None and self.schedule == "adaptive"
         self.optimizer1.zero_grad(set_to_none=True)
         loss.backward()
         if _collectives_on():
-            _allreduce_mean_grads(self._params1, _world())
+            kl_mean = _allreduce_mean_grads(self._params1, _world(), kl_mean if adaptive else None)
+        if adaptive:
+            lr = self._lr_t
+            up, down = torch.clamp(lr * 1.5, max=1e-2), torch.clamp(lr / 1.5, min=1e-5)
+            lr.copy_(torch.where(kl_mean > self.desired_kl * 2.0, down, torch.where((kl_mean < self.desired_kl / 2.0) & (kl_mean > 0.0), up, lr)))
         nn.utils.clip_grad_norm_(self._params1, self.max_grad_norm, foreach=True)
         self.optimizer1.step()
         self._acc[:3].add_(torch.stack([value_loss.detach(), surrogate_loss.detach(), ent.detach()]))

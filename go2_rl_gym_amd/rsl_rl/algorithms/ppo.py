@@ -43,6 +43,17 @@ def _collectives_on():
     return dist.get_world_size() > 1 or os.environ.get("GO2_FORCE_COLLECTIVES", "0") == "1"
 
 
+def allreduce_mean_bucket(grads, world, extra=None):
+    parts = [g.reshape(-1) for g in grads] + ([extra.detach().reshape(1)] if extra is not None else [])
+    flat = torch.cat(parts)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= world
+    off = 0
+    for g in grads:
+        n = g.numel(); g.copy_(flat[off:off + n].view_as(g)); off += n
+    return flat[off] if extra is not None else None
+
+
 class _RolloutHeads:
     """Shared pieces of the PPO-family algorithms: two-stream actor/critic evaluation and the per-step rollout heads."""
     _side = None
@@ -261,14 +272,11 @@ class PPO(_RolloutHeads):
         loss = surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * ent_b.mean()
         return loss, value_loss, surrogate_loss, kl_mean
 
-    def _allreduce_grads(self, world):
-        grads = [p.grad for p in self.actor_critic.parameters() if p.grad is not None]
-        flat = torch.cat([g.reshape(-1) for g in grads])     # one flat bucket: 1.96 MB of fp32 gradients, latency-bound on xGMI
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat /= world
-        off = 0
-        for g in grads:
-            n = g.numel(); g.copy_(flat[off:off + n].view_as(g)); off += n
+    def _allreduce_grads(self, world, kl_mean=None):
+        """Average the gradients — and the mean KL riding in the same bucket — over the shards with ONE all-reduce (1.96 MB of
+        fp32, latency-bound on xGMI): the learning-rate decision only matters at optimizer.step(), so it can wait for the
+        backward pass and share its collective.  -> the shard-averaged KL (or None)."""
+        return allreduce_mean_bucket([p.grad for p in self.actor_critic.parameters() if p.grad is not None], world, kl_mean)
 
     def _update_eager(self):
         mean_value_loss, mean_surrogate_loss = 0.0, 0.0
@@ -276,10 +284,11 @@ class PPO(_RolloutHeads):
         adaptive = self.desired_kl is not None and self.schedule == "adaptive"
         for batch in self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
             loss, value_loss, surrogate_loss, kl_mean = self._losses(*batch[:9])
-            if adaptive:
-                if _collectives_on():
-                    dist.all_reduce(kl_mean, op=dist.ReduceOp.SUM)
-                    kl_mean /= world
+            self.optimizer.zero_grad()
+            loss.backward()
+            if _collectives_on():
+                kl_mean = self._allreduce_grads(world, kl_mean if adaptive else None)
+            if adaptive:        # the reference decides before backward (ppo.py:140-155); the rate is only read by optimizer.step()
                 if kl_mean > self.desired_kl * 2.0:
                     self.learning_rate = max(1e-5, self.learning_rate / 1.5)
                 elif kl_mean < self.desired_kl / 2.0 and kl_mean > 0.0:
@@ -289,10 +298,6 @@ class PPO(_RolloutHeads):
                         g["lr"].fill_(self.learning_rate)
                     else:
                         g["lr"] = self.learning_rate
-            self.optimizer.zero_grad()
-            loss.backward()
-            if _collectives_on():
-                self._allreduce_grads(world)
             nn.utils.clip_grad_norm_(self.actor_critic.parameters(), self.max_grad_norm)
             self.optimizer.step()
             mean_value_loss += value_loss.item()
@@ -309,19 +314,17 @@ class PPO(_RolloutHeads):
         rollout_storage.py:150): 4 chunk gathers per iteration instead of 20 mini-batch gathers."""
         mb = self._mb
         loss, value_loss, surrogate_loss, kl_mean = self._losses(*(self._perm[k][i * mb:(i + 1) * mb] for k in self._KEYS))
-        if self.desired_kl is not None and self.schedule == "adaptive":
-            if _collectives_on():          # RCCL all-reduce captured inside the graph: every rank takes the same LR branch
-                dist.all_reduce(kl_mean, op=dist.ReduceOp.SUM)
-                kl_mean = kl_mean / _world()
+        adaptive = self.desired_kl is not None and self.schedule == "adaptive"
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        if _collectives_on():              # ONE RCCL all-reduce (gradients + KL), captured inside the graph: every rank takes the same LR branch
+            kl_mean = self._allreduce_grads(_world(), kl_mean if adaptive else None)
+        if adaptive:
             lr = self._lr_t
             up = torch.clamp(lr * 1.5, max=1e-2)
             down = torch.clamp(lr / 1.5, min=1e-5)
             new_lr = torch.where(kl_mean > self.desired_kl * 2.0, down, torch.where((kl_mean < self.desired_kl / 2.0) & (kl_mean > 0.0), up, lr))
             lr.copy_(new_lr)
-        self.optimizer.zero_grad(set_to_none=True)
-        loss.backward()
-        if _collectives_on():
-            self._allreduce_grads(_world())
         nn.utils.clip_grad_norm_(self.actor_critic.parameters(), self.max_grad_norm, foreach=True)
         self.optimizer.step()
         self._acc.add_(torch.stack([value_loss.detach(), surrogate_loss.detach()]))
