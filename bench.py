@@ -161,10 +161,20 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(task=a.task)
             except Exception as e:   # never lose the GPU number to a CPU-side problem
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
-        print(json.dumps(out))
+    else:
+        out = None
     env.close()
     if dist.is_initialized():
         dist.destroy_process_group()
+    # RCCL prints its version banner through C stdio, which is flushed at exit when stdout is a pipe: flush it now so that the JSON
+    # line is the LAST line of the output
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if out is not None:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
