@@ -48,9 +48,10 @@ def allreduce_mean_bucket(grads, world, extra=None):
     flat = torch.cat(parts)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     flat /= world
-    off = 0
+    views, off = [], 0
     for g in grads:
-        n = g.numel(); g.copy_(flat[off:off + n].view_as(g)); off += n
+        n = g.numel(); views.append(flat[off:off + n].view_as(g)); off += n
+    torch._foreach_copy_(grads, views)           # one multi-tensor launch instead of one copy per parameter
     return flat[off] if extra is not None else None
 
 
