@@ -140,6 +140,15 @@ def main():
             if pm.get("num_envs") == N and pm.get("task", "go2_flat") == a.task:
                 traffic, traffic_src = pm["hbm_bytes_per_launch_corrected"], os.path.relpath(f, ROOT)
                 break
+        # VALU-issue view of the same kernel (what actually binds it): lane-instructions per env-step from the SQ PMC pass
+        # (tools/sq_pass.sh -> profiles/*_sq_step_kernel.json) x envs / measured kernel time, against 1024 SIMDs x 16 lanes x 2.4 GHz
+        valu = None
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_step_kernel.json")))[::-1]:
+            sq = json.load(open(f))
+            per_env = sq["SQ_INSTS_VALU"] * 64 / sq["num_envs"]
+            valu = {"lane_instr_per_env_step": per_env, "achieved_Tlane_ops": per_env * N / (k_ms * 1e-3) / 1e12, "peak_Tlane_ops": 1024 * 16 * 2.4e9 / 1e12,
+                    "frac": per_env * N / (k_ms * 1e-3) / (1024 * 16 * 2.4e9), "source": os.path.relpath(f, ROOT)}
+            break
         out = {
             "metric": "env-steps/sec at 4096 envs (go2 flat); 1/2/4/8-GPU scaling", "value": total_steps / elapsed, "unit": "env-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
@@ -151,10 +160,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "go2_step_kernel<PHYS|POST>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo * N, "kernel_ms": k_ms, "launches": n.value, "algorithmic_bytes_per_env_step": algo,
                          "note": "latency/occupancy-bound by construction: 4096 envs x 4 lanes = 256 waves for 1024 SIMDs; the binding resource is VALU issue, "
-                                 "not HBM: 35.7k VALU instr per wave per step at 1 wave/SIMD (profiles/r1_sq_step_kernel.json); kernel-only throughput scales "
+                                 "not HBM: ~32k VALU instr per wave per step at 1 wave/SIMD (profiles/r1_sq_step_kernel.json); kernel-only throughput scales "
                                  "3.5x from 4096 to 32768 envs at constant latency (profiles/r1_kernel_scaling.txt, DESIGN.md 6)",
-                         "valu_issue": {"lane_instr_per_env_step": 35663 * 64 * 256 / 4096, "achieved_Tlane_ops": 35663 * 64 * 256 / 4096 * N / (k_ms * 1e-3) / 1e12,
-                                        "peak_Tlane_ops": 1024 * 16 * 2.4e9 / 1e12, "frac": 35663 * 64 * 256 / 4096 * N / (k_ms * 1e-3) / (1024 * 16 * 2.4e9)}},
+                         "valu_issue": valu},
         }
         if world == 1 and not a.no_cpu_baseline:
             try:
