@@ -70,6 +70,7 @@ def cpu_baseline(num_envs=512, task="go2_flat"):
 def main():
     a = parse()
     os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, CPU_THREADS)))   # read by libgomp (the oracle) at load
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")                               # dmabuf IPC for RCCL across processes (host driver requirement)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
