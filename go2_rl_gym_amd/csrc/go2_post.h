@@ -154,7 +154,6 @@ struct LegPost {
   }
   float to_timer;
   // one sample of _get_heights (:1188-1224) around base (bx, by) with yaw quaternion (0,0,yz,yw)
-  float hq_z, hq_w, hpx, hpy;
   GO2_HD float height_at(int i, float yz, float yw, float bx, float by) const {
     const Go2Launch& c = *L;
     if (c.terrain_mode == 0) return 0.f;
@@ -211,7 +210,6 @@ struct LegPost {
     float hsum = 0.f;
     if (c.measure_heights && c.terrain_mode != 0) {   // on a plane measured_heights stays the all-zero buffer it was created as (:1201-1202)
       float nn = fmaxf(sqrtf(qz * qz + qw * qw), 1e-9f), yz = qz / nn, yw = qw / nn;  // quat_apply_yaw (utils/math.py:8-12)
-      hq_z = yz; hq_w = yw; hpx = o.pw.x; hpy = o.pw.y;
       for (int i = lane; i < GO2_NUM_HEIGHT_POINTS; i += 4) {
         const float hv = height_at(i, yz, yw, o.pw.x, o.pw.y);
         const int ix = i / 11, iy = i - 11 * ix;
@@ -440,7 +438,8 @@ struct LegPost {
       for (int i = lane; i < GO2_NUM_HEIGHT_POINTS; i += 4) pv[76 + i] = hv;
     } else {
       for (int i = lane; i < GO2_NUM_HEIGHT_POINTS; i += 4) {
-        float hh = fminf(fmaxf(o.pw.z - 0.5f - height_at(i, hq_z, hq_w, hpx, hpy), -1.f), 1.f);   // same samples as postA (pre-reset pose, App. E.3)
+        // the samples postA took at the pre-reset pose (App. E.3): this lane wrote exactly these entries of measured_heights there
+        float hh = fminf(fmaxf(o.pw.z - 0.5f - F2D(p.heights, i, e), -1.f), 1.f);
         pv[76 + i] = CLIP(hh * c.os_height);
       }
     }

@@ -11,6 +11,9 @@
  *     with an in-memory isaacgym stub (oracle/gen_golden.py).
  *   - RolloutStorage.compute_returns (rsl_rl/rsl_rl/storage/rollout_storage.py:123-137).  PINNED the
  *     same way.
+ *   - the element-wise heads of the PPO / CTS rollout and update that the product runs as library kernels: the fused loss head
+ *     (go2sim_ppo_loss: PINNED against torch autograd of the reference's formulation and by the reference's own PPO.update /
+ *     CTS.update goldens), PPO.act's sampling head, process_env_step, the CTS history ring, ELU-backward + bias gradient.
  *   - the rigid-body physics.  The reference delegates it to NVIDIA Isaac Gym / PhysX (setup.py:12
  *     `isaacgym`, unpinned, closed source, absent from /root/reference), so there is nothing to restate:
  *     this file states a NEW model in textbook form — Featherstone's
