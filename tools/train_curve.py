@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Learning-curve check: train a task for N iterations on the GPU and print reward / episode length / tracking terms every K iterations.
+   python tools/train_curve.py [task] [iterations] [every]"""
+import os, sys, tempfile, io, contextlib, re
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from go2_rl_gym_amd.envs import task_registry
+from go2_rl_gym_amd.utils import get_args
+task = sys.argv[1] if len(sys.argv) > 1 else "go2_flat"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+every = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+args = get_args(["--task", task, "--num_envs", "4096", "--headless", "--seed", "1"])
+env, _ = task_registry.make_env(task, args)
+runner, _ = task_registry.make_alg_runner(env, task, args, log_root=tempfile.mkdtemp())
+env.common_step_counter = 0
+env.update_reward_curriculum(force_update=True)
+done = 0
+while done < iters:
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        runner.learn(every, init_at_random_ep_len=(done == 0))
+    done += every
+    txt = buf.getvalue()
+    last = txt[txt.rfind("Learning iteration"):]
+    pick = lambda key: (re.findall(key + r"\s*(-?[\d.]+)", last) or ["nan"])[-1]
+    names = ("Mean reward:", "Mean teacher reward:", "Mean episode length:", "Mean teacher episode length:", "Mean episode rew_tracking_lin_vel:", "Mean episode rew_tracking_ang_vel:", "Mean action noise std:", "Computation:")
+    print("it %4d | " % done + " | ".join("%s %s" % (n.replace("Mean ", "").replace("episode ", "").rstrip(":"), pick(re.escape(n))) for n in names if pick(re.escape(n)) != "nan"), flush=True)
+env.close()
