@@ -46,11 +46,39 @@ NU = ABI.GO2_NUM_UNIFORMS
 TERRAIN_SEED = 11
 
 
-def make_env(N, seed=1, mesh_type="plane", turn_over=False):
+# "alt" sequence: the other branch of the booleans the registered go2 config leaves one way, and EVERY reward term switched on
+# (the go2 config uses 14 of the 28).  Applied by dotted path to the reference's config here and, in the tests, to this build's
+# config classes — so the host layer's config translation (LeggedRobot._fill_cfg) is part of what the fixture pins.
+ALT_OVERRIDES = {
+    "commands.heading_command": True, "commands.dynamic_resample_commands": False, "commands.limit_vel_invert_when_continuous": False,
+    "commands.stop_heading_at_limit": False, "commands.resampling_time": 4.0,
+    "rewards.only_positive_rewards": True, "rewards.tracking_sigma": 0.3, "rewards.base_height_target": 0.34, "rewards.max_contact_force": 60.0,
+    "rewards.soft_dof_pos_limit": 0.85, "rewards.soft_dof_vel_limit": 0.3, "rewards.soft_torque_limit": 0.4, "rewards.min_legs_distance": 0.25,
+    "rewards.scales.orientation": -0.3, "rewards.scales.base_height": -1.5, "rewards.scales.dof_vel": -1e-4, "rewards.scales.termination": -2.0,
+    "rewards.scales.dof_vel_limits": -0.2, "rewards.scales.torque_limits": -0.01, "rewards.scales.feet_air_time": 1.0, "rewards.scales.stumble": -0.3,
+    "rewards.scales.stand_still": -0.05, "rewards.scales.feet_contact_forces": -0.01, "rewards.scales.similar_to_default": -0.02,
+    "rewards.scales.upright": 0.2, "rewards.scales.legs_distance": -1.5, "rewards.scales.x_command_hip_regular": -0.1,
+    "domain_rand.randomize_motor_strength": False, "domain_rand.randomize_pd_gains": False, "domain_rand.randomize_action_delay": False,
+    "domain_rand.push_interval_s": 3, "noise.noise_level": 0.5, "normalization.clip_observations": 5.0, "normalization.clip_actions": 3.0,
+    "control.action_scale": 0.3,
+}
+
+
+def set_dotted(cfg, path, value):
+    obj = cfg
+    parts = path.split(".")
+    for p_ in parts[:-1]:
+        obj = getattr(obj, p_)
+    setattr(obj, parts[-1], value)
+
+
+def make_env(N, seed=1, mesh_type="plane", turn_over=False, overrides=None):
     env_cfg, train_cfg = task_registry.get_cfgs("go2")
     env_cfg.env.num_envs = N
     env_cfg.terrain.mesh_type = mesh_type
     env_cfg.init_state.turn_over = turn_over
+    for k_, v_ in (overrides or {}).items():
+        set_dotted(env_cfg, k_, v_)
     if turn_over:
         env_cfg.init_state.turn_over_proportions = [0.25, 0.35, 0.4]      # every branch of :654-684 gets exercised
         env_cfg.rewards.turn_over_scales.dof_power = -2e-5                  # a term present in both scale tables, besides `upright`
@@ -102,9 +130,9 @@ def synth_state(rng, N, env, wide_roll=False):
     return root, dof, contact.astype(np.float32), feet_state
 
 
-def gen_env_sequence(N=16, T=64, seed=7, mesh_type="plane", turn_over=False):
+def gen_env_sequence(N=16, T=64, seed=7, mesh_type="plane", turn_over=False, overrides=None):
     rng = np.random.default_rng(seed)
-    env, env_cfg, train_cfg = make_env(N, mesh_type=mesh_type, turn_over=turn_over)
+    env, env_cfg, train_cfg = make_env(N, mesh_type=mesh_type, turn_over=turn_over, overrides=overrides)
     hf = mesh_type != "plane"
     fig.patch_torch()
     names_active = list(env.episode_sums.keys())
@@ -244,6 +272,8 @@ def gen_env_sequence(N=16, T=64, seed=7, mesh_type="plane", turn_over=False):
         lv = np.stack(rec["terrain_levels"])
         counters["level_changes"] = int((np.diff(np.concatenate([rec_levels0[None], lv]), axis=0) != 0).sum())
         counters["nonzero_heights"] = float((np.abs(np.stack(rec["measured_heights"])) > 0).mean())
+    if overrides:
+        out["cfg_overrides"] = np.array(json.dumps(overrides))
     if turn_over:
         tt = np.stack(rec["turn_over_timer"])
         counters["timer_running"] = int((tt > 0).sum()); counters["rolled"] = int((np.abs(np.stack(rec["rpy"])[..., 0]) > np.pi / 4).sum())
@@ -512,6 +542,7 @@ def main():
     hfseq = gen_env_sequence(N=12, T=40, seed=9, mesh_type="heightfield")
     _save(files, "go2_heightfield_sequence.npz", hfseq)
     _save(files, "go2_turn_over_sequence.npz", gen_env_sequence(N=12, T=40, seed=13, turn_over=True))
+    _save(files, "go2_alt_sequence.npz", gen_env_sequence(N=12, T=48, seed=17, mesh_type="heightfield", overrides=ALT_OVERRIDES))
     _save(files, "terrain.npz", gen_terrain())
     _save(files, "gae.npz", gen_gae())
     _save(files, "ppo_update.npz", gen_ppo())

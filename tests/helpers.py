@@ -62,8 +62,21 @@ class HostSim:
         self.cfg = cfg
         h = C.c_void_p()
         _abi.check(lib, lib.go2sim_create(C.byref(cfg), 0, C.byref(h)), "go2sim_create")
+        self._wrap(h, cfg.num_envs)
+
+    @classmethod
+    def attach(cls, env):
+        """View the simulator a LeggedRobot (host layer) created — its config translation is then part of what the test checks."""
+        self = cls.__new__(cls)
+        self.lib, self.abi, self.real, self._keep, self.cfg, self._env = env.lib, env.lib.abi, _NP[env.lib.abi.real], [], env._c, env
+        self._wrap(env.handle, env.num_envs)
+        self.close = lambda: None            # the env owns the handle
+        return self
+
+    def _wrap(self, h, N):
+        lib = self.lib
         self.h = h
-        self.N = cfg.num_envs
+        self.N = N
         b = self.abi.Buffers()
         _abi.check(lib, lib.go2sim_get_buffers(h, C.byref(b)), "go2sim_get_buffers")
         shapes = _abi.buffer_shapes(self.abi, self.N)
@@ -179,7 +192,21 @@ class DeviceSim:
         self.cfg = cfg
         h = C.c_void_p()
         _abi.check(lib, lib.go2sim_create(C.byref(cfg), torch.device(device).index or 0, C.byref(h)), "go2sim_create")
-        self.h, self.N = h, cfg.num_envs
+        self._wrap(h, cfg.num_envs, device)
+
+    @classmethod
+    def attach(cls, env):
+        self = cls.__new__(cls)
+        self.lib, self.abi, self.device, self.real, self._keep, self.cfg, self._env = env.lib, env.lib.abi, env.device, np.float32, [], env._c, env
+        self._wrap(env.handle, env.num_envs, env.device)
+        self.close = lambda: None
+        return self
+
+    def _wrap(self, h, N, device):
+        import torch
+        from go2_rl_gym_amd.envs.base.base_task import wrap_buffers
+        lib = self.lib
+        self.h, self.N = h, N
         self.t = wrap_buffers(lib, h, self.N, device)
         self.buf = {k: _Proxy(v) for k, v in self.t.items()}
         for k, v in self.buf.items():

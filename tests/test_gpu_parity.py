@@ -21,7 +21,7 @@ def hip():
     return lib
 
 
-@pytest.mark.parametrize("terrain", ["plane", "heightfield", "turn_over"])
+@pytest.mark.parametrize("terrain", ["plane", "heightfield", "turn_over", "alt"])
 def test_golden_sequence_on_gpu(hip, terrain):
     """post_physics_step of the reference (golden vectors, injected uniforms) reproduced by the HIP kernel:
     obs / priv obs <= 2e-5, rewards <= 2e-6 (fp32, tolerances in test_oracle_golden.TOL).  heightfield: + the 187-point

@@ -14,12 +14,45 @@ G = os.path.join(ROOT, "tests", "golden")
 FEET = [6, 10, 14, 18]
 
 
-@pytest.fixture(scope="module", params=["plane", "heightfield", "turn_over"])
+@pytest.fixture(scope="module", params=["plane", "heightfield", "turn_over", "alt"])
 def seq(request):
     return dict(np.load(os.path.join(G, "go2_%s_sequence.npz" % request.param)))
 
 
+def _mk_through_host_layer(lib, g, sim):
+    """Sequences recorded with a modified reference config (cfg_overrides): the same dotted overrides are applied to this build's config
+    classes and the simulator is created by the PRODUCT's host layer (task_registry -> LeggedRobot._fill_cfg), so the config
+    translation is part of what is pinned."""
+    import json
+    from go2_rl_gym_amd.envs import task_registry
+    from go2_rl_gym_amd.envs.go2.go2_config import GO2Cfg
+    from go2_rl_gym_amd.utils import get_args
+    N = g["actions"].shape[1]
+    cfg = GO2Cfg()
+    cfg.terrain.mesh_type = "heightfield" if "hf_sha256" in g else "plane"
+    for path, val in json.loads(str(g["cfg_overrides"])).items():
+        obj = cfg
+        parts = path.split(".")
+        for p_ in parts[:-1]:
+            obj = getattr(obj, p_)
+        setattr(obj, parts[-1], val)
+    cfg.seed = int(g["terrain_seed"]) if "terrain_seed" in g else 1        # make_env seeds numpy with it before the Terrain is built (task_registry.py:36)
+    on_gpu = lib.go2sim_is_device_library() == 1
+    dev = "cuda:0" if on_gpu else "cpu"
+    args = get_args(["--task", "go2", "--num_envs", str(N), "--headless", "--sim_device", dev, "--rl_device", dev, "--seed", str(int(g["terrain_seed"]) if "terrain_seed" in g else 1)])
+    env, _ = task_registry.make_env("go2", args, env_cfg=cfg, lib=lib)
+    s = sim.attach(env)
+    return s
+
+
 def _mk(lib, g, sim=HostSim, **kw):
+    if "cfg_overrides" in g:
+        s = _mk_through_host_layer(lib, g, sim)
+        lib.go2sim_set_common_step_counter(s.h, int(g["start_counter"]))
+        lib.go2sim_update_reward_curriculum(s.h, 1)
+        if "hf_sha256" in g:
+            np.testing.assert_array_equal(np.asarray(s.terrain_levels), g["terrain_levels0"])
+        return s
     N = g["actions"].shape[1]
     if "hf_sha256" in g:      # heightfield sequence: rebuild the terrain from its seed with this repo's generator
         import hashlib
@@ -49,7 +82,7 @@ def test_static_tables(seq):
     # reward scales x dt (legged_robot.py:914-920) for the 14 active go2 terms, nothing else active
     cfg_scales = np.array(list(s.cfg.reward_scales), np.float32) * np.float32(0.02)
     np.testing.assert_allclose(cfg_scales, seq["reward_scales_dt"], rtol=1e-6)
-    assert int((seq["reward_scales_dt"] != 0).sum()) == 14
+    assert int((seq["reward_scales_dt"] != 0).sum()) == (28 if "cfg_overrides" in seq else 14)
     if "turn_over" in seq:
         np.testing.assert_allclose(np.array(list(s.cfg.turn_over_scales), np.float32) * np.float32(0.02), seq["turn_over_scales_dt"], rtol=1e-6)
     comb = np.array([list(r) for r in s.cfg.limit_vel_comb], np.float32)[: s.cfg.limit_vel_comb_count]
@@ -91,7 +124,7 @@ def run_sequence(s, lib, g, check):
             # libraries without the torque-trace hook (the lane emulation): take the reference's own clipped
             # actions / last-substep torques as inputs of post_physics_step; their PD path is covered by the
             # physics parity tests against the oracle
-            s.actions[:] = np.clip(g["actions"][t], -100.0, 100.0)
+            s.actions[:] = np.clip(g["actions"][t], -s.cfg.clip_actions, s.cfg.clip_actions)
             s.torques[:] = g["torques"][t][3]
             s.root_states[:] = g["root_in"][t]; s.dof_state[:] = g["dof_in"][t][3]; s.contact_forces[:] = g["contact_in"][t]
             s.rigid_body_states[:] = 0; s.rigid_body_states[:, FEET, :] = g["feet_in"][t]
