@@ -13,8 +13,14 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define GO2_HD __host__ __device__ __forceinline__
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GO2_DIV_RN(a, b) __fdiv_rn((a), (b))      // IEEE round-to-nearest even under -ffast-math
+#else
+#define GO2_DIV_RN(a, b) ((a) / (b))
+#endif
 #else
 #define GO2_HD inline
+#define GO2_DIV_RN(a, b) ((a) / (b))
 #endif
 
 struct V3 { float x, y, z; };

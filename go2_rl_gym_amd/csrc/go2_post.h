@@ -159,7 +159,9 @@ struct LegPost {
     if (c.terrain_mode == 0) return 0.f;
     const int ix = i / 11, iy = i - 11 * ix;
     V3 w = quat_apply(0.f, 0.f, yz, yw, v3((float)(ix - 8) * 0.1f, (float)(iy - 5) * 0.1f, 0.f));
-    float x = (w.x + bx + c.hf_border) / c.hf_hscale, y = (w.y + by + c.hf_border) / c.hf_hscale;
+    // correctly rounded division (the build uses -ffast-math, whose reciprocal-multiply can land a sample that sits exactly on a cell
+    // boundary in the neighbouring cell: one such sample in 10^5 showed up against the reference's golden vectors)
+    float x = GO2_DIV_RN(w.x + bx + c.hf_border, c.hf_hscale), y = GO2_DIV_RN(w.y + by + c.hf_border, c.hf_hscale);
     int px = (int)x, py = (int)y;
     px = px < 0 ? 0 : (px > c.hf_rows - 2 ? c.hf_rows - 2 : px); py = py < 0 ? 0 : (py > c.hf_cols - 2 ? c.hf_cols - 2 : py);
     int h1 = P->hf[px * c.hf_cols + py], h2 = P->hf[(px + 1) * c.hf_cols + py], h3 = P->hf[px * c.hf_cols + py + 1];
