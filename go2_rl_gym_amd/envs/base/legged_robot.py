@@ -135,6 +135,9 @@ class LeggedRobot(BaseTask):
         c.push_robots, c.push_interval, c.max_push_vel_xy, c.max_push_ang_vel = int(d.push_robots), int(d.push_interval), d.max_push_vel_xy, d.max_push_ang_vel
         c.randomize_action_delay = int(d.randomize_action_delay)
         cm = cfg.commands
+        if getattr(cm, "curriculum", False):
+            raise NotImplementedError("commands.curriculum (tracking-reward-driven widening of lin_vel_x, legged_robot.py:728-737) is off in every go2 config "
+                                      "and not built; the iteration-driven command_range_curriculum / zero_command_curriculum are")
         c.cmd_resampling_time, c.heading_command, c.dynamic_resample_commands = cm.resampling_time, int(cm.heading_command), int(cm.dynamic_resample_commands)
         c.limit_vel_prob, c.limit_vel_invert_when_continuous, c.stop_heading_at_limit = cm.limit_vel_prob, int(cm.limit_vel_invert_when_continuous), int(cm.stop_heading_at_limit)
         c.limit_ang_vel_at_zero_command_prob = cm.limit_ang_vel_at_zero_command_prob
