@@ -326,3 +326,18 @@ class LeggedRobotCfgMoECTS(LeggedRobotCfgCTS):
     class runner(LeggedRobotCfgCTS.runner):
         policy_class_name = "ActorCriticMoECTS"
         algorithm_class_name = "MoECTS"
+
+
+class LeggedRobotCfgMoENGCTS(LeggedRobotCfgCTS):
+    """MoE student encoder whose experts do not see the command (legged_robot_config.py:361-371)."""
+
+    class policy(LeggedRobotCfgCTS.policy):
+        obs_no_goal_mask = None
+        student_expert_num = 8
+
+    class algorithm(LeggedRobotCfgCTS.algorithm):
+        load_balance_coef = 0.01
+
+    class runner(LeggedRobotCfgCTS.runner):
+        policy_class_name = "ActorCriticMoENGCTS"
+        algorithm_class_name = "MoENGCTS"

@@ -3,7 +3,7 @@
 (legged_gym/envs/go2/go2_config_fast_flat_move.py:98; the BASELINE workload "task=go2 flat terrain")."""
 import math
 
-from ..base.legged_robot_config import LeggedRobotCfg, LeggedRobotCfgCTS, LeggedRobotCfgMoECTS, LeggedRobotCfgPPO, _max_cmd_table
+from ..base.legged_robot_config import LeggedRobotCfg, LeggedRobotCfgCTS, LeggedRobotCfgMoECTS, LeggedRobotCfgMoENGCTS, LeggedRobotCfgPPO, _max_cmd_table
 
 _LEGS = ("FL", "FR", "RL", "RR")
 
@@ -187,3 +187,18 @@ class GO2FlatCfgCTS(GO2CfgCTS):
 class GO2FlatCfgMoECTS(GO2CfgMoECTS):
     class runner(GO2CfgMoECTS.runner):
         experiment_name = "go2_flat_moe_cts"
+
+
+class GO2CfgMoENGCTS(LeggedRobotCfgMoENGCTS):       # go2_config.py:231-243
+    class policy(LeggedRobotCfgMoENGCTS.policy):
+        obs_no_goal_mask = [True] * 6 + [False] * 3 + [True] * 36      # observation without the command entries
+        student_expert_num = 8
+
+    class algorithm(LeggedRobotCfgMoENGCTS.algorithm):
+        load_balance_coef = 0.01
+
+    class runner(LeggedRobotCfgMoENGCTS.runner):
+        run_name = ""
+        experiment_name = "go2_moe_no_goal_cts"
+        max_iterations = 150000
+        save_interval = 500

@@ -20,3 +20,7 @@ class MoECTS(CTS):
         usage = gate.mean(dim=0)
         load_balance_loss = (usage - 1.0 / gate.shape[1]).pow(2).mean()
         return latent_loss + self.load_balance_coef * load_balance_loss, (latent_loss, load_balance_loss)
+
+
+class MoENGCTS(MoECTS):
+    """rsl_rl/rsl_rl/algorithms/moe_ng_cts.py: MoECTS whose student latent comes from the no-goal encoder (the model's `student_latent` hook)."""

@@ -10,12 +10,12 @@ from collections import deque
 
 import torch
 
-from ..algorithms import CTS, MoECTS
-from ..modules import ActorCriticCTS, ActorCriticMoECTS
+from ..algorithms import CTS, MoECTS, MoENGCTS
+from ..modules import ActorCriticCTS, ActorCriticMoECTS, ActorCriticMoENGCTS
 from .on_policy_runner import OnPolicyRunner
 
-_POLICIES = {"ActorCriticCTS": ActorCriticCTS, "ActorCriticMoECTS": ActorCriticMoECTS}
-_ALGS = {"CTS": CTS, "MoECTS": MoECTS}
+_POLICIES = {"ActorCriticCTS": ActorCriticCTS, "ActorCriticMoECTS": ActorCriticMoECTS, "ActorCriticMoENGCTS": ActorCriticMoENGCTS}
+_ALGS = {"CTS": CTS, "MoECTS": MoECTS, "MoENGCTS": MoENGCTS}
 
 
 class OnPolicyRunnerCTS(OnPolicyRunner):
@@ -31,7 +31,7 @@ class OnPolicyRunnerCTS(OnPolicyRunner):
         H = self.history_length = train_cfg["history_length"]
         name = self.cfg["policy_class_name"]
         if name not in _POLICIES or self.cfg["algorithm_class_name"] not in _ALGS:
-            raise NotImplementedError("policy %r / algorithm %r: only CTS and MoECTS are built (SURVEY 8 f2)" % (name, self.cfg["algorithm_class_name"]))
+            raise NotImplementedError("policy %r / algorithm %r: CTS, MoECTS and MoENGCTS are built (SURVEY 8 f2; the MCP / AC-MoE / Dual-MoE ablations are not)" % (name, self.cfg["algorithm_class_name"]))
         model = _POLICIES[name](env.num_obs, env.num_privileged_obs, env.num_actions, env.num_envs, H, **self.policy_cfg).to(self.device)
         self.alg = _ALGS[self.cfg["algorithm_class_name"]](model, env.num_envs, H, device=self.device, lib=self.lib, use_graphs=use_graphs, **self.alg_cfg)
         self.history = torch.zeros(env.num_envs, H, env.num_obs, device=self.device)

@@ -76,6 +76,26 @@ def _plain(m):
     return nn.Sequential(*m.children()) if isinstance(m, FusedSequential) else m
 
 
+class _MoENGCTSPolicy(nn.Module):
+    def __init__(self, actor, student_moe_encoder, mask, history_length: int, num_obs: int, normalizer):
+        super().__init__()
+        self.actor, self.student_moe_encoder, self.normalizer = actor, student_moe_encoder, normalizer
+        self.history_length = history_length
+        self.obs_no_goal_mask = mask
+        self.history = torch.zeros(1, history_length, num_obs)
+
+    def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]:
+        x = self.normalizer(x)
+        self.history = torch.cat([self.history[:, 1:], x.unsqueeze(1)], dim=1)
+        no_goal = self.history.reshape(1, self.history_length, -1)[:, :, self.obs_no_goal_mask].reshape(1, -1)
+        latent, weights = self.student_moe_encoder(self.history.flatten(1), no_goal)
+        return self.actor(torch.cat([latent, x], dim=1)), (weights, latent)
+
+    @torch.jit.export
+    def reset(self):
+        self.history = torch.zeros_like(self.history)
+
+
 def _cpu_copy(m):
     return _plain(copy.deepcopy(m).cpu())
 
@@ -87,6 +107,8 @@ def _deployment_module(policy, normalizer=None):
     if not hasattr(policy, "actor"):
         raise ValueError("Policy does not have an actor/student module.")
     actor = _cpu_copy(policy.actor)
+    if hasattr(policy, "student_moe_encoder") and hasattr(policy, "obs_no_goal_mask"):
+        return _MoENGCTSPolicy(actor, _cpu_copy(policy.student_moe_encoder), policy.obs_no_goal_mask.detach().clone().cpu(), policy.history.shape[1], policy.history.shape[2], norm)
     if hasattr(policy, "student_moe_encoder"):
         return _MoECTSPolicy(actor, _cpu_copy(policy.student_moe_encoder), policy.history.shape[1], policy.history.shape[2], norm)
     if hasattr(policy, "student_encoder"):
@@ -121,6 +143,7 @@ class _OnnxPolicy(nn.Module):
         obs_dim = sum(_TERM_DIMS)
         self.frames = policy.history.shape[1] if self.kind != "ppo" else 1
         self.input_dim = obs_dim * self.frames
+        self.no_goal_mask = policy.obs_no_goal_mask.detach().clone().cpu() if hasattr(policy, "obs_no_goal_mask") else None
 
     def by_frame(self, x):
         obs_dim = sum(_TERM_DIMS)
@@ -138,7 +161,11 @@ class _OnnxPolicy(nn.Module):
             return self.actor(last)
         if self.kind == "cts":
             return self.actor(torch.cat([self.encoder(history), last], dim=1))
-        latent, weights = self.encoder(history)
+        if self.no_goal_mask is not None:      # MoE-NG: the experts read the history without the command entries (:268-277)
+            no_goal = history.view(-1, self.frames, obs_dim)[:, :, self.no_goal_mask].reshape(x.shape[0], -1)
+            latent, weights = self.encoder(history, no_goal)
+        else:
+            latent, weights = self.encoder(history)
         return self.actor(torch.cat([latent, last], dim=1)), weights, latent
 
 

@@ -439,6 +439,11 @@ def gen_cts(kind, seed=21):
     if kind == "MoECTS":
         policy["expert_num"] = 4
         algorithm["load_balance_coef"] = 0.01
+    if kind == "MoENGCTS":
+        policy["student_encoder_hidden_dims"] = [32, 16]
+        policy["student_expert_num"] = 4
+        policy["obs_no_goal_mask"] = [True] * 6 + [False] * 3 + [True] * 36
+        algorithm["load_balance_coef"] = 0.01
     train_cfg = {"runner": dict(policy_class_name="ActorCritic" + kind, algorithm_class_name=kind, num_steps_per_env=T, max_iterations=1, save_interval=1000,
                                 experiment_name="golden", run_name=""),
                  "algorithm": algorithm, "policy": policy, "history_length": H, "robogauge": {"enabled": False, "port": 0}}
@@ -549,6 +554,7 @@ def main():
     _save(files, "pretrained_go2_cts_150k.npz", gen_pretrained())
     _save(files, "cts_iteration.npz", gen_cts("CTS"))
     _save(files, "moe_cts_iteration.npz", gen_cts("MoECTS"))
+    _save(files, "moe_ng_cts_iteration.npz", gen_cts("MoENGCTS"))
     for f in files:
         files[f] = hashlib.sha256(open(os.path.join(OUT, f), "rb").read()).hexdigest()
     try:

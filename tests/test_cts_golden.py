@@ -56,12 +56,15 @@ def _train_cfg(kind, T):
     if kind == "MoECTS":
         policy["expert_num"] = 4
         algorithm["load_balance_coef"] = 0.01
+    if kind == "MoENGCTS":
+        policy.update(student_encoder_hidden_dims=[32, 16], student_expert_num=4, obs_no_goal_mask=[True] * 6 + [False] * 3 + [True] * 36)
+        algorithm["load_balance_coef"] = 0.01
     return {"runner": dict(policy_class_name="ActorCritic" + kind, algorithm_class_name=kind, num_steps_per_env=T, max_iterations=1, save_interval=1000,
                            experiment_name="golden", run_name=""), "algorithm": algorithm, "policy": policy, "history_length": 5}
 
 
 @pytest.mark.parametrize("fused", [False, True])
-@pytest.mark.parametrize("kind,fixture", [("CTS", "cts_iteration.npz"), ("MoECTS", "moe_cts_iteration.npz")])
+@pytest.mark.parametrize("kind,fixture", [("CTS", "cts_iteration.npz"), ("MoECTS", "moe_cts_iteration.npz"), ("MoENGCTS", "moe_ng_cts_iteration.npz")])
 def test_one_iteration_matches_reference(kind, fixture, fused, monkeypatch, tmp_path):
     g = dict(np.load(os.path.join(G, fixture)))
     T, N = g["rew"].shape

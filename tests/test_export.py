@@ -14,7 +14,7 @@ import pytest
 import torch
 
 from helpers import ROOT, HostSim, load_oracle
-from go2_rl_gym_amd.rsl_rl.modules import ActorCritic, ActorCriticCTS, ActorCriticMoECTS
+from go2_rl_gym_amd.rsl_rl.modules import ActorCritic, ActorCriticCTS, ActorCriticMoECTS, ActorCriticMoENGCTS
 from go2_rl_gym_amd.utils.exporter import _OnnxPolicy, export_policy_as_jit, export_policy_as_onnx, export_policy_as_pkl
 
 G = os.path.join(ROOT, "tests", "golden")
@@ -53,13 +53,16 @@ def test_pretrained_reference_policy_roundtrip(tmp_path):
     assert set(sd) == set(m.state_dict())
 
 
-@pytest.mark.parametrize("kind,fixture,cls", [("CTS", "cts_iteration.npz", ActorCriticCTS), ("MoECTS", "moe_cts_iteration.npz", ActorCriticMoECTS)])
+@pytest.mark.parametrize("kind,fixture,cls", [("CTS", "cts_iteration.npz", ActorCriticCTS), ("MoECTS", "moe_cts_iteration.npz", ActorCriticMoECTS),
+                                              ("MoENGCTS", "moe_ng_cts_iteration.npz", ActorCriticMoENGCTS)])
 def test_exported_cts_policies_match_reference_exporter(kind, fixture, cls, tmp_path):
     g = dict(np.load(os.path.join(G, fixture)))
     kw = dict(actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16], teacher_encoder_hidden_dims=[32, 16], latent_dim=8,
               student_encoder_hidden_dims=[32, 16] if kind == "CTS" else [32, 16, 8])
     if kind == "MoECTS":
         kw["expert_num"] = 4
+    if kind == "MoENGCTS":
+        kw.update(student_encoder_hidden_dims=[32, 16], student_expert_num=4, obs_no_goal_mask=[True] * 6 + [False] * 3 + [True] * 36)
     m = cls(45, 263, 12, 32, 5, **kw)
     m.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w1_")})
     jit = torch.jit.load(export_policy_as_jit(m, str(tmp_path)))
@@ -75,7 +78,7 @@ def test_exported_cts_policies_match_reference_exporter(kind, fixture, cls, tmp_
             wts.append(w.detach().numpy())
     np.testing.assert_allclose(np.stack(acts), g["jit_actions"], atol=2e-6)
     np.testing.assert_allclose(np.stack(lats), g["jit_latent"], atol=2e-6)
-    if kind == "MoECTS":
+    if kind != "CTS":
         np.testing.assert_allclose(np.stack(wts), g["jit_weights"], atol=2e-6)
     else:
         assert not wts
