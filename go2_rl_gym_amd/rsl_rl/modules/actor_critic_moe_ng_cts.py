@@ -44,6 +44,8 @@ class ActorCriticMoENGCTS(ActorCriticCTS):
         super().__init__(num_obs, num_critic_obs, num_actions, num_envs, history_length, actor_hidden_dims, critic_hidden_dims,
                          teacher_encoder_hidden_dims, student_encoder_hidden_dims, activation, init_noise_std, latent_dim, norm_type, **kwargs)
         self.register_buffer("obs_no_goal_mask", torch.tensor(self._mask_list, dtype=torch.bool), persistent=False)
+        # integer form of the mask: a boolean-mask index is a nonzero() + host sync, which a HIP-graph capture does not allow
+        self.register_buffer("_no_goal_idx", torch.nonzero(self.obs_no_goal_mask).flatten(), persistent=False)
 
     def _build_encoders(self, n_obs, n_priv, H, t_hidden, s_hidden, activation, latent_dim, norm_type, extra):
         self.teacher_encoder = _encoder(n_priv, t_hidden, latent_dim, activation, norm_type)
@@ -55,7 +57,7 @@ class ActorCriticMoENGCTS(ActorCriticCTS):
 
     def get_student_latent_and_weights(self, history):
         B = history.shape[0]
-        no_goal = history.reshape(B, self.history_length, -1)[:, :, self.obs_no_goal_mask].reshape(B, -1)
+        no_goal = history.reshape(B, self.history_length, -1).index_select(2, self._no_goal_idx).reshape(B, -1)
         return self.student_moe_encoder(history, no_goal)
 
     def student_latent(self, history):
