@@ -341,3 +341,26 @@ class LeggedRobotCfgMoENGCTS(LeggedRobotCfgCTS):
     class runner(LeggedRobotCfgCTS.runner):
         policy_class_name = "ActorCriticMoENGCTS"
         algorithm_class_name = "MoENGCTS"
+
+
+class LeggedRobotCfgACMoECTS(LeggedRobotCfgCTS):
+    """MoE actor + expert critic sharing the actor gate (legged_robot_config.py:382-388)."""
+
+    class policy(LeggedRobotCfgCTS.policy):
+        expert_num = 8
+
+    class runner(LeggedRobotCfgCTS.runner):
+        policy_class_name = "ActorCriticACMoECTS"
+        algorithm_class_name = "ACMoECTS"
+
+
+class LeggedRobotCfgDualMoECTS(LeggedRobotCfgCTS):
+    """AC-MoE heads + MoE student encoder (legged_robot_config.py:390-397)."""
+
+    class policy(LeggedRobotCfgCTS.policy):
+        expert_num = 8
+        student_encoder_hidden_dims = [512, 256, 256]
+
+    class runner(LeggedRobotCfgCTS.runner):
+        policy_class_name = "ActorCriticDualMoECTS"
+        algorithm_class_name = "DualMoECTS"

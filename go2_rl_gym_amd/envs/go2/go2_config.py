@@ -3,7 +3,7 @@
 (legged_gym/envs/go2/go2_config_fast_flat_move.py:98; the BASELINE workload "task=go2 flat terrain")."""
 import math
 
-from ..base.legged_robot_config import LeggedRobotCfg, LeggedRobotCfgCTS, LeggedRobotCfgMoECTS, LeggedRobotCfgMoENGCTS, LeggedRobotCfgPPO, _max_cmd_table
+from ..base.legged_robot_config import LeggedRobotCfg, LeggedRobotCfgACMoECTS, LeggedRobotCfgCTS, LeggedRobotCfgDualMoECTS, LeggedRobotCfgMoECTS, LeggedRobotCfgMoENGCTS, LeggedRobotCfgPPO, _max_cmd_table
 
 _LEGS = ("FL", "FR", "RL", "RR")
 
@@ -200,5 +200,27 @@ class GO2CfgMoENGCTS(LeggedRobotCfgMoENGCTS):       # go2_config.py:231-243
     class runner(LeggedRobotCfgMoENGCTS.runner):
         run_name = ""
         experiment_name = "go2_moe_no_goal_cts"
+        max_iterations = 150000
+        save_interval = 500
+
+
+class GO2CfgACMoECTS(LeggedRobotCfgACMoECTS):       # go2_config.py:256-264
+    class policy(LeggedRobotCfgACMoECTS.policy):
+        expert_num = 8
+
+    class runner(LeggedRobotCfgACMoECTS.runner):
+        run_name = ""
+        experiment_name = "go2_ac_moe_cts"
+        max_iterations = 150000
+        save_interval = 500
+
+
+class GO2CfgDualMoECTS(LeggedRobotCfgDualMoECTS):   # go2_config.py:266-274
+    class policy(LeggedRobotCfgDualMoECTS.policy):
+        expert_num = 8
+
+    class runner(LeggedRobotCfgDualMoECTS.runner):
+        run_name = ""
+        experiment_name = "go2_dual_moe_cts"
         max_iterations = 150000
         save_interval = 500

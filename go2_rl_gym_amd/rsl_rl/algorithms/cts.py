@@ -45,8 +45,7 @@ class CTS(_RolloutHeads):
         if on_gpu and lib is not None and os.environ.get("GO2_FUSED_MLP", "0") == "1":
             from ..modules import fused
             fused.set_library(lib)
-        groups1 = [{"params": list(self.model.teacher_encoder.parameters())}, {"params": list(self.model.critic.parameters())},
-                   {"params": list(self.model.actor.parameters())}, {"params": [self.model.std]}]           # same 4 groups as the reference (:72-77)
+        groups1 = [{"params": g} for g in self.model.policy_parameter_groups()]                           # same 4 groups as the reference (:72-77)
         self._params1 = list(itertools.chain.from_iterable(g["params"] for g in groups1))
         self._params2 = list(self.model.student_parameters())
         if self.use_graphs:
@@ -122,10 +121,10 @@ class CTS(_RolloutHeads):
         st.history[s].copy_(history)
         latent = self._latent_env_order(privileged_obs, history)
         if self.fused_rollout:
-            mu, value = self._pair(lambda: m.actor(torch.cat([latent, obs], dim=1)), lambda: m.evaluate_joint(privileged_obs, latent), enabled=self.use_graphs)
+            mu, value = self._pair(lambda: m.policy_mean(latent, obs), lambda: m.evaluate_joint(privileged_obs, latent, obs), enabled=self.use_graphs)
             return self._act_head(mu, m.std, m._noise(mu), value, s)
         t.actions = m.act_joint(obs, latent).detach()
-        t.values = m.evaluate_joint(privileged_obs, latent).detach()
+        t.values = m.evaluate_joint(privileged_obs, latent, obs).detach()
         t.actions_log_prob = m.get_actions_log_prob(t.actions).detach()
         t.action_mean, t.action_sigma = m.action_mean.detach(), m.action_std.detach()
         st.actions[s].copy_(t.actions)
@@ -150,9 +149,9 @@ class CTS(_RolloutHeads):
         self.transition.clear()
         self.model.history.masked_fill_(dones.view(-1, 1, 1) > 0, 0.0)          # model.reset(dones) (:163) without a boolean-index sync
 
-    def compute_returns(self, last_privileged_obs, last_history):
+    def compute_returns(self, last_privileged_obs, last_history, last_obs=None):
         latent = self._latent_env_order(last_privileged_obs, last_history)
-        last_values = self.model.evaluate_joint(last_privileged_obs, latent).detach()
+        last_values = self.model.evaluate_joint(last_privileged_obs, latent, last_obs).detach()
         self.storage.compute_returns(last_values, self.gamma, self.lam)
 
     # ------------------------------------------------------------------ update half (:167-286)
@@ -161,13 +160,13 @@ class CTS(_RolloutHeads):
         m = self.model
         latent = m.latents(priv_b, hist_b, n_t)
         if self.fused_loss:
-            mu_b, val_b = self._pair(lambda: m.actor(torch.cat([latent, obs_b], dim=1)), lambda: m.evaluate_joint(priv_b, latent), enabled=self.use_graphs)
+            mu_b, (val_b, aux) = self._pair(lambda: m.policy_mean(latent, obs_b), lambda: m.value(latent, obs_b, priv_b), enabled=self.use_graphs)
             self.surrogate_split = n_t
             loss, stats = _FusedPPOLoss.apply(mu_b, m.std, val_b, self, act_b, tv_b, adv_b, ret_b, old_lp_b, old_mu_b, old_sig_b)
-            return loss, stats[1], stats[0], stats[3], stats[2]
+            return self._policy_extra(loss, aux), stats[1], stats[0], stats[3], stats[2]
         m.update_distribution(torch.cat([latent, obs_b], dim=1))
         lp_b = m.get_actions_log_prob(act_b)
-        val_b = m.evaluate_joint(priv_b, latent)
+        val_b, aux = m.value(latent, obs_b, priv_b)
         mu_b, sig_b, ent_b = m.action_mean, m.action_std, m.entropy
         with torch.no_grad():
             kl = torch.sum(torch.log(sig_b / old_sig_b + 1.0e-5) + (torch.square(old_sig_b) + torch.square(old_mu_b - mu_b)) / (2.0 * torch.square(sig_b)) - 0.5, axis=-1)
@@ -184,7 +183,14 @@ class CTS(_RolloutHeads):
             value_loss = (ret_b - val_b).pow(2).mean()
         ent = ent_b.mean()
         loss = surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * ent
-        return loss, value_loss, surrogate_loss, ent, kl_mean
+        return self._policy_extra(loss, aux), value_loss, surrogate_loss, ent, kl_mean
+
+    _NUM_POLICY_LOGS = 0
+    _policy_logs = ()           # 0-d tensors logged by the last _policy_extra call (the actor load-balance term of the AC-MoE variants)
+
+    def _policy_extra(self, loss, aux):
+        """Hook: extra terms of the policy loss from the value head's auxiliary output (the actor gate weights of the AC-MoE variants)."""
+        return loss
 
     def _student_losses(self, hist_s, priv_s):
         """-> total loss, (latent_loss, ...) for the log    (student rows only)"""
@@ -206,7 +212,8 @@ class CTS(_RolloutHeads):
         fl, n_t = self.storage.flat(), self._teacher_rows()
         idx = self.storage.mini_batch_indices(self.num_mini_batches)
         world, sync = _world(), _collectives_on()
-        acc = [0.0] * (3 + self._NUM_STUDENT_LOGS)
+        P = self._NUM_POLICY_LOGS
+        acc = [0.0] * (3 + P + self._NUM_STUDENT_LOGS)
         for _ in range(self.num_learning_epochs):
             for b in idx:
                 loss, value_loss, surrogate_loss, ent, kl_mean = self._policy_losses(*self._gather(fl, b), n_t)
@@ -228,6 +235,8 @@ class CTS(_RolloutHeads):
                 nn.utils.clip_grad_norm_(self._params1, self.max_grad_norm)
                 self.optimizer1.step()
                 acc[0] += value_loss.item(); acc[1] += surrogate_loss.item(); acc[2] += ent.item()
+                for i, v in enumerate(self._policy_logs):
+                    acc[3 + i] += v.item()
         for _ in range(self.num_learning_epochs):
             for b in idx:
                 bs = b[n_t:]
@@ -239,9 +248,14 @@ class CTS(_RolloutHeads):
                 nn.utils.clip_grad_norm_(self._params2, self.max_grad_norm)
                 self.optimizer2.step()
                 for i, v in enumerate(logs):
-                    acc[3 + i] += v.item()
+                    acc[3 + P + i] += v.item()
         n = self.num_learning_epochs * self.num_mini_batches
-        return tuple(a / n for a in acc)
+        return self._ordered(tuple(a / n for a in acc))
+
+    def _ordered(self, acc):
+        """accumulators [value, surrogate, entropy | policy logs | student logs] -> the reference's return order: ..., student logs, policy logs"""
+        P = self._NUM_POLICY_LOGS
+        return acc[:3] + acc[3 + P:] + acc[3:3 + P]
 
     # ---- graph mode: every decision on the device; one captured policy step and one captured student step per mini-batch slot ----
     _KEYS = ("obs", "cobs", "hist", "act", "val", "adv", "ret", "logp", "mu", "sig")
@@ -260,7 +274,7 @@ class CTS(_RolloutHeads):
             lr.copy_(torch.where(kl_mean > self.desired_kl * 2.0, down, torch.where((kl_mean < self.desired_kl / 2.0) & (kl_mean > 0.0), up, lr)))
         nn.utils.clip_grad_norm_(self._params1, self.max_grad_norm, foreach=True)
         self.optimizer1.step()
-        self._acc[:3].add_(torch.stack([value_loss.detach(), surrogate_loss.detach(), ent.detach()]))
+        self._acc[:3 + self._NUM_POLICY_LOGS].add_(torch.stack([value_loss.detach(), surrogate_loss.detach(), ent.detach()] + [v.detach() for v in self._policy_logs]))
 
     def _student_step(self, i):
         mb, n_t = self._mb, self._teacher_rows()
@@ -271,7 +285,7 @@ class CTS(_RolloutHeads):
             _allreduce_mean_grads(self._params2, _world())
         nn.utils.clip_grad_norm_(self._params2, self.max_grad_norm, foreach=True)
         self.optimizer2.step()
-        self._acc[3:].add_(torch.stack([v.detach() for v in logs]))
+        self._acc[3 + self._NUM_POLICY_LOGS:].add_(torch.stack([v.detach() for v in logs]))
 
     def _update_graphs(self):
         st, nmb = self.storage, self.num_mini_batches
@@ -279,7 +293,7 @@ class CTS(_RolloutHeads):
             self._flat = st.flat()
             self._mb = (st.teacher_num_envs * st.num_transitions_per_env) // nmb + (st.student_num_envs * st.num_transitions_per_env) // nmb
             self._perm = {k: torch.empty((nmb * self._mb,) + tuple(self._flat[k].shape[1:]), device=self.device, dtype=self._flat[k].dtype) for k in self._KEYS}
-            self._acc = torch.zeros(3 + self._NUM_STUDENT_LOGS, device=self.device)
+            self._acc = torch.zeros(3 + self._NUM_POLICY_LOGS + self._NUM_STUDENT_LOGS, device=self.device)
             mk = lambda fn, name: [CapturedStep((lambda i=i: fn(i)), warmup=3 if i == 0 else 1, name="CTS %s step %d" % (name, i)) for i in range(nmb)]
             self._steps = (mk(self._policy_step, "policy"), mk(self._student_step, "student"))
         self._acc.zero_()
@@ -295,7 +309,7 @@ class CTS(_RolloutHeads):
         n = self.num_learning_epochs * nmb
         out = (self._acc / n).tolist()
         self.learning_rate = float(self._lr_t.item())
-        return tuple(out)
+        return self._ordered(tuple(out))
 
     def update(self):
         out = self._update_graphs() if self.use_graphs else self._update_eager()

@@ -24,3 +24,40 @@ class MoECTS(CTS):
 
 class MoENGCTS(MoECTS):
     """rsl_rl/rsl_rl/algorithms/moe_ng_cts.py: MoECTS whose student latent comes from the no-goal encoder (the model's `student_latent` hook)."""
+
+
+def _balance(weights):
+    """mean((mean_batch(gate) - 1/E)^2) (ac_moe_cts.py:186-189)"""
+    return (weights.mean(dim=0) - 1.0 / weights.shape[1]).pow(2).mean()
+
+
+class ACMoECTS(CTS):
+    """CTS with the mixture-of-experts actor / expert critic (rsl_rl/rsl_rl/algorithms/ac_moe_cts.py:40-250): the policy loss adds
+    coef * load-balance of the ACTOR gate over the whole [teacher | student] mini-batch; update() returns it after the latent loss.
+    compute_returns takes the proprioceptive observation too (the value head mixes its experts with the actor gate)."""
+    _NUM_POLICY_LOGS = 1
+
+    def __init__(self, model, num_envs, history_length, load_balance_coef=0.01, **kwargs):
+        super().__init__(model, num_envs, history_length, **kwargs)
+        self.load_balance_coef = load_balance_coef
+
+    def _policy_extra(self, loss, aux):
+        lb = _balance(aux)
+        self._policy_logs = (lb.detach(),)
+        return loss + self.load_balance_coef * lb
+
+    def compute_returns(self, last_obs, last_privileged_obs, last_history):
+        super().compute_returns(last_privileged_obs, last_history, last_obs)
+
+
+class DualMoECTS(ACMoECTS):
+    """AC-MoE heads + the MoE student encoder (dual_moe_cts.py:40-262): returns (..., latent, student load balance, actor load balance)."""
+    _NUM_STUDENT_LOGS = 2
+
+    def _student_losses(self, hist_s, priv_s):
+        student_latent, gate = self.model.student_latent(hist_s)
+        with torch.no_grad():
+            teacher_latent = self.model.teacher_encoder(priv_s)
+        latent_loss = (teacher_latent - student_latent).pow(2).mean()
+        lb = _balance(gate)
+        return latent_loss + self.load_balance_coef * lb, (latent_loss, lb)

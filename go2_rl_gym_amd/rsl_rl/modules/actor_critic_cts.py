@@ -55,6 +55,17 @@ class ActorCriticCTS(nn.Module):
     def student_parameters(self):
         return self.student_encoder.parameters()
 
+    # -- the two heads as hooks (the AC-MoE variants replace them): action mean from [latent, obs]; value (+ auxiliary gate weights) --
+    def policy_mean(self, latent, obs):
+        return self.actor(torch.cat([latent, obs], dim=1))
+
+    def value(self, latent, obs, privileged_obs):
+        return self.critic(torch.cat([latent.detach(), privileged_obs], dim=1)), None
+
+    def policy_parameter_groups(self):
+        """optimizer1's param groups, in the reference's order (cts.py:72-77)."""
+        return [list(self.teacher_encoder.parameters()), list(self.critic.parameters()), list(self.actor.parameters()), [self.std]]
+
     def student_latent(self, history):
         """-> (latent, gating weights or None)"""
         return self.student_encoder(history), None
@@ -79,7 +90,8 @@ class ActorCriticCTS(nn.Module):
         return self.distribution.entropy().sum(dim=-1)
 
     def update_distribution(self, latent_and_obs):
-        mean = self.actor(latent_and_obs)
+        L = latent_and_obs.shape[1] - self.num_actor_obs
+        mean = self.policy_mean(latent_and_obs[:, :L], latent_and_obs[:, L:])
         self.distribution = Normal(mean, mean * 0.0 + self.std, validate_args=False)
 
     def _noise(self, like):
@@ -100,11 +112,11 @@ class ActorCriticCTS(nn.Module):
     def act_inference(self, obs):
         self.history = torch.cat([self.history[:, 1:], obs.unsqueeze(1)], dim=1)
         latent = self.student_latent(self.history.flatten(1))[0]
-        return self.actor(torch.cat([latent, obs], dim=1))
+        return self.policy_mean(latent, obs)
 
     def evaluate(self, privileged_obs, history, is_teacher, **kwargs):
         latent = self.teacher_encoder(privileged_obs) if is_teacher else self.student_latent(history)[0]
-        return self.critic(torch.cat([latent.detach(), privileged_obs], dim=1))
+        return self.value(latent, None, privileged_obs)[0]
 
     # -- whole-batch surface: rows [0, n_teacher) are teacher rows, the rest student rows --------------------
     def latents(self, privileged_obs, history, n_teacher):
@@ -116,5 +128,5 @@ class ActorCriticCTS(nn.Module):
         self.update_distribution(torch.cat([latent, obs], dim=1))
         return self._sample()
 
-    def evaluate_joint(self, privileged_obs, latent):
-        return self.critic(torch.cat([latent.detach(), privileged_obs], dim=1))
+    def evaluate_joint(self, privileged_obs, latent, obs=None):
+        return self.value(latent, obs, privileged_obs)[0]

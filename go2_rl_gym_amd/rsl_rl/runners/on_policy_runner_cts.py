@@ -10,17 +10,19 @@ from collections import deque
 
 import torch
 
-from ..algorithms import CTS, MoECTS, MoENGCTS
-from ..modules import ActorCriticCTS, ActorCriticMoECTS, ActorCriticMoENGCTS
+from ..algorithms import CTS, ACMoECTS, DualMoECTS, MoECTS, MoENGCTS
+from ..modules import ActorCriticACMoECTS, ActorCriticCTS, ActorCriticDualMoECTS, ActorCriticMoECTS, ActorCriticMoENGCTS
 from .on_policy_runner import OnPolicyRunner
 
-_POLICIES = {"ActorCriticCTS": ActorCriticCTS, "ActorCriticMoECTS": ActorCriticMoECTS, "ActorCriticMoENGCTS": ActorCriticMoENGCTS}
-_ALGS = {"CTS": CTS, "MoECTS": MoECTS, "MoENGCTS": MoENGCTS}
+_POLICIES = {"ActorCriticCTS": ActorCriticCTS, "ActorCriticMoECTS": ActorCriticMoECTS, "ActorCriticMoENGCTS": ActorCriticMoENGCTS,
+             "ActorCriticACMoECTS": ActorCriticACMoECTS, "ActorCriticDualMoECTS": ActorCriticDualMoECTS}
+_ALGS = {"CTS": CTS, "MoECTS": MoECTS, "MoENGCTS": MoENGCTS, "ACMoECTS": ACMoECTS, "DualMoECTS": DualMoECTS}
 
 
 class OnPolicyRunnerCTS(OnPolicyRunner):
     _LOSS_NAMES = OnPolicyRunner._LOSS_NAMES + (("mean_entropy_loss", "Loss/entropy", "Entropy loss:"), ("mean_latent_loss", "Loss/latent", "Latent loss:"),
-                                                ("mean_load_balance_loss", "Loss/load_balance", "Load balance loss:"))
+                                                ("mean_load_balance_loss", "Loss/load_balance", "Load balance loss:"),
+                                                ("mean_actor_load_balance_loss", "Loss/actor_load_balance", "Actor load balance loss:"))
 
     def _build_algorithm(self, train_cfg, use_graphs):
         env = self.env
@@ -31,7 +33,7 @@ class OnPolicyRunnerCTS(OnPolicyRunner):
         H = self.history_length = train_cfg["history_length"]
         name = self.cfg["policy_class_name"]
         if name not in _POLICIES or self.cfg["algorithm_class_name"] not in _ALGS:
-            raise NotImplementedError("policy %r / algorithm %r: CTS, MoECTS and MoENGCTS are built (SURVEY 8 f2; the MCP / AC-MoE / Dual-MoE ablations are not)" % (name, self.cfg["algorithm_class_name"]))
+            raise NotImplementedError("policy %r / algorithm %r: CTS, MoECTS, MoENGCTS, ACMoECTS and DualMoECTS are built (the MCP ablation is not)" % (name, self.cfg["algorithm_class_name"]))
         model = _POLICIES[name](env.num_obs, env.num_privileged_obs, env.num_actions, env.num_envs, H, **self.policy_cfg).to(self.device)
         self.alg = _ALGS[self.cfg["algorithm_class_name"]](model, env.num_envs, H, device=self.device, lib=self.lib, use_graphs=use_graphs, **self.alg_cfg)
         self.history = torch.zeros(env.num_envs, H, env.num_obs, device=self.device)
@@ -79,7 +81,11 @@ class OnPolicyRunnerCTS(OnPolicyRunner):
         return ep_infos
 
     def _compute_returns(self):
-        self.alg.compute_returns(self.env.get_privileged_observations().to(self.device), self.history.flatten(1))
+        obs, priv = self.env.get_observations().to(self.device), self.env.get_privileged_observations().to(self.device)
+        if isinstance(self.alg, ACMoECTS):        # (on_policy_runner_cts.py:174-177)
+            self.alg.compute_returns(obs, priv, self.history.flatten(1))
+        else:
+            self.alg.compute_returns(priv, self.history.flatten(1))
 
     def _collect_episode_stats(self, bk):
         m = bk["fin_mask"].cpu().numpy()

@@ -96,6 +96,46 @@ class _MoENGCTSPolicy(nn.Module):
         self.history = torch.zeros_like(self.history)
 
 
+class _ACMoECTSPolicy(nn.Module):
+    """forward(obs) -> (action, (actor gate weights, latent))   (exporter.py:165-171)"""
+
+    def __init__(self, actor_moe, student_encoder, history_length: int, num_obs: int, normalizer):
+        super().__init__()
+        self.actor, self.student_encoder, self.normalizer = actor_moe, student_encoder, normalizer
+        self.history = torch.zeros(1, history_length, num_obs)
+
+    def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]:
+        x = self.normalizer(x)
+        self.history = torch.cat([self.history[:, 1:], x.unsqueeze(1)], dim=1)
+        latent = self.student_encoder(self.history.flatten(1))
+        mean, weights = self.actor(torch.cat([latent, x], dim=1))
+        return mean, (weights, latent)
+
+    @torch.jit.export
+    def reset(self):
+        self.history = torch.zeros_like(self.history)
+
+
+class _DualMoECTSPolicy(nn.Module):
+    """forward(obs) -> (action, (student gate weights, actor gate weights, latent))   (exporter.py:173-180)"""
+
+    def __init__(self, actor_moe, student_moe_encoder, history_length: int, num_obs: int, normalizer):
+        super().__init__()
+        self.actor, self.student_moe_encoder, self.normalizer = actor_moe, student_moe_encoder, normalizer
+        self.history = torch.zeros(1, history_length, num_obs)
+
+    def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+        x = self.normalizer(x)
+        self.history = torch.cat([self.history[:, 1:], x.unsqueeze(1)], dim=1)
+        latent, sw = self.student_moe_encoder(self.history.flatten(1))
+        mean, aw = self.actor(torch.cat([latent, x], dim=1))
+        return mean, (sw, aw, latent)
+
+    @torch.jit.export
+    def reset(self):
+        self.history = torch.zeros_like(self.history)
+
+
 def _cpu_copy(m):
     return _plain(copy.deepcopy(m).cpu())
 
@@ -106,6 +146,11 @@ def _deployment_module(policy, normalizer=None):
     norm = _cpu_copy(normalizer) if normalizer else nn.Identity()
     if not hasattr(policy, "actor"):
         raise ValueError("Policy does not have an actor/student module.")
+    if hasattr(policy, "actor_moe"):
+        am = _cpu_copy(policy.actor_moe)
+        if hasattr(policy, "student_moe_encoder"):
+            return _DualMoECTSPolicy(am, _cpu_copy(policy.student_moe_encoder), policy.history.shape[1], policy.history.shape[2], norm)
+        return _ACMoECTSPolicy(am, _cpu_copy(policy.student_encoder), policy.history.shape[1], policy.history.shape[2], norm)
     actor = _cpu_copy(policy.actor)
     if hasattr(policy, "student_moe_encoder") and hasattr(policy, "obs_no_goal_mask"):
         return _MoENGCTSPolicy(actor, _cpu_copy(policy.student_moe_encoder), policy.obs_no_goal_mask.detach().clone().cpu(), policy.history.shape[1], policy.history.shape[2], norm)
@@ -137,7 +182,8 @@ class _OnnxPolicy(nn.Module):
     def __init__(self, policy, normalizer=None):
         super().__init__()
         self.normalizer = _cpu_copy(normalizer) if normalizer else nn.Identity()
-        self.actor = _cpu_copy(policy.actor)
+        self.actor = _cpu_copy(policy.actor_moe if hasattr(policy, "actor_moe") else policy.actor)
+        self.actor_is_moe = hasattr(policy, "actor_moe")
         self.kind = "moe" if hasattr(policy, "student_moe_encoder") else ("cts" if hasattr(policy, "student_encoder") else "ppo")
         self.encoder = _cpu_copy(policy.student_moe_encoder) if self.kind == "moe" else (_cpu_copy(policy.student_encoder) if self.kind == "cts" else None)
         obs_dim = sum(_TERM_DIMS)
@@ -159,6 +205,9 @@ class _OnnxPolicy(nn.Module):
         last = history[:, -obs_dim:]
         if self.kind == "ppo":
             return self.actor(last)
+        if self.actor_is_moe:                  # AC-MoE / Dual-MoE: the actor returns (mean, gate weights)
+            latent = self.encoder(history) if self.kind == "cts" else self.encoder(history)[0]
+            return self.actor(torch.cat([latent, last], dim=1))[0]
         if self.kind == "cts":
             return self.actor(torch.cat([self.encoder(history), last], dim=1))
         if self.no_goal_mask is not None:      # MoE-NG: the experts read the history without the command entries (:268-277)

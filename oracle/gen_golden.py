@@ -439,6 +439,10 @@ def gen_cts(kind, seed=21):
     if kind == "MoECTS":
         policy["expert_num"] = 4
         algorithm["load_balance_coef"] = 0.01
+    if kind in ("ACMoECTS", "DualMoECTS"):
+        policy["expert_num"] = 4
+        policy["student_encoder_hidden_dims"] = [32, 16] if kind == "ACMoECTS" else [32, 16, 8]
+        policy["actor_hidden_dims"] = [32, 16, 8]; policy["critic_hidden_dims"] = [32, 16, 8]
     if kind == "MoENGCTS":
         policy["student_encoder_hidden_dims"] = [32, 16]
         policy["student_expert_num"] = 4
@@ -514,10 +518,11 @@ def gen_cts(kind, seed=21):
         if t == "reset":
             jit.reset()
             continue
-        a, (w, l) = jit(obs[t][:1])
+        a, extra = jit(obs[t][:1])
+        w, l = extra[0], extra[-1]                      # (weights | None, [actor weights,] latent)
         acts.append(a.detach().numpy().copy()); lats.append(l.detach().numpy().copy())
         if w is not None:
-            wts.append(w.detach().numpy().copy())
+            wts.append(np.concatenate([x.detach().numpy() for x in extra[:-1]], axis=-1))
     out["jit_actions"], out["jit_latent"] = np.stack(acts), np.stack(lats)
     if wts:
         out["jit_weights"] = np.stack(wts)
@@ -555,6 +560,8 @@ def main():
     _save(files, "cts_iteration.npz", gen_cts("CTS"))
     _save(files, "moe_cts_iteration.npz", gen_cts("MoECTS"))
     _save(files, "moe_ng_cts_iteration.npz", gen_cts("MoENGCTS"))
+    _save(files, "ac_moe_cts_iteration.npz", gen_cts("ACMoECTS"))
+    _save(files, "dual_moe_cts_iteration.npz", gen_cts("DualMoECTS"))
     for f in files:
         files[f] = hashlib.sha256(open(os.path.join(OUT, f), "rb").read()).hexdigest()
     try:

@@ -14,7 +14,7 @@ import pytest
 import torch
 
 from helpers import ROOT, HostSim, load_oracle
-from go2_rl_gym_amd.rsl_rl.modules import ActorCritic, ActorCriticCTS, ActorCriticMoECTS, ActorCriticMoENGCTS
+from go2_rl_gym_amd.rsl_rl.modules import ActorCritic, ActorCriticACMoECTS, ActorCriticCTS, ActorCriticDualMoECTS, ActorCriticMoECTS, ActorCriticMoENGCTS
 from go2_rl_gym_amd.utils.exporter import _OnnxPolicy, export_policy_as_jit, export_policy_as_onnx, export_policy_as_pkl
 
 G = os.path.join(ROOT, "tests", "golden")
@@ -54,11 +54,14 @@ def test_pretrained_reference_policy_roundtrip(tmp_path):
 
 
 @pytest.mark.parametrize("kind,fixture,cls", [("CTS", "cts_iteration.npz", ActorCriticCTS), ("MoECTS", "moe_cts_iteration.npz", ActorCriticMoECTS),
-                                              ("MoENGCTS", "moe_ng_cts_iteration.npz", ActorCriticMoENGCTS)])
+                                              ("MoENGCTS", "moe_ng_cts_iteration.npz", ActorCriticMoENGCTS), ("ACMoECTS", "ac_moe_cts_iteration.npz", ActorCriticACMoECTS),
+                                              ("DualMoECTS", "dual_moe_cts_iteration.npz", ActorCriticDualMoECTS)])
 def test_exported_cts_policies_match_reference_exporter(kind, fixture, cls, tmp_path):
     g = dict(np.load(os.path.join(G, fixture)))
     kw = dict(actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16], teacher_encoder_hidden_dims=[32, 16], latent_dim=8,
               student_encoder_hidden_dims=[32, 16] if kind == "CTS" else [32, 16, 8])
+    if kind in ("ACMoECTS", "DualMoECTS"):
+        kw.update(expert_num=4, student_encoder_hidden_dims=[32, 16] if kind == "ACMoECTS" else [32, 16, 8], actor_hidden_dims=[32, 16, 8], critic_hidden_dims=[32, 16, 8])
     if kind == "MoECTS":
         kw["expert_num"] = 4
     if kind == "MoENGCTS":
@@ -72,10 +75,11 @@ def test_exported_cts_policies_match_reference_exporter(kind, fixture, cls, tmp_
         if t == "reset":
             jit.reset()
             continue
-        a, (w, lat) = jit(obs[t][:1])
+        a, extra = jit(obs[t][:1])
+        w, lat = extra[0], extra[-1]
         acts.append(a.detach().numpy()); lats.append(lat.detach().numpy())
         if w is not None:
-            wts.append(w.detach().numpy())
+            wts.append(np.concatenate([x.detach().numpy() for x in extra[:-1]], axis=-1))
     np.testing.assert_allclose(np.stack(acts), g["jit_actions"], atol=2e-6)
     np.testing.assert_allclose(np.stack(lats), g["jit_latent"], atol=2e-6)
     if kind != "CTS":

@@ -281,7 +281,7 @@ def test_cts_kernels_on_gpu(hip):
     assert abs(np.abs(res["hip"][0][split:]).mean() / np.abs(res["hip"][0][:split]).mean() - 3.0) < 0.5
 
 
-@pytest.mark.parametrize("task", ["go2_flat_cts", "go2_moe_cts", "go2_moe_ng_cts"])
+@pytest.mark.parametrize("task", ["go2_flat_cts", "go2_moe_cts", "go2_moe_ng_cts", "go2_ac_moe_cts", "go2_dual_moe_cts"])
 def test_cts_training_graph_vs_eager_on_gpu(hip, task):
     """CTS / MoE-CTS through the product path, HIP-graph mode against eager mode from the same seeds (the eager arithmetic is
     pinned to the reference in tests/test_cts_golden.py)."""
