@@ -68,6 +68,10 @@ class _RolloutHeads:
         cur = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream()
+            try:    # the critic's AccumulateGrad nodes live on the side stream on purpose
+                torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+            except AttributeError:
+                pass
         self._side.wait_stream(cur)
         with torch.cuda.stream(self._side):
             b = side_fn()
