@@ -36,7 +36,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--num-envs", type=int, default=NUM_ENVS, help="envs PER GPU (weak scaling)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--task", default="go2_flat", choices=["go2_flat", "go2", "go2_flat_cts", "go2_flat_moe_cts", "go2_cts", "go2_moe_cts", "go2_moe_ng_cts", "go2_ac_moe_cts", "go2_dual_moe_cts"],
+    p.add_argument("--task", default="go2_flat", choices=["go2_flat", "go2", "go2_flat_cts", "go2_flat_moe_cts", "go2_cts", "go2_moe_cts", "go2_moe_ng_cts", "go2_ac_moe_cts", "go2_dual_moe_cts", "go2_mcp_cts"],
                    help="go2_flat is the BASELINE workload; the others are extra lines (rough curriculum terrain, CTS / MoE-CTS algorithms), never the headline")
     return p.parse_args()
 

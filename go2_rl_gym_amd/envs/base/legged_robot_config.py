@@ -364,3 +364,15 @@ class LeggedRobotCfgDualMoECTS(LeggedRobotCfgCTS):
     class runner(LeggedRobotCfgCTS.runner):
         policy_class_name = "ActorCriticDualMoECTS"
         algorithm_class_name = "DualMoECTS"
+
+
+class LeggedRobotCfgMCPCTS(LeggedRobotCfgCTS):
+    """Multiplicative-compositional actor (legged_robot_config.py:373-380)."""
+
+    class policy(LeggedRobotCfgCTS.policy):
+        obs_no_goal_mask = None
+        student_expert_num = 8
+
+    class runner(LeggedRobotCfgCTS.runner):
+        policy_class_name = "ActorCriticMCPCTS"
+        algorithm_class_name = "MCPCTS"

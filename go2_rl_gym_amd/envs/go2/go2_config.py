@@ -3,7 +3,7 @@
 (legged_gym/envs/go2/go2_config_fast_flat_move.py:98; the BASELINE workload "task=go2 flat terrain")."""
 import math
 
-from ..base.legged_robot_config import LeggedRobotCfg, LeggedRobotCfgACMoECTS, LeggedRobotCfgCTS, LeggedRobotCfgDualMoECTS, LeggedRobotCfgMoECTS, LeggedRobotCfgMoENGCTS, LeggedRobotCfgPPO, _max_cmd_table
+from ..base.legged_robot_config import LeggedRobotCfg, LeggedRobotCfgACMoECTS, LeggedRobotCfgCTS, LeggedRobotCfgDualMoECTS, LeggedRobotCfgMCPCTS, LeggedRobotCfgMoECTS, LeggedRobotCfgMoENGCTS, LeggedRobotCfgPPO, _max_cmd_table
 
 _LEGS = ("FL", "FR", "RL", "RR")
 
@@ -222,5 +222,17 @@ class GO2CfgDualMoECTS(LeggedRobotCfgDualMoECTS):   # go2_config.py:266-274
     class runner(LeggedRobotCfgDualMoECTS.runner):
         run_name = ""
         experiment_name = "go2_dual_moe_cts"
+        max_iterations = 150000
+        save_interval = 500
+
+
+class GO2CfgMCPCTS(LeggedRobotCfgMCPCTS):           # go2_config.py:245-254
+    class policy(LeggedRobotCfgMCPCTS.policy):
+        obs_no_goal_mask = [True] * 6 + [False] * 3 + [True] * 36
+        student_expert_num = 8
+
+    class runner(LeggedRobotCfgMCPCTS.runner):
+        run_name = ""
+        experiment_name = "go2_mcp_cts"
         max_iterations = 150000
         save_interval = 500

@@ -1,3 +1,3 @@
 from .ppo import PPO
 from .cts import CTS
-from .moe_cts import ACMoECTS, DualMoECTS, MoECTS, MoENGCTS
+from .moe_cts import ACMoECTS, DualMoECTS, MCPCTS, MoECTS, MoENGCTS

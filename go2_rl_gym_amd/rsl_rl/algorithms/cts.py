@@ -42,6 +42,8 @@ class CTS(_RolloutHeads):
         self.use_graphs = on_gpu if use_graphs is None else bool(use_graphs and on_gpu)
         self.fused_loss = (on_gpu and lib is not None) if fused_loss is None else bool(fused_loss and lib is not None)
         self.fused_rollout = (on_gpu and lib is not None) if fused_rollout is None else bool(fused_rollout and lib is not None)
+        if getattr(model, "state_dependent_std", False):       # MCP actor: the fused heads assume one std per action dimension
+            self.fused_loss = self.fused_rollout = False
         if on_gpu and lib is not None and os.environ.get("GO2_FUSED_MLP", "0") == "1":
             from ..modules import fused
             fused.set_library(lib)

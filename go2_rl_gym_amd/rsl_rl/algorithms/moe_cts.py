@@ -61,3 +61,7 @@ class DualMoECTS(ACMoECTS):
         latent_loss = (teacher_latent - student_latent).pow(2).mean()
         lb = _balance(gate)
         return latent_loss + self.load_balance_coef * lb, (latent_loss, lb)
+
+
+class MCPCTS(CTS):
+    """rsl_rl/rsl_rl/algorithms/mcp_cts.py: CTS on the multiplicative-compositional actor (3 param groups: teacher encoder, critic, actor_mcp)."""

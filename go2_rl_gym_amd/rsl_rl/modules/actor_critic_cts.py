@@ -59,6 +59,12 @@ class ActorCriticCTS(nn.Module):
     def policy_mean(self, latent, obs):
         return self.actor(torch.cat([latent, obs], dim=1))
 
+    state_dependent_std = False
+
+    def policy_dist(self, latent, obs):
+        mean = self.policy_mean(latent, obs)
+        return mean, mean * 0.0 + self.std
+
     def value(self, latent, obs, privileged_obs):
         return self.critic(torch.cat([latent.detach(), privileged_obs], dim=1)), None
 
@@ -91,8 +97,8 @@ class ActorCriticCTS(nn.Module):
 
     def update_distribution(self, latent_and_obs):
         L = latent_and_obs.shape[1] - self.num_actor_obs
-        mean = self.policy_mean(latent_and_obs[:, :L], latent_and_obs[:, L:])
-        self.distribution = Normal(mean, mean * 0.0 + self.std, validate_args=False)
+        mean, std = self.policy_dist(latent_and_obs[:, :L], latent_and_obs[:, L:])
+        self.distribution = Normal(mean, std, validate_args=False)
 
     def _noise(self, like):
         return torch.randn_like(like)

@@ -250,7 +250,8 @@ class OnPolicyRunner:
                 value = torch.mean(torch.cat(vals))
                 self.writer.add_scalar(("Terrain/" if "terrain" in key else "Episode/") + key, value, locs["it"])
                 ep_string += f"""{f'Mean episode {key}:':>{pad}} {value:.4f}\n"""
-        mean_std = self.alg.actor_critic.std.mean()
+        ac = self.alg.actor_critic
+        mean_std = ac.std.mean() if hasattr(ac, "std") else ac.action_std.mean()       # MCP-CTS has no std parameter (on_policy_runner_cts.py:218-219)
         fps = int(self.num_steps_per_env * self.env.num_envs / (locs["collection_time"] + locs["learn_time"]))
         w = self.writer
         for (name, tag, _), v in zip(self._LOSS_NAMES, locs["losses"]):

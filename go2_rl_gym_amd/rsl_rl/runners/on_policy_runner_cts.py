@@ -10,13 +10,13 @@ from collections import deque
 
 import torch
 
-from ..algorithms import CTS, ACMoECTS, DualMoECTS, MoECTS, MoENGCTS
-from ..modules import ActorCriticACMoECTS, ActorCriticCTS, ActorCriticDualMoECTS, ActorCriticMoECTS, ActorCriticMoENGCTS
+from ..algorithms import CTS, ACMoECTS, DualMoECTS, MCPCTS, MoECTS, MoENGCTS
+from ..modules import ActorCriticACMoECTS, ActorCriticCTS, ActorCriticDualMoECTS, ActorCriticMCPCTS, ActorCriticMoECTS, ActorCriticMoENGCTS
 from .on_policy_runner import OnPolicyRunner
 
 _POLICIES = {"ActorCriticCTS": ActorCriticCTS, "ActorCriticMoECTS": ActorCriticMoECTS, "ActorCriticMoENGCTS": ActorCriticMoENGCTS,
-             "ActorCriticACMoECTS": ActorCriticACMoECTS, "ActorCriticDualMoECTS": ActorCriticDualMoECTS}
-_ALGS = {"CTS": CTS, "MoECTS": MoECTS, "MoENGCTS": MoENGCTS, "ACMoECTS": ACMoECTS, "DualMoECTS": DualMoECTS}
+             "ActorCriticACMoECTS": ActorCriticACMoECTS, "ActorCriticDualMoECTS": ActorCriticDualMoECTS, "ActorCriticMCPCTS": ActorCriticMCPCTS}
+_ALGS = {"CTS": CTS, "MoECTS": MoECTS, "MoENGCTS": MoENGCTS, "ACMoECTS": ACMoECTS, "DualMoECTS": DualMoECTS, "MCPCTS": MCPCTS}
 
 
 class OnPolicyRunnerCTS(OnPolicyRunner):
@@ -33,7 +33,7 @@ class OnPolicyRunnerCTS(OnPolicyRunner):
         H = self.history_length = train_cfg["history_length"]
         name = self.cfg["policy_class_name"]
         if name not in _POLICIES or self.cfg["algorithm_class_name"] not in _ALGS:
-            raise NotImplementedError("policy %r / algorithm %r: CTS, MoECTS, MoENGCTS, ACMoECTS and DualMoECTS are built (the MCP ablation is not)" % (name, self.cfg["algorithm_class_name"]))
+            raise NotImplementedError("policy %r / algorithm %r: the reference's six CTS-family algorithms are built" % (name, self.cfg["algorithm_class_name"]))
         model = _POLICIES[name](env.num_obs, env.num_privileged_obs, env.num_actions, env.num_envs, H, **self.policy_cfg).to(self.device)
         self.alg = _ALGS[self.cfg["algorithm_class_name"]](model, env.num_envs, H, device=self.device, lib=self.lib, use_graphs=use_graphs, **self.alg_cfg)
         self.history = torch.zeros(env.num_envs, H, env.num_obs, device=self.device)

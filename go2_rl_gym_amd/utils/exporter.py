@@ -96,6 +96,27 @@ class _MoENGCTSPolicy(nn.Module):
         self.history = torch.zeros_like(self.history)
 
 
+class _MCPCTSPolicy(nn.Module):
+    """forward(obs) -> (action mean, (gate weights, latent))   (exporter.py:153-163)"""
+
+    def __init__(self, actor_mcp, student_encoder, mask, history_length: int, num_obs: int, normalizer):
+        super().__init__()
+        self.actor, self.student_encoder, self.normalizer = actor_mcp, student_encoder, normalizer
+        self.obs_no_goal_mask = mask
+        self.history = torch.zeros(1, history_length, num_obs)
+
+    def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]:
+        x = self.normalizer(x)
+        self.history = torch.cat([self.history[:, 1:], x.unsqueeze(1)], dim=1)
+        latent = self.student_encoder(self.history.flatten(1))
+        mean, std, weights = self.actor(torch.cat([latent, x], dim=1), torch.cat([latent, x[:, self.obs_no_goal_mask]], dim=1))
+        return mean, (weights, latent)
+
+    @torch.jit.export
+    def reset(self):
+        self.history = torch.zeros_like(self.history)
+
+
 class _ACMoECTSPolicy(nn.Module):
     """forward(obs) -> (action, (actor gate weights, latent))   (exporter.py:165-171)"""
 
@@ -146,6 +167,9 @@ def _deployment_module(policy, normalizer=None):
     norm = _cpu_copy(normalizer) if normalizer else nn.Identity()
     if not hasattr(policy, "actor"):
         raise ValueError("Policy does not have an actor/student module.")
+    if hasattr(policy, "actor_mcp"):
+        return _MCPCTSPolicy(_cpu_copy(policy.actor_mcp), _cpu_copy(policy.student_encoder), policy.obs_no_goal_mask.detach().clone().cpu(),
+                             policy.history.shape[1], policy.history.shape[2], norm)
     if hasattr(policy, "actor_moe"):
         am = _cpu_copy(policy.actor_moe)
         if hasattr(policy, "student_moe_encoder"):
@@ -182,8 +206,9 @@ class _OnnxPolicy(nn.Module):
     def __init__(self, policy, normalizer=None):
         super().__init__()
         self.normalizer = _cpu_copy(normalizer) if normalizer else nn.Identity()
-        self.actor = _cpu_copy(policy.actor_moe if hasattr(policy, "actor_moe") else policy.actor)
+        self.actor = _cpu_copy(policy.actor_mcp if hasattr(policy, "actor_mcp") else (policy.actor_moe if hasattr(policy, "actor_moe") else policy.actor))
         self.actor_is_moe = hasattr(policy, "actor_moe")
+        self.actor_is_mcp = hasattr(policy, "actor_mcp")
         self.kind = "moe" if hasattr(policy, "student_moe_encoder") else ("cts" if hasattr(policy, "student_encoder") else "ppo")
         self.encoder = _cpu_copy(policy.student_moe_encoder) if self.kind == "moe" else (_cpu_copy(policy.student_encoder) if self.kind == "cts" else None)
         obs_dim = sum(_TERM_DIMS)
@@ -205,6 +230,10 @@ class _OnnxPolicy(nn.Module):
         last = history[:, -obs_dim:]
         if self.kind == "ppo":
             return self.actor(last)
+        if self.actor_is_mcp:                  # MCP: (mean, weights) from the full and the command-free input (:279-287)
+            latent = self.encoder(history)
+            mean, std, weights = self.actor(torch.cat([latent, last], dim=1), torch.cat([latent, last[:, self.no_goal_mask]], dim=1))
+            return mean, weights
         if self.actor_is_moe:                  # AC-MoE / Dual-MoE: the actor returns (mean, gate weights)
             latent = self.encoder(history) if self.kind == "cts" else self.encoder(history)[0]
             return self.actor(torch.cat([latent, last], dim=1))[0]

@@ -443,6 +443,9 @@ def gen_cts(kind, seed=21):
         policy["expert_num"] = 4
         policy["student_encoder_hidden_dims"] = [32, 16] if kind == "ACMoECTS" else [32, 16, 8]
         policy["actor_hidden_dims"] = [32, 16, 8]; policy["critic_hidden_dims"] = [32, 16, 8]
+    if kind == "MCPCTS":
+        policy.pop("init_noise_std")
+        policy.update(actor_hidden_dims=[32, 16], student_expert_num=4, obs_no_goal_mask=[True] * 6 + [False] * 3 + [True] * 36)
     if kind == "MoENGCTS":
         policy["student_encoder_hidden_dims"] = [32, 16]
         policy["student_expert_num"] = 4
@@ -562,6 +565,7 @@ def main():
     _save(files, "moe_ng_cts_iteration.npz", gen_cts("MoENGCTS"))
     _save(files, "ac_moe_cts_iteration.npz", gen_cts("ACMoECTS"))
     _save(files, "dual_moe_cts_iteration.npz", gen_cts("DualMoECTS"))
+    _save(files, "mcp_cts_iteration.npz", gen_cts("MCPCTS"))
     for f in files:
         files[f] = hashlib.sha256(open(os.path.join(OUT, f), "rb").read()).hexdigest()
     try:

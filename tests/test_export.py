@@ -14,7 +14,8 @@ import pytest
 import torch
 
 from helpers import ROOT, HostSim, load_oracle
-from go2_rl_gym_amd.rsl_rl.modules import ActorCritic, ActorCriticACMoECTS, ActorCriticCTS, ActorCriticDualMoECTS, ActorCriticMoECTS, ActorCriticMoENGCTS
+from go2_rl_gym_amd.rsl_rl.modules import (ActorCritic, ActorCriticACMoECTS, ActorCriticCTS, ActorCriticDualMoECTS, ActorCriticMCPCTS, ActorCriticMoECTS,
+                                           ActorCriticMoENGCTS)
 from go2_rl_gym_amd.utils.exporter import _OnnxPolicy, export_policy_as_jit, export_policy_as_onnx, export_policy_as_pkl
 
 G = os.path.join(ROOT, "tests", "golden")
@@ -55,7 +56,7 @@ def test_pretrained_reference_policy_roundtrip(tmp_path):
 
 @pytest.mark.parametrize("kind,fixture,cls", [("CTS", "cts_iteration.npz", ActorCriticCTS), ("MoECTS", "moe_cts_iteration.npz", ActorCriticMoECTS),
                                               ("MoENGCTS", "moe_ng_cts_iteration.npz", ActorCriticMoENGCTS), ("ACMoECTS", "ac_moe_cts_iteration.npz", ActorCriticACMoECTS),
-                                              ("DualMoECTS", "dual_moe_cts_iteration.npz", ActorCriticDualMoECTS)])
+                                              ("DualMoECTS", "dual_moe_cts_iteration.npz", ActorCriticDualMoECTS), ("MCPCTS", "mcp_cts_iteration.npz", ActorCriticMCPCTS)])
 def test_exported_cts_policies_match_reference_exporter(kind, fixture, cls, tmp_path):
     g = dict(np.load(os.path.join(G, fixture)))
     kw = dict(actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16], teacher_encoder_hidden_dims=[32, 16], latent_dim=8,
@@ -66,6 +67,8 @@ def test_exported_cts_policies_match_reference_exporter(kind, fixture, cls, tmp_
         kw["expert_num"] = 4
     if kind == "MoENGCTS":
         kw.update(student_encoder_hidden_dims=[32, 16], student_expert_num=4, obs_no_goal_mask=[True] * 6 + [False] * 3 + [True] * 36)
+    if kind == "MCPCTS":
+        kw.update(actor_hidden_dims=[32, 16], student_expert_num=4, obs_no_goal_mask=[True] * 6 + [False] * 3 + [True] * 36)
     m = cls(45, 263, 12, 32, 5, **kw)
     m.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w1_")})
     jit = torch.jit.load(export_policy_as_jit(m, str(tmp_path)))

@@ -281,7 +281,7 @@ def test_cts_kernels_on_gpu(hip):
     assert abs(np.abs(res["hip"][0][split:]).mean() / np.abs(res["hip"][0][:split]).mean() - 3.0) < 0.5
 
 
-@pytest.mark.parametrize("task", ["go2_flat_cts", "go2_moe_cts", "go2_moe_ng_cts", "go2_ac_moe_cts", "go2_dual_moe_cts"])
+@pytest.mark.parametrize("task", ["go2_flat_cts", "go2_moe_cts", "go2_moe_ng_cts", "go2_ac_moe_cts", "go2_dual_moe_cts", "go2_mcp_cts"])
 def test_cts_training_graph_vs_eager_on_gpu(hip, task):
     """CTS / MoE-CTS through the product path, HIP-graph mode against eager mode from the same seeds (the eager arithmetic is
     pinned to the reference in tests/test_cts_golden.py)."""
@@ -294,7 +294,7 @@ def test_cts_training_graph_vs_eager_on_gpu(hip, task):
         env, _ = task_registry.make_env(task, args)
         torch.manual_seed(3)
         runner, _ = task_registry.make_alg_runner(env, task, args, log_root=None, use_graphs=mode)
-        assert runner.use_graphs == mode and runner.alg.use_graphs == mode and runner.alg.fused_loss
+        assert runner.use_graphs == mode and runner.alg.use_graphs == mode and (runner.alg.fused_loss or task == "go2_mcp_cts")
         env.common_step_counter = 0
         runner.learn(5, init_at_random_ep_len=True)
         torch.cuda.synchronize()
