@@ -40,7 +40,7 @@ class ActorCriticACMoECTS(ActorCriticCTS):
     def value(self, latent, obs, privileged_obs):
         weights = self.actor_moe.gating_network(torch.cat([latent, obs], dim=1))                   # [B, E]  (latent NOT detached here, :127-129)
         experts_value = self.critic_experts(torch.cat([latent.detach(), privileged_obs], dim=1))   # [B, E, 1]
-        return torch.bmm(weights.unsqueeze(1), experts_value).squeeze(1), weights
+        return torch.sum(weights.unsqueeze(-1) * experts_value, dim=1), weights
 
     def policy_parameter_groups(self):
         return [list(self.teacher_encoder.parameters()), list(self.critic_experts.parameters()), list(self.actor_moe.parameters()), [self.std]]

@@ -33,7 +33,7 @@ class StudentMoENoGoalEncoder(nn.Module):
     def forward(self, obs, obs_no_goal):
         weights = self.gating_network(obs)                                            # [B, E]
         expert_latent = self.experts_out(self.experts_hidden(self.experts_backbone(obs_no_goal)))   # [B, E, latent]
-        return self.norm_layer(torch.bmm(weights.unsqueeze(1), expert_latent).squeeze(1)), weights
+        return self.norm_layer(torch.sum(weights.unsqueeze(-1) * expert_latent, dim=1)), weights
 
 
 class ActorCriticMoENGCTS(ActorCriticCTS):

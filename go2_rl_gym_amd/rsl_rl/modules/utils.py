@@ -99,7 +99,7 @@ class MoE(nn.Module):
     def forward(self, x):
         weights = self.gating_network(x)                               # [B, E]
         outs = self.experts(x)                                         # [B, E, out]
-        return torch.bmm(weights.unsqueeze(1), outs).squeeze(1), weights
+        return torch.sum(weights.unsqueeze(-1) * outs, dim=1), weights                   # [B, out]
 
 
 class StudentMoEEncoder(nn.Module):
