@@ -123,7 +123,7 @@ class CTS(_RolloutHeads):
         st.history[s].copy_(history)
         latent = self._latent_env_order(privileged_obs, history)
         if self.fused_rollout:
-            mu, value = self._pair(lambda: m.policy_mean(latent, obs), lambda: m.evaluate_joint(privileged_obs, latent, obs), enabled=self.use_graphs)
+            mu, value = self._pair(lambda: m.policy_mean(latent, obs), lambda: m.evaluate_joint(privileged_obs, latent, obs), enabled=self.use_graphs and not m.heads_share_parameters)
             return self._act_head(mu, m.std, m._noise(mu), value, s)
         t.actions = m.act_joint(obs, latent).detach()
         t.values = m.evaluate_joint(privileged_obs, latent, obs).detach()
@@ -162,7 +162,7 @@ class CTS(_RolloutHeads):
         m = self.model
         latent = m.latents(priv_b, hist_b, n_t)
         if self.fused_loss:
-            mu_b, (val_b, aux) = self._pair(lambda: m.policy_mean(latent, obs_b), lambda: m.value(latent, obs_b, priv_b), enabled=self.use_graphs)
+            mu_b, (val_b, aux) = self._pair(lambda: m.policy_mean(latent, obs_b), lambda: m.value(latent, obs_b, priv_b), enabled=self.use_graphs and not m.heads_share_parameters)
             self.surrogate_split = n_t
             loss, stats = _FusedPPOLoss.apply(mu_b, m.std, val_b, self, act_b, tv_b, adv_b, ret_b, old_lp_b, old_mu_b, old_sig_b)
             return self._policy_extra(loss, aux), stats[1], stats[0], stats[3], stats[2]

@@ -15,6 +15,8 @@ from .utils import MLP, Experts, MoE, StudentMoEEncoder, make_norm
 
 
 class ActorCriticACMoECTS(ActorCriticCTS):
+    heads_share_parameters = True       # the critic mixes its experts with the ACTOR's gate
+
     def __init__(self, num_obs, num_critic_obs, num_actions, num_envs, history_length, actor_hidden_dims=(512, 256, 128),
                  critic_hidden_dims=(512, 256, 128), teacher_encoder_hidden_dims=(512, 256), student_encoder_hidden_dims=(512, 256),
                  expert_num=8, activation="elu", init_noise_std=1.0, latent_dim=32, norm_type="l2norm", **kwargs):

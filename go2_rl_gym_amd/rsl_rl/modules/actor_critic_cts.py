@@ -60,6 +60,7 @@ class ActorCriticCTS(nn.Module):
         return self.actor(torch.cat([latent, obs], dim=1))
 
     state_dependent_std = False
+    heads_share_parameters = False      # True when value() reuses actor modules (AC-MoE gate): no two-stream split of the two heads then
 
     def policy_dist(self, latent, obs):
         mean = self.policy_mean(latent, obs)

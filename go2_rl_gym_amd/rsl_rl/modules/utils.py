@@ -71,9 +71,17 @@ class GroupedHeads(nn.Module):
 
     def forward(self, x):                                              # x [B, E*hidden] -> [B, E, out]
         B = x.shape[0]
+
         xe = x.view(B, self.groups, self.cin).transpose(0, 1)          # [E, B, hidden]
         w = self.weight.view(self.groups, self.cout, self.cin).transpose(1, 2)   # [E, hidden, out]
-        y = torch.baddbmm(self.bias.view(self.groups, 1, self.cout), xe, w)      # [E, B, out]
+        b = self.bias.view(self.groups, 1, self.cout)
+        if self.cout < 32 and x.is_cuda:
+            # narrow heads (12 actions, 1 value): the strided-batched GEMM with N < 32 runs ~100x slower on ROCm 7 (58 ms vs 0.5 ms
+            # per fwd+bwd at 24576 rows, tools/probe_heads.py) — pad the output to 32 zero columns and slice them off again
+            pad = 32 - self.cout
+            y = torch.baddbmm(F.pad(b, (0, pad)), xe, F.pad(w, (0, pad)))[..., :self.cout]
+        else:
+            y = torch.baddbmm(b, xe, w)                                 # [E, B, out]
         return y.transpose(0, 1)
 
 
