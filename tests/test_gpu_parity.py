@@ -293,7 +293,13 @@ def test_cts_training_graph_vs_eager_on_gpu(hip, task):
         args = get_args(["--task", task, "--num_envs", "512", "--headless", "--seed", "3"])
         env, _ = task_registry.make_env(task, args)
         torch.manual_seed(3)
-        runner, _ = task_registry.make_alg_runner(env, task, args, log_root=None, use_graphs=mode)
+        _, train_cfg = task_registry.get_cfgs(task)
+        sched0 = train_cfg.algorithm.schedule
+        train_cfg.algorithm.schedule = "fixed"      # the adaptive rate at 512 envs is chaotic (x1.5 per mini-batch): compare the two modes at a fixed rate
+        try:
+            runner, _ = task_registry.make_alg_runner(env, task, args, train_cfg=train_cfg, log_root=None, use_graphs=mode)
+        finally:
+            train_cfg.algorithm.schedule = sched0
         assert runner.use_graphs == mode and runner.alg.use_graphs == mode and (runner.alg.fused_loss or task == "go2_mcp_cts")
         env.common_step_counter = 0
         runner.learn(5, init_at_random_ep_len=True)
@@ -305,7 +311,9 @@ def test_cts_training_graph_vs_eager_on_gpu(hip, task):
         env.close()
     assert out[True][2] == out[False][2] == 5 * 24
     assert np.isfinite(out[True][1]).all() and out[True][4] > 0
-    assert 1.5 ** -8 < out[True][0] / out[False][0] < 1.5 ** 8        # the adaptive rate moves by x1.5 per mini-batch (100 of them); different sampling noise
+    assert abs(out[True][0] - 1e-3) < 1e-9 and abs(out[False][0] - 1e-3) < 1e-9
+    d = np.abs(out[True][1] - out[False][1])
+    assert np.median(d) < 5e-3, np.median(d)          # same data distribution, different noise: the weights stay close after 100 fixed-rate steps
     assert abs(out[True][3] - out[False][3]) < 0.05
 
 
