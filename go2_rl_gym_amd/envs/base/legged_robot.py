@@ -8,7 +8,6 @@ under the attribute names the reference uses and keeps the Pytho
 (common_step_counter, curricula) in sync.
 """
 import ctypes as C
-import math
 from itertools import product
 
 import numpy as np

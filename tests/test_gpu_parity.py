@@ -437,3 +437,17 @@ def test_error_codes_on_gpu(hip):
     cfg.terrain_mode = 0; cfg.struct_size += 8
     assert hip.go2sim_create(C.byref(cfg), 0, C.byref(h)) == abi.GO2SIM_EINVAL and b"mismatch" in hip.go2sim_last_error()
     assert hip.go2sim_step(None, None, None) != 0 and hip.go2sim_act_head(*([None] * 10), 4, 12, None) != 0
+
+
+def test_train_script_entry_point_on_gpu(hip, tmp_path, monkeypatch):
+    """scripts/train.py's train(args) — the reference's legged_gym/scripts/train.py:11-16 — for two iterations."""
+    import torch
+    from go2_rl_gym_amd.scripts import train as train_script
+    import sys
+    from go2_rl_gym_amd.utils import get_args
+    monkeypatch.setattr(sys.modules["go2_rl_gym_amd.utils.task_registry"], "ROOT_DIR", str(tmp_path))     # logs/<experiment>/... under the temp dir
+    args = get_args(["--task", "go2_flat", "--num_envs", "256", "--headless", "--max_iterations", "2"])
+    train_script.train(args)
+    runs = list((tmp_path / "logs" / "go2_flat_ppo").iterdir())
+    assert len(runs) == 1 and any(f.name.startswith("model_") for f in runs[0].iterdir())
+    torch.cuda.synchronize()
