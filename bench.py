@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALGO_BYTES_FLAT = 2936          # algorithmic bytes per env-step on a plane: 778 read + 2158 written
-ALGO_BYTES_ROUGH = 2936 + 187 * 4 + 187 * 3 * 2 + 27 * 4 * 2     # + measured_heights written, 3 int16 samples per scan point, 4 per contact candidate
+ALGO_BYTES_ROUGH = 2936 + 187 * 3 * 2 + 13 * 4 * 4               # SURVEY 8d ALGO_BYTES_HF = 4266: + 3 int16 samples per scan point, 13 contact shapes x 4 substeps x 4 B
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md)
 NUM_ENVS = 4096
 
@@ -32,8 +32,8 @@ NUM_ENVS = 4096
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--steps", type=int, default=100)     # 100 iterations = 9.8 M env-steps, ~3 s on one MI355X
+    p.add_argument("--warmup", type=int, default=20)     # resets / pushes / resamples reach their steady-state rates
     p.add_argument("--num-envs", type=int, default=NUM_ENVS, help="envs PER GPU (weak scaling)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--task", default="go2_flat", choices=["go2_flat", "go2", "go2_flat_cts", "go2_flat_moe_cts", "go2_cts", "go2_moe_cts", "go2_moe_ng_cts", "go2_ac_moe_cts", "go2_dual_moe_cts", "go2_mcp_cts"],
