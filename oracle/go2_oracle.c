@@ -1067,8 +1067,8 @@ int go2sim_step(Go2Sim* s, const float* actions, void* stream) {
   s->injected = inj;
   return go2sim_post_physics(s,stream);
 }
-int go2sim_set_root_state_indexed(Go2Sim* s, const int32_t* ids, int32_t count, void* stream) { (void)s;(void)ids;(void)count;(void)stream; return 0; }
-int go2sim_set_dof_state_indexed(Go2Sim* s, const int32_t* ids, int32_t count, void* stream) { (void)s;(void)ids;(void)count;(void)stream; return 0; }
+int go2sim_set_root_state_indexed(Go2Sim* s, const int32_t* ids, int32_t count, void* stream) { (void)ids;(void)count;(void)stream; return s ? 0 : GO2SIM_EINVAL; }   /* the API tensors are the state */
+int go2sim_set_dof_state_indexed(Go2Sim* s, const int32_t* ids, int32_t count, void* stream) { (void)ids;(void)count;(void)stream; return s ? 0 : GO2SIM_EINVAL; }
 int go2sim_set_common_step_counter(Go2Sim* s, int64_t v) { if (!s) return GO2SIM_EINVAL; s->common_step_counter=v; return 0; }
 int64_t go2sim_get_common_step_counter(Go2Sim* s) { return s ? s->common_step_counter : -1; }
 int go2sim_update_reward_curriculum(Go2Sim* s, int force) { if (!s) return GO2SIM_EINVAL; update_reward_curriculum(s,force); return 0; }

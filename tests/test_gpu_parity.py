@@ -451,3 +451,18 @@ def test_train_script_entry_point_on_gpu(hip, tmp_path, monkeypatch):
     runs = list((tmp_path / "logs" / "go2_flat_ppo").iterdir())
     assert len(runs) == 1 and any(f.name.startswith("model_") for f in runs[0].iterdir())
     torch.cuda.synchronize()
+
+
+def test_fine_grained_calls_equal_the_fused_step_on_gpu(hip):
+    """go2sim_simulate + go2sim_post_physics (two launches, the Isaac-Gym-shaped path) == go2sim_step (one fused launch), bit for bit."""
+    a_, b_ = DeviceSim(hip, num_envs=128, seed=4), DeviceSim(hip, num_envs=128, seed=4)
+    a_.reset_all(); b_.reset_all()
+    rng = np.random.default_rng(3)
+    for it in range(10):
+        act = rng.normal(0, 1, (128, 12)).astype(np.float32)
+        a_.step(act)
+        b_.actions[:] = act; b_.simulate(); b_.post_physics(); b_.torch.cuda.synchronize()
+        for k in ("root_states", "dof_state", "obs_buf", "privileged_obs_buf", "rew_buf", "reset_buf", "torques", "contact_forces"):
+            np.testing.assert_array_equal(np.asarray(getattr(a_, k)), np.asarray(getattr(b_, k)), err_msg="%s at %d" % (k, it))
+    assert hip.go2sim_get_common_step_counter(a_.h) == hip.go2sim_get_common_step_counter(b_.h) == 10
+    a_.close(); b_.close()

@@ -67,3 +67,58 @@ def test_free_trajectory_stays_statistically_close():
     zo, ze = np.asarray(so.root_states)[:, 2], np.asarray(se.root_states)[:, 2]
     assert abs(zo.mean() - ze.mean()) < 0.01 and 0.15 < ze.mean() < 0.40
     assert abs(np.asarray(so.rew_buf).mean() - np.asarray(se.rew_buf).mean()) < 5e-3
+
+
+@pytest.mark.parametrize("which", ["oracle", "lane_emulation"])
+def test_fine_grained_calls_equal_the_fused_step(which):
+    """The Isaac-Gym-shaped path — write actions, go2sim_simulate (the 4-substep torque/physics loop), then go2sim_post_physics — and the
+    fused go2sim_step give the same result from the same state; set_*_state_indexed accept the Python-side writes (the API tensors ARE
+    the state here, so a row written by the caller is simply what the next call reads)."""
+    import ctypes as C
+    lib = load_oracle() if which == "oracle" else load_emu()
+    a_, b_ = HostSim(lib, num_envs=24, seed=4), HostSim(lib, num_envs=24, seed=4)
+    a_.reset_all(); b_.reset_all()
+    rng = np.random.default_rng(3)
+    for it in range(12):
+        act = rng.normal(0, 1, (24, 12)).astype(np.float32)
+        if it == 5:       # teleport two robots through the API tensors, as reset code on top of Isaac Gym would
+            for s in (a_, b_):
+                s.root_states[3, :3] += np.array([0.5, -0.25, 0.1], np.float32); s.dof_state[7, :, 0] *= 0.9
+                ids = np.array([3, 7], np.int32)
+                assert lib.go2sim_set_root_state_indexed(s.h, ids.ctypes.data, 2, None) == 0
+                assert lib.go2sim_set_dof_state_indexed(s.h, ids.ctypes.data, 2, None) == 0
+        a_.step(act)
+        b_.actions[:] = act; b_.simulate(); b_.post_physics()
+        for k in ("root_states", "dof_state", "obs_buf", "privileged_obs_buf", "rew_buf", "reset_buf", "torques", "contact_forces", "commands"):
+            np.testing.assert_array_equal(np.asarray(getattr(a_, k)), np.asarray(getattr(b_, k)), err_msg="%s at %d" % (k, it))
+    assert lib.go2sim_get_common_step_counter(a_.h) == lib.go2sim_get_common_step_counter(b_.h) == 12
+    assert lib.go2sim_set_root_state_indexed(None, None, 0, None) != 0
+    a_.close(); b_.close()
+
+
+def test_curriculum_state_follows_the_counter():
+    """reward-curriculum scales, command ranges and zero-command probability as pure functions of common_step_counter // 24
+    (get_current_scale :154-168, update_command_ranges, zero_command_curriculum) — values at a few iterations of the go2 config."""
+    import ctypes as C
+    lib = load_emu()
+    s = HostSim(lib, num_envs=4)
+    rcs, cr, zp = (C.c_float * lib.abi.GO2_NUM_REWARDS)(), (C.c_float * 8)(), C.c_float()
+    names = lib.abi.reward_names
+
+    def state(it):
+        lib.go2sim_set_common_step_counter(s.h, it * 24)
+        assert lib.go2sim_get_curriculum_state(s.h, rcs, cr, C.byref(zp)) == 0
+        return {n: rcs[i] for i, n in enumerate(names)}, [[cr[2 * r], cr[2 * r + 1]] for r in range(4)], zp.value
+
+    r0, c0, z0 = state(0)
+    r1, c1, z1 = state(750)
+    r2, c2, z2 = state(60000)
+    assert abs(z0 - 0.0) < 1e-7 and abs(z1 - 0.05) < 1e-6 and abs(z2 - 0.1) < 1e-7          # zero_command_curriculum 0 -> 0.1 over 1500 iterations
+    np.testing.assert_allclose(c0[0], [-0.5, 0.5]); np.testing.assert_allclose(c2[0], [-2.0, 2.0])   # command_range_curriculum at iter 20000 / 50000
+    np.testing.assert_allclose(c2[2], [-2.0, 2.0], atol=1e-6)
+    cur = [n for n in names if r0[n] != r2[n]]
+    assert cur, "the go2 config has reward curricula"                                        # (go2_config.py:161-167)
+    for n in names:
+        if n not in cur:
+            assert r0[n] == r1[n] == r2[n] == 1.0
+    s.close()
