@@ -116,3 +116,59 @@ def test_flipped_robots_settle(which):
     assert (np.asarray(s.commands)[:, :3] == 0).all()                       # zero commands while the turn-over timer runs (:586-590)
     assert (np.asarray(s.turn_over_timer) > 0).all() and (np.asarray(s.turn_over_timer) <= 3.0 + 1e-3).all()     # 5 s (back) or 3 s (side) minus the 2 s simulated
     s.close()
+
+
+@pytest.mark.parametrize("which", ["oracle", "lane_emulation"])
+def test_coulomb_friction_cone(which):
+    """Tilted gravity = a slope; friction randomisation off, so mu = 0.5 * (1 + 1) = 1.  (i) every foot force stays inside the Coulomb cone
+    |F_t| <= mu F_n at every step on both slopes; (ii) with a firmer stance (Kp 40, Kd 1: the default 20 / 0.5 sags and tips over on a slope
+    without a policy; much stiffer gains leave the stable range of the explicit 200 Hz PD) the robot holds its place on an 11 degree
+    slope (tan = 0.2 << mu); (iii) on a 61 degree slope (tan = 1.8 >> mu) it goes downhill."""
+    from helpers import load_emu
+    lib = load_oracle() if which == "oracle" else load_emu()
+    out = {}
+    for tan_t in (0.2, 1.8):
+        th = np.arctan(tan_t)
+        g = [9.81 * np.sin(th), 0.0, -9.81 * np.cos(th)]                  # down-slope = +x
+        s = HostSim(lib, num_envs=6, gravity=g, push_robots=0, randomize_friction=0, randomize_restitution=0, randomize_action_delay=0,
+                    randomize_pd_gains=0, randomize_motor_strength=0, kp=[40.0] * 12, kd=[1.0] * 12, seed=2)
+        s.reset_all()
+        s.root_states[:, 3:7] = np.array([0, 0, 0, 1], np.float32); s.root_states[:, 7:13] = 0; s.root_states[:, 2] = 0.34
+        a = np.zeros((6, 12), np.float32)
+        worst, was_reset = 0.0, np.zeros(6, bool)
+        for it in range(100):
+            if it == 50:
+                x0 = np.asarray(s.root_states)[:, 0].copy()                # settled on the feet by now
+            s.step(a)
+            was_reset |= np.asarray(s.reset_buf) > 0
+            f = np.asarray(s.contact_forces)[:, [6, 10, 14, 18]].astype(np.float64)
+            ft, fn = np.hypot(f[..., 0], f[..., 1]), f[..., 2]
+            assert (fn >= -1e-3).all()
+            worst = max(worst, float((ft - 1.0 * fn).max()))
+        out[tan_t] = (np.asarray(s.root_states)[:, 0] - x0, worst, was_reset)
+        s.close()
+    assert out[0.2][1] < 0.05 and out[1.8][1] < 0.05, (out[0.2][1], out[1.8][1])         # cone respected (N; forces are impulse / 5 ms)
+    dx, _, rs = out[0.2]
+    assert rs.sum() <= 1 and np.abs(dx[~rs]).max() < 0.02, (dx, rs)                        # 1 s on the gentle slope: holds (an env whose episode
+    #                                                                                        ended in the window was re-spawned elsewhere)
+    assert (out[1.8][0][~out[1.8][2]] > 0.4).all(), out[1.8][0]
+
+
+def test_pd_drive_reaches_its_target_in_the_air():
+    """Robot held in zero gravity: the PD actuation (:594-618) drives every joint to q0 + action_scale * a and holds it (damped, no overshoot
+    beyond a few percent), torques saturating at the URDF effort limits on the way."""
+    s = HostSim(load_oracle(), num_envs=4, gravity=[0, 0, 0], push_robots=0, randomize_action_delay=0, randomize_motor_strength=0, randomize_pd_gains=0,
+                randomize_motor_zero_offset=0)
+    s.reset_all()
+    s.root_states[:, 2] = 3.0
+    a = np.tile(np.array([0.4, -0.6, 0.8] * 4, np.float32), (4, 1))
+    target = np.array(list(s.cfg.default_dof_pos), np.float32) + 0.25 * a[0]
+    peak = np.zeros(12)
+    for it in range(60):
+        s.step(a)
+        peak = np.maximum(peak, np.abs(np.asarray(s.torques)).max(0))
+    q = np.asarray(s.dof_state)[:, :, 0]
+    np.testing.assert_allclose(q, np.tile(target, (4, 1)), atol=5e-3)
+    assert np.abs(np.asarray(s.dof_state)[:, :, 1]).max() < 0.05
+    assert (peak <= np.array([23.7, 23.7, 35.55] * 4) + 1e-4).all()
+    s.close()
