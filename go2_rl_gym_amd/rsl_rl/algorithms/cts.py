@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.optim as optim
 
 from ..storage import RolloutStorageCTS
-from ._graph import CapturedStep
+from ._graph import CapturedStep, GradBucket, ReducedStep, collectives_in_graph
 from .ppo import _ADAM_IMPL, _collectives_on, _FusedPPOLoss, _RolloutHeads, _world, allreduce_mean_bucket
 
 
@@ -40,6 +40,9 @@ class CTS(_RolloutHeads):
         self.storage = None
         on_gpu = str(device).startswith("cuda")
         self.use_graphs = on_gpu if use_graphs is None else bool(use_graphs and on_gpu)
+        self._capture = self.use_graphs and use_graphs != "uncaptured"
+        if use_graphs == "uncaptured":     # the graph-mode update run eagerly on any device (CPU tests), see PPO
+            self.use_graphs = True
         self.fused_loss = (on_gpu and lib is not None) if fused_loss is None else bool(fused_loss and lib is not None)
         self.fused_rollout = (on_gpu and lib is not None) if fused_rollout is None else bool(fused_rollout and lib is not None)
         if getattr(model, "state_dependent_std", False):       # MCP actor: the fused heads assume one std per action dimension
@@ -52,8 +55,9 @@ class CTS(_RolloutHeads):
         self._params2 = list(self.model.student_parameters())
         if self.use_graphs:
             self._lr_t = torch.tensor(float(learning_rate), device=device)
-            self.optimizer1 = optim.Adam(groups1, lr=self._lr_t, capturable=True, **_ADAM_IMPL)
-            self.optimizer2 = optim.Adam(self._params2, lr=torch.tensor(float(student_encoder_learning_rate), device=device), capturable=True, **_ADAM_IMPL)
+            kw = dict(capturable=True, **_ADAM_IMPL) if self._capture else dict(foreach=False)
+            self.optimizer1 = optim.Adam(groups1, lr=self._lr_t, **kw)
+            self.optimizer2 = optim.Adam(self._params2, lr=torch.tensor(float(student_encoder_learning_rate), device=device), **kw)
         else:
             self._lr_t = None
             self.optimizer1 = optim.Adam(groups1, lr=learning_rate)
@@ -123,7 +127,7 @@ class CTS(_RolloutHeads):
         st.history[s].copy_(history)
         latent = self._latent_env_order(privileged_obs, history)
         if self.fused_rollout:
-            mu, value = self._pair(lambda: m.policy_mean(latent, obs), lambda: m.evaluate_joint(privileged_obs, latent, obs), enabled=self.use_graphs and not m.heads_share_parameters)
+            mu, value = self._pair(lambda: m.policy_mean(latent, obs), lambda: m.evaluate_joint(privileged_obs, latent, obs), enabled=self._capture and not m.heads_share_parameters)
             return self._act_head(mu, m.std, m._noise(mu), value, s)
         t.actions = m.act_joint(obs, latent).detach()
         t.values = m.evaluate_joint(privileged_obs, latent, obs).detach()
@@ -162,7 +166,7 @@ class CTS(_RolloutHeads):
         m = self.model
         latent = m.latents(priv_b, hist_b, n_t)
         if self.fused_loss:
-            mu_b, (val_b, aux) = self._pair(lambda: m.policy_mean(latent, obs_b), lambda: m.value(latent, obs_b, priv_b), enabled=self.use_graphs and not m.heads_share_parameters)
+            mu_b, (val_b, aux) = self._pair(lambda: m.policy_mean(latent, obs_b), lambda: m.value(latent, obs_b, priv_b), enabled=self._capture and not m.heads_share_parameters)
             self.surrogate_split = n_t
             loss, stats = _FusedPPOLoss.apply(mu_b, m.std, val_b, self, act_b, tv_b, adv_b, ret_b, old_lp_b, old_mu_b, old_sig_b)
             return self._policy_extra(loss, aux), stats[1], stats[0], stats[3], stats[2]
@@ -262,32 +266,63 @@ class CTS(_RolloutHeads):
     # ---- graph mode: every decision on the device; one captured policy step and one captured student step per mini-batch slot ----
     _KEYS = ("obs", "cobs", "hist", "act", "val", "adv", "ret", "logp", "mu", "sig")
 
-    def _policy_step(self, i):
+    def _adaptive(self):
+        return self.desired_kl is not None and self.schedule == "adaptive"
+
+    def _policy_front(self, i, split=False):
         mb = self._mb
         loss, value_loss, surrogate_loss, ent, kl_mean = self._policy_losses(*(self._perm[k][i * mb:(i + 1) * mb] for k in self._KEYS), self._teacher_rows())
-        adaptive = self.desired_kl is not None and self.schedule == "adaptive"
         self.optimizer1.zero_grad(set_to_none=True)
         loss.backward()
-        if _collectives_on():
-            kl_mean = _allreduce_mean_grads(self._params1, _world(), kl_mean if adaptive else None)
-        if adaptive:
+        self._acc[:3 + self._NUM_POLICY_LOGS].add_(torch.stack([value_loss.detach(), surrogate_loss.detach(), ent.detach()] + [v.detach() for v in self._policy_logs]))
+        if split:      # more than one rank: gradients + mean KL into the all-reduce bucket (_graph.py)
+            if self._bucket1 is None:
+                self._bucket1 = GradBucket(self._params1, 1 if self._adaptive() else 0)
+            self._bucket1.pack(kl_mean)
+        else:
+            self._kl = kl_mean
+
+    def _policy_back(self, split=False):
+        if split:
+            kl_mean = self._bucket1.unpack(_world())
+        else:
+            kl_mean = self._kl
+            if _collectives_on():          # GO2_GRAPH_COLLECTIVES=1: the all-reduce recorded inside the graph
+                kl_mean = _allreduce_mean_grads(self._params1, _world(), kl_mean if self._adaptive() else None)
+        if self._adaptive():
             lr = self._lr_t
+            kl_mean = kl_mean.reshape(())
             up, down = torch.clamp(lr * 1.5, max=1e-2), torch.clamp(lr / 1.5, min=1e-5)
             lr.copy_(torch.where(kl_mean > self.desired_kl * 2.0, down, torch.where((kl_mean < self.desired_kl / 2.0) & (kl_mean > 0.0), up, lr)))
         nn.utils.clip_grad_norm_(self._params1, self.max_grad_norm, foreach=True)
         self.optimizer1.step()
-        self._acc[:3 + self._NUM_POLICY_LOGS].add_(torch.stack([value_loss.detach(), surrogate_loss.detach(), ent.detach()] + [v.detach() for v in self._policy_logs]))
 
-    def _student_step(self, i):
+    def _policy_step(self, i):
+        self._policy_front(i)
+        self._policy_back()
+
+    def _student_front(self, i, split=False):
         mb, n_t = self._mb, self._teacher_rows()
         loss, logs = self._student_losses(self._perm["hist"][i * mb + n_t:(i + 1) * mb], self._perm["cobs"][i * mb + n_t:(i + 1) * mb])
         self.optimizer2.zero_grad(set_to_none=True)
         loss.backward()
-        if _collectives_on():
+        self._acc[3 + self._NUM_POLICY_LOGS:].add_(torch.stack([v.detach() for v in logs]))
+        if split:
+            if self._bucket2 is None:
+                self._bucket2 = GradBucket(self._params2)
+            self._bucket2.pack()
+
+    def _student_back(self, split=False):
+        if split:
+            self._bucket2.unpack(_world())
+        elif _collectives_on():
             _allreduce_mean_grads(self._params2, _world())
         nn.utils.clip_grad_norm_(self._params2, self.max_grad_norm, foreach=True)
         self.optimizer2.step()
-        self._acc[3 + self._NUM_POLICY_LOGS:].add_(torch.stack([v.detach() for v in logs]))
+
+    def _student_step(self, i):
+        self._student_front(i)
+        self._student_back()
 
     def _update_graphs(self):
         st, nmb = self.storage, self.num_mini_batches
@@ -296,8 +331,15 @@ class CTS(_RolloutHeads):
             self._mb = (st.teacher_num_envs * st.num_transitions_per_env) // nmb + (st.student_num_envs * st.num_transitions_per_env) // nmb
             self._perm = {k: torch.empty((nmb * self._mb,) + tuple(self._flat[k].shape[1:]), device=self.device, dtype=self._flat[k].dtype) for k in self._KEYS}
             self._acc = torch.zeros(3 + self._NUM_POLICY_LOGS + self._NUM_STUDENT_LOGS, device=self.device)
-            mk = lambda fn, name: [CapturedStep((lambda i=i: fn(i)), warmup=3 if i == 0 else 1, name="CTS %s step %d" % (name, i)) for i in range(nmb)]
-            self._steps = (mk(self._policy_step, "policy"), mk(self._student_step, "student"))
+            self._bucket1 = self._bucket2 = None
+            if _collectives_on() and not collectives_in_graph():     # two captured halves per slot, the gradient all-reduce eager between them
+                mk = lambda front, back, bucket, name: [ReducedStep((lambda i=i: front(i, True)), (lambda: back(True)), bucket, enabled=self._capture, warmup=3 if i == 0 else 1,
+                                                                    name="CTS %s step %d" % (name, i)) for i in range(nmb)]
+                self._steps = (mk(self._policy_front, self._policy_back, (lambda: self._bucket1), "policy"),
+                               mk(self._student_front, self._student_back, (lambda: self._bucket2), "student"))
+            else:
+                mk = lambda fn, name: [CapturedStep((lambda i=i: fn(i)), enabled=self._capture, warmup=3 if i == 0 else 1, name="CTS %s step %d" % (name, i)) for i in range(nmb)]
+                self._steps = (mk(self._policy_step, "policy"), mk(self._student_step, "student"))
         self._acc.zero_()
         # the rollout is gathered ONCE per update into mini-batch order ([teacher rows | student rows] per mini-batch; every epoch
         # reuses the same permutation, rollout_storage_cts.py:152-160), so each captured step reads a contiguous chunk

@@ -23,7 +23,7 @@ import torch.nn as nn
 import torch.optim as optim
 
 from ..storage import RolloutStorage
-from ._graph import CapturedStep
+from ._graph import CapturedStep, GradBucket, ReducedStep, collectives_in_graph
 
 
 # Adam as ONE multi-tensor kernel per param group (fused) instead of ~6 foreach launches; GO2_ADAM=foreach restores the latter
@@ -159,9 +159,13 @@ class PPO(_RolloutHeads):
         self.storage = None
         on_gpu = str(device).startswith("cuda")
         self.use_graphs = on_gpu if use_graphs is None else bool(use_graphs and on_gpu)
+        self._capture = self.use_graphs and use_graphs != "uncaptured"
+        if use_graphs == "uncaptured":     # the graph-mode update (device-side LR decision, permuted chunks, split all-reduce) run eagerly on any
+            self.use_graphs = True         # device: how the CPU tests cover it
         if self.use_graphs:
             self._lr_t = torch.tensor(float(learning_rate), device=device)
-            self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=self._lr_t, capturable=True, **_ADAM_IMPL)
+            self.optimizer = (optim.Adam(self.actor_critic.parameters(), lr=self._lr_t, capturable=True, **_ADAM_IMPL) if self._capture else
+                              optim.Adam(self.actor_critic.parameters(), lr=self._lr_t, foreach=False))
         else:
             self._lr_t = None
             self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=learning_rate)
@@ -211,7 +215,7 @@ class PPO(_RolloutHeads):
             if st.privileged_observations is not None:
                 st.privileged_observations[s].copy_(critic_obs)
             t.observations, t.critic_observations = obs, critic_obs
-            mu, value = self._pair(lambda: ac.actor(obs), lambda: ac.evaluate(critic_obs), enabled=self.use_graphs)
+            mu, value = self._pair(lambda: ac.actor(obs), lambda: ac.evaluate(critic_obs), enabled=self._capture)
             return self._act_head(mu, ac.std, ac._noise(mu), value, s)
         t.actions = ac.act(obs).detach()
         t.values = ac.evaluate(critic_obs).detach()
@@ -255,7 +259,7 @@ class PPO(_RolloutHeads):
     def _losses(self, obs_b, cobs_b, act_b, tv_b, adv_b, ret_b, old_lp_b, old_mu_b, old_sig_b):
         ac = self.actor_critic
         if self.fused_loss:
-            mu_b, val_b = self._pair(lambda: ac.actor(obs_b), lambda: ac.evaluate(cobs_b), enabled=self.use_graphs)
+            mu_b, val_b = self._pair(lambda: ac.actor(obs_b), lambda: ac.evaluate(cobs_b), enabled=self._capture)
             loss, stats = _FusedPPOLoss.apply(mu_b, ac.std, val_b, self, act_b, tv_b, adv_b, ret_b, old_lp_b, old_mu_b, old_sig_b)
             return loss, stats[1], stats[0], stats[2]
         ac.update_distribution(obs_b)     # the reference calls act() here and discards the sample (ppo.py:131)
@@ -313,26 +317,48 @@ class PPO(_RolloutHeads):
     # ---- graph mode -------------------------------------------------------------------------------------------
     _KEYS = ("obs", "cobs", "act", "val", "adv", "ret", "logp", "mu", "sig")
 
-    def _graph_step(self, i):
-        """One mini-batch update with every decision on the device (same arithmetic as _update_eager).  Mini-batch i is the i-th
-        contiguous chunk of the rollout permuted ONCE per update (the reference reuses one permutation for all epochs,
-        rollout_storage.py:150): 4 chunk gathers per iteration instead of 20 mini-batch gathers."""
+    def _graph_front(self, i, split=False):
+        """Forward, losses, backward of mini-batch i with every decision on the device (same arithmetic as _update_eager).  Mini-batch i
+        is the i-th contiguous chunk of the rollout permuted ONCE per update (the reference reuses one permutation for all epochs,
+        rollout_storage.py:150): 4 chunk gathers per iteration instead of 20 mini-batch gathers.  split: the gradients and the mean
+        KL are packed into the all-reduce bucket (more than one rank)."""
         mb = self._mb
         loss, value_loss, surrogate_loss, kl_mean = self._losses(*(self._perm[k][i * mb:(i + 1) * mb] for k in self._KEYS))
-        adaptive = self.desired_kl is not None and self.schedule == "adaptive"
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
-        if _collectives_on():              # ONE RCCL all-reduce (gradients + KL), captured inside the graph: every rank takes the same LR branch
-            kl_mean = self._allreduce_grads(_world(), kl_mean if adaptive else None)
-        if adaptive:
+        self._acc.add_(torch.stack([value_loss.detach(), surrogate_loss.detach()]))
+        if split:
+            if self._bucket is None:
+                self._bucket = GradBucket(list(self.actor_critic.parameters()), 1 if self._adaptive() else 0)
+            self._bucket.pack(kl_mean)
+        else:
+            self._kl = kl_mean
+
+    def _adaptive(self):
+        return self.desired_kl is not None and self.schedule == "adaptive"
+
+    def _graph_back(self, split=False):
+        """LR decision, gradient clipping, Adam.  split: on the all-reduced bucket (shard-mean gradients and KL: every rank takes the
+        same LR branch); otherwise on this rank's gradients, after an all-reduce recorded in the same graph if collectives are on."""
+        if split:
+            kl_mean = self._bucket.unpack(_world())
+        else:
+            kl_mean = self._kl
+            if _collectives_on():          # GO2_GRAPH_COLLECTIVES=1: ONE RCCL all-reduce (gradients + KL) recorded inside the graph
+                kl_mean = self._allreduce_grads(_world(), kl_mean if self._adaptive() else None)
+        if self._adaptive():
             lr = self._lr_t
             up = torch.clamp(lr * 1.5, max=1e-2)
             down = torch.clamp(lr / 1.5, min=1e-5)
+            kl_mean = kl_mean.reshape(())
             new_lr = torch.where(kl_mean > self.desired_kl * 2.0, down, torch.where((kl_mean < self.desired_kl / 2.0) & (kl_mean > 0.0), up, lr))
             lr.copy_(new_lr)
         nn.utils.clip_grad_norm_(self.actor_critic.parameters(), self.max_grad_norm, foreach=True)
         self.optimizer.step()
-        self._acc.add_(torch.stack([value_loss.detach(), surrogate_loss.detach()]))
+
+    def _graph_step(self, i):
+        self._graph_front(i)
+        self._graph_back()
 
     def _update_graphs(self):
         st = self.storage
@@ -348,7 +374,13 @@ class PPO(_RolloutHeads):
             # one captured step per mini-batch slot (each reads its own chunk of the permuted rollout).  Slot 0 runs 3 eager steps on
             # a side stream first (allocator / lazy initialisation settle; they are real PPO steps of the first update), the others
             # one; then each is captured once and replayed.  A failed capture degrades that slot to eager execution.
-            self._graph = [CapturedStep((lambda i=i: self._graph_step(i)), warmup=3 if i == 0 else 1, name="PPO mini-batch step %d" % i) for i in range(nmb)]
+            # More than one rank: two captured halves per slot with the gradient all-reduce eager between them (_graph.py).
+            self._bucket = None
+            if _collectives_on() and not collectives_in_graph():
+                self._graph = [ReducedStep((lambda i=i: self._graph_front(i, True)), (lambda: self._graph_back(True)), (lambda: self._bucket),
+                                           enabled=self._capture, warmup=3 if i == 0 else 1, name="PPO mini-batch step %d" % i) for i in range(nmb)]
+            else:
+                self._graph = [CapturedStep((lambda i=i: self._graph_step(i)), enabled=self._capture, warmup=3 if i == 0 else 1, name="PPO mini-batch step %d" % i) for i in range(nmb)]
         self._acc.zero_()
         # ONE permutation for the whole update, reused by every epoch, as in the reference (rollout_storage.py:150)
         indices = torch.randperm(nmb * mb, requires_grad=False, device=self.device)

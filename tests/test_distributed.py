@@ -135,3 +135,80 @@ def test_sharded_runner_world_size_2(tmp_path):
     assert out[0]["fps"] > 0 and not np.array_equal(out[0]["origin"], out[1]["origin"])     # different shards of one global grid
     runs = [d for d in os.listdir(tmp_path)]
     assert len(runs) == 1 and any(f.startswith("model_") for f in os.listdir(os.path.join(tmp_path, runs[0])))
+
+
+def _fill_and_update(alg, n, seed, cts=False):
+    g = torch.Generator().manual_seed(seed)
+    for t in range(T):
+        obs, cobs = torch.randn(n, 45, generator=g), torch.randn(n, 263, generator=g)
+        args = (obs, cobs, torch.randn(n, 225, generator=g)) if cts else (obs, cobs)
+        alg.act(*args)
+        alg.process_env_step(torch.randn(n, generator=g) * 0.05, torch.rand(n, generator=g) < 0.05, {"time_outs": torch.zeros(n, dtype=torch.bool)})
+    last = (torch.randn(n, 263, generator=g), torch.randn(n, 225, generator=g)) if cts else (torch.randn(n, 263, generator=g),)
+    alg.compute_returns(*last)
+    return alg.update()
+
+
+def _graph_mode_worker(rank, world, port, out):
+    """Both update paths on the same shard data from the same initial replica: _update_eager (all-reduce inline) and the graph-mode
+    update (permuted chunks, device-side LR decision; with > 1 rank split into front | eager all-reduce of the GradBucket | back),
+    the latter run uncaptured — a HIP graph replays exactly these calls."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from go2_rl_gym_amd.rsl_rl.algorithms import CTS, PPO
+    from go2_rl_gym_amd.rsl_rl.algorithms._graph import ReducedStep
+    from go2_rl_gym_amd.rsl_rl.modules import ActorCritic, ActorCriticCTS
+    lib = load_oracle()
+    n = N // world
+    res = {}
+    for mode in (None, "uncaptured"):
+        torch.manual_seed(11)
+        ac = ActorCritic(45, 263, 12, actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16])
+        alg = PPO(ac, num_learning_epochs=2, num_mini_batches=2, entropy_coef=0.01, schedule="adaptive", desired_kl=0.002, device="cpu", lib=lib, use_graphs=mode)
+        alg.init_storage(n, T, [45], [263], [12])
+        for it in range(2):
+            torch.manual_seed(300 + 10 * it + rank)          # sampling noise and the mini-batch permutation
+            losses = _fill_and_update(alg, n, 7 + rank + 100 * it)
+        key = "eager" if mode is None else "graph"
+        res[key] = torch.cat([p.detach().reshape(-1) for p in ac.parameters()]).numpy().copy()
+        res[key + "_lr"], res[key + "_loss"] = alg.learning_rate, losses
+        if mode:
+            res["split"] = isinstance(alg._graph[0], ReducedStep)
+        torch.manual_seed(12)
+        m = ActorCriticCTS(45, 263, 12, n, 5, actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16], teacher_encoder_hidden_dims=[32], student_encoder_hidden_dims=[32], latent_dim=8)
+        cts = CTS(m, n, 5, num_learning_epochs=2, num_mini_batches=2, entropy_coef=0.01, schedule="adaptive", desired_kl=0.002, device="cpu", lib=lib, use_graphs=mode)
+        cts.init_storage(n, T, [45], [263], [12])
+        for it in range(2):
+            torch.manual_seed(400 + 10 * it + rank)
+            _fill_and_update(cts, n, 9 + rank + 100 * it, cts=True)
+        res["cts_" + key] = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).numpy().copy()
+        res["cts_" + key + "_lr"] = cts.learning_rate
+        if mode:
+            res["cts_split"] = isinstance(cts._steps[0][0], ReducedStep) and isinstance(cts._steps[1][0], ReducedStep)
+    out[rank] = res
+    if world > 1:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_graph_mode_update_equals_eager_update(world):
+    """world 1: one graph per mini-batch slot.  world 2: two halves per slot with the eager all-reduce of the gradient bucket between
+    them — replicas stay identical, the LR decision (mean KL over the shards) is the same on every rank, and the result is the eager
+    path's (same permutation, same arithmetic; single-tensor Adam on both sides)."""
+    port = _free_port()
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_graph_mode_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        o = out[r]
+        assert o["split"] == (world > 1) and o["cts_split"] == (world > 1)
+        for pre in ("", "cts_"):
+            np.testing.assert_allclose(o[pre + "graph"], o[pre + "eager"], atol=2e-6, rtol=1e-5, err_msg=pre)
+            assert abs(o[pre + "graph_lr"] - o[pre + "eager_lr"]) < 1e-9 * max(1.0, o[pre + "eager_lr"]) + 1e-10, (pre, o[pre + "graph_lr"], o[pre + "eager_lr"])
+        np.testing.assert_allclose(o["graph_loss"], o["eager_loss"], atol=1e-5)
+        assert o["eager_lr"] != 1e-3                      # the adaptive schedule did move
+    if world == 2:
+        for k in ("graph", "cts_graph"):
+            np.testing.assert_array_equal(out[0][k], out[1][k])
+        assert out[0]["graph_lr"] == out[1]["graph_lr"] and out[0]["cts_graph_lr"] == out[1]["cts_graph_lr"]
