@@ -67,7 +67,7 @@ GO2_HD void go2_step_scalars(const Go2Launch& L, const Go2Dyn& dyn, const float*
 
 struct LegPost {
   int e, lane, N;
-  const Go2Ptrs* P; const Go2Launch* L; const Go2Step* S;
+  const Go2PtrsK* P; const Go2Launch* L; const Go2Step* S;
   PhysOut o;
   // env scalars (replicated)
   int64_t ep_len; float timer, cmd[4], acc[2]; uint8_t stop_heading, last_limit;
@@ -180,7 +180,7 @@ struct LegPost {
 
   // ------------------------------------------------------------------------------------------------
   GO2_HD void postA(const LegTab& t, float* part) {
-    const Go2Ptrs& p = *P; const Go2Launch& c = *L;
+    const Go2PtrsK& p = *P; const Go2Launch& c = *L;
     ep_len = p.ep_len[e] + 1;                      // :111
     timer = p.cmd_timer[e] - 1.f;                  // :113
     to_timer = c.turn_over ? fmaxf(p.to_timer[e] - c.dt, 0.f) : 0.f;     // :114-115
@@ -274,7 +274,7 @@ struct LegPost {
   float own_f2b, own_fvel2, rpy[3], max_move, org_x, org_y, org_z; int64_t tlevel, ttype;
   // replicated fields that lane 0 rewrites in postB: every lane reads them BEFORE any lane writes
   GO2_HD void load_terrain_fields() {
-    const Go2Ptrs& p = *P;
+    const Go2PtrsK& p = *P;
     org_x = F2D(p.origins, 0, e); org_y = F2D(p.origins, 1, e); org_z = F2D(p.origins, 2, e);
     tlevel = p.terrain_levels[e]; ttype = p.terrain_types[e];
   }
@@ -295,7 +295,7 @@ struct LegPost {
   // ------------------------------------------------------------------------------------------------
   // red = quad-summed partials; feet_reg = quad-summed regulation()
   GO2_HD void postB(const LegTab& t, const float* red, float feet_reg) {
-    const Go2Ptrs& p = *P; const Go2Launch& c = *L; const int N_ = N; (void)N_;
+    const Go2PtrsK& p = *P; const Go2Launch& c = *L; const int N_ = N; (void)N_;
     float raw[GO2_NUM_REWARDS];
 #pragma unroll
     for (int i = 0; i < GO2_NUM_REWARDS; ++i) raw[i] = 0.f;

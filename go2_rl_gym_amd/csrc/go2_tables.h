@@ -40,16 +40,28 @@ struct Go2Tables { LegTab leg[4]; BaseTab base; uint8_t slot_code[GO2_NUM_UNIFOR
 // logical [N, a, b] lives at ((b_idx * A + a_idx) * N + env), i.e. C order of the reversed logical dims,
 // so that consecutive lanes (envs) touch consecutive addresses.  obs_buf and privileged_obs_buf are the
 // exception: they are the policy's GEMM inputs and stay row-major [N,45] / [N,263].
-struct Go2Ptrs {
-  float *root, *dof, *contact, *rigid, *obs, *priv, *rew; uint8_t *reset, *time_out; int64_t* ep_len;
-  float *torques, *actions, *last_actions, *last_last_actions, *last_dof_vel, *last_root_vel, *commands, *cmd_timer, *cmd_xy_acc;
-  uint8_t *stop_heading, *last_is_limit_vel; float *base_lin_vel, *base_ang_vel, *proj_gravity, *rpy, *heights, *max_move, *to_timer, *feet_air_time;
-  uint8_t *last_contacts, *last_contacts2; float *strength, *zero_off, *kp_mul, *kd_mul, *origins; int64_t *terrain_levels, *terrain_types;
-  float *ep_sums, *friction, *restitution, *added_mass, *added_com, *mass_ratio, *episode_info, *foot_impulse;
-  // internal
-  int32_t* terrain_kind; float* ep_accum /*[NUM_REWARDS+1]*/; const float* inj_storage; const int16_t* hf; const float* terrain_origins;
-  const Go2Tables* tables; long long* dbg_clock;
-};
+#define GO2_PTRS_BODY(G) \
+  G float *root, *dof, *contact, *rigid, *obs, *priv, *rew; G uint8_t *reset, *time_out; G int64_t* ep_len; \
+  G float *torques, *actions, *last_actions, *last_last_actions, *last_dof_vel, *last_root_vel, *commands, *cmd_timer, *cmd_xy_acc; \
+  G uint8_t *stop_heading, *last_is_limit_vel; G float *base_lin_vel, *base_ang_vel, *proj_gravity, *rpy, *heights, *max_move, *to_timer, *feet_air_time; \
+  G uint8_t *last_contacts, *last_contacts2; G float *strength, *zero_off, *kp_mul, *kd_mul, *origins; G int64_t *terrain_levels, *terrain_types; \
+  G float *ep_sums, *friction, *restitution, *added_mass, *added_com, *mass_ratio, *episode_info, *foot_impulse; \
+  /* internal */ \
+  G int32_t* terrain_kind; G float* ep_accum /*[NUM_REWARDS+1]*/; const G float* inj_storage; const G int16_t* hf; const G float* terrain_origins; \
+  const G Go2Tables* tables; G long long* dbg_clock;
+struct Go2Ptrs { GO2_PTRS_BODY() };
+// The kernels read these pointers out of the device block (scalar loads), where the compiler cannot know their address space and would
+// emit FLAT loads/stores (which also tick the LDS counter: every ds_read wait then waits for outstanding stores).  The kernel-side view
+// of the same bytes types them as global (address space 1) -> global_load / global_store.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GO2_GLOBAL_AS __attribute__((address_space(1)))
+struct Go2PtrsK { GO2_PTRS_BODY(GO2_GLOBAL_AS) };
+static_assert(sizeof(Go2PtrsK) == sizeof(Go2Ptrs), "same layout");
+#define GO2_GENERIC(T, ptr) ((T)(ptr))          /* explicit global -> generic cast for a callee that takes a plain pointer */
+#else
+typedef Go2Ptrs Go2PtrsK;
+#define GO2_GENERIC(T, ptr) (ptr)
+#endif
 
 // everything a launch needs besides pointers: config constants + the host-side scalars of this step
 struct Go2Launch {

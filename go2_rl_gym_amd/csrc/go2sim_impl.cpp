@@ -43,7 +43,7 @@ struct LaneAux { float kp[3], kd[3], q0[3], zoff[3], strength[3], act_new[3], ac
 #define LANE_PARAMS LegPhys& ph_, LegPost& po_, LaneAux& ax
 #define LANE_ARGS(i) c_ph[i], c_po[i], c_ax[i]
 
-GO2_HD void lane_load_phys(LANE_PARAMS, const Go2Tables& tab, const Go2Ptrs& p, const Go2Launch& L, const Go2Step& S, const float* actions_in, int e, int lane) {
+GO2_HD void lane_load_phys(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p, const Go2Launch& L, const Go2Step& S, const float* actions_in, int e, int lane) {
   const int N = L.N;
   const LegTab& t = tab.leg[lane];
   LegPhys& ph = ph_;
@@ -95,7 +95,7 @@ GO2_HD void quat_mul(const float* a, const float* b, float* o) {  // (x,y,z,w)
 
 // after the last substep: forward kinematics at the new state, API tensors, PhysOut.  fbase = this lane's
 // contribution to the base / head contact forces (3 bodies x 3), to be quad-summed by the caller.
-GO2_HD void lane_finish_phys(LANE_PARAMS, const Go2Tables& tab, const Go2Ptrs& p, const Go2Launch& L, int e, int lane, float* fbase) {
+GO2_HD void lane_finish_phys(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p, const Go2Launch& L, int e, int lane, float* fbase) {
   const int N = L.N;
   const LegTab& t = tab.leg[lane];
   LegPhys& ph = ph_; PhysOut& o = po_.o;
@@ -153,13 +153,13 @@ GO2_HD void lane_finish_phys(LANE_PARAMS, const Go2Tables& tab, const Go2Ptrs& p
   }
 }
 // fbase_sum = quad-summed base/head forces
-GO2_HD void lane_store_base_forces(LANE_PARAMS, const Go2Ptrs& p, const Go2Launch& L, int e, int lane, const float* fbase_sum) {
+GO2_HD void lane_store_base_forces(LANE_PARAMS, const Go2PtrsK& p, const Go2Launch& L, int e, int lane, const float* fbase_sum) {
   const int N = L.N;
   po_.o.Fbase = v3(fbase_sum[0], fbase_sum[1], fbase_sum[2]);
   if (lane < 3) for (int k = 0; k < 3; ++k) F3D(p.contact, 19, lane, k, e) = fbase_sum[3 * lane + k];
 }
 // post-only entry: rebuild PhysOut from the API tensors
-GO2_HD void lane_load_physout(LANE_PARAMS, const Go2Tables& tab, const Go2Ptrs& p, const Go2Launch& L, int e, int lane) {
+GO2_HD void lane_load_physout(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p, const Go2Launch& L, int e, int lane) {
   const int N = L.N; const LegTab& t = tab.leg[lane]; PhysOut& o = po_.o;
   o.pw = v3(F2D(p.root, 0, e), F2D(p.root, 1, e), F2D(p.root, 2, e));
   o.qx = F2D(p.root, 3, e); o.qy = F2D(p.root, 4, e); o.qz = F2D(p.root, 5, e); o.qw = F2D(p.root, 6, e);
@@ -171,12 +171,12 @@ GO2_HD void lane_load_physout(LANE_PARAMS, const Go2Tables& tab, const Go2Ptrs& 
   o.foot_pos = v3(F3D(p.rigid, 19, fb, 0, e), F3D(p.rigid, 19, fb, 1, e), F3D(p.rigid, 19, fb, 2, e));
   o.foot_vel = v3(F3D(p.rigid, 19, fb, 7, e), F3D(p.rigid, 19, fb, 8, e), F3D(p.rigid, 19, fb, 9, e));
 }
-GO2_HD void lane_init_post(LANE_PARAMS, const uint8_t* codes, const Go2Ptrs* p, const Go2Launch* L, const Go2Step* S, int e, int lane) {
+GO2_HD void lane_init_post(LANE_PARAMS, const uint8_t* codes, const Go2PtrsK* p, const Go2Launch* L, const Go2Step* S, int e, int lane) {
   po_.codes = codes; po_.cg = -1; po_.cw0 = po_.cw1 = po_.cw2 = po_.cw3 = 0u;
   po_.e = e; po_.lane = lane; po_.N = L->N; po_.P = p; po_.L = L; po_.S = S;
 }
 // reset_idx(all envs) without a step (base_task.py:82-84): postB's reset branch with reset forced on
-GO2_HD void lane_reset_all(LANE_PARAMS, const Go2Tables& tab, const Go2Ptrs& p, const Go2Launch& L, const Go2Step& S, int e, int lane) {
+GO2_HD void lane_reset_all(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p, const Go2Launch& L, const Go2Step& S, int e, int lane) {
   const int N = L.N;
   lane_load_physout(ph_, po_, ax, tab, p, L, e, lane);
   lane_init_post(ph_, po_, ax, tab.slot_code, &p, &L, &S, e, lane);
@@ -220,7 +220,7 @@ template <int MODE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) go2_step_kernel(const Go2DevBlock* __restrict__ blk, const float* __restrict__ actions_in, int initial_reset) {
   __shared__ Go2Tables tab;   // robot link / collision tables staged in LDS (per-lane leg index -> ds_read)
   __shared__ Go2Step S;       // this step's scalars, computed on device from the device-resident counters
-  const Go2Ptrs& p = blk->p; const Go2Launch& L = blk->L;   // uniform addresses -> scalar loads
+  const Go2PtrsK& p = *(const Go2PtrsK*)&blk->p; const Go2Launch& L = blk->L;   // uniform addresses -> scalar loads; pointers typed global
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(p.tables); uint32_t* dst = reinterpret_cast<uint32_t*>(&tab);
     for (int i = threadIdx.x; i < (int)(sizeof(Go2Tables) / 4); i += 64) dst[i] = src[i];

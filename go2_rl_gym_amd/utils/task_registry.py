@@ -1,4 +1,5 @@
 """Task registry with the reference's surface (legged_gym/utils/task_registry.py:15-128)."""
+import copy
 import os
 from datetime import datetime
 
@@ -20,7 +21,10 @@ class TaskRegistry:
         return self.task_classes[name]
 
     def get_cfgs(self, name):
-        train_cfg, env_cfg = self.train_cfgs[name], self.env_cfgs[name]
+        # copies: the reference hands out the registered instances themselves (task_registry.py:24-28), so what one caller changes
+        # (play.py: resume, noise off, fewer envs; --resume from the CLI) silently carries over to every later make_env /
+        # make_alg_runner of the process.  Scripts that edit the returned objects and pass them back in behave the same.
+        train_cfg, env_cfg = copy.deepcopy(self.train_cfgs[name]), copy.deepcopy(self.env_cfgs[name])
         env_cfg.seed = train_cfg.seed
         return env_cfg, train_cfg
 

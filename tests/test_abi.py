@@ -112,3 +112,13 @@ def test_ragged_batch_matches_oracle_lane_for_lane():
         d = np.abs(np.asarray(so.obs_buf, np.float64) - np.asarray(se.obs_buf, np.float64)).max(1)
         assert np.sort(d)[-2] < 2e-4 and d.max() < 2e-2, (it, np.sort(d)[-3:])
     so.close(); se.close()
+
+
+def test_registry_hands_out_copies_of_the_registered_configs():
+    """What one caller edits (play.py: resume, noise off, 100 envs) must not carry over to the next make_env / make_alg_runner."""
+    from go2_rl_gym_amd.envs import task_registry
+    env_cfg, train_cfg = task_registry.get_cfgs("go2_flat_cts")
+    env_cfg.noise.add_noise = False; env_cfg.env.num_envs = 7; train_cfg.runner.resume = True; train_cfg.algorithm.schedule = "fixed"
+    env_cfg2, train_cfg2 = task_registry.get_cfgs("go2_flat_cts")
+    assert env_cfg2.noise.add_noise is True and env_cfg2.env.num_envs != 7 and train_cfg2.runner.resume is False
+    assert train_cfg2.algorithm.schedule == "adaptive" and env_cfg2.seed == train_cfg2.seed
