@@ -404,8 +404,16 @@ __global__ void go2_ppo_loss_finish_kernel(const float* __restrict__ part, const
   __syncthreads();
   if (k == 0) stats[4] = stats[0] + vcoef * stats[1] - ecoef * stats[3];
 }
-// ---- ELU backward + bias gradient in one pass.  Block = 64 column-quads (float4) x 4 row lanes over a 256-col x 128-row tile --------
-#define EB_ROWS 128
+// ---- ELU backward + bias gradient in one pass.  Block = 64 column-quads (float4) x 4 row lanes over a 256-col x EB_ROWS-row tile; HBM-bound
+// (reads gy, y, writes gz: 12 B per element), so each thread keeps 4 rows = 8 float4 loads in flight.  Column partials per row tile go to a
+// workspace and are summed in a fixed order by a second, tree-shaped kernel (deterministic; no atomics) --------------------------------
+#define EB_ROWS 64
+__device__ __forceinline__ float4 elu_bwd4(const float4 g, const float4 v) {
+  float4 o;
+  o.x = g.x * (v.x > 0.f ? 1.f : v.x + 1.f); o.y = g.y * (v.y > 0.f ? 1.f : v.y + 1.f);
+  o.z = g.z * (v.z > 0.f ? 1.f : v.z + 1.f); o.w = g.w * (v.w > 0.f ? 1.f : v.w + 1.f);
+  return o;
+}
 __global__ void __launch_bounds__(256) go2_elu_bwd_bias_kernel(const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ gz, float* __restrict__ part, int B, int C) {
   __shared__ float4 sh[4][64];
   const int cq = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -413,12 +421,21 @@ __global__ void __launch_bounds__(256) go2_elu_bwd_bias_kernel(const float* __re
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c0 < C) {
     const int r1 = min(r0 + EB_ROWS, B);
-    for (int r = r0 + rl; r < r1; r += 4) {
+    int r = r0 + rl;
+    for (; r + 12 < r1; r += 16) {          // 4 rows of this row lane per trip, all 8 loads issued before the first use
+      float4 g[4], v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const size_t k = (size_t)(r + 4 * u) * C + c0; g[u] = *reinterpret_cast<const float4*>(gy + k); v[u] = *reinterpret_cast<const float4*>(y + k); }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float4 o = elu_bwd4(g[u], v[u]);
+        *reinterpret_cast<float4*>(gz + (size_t)(r + 4 * u) * C + c0) = o;
+        acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+      }
+    }
+    for (; r < r1; r += 4) {
       const size_t k = (size_t)r * C + c0;
-      const float4 g = *reinterpret_cast<const float4*>(gy + k), v = *reinterpret_cast<const float4*>(y + k);
-      float4 o;
-      o.x = g.x * (v.x > 0.f ? 1.f : v.x + 1.f); o.y = g.y * (v.y > 0.f ? 1.f : v.y + 1.f);
-      o.z = g.z * (v.z > 0.f ? 1.f : v.z + 1.f); o.w = g.w * (v.w > 0.f ? 1.f : v.w + 1.f);
+      const float4 o = elu_bwd4(*reinterpret_cast<const float4*>(gy + k), *reinterpret_cast<const float4*>(y + k));
       *reinterpret_cast<float4*>(gz + k) = o;
       acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
     }
@@ -431,12 +448,24 @@ __global__ void __launch_bounds__(256) go2_elu_bwd_bias_kernel(const float* __re
     *reinterpret_cast<float4*>(part + (size_t)blockIdx.y * C + c0) = o;
   }
 }
+// column sums of part[nrows][C]: block = 16 columns x 16 row groups; each thread adds its rows (stride 16) in order, then a fixed LDS tree
 __global__ void __launch_bounds__(256) go2_colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ gb, int nrows, int C) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float sh[16][17];
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
   float s = 0.f;
-  for (int r = 0; r < nrows; ++r) s += part[(size_t)r * C + c];     // fixed order: deterministic
-  gb[c] = s;
+  if (c < C) for (int r = rg; r < nrows; r += 16) s += part[(size_t)r * C + c];
+  sh[rg][cl] = s;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    float t[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = sh[i][cl];
+#pragma unroll
+    for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+      for (int i = 0; i < w; ++i) t[i] += t[i + w];
+    gb[c] = t[0];
+  }
 }
 
 // ---- rollout heads: PPO.act sampling + storage rows, PPO.process_env_step (one thread per env) ----------------------------
@@ -1002,7 +1031,7 @@ int go2sim_elu_backward_bias(const float* gy, const float* y, float* gz, float* 
 #else
   const int nr = (B + EB_ROWS - 1) / EB_ROWS;
   hipLaunchKernelGGL(go2_elu_bwd_bias_kernel, dim3((C / 4 + 63) / 64, nr), dim3(256), 0, (hipStream_t)stream, gy, y, gz, workspace, B, C);
-  hipLaunchKernelGGL(go2_colsum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace, gb, nr, C);
+  hipLaunchKernelGGL(go2_colsum_finish_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, workspace, gb, nr, C);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

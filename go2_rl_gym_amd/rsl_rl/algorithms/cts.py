@@ -47,7 +47,7 @@ class CTS(_RolloutHeads):
         self.fused_rollout = (on_gpu and lib is not None) if fused_rollout is None else bool(fused_rollout and lib is not None)
         if getattr(model, "state_dependent_std", False):       # MCP actor: the fused heads assume one std per action dimension
             self.fused_loss = self.fused_rollout = False
-        if on_gpu and lib is not None and os.environ.get("GO2_FUSED_MLP", "0") == "1":
+        if on_gpu and lib is not None and os.environ.get("GO2_FUSED_MLP", "1") == "1":
             from ..modules import fused
             fused.set_library(lib)
         groups1 = [{"params": g} for g in self.model.policy_parameter_groups()]                           # same 4 groups as the reference (:72-77)

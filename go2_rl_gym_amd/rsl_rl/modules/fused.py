@@ -31,7 +31,7 @@ class _LinearELU(torch.autograd.Function):
         gy = gy.contiguous()
         B, Cn = y.shape
         gz, gb = torch.empty_like(y), torch.empty(Cn, device=y.device, dtype=y.dtype)
-        ws = torch.empty(Cn * ((B + 127) // 128), device=y.device, dtype=y.dtype)
+        ws = torch.empty(Cn * ((B + 63) // 64), device=y.device, dtype=y.dtype)      # one row of column partials per 64-row tile
         p = lambda t: C.c_void_p(t.data_ptr())
         stream = C.c_void_p(torch.cuda.current_stream(y.device).cuda_stream) if y.is_cuda else None
         rc = _LIB.go2sim_elu_backward_bias(p(gy), p(y), p(gz), p(gb), p(ws), B, Cn, stream)

@@ -382,7 +382,7 @@ int  go2sim_store_transition(const float* rewards, const uint8_t* dones, const u
  * modules/actor_critic.py:60-90): given the upstream gradient gy [B,C] and the layer OUTPUT y = elu(z) [B,C] (alpha = 1),
  *   gz = gy * (y > 0 ? 1 : y + 1)            (= torch's elu_backward with is_result=True)
  *   gb[c] = sum_b gz[b,c]                    (the Linear's bias gradient; deterministic two-stage reduction)
- * in one pass over the activations instead of two.  workspace: >= C * ceil(B/128) floats.  gz may alias gy. */
+ * in one pass over the activations instead of two.  workspace: >= C * ceil(B/64) floats.  gz may alias gy. */
 int  go2sim_elu_backward_bias(const float* gy, const float* y, float* gz, float* gb, float* workspace, int32_t B, int32_t C, void* stream);
 
 /* Observation-history ring of the CTS runner (on_policy_runner_cts.py:155-156), in place:

@@ -407,6 +407,30 @@ def test_fused_linear_elu_on_gpu(hip):
         np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), atol=2e-6, rtol=2e-3)
 
 
+@pytest.mark.parametrize("B,Cn", [(1, 4), (63, 12), (70, 260), (1000, 512), (24576, 128), (4099, 32)])
+def test_elu_backward_bias_kernel_shapes_on_gpu(hip, B, Cn):
+    """go2sim_elu_backward_bias at ragged shapes (rows not a multiple of the 64-row tile / of the 16-row trip, columns not a multiple of
+    the 256-column block): every element of gz and the deterministic column sums against torch; gz may alias gy."""
+    import torch
+    torch.manual_seed(B + Cn)
+    gy, y = torch.randn(B, Cn, device="cuda"), torch.randn(B, Cn, device="cuda")
+    gz, gb = torch.empty_like(y), torch.empty(Cn, device="cuda")
+    ws = torch.full((Cn * ((B + 63) // 64),), float("nan"), device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ref = gy * torch.where(y > 0, torch.ones_like(y), y + 1.0)
+    assert hip.go2sim_elu_backward_bias(p(gy), p(y), p(gz), p(gb), p(ws), B, Cn, st) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(gz.cpu().numpy(), ref.cpu().numpy(), atol=1e-6)
+    np.testing.assert_allclose(gb.cpu().numpy(), ref.double().sum(0).float().cpu().numpy(), atol=2e-5 * max(1.0, B ** 0.5), rtol=1e-5)
+    gb1 = gb.clone()
+    g2 = gy.clone()
+    assert hip.go2sim_elu_backward_bias(p(g2), p(y), p(g2), p(gb), p(ws), B, Cn, st) == 0       # in place, and bit-reproducible
+    torch.cuda.synchronize()
+    assert torch.equal(g2, gz) and torch.equal(gb, gb1)
+    assert hip.go2sim_elu_backward_bias(p(gy), p(y), p(gz), p(gb), p(ws), B, 6, st) != 0           # C must be a multiple of 4
+
+
 @pytest.mark.parametrize("N", [1, 17, 4097])
 def test_ragged_batches_on_gpu(hip, N):
     """Smallest, ragged (one full 16-env workgroup + 1) and just-over-BASELINE batches: the partially filled last workgroup
