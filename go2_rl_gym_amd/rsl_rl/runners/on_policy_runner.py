@@ -53,7 +53,9 @@ def _enable_tuned_gemms():
         tn.enable(True)
         tn.tuning_enable(tune)
         tn.record_untuned_enable(False)
-        if tune:
+        if tune:                       # keeps the shipped selections, tunes the shapes that are not in the table, writes the union to the cwd
+            if os.path.exists(path):
+                tn.read_file(path)
             tn.set_max_tuning_duration(50)
             tn.set_filename(os.path.join(os.getcwd(), "tunableop_results.csv"))
         else:
