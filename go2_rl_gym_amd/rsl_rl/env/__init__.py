@@ -1,1 +1,1 @@
-from .vec_env import VecEnv
+from .vec_env import VecEnv, missing_members

@@ -20,6 +20,7 @@ import yaml
 
 from ...utils.helpers import class_to_dict
 from ..algorithms import PPO
+from ..env import missing_members
 from ..modules import ActorCritic
 
 _POLICIES = {"ActorCritic": ActorCritic}
@@ -61,6 +62,7 @@ def _enable_tuned_gemms():
         else:
             ok = tn.read_file(path)
             tn.set_filename(os.path.join(tempfile.gettempdir(), "go2_tunableop_unused.csv"))   # never write over the shipped table
+            tn.write_file_on_exit(False)                                                        # (and N ranks do not race on one file)
             if not ok:
                 tn.enable(False)       # validators (torch / hipBLASLt / arch) do not match this table
     except Exception as e:             # never fail the run over an optional speed-up
@@ -86,6 +88,9 @@ class OnPolicyRunner:
         self.alg_cfg = train_cfg["algorithm"]
         self.policy_cfg = train_cfg["policy"]
         self.device = device
+        lacking = missing_members(env)
+        if lacking:
+            raise TypeError("env does not satisfy the VecEnv contract (rsl_rl/env/vec_env.py); missing: " + ", ".join(lacking))
         self.env = env
         self.lib = getattr(env, "lib", None)
         self._build_algorithm(train_cfg, use_graphs)

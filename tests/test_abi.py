@@ -122,3 +122,19 @@ def test_registry_hands_out_copies_of_the_registered_configs():
     env_cfg2, train_cfg2 = task_registry.get_cfgs("go2_flat_cts")
     assert env_cfg2.noise.add_noise is True and env_cfg2.env.num_envs != 7 and train_cfg2.runner.resume is False
     assert train_cfg2.algorithm.schedule == "adaptive" and env_cfg2.seed == train_cfg2.seed
+
+
+def test_runner_names_what_an_env_lacks():
+    """The VecEnv contract is checked up front (rsl_rl/env/vec_env.py): a stand-in without get_privileged_observations is refused by name."""
+    from go2_rl_gym_amd.rsl_rl.env import VecEnv, missing_members
+    from go2_rl_gym_amd.rsl_rl.runners import OnPolicyRunner
+
+    class Half:
+        num_envs, num_obs, num_privileged_obs, num_actions, max_episode_length, device = 4, 45, None, 12, 10, "cpu"
+        episode_length_buf = None
+        def step(self, a): ...
+        def reset(self): ...
+        def get_observations(self): ...
+    assert missing_members(Half()) == ["get_privileged_observations"] and not isinstance(Half(), VecEnv)
+    with pytest.raises(TypeError, match="get_privileged_observations"):
+        OnPolicyRunner(Half(), {"runner": {}, "algorithm": {}, "policy": {}})
