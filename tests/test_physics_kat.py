@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import HostSim, load_oracle
+from helpers import ROOT, HostSim, load_oracle
 
 N = 8
 
@@ -172,3 +172,15 @@ def test_pd_drive_reaches_its_target_in_the_air():
     assert np.abs(np.asarray(s.dof_state)[:, :, 1]).max() < 0.05
     assert (peak <= np.array([23.7, 23.7, 35.55] * 4) + 1e-4).all()
     s.close()
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/resources/robots/go2/urdf/go2.urdf"), reason="container-only: needs the reference's URDF")
+def test_model_table_is_what_the_generator_derives_from_the_urdf(tmp_path):
+    """include/go2_model_data.h (numbers only) is regenerated from the Go2 URDF by tools/gen_go2_model.py and must equal the committed
+    file: masses, COMs, inertias, joint origins / axes / limits / efforts and the collision spheres are the URDF's, not hand-typed."""
+    import subprocess
+    import sys
+    out = tmp_path / "go2_model_data.h"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_go2_model.py"), "/root/reference/resources/robots/go2/urdf/go2.urdf", str(out)],
+                   check=True, capture_output=True, cwd=ROOT)
+    assert out.read_text() == open(os.path.join(ROOT, "include", "go2_model_data.h")).read()
