@@ -174,6 +174,36 @@ def test_pd_drive_reaches_its_target_in_the_air():
     s.close()
 
 
+@pytest.mark.parametrize("which", ["oracle", "lane_emulation"])
+def test_joint_stops_hold_against_saturated_motors(which):
+    """Robot floating in zero gravity, one leg per env driven with saturated torque into its upper (envs 0-3) or lower (4-7) URDF stops, arriving
+    at the velocity limit (30.1 / 20.07 rad/s): the limit rows of the velocity-level solve stop every joint — transient overshoot below
+    one substep's travel at that speed (0.15 rad), then at rest within 0.015 rad of the stop while the motor keeps pushing."""
+    from helpers import load_emu
+    lib = load_oracle() if which == "oracle" else load_emu()
+    lo = np.array([-1.0472, -1.5708, -2.7227, -1.0472, -1.5708, -2.7227, -1.0472, -0.5236, -2.7227, -1.0472, -0.5236, -2.7227])
+    hi = np.array([1.0472, 3.4907, -0.83776, 1.0472, 3.4907, -0.83776, 1.0472, 4.5379, -0.83776, 1.0472, 4.5379, -0.83776])
+    s = HostSim(lib, num_envs=8, gravity=[0, 0, 0], push_robots=0, randomize_action_delay=0, randomize_motor_strength=0, randomize_pd_gains=0,
+                randomize_motor_zero_offset=0)
+    s.reset_all()
+    s.root_states[:, 2] = 3.0; s.root_states[:, 7:13] = 0
+    a = np.zeros((8, 12), np.float32)
+    for e in range(8):
+        a[e, 3 * (e % 4):3 * (e % 4) + 3] = 40.0 if e < 4 else -40.0          # target 10 rad beyond: the torque stays at the effort limit
+    over = np.zeros(8)
+    for _ in range(100):
+        s.step(a)
+        q = np.asarray(s.dof_state)[:, :, 0]
+        over = np.maximum(over, np.maximum(q - hi, lo - q).max(1))
+    q, qd, tq = np.asarray(s.dof_state)[:, :, 0], np.asarray(s.dof_state)[:, :, 1], np.asarray(s.torques)
+    assert over.max() < 0.1, over
+    for e in range(8):
+        sl = slice(3 * (e % 4), 3 * (e % 4) + 3)
+        assert np.abs(q[e, sl] - (hi if e < 4 else lo)[sl]).max() < 0.015 and np.abs(qd[e, sl]).max() < 0.02, (e, q[e, sl], qd[e, sl])
+        np.testing.assert_allclose(np.abs(tq[e, sl]), [23.7, 23.7, 35.55], atol=1e-4)
+    s.close()
+
+
 @pytest.mark.skipif(not os.path.exists("/root/reference/resources/robots/go2/urdf/go2.urdf"), reason="container-only: needs the reference's URDF")
 def test_model_table_is_what_the_generator_derives_from_the_urdf(tmp_path):
     """include/go2_model_data.h (numbers only) is regenerated from the Go2 URDF by tools/gen_go2_model.py and must equal the committed
