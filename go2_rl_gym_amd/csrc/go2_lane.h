@@ -311,6 +311,11 @@ struct LegPhys {
     for (int j = 0; j < 3; ++j) qdp[j] = fminf(fmaxf(qdp[j], -t.vel_lim[j]), t.vel_lim[j]);
     V3 lin_b = V0p.l + h * cross(wb, vb);
     ww = mul(Rwb, V0p.a); vw = mul(Rwb, lin_b);
+    {   // asset.max_angular_velocity / max_linear_velocity: the base twist is clamped, so no state can run off to inf
+      const float w2 = dot(ww, ww), v2 = dot(vw, vw);
+      if (w2 > L.max_ang_vel * L.max_ang_vel) ww = (L.max_ang_vel / sqrtf(w2)) * ww;
+      if (v2 > L.max_lin_vel * L.max_lin_vel) vw = (L.max_lin_vel / sqrtf(v2)) * vw;
+    }
     pw = pw + h * vw;
     float th = sqrtf(dot(ww, ww)) * h; float dx, dy, dz, dwq;
     if (th > 1e-9f) { float sc = sinf(0.5f * th) / (th / h); dx = ww.x * sc; dy = ww.y * sc; dz = ww.z * sc; dwq = cosf(0.5f * th); }

@@ -67,7 +67,7 @@ typedef Go2Ptrs Go2PtrsK;
 struct Go2Launch {
   int32_t N, env_offset, decimation, solver_iterations;
   uint32_t seed_lo, seed_hi;
-  float sim_dt, dt, gravity[3], contact_offset, erp, max_depen_vel, bounce_thr, cfm, armature, limit_margin;
+  float sim_dt, dt, gravity[3], contact_offset, erp, max_depen_vel, bounce_thr, cfm, armature, limit_margin, max_lin_vel, max_ang_vel;
   int32_t terrain_mode, hf_rows, hf_cols; float hf_hscale, hf_vscale, hf_border, terrain_friction, terrain_restitution;
   int32_t terrain_num_levels, terrain_num_types, terrain_curriculum, move_down_by_acc, measure_heights, full_body_states; float terrain_length;
   float kp[12], kd[12], q0[12], action_scale, clip_actions, clip_obs, base_init[13];

@@ -697,6 +697,7 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
   L.sim_dt = cfg->sim_dt; L.dt = s->dt; memcpy(L.gravity, cfg->gravity, sizeof(L.gravity));
   L.contact_offset = cfg->contact_offset; L.erp = cfg->erp; L.max_depen_vel = cfg->max_depenetration_velocity; L.bounce_thr = cfg->bounce_threshold_velocity;
   L.cfm = cfg->contact_cfm; L.armature = cfg->joint_armature; L.limit_margin = cfg->joint_limit_margin;
+  L.max_lin_vel = cfg->max_linear_velocity; L.max_ang_vel = cfg->max_angular_velocity;
   L.terrain_mode = cfg->terrain_mode; L.hf_rows = cfg->hf_rows; L.hf_cols = cfg->hf_cols; L.hf_hscale = cfg->hf_hscale; L.hf_vscale = cfg->hf_vscale; L.hf_border = cfg->hf_border;
   L.terrain_friction = cfg->terrain_friction; L.terrain_restitution = cfg->terrain_restitution; L.terrain_num_levels = cfg->terrain_num_levels; L.terrain_num_types = cfg->terrain_num_types;
   L.terrain_curriculum = cfg->terrain_curriculum; L.move_down_by_acc = cfg->move_down_by_accumulated_xy_command; L.measure_heights = cfg->measure_heights; L.full_body_states = cfg->full_body_states; L.terrain_length = cfg->terrain_length;

@@ -70,6 +70,7 @@ class LeggedRobot(BaseTask):
         px = cfg.sim.physx
         c.contact_offset, c.max_depenetration_velocity, c.bounce_threshold_velocity = px.contact_offset, px.max_depenetration_velocity, px.bounce_threshold_velocity
         c.joint_armature = cfg.asset.armature
+        c.max_linear_velocity, c.max_angular_velocity = cfg.asset.max_linear_velocity, cfg.asset.max_angular_velocity
         mesh = cfg.terrain.mesh_type
         if mesh == "plane":
             c.terrain_mode = 0

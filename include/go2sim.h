@@ -122,6 +122,8 @@ typedef struct Go2SimCfg {
   float    contact_cfm;       /* relative softness added to the Delassus diagonal */
   float    joint_armature;    /* 0 (legged_robot_config.py:133) */
   float    joint_limit_margin;/* rad: joint-limit row active within this distance of a hard limit */
+  float    max_linear_velocity;  /* 1000 m/s   (asset.max_linear_velocity,  legged_robot_config.py:132): the base's linear velocity is clamped */
+  float    max_angular_velocity; /* 1000 rad/s (asset.max_angular_velocity, :131): ... and its angular velocity; the state stays finite */
 
   /* ---- terrain: legged_robot_config.py:15-40 ---- */
   int32_t  terrain_mode;      /* 0 = plane, 1 = heightfield */

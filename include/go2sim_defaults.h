@@ -26,6 +26,8 @@ static inline void go2sim_fill_default_cfg(Go2SimCfg* c) {
   c->bounce_threshold_velocity = 0.5f;           /* :255 */
   c->contact_cfm = 1e-3f;                        /* own choice */
   c->joint_armature = 0.f;                       /* :133 */
+  c->max_linear_velocity = 1000.f;               /* :132 */
+  c->max_angular_velocity = 1000.f;              /* :131 */
   c->joint_limit_margin = 0.05f;                 /* own choice */
   c->terrain_mode = 0;
   c->terrain_friction = 1.0f;                    /* :21-22 */

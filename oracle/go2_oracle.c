@@ -549,6 +549,10 @@ static void physics_substep(Go2Sim* s, int e, R* root, R* q, R* qd, const R* tau
   R wxv[3]; cross3(k.v[0], k.v[0]+3, wxv);
   R lin_b[3] = {nup[3]+h*wxv[0], nup[4]+h*wxv[1], nup[5]+h*wxv[2]};
   R ww[3], vw[3]; mat3_vec(k.Rw[0], nup, ww); mat3_vec(k.Rw[0], lin_b, vw);
+  { /* asset.max_angular_velocity / max_linear_velocity (legged_robot.py:974-975): the base twist is clamped, so no state can run off to inf */
+    R wm = (R)cfg->max_angular_velocity, vm = (R)cfg->max_linear_velocity, w2 = dot3(ww,ww), v2 = dot3(vw,vw);
+    if (w2 > wm*wm) { R sc = wm/SQRT(w2); ww[0]*=sc; ww[1]*=sc; ww[2]*=sc; }
+    if (v2 > vm*vm) { R sc = vm/SQRT(v2); vw[0]*=sc; vw[1]*=sc; vw[2]*=sc; } }
   for (int i=0;i<3;++i) { root[7+i] = vw[i]; root[10+i] = ww[i]; root[i] += h*vw[i]; }
   { R th = SQRT(dot3(ww,ww))*h; R dq[4];
     if (th > RC(1e-9)) { R sc = SIN(th/2)/(th/h); dq[0]=ww[0]*sc; dq[1]=ww[1]*sc; dq[2]=ww[2]*sc; dq[3]=COS(th/2); }

@@ -204,6 +204,30 @@ def test_joint_stops_hold_against_saturated_motors(which):
     s.close()
 
 
+@pytest.mark.parametrize("which", ["oracle", "lane_emulation"])
+def test_state_stays_finite_in_a_runaway(which):
+    """The worst input the API admits — a free-floating robot, every motor saturated in one direction, then the other, for 160 steps —
+    spins the base up until the explicit integration diverges.  asset.max_linear_velocity / max_angular_velocity (legged_robot_config.py:
+    131-132, clamped on the base twist as PhysX does) bound it: every buffer stays finite and the clamp holds, so one env can never
+    poison a batch with NaN."""
+    from helpers import load_emu
+    lib = load_oracle() if which == "oracle" else load_emu()
+    s = HostSim(lib, num_envs=4, gravity=[0, 0, 0], push_robots=0, randomize_action_delay=0, max_linear_velocity=50.0, max_angular_velocity=100.0)
+    s.reset_all()
+    s.root_states[:, 2] = 3.0
+    for sign in (1.0, -1.0):
+        a = np.full((4, 12), sign * 40.0, np.float32)
+        for _ in range(80):
+            s.step(a)
+            for k in ("root_states", "dof_state", "obs_buf", "privileged_obs_buf", "rew_buf", "torques", "contact_forces"):
+                assert np.isfinite(np.asarray(getattr(s, k))).all(), k
+            r = np.asarray(s.root_states)
+            assert (np.linalg.norm(r[:, 7:10], axis=1) <= 50.0 * (1 + 1e-5)).all() and (np.linalg.norm(r[:, 10:13], axis=1) <= 100.0 * (1 + 1e-5)).all()
+    s.close()
+    d = lib.abi.Cfg(); lib.go2sim_default_cfg(d)
+    assert d.max_linear_velocity == 1000.0 and d.max_angular_velocity == 1000.0        # the reference's asset options
+
+
 @pytest.mark.skipif(not os.path.exists("/root/reference/resources/robots/go2/urdf/go2.urdf"), reason="container-only: needs the reference's URDF")
 def test_model_table_is_what_the_generator_derives_from_the_urdf(tmp_path):
     """include/go2_model_data.h (numbers only) is regenerated from the Go2 URDF by tools/gen_go2_model.py and must equal the committed
