@@ -311,10 +311,9 @@ struct LegPhys {
     for (int j = 0; j < 3; ++j) qdp[j] = fminf(fmaxf(qdp[j], -t.vel_lim[j]), t.vel_lim[j]);
     V3 lin_b = V0p.l + h * cross(wb, vb);
     ww = mul(Rwb, V0p.a); vw = mul(Rwb, lin_b);
-    {   // asset.max_angular_velocity / max_linear_velocity: the base twist is clamped, so no state can run off to inf
-      const float w2 = dot(ww, ww), v2 = dot(vw, vw);
-      if (w2 > L.max_ang_vel * L.max_ang_vel) ww = (L.max_ang_vel / sqrtf(w2)) * ww;
-      if (v2 > L.max_lin_vel * L.max_lin_vel) vw = (L.max_lin_vel / sqrtf(v2)) * vw;
+    {   // asset.max_angular_velocity / max_linear_velocity: the base twist is clamped, so no state can run off to inf (branch-free: x1 when inside)
+      ww = fminf(1.f, L.max_ang_vel / sqrtf(fmaxf(dot(ww, ww), 1e-30f))) * ww;
+      vw = fminf(1.f, L.max_lin_vel / sqrtf(fmaxf(dot(vw, vw), 1e-30f))) * vw;
     }
     pw = pw + h * vw;
     float th = sqrtf(dot(ww, ww)) * h; float dx, dy, dz, dwq;
