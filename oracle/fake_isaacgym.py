@@ -14,7 +14,6 @@ rand_like / randint_like / torch_rand_float call made from a known call site of 
 per-env uniforms from the [N, GO2_NUM_UNIFORMS] table instead of fresh random numbers, using the slot
 layout of include/go2sim.h.  Unknown call sites fall through to the real generator.
 """
-import inspect
 import sys
 import types
 

@@ -1,13 +1,12 @@
 """The C-ABI libraries export every symbol include/go2sim.h declares, and the structs agree with the header.  CPU only:
 no compute call is made on the HIP library here."""
 import ctypes as C
-import os
 import subprocess
 
 import numpy as np
 import pytest
 
-from helpers import ROOT, load_emu, load_oracle
+from helpers import load_emu, load_oracle
 from go2_rl_gym_amd import _abi, build
 
 
@@ -56,7 +55,6 @@ def test_product_refuses_to_run_without_the_gpu_library(monkeypatch, tmp_path):
 
 def test_wrap_buffers_square_shapes():
     """num_envs == 12 makes the [N, 12] buffers square: their field-major storage must still be viewed transposed."""
-    import torch
     from helpers import HostSim, load_emu
     from go2_rl_gym_amd.envs.base.base_task import wrap_buffers
     lib = load_emu()

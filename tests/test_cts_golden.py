@@ -2,7 +2,6 @@
 the reference's OnPolicyRunnerCTS.learn (on_policy_runner_cts.py:123-202) captured by oracle/gen_golden.py on a scripted env:
 same weights, observations, sampling noise and permutations in -> same actions, history ring, returns, advantages, final
 weights, learning rate and checkpoint layout out.  CPU; the library calls (GAE, history ring, fused loss) go to the oracle."""
-import ctypes as C
 import os
 
 import numpy as np

@@ -4,7 +4,6 @@
 import os, sys, tempfile, io, contextlib, re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import torch
 from go2_rl_gym_amd.envs import task_registry
 from go2_rl_gym_amd.utils import get_args
 task = sys.argv[1] if len(sys.argv) > 1 else "go2_flat"
