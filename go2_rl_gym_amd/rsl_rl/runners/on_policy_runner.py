@@ -54,7 +54,8 @@ def _enable_tuned_gemms():
         tn.enable(True)
         tn.tuning_enable(tune)
         tn.record_untuned_enable(False)
-        if tune:                       # keeps the shipped selections, tunes the shapes that are not in the table, writes the union to the cwd
+        if tune:                       # keeps the shipped selections, tunes the shapes that are not in the table and writes those to the cwd
+                                       # (append them to the shipped table)
             if os.path.exists(path):
                 tn.read_file(path)
             tn.set_max_tuning_duration(50)
@@ -62,7 +63,6 @@ def _enable_tuned_gemms():
         else:
             ok = tn.read_file(path)
             tn.set_filename(os.path.join(tempfile.gettempdir(), "go2_tunableop_unused.csv"))   # never write over the shipped table
-            tn.write_file_on_exit(False)                                                        # (and N ranks do not race on one file)
             if not ok:
                 tn.enable(False)       # validators (torch / hipBLASLt / arch) do not match this table
     except Exception as e:             # never fail the run over an optional speed-up
