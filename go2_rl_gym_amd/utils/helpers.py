@@ -69,7 +69,7 @@ def get_load_path(root, load_run=-1, checkpoint=-1):
             runs.remove("exported")
         last_run = os.path.join(root, runs[-1])
     except Exception:
-        raise ValueError("No runs in this directory: " + root)
+        raise ValueError("No runs in this directory: %s" % (root,))
     load_run = last_run if load_run == -1 else os.path.join(root, load_run)
     if checkpoint == -1:
         models = [f for f in os.listdir(load_run) if "model" in f]
