@@ -59,3 +59,22 @@ def test_train_checkpoint_resume(tmp_path):
         get_load_path(str(tmp_path / "nowhere"))
     with pytest.raises(ValueError, match="No runs"):
         get_load_path(None)
+
+
+def test_cli_accepts_the_reference_flags_and_derives_the_same_fields():
+    """helpers.py:128-157 + what gymutil.parse_arguments adds: every flag parses, the derived attributes the reference reads
+    back (helpers.py:56-70,153-156) are there, and args override the configs the way update_cfg_from_args does (:88-108)."""
+    from go2_rl_gym_amd.utils.helpers import update_cfg_from_args
+    a = get_args(["--task", "go2", "--resume", "--experiment_name", "e", "--run_name", "r", "--load_run", "x", "--checkpoint", "3", "--headless", "--horovod",
+                  "--rl_device", "cuda:1", "--num_envs", "8", "--seed", "2", "--max_iterations", "5", "--robogauge", "--robogauge_port", "9973",
+                  "--sim_device", "cuda:1", "--pipeline", "gpu", "--graphics_device_id", "0", "--physx", "--num_threads", "4", "--subscenes", "2", "--slices", "1"])
+    assert (a.sim_device_type, a.compute_device_id, a.use_gpu, a.use_gpu_pipeline) == ("cuda", 1, True, True)
+    assert (a.num_threads, a.subscenes, a.slices, a.robogauge, a.robogauge_port) == (4, 2, 1, True, 9973)
+    env_cfg, train_cfg = task_registry.get_cfgs("go2")
+    env_cfg, train_cfg = update_cfg_from_args(env_cfg, train_cfg, a)
+    assert env_cfg.env.num_envs == 8 and train_cfg.seed == 2 and train_cfg.runner.max_iterations == 5 and train_cfg.runner.resume is True
+    assert (train_cfg.runner.experiment_name, train_cfg.runner.run_name, train_cfg.runner.load_run, train_cfg.runner.checkpoint) == ("e", "r", "x", 3)
+    d = get_args(["--task", "go2_flat"])                  # defaults: GPU pipeline on device 0, nothing overridden
+    assert (d.sim_device_type, d.compute_device_id, d.num_envs, d.seed, d.max_iterations, d.resume) == ("cuda", 0, None, None, None, False)
+    c = get_args(["--task", "go2_flat", "--sim_device", "cpu"])
+    assert c.sim_device_type == "cpu" and c.use_gpu is False and c.use_gpu_pipeline is False
