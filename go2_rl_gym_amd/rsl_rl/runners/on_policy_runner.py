@@ -83,6 +83,7 @@ def _make_writer(log_dir):
 
 
 class OnPolicyRunner:
+    _TERRAIN_TAGS = False       # the PPO runner logs every episode key under 'Episode/' (on_policy_runner.py:191); the CTS runner splits off 'Terrain/' (:221-224)
     def __init__(self, env, train_cfg, log_dir=None, device="cpu", use_graphs=None):
         self.cfg = train_cfg["runner"]
         self.alg_cfg = train_cfg["algorithm"]
@@ -255,7 +256,7 @@ class OnPolicyRunner:
                     v = torch.as_tensor(v, dtype=torch.float, device=self.device).reshape(-1)
                     vals.append(v)
                 value = torch.mean(torch.cat(vals))
-                self.writer.add_scalar(("Terrain/" if "terrain" in key else "Episode/") + key, value, locs["it"])
+                self.writer.add_scalar(("Terrain/" if self._TERRAIN_TAGS and "terrain" in key else "Episode/") + key, value, locs["it"])
                 ep_string += f"""{f'Mean episode {key}:':>{pad}} {value:.4f}\n"""
         ac = self.alg.actor_critic
         mean_std = ac.std.mean() if hasattr(ac, "std") else ac.action_std.mean()       # MCP-CTS has no std parameter (on_policy_runner_cts.py:218-219)
@@ -264,7 +265,8 @@ class OnPolicyRunner:
         for (name, tag, _), v in zip(self._LOSS_NAMES, locs["losses"]):
             w.add_scalar(tag, v, locs["it"])
         w.add_scalar("Loss/learning_rate", self.alg.learning_rate, locs["it"])
-        w.add_scalar("Policy/mean_noise_std", mean_std.item(), locs["it"])
+        if hasattr(ac, "std"):         # not for the MCP actor, whose std is an output of the network (on_policy_runner_cts.py:239-240)
+            w.add_scalar("Policy/mean_noise_std", mean_std.item(), locs["it"])
         w.add_scalar("Perf/total_fps", fps, locs["it"])
         w.add_scalar("Perf/collection time", locs["collection_time"], locs["it"])
         w.add_scalar("Perf/learning_time", locs["learn_time"], locs["it"])

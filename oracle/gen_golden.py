@@ -415,7 +415,19 @@ class _ScriptedEnv:
         self.actions.append(actions.clone().numpy())
         t = self.t
         self.t += 1
-        return self.obs_seq[t + 1], self.priv_seq[t + 1], self.rew_seq[t], self.done_seq[t], {"time_outs": self.tout_seq[t]}
+        # 'episode': what LeggedRobot.reset_idx reports (:229-242) - a reward term and a terrain key, for the runners' scalar tags
+        return self.obs_seq[t + 1], self.priv_seq[t + 1], self.rew_seq[t], self.done_seq[t], {
+            "time_outs": self.tout_seq[t], "episode": {"rew_tracking_lin_vel": torch.tensor(0.25), "terrain_level": 1.5}}
+
+
+class _TagRecorder:
+    """stands in for the SummaryWriter: the scalar tags a runner writes, in order"""
+
+    def __init__(self):
+        self.tags = []
+
+    def add_scalar(self, tag, *a, **k):
+        self.tags.append(tag)
 
 
 def gen_cts(kind, seed=21):
@@ -496,6 +508,7 @@ def gen_cts(kind, seed=21):
     Normal.sample = sample
     torch.randperm = lambda n, **kw: perms[n]
     alg.update = update
+    runner.writer = _TagRecorder()
     try:
         runner.learn(1, init_at_random_ep_len=False)
     finally:
@@ -506,7 +519,8 @@ def gen_cts(kind, seed=21):
                actions=np.stack(env.actions), perm_teacher=perms[len(ti) * T].numpy(), perm_student=perms[len(si) * T].numpy(),
                teacher_env_idxs=ti.numpy(), student_env_idxs=si.numpy(), final_lr=np.float64(alg.learning_rate),
                checkpoint_keys=np.array(sorted(ckpt.keys())), optimizer1_groups=np.array([len(g["params"]) for g in ckpt["optimizer1_state_dict"]["param_groups"]]),
-               optimizer2_groups=np.array([len(g["params"]) for g in ckpt["optimizer2_state_dict"]["param_groups"]]), **rec)
+               optimizer2_groups=np.array([len(g["params"]) for g in ckpt["optimizer2_state_dict"]["param_groups"]]),
+               log_tags=np.array(runner.writer.tags), **rec)
     # act_inference on a fresh model copy state: deployment path (history shift inside the module)
     alg.model.history[:] = 0
     inf = [alg.model.act_inference(obs[t]).detach().numpy().copy() for t in range(3)]
@@ -535,6 +549,34 @@ def gen_cts(kind, seed=21):
     return out
 
 
+def gen_ppo_runner(seed=41):
+    """ONE iteration of the reference's OnPolicyRunner.learn (on_policy_runner.py:113-172) on the scripted env: the scalar tags it logs
+    (:185-207), the checkpoint layout (:243-250) and the parameter names."""
+    import tempfile
+    from rsl_rl.runners import OnPolicyRunner
+    g = torch.Generator().manual_seed(seed)
+    N, T = 8, 6
+    obs, priv = torch.randn(T + 1, N, 45, generator=g), torch.randn(T + 1, N, 263, generator=g)
+    rew = torch.randn(T, N, generator=g) * 0.05
+    dones = torch.rand(T, N, generator=g) < 0.3
+    touts = dones & (torch.rand(T, N, generator=g) < 0.5)
+    env = _ScriptedEnv(obs, priv, rew, dones, touts)
+    train_cfg = {"runner": dict(policy_class_name="ActorCritic", algorithm_class_name="PPO", num_steps_per_env=T, max_iterations=1, save_interval=50,
+                                experiment_name="golden", run_name=""),
+                 "algorithm": dict(value_loss_coef=1.0, use_clipped_value_loss=True, clip_param=0.2, entropy_coef=0.01, num_learning_epochs=2, num_mini_batches=2,
+                                   learning_rate=1e-3, schedule="adaptive", gamma=0.99, lam=0.95, desired_kl=0.01, max_grad_norm=1.0),
+                 "policy": dict(init_noise_std=1.0, actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16], activation="elu"),
+                 "robogauge": {"enabled": False, "port": 0}}
+    torch.manual_seed(seed)
+    runner = OnPolicyRunner(env, train_cfg, log_dir=tempfile.mkdtemp(), device="cpu")
+    runner.writer = _TagRecorder()
+    runner.learn(1, init_at_random_ep_len=False)
+    ckpt = torch.load(os.path.join(runner.log_dir, "model_1.pt"), weights_only=False)
+    return dict(log_tags=np.array(runner.writer.tags), checkpoint_keys=np.array(sorted(ckpt.keys())), checkpoint_iter=np.int64(ckpt["iter"]),
+                state_dict_keys=np.array(list(ckpt["model_state_dict"].keys())), saved_files=np.array(sorted(f for f in os.listdir(runner.log_dir) if f.startswith("model_"))),
+                obs=obs.numpy(), priv=priv.numpy(), rew=rew.numpy(), dones=dones.numpy().astype(np.uint8), time_outs=touts.numpy().astype(np.uint8))
+
+
 def _save(files, name, data):
     """Write tests/golden/<name> unless it already holds exactly these arrays (zip timestamps would churn the git history)."""
     path = os.path.join(OUT, name)
@@ -559,6 +601,7 @@ def main():
     _save(files, "terrain.npz", gen_terrain())
     _save(files, "gae.npz", gen_gae())
     _save(files, "ppo_update.npz", gen_ppo())
+    _save(files, "ppo_runner_log.npz", gen_ppo_runner())
     _save(files, "pretrained_go2_cts_150k.npz", gen_pretrained())
     _save(files, "cts_iteration.npz", gen_cts("CTS"))
     _save(files, "moe_cts_iteration.npz", gen_cts("MoECTS"))

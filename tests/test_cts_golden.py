@@ -43,7 +43,18 @@ class ScriptedEnv:
         self.actions.append(actions.clone().numpy())
         t = self.t
         self.t += 1
-        return self.obs_seq[t + 1], self.priv_seq[t + 1], self.rew_seq[t], self.done_seq[t], {"time_outs": self.tout_seq[t]}
+        return self.obs_seq[t + 1], self.priv_seq[t + 1], self.rew_seq[t], self.done_seq[t], {
+            "time_outs": self.tout_seq[t], "episode": {"rew_tracking_lin_vel": torch.tensor(0.25), "terrain_level": 1.5}}     # as oracle/gen_golden.py's env
+
+
+class TagRecorder:
+    """stands in for the SummaryWriter: the scalar tags a runner writes, in order"""
+
+    def __init__(self):
+        self.tags = []
+
+    def add_scalar(self, tag, *a, **k):
+        self.tags.append(tag)
 
 
 def _train_cfg(kind, T):
@@ -99,7 +110,9 @@ def test_one_iteration_matches_reference(kind, fixture, fused, monkeypatch, tmp_
         return real_update()
 
     alg.update = update
+    runner.writer = TagRecorder()
     runner.learn(1, init_at_random_ep_len=False)
+    assert runner.writer.tags == list(g["log_tags"])          # the TensorBoard scalars of on_policy_runner_cts.py:205-256, same names, same order
     np.testing.assert_allclose(np.stack(env.actions), g["actions"], atol=2e-6)
     np.testing.assert_array_equal(seen["history_after_rollout"], g["history_after_rollout"])      # the ring is pure data movement: exact
     np.testing.assert_array_equal(seen["history"], g["storage_history"])

@@ -78,3 +78,27 @@ def test_cli_accepts_the_reference_flags_and_derives_the_same_fields():
     assert (d.sim_device_type, d.compute_device_id, d.num_envs, d.seed, d.max_iterations, d.resume) == ("cuda", 0, None, None, None, False)
     c = get_args(["--task", "go2_flat", "--sim_device", "cpu"])
     assert c.sim_device_type == "cpu" and c.use_gpu is False and c.use_gpu_pipeline is False
+
+
+def test_ppo_runner_logs_and_saves_like_the_reference(tmp_path):
+    """One OnPolicyRunner.learn iteration on the scripted env of tests/test_cts_golden.py against what the reference's runner did on the same
+    env (oracle/gen_golden.py:gen_ppo_runner): the TensorBoard scalar tags in order (on_policy_runner.py:185-207 — every episode key under
+    'Episode/', no 'Terrain/' split in this runner), which checkpoints get written, their keys, and the parameter names."""
+    from go2_rl_gym_amd.rsl_rl.runners import OnPolicyRunner
+    from helpers import ROOT
+    from test_cts_golden import ScriptedEnv, TagRecorder
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "ppo_runner_log.npz")))
+    T = g["rew"].shape[0]
+    env = ScriptedEnv(g, load_oracle())
+    train_cfg = {"runner": dict(policy_class_name="ActorCritic", algorithm_class_name="PPO", num_steps_per_env=T, max_iterations=1, save_interval=50, experiment_name="golden", run_name=""),
+                 "algorithm": dict(value_loss_coef=1.0, use_clipped_value_loss=True, clip_param=0.2, entropy_coef=0.01, num_learning_epochs=2, num_mini_batches=2,
+                                   learning_rate=1e-3, schedule="adaptive", gamma=0.99, lam=0.95, desired_kl=0.01, max_grad_norm=1.0),
+                 "policy": dict(init_noise_std=1.0, actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16], activation="elu")}
+    runner = OnPolicyRunner(env, train_cfg, log_dir=str(tmp_path), device="cpu")
+    runner.writer = TagRecorder()
+    runner.learn(1, init_at_random_ep_len=False)
+    assert runner.writer.tags == list(g["log_tags"])
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("model_")) == list(g["saved_files"])
+    ck = torch.load(os.path.join(tmp_path, "model_1.pt"), weights_only=False)
+    assert sorted(ck) == list(g["checkpoint_keys"]) and ck["iter"] == int(g["checkpoint_iter"])
+    assert list(ck["model_state_dict"].keys()) == list(g["state_dict_keys"])
