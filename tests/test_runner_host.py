@@ -34,7 +34,7 @@ def test_train_checkpoint_resume(tmp_path):
     env.close()
 
     # --resume: the latest run, its highest checkpoint; the train.py flow restores the env's curriculum clock from the iteration count
-    env, runner, train_cfg = _make(tmp_path, "--resume")
+    env, runner, train_cfg = _make(tmp_path, "--resume", "--run_name", "second")       # (run directories are named by the second: keep the two apart)
     assert runner.current_learning_iteration == 2 and train_cfg.runner.resume is True
     np.testing.assert_array_equal(_flat(runner), w2)
     assert abs(runner.alg.learning_rate - lr2) < 1e-12
