@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GO2SIM_ABI_VERSION 2
+#define GO2SIM_ABI_VERSION 3   /* 3: Go2SimCfg gained max_linear_velocity / max_angular_velocity; go2sim_elu_backward_bias workspace is C*ceil(B/64) */
 
 #define GO2SIM_EINVAL   (-1)  /* bad argument / config */
 #define GO2SIM_ENOMEM   (-2)
