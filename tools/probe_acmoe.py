@@ -1,3 +1,5 @@
+"""Forward / backward wall time of the AC-MoE-CTS model at the mini-batch shape, piece by piece (found the N < 32 strided-batched
+GEMM cliff and the shared-gate two-stream hang).   python tools/probe_acmoe.py   (GPU)"""
 import sys, time, torch
 sys.path.insert(0, ".")
 from go2_rl_gym_amd.rsl_rl.modules import ActorCriticACMoECTS

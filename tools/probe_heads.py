@@ -1,3 +1,5 @@
+"""GroupedHeads (the MoE expert heads as one batched GEMM) forward + backward time for 1 / 12 / 32 output columns: strided-batched fp32
+GEMMs with N < 32 are ~100x slower on ROCm 7, hence the zero-padding to 32 columns in modules/utils.py.   python tools/probe_heads.py   (GPU)"""
 import sys, time, torch
 sys.path.insert(0, ".")
 from go2_rl_gym_amd.rsl_rl.modules.utils import GroupedHeads
