@@ -122,3 +122,20 @@ def test_curriculum_state_follows_the_counter():
         if n not in cur:
             assert r0[n] == r1[n] == r2[n] == 1.0
     s.close()
+
+
+def test_soak_under_training_like_action_noise():
+    """400 steps x 48 envs of N(0, 2) actions (twice the policy's initial exploration noise) through the lane programs: every buffer finite,
+    base spin far from the max_angular_velocity safety clamp (DESIGN.md 4 'validity range'), robots keep getting reset and re-spawned."""
+    s = HostSim(load_emu(), num_envs=N, seed=11)
+    s.reset_all()
+    rng = np.random.default_rng(0)
+    resets, wmax = 0, 0.0
+    for _ in range(400):
+        s.step(rng.normal(0, 2.0, (N, 12)).astype(np.float32))
+        resets += int(np.asarray(s.reset_buf).sum())
+        wmax = max(wmax, float(np.linalg.norm(np.asarray(s.root_states)[:, 10:13], axis=1).max()))
+        for k in ("root_states", "dof_state", "obs_buf", "privileged_obs_buf", "rew_buf", "torques", "contact_forces"):
+            assert np.isfinite(np.asarray(getattr(s, k))).all(), k
+    assert wmax < 60.0 and resets > 10, (wmax, resets)
+    s.close()
