@@ -142,6 +142,39 @@ def pit_terrain(terrain, depth, platform_size=1.0):                 # legged_gym
     terrain.height_field_raw[x1:x2, y1:y2] = -d
 
 
+def convert_heightfield_to_trimesh(height_field_raw, horizontal_scale, vertical_scale, slope_threshold=None):
+    """The triangle mesh PhysX gets for mesh_type 'trimesh' (isaacgym.terrain_utils, third-party and absent; restated from its documented
+    behaviour; used at legged_gym/utils/terrain.py:46-49).  One vertex per sample at (i*hs, j*hs, h*vs), two triangles per cell split along
+    (i,j)-(i+1,j+1).  With a slope threshold, the LOWER vertex of every edge steeper than it is moved one cell towards the higher one
+    (axis moves first, the diagonal move only where no axis move happened), which turns 1-cell ramps into vertical walls.
+    -> vertices float32 [rows*cols, 3], triangles uint32 [2*(rows-1)*(cols-1), 3]."""
+    hf = np.asarray(height_field_raw)
+    rows, cols = hf.shape
+    yy, xx = np.meshgrid(np.linspace(0, (cols - 1) * horizontal_scale, cols), np.linspace(0, (rows - 1) * horizontal_scale, rows))
+    if slope_threshold is not None:
+        thr = slope_threshold * horizontal_scale / vertical_scale           # in height units per cell
+        h = hf.astype(np.int64)
+        move_x, move_y, move_c = np.zeros((rows, cols)), np.zeros((rows, cols)), np.zeros((rows, cols))
+        move_x[:rows - 1, :] += h[1:, :] - h[:rows - 1, :] > thr
+        move_x[1:, :] -= h[:rows - 1, :] - h[1:, :] > thr
+        move_y[:, :cols - 1] += h[:, 1:] - h[:, :cols - 1] > thr
+        move_y[:, 1:] -= h[:, :cols - 1] - h[:, 1:] > thr
+        move_c[:rows - 1, :cols - 1] += h[1:, 1:] - h[:rows - 1, :cols - 1] > thr
+        move_c[1:, 1:] -= h[:rows - 1, :cols - 1] - h[1:, 1:] > thr
+        xx = xx + (move_x + move_c * (move_x == 0)) * horizontal_scale
+        yy = yy + (move_y + move_c * (move_y == 0)) * horizontal_scale
+    vertices = np.zeros((rows * cols, 3), dtype=np.float32)
+    vertices[:, 0], vertices[:, 1], vertices[:, 2] = xx.flatten(), yy.flatten(), hf.flatten() * vertical_scale
+    triangles = -np.ones((2 * (rows - 1) * (cols - 1), 3), dtype=np.uint32)
+    for i in range(rows - 1):
+        ind0 = np.arange(0, cols - 1) + i * cols
+        ind1, ind2, ind3 = ind0 + 1, ind0 + cols, ind0 + cols + 1
+        a, b = 2 * i * (cols - 1), 2 * (i + 1) * (cols - 1)
+        triangles[a:b:2, 0], triangles[a:b:2, 1], triangles[a:b:2, 2] = ind0, ind3, ind1
+        triangles[a + 1:b:2, 0], triangles[a + 1:b:2, 1], triangles[a + 1:b:2, 2] = ind0, ind2, ind3
+    return vertices, triangles
+
+
 KIND_NAMES = ("wave", "slope", "rough_slope", "stairs_up", "stairs_down", "obstacles", "stepping_stones", "gap", "flat")
 
 
@@ -171,8 +204,22 @@ class Terrain:
         else:
             self.randomized_terrain()
         self.heightsamples = self.height_field_raw
-        # mesh_type 'trimesh' (the reference's default) converts this same height field to triangles for PhysX; this build's
-        # contact queries work on the height field directly, so both mesh types share one collision representation.
+        # mesh_type 'trimesh' (the reference's default) converts this same height field to triangles for PhysX (:45-49); this build's
+        # contact queries work on the height field directly, so the mesh is only built when somebody asks for it (vertices / triangles).
+        self._trimesh = None
+
+    def _mesh(self):
+        if self._trimesh is None:
+            self._trimesh = convert_heightfield_to_trimesh(self.height_field_raw, self.cfg.horizontal_scale, self.cfg.vertical_scale, self.cfg.slope_treshold)
+        return self._trimesh
+
+    @property
+    def vertices(self):
+        return self._mesh()[0]
+
+    @property
+    def triangles(self):
+        return self._mesh()[1]
 
     def selected_terrain(self):
         """Every tile from ONE named generator (terrain.py:72-85; the reference's version dereferences attributes that do not

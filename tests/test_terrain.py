@@ -181,3 +181,47 @@ def test_rough_task_through_the_host_layer():
         assert abs(float(ep["terrain_level_" + name]) - float(env.terrain_levels[m].float().mean())) < 1e-5
     assert priv.shape == (40, 263) and float(env.measured_heights.abs().max()) > 0.02
     env.close()
+
+
+def test_heightfield_to_trimesh():
+    """convert_heightfield_to_trimesh (the mesh the reference hands PhysX for mesh_type 'trimesh', terrain.py:45-49): counts, the cell
+    diagonal the HIP contact query also uses, and the slope-threshold correction — a 1-cell ramp steeper than the threshold becomes a
+    vertical wall standing at the HIGH vertex, the low ground extending up to it; gentle slopes are untouched."""
+    from go2_rl_gym_amd.utils.terrain import convert_heightfield_to_trimesh
+    hs, vs = 0.1, 0.005
+    hf = np.zeros((6, 8), np.int16)
+    hf[3:, :] = 40                                    # a 0.2 m step across x between rows 2 and 3: slope 2.0 over one cell
+    hf[:, 6:] += 4                                    # a 0.02 m step across y between cols 5 and 6: slope 0.2
+    v0, t0 = convert_heightfield_to_trimesh(hf, hs, vs, None)
+    assert v0.shape == (48, 3) and v0.dtype == np.float32 and t0.shape == (2 * 5 * 7, 3) and t0.dtype == np.uint32
+    np.testing.assert_allclose(v0[:, 2].reshape(6, 8), hf * vs, atol=1e-7)
+    np.testing.assert_allclose(v0[:, 0].reshape(6, 8), np.arange(6)[:, None] * hs * np.ones((1, 8)), atol=1e-6)
+    np.testing.assert_array_equal(t0[0], [0, 9, 1]); np.testing.assert_array_equal(t0[1], [0, 8, 9])     # cell (0,0): split along (0,0)-(1,1)
+    assert t0.max() == 47
+    v1, t1 = convert_heightfield_to_trimesh(hf, hs, vs, 0.75)
+    np.testing.assert_array_equal(t1, t0)
+    x1, y1 = v1[:, 0].reshape(6, 8), v1[:, 1].reshape(6, 8)
+    np.testing.assert_allclose(x1[2], 0.3, atol=1e-6)            # the low row next to the step moved under the edge: wall at x = 0.3
+    np.testing.assert_allclose(x1[[0, 1, 3, 4, 5]], v0[:, 0].reshape(6, 8)[[0, 1, 3, 4, 5]], atol=1e-6)
+    y0 = v0[:, 1].reshape(6, 8)
+    np.testing.assert_allclose(y1[[0, 1, 3, 4, 5]], y0[[0, 1, 3, 4, 5]], atol=1e-6)                      # the gentle step is left alone
+    # the diagonal rule also fires along a straight wall (h[i+1,j+1] - h[i,j] > thr) and, having no y move to defer to, slides the wall-foot
+    # vertices one cell along the wall; their heights are those of the foot line, so the surface is the same
+    np.testing.assert_allclose(y1[2, :7], y0[2, :7] + hs, atol=1e-6); np.testing.assert_allclose(y1[2, 7], y0[2, 7], atol=1e-6)
+    np.testing.assert_array_equal(v1[:, 2], v0[:, 2])
+    # a one-sample pit: pulled both ways, stays where it is
+    pit = np.full((5, 5), 40, np.int16); pit[2, 2] = 0
+    vp, _ = convert_heightfield_to_trimesh(pit, hs, vs, 0.75)
+    np.testing.assert_allclose(vp[12, :2], [0.2, 0.2], atol=1e-6)
+
+
+def test_terrain_class_exposes_the_trimesh_lazily():
+    from go2_rl_gym_amd.envs.go2.go2_config import GO2Cfg
+    from go2_rl_gym_amd.utils.terrain import Terrain
+    tc = GO2Cfg().terrain
+    tc.mesh_type, tc.num_rows, tc.num_cols, tc.border_size = "trimesh", 2, 2, 1.0
+    np.random.seed(3)
+    t = Terrain(tc, 4)
+    assert t._trimesh is None
+    assert t.vertices.shape == (t.tot_rows * t.tot_cols, 3) and t.triangles.shape == (2 * (t.tot_rows - 1) * (t.tot_cols - 1), 3)
+    assert abs(float(t.vertices[:, 2].max()) - float(t.height_field_raw.max()) * tc.vertical_scale) < 1e-6
