@@ -344,9 +344,8 @@ def install():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from go2_rl_gym_amd.utils import terrain as _gen
     for n in ("SubTerrain", "random_uniform_terrain", "pyramid_sloped_terrain", "pyramid_stairs_terrain", "discrete_obstacles_terrain",
-              "wave_terrain", "stepping_stones_terrain"):
+              "wave_terrain", "stepping_stones_terrain", "convert_heightfield_to_trimesh"):
         setattr(terr, n, getattr(_gen, n))
-    terr.convert_heightfield_to_trimesh = lambda hf, hs, vs, thr: (np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint32))
     iso.gymapi, iso.gymutil, iso.gymtorch, iso.torch_utils, iso.terrain_utils = gymapi, gymutil, gymtorch, tu, terr
     for m in (iso, gymapi, gymutil, gymtorch, tu, terr):
         sys.modules[m.__name__] = m
