@@ -44,9 +44,21 @@ def parse():
 CPU_THREADS = 16
 
 
-def cpu_baseline(num_envs=512, task="go2_flat"):
-    """The same PPO iteration on the host CPU: the plain-C oracle (OpenMP) as the env + torch-CPU PPO, on a bounded
-    sample (1/8 of the envs, one full iteration after one warm-up).  Test-infrastructure code, timed only here."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(task="go2_flat", sizes=(64, NUM_ENVS), iters=3):
+    """The same PPO iteration on the host CPU: the plain-C oracle (OpenMP over envs) as the env + torch-CPU PPO, at
+    N = 64 (BASELINE config 1) and N = 4096 (the headline size), `iters` timed iterations each after one warm-up iteration, collection-only
+    and total.  The reference's own --sim_device=cpu path cannot run anywhere (Isaac Gym is absent), so this is the build's CPU
+    restatement of the same path ("kind": "port").  Test-infrastructure code, timed only here, never inside the GPU region."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import load_oracle
@@ -54,23 +66,32 @@ def cpu_baseline(num_envs=512, task="go2_flat"):
     from go2_rl_gym_amd.utils import get_args
     cores = min(os.cpu_count() or 1, CPU_THREADS)     # threads actually used: more only oversubscribes these small problems
     torch.set_num_threads(cores)
-    args = get_args(["--task", task, "--num_envs", str(num_envs), "--sim_device", "cpu", "--rl_device", "cpu", "--headless"])
-    env, _ = task_registry.make_env(task, args, lib=load_oracle())
-    runner, _ = task_registry.make_alg_runner(env, task, args, log_root=None)
-    runner.learn(1, init_at_random_ep_len=True)
-    t0 = time.time()
-    runner.learn(1)
-    dt = time.time() - t0
-    env.close()
-    return {"value": num_envs * 24 / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "num_envs=%d (1/%d of the workload), 1 full PPO iteration (24 steps + 5x4 mini-batches) after 1 warm-up; oracle env (OpenMP) + torch-CPU PPO; "
-                      "collection %.2fs, learning %.2fs" % (num_envs, NUM_ENVS // num_envs, runner.last_collection_time, runner.last_learn_time)}
+    per_size = {}
+    for n in sizes:
+        args = get_args(["--task", task, "--num_envs", str(n), "--sim_device", "cpu", "--rl_device", "cpu", "--headless"])
+        env, _ = task_registry.make_env(task, args, lib=load_oracle())
+        runner, _ = task_registry.make_alg_runner(env, task, args, log_root=None)
+        runner.learn(1, init_at_random_ep_len=True)
+        tot = col = 0.0
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            runner.learn(1)
+            tot += time.perf_counter() - t0
+            col += runner.last_collection_time
+        env.close()
+        per_size[str(n)] = {"env_steps_per_s": n * 24 * iters / tot, "collection_only_env_steps_per_s": n * 24 * iters / col, "iterations": iters, "seconds": tot}
+    head = per_size[str(sizes[-1])]
+    return {"value": head["env_steps_per_s"], "unit": "env-steps/s", "cores": cores, "kind": "port", "nproc": os.cpu_count(), "omp_threads": int(os.environ.get("OMP_NUM_THREADS", cores)),
+            "torch_threads": cores, "cpu_model": _cpu_model(), "collection_only": head["collection_only_env_steps_per_s"], "per_num_envs": per_size,
+            "sample": "oracle env (plain C, OpenMP) + torch-CPU PPO; full PPO iterations (24 steps + GAE + 5x4 mini-batches), %d timed after 1 warm-up, at num_envs = %s; "
+                      "value = the num_envs=%d line (the headline size)" % (iters, " and ".join(str(n) for n in sizes), sizes[-1])}
 
 
 def main():
     a = parse()
     os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, CPU_THREADS)))   # read by libgomp (the oracle) at load
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")                               # dmabuf IPC for RCCL across processes (host driver requirement)
+    os.environ.setdefault("GO2_STRICT_GRAPHS", "1")          # a failed HIP-graph capture raises: no number from a silently degraded (eager) run
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -98,7 +119,19 @@ def main():
     env.update_reward_curriculum(force_update=True)
 
     runner.learn(a.warmup, init_at_random_ep_len=True)        # untimed: also brings resets/pushes/resamples to steady state
+    extra = 0
+    while not all(runner.graphs_captured().values()) and extra < 6:     # a --warmup shorter than the capture schedule (rollout: 3rd iteration,
+        runner.learn(1); extra += 1                                      # update slot 0: its 4th call): finish capturing, still untimed
 
+    # every RCCL collective issued from Python inside the timed region is counted (the driver can check that RCCL saw N ranks and how often)
+    ncoll = {"all_reduce": 0}
+    if dist.is_initialized():
+        _ar = dist.all_reduce
+
+        def counted_all_reduce(*args_, **kw):
+            ncoll["all_reduce"] += 1
+            return _ar(*args_, **kw)
+        dist.all_reduce = counted_all_reduce
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -111,6 +144,11 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if dist.is_initialized():
+        dist.all_reduce = _ar
+    graphs = runner.graphs_captured()
+    if not (graphs["rollout"] and graphs["update"]):
+        raise SystemExit("bench.py: HIP-graph capture degraded to eager execution (%r): refusing to report a number for a different execution mode" % (graphs,))
     # The rollout is replayed from a HIP graph, where per-launch events cannot be recorded; so the dominant kernel is timed
     # right after the timed region, live, with HIP events on the stream it is launched on: 48 eager env steps from the same
     # (steady-state) simulator state under the current policy.  profiles/*kernel_stats.csv of the same command must agree.
@@ -158,6 +196,10 @@ def main():
                                    % ("go2 flat terrain (go2_flat)" if a.task == "go2_flat" else a.task + " (NOT the BASELINE workload)", N),
                        "num_envs_per_gpu": N, "num_steps_per_env": 24, "parallelism": "env-sharded dp%d" % world},
             "collection_only": world * N * 24 * a.steps / col,
+            "graphs": graphs,      # both halves of every timed iteration were replayed from HIP graphs (bench.py exits non-zero otherwise)
+            "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+            "collectives_per_iteration": {"all_reduce": ncoll["all_reduce"] / max(a.steps, 1),
+                                          "what": "1 x 24-byte fp64 advantage-statistics all-reduce (rollout_storage.py:137) + 1 flat gradient+KL bucket per mini-batch step (5 x 4)"},
             "roofline": {"bound": "hbm", "kernel": "go2_step_kernel<PHYS|POST>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo * N, "kernel_ms": k_ms, "launches": n.value, "algorithmic_bytes_per_env_step": algo,
                          "note": "latency/occupancy-bound by construction: 4096 envs x 4 lanes = 256 waves for 1024 SIMDs; the binding resource is VALU issue, "

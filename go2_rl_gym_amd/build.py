@@ -28,7 +28,18 @@ def hipcc_path():
     raise RuntimeError("hipcc not found (need ROCm): the HIP library is the only compute path of this package")
 
 
-def build_hip(force=False, verbose=False):
+PRECISE_OUT = os.path.join(ROOT, "tests", "emu", "libgo2sim_hip_precise.so")
+
+
+def build_hip_precise(force=False):
+    """TEST-ONLY second device build of the same source without -ffast-math (IEEE division / sqrt / no reassociation), next to the host
+    emulation under tests/emu/: tests/test_gpu_parity.py uses it to separate fast-math artefacts from fp32 conditioning."""
+    return build_hip(force=force, out=PRECISE_OUT, flags=[])
+
+
+def build_hip(force=False, verbose=False, out=OUT, flags=None):
+    OUT, EXTRA_FLAGS = out, (globals()["EXTRA_FLAGS"] if flags is None else flags)
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= max(os.path.getmtime(p) for p in _deps()):
         return OUT
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + EXTRA_FLAGS + ["-o", OUT, SRC]

@@ -13,14 +13,39 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define GO2_HD __host__ __device__ __forceinline__
-#if defined(__HIP_DEVICE_COMPILE__)
-#define GO2_DIV_RN(a, b) __fdiv_rn((a), (b))      // IEEE round-to-nearest even under -ffast-math
-#else
-#define GO2_DIV_RN(a, b) ((a) / (b))
-#endif
 #else
 #define GO2_HD inline
-#define GO2_DIV_RN(a, b) ((a) / (b))
+#endif
+
+// ---- individually rounded fp32 operations -------------------------------------------------------------------------------
+// INDEX arithmetic that the reference does in eager torch (one correctly rounded IEEE operation per tensor op) must come out
+// bit-identical here: a sample that lands an ulp on the other side of a cell boundary reads a different height.  The device build
+// uses -ffast-math (FMA contraction, rcp-based division, 1-ulp sqrt; pragmas do not switch contraction off on this target), so
+// these are spelled so that the compiler cannot touch them: single VALU instructions through inline asm, division / sqrt by the
+// exactly-rounded constructions below.  Host builds (oracle-side emulation, x86-64 without FMA) use the plain operators.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float go2_mul_rn(float a, float b) { float r; asm("v_mul_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float go2_add_rn(float a, float b) { float r; asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float go2_sub_rn(float a, float b) { float r; asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// a / b: the quotient formed in fp64 and rounded once more to fp32 is the correctly rounded fp32 quotient (53 >= 2*24 + 2 bits; the
+// exact quotient of two fp32 numbers stays >= 2^-49 (relative) away from every fp32 rounding boundary, the fp64 result is within 2^-51)
+__device__ __forceinline__ float go2_div_rn(float a, float b) { return (float)((double)a / (double)b); }
+__device__ __forceinline__ float go2_mul_inv_rn(float a, double inv_b) { return (float)((double)a * inv_b); }   // a / b with inv_b = 1.0 / (double)b
+// sqrt: the hardware's 1-ulp v_sqrt_f32 moved to the correctly rounded neighbour by two exact FMA residual tests
+__device__ __forceinline__ float go2_sqrt_rn(float x) {
+  float y = __builtin_amdgcn_sqrtf(x);
+  const float yd = __int_as_float(__float_as_int(y) - 1), yu = __int_as_float(__float_as_int(y) + 1);
+  const float vp = __builtin_fmaf(-yd, y, x), vs = __builtin_fmaf(-yu, y, x);
+  y = vp <= 0.f ? yd : y; y = vs > 0.f ? yu : y;
+  return x == 0.f ? 0.f : y;
+}
+#else
+GO2_HD float go2_mul_rn(float a, float b) { return a * b; }
+GO2_HD float go2_add_rn(float a, float b) { return a + b; }
+GO2_HD float go2_sub_rn(float a, float b) { return a - b; }
+GO2_HD float go2_div_rn(float a, float b) { return a / b; }
+GO2_HD float go2_mul_inv_rn(float a, double inv_b) { return (float)((double)a * inv_b); }
+GO2_HD float go2_sqrt_rn(float x) { return sqrtf(x); }
 #endif
 
 struct V3 { float x, y, z; };

@@ -153,15 +153,19 @@ struct LegPost {
     acc[0] += cmd[0]; acc[1] += cmd[1];
   }
   float to_timer;
-  // one sample of _get_heights (:1188-1224) around base (bx, by) with yaw quaternion (0,0,yz,yw)
+  // one sample of _get_heights (:1188-1224) around base (bx, by) with yaw quaternion (0,0,yz,yw).  INDEX work: every operation is
+  // rounded on its own, in the reference's order (quat_apply: t = 2 cross(q, v); v + w t + cross(q, t); then + base, + border, / scale,
+  // truncate), so the cell index equals the reference's bit for bit (go2_math.h: go2_*_rn).
   GO2_HD float height_at(int i, float yz, float yw, float bx, float by) const {
     const Go2Launch& c = *L;
     if (c.terrain_mode == 0) return 0.f;
     const int ix = i / 11, iy = i - 11 * ix;
-    V3 w = quat_apply(0.f, 0.f, yz, yw, v3((float)(ix - 8) * 0.1f, (float)(iy - 5) * 0.1f, 0.f));
-    // correctly rounded division (the build uses -ffast-math, whose reciprocal-multiply can land a sample that sits exactly on a cell
-    // boundary in the neighbouring cell: one such sample in 10^5 showed up against the reference's golden vectors)
-    float x = GO2_DIV_RN(w.x + bx + c.hf_border, c.hf_hscale), y = GO2_DIV_RN(w.y + by + c.hf_border, c.hf_hscale);
+    const float vx = (float)(ix - 8) * 0.1f, vy = (float)(iy - 5) * 0.1f;      // height_points: 0.1 * [-8..8] x 0.1 * [-5..5] (legged_robot_config.py:26-27)
+    // q = (0, 0, yz, yw): c = cross(q, v) = (-yz vy, yz vx, 0), cc = cross(q, c) = (-yz c.y, yz c.x, 0); o = (v + (2 yw) c) + 2 cc
+    const float cx = -go2_mul_rn(yz, vy), cy = go2_mul_rn(yz, vx), w2 = 2.f * yw;
+    const float ccx = -go2_mul_rn(yz, cy), ccy = go2_mul_rn(yz, cx);
+    const float wx = go2_add_rn(go2_add_rn(vx, go2_mul_rn(w2, cx)), 2.f * ccx), wy = go2_add_rn(go2_add_rn(vy, go2_mul_rn(w2, cy)), 2.f * ccy);
+    const float x = go2_mul_inv_rn(go2_add_rn(go2_add_rn(wx, bx), c.hf_border), c.hf_inv_hscale), y = go2_mul_inv_rn(go2_add_rn(go2_add_rn(wy, by), c.hf_border), c.hf_inv_hscale);
     int px = (int)x, py = (int)y;
     px = px < 0 ? 0 : (px > c.hf_rows - 2 ? c.hf_rows - 2 : px); py = py < 0 ? 0 : (py > c.hf_cols - 2 ? c.hf_cols - 2 : py);
     int h1 = P->hf[px * c.hf_cols + py], h2 = P->hf[(px + 1) * c.hf_cols + py], h3 = P->hf[px * c.hf_cols + py + 1];
@@ -211,7 +215,8 @@ struct LegPost {
     // _get_heights (:1188-1224): this lane samples points lane, lane+4, ...
     float hsum = 0.f;
     if (c.measure_heights && c.terrain_mode != 0) {   // on a plane measured_heights stays the all-zero buffer it was created as (:1201-1202)
-      float nn = fmaxf(sqrtf(qz * qz + qw * qw), 1e-9f), yz = qz / nn, yw = qw / nn;  // quat_apply_yaw (utils/math.py:8-12)
+      // quat_apply_yaw (utils/math.py:8-12): zero x, y, normalise — individually rounded, it feeds the cell index
+      const float nn = fmaxf(go2_sqrt_rn(go2_add_rn(go2_mul_rn(qz, qz), go2_mul_rn(qw, qw))), 1e-9f), yz = go2_div_rn(qz, nn), yw = go2_div_rn(qw, nn);
       for (int i = lane; i < GO2_NUM_HEIGHT_POINTS; i += 4) {
         const float hv = height_at(i, yz, yw, o.pw.x, o.pw.y);
         const int ix = i / 11, iy = i - 11 * ix;

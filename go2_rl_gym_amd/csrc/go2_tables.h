@@ -65,6 +65,7 @@ typedef Go2Ptrs Go2PtrsK;
 
 // everything a launch needs besides pointers: config constants + the host-side scalars of this step
 struct Go2Launch {
+  double hf_inv_hscale;   // 1.0 / (double)hf_hscale: x * this, rounded to fp32, is the correctly rounded fp32 quotient x / hf_hscale (go2_math.h)
   int32_t N, env_offset, decimation, solver_iterations;
   uint32_t seed_lo, seed_hi;
   float sim_dt, dt, gravity[3], contact_offset, erp, max_depen_vel, bounce_thr, cfm, armature, limit_margin, max_lin_vel, max_ang_vel;

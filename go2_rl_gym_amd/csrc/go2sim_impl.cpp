@@ -293,6 +293,37 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   }
 }
 
+// ---- test hooks (declared in include/go2sim.h under "test hooks"; no product path calls them) --------------------------------
+// legged_robot.py:67-81 on the kernel's own pd() / delay select with caller-supplied DOF states per substep ("fake physics"): what the
+// oracle's go2o_torque_trace does, so the reference's golden torques can be compared with the HIP arithmetic directly.
+__global__ void __launch_bounds__(64) go2_torque_trace_kernel(const Go2DevBlock* __restrict__ blk, const float* __restrict__ actions_raw, const float* __restrict__ dof, float* __restrict__ out) {
+  __shared__ Go2Tables tab; __shared__ Go2Step S;
+  const Go2PtrsK& p = *(const Go2PtrsK*)&blk->p; const Go2Launch& L = blk->L;
+  { const uint32_t* src = reinterpret_cast<const uint32_t*>(p.tables); uint32_t* dst = reinterpret_cast<uint32_t*>(&tab);
+    for (int i = threadIdx.x; i < (int)(sizeof(Go2Tables) / 4); i += 64) dst[i] = src[i];
+    if (threadIdx.x == 0) go2_step_scalars(L, blk->dyn, p.inj_storage, blk->dyn.common_step_counter, 0, &S); }
+  __syncthreads();
+  const int e = blockIdx.x * 16 + (threadIdx.x >> 2), lane = threadIdx.x & 3, N = L.N;
+  if (e >= N) return;
+  LegPhys ph_; LegPost po_; LaneAux ax;
+  lane_load_phys(ph_, po_, ax, tab, p, L, S, actions_raw, e, lane);
+  const LegTab& t = tab.leg[lane];
+  for (int sub = 0; sub < L.decimation; ++sub) {
+    const bool old = L.rand_delay && sub < ax.start;
+    const float a[3] = {old ? ax.act_old[0] : ax.act_new[0], old ? ax.act_old[1] : ax.act_new[1], old ? ax.act_old[2] : ax.act_new[2]};
+    for (int j = 0; j < 3; ++j) { const float* d = dof + (((size_t)sub * N + e) * 12 + 3 * lane + j) * 2; ph_.q[j] = d[0]; ph_.qd[j] = d[1]; }
+    ph_.pd(t, L, a, ax.kp, ax.kd, ax.q0, ax.zoff, ax.strength);
+    for (int j = 0; j < 3; ++j) { out[((size_t)sub * N + e) * 12 + 3 * lane + j] = ph_.tau[j]; F2D(p.torques, 3 * lane + j, e) = ph_.tau[j]; }
+  }
+}
+// the individually rounded operations of go2_math.h over arrays: out[0..4][n] = a*b, a+b, a-b, a/b, sqrt(|a|)
+__global__ void go2_strict_ops_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n, double inv_b0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = go2_mul_rn(a[i], b[i]); out[n + i] = go2_add_rn(a[i], b[i]); out[2 * (size_t)n + i] = go2_sub_rn(a[i], b[i]);
+  out[3 * (size_t)n + i] = go2_div_rn(a[i], b[i]); out[4 * (size_t)n + i] = go2_sqrt_rn(fabsf(a[i])); out[5 * (size_t)n + i] = go2_mul_inv_rn(a[i], inv_b0);
+}
+
 // after a step: extras["episode"] means, then advance the device-resident counters
 __global__ void go2_finish_kernel(Go2DevBlock* blk, int counter_inc) {
   float* accum = blk->p.ep_accum; float* info = blk->p.episode_info;
@@ -698,7 +729,7 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
   L.contact_offset = cfg->contact_offset; L.erp = cfg->erp; L.max_depen_vel = cfg->max_depenetration_velocity; L.bounce_thr = cfg->bounce_threshold_velocity;
   L.cfm = cfg->contact_cfm; L.armature = cfg->joint_armature; L.limit_margin = cfg->joint_limit_margin;
   L.max_lin_vel = cfg->max_linear_velocity; L.max_ang_vel = cfg->max_angular_velocity;
-  L.terrain_mode = cfg->terrain_mode; L.hf_rows = cfg->hf_rows; L.hf_cols = cfg->hf_cols; L.hf_hscale = cfg->hf_hscale; L.hf_vscale = cfg->hf_vscale; L.hf_border = cfg->hf_border;
+  L.terrain_mode = cfg->terrain_mode; L.hf_rows = cfg->hf_rows; L.hf_cols = cfg->hf_cols; L.hf_hscale = cfg->hf_hscale; L.hf_inv_hscale = cfg->hf_hscale != 0.f ? 1.0 / (double)cfg->hf_hscale : 0.0; L.hf_vscale = cfg->hf_vscale; L.hf_border = cfg->hf_border;
   L.terrain_friction = cfg->terrain_friction; L.terrain_restitution = cfg->terrain_restitution; L.terrain_num_levels = cfg->terrain_num_levels; L.terrain_num_types = cfg->terrain_num_types;
   L.terrain_curriculum = cfg->terrain_curriculum; L.move_down_by_acc = cfg->move_down_by_accumulated_xy_command; L.measure_heights = cfg->measure_heights; L.full_body_states = cfg->full_body_states; L.terrain_length = cfg->terrain_length;
   memcpy(L.kp, cfg->kp, sizeof(L.kp)); memcpy(L.kd, cfg->kd, sizeof(L.kd)); memcpy(L.q0, cfg->default_dof_pos, sizeof(L.q0));
@@ -952,6 +983,45 @@ int go2sim_peek_uniforms(Go2Sim* s, float* out, void* stream) {
 #else
   int n = s->N * GO2_NUM_UNIFORMS;
   hipLaunchKernelGGL(go2_peek_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, s->d_tables, s->N, s->cfg.env_offset, (uint32_t)sc, (uint32_t)(sc >> 32), (uint32_t)s->cfg.seed, (uint32_t)(s->cfg.seed >> 32));
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+// ---- test hooks --------------------------------------------------------------------------------------------------------------
+int go2sim_debug_torque_trace(Go2Sim* s, const float* actions_raw, const float* dof, float* out, void* stream) {
+  if (!s || !actions_raw || !dof || !out) FAIL(GO2SIM_EINVAL, "null argument");
+#ifdef GO2_EMU
+  (void)stream;
+  Go2DevBlock* blk = s->d_blk; Go2Tables& tab = *s->d_tables; const Go2Ptrs& p = blk->p; const Go2Launch& L = blk->L; const int N = L.N;
+  Go2Step S; go2_step_scalars(L, blk->dyn, p.inj_storage, blk->dyn.common_step_counter, 0, &S);
+  for (int e = 0; e < N; ++e) for (int lane = 0; lane < 4; ++lane) {
+    static thread_local LegPhys ph_; static thread_local LegPost po_; static thread_local LaneAux ax;
+    lane_load_phys(ph_, po_, ax, tab, p, L, S, actions_raw, e, lane);
+    for (int sub = 0; sub < L.decimation; ++sub) {
+      const bool old = L.rand_delay && sub < ax.start;
+      const float a[3] = {old ? ax.act_old[0] : ax.act_new[0], old ? ax.act_old[1] : ax.act_new[1], old ? ax.act_old[2] : ax.act_new[2]};
+      for (int j = 0; j < 3; ++j) { const float* d = dof + (((size_t)sub * N + e) * 12 + 3 * lane + j) * 2; ph_.q[j] = d[0]; ph_.qd[j] = d[1]; }
+      ph_.pd(tab.leg[lane], L, a, ax.kp, ax.kd, ax.q0, ax.zoff, ax.strength);
+      for (int j = 0; j < 3; ++j) { out[((size_t)sub * N + e) * 12 + 3 * lane + j] = ph_.tau[j]; F2D(p.torques, 3 * lane + j, e) = ph_.tau[j]; }
+    }
+  }
+#else
+  hipLaunchKernelGGL(go2_torque_trace_kernel, dim3((s->N + 15) / 16), dim3(64), 0, (hipStream_t)stream, s->d_blk, actions_raw, dof, out);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+int go2sim_debug_strict_ops(const float* a, const float* b, float* out, int32_t n, void* stream) {
+  if (!a || !b || !out || n <= 0) FAIL(GO2SIM_EINVAL, "bad argument");
+#ifdef GO2_EMU
+  (void)stream;
+  const double inv = 1.0 / (double)b[0];
+  for (int i = 0; i < n; ++i) { out[i] = go2_mul_rn(a[i], b[i]); out[n + i] = go2_add_rn(a[i], b[i]); out[2 * (size_t)n + i] = go2_sub_rn(a[i], b[i]);
+    out[3 * (size_t)n + i] = go2_div_rn(a[i], b[i]); out[4 * (size_t)n + i] = go2_sqrt_rn(fabsf(a[i])); out[5 * (size_t)n + i] = go2_mul_inv_rn(a[i], inv); }
+#else
+  float b0 = 0.f; HIPCHK(hipMemcpyAsync(&b0, b, sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream)); HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  hipLaunchKernelGGL(go2_strict_ops_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, b, out, n, 1.0 / (double)b0);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

@@ -83,6 +83,11 @@ class LeggedRobot(BaseTask):
             hs = np.ascontiguousarray(self.terrain.heightsamples, dtype=np.int16)
             org = np.ascontiguousarray(self.terrain.env_origins, dtype=np.float32)
             ids = np.ascontiguousarray(self.terrain.cols2id, dtype=np.int32)
+            if ids.shape[0] == 0:
+                # Terrain fills cols2id only in curiculum() (utils/terrain.py); with terrain.curriculum off (play.py) the reference has no
+                # terrain_ids and falls back to the global command ranges / the default tracking sigma (legged_robot.py:863,1074-1075,1303).
+                # The library's sentinel for "no terrain kind" is -1.
+                ids = np.full(cfg.terrain.num_cols, -1, dtype=np.int32)
             if ids.shape[0] != cfg.terrain.num_cols:
                 raise ValueError("terrain.cols2id has %d entries for %d columns" % (ids.shape[0], cfg.terrain.num_cols))
             self._terrain_host = (hs, org, ids)                                    # keep alive until go2sim_create has copied them
@@ -280,7 +285,8 @@ class LeggedRobot(BaseTask):
             hs, org, ids = self._terrain_host
             self.height_samples = torch.from_numpy(hs).view(self.terrain.tot_rows, self.terrain.tot_cols).to(dev)
             self.terrain_cols2id = torch.from_numpy(ids).to(dev).long()
-            self.terrain_ids = self.terrain_cols2id[self.terrain_types]
+            if len(self.terrain.cols2id):                                            # (:1074-1075) no terrain_ids attribute without a curriculum layout
+                self.terrain_ids = self.terrain_cols2id[self.terrain_types]
             self.max_terrain_level = self.cfg.terrain.num_rows
             self.terrain_origins = torch.from_numpy(org).to(dev)
             # extras terrain_level_<name> (:230-235): one [groups, N] membership matrix, applied to terrain_levels per step

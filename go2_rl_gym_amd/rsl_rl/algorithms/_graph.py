@@ -47,6 +47,22 @@ class GradBucket:
         return self.extra
 
 
+def strict_graphs():
+    """GO2_STRICT_GRAPHS=1 (bench.py sets it): a failed HIP-graph capture raises instead of degrading to eager execution."""
+    return os.environ.get("GO2_STRICT_GRAPHS", "0") == "1"
+
+
+def all_captured(steps):
+    """True iff every CapturedStep / ReducedStep of `steps` (nested lists allowed) is being replayed from a HIP graph."""
+    if steps is None:
+        return False
+    if isinstance(steps, (list, tuple)):
+        return len(steps) > 0 and all(all_captured(s) for s in steps)
+    if isinstance(steps, ReducedStep):
+        return steps.front.graph is not None and steps.back.graph is not None
+    return steps.graph is not None
+
+
 class CapturedStep:
     def __init__(self, fn, enabled=True, warmup=3, name="step"):
         self.fn, self.enabled, self.warmup, self.name = fn, enabled, warmup, name
@@ -63,7 +79,9 @@ class CapturedStep:
             try:
                 with torch.cuda.graph(g):
                     self.fn()
-            except Exception as e:      # noqa: BLE001 — any capture problem degrades to eager execution
+            except Exception as e:      # noqa: BLE001 — any capture problem degrades to eager execution (unless GO2_STRICT_GRAPHS=1)
+                if strict_graphs():
+                    raise RuntimeError("HIP-graph capture of %s failed (%s: %s)" % (self.name, type(e).__name__, e)) from e
                 print("[go2_rl_gym_amd] HIP-graph capture of %s failed (%s: %s); continuing eagerly" % (self.name, type(e).__name__, e))
                 self.enabled = False
                 torch.cuda.synchronize()

@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.optim as optim
 
 from ..storage import RolloutStorageCTS
-from ._graph import CapturedStep, GradBucket, ReducedStep, collectives_in_graph
+from ._graph import CapturedStep, GradBucket, ReducedStep, all_captured, collectives_in_graph
 from .ppo import _ADAM_IMPL, _collectives_on, _FusedPPOLoss, _RolloutHeads, _world, allreduce_mean_bucket
 
 
@@ -354,6 +354,10 @@ class CTS(_RolloutHeads):
         out = (self._acc / n).tolist()
         self.learning_rate = float(self._lr_t.item())
         return self._ordered(tuple(out))
+
+    def graphs_captured(self):
+        """True iff every policy / student mini-batch step is being replayed from a HIP graph."""
+        return bool(self.use_graphs and self._capture and all_captured(self._steps))
 
     def update(self):
         out = self._update_graphs() if self.use_graphs else self._update_eager()

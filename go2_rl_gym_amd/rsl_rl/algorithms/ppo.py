@@ -23,7 +23,7 @@ import torch.nn as nn
 import torch.optim as optim
 
 from ..storage import RolloutStorage
-from ._graph import CapturedStep, GradBucket, ReducedStep, collectives_in_graph
+from ._graph import CapturedStep, GradBucket, ReducedStep, all_captured, collectives_in_graph
 
 
 # Adam as ONE multi-tensor kernel per param group (fused) instead of ~6 foreach launches; GO2_ADAM=foreach restores the latter
@@ -393,6 +393,11 @@ class PPO(_RolloutHeads):
         acc = (self._acc / n).tolist()
         self.learning_rate = float(self._lr_t.item())
         return acc[0], acc[1]
+
+    def graphs_captured(self):
+        """True iff every mini-batch step of the update is being replayed from a HIP graph (bench.py reports it and refuses to quote a
+        number from a silently degraded run)."""
+        return bool(self.use_graphs and self._capture and all_captured(self._graph))
 
     def update(self):
         if self.use_graphs:

@@ -128,7 +128,8 @@ class ActorCriticCTS(nn.Module):
     # -- whole-batch surface: rows [0, n_teacher) are teacher rows, the rest student rows --------------------
     def latents(self, privileged_obs, history, n_teacher):
         lt = self.teacher_encoder(privileged_obs[:n_teacher])
-        ls = self.student_latent(history[n_teacher:])[0].detach()      # the policy loss never reaches the student encoder (:145)
+        with torch.no_grad():                                          # the policy loss never reaches the student encoder (:145), and its
+            ls = self.student_latent(history[n_teacher:])[0]           # parameters are not in optimizer1: no activations kept for a backward
         return torch.cat([lt, ls], dim=0)
 
     def act_joint(self, obs, latent):

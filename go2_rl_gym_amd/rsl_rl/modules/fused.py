@@ -17,13 +17,14 @@ import torch.nn.functional as F
 
 _LIB = None
 _WGRAD_SPLIT = int(os.environ.get("GO2_WGRAD_SPLIT", "8"))       # 1 = plain mm
+_WGRAD_MIN_ROWS = 256       # rows per split below which the plain mm is used (tests lower it to drive the split path with small goldens)
 
 
 def _wgrad(gz, x):
     """dW[C, K] = gz[B, C]^T x[B, K]"""
     B, S = gz.shape[0], _WGRAD_SPLIT
     # narrow outputs (the 12 / 1-column heads) keep the tuned mm: splitting them gave nothing (measured)
-    if S > 1 and gz.is_cuda and B % S == 0 and B // S >= 256 and gz.shape[1] >= 32:
+    if S > 1 and gz.is_cuda and B % S == 0 and B // S >= _WGRAD_MIN_ROWS and gz.shape[1] >= 32:
         return torch.bmm(gz.reshape(S, B // S, -1).transpose(1, 2), x.reshape(S, B // S, -1)).sum(0)
     return gz.t().mm(x)
 

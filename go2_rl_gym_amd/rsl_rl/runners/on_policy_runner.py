@@ -20,6 +20,7 @@ import yaml
 
 from ...utils.helpers import class_to_dict
 from ..algorithms import PPO
+from ..algorithms._graph import strict_graphs
 from ..env import missing_members
 from ..modules import ActorCritic
 
@@ -83,6 +84,10 @@ def _make_writer(log_dir):
 
 
 class OnPolicyRunner:
+    # The reference's PPO runner advances current_learning_iteration only after the loop (on_policy_runner.py:168-171: every intermediate
+    # checkpoint carries the START iteration); its CTS runner advances it per iteration before saving (on_policy_runner_cts.py:195), so
+    # a mid-run CTS checkpoint resumes the curricula where they were (train.py restores common_step_counter = iter * 24).
+    _ITER_IN_CHECKPOINTS = False
     _TERRAIN_TAGS = False       # the PPO runner logs every episode key under 'Episode/' (on_policy_runner.py:191); the CTS runner splits off 'Terrain/' (:221-224)
     def __init__(self, env, train_cfg, log_dir=None, device="cpu", use_graphs=None):
         self.cfg = train_cfg["runner"]
@@ -180,9 +185,10 @@ class OnPolicyRunner:
         rewbuffer, lenbuffer = self._rewbuffer, self._lenbuffer
         N, T = self.env.num_envs, self.num_steps_per_env
         bk = self._bk if self.log_dir is not None else None
-        tot_iter = self.current_learning_iteration + num_learning_iterations
-        it = self.current_learning_iteration
-        for it in range(self.current_learning_iteration, tot_iter):
+        start_iter = self.current_learning_iteration
+        tot_iter = start_iter + num_learning_iterations
+        it = start_iter
+        for it in range(start_iter, tot_iter):
             self._sync()
             start = time.time()
             with torch.inference_mode():
@@ -198,6 +204,8 @@ class OnPolicyRunner:
                         with torch.cuda.graph(g):
                             self._graph_ep_infos = self._rollout(bk)
                     except Exception as e:     # noqa: BLE001 — a capture problem must never stop training: fall back to the eager rollout
+                        if strict_graphs():    # ... unless the caller asked for it to (bench.py: no number from a silently degraded run)
+                            raise RuntimeError("HIP-graph capture of the rollout failed (%s: %s)" % (type(e).__name__, e)) from e
                         print("[go2_rl_gym_amd] HIP-graph capture of the rollout failed (%s: %s); continuing eagerly" % (type(e).__name__, e))
                         self.use_graphs = False
                         torch.cuda.synchronize()
@@ -228,11 +236,17 @@ class OnPolicyRunner:
                 self.log(locals())
             self.last_collection_time, self.last_learn_time = collection_time, learn_time
             self.last_fps = T * N * _world() / (collection_time + learn_time)
+            if self._ITER_IN_CHECKPOINTS:
+                self.current_learning_iteration = it + 1
             if self.log_dir is not None and it % self.save_interval == 0:
                 self.save(os.path.join(self.log_dir, "model_{}.pt".format(it)), it, False)
-        self.current_learning_iteration += num_learning_iterations
+        self.current_learning_iteration = tot_iter
         if self.log_dir is not None:
             self.save(os.path.join(self.log_dir, "model_{}.pt".format(self.current_learning_iteration)), it, True)
+
+    def graphs_captured(self):
+        """{"rollout": bool, "update": bool}: which halves of an iteration are being replayed from HIP graphs right now."""
+        return {"rollout": self._rollout_graph is not None, "update": bool(getattr(self.alg, "graphs_captured", lambda: False)())}
 
     def _collect_episode_stats(self, bk):
         m = bk["fin_mask"].cpu().numpy()   # one device->host read per iteration, same deque order as the reference (step-major)
@@ -276,7 +290,7 @@ class OnPolicyRunner:
             w.add_scalar("Train/mean_%sepisode_length" % sfx, statistics.mean(lb), locs["it"])
             w.add_scalar("Train/mean_%sreward/time" % sfx, statistics.mean(rb), self.tot_time)
             w.add_scalar("Train/mean_%sepisode_length/time" % sfx, statistics.mean(lb), self.tot_time)
-        head = f" \033[1m Learning iteration {locs['it']}/{self.current_learning_iteration + locs['num_learning_iterations']} \033[0m "
+        head = f" \033[1m Learning iteration {locs['it']}/{locs['tot_iter']} \033[0m "
         s = (f"""{'#' * width}\n{head.center(width, ' ')}\n\n"""
              f"""{'Computation:':>{pad}} {fps:.0f} steps/s (collection: {locs['collection_time']:.3f}s, learning {locs['learn_time']:.3f}s)\n"""
              )
@@ -289,7 +303,7 @@ class OnPolicyRunner:
         s += ep_string
         s += (f"""{'-' * width}\n{'Total timesteps:':>{pad}} {self.tot_timesteps}\n{'Iteration time:':>{pad}} {iteration_time:.2f}s\n"""
               f"""{'Total time:':>{pad}} {self.tot_time:.2f}s\n"""
-              f"""{'ETA:':>{pad}} {self.tot_time / (locs['it'] + 1) * (locs['num_learning_iterations'] - locs['it']):.1f}s\n""")
+              f"""{'ETA:':>{pad}} {self.tot_time / (locs['it'] - locs['start_iter'] + 1) * (locs['tot_iter'] - locs['it']):.1f}s\n""")
         print(s)
 
     def save(self, path, it=None, last_model=False, infos=None):

@@ -21,6 +21,7 @@ _ALGS = {"CTS": CTS, "MoECTS": MoECTS, "MoENGCTS": MoENGCTS, "ACMoECTS": ACMoECT
 
 class OnPolicyRunnerCTS(OnPolicyRunner):
     _TERRAIN_TAGS = True
+    _ITER_IN_CHECKPOINTS = True       # on_policy_runner_cts.py:195: incremented before the save
     _LOSS_NAMES = OnPolicyRunner._LOSS_NAMES + (("mean_entropy_loss", "Loss/entropy", "Entropy loss:"), ("mean_latent_loss", "Loss/latent", "Latent loss:"),
                                                 ("mean_load_balance_loss", "Loss/load_balance", "Load balance loss:"),
                                                 ("mean_actor_load_balance_loss", "Loss/actor_load_balance", "Actor load balance loss:"))

@@ -251,7 +251,14 @@ def export_policy_as_onnx(policy, path, normalizer=None, filename="policy.onnx",
     """ONNX graph, opset 11, static shapes (exporter.py:25-40,289-307)."""
     os.makedirs(path, exist_ok=True)
     mod = _OnnxPolicy(policy, normalizer).to("cpu")
-    names = ["actions"] + (["weights", "latent"] if mod.kind == "moe" else [])
+    # output names follow what forward() returns for the policy class (exporter.py:289-307): MCP (mean, weights); AC-MoE / Dual-MoE mean only;
+    # MoE / MoE-NG (mean, weights, latent); PPO / CTS mean only
+    if mod.kind != "ppo" and mod.actor_is_mcp:
+        names = ["actions", "weights"]
+    elif mod.kind != "ppo" and mod.actor_is_moe:
+        names = ["actions"]
+    else:
+        names = ["actions"] + (["weights", "latent"] if mod.kind == "moe" else [])
     torch.onnx.export(mod, torch.zeros(1, mod.input_dim), os.path.join(path, filename), export_params=True, opset_version=11, verbose=verbose,
                       input_names=["obs"], output_names=names, dynamic_axes={}, dynamo=False)
     return os.path.join(path, filename)

@@ -11,35 +11,36 @@ import numpy as np
 import torch
 
 
+def _public_attrs(obj):
+    return ((k, getattr(obj, k)) for k in dir(obj) if not k.startswith("_"))
+
+
 def class_to_dict(obj) -> dict:
+    """Nested config classes -> plain nested dicts (what the runner dumps to config.yaml).  Leaves (anything without a __dict__) pass
+    through; lists are converted element-wise.  Reference surface: legged_gym/utils/helpers.py class_to_dict."""
     if not hasattr(obj, "__dict__"):
         return obj
-    result = {}
-    for key in dir(obj):
-        if key.startswith("_"):
-            continue
-        val = getattr(obj, key)
-        result[key] = [class_to_dict(v) for v in val] if isinstance(val, list) else class_to_dict(val)
-    return result
+    conv = lambda v: list(map(class_to_dict, v)) if isinstance(v, list) else class_to_dict(v)
+    return {k: conv(v) for k, v in _public_attrs(obj)}
 
 
 def update_class_from_dict(obj, d):
+    """Inverse direction: write the entries of a (nested) dict into the matching (nested) config classes."""
     for key, val in d.items():
-        attr = getattr(obj, key, None)
-        if isinstance(attr, type):
-            update_class_from_dict(attr, val)
-        else:
-            setattr(obj, key, val)
+        target = getattr(obj, key, None)
+        if isinstance(target, type):
+            update_class_from_dict(target, val)
+            continue
+        setattr(obj, key, val)
 
 
 def set_seed(seed):
-    if seed == -1:
-        seed = np.random.randint(0, 10000)
-    print("Setting seed: {}".format(seed))
-    random.seed(seed)
-    np.random.seed(seed)
-    torch.manual_seed(seed)
+    """Seed every generator a run touches (python, numpy, torch CPU + all GPUs); -1 draws one.  -> the seed used."""
+    seed = int(np.random.randint(0, 10000)) if seed == -1 else seed
+    print(f"Setting seed: {seed}")
     os.environ["PYTHONHASHSEED"] = str(seed)
+    for seeder in (random.seed, np.random.seed, torch.manual_seed):
+        seeder(seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(seed)
     return seed
@@ -61,47 +62,55 @@ def parse_sim_params(args, cfg):
     return sp
 
 
+def _checkpoint_number(path):
+    stem = path.stem.split("_", 1)[-1]
+    return int(stem) if stem.isdigit() else -1
+
+
 def get_load_path(root, load_run=-1, checkpoint=-1):
-    try:
-        runs = [r for r in os.listdir(root) if len(list((Path(root) / r).glob("model_*.pt"))) > 0]
-        runs.sort()
-        if "exported" in runs:
-            runs.remove("exported")
-        last_run = os.path.join(root, runs[-1])
-    except Exception:
-        raise ValueError("No runs in this directory: %s" % (root,))
-    load_run = last_run if load_run == -1 else os.path.join(root, load_run)
-    if checkpoint == -1:
-        models = [f for f in os.listdir(load_run) if "model" in f]
-        models.sort(key=lambda m: "{0:0>15}".format(m))
-        model = models[-1]
+    """logs/<experiment>/<run>/model_<it>.pt to resume from: the last run directory (by name) that holds checkpoints unless `load_run`
+    names one, and its highest-numbered checkpoint unless `checkpoint` names one (legged_gym/utils/helpers.py get_load_path)."""
+    root = Path(root) if root is not None else None
+    if load_run == -1:
+        runs = sorted(d.name for d in root.iterdir() if d.is_dir() and d.name != "exported" and any(d.glob("model_*.pt"))) if root is not None and root.is_dir() else []
+        if not runs:
+            raise ValueError("No runs in this directory: %s" % (root,))
+        run_dir = root / runs[-1]
     else:
-        model = "model_{}.pt".format(checkpoint)
-    return os.path.join(load_run, model)
+        run_dir = root / load_run
+    if checkpoint != -1:
+        return str(run_dir / ("model_%s.pt" % checkpoint))
+    saved = sorted(run_dir.glob("model*"), key=lambda f: (_checkpoint_number(f), f.name))
+    if not saved:
+        raise ValueError("No checkpoints in %s" % (run_dir,))
+    return str(saved[-1])
+
+
+# command-line argument -> attribute of train_cfg.runner it overrides when given
+_RUNNER_OVERRIDES = ("max_iterations", "experiment_name", "run_name", "load_run", "checkpoint")
 
 
 def update_cfg_from_args(env_cfg, cfg_train, args):
+    """Command-line overrides onto the config objects (legged_gym/utils/helpers.py update_cfg_from_args): --num_envs onto the env config;
+    --seed, --resume and the runner fields above onto the train config; the RoboGauge switches when the train config has that section."""
     if env_cfg is not None and args.num_envs is not None:
         env_cfg.env.num_envs = args.num_envs
-    if cfg_train is not None:
-        if args.seed is not None:
-            cfg_train.seed = args.seed
-        if args.max_iterations is not None:
-            cfg_train.runner.max_iterations = args.max_iterations
-        if args.resume:
-            cfg_train.runner.resume = args.resume
-        if args.experiment_name is not None:
-            cfg_train.runner.experiment_name = args.experiment_name
-        if args.run_name is not None:
-            cfg_train.runner.run_name = args.run_name
-        if args.load_run is not None:
-            cfg_train.runner.load_run = args.load_run
-        if args.checkpoint is not None:
-            cfg_train.runner.checkpoint = args.checkpoint
-        if getattr(args, "robogauge", None) is not None and hasattr(cfg_train, "robogauge"):
-            cfg_train.robogauge.enabled = args.robogauge
-        if getattr(args, "robogauge_port", None) is not None and hasattr(cfg_train, "robogauge"):
-            cfg_train.robogauge.port = args.robogauge_port
+    if cfg_train is None:
+        return env_cfg, cfg_train
+    if args.seed is not None:
+        cfg_train.seed = args.seed
+    if args.resume:
+        cfg_train.runner.resume = True
+    for name in _RUNNER_OVERRIDES:
+        given = getattr(args, name)
+        if given is not None:
+            setattr(cfg_train.runner, name, given)
+    gauge = getattr(cfg_train, "robogauge", None)
+    if gauge is not None:
+        for arg_name, field in (("robogauge", "enabled"), ("robogauge_port", "port")):
+            given = getattr(args, arg_name, None)
+            if given is not None:
+                setattr(gauge, field, given)
     return env_cfg, cfg_train
 
 

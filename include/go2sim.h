@@ -330,6 +330,14 @@ int  go2sim_notify_replayed(Go2Sim* h, int32_t steps);
 int  go2sim_inject_uniforms(Go2Sim* h, const float* uniforms, void* stream);
 /* Copy the Philox uniforms the next step would use into `out` [N][GO2_NUM_UNIFORMS]. */
 int  go2sim_peek_uniforms(Go2Sim* h, float* out, void* stream);
+/* LeggedRobot.step's torque loop (legged_robot.py:67-81, _compute_torques :594-618) on caller-supplied DOF states ("fake physics"):
+ * clip the raw actions [N,12], draw the action delay (:71-78), and for each of the `decimation` substeps compute the PD torques from
+ * dof [decimation][N][12][2] (row-major) -> out [decimation][N][12].  Leaves the clipped actions / the last substep's torques in the
+ * library's buffers like step().  Lets the reference's golden torques be compared with each library's own arithmetic. */
+int  go2sim_debug_torque_trace(Go2Sim* h, const float* actions_raw, const float* dof, float* out, void* stream);
+/* The individually rounded fp32 operations the height-scan INDEX arithmetic is built from (csrc/go2_math.h go2_*_rn) over arrays:
+ * out [6][n] = a*b, a+b, a-b, a/b, sqrt(|a|), a/b[0] (through the double-precision reciprocal) — each must equal the IEEE result. */
+int  go2sim_debug_strict_ops(const float* a, const float* b, float* out, int32_t n, void* stream);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* While enabled, every go2sim_step / go2sim_simulate brackets its main kernel with events ON THE STREAM IT

@@ -1175,6 +1175,17 @@ int go2o_torque_trace(Go2Sim* s, const float* actions_raw, const float* dof, flo
   return 0;
 }
 
+int go2sim_debug_torque_trace(Go2Sim* s, const float* actions_raw, const float* dof, float* out, void* stream) {
+  (void)stream; if (!s||!actions_raw||!dof||!out) return GO2SIM_EINVAL; return go2o_torque_trace(s, actions_raw, dof, out);
+}
+/* the IEEE operations themselves (gcc, x86-64 baseline: no FMA contraction, correctly rounded / and sqrt) */
+int go2sim_debug_strict_ops(const float* a, const float* b, float* out, int32_t n, void* stream) {
+  (void)stream; if (!a||!b||!out||n<=0) return GO2SIM_EINVAL;
+  for (int i=0;i<n;++i) { volatile float x=a[i], y=b[i], y0=b[0]; out[i]=x*y; out[n+i]=x+y; out[2*(size_t)n+i]=x-y; out[3*(size_t)n+i]=x/y;
+    out[4*(size_t)n+i]=SQRT(FABS(x)); out[5*(size_t)n+i]=x/y0; }
+  return 0;
+}
+
 /* Fused PPO loss head, CPU restatement (ppo.py:131-170).  Same contract as the HIP kernel. */
 int go2sim_ppo_loss(const float* mu, const float* std, const float* value, const float* actions, const float* old_mu, const float* old_sigma,
                     const float* old_logp, const float* adv, const float* tv, const float* ret, float* gmu, float* gstd, float* gval, float* stats,

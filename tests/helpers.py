@@ -255,6 +255,16 @@ def load_hip():
     return _lib.load_hip()
 
 
+def load_hip_precise():
+    """The device library built WITHOUT -ffast-math (go2_rl_gym_amd/build.py:build_hip_precise): a TEST-ONLY second build of the same
+    source, used to show which parity differences are fast-math artefacts and which are not.  Never loaded by the product."""
+    from go2_rl_gym_amd import _lib, build  # noqa: F401  (imports torch first)
+    path = build.build_hip_precise()
+    lib = _abi.bind(path, C.c_float)
+    assert lib.go2sim_is_device_library() == 1
+    return lib
+
+
 # state that fully determines the next step (copied oracle -> device before a one-step comparison)
 STEP_STATE = ["root_states", "dof_state", "last_actions", "last_last_actions", "last_dof_vel", "commands", "commands_resampling_step",
               "commands_xy_accumulation", "episode_length_buf", "motor_strengths", "motor_zero_offsets", "p_gains_multiplier", "d_gains_multiplier",

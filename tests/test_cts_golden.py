@@ -210,3 +210,37 @@ def test_checkpoint_roundtrip(tmp_path):
         assert torch.equal(a, b), k
     st1, st2 = r1.alg.optimizer1.state_dict()["state"], r2.alg.optimizer1.state_dict()["state"]
     assert all(torch.equal(st1[i]["exp_avg"], st2[i]["exp_avg"]) for i in st1)
+
+
+def test_midrun_checkpoints_carry_their_iteration(tmp_path):
+    """on_policy_runner_cts.py:195-199: the CTS runner advances current_learning_iteration BEFORE it saves, so model_{it}.pt holds
+    iter = it + 1 and a run resumed from it restores the curricula (train.py: common_step_counter = iter * 24) where they were.  The PPO
+    runner of the reference advances only after the loop (on_policy_runner.py:168-171): its mid-run checkpoints carry the start iteration."""
+    from go2_rl_gym_amd.rsl_rl.runners import OnPolicyRunner
+    g = dict(np.load(os.path.join(G, "cts_iteration.npz")))
+    T = g["rew"].shape[0]
+    cfg = _train_cfg("CTS", T)
+    cfg["runner"]["save_interval"] = 1
+
+    class LoopEnv(ScriptedEnv):
+        def step(self, actions):
+            out = super().step(actions)
+            self.t %= T
+            return out
+    r = OnPolicyRunnerCTS(LoopEnv(g, load_oracle()), cfg, log_dir=str(tmp_path / "cts"), device="cpu")
+    r.writer = TagRecorder(); os.makedirs(str(tmp_path / "cts"))
+    r.learn(3)
+    for it in range(3):
+        assert torch.load(str(tmp_path / "cts" / ("model_%d.pt" % it)), weights_only=False)["iter"] == it + 1
+    assert torch.load(str(tmp_path / "cts" / "model_3.pt"), weights_only=False)["iter"] == 3 and r.current_learning_iteration == 3
+    r2 = OnPolicyRunnerCTS(LoopEnv(g, load_oracle()), cfg, log_dir=None, device="cpu")
+    r2.load(str(tmp_path / "cts" / "model_1.pt"))
+    assert r2.current_learning_iteration == 2
+    pcfg = {"runner": dict(cfg["runner"], policy_class_name="ActorCritic", algorithm_class_name="PPO"),
+            "algorithm": {k: v for k, v in cfg["algorithm"].items() if k not in ("student_encoder_learning_rate", "teacher_env_ratio")},
+            "policy": dict(init_noise_std=1.0, actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16], activation="elu")}
+    p = OnPolicyRunner(LoopEnv(g, load_oracle()), pcfg, log_dir=str(tmp_path / "ppo"), device="cpu")
+    p.writer = TagRecorder(); os.makedirs(str(tmp_path / "ppo"))
+    p.learn(2)
+    assert torch.load(str(tmp_path / "ppo" / "model_1.pt"), weights_only=False)["iter"] == 0
+    assert torch.load(str(tmp_path / "ppo" / "model_2.pt"), weights_only=False)["iter"] == 2

@@ -29,12 +29,19 @@ def test_golden_sequence_on_gpu(hip, terrain):
     g = dict(np.load(os.path.join(G, "go2_%s_sequence.npz" % terrain)))
     s = tg._mk(hip, g, sim=DeviceSim)
     n = 0
-    for t in tg.run_sequence(s, hip, g, None):
+    def check(name, t_, got, want):      # torques of all 4 substeps from the kernel's own pd() + delay select vs the reference's (2e-5)
+        np.testing.assert_allclose(got, want, atol=tg.TOL[name], rtol=1e-5, err_msg="%s at step %d" % (name, t_))
+    for t in tg.run_sequence(s, hip, g, check):
         s.torch.cuda.synchronize()
         tg.compare_step(s, g, t)
         n += 1
     assert n == g["actions"].shape[0]
     s.close()
+
+
+def test_strict_ops_on_gpu(hip):
+    """The individually rounded fp32 operations under the height-scan index arithmetic equal IEEE on the device build (-ffast-math)."""
+    tg.check_strict_ops(hip, "cuda:0")
 
 
 def test_reset_all_golden_on_gpu(hip):
@@ -281,7 +288,7 @@ def test_cts_kernels_on_gpu(hip):
     assert abs(np.abs(res["hip"][0][split:]).mean() / np.abs(res["hip"][0][:split]).mean() - 3.0) < 0.5
 
 
-@pytest.mark.parametrize("task", ["go2_flat_cts", "go2_moe_cts", "go2_moe_ng_cts", "go2_ac_moe_cts", "go2_dual_moe_cts", "go2_mcp_cts"])
+@pytest.mark.parametrize("task", ["go2_flat_cts", "go2_cts", "go2_moe_cts", "go2_moe_ng_cts", "go2_ac_moe_cts", "go2_dual_moe_cts", "go2_mcp_cts"])
 def test_cts_training_graph_vs_eager_on_gpu(hip, task):
     """CTS / MoE-CTS through the product path, HIP-graph mode against eager mode from the same seeds (the eager arithmetic is
     pinned to the reference in tests/test_cts_golden.py)."""
@@ -541,3 +548,100 @@ def test_multi_rank_update_shape_on_one_gpu(hip, task, monkeypatch):
     # chaotic (x1.5 per mini-batch), so the two runs are compared by behaviour, not by weights.
     assert np.isfinite(out[True][1]).all() and 1e-5 - 1e-12 <= out[True][0] <= 1e-2 + 1e-12
     assert abs(out[True][2] - out[False][2]) < 0.05
+
+
+@pytest.mark.parametrize("terrain", ["plane", "heightfield"])
+def test_env_shards_equal_slices_of_one_sim_on_gpu(hip, terrain):
+    """Multi-GPU sharding on the real library (the oracle-side twin is tests/test_distributed.py): two HIP simulators with
+    env_offset 0 / 2048 of num_envs_global = 4096 are rows [0, 2048) / [2048, 4096) of ONE 4096-env HIP simulator, bit for bit, after
+    creation, reset and 20 steps — Philox key, plane grid origin, terrain level / type round robin, friction buckets and every
+    creation-time draw depend on the GLOBAL env index only (go2sim_impl.cpp create / lane programs)."""
+    import torch
+    from helpers import heightfield_overrides
+    Ng, n = 4096, 2048
+    ov = heightfield_overrides(Ng)[1] if terrain == "heightfield" else {}
+    whole = DeviceSim(hip, num_envs=Ng, seed=5, **ov)
+    parts = [DeviceSim(hip, num_envs=n, env_offset=r * n, num_envs_global=Ng, seed=5, **ov) for r in range(2)]
+    keys = ("root_states", "dof_state", "obs_buf", "privileged_obs_buf", "rew_buf", "reset_buf", "commands", "env_origins", "friction_coeffs", "link_mass_ratio",
+            "added_base_mass", "motor_strengths", "episode_length_buf", "terrain_levels", "terrain_types", "contact_forces", "measured_heights", "episode_sums")
+
+    def same(tag):
+        for k in keys:
+            w = whole.t[k]
+            for r, prt in enumerate(parts):
+                sl = w[:, r * n:(r + 1) * n] if k == "episode_sums" else w[r * n:(r + 1) * n]
+                assert torch.equal(sl, prt.t[k]), "%s: %s differs between shard %d and the slice of the single simulator" % (tag, k, r)
+    same("create")
+    for s_ in [whole] + parts:
+        s_.reset_all()
+    torch.cuda.synchronize()
+    same("reset")
+    g = torch.Generator(device="cuda:0"); g.manual_seed(0)
+    for it in range(20):
+        a = torch.randn(Ng, 12, device="cuda:0", generator=g)
+        hip.go2sim_step(whole.h, C.c_void_p(a.data_ptr()), whole._st())
+        for r, prt in enumerate(parts):
+            ar = a[r * n:(r + 1) * n].contiguous()
+            hip.go2sim_step(prt.h, C.c_void_p(ar.data_ptr()), prt._st())
+        torch.cuda.synchronize()
+        same("step %d" % it)
+    assert int(whole.t["reset_buf"].sum()) >= 0 and float(whole.t["contact_forces"].abs().max()) > 1.0
+    for s_ in [whole] + parts:
+        s_.close()
+
+
+def _stats_vs(ref, got, N):
+    return np.abs(np.asarray(ref, np.float64) - np.asarray(got, np.float64)).reshape(N, -1).max(1)
+
+
+def test_parity_outliers_are_conditioning_not_fast_math(hip):
+    """What the percentile gates of the physics parity tests stand on, measured instead of asserted:
+      * the device library built WITHOUT -ffast-math (tests/emu/libgo2sim_hip_precise.so, IEEE division / sqrt, same contraction) shows the
+        same population of outlier envs against the fp32 oracle as the shipped -ffast-math build => they are not fast-math artefacts;
+      * the fp32 oracle itself differs from the fp64 oracle on the same envs with the same magnitude => the outliers are envs whose step is
+        ill-conditioned in fp32 (a contact row switching on/off at gap = contact_offset, a friction cone boundary, a joint-limit row), where
+        ANY two fp32 evaluation orders disagree — the oracle's own included.
+    The bound this yields (and the one the one-step tests use): per env, |HIP - oracle32| <= max(tol, 8 x |oracle32 - oracle64|)."""
+    import json
+    from helpers import load_hip_precise
+    N, steps = 256, 60
+    so, s64 = HostSim(load_oracle(), num_envs=N), HostSim(load_oracle(f64=True), num_envs=N)
+    sims = {"fast_math": DeviceSim(hip, num_envs=N), "precise": DeviceSim(load_hip_precise(), num_envs=N)}
+    for s_ in [so, s64] + list(sims.values()):
+        s_.reset_all()
+    rng = np.random.default_rng(0)
+    tol = {"root_states": 5e-4, "dof_state": 2e-3, "obs_buf": 2e-4, "rew_buf": 5e-6}
+    count = {b: {k: 0 for k in tol} for b in list(sims) + ["oracle32_vs_64"]}
+    excess, worst_ratio = {b: 0 for b in sims}, {b: 0.0 for b in sims}
+    for it in range(steps):
+        a = rng.normal(0, 1, (N, 12)).astype(np.float32)
+        for k in STEP_STATE:
+            v = np.asarray(getattr(so, k))
+            getattr(s64, k)[...] = v
+            for sd in sims.values():
+                getattr(sd, k)[...] = v
+        so.step(a); s64.step(a.astype(np.float64))
+        for sd in sims.values():
+            sd.step(a)
+        for k, t in tol.items():
+            cond = _stats_vs(getattr(s64, k), getattr(so, k), N)          # the fp32 oracle against the fp64 oracle: the step's fp32 conditioning
+            count["oracle32_vs_64"][k] += int((cond > t).sum())
+            for b, sd in sims.items():
+                d = _stats_vs(getattr(so, k), getattr(sd, k), N)
+                count[b][k] += int((d > t).sum())
+                bad = d > np.maximum(t, 8.0 * cond)
+                excess[b] += int(bad.sum())
+                worst_ratio[b] = max(worst_ratio[b], float((d / np.maximum(t, 8.0 * cond)).max()))
+    report = {"envs": N, "steps": steps, "tolerances": tol, "env_steps_above_tol": count, "env_steps_above_max(tol,8*conditioning)": excess, "worst_ratio": worst_ratio}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(report, open(os.path.join(ROOT, "gpurun_out", "parity_outliers.json"), "w"), indent=1)
+    print(json.dumps(report))
+    tot = N * steps
+    for k in tol:
+        # the precise build does not make the outliers go away (same order of magnitude), and the fp32 oracle has them against fp64 too
+        assert count["precise"][k] >= 0.3 * count["fast_math"][k] - 3, (k, count)
+        assert count["fast_math"][k] <= 0.06 * tot and count["precise"][k] <= 0.06 * tot, (k, count)
+    for b in sims:
+        assert excess[b] <= 0.002 * tot * len(tol), (b, excess, worst_ratio)      # (almost) every env is inside max(tol, 8 x its own fp32 conditioning)
+    for s_ in [so, s64] + list(sims.values()):
+        s_.close()

@@ -1,0 +1,199 @@
+"""Row a16 on the GPU path: the update the benchmark times — HIP-graph capture (algorithms/_graph.py), one permutation gather per
+update, actor / critic on two streams, modules/fused.py (in-place ELU, fused ELU-backward + bias gradient, row-split weight gradients),
+fused multi-tensor Adam, device-resident learning rate, the fused loss head — against the REFERENCE's goldens
+(rsl_rl/rsl_rl/algorithms/ppo.py:120-187 -> ppo_update.npz; on_policy_runner_cts.py:123-202 + cts.py:167-286 -> cts_iteration.npz,
+moe_cts_iteration.npz): same weights in, same rollout, same sampling noise, same permutation -> same final weights and learning rate.
+
+Both execution modes: eager on the GPU, and graphs — where the goldens are compared on REPLAYED graphs: warm-up updates run first (the
+capture needs them), then weights / optimizer state / learning rate / history are restored in place and the golden iteration is replayed.
+Run with -m gpu."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from helpers import ROOT, load_hip  # noqa: E402
+import test_cts_golden as tc  # noqa: E402
+
+G = os.path.join(ROOT, "tests", "golden")
+DEV = "cuda:0"
+
+
+def _reset_adam(opt):
+    for st in opt.state.values():
+        for v in st.values():
+            if hasattr(v, "zero_"):
+                v.zero_()
+
+
+def _check_weights(sd, g, what):
+    # analytic (fused loss head) vs autograd gradients and GPU vs CPU GEMM summation order differ in the last bits; Adam's step g / sqrt(v)
+    # is scale-free, so an element whose gradient is ~0 can move by a visible fraction of lr (1e-3..3e-3 here): nearly all elements tight,
+    # every element << one step x lr.  (Same bound as the CPU fused-path golden, tests/test_cts_golden.py.)
+    for k, v in sd.items():
+        w = g["w1_" + k]
+        d = np.abs(v.detach().cpu().numpy() - w)
+        assert (d <= 5e-6 + 5e-5 * np.abs(w)).mean() >= 0.998 and d.max() < 3e-4, (what, k, float(d.max()), float((d <= 5e-6 + 5e-5 * np.abs(w)).mean()))
+
+
+@pytest.mark.parametrize("mode", ["eager", "graphs"])
+def test_ppo_update_golden_on_gpu(monkeypatch, mode):
+    import torch
+    from go2_rl_gym_amd.rsl_rl.algorithms import PPO
+    from go2_rl_gym_amd.rsl_rl.modules import ActorCritic, fused
+    hip = load_hip()
+    monkeypatch.setattr(fused, "_WGRAD_MIN_ROWS", 8)          # 96-row mini-batches: take the 8-way row-split weight-gradient path the 24576-row ones take
+    g = dict(np.load(os.path.join(G, "ppo_update.npz")))
+    T, N = g["rew"].shape
+    d = lambda x: torch.as_tensor(np.ascontiguousarray(x), device=DEV)
+    ac = ActorCritic(45, 263, 12, actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16], activation="elu", init_noise_std=1.0)
+    sd0 = {k[3:]: d(v) for k, v in g.items() if k.startswith("w0_")}
+    ac.load_state_dict(sd0)
+    alg = PPO(ac, num_learning_epochs=2, num_mini_batches=2, clip_param=0.2, gamma=0.99, lam=0.95, value_loss_coef=1.0, entropy_coef=0.01,
+              learning_rate=1e-3, max_grad_norm=1.0, use_clipped_value_loss=True, schedule="adaptive", desired_kl=0.01, device=DEV, lib=hip,
+              use_graphs=(mode == "graphs"))
+    assert alg.fused_loss and alg.fused_rollout and fused._LIB is hip and alg.use_graphs == (mode == "graphs")
+    alg.init_storage(N, T, [45], [263], [12])
+    obs, cobs, noise = d(g["obs"]), d(g["cobs"]), d(g["noise"])
+    rew, dones, touts = d(g["rew"]), d(g["dones"]).bool(), d(g["time_outs"]).bool()
+    perm = d(g["perm"])
+    monkeypatch.setattr(torch, "randperm", lambda n, **kw: perm)
+
+    def rollout(check):
+        for t in range(T):
+            monkeypatch.setattr(ActorCritic, "_noise", lambda self, like, _t=t: noise[_t])
+            a = alg.act(obs[t], cobs[t])
+            if check:
+                np.testing.assert_allclose(a.cpu().numpy(), g["actions"][t], atol=2e-6)
+                np.testing.assert_allclose(alg.transition.values.cpu().numpy().reshape(-1), g["values"][t].reshape(-1), atol=2e-6)
+                np.testing.assert_allclose(alg.transition.actions_log_prob.cpu().numpy().reshape(-1), g["logp"][t], atol=1e-5)
+            alg.process_env_step(rew[t], dones[t], {"time_outs": touts[t]})
+        alg.compute_returns(cobs[T])
+
+    if mode == "graphs":
+        for _ in range(2):          # slot 0 is captured at its 4th call, slot 1 at its 2nd: two warm-up updates, then everything replays
+            rollout(False)
+            alg.update()
+        torch.cuda.synchronize()
+        assert all(s.graph is not None for s in alg._graph), "HIP-graph capture of the PPO mini-batch step degraded to eager"
+        ac.load_state_dict(sd0)
+        _reset_adam(alg.optimizer)
+        alg.learning_rate = 1e-3
+        alg._lr_t.fill_(1e-3)
+    rollout(True)
+    np.testing.assert_allclose(alg.storage.rewards.cpu().numpy(), g["stored_rewards"], atol=1e-6)
+    np.testing.assert_allclose(alg.storage.returns.cpu().numpy(), g["returns"], atol=5e-6)
+    np.testing.assert_allclose(alg.storage.advantages.cpu().numpy(), g["advantages"], atol=5e-5)
+    mvl, msl = alg.update()
+    torch.cuda.synchronize()
+    assert abs(mvl - float(g["mean_value_loss"])) < 2e-5 and abs(msl - float(g["mean_surrogate_loss"])) < 2e-5
+    assert abs(alg.learning_rate - float(g["final_lr"])) < 1e-9 * float(g["final_lr"]) + 1e-12, (alg.learning_rate, float(g["final_lr"]))
+    _check_weights(ac.state_dict(), g, "PPO " + mode)
+    fused.set_library(None)
+
+
+class DeviceScriptedEnv(tc.ScriptedEnv):
+    """The scripted env of tests/test_cts_golden.py with its tensors in device memory and the HIP library behind `lib`, written so that a
+    rollout over it can be captured and replayed: the time index is the rollout storage's own step counter (0 at the start of every
+    rollout, T after it, replayed or not) and the actions are copied into a device buffer instead of being pulled to the host."""
+
+    def __init__(self, g, lib):
+        import torch
+        super().__init__(g, lib)
+        for k in ("obs_seq", "priv_seq", "rew_seq", "done_seq", "tout_seq", "episode_length_buf"):
+            setattr(self, k, getattr(self, k).to(DEV))
+        self.device = DEV
+        self.act_buf = torch.zeros(self.rew_seq.shape[0], self.num_envs, 12, device=DEV)
+        self.alg = None
+        self._ep = {"rew_tracking_lin_vel": torch.tensor(0.25, device=DEV), "terrain_level": torch.tensor(1.5, device=DEV)}
+
+    @property
+    def t(self):
+        return self.alg.storage.step if self.alg is not None else 0
+
+    @t.setter
+    def t(self, v):
+        pass
+
+    def step(self, actions):
+        t = self.t
+        self.act_buf[t].copy_(actions)
+        return self.obs_seq[t + 1], self.priv_seq[t + 1], self.rew_seq[t], self.done_seq[t], {"time_outs": self.tout_seq[t], "episode": self._ep}
+
+
+@pytest.mark.parametrize("mode", ["eager", "graphs"])
+@pytest.mark.parametrize("kind,fixture", [("CTS", "cts_iteration.npz"), ("MoECTS", "moe_cts_iteration.npz")])
+def test_cts_iteration_golden_on_gpu(kind, fixture, mode, monkeypatch):
+    """One full OnPolicyRunnerCTS iteration of the reference (rollout with the history ring, GAE, 2 x 2 policy steps, 2 x 2 student steps)
+    through the GPU product path."""
+    import torch
+    from go2_rl_gym_amd.rsl_rl.modules import ActorCriticCTS, fused
+    from go2_rl_gym_amd.rsl_rl.runners import OnPolicyRunnerCTS
+    hip = load_hip()
+    monkeypatch.setattr(fused, "_WGRAD_MIN_ROWS", 8)
+    g = dict(np.load(os.path.join(G, fixture)))
+    T, N = g["rew"].shape
+    env = DeviceScriptedEnv(g, hip)
+    runner = OnPolicyRunnerCTS(env, tc._train_cfg(kind, T), log_dir=None, device=DEV, use_graphs=(mode == "graphs"))
+    alg, model = runner.alg, runner.alg.model
+    env.alg = alg
+    assert runner.use_graphs == alg.use_graphs == (mode == "graphs") and alg.fused_loss and alg.fused_rollout
+    np.testing.assert_array_equal(alg.teacher_env_idxs.cpu().numpy(), g["teacher_env_idxs"])
+    sd0 = {k[3:]: torch.as_tensor(v, device=DEV) for k, v in g.items() if k.startswith("w0_")}
+    model.load_state_dict(sd0)
+    noise = torch.as_tensor(g["noise"], device=DEV)
+    monkeypatch.setattr(ActorCriticCTS, "_noise", lambda self, like: noise[env.t])
+    perms = {len(g["perm_teacher"]): torch.as_tensor(g["perm_teacher"], device=DEV), len(g["perm_student"]): torch.as_tensor(g["perm_student"], device=DEV)}
+    monkeypatch.setattr(torch, "randperm", lambda n, **kw: perms[n])
+    real_update, seen = alg.update, {}
+
+    def update():
+        st = alg.storage
+        for k in ("returns", "advantages", "values", "rewards", "actions_log_prob", "history", "observations", "mu"):
+            seen[k] = getattr(st, k).cpu().numpy().copy()
+        seen["history_after_rollout"] = runner.history.cpu().numpy().copy()
+        return real_update()
+
+    alg.update = update
+    if mode == "graphs":
+        for _ in range(3):          # rollout: 2 eager + capture; update slots: captured at their 4th / 2nd call
+            runner.history.zero_()
+            runner.learn(1, init_at_random_ep_len=False)
+        torch.cuda.synchronize()
+        assert runner._rollout_graph is not None, "HIP-graph capture of the rollout degraded to eager"
+        assert all(s.graph is not None for grp in alg._steps for s in grp), "HIP-graph capture of a CTS update step degraded to eager"
+        model.load_state_dict(sd0)
+        _reset_adam(alg.optimizer1); _reset_adam(alg.optimizer2)
+        alg.learning_rate = 1e-3
+        alg._lr_t.fill_(1e-3)
+        runner.history.zero_(); model.history.zero_()
+        env.act_buf.zero_()
+    runner.learn(1, init_at_random_ep_len=False)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(env.act_buf.cpu().numpy(), g["actions"], atol=5e-6)
+    np.testing.assert_array_equal(seen["history_after_rollout"], g["history_after_rollout"])      # the ring is pure data movement: exact
+    np.testing.assert_array_equal(seen["history"], g["storage_history"])
+    np.testing.assert_array_equal(seen["observations"], g["storage_observations"])
+    for k, tol in (("values", 5e-6), ("mu", 5e-6), ("actions_log_prob", 2e-5), ("rewards", 5e-6), ("returns", 1e-5), ("advantages", 1e-4)):
+        np.testing.assert_allclose(seen[k], g["storage_" + k], atol=tol, err_msg=k)
+    assert abs(alg.learning_rate - float(g["final_lr"])) < 1e-9 * float(g["final_lr"]) + 1e-12, (alg.learning_rate, float(g["final_lr"]))
+    _check_weights(model.state_dict(), g, kind + " " + mode)
+    fused.set_library(None)
+
+
+def test_row_split_weight_gradient_on_gpu():
+    """modules/fused.py:_wgrad at the real mini-batch shapes: the 8-way row split (one batched GEMM + a fixed-order sum) against the
+    float64 product — scale, orientation and determinism."""
+    import torch
+    from go2_rl_gym_amd.rsl_rl.modules import fused
+    torch.manual_seed(0)
+    for B, Cn, K in ((24576, 512, 263), (24576, 256, 512), (24576, 128, 256), (24576, 512, 45)):
+        gz, x = torch.randn(B, Cn, device=DEV), torch.randn(B, K, device=DEV)
+        w = fused._wgrad(gz, x)
+        ref = (gz.double().t() @ x.double())
+        assert w.shape == (Cn, K)
+        err = (w.double() - ref).abs().max().item()
+        assert err < 2e-4 * ref.abs().max().item() + 1e-3, (B, Cn, K, err)
+        assert torch.equal(w, fused._wgrad(gz, x))

@@ -102,3 +102,28 @@ def test_ppo_runner_logs_and_saves_like_the_reference(tmp_path):
     ck = torch.load(os.path.join(tmp_path, "model_1.pt"), weights_only=False)
     assert sorted(ck) == list(g["checkpoint_keys"]) and ck["iter"] == int(g["checkpoint_iter"])
     assert list(ck["model_state_dict"].keys()) == list(g["state_dict_keys"])
+
+
+def test_play_configuration_on_a_trimesh_task():
+    """scripts/play.py's config edits on a trimesh task (legged_gym/scripts/play.py:17-31): terrain.curriculum = False leaves the Terrain
+    without a column -> terrain-kind table (utils/terrain.py fills cols2id only in curiculum()), which the reference tolerates
+    (legged_robot.py:1074-1075: no terrain_ids; global command ranges :863, default tracking sigma :1303).  The env must come up, step, and
+    resample commands from the global ranges."""
+    _, _ = task_registry.get_cfgs("go2")
+    env_cfg, _ = task_registry.get_cfgs("go2")
+    env_cfg.env.num_envs = 20
+    env_cfg.terrain.num_rows = env_cfg.terrain.num_cols = 7
+    env_cfg.terrain.curriculum = False
+    env_cfg.noise.add_noise = False
+    env_cfg.env.test = True
+    assert env_cfg.terrain.mesh_type == "trimesh"
+    args = get_args(["--task", "go2", "--num_envs", "20", "--headless", "--sim_device", "cpu", "--rl_device", "cpu"])
+    env, _ = task_registry.make_env("go2", args, env_cfg=env_cfg, lib=load_oracle())
+    assert len(env.terrain.cols2id) == 0 and not hasattr(env, "terrain_ids")
+    obs = env.get_observations()
+    for _ in range(30):
+        obs, priv, rew, done, info = env.step(torch.zeros(20, 12))
+    assert torch.isfinite(obs).all() and torch.isfinite(priv).all() and torch.isfinite(rew).all()
+    lo, hi = env_cfg.commands.ranges.lin_vel_x
+    assert (env.commands[:, 0] >= lo - 1e-6).all() and (env.commands[:, 0] <= hi + 1e-6).all()
+    env.close()
