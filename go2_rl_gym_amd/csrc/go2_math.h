@@ -28,9 +28,12 @@ __device__ __forceinline__ float go2_mul_rn(float a, float b) { float r; asm("v_
 __device__ __forceinline__ float go2_add_rn(float a, float b) { float r; asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float go2_sub_rn(float a, float b) { float r; asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // a / b: the quotient formed in fp64 and rounded once more to fp32 is the correctly rounded fp32 quotient (53 >= 2*24 + 2 bits; the
-// exact quotient of two fp32 numbers stays >= 2^-49 (relative) away from every fp32 rounding boundary, the fp64 result is within 2^-51)
-__device__ __forceinline__ float go2_div_rn(float a, float b) { return (float)((double)a / (double)b); }
-__device__ __forceinline__ float go2_mul_inv_rn(float a, double inv_b) { return (float)((double)a * inv_b); }   // a / b with inv_b = 1.0 / (double)b
+// exact quotient of two fp32 numbers stays >= 2^-49 (relative) away from every fp32 rounding boundary, the fp64 result is within 2^-51).
+// The widened operands pass through empty asm statements: -ffast-math would otherwise narrow fptrunc(fdiv(fpext a, fpext b)) back to
+// an (rcp-based) fp32 division.
+__device__ __forceinline__ double go2_opaque(double x) { asm("" : "+v"(x)); return x; }
+__device__ __forceinline__ float go2_div_rn(float a, float b) { return (float)go2_opaque(go2_opaque((double)a) / go2_opaque((double)b)); }
+__device__ __forceinline__ float go2_mul_inv_rn(float a, double inv_b) { return (float)go2_opaque(go2_opaque((double)a) * inv_b); }   // a / b with inv_b = 1.0 / (double)b
 // sqrt: the hardware's 1-ulp v_sqrt_f32 moved to the correctly rounded neighbour by two exact FMA residual tests
 __device__ __forceinline__ float go2_sqrt_rn(float x) {
   float y = __builtin_amdgcn_sqrtf(x);
