@@ -1,34 +1,39 @@
-// go2_lane.h — the per-lane physics program: one lane = one (env, leg).
+// go2_lane.h — the per-lane physics program: one lane = one (env, leg, sub).
 //
 // Replaces gym.simulate + the torque loop of LeggedRobot.step (legged_gym/envs/base/legged_robot.py:73-92)
 // with a new articulated-body model (the reference's physics is NVIDIA Isaac Gym / PhysX, which is not part of
 // the reference tree; the model is specified in DESIGN.md section 4 and restated independently by the oracle).
 //
-// Four lanes of a quad own the four legs of one environment and replicate the floating base.  Per substep:
-//   A. (lane)  leg kinematics, leg link inertias in the common frame, velocity-product forces, the leg's
-//              3x3 joint-space inertia A, its inverse, B = [Ic_i S_i], and the leg's Schur terms
-//              K = B A^-1 B^T, r = B A^-1 (tau - C)
-//      (quad)  sum {Ic_leg (10), K (21), F_leg (6), r (6)} over the 4 lanes        <- DPP quad shuffles
-//   B. (lane, replicated) base articulated inertia IA = I_base + sum Ic - sum K, Phi = IA^-1, base and joint
-//              accelerations, unconstrained end-of-substep velocities
-//   C. (lane)  contact candidates (foot sphere; deepest of the other leg/base spheres), joint-limit rows;
-//              per row: Jc (3), Z = A^-1 Jc^T, G = Ec + Jc N, H = G Phi, diagonal
-//      (quad)  projected Gauss-Seidel, lanes take turns, base velocity change w broadcast after each turn
-//   D. (lane)  velocities, semi-implicit Euler integration, contact forces
-// The cross-lane steps live in the caller (the HIP kernel uses DPP; the host emulation loops over 4 structs).
+// Sixteen lanes — one DPP row — own one environment: row lane = leg * 4 + sub (go2_xlane.h).  The four SUB-lanes of a leg hold the
+// same leg state and run the leg's dynamics replicated; what they divide among themselves is the contact problem:
+//   * the leg's collision candidates (each sub-lane tests a quarter, a 2-step quad tournament finds the deepest),
+//   * every constraint row of the leg, SLICED: a row acts on the 9 numbers (z = change of the leg's 3 joint rates, w = change of the
+//     base twist, angular | linear); sub-lane 0 keeps the z slice of every row, sub-lane 1 the w.angular slice, sub-lane 2 the w.linear
+//     slice (sub-lane 3 idles there).  A row visit of the projected Gauss-Seidel is then 3 FMAs + one quad sum instead of a 9-term dot
+//     product, its state update 3 FMAs instead of 9, and a lane keeps 6 numbers per row instead of 24.
+// Per substep:
+//   A. (lane, replicated in the quad) leg kinematics, leg link inertias in the common frame, velocity-product forces, the leg's
+//              3x3 joint-space inertia A, its inverse, B = [Ic_i S_i], and the leg's Schur terms K = B A^-1 B^T, r = B A^-1 (tau - C)
+//      (row)   sum {Ic_leg (10), K (21), F_leg (6), r (6)} over the 4 legs                     <- DPP row rotations
+//   B. (lane, replicated) base articulated inertia IA = I_base + sum Ic - sum K, Phi = IA^-1, base and joint accelerations,
+//              unconstrained end-of-substep velocities; each sub-lane keeps ITS 3 rows of the map row -> response ([A^-1 | 0], Phi rows)
+//   C. (lane)  contact candidates (foot sphere; deepest of the other leg/base spheres), joint-limit rows; per row the lane's slice of
+//              J = [Jc | G] and Y = [Z | H] (Z = A^-1 Jc^T, G = Ec + Jc N, H = Phi G), the diagonal by a quad sum
+//      (row)   projected Gauss-Seidel, legs take turns, the base-twist slices broadcast to the other legs after each turn
+//   D. (lane, replicated) velocities, semi-implicit Euler integration, contact forces
 #pragma once
 #include "go2_math.h"
 #include "go2_tables.h"
+#include "go2_xlane.h"
 
 #define GO2_QUAD_PARTIALS 43
 
-struct ContactSlot {
-  float Jc[3][3]; float Z[3][3]; SV G[3]; SV H[3]; float dinv[3]; float vfb[3]; float lam[3];
-  float mu; float active; int32_t body; V3 nw, t1w, t2w;
-};
-struct LimitRow { float Z[3]; SV G; SV H; float dinv, vfb, lam, active, sgn; };
+// one constraint row as THIS sub-lane sees it: its 3-number slice of the row vector J = [Jc | G.ang | G.lin] and of the response
+// Y = M^-1 J^T = [Z | H.ang | H.lin]; the scalars are replicated in the quad
+struct Row { float J[3], Y[3], dinv, vfb, lam; };
 
 struct LegPhys {
+  int leg, sub;
   // ---- state (persistent over the substeps of one step) ----
   V3 pw, vw, ww; float qx, qy, qz, qw;
   float q[3], qd[3];
@@ -37,12 +42,15 @@ struct LegPhys {
   float lam_foot[3];
   // ---- substep temporaries that cross phase boundaries ----
   M3 Rwb, R1, R2, R3; V3 wb, vb, p1, p2, p3, a2;
-  SV S1, S2, S3, B1, B2, B3, T1, T2, T3, f0, V0, V0f;
+  SV B1, B2, B3, T1, T2, T3, f0, V0, V0f;
   float Ainv[6];  // 11 12 13 22 23 33
   float u[3], qdf[3];
-  float Phi[21];
-  ContactSlot cs[2]; LimitRow lr[3];
-  SV w; float z[3];
+  float Msub[3][6];          // this sub-lane's rows of the response map: sub 0 [A^-1 | 0], sub 1 Phi rows 0..2, sub 2 Phi rows 3..5
+  Row foot[3], other[3], lim[3];
+  float act_foot, act_other, act_lim[3];
+  V3 f_n, f_t1, f_t2, o_n, o_t1, o_t2;     // world directions of the two contact frames
+  float x[3];                // this sub-lane's slice of the velocity change: sub 0 z, sub 1 w.ang, sub 2 w.lin
+  SV w; float z[3];          // the gathered velocity change (after the solve)
   float tau[3];
   V3 force_foot, force_other; int32_t other_body;
 
@@ -57,7 +65,7 @@ struct LegPhys {
     wb = mulT(Rwb, ww); vb = mulT(Rwb, vw);
     V3 gb = mulT(Rwb, v3(L.gravity[0], L.gravity[1], L.gravity[2]));
     float s1, c1, s2, c2, s3, c3;
-    sincosf(q[0], &s1, &c1); sincosf(q[1], &s2, &c2); sincosf(q[2], &s3, &c3);
+    go2_sincos(q[0], &s1, &c1); go2_sincos(q[1], &s2, &c2); go2_sincos(q[2], &s3, &c3);
     float c23 = c2 * c3 - s2 * s3, s23 = s2 * c3 + c2 * s3;
     R1.x = v3(1, 0, 0); R1.y = v3(0, c1, s1); R1.z = v3(0, -s1, c1);
     R2.x = c2 * R1.x - s2 * R1.z; R2.y = R1.y; R2.z = s2 * R1.x + c2 * R1.z;
@@ -66,7 +74,7 @@ struct LegPhys {
     p2 = p1 + mul(R1, v3(t.o2[0], t.o2[1], t.o2[2]));
     p3 = p2 + mul(R2, v3(t.o3[0], t.o3[1], t.o3[2]));
     V3 a1 = v3(1, 0, 0); a2 = R1.y;
-    S1 = sv(a1, cross(p1, a1)); S2 = sv(a2, cross(p2, a2)); S3 = sv(a2, cross(p3, a2));
+    SV S1 = sv(a1, cross(p1, a1)), S2 = sv(a2, cross(p2, a2)), S3 = sv(a2, cross(p3, a2));
     RB I1 = to_common(Lhip, R1, p1), I2 = to_common(Lthigh, R2, p2), I3 = to_common(Lcalf, R3, p3);
     RB Ic2 = I2 + I3, Ic1 = I1 + Ic2;
     V0 = sv(wb, vb);
@@ -109,7 +117,7 @@ struct LegPhys {
     RB Ileg; Ileg.m = red[0]; Ileg.h = v3(red[1], red[2], red[3]);
     Ileg.J.xx = red[4]; Ileg.J.yy = red[5]; Ileg.J.zz = red[6]; Ileg.J.xy = red[7]; Ileg.J.xz = red[8]; Ileg.J.yz = red[9];
     RB Itot = Ibase + Ileg;
-    float IA[21]; rb_to_s6(Itot, IA);
+    float IA[21], Phi[21]; rb_to_s6(Itot, IA);
 #pragma unroll
     for (int i = 0; i < 21; ++i) IA[i] -= red[10 + i];
     spd6_inverse(IA, Phi);
@@ -122,6 +130,15 @@ struct LegPhys {
     qdf[1] = qd[1] + h * (Ainv[1] * e0 + Ainv[3] * e1 + Ainv[4] * e2);
     qdf[2] = qd[2] + h * (Ainv[2] * e0 + Ainv[4] * e1 + Ainv[5] * e2);
     V0f = V0 + h * a0;
+    // this sub-lane's three rows of the response map  [dz; dw] = [A^-1 Jc^T ; Phi G^T] dl
+    const bool joint = sub == 0 || sub == 3, lin = sub == 2;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const float ph = lin ? s6at(Phi, 3 + i, k) : s6at(Phi, i, k);
+        Msub[i][k] = joint ? (k < 3 ? ainv(i, k) : 0.f) : ph;
+      }
   }
 
   // terrain height and unit normal under world point (x, y)
@@ -142,164 +159,191 @@ struct LegPhys {
     *n = v3(nx * inv, ny * inv, inv);
   }
 
-  GO2_HD void build_slot(ContactSlot& s, const Go2Launch& L, float gap, V3 cb, float rad, int link, int body, V3 nw, bool warm) {
-    float h = L.sim_dt;
-    s.active = gap < L.contact_offset ? 1.f : 0.f;
-    s.body = body; s.mu = mu; s.nw = nw;
-    V3 ex = v3(1, 0, 0); float dn = dot(ex, nw);
-    V3 t1 = ex - dn * nw; t1 = (1.0f / sqrtf(dot(t1, t1))) * t1;
-    s.t1w = t1; s.t2w = cross(nw, t1);
-    V3 dirs[3] = {mulT(Rwb, s.nw), mulT(Rwb, s.t1w), mulT(Rwb, s.t2w)};
-    V3 rb = cb - rad * dirs[0];
-    V3 zero3 = v3(0, 0, 0);
-    V3 col1 = sel(link >= 1, cross(v3(1, 0, 0), rb - p1), zero3);
-    V3 col2 = sel(link >= 2, cross(a2, rb - p2), zero3);
-    V3 col3 = sel(link >= 3, cross(a2, rb - p3), zero3);
-    float cfm1 = 1.0f + L.cfm;
+  // One constraint row from its joint-space row Jc (3) and its base-space row Ec (6): this sub-lane's slices of J = [Jc | G], Y = [Z | H]
+  // (G = Ec - sum_j Jc_j T_j, Z = A^-1 Jc, H = Phi G), the inverse diagonal (quad sum of the slice products) and the free velocity.
+  GO2_HD void build_row(Row& r, const float* Jc, const SV& Ec, float cfm1, float bias, float lam0) {
+    const SV G = Ec - (Jc[0] * T1 + Jc[1] * T2 + Jc[2] * T3);
+    const bool joint = sub == 0 || sub == 3;
+    const float x6[6] = {joint ? Jc[0] : G.a.x, joint ? Jc[1] : G.a.y, joint ? Jc[2] : G.a.z, joint ? 0.f : G.l.x, joint ? 0.f : G.l.y, joint ? 0.f : G.l.z};
+    const float live = sub == 3 ? 0.f : 1.f;      // sub-lane 3 keeps an all-zero slice (it mirrors sub-lane 0's arithmetic, never its contribution)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s += Msub[i][k] * x6[k];
+      r.Y[i] = live * s;
+    }
+    r.J[0] = live * (sub == 2 ? G.l.x : x6[0]); r.J[1] = live * (sub == 2 ? G.l.y : x6[1]); r.J[2] = live * (sub == 2 ? G.l.z : x6[2]);
+    const float d_ = xl::sub_sum(r.J[0] * r.Y[0] + r.J[1] * r.Y[1] + r.J[2] * r.Y[2]) * cfm1;
+    r.dinv = d_ > 0.f ? 1.0f / d_ : 0.f;
+    r.vfb = dot(Ec, V0f) + Jc[0] * qdf[0] + Jc[1] * qdf[1] + Jc[2] * qdf[2] + bias;
+    r.lam = lam0;
+  }
+
+  // the three rows (normal, two tangents) of a sphere contact: gap, sphere centre cb in the base frame, radius, link (0 base, 1..3), world normal
+  GO2_HD void build_slot(Row* rows, float* active, V3* dn, V3* dt1, V3* dt2, const Go2Launch& L, float gap, V3 cb, float rad, int link, V3 nw, bool warm) {
+    const float h = L.sim_dt, cfm1 = 1.0f + L.cfm;
+    const float act = gap < L.contact_offset ? 1.f : 0.f;
+    *active = act; *dn = nw;
+    V3 ex = v3(1, 0, 0); float dnx = dot(ex, nw);
+    V3 t1 = ex - dnx * nw; t1 = (1.0f / sqrtf(dot(t1, t1))) * t1;
+    *dt1 = t1; *dt2 = cross(nw, t1);
+    const V3 dirs[3] = {mulT(Rwb, nw), mulT(Rwb, t1), mulT(Rwb, *dt2)};
+    const V3 rb = cb - rad * dirs[0];
+    const V3 zero3 = v3(0, 0, 0);
+    const V3 col1 = sel(link >= 1, cross(v3(1, 0, 0), rb - p1), zero3);
+    const V3 col2 = sel(link >= 2, cross(a2, rb - p2), zero3);
+    const V3 col3 = sel(link >= 3, cross(a2, rb - p3), zero3);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      V3 d = dirs[a];
-      float j0 = dot(d, col1), j1 = dot(d, col2), j2 = dot(d, col3);
-      s.Jc[a][0] = j0; s.Jc[a][1] = j1; s.Jc[a][2] = j2;
-      SV Ec = sv(cross(rb, d), d);
-      s.G[a] = Ec - (j0 * T1 + j1 * T2 + j2 * T3);
-      s.Z[a][0] = Ainv[0] * j0 + Ainv[1] * j1 + Ainv[2] * j2;
-      s.Z[a][1] = Ainv[1] * j0 + Ainv[3] * j1 + Ainv[4] * j2;
-      s.Z[a][2] = Ainv[2] * j0 + Ainv[4] * j1 + Ainv[5] * j2;
-      s.H[a] = spd6_mul(Phi, s.G[a]);
-      float d_ = (j0 * s.Z[a][0] + j1 * s.Z[a][1] + j2 * s.Z[a][2] + dot(s.G[a], s.H[a])) * cfm1;
-      s.dinv[a] = 1.0f / d_;
-      s.vfb[a] = dot(Ec, V0f) + j0 * qdf[0] + j1 * qdf[1] + j2 * qdf[2];
+      const V3 d = dirs[a];
+      const float Jc[3] = {dot(d, col1), dot(d, col2), dot(d, col3)};
+      const SV Ec = sv(cross(rb, d), d);
+      float bias = 0.f;
       if (a == 0) {
-        float vn_pre = dot(Ec, V0) + j0 * qd[0] + j1 * qd[1] + j2 * qd[2];
+        const float vn_pre = dot(Ec, V0) + Jc[0] * qd[0] + Jc[1] * qd[1] + Jc[2] * qd[2];
         float b = gap >= 0.f ? gap / h : gap * L.erp / h;
         b = fmaxf(b, -L.max_depen_vel);
         if (vn_pre < -L.bounce_thr && gap + vn_pre * h < 0.f) b = fminf(b, rest * vn_pre);
-        s.vfb[0] += b;
+        bias = b;
       }
-      s.lam[a] = (warm && s.active > 0.f) ? lam_foot[a] : 0.f;
+      build_row(rows[a], Jc, Ec, cfm1, bias, (warm && act > 0.f) ? lam_foot[a] : 0.f);
     }
   }
 
   // ------------------------------------------------------------------------------------------------
-  GO2_HD void phaseC(const LegTab& t, const Go2Launch& L, const int16_t* hf, float* dw_out) {
+  GO2_HD void phaseC(const LegTab& t, const Go2Launch& L, const int16_t* hf) {
     // foot
     {
       V3 cb = p3 + mul(R3, v3(t.foot_pt[0], t.foot_pt[1], t.foot_pt[2]));
       V3 cw = pw + mul(Rwb, cb); float hh; V3 n; terrain(L, hf, cw.x, cw.y, &hh, &n);
       float gap = (cw.z - hh) * n.z - t.foot_pt[3];
-      build_slot(cs[0], L, gap, cb, t.foot_pt[3], 3, t.body_index[3], n, true);
+      build_slot(foot, &act_foot, &f_n, &f_t1, &f_t2, L, gap, cb, t.foot_pt[3], 3, n, true);
     }
-    // deepest of the other candidates.  They are tabulated per link in a fixed order (hip, thigh, calf, then this lane's share of
-    // the base points), so each link's world pose is formed once and a candidate costs one 3x3 transform; only the winner's
-    // base-frame position is reconstructed afterwards.
+    // deepest of the other candidates: this sub-lane tests its quarter of the leg's 16 + the leg's share of the base points (table
+    // slots with a fixed link type per slot, go2_tables.h SubCand), then two quad-exchange rounds carry the deepest one — with the
+    // base-frame position, radius, link, body and facet normal it needs for its rows — to all four sub-lanes.  Ties go to the lower
+    // candidate index (the scan order of the sequential formulation).
     {
-      float best = 1e30f; int bi = 0; V3 bn = v3(0, 0, 1);
-      const M3 Rw1 = {mul(Rwb, R1.x), mul(Rwb, R1.y), mul(Rwb, R1.z)}, Rw2 = {mul(Rwb, R2.x), mul(Rwb, R2.y), mul(Rwb, R2.z)}, Rw3 = {mul(Rwb, R3.x), mul(Rwb, R3.y), mul(Rwb, R3.z)};
-      const V3 o1 = pw + mul(Rwb, p1), o2 = pw + mul(Rwb, p2), o3 = pw + mul(Rwb, p3);
-#define GO2_CAND(idx, PT, RW, OW) { \
-        const V3 cw = OW + mul(RW, v3(PT[0], PT[1], PT[2])); float hh; V3 n; terrain(L, hf, cw.x, cw.y, &hh, &n); \
-        const float gap = (cw.z - hh) * n.z - PT[3]; \
-        if (gap < best) { best = gap; bi = (idx); bn = n; } }
-#define GO2_CAND_UNROLL 1     // rolled: unrolling the 19 candidates raises register pressure into scratch (124 vs 117 us, measured)
-#pragma unroll GO2_CAND_UNROLL
-      for (int i = 0; i < GO2_N_HIP_PTS; ++i) GO2_CAND(i, t.other_pt[i], Rw1, o1)
-#pragma unroll GO2_CAND_UNROLL
-      for (int i = GO2_N_HIP_PTS; i < GO2_N_HIP_PTS + GO2_N_THIGH_PTS; ++i) GO2_CAND(i, t.other_pt[i], Rw2, o2)
-#pragma unroll GO2_CAND_UNROLL
-      for (int i = GO2_N_HIP_PTS + GO2_N_THIGH_PTS; i < GO2_NLEG_OTHER; ++i) GO2_CAND(i, t.other_pt[i], Rw3, o3)
-#pragma unroll GO2_CAND_UNROLL
-      for (int k = 0; k < GO2_LANE_BASE_PTS; ++k) if (k < t.n_base) GO2_CAND(GO2_NLEG_OTHER + k, t.base_pt[k], Rwb, pw)
+      const SubCand& sc = t.cand[sub];
+      float best = 1e30f; int bi = 1 << 20; V3 bn = v3(0, 0, 1), bcb = v3(0, 0, 0); float brad = 0.f; int blink = 0, bbody = 0;
+      const V3 q2 = p2, q3 = p3;
+#define GO2_CAND(k, R, P, LINK) { \
+        const V3 c = v3(sc.pt[k][0], sc.pt[k][1], sc.pt[k][2]); const V3 cbk = P + mul(R, c); \
+        const V3 cw = pw + mul(Rwb, cbk); float hh; V3 n; terrain(L, hf, cw.x, cw.y, &hh, &n); \
+        const float gap = (cw.z - hh) * n.z - sc.pt[k][3]; \
+        const bool tk = sc.idx[k] >= 0 && (gap < best || (gap == best && sc.idx[k] < bi)); \
+        best = tk ? gap : best; bi = tk ? sc.idx[k] : bi; bn = sel(tk, n, bn); bcb = sel(tk, cbk, bcb); brad = tk ? sc.pt[k][3] : brad; \
+        blink = tk ? (LINK) : blink; bbody = tk ? sc.body[k] : bbody; }
+      GO2_CAND(0, R2, q2, 2)
+      GO2_CAND(1, R2, q2, 2)
+      GO2_CAND(2, R3, q3, 3)
+      {   // slot 3: a calf point for sub-lanes 0 and 1, a hip point for sub-lanes 2 and 3
+        const bool hipk = sub >= 2;
+        const M3 Rx = {sel(hipk, R1.x, R3.x), sel(hipk, R1.y, R3.y), sel(hipk, R1.z, R3.z)}; const V3 px = sel(hipk, p1, p3);
+        GO2_CAND(3, Rx, px, hipk ? 1 : 3)
+      }
+      {   // slot 4: one of the leg's base / head points (sub-lane < number of points of this leg)
+        const M3 Id = {v3(1, 0, 0), v3(0, 1, 0), v3(0, 0, 1)}; const V3 o = v3(0, 0, 0);
+        GO2_CAND(4, Id, o, 0)
+      }
 #undef GO2_CAND
-      const bool isb = bi >= GO2_NLEG_OTHER;
-      const int kb = isb ? bi - GO2_NLEG_OTHER : 0, ko = isb ? 0 : bi;
-      const V3 c = isb ? v3(t.base_pt[kb][0], t.base_pt[kb][1], t.base_pt[kb][2]) : v3(t.other_pt[ko][0], t.other_pt[ko][1], t.other_pt[ko][2]);
-      const float brad = isb ? t.base_pt[kb][3] : t.other_pt[ko][3];
-      const int bbody = isb ? t.base_body[kb] : t.other_body[ko];
-      const int blink = isb ? 0 : (bi < GO2_N_HIP_PTS ? 1 : (bi < GO2_N_HIP_PTS + GO2_N_THIGH_PTS ? 2 : 3));
-      const V3 bcb = sel(blink == 0, c, sel(blink == 1, p1 + mul(R1, c), sel(blink == 2, p2 + mul(R2, c), p3 + mul(R3, c))));
-      build_slot(cs[1], L, best, bcb, brad, blink, bbody, bn, false);
+      // quad tournament: partner sub^1, then sub^2
+#define GO2_ROUND(PERM) { \
+        const float g2 = xl::quad_perm<PERM>(best); const int i2 = xl::quad_perm_i<PERM>(bi); \
+        const bool tk = g2 < best || (g2 == best && i2 < bi); \
+        const float nx = xl::quad_perm<PERM>(bn.x), ny = xl::quad_perm<PERM>(bn.y), nz = xl::quad_perm<PERM>(bn.z); \
+        const float cx = xl::quad_perm<PERM>(bcb.x), cy = xl::quad_perm<PERM>(bcb.y), cz = xl::quad_perm<PERM>(bcb.z); \
+        const float r2 = xl::quad_perm<PERM>(brad); const int l2 = xl::quad_perm_i<PERM>(blink), b2 = xl::quad_perm_i<PERM>(bbody); \
+        best = tk ? g2 : best; bi = tk ? i2 : bi; bn = sel(tk, v3(nx, ny, nz), bn); bcb = sel(tk, v3(cx, cy, cz), bcb); \
+        brad = tk ? r2 : brad; blink = tk ? l2 : blink; bbody = tk ? b2 : bbody; }
+#define GO2_P1 1, 0, 3, 2
+#define GO2_P2 2, 3, 0, 1
+      GO2_ROUND(GO2_P1)
+      GO2_ROUND(GO2_P2)
+#undef GO2_P1
+#undef GO2_P2
+#undef GO2_ROUND
+      other_body = bbody;
+      // rows only if some lane of the wave has a candidate inside the contact margin this substep (wave-uniform branch; an inactive
+      // slot's rows are never visited by the solver, so skipping their construction changes no result)
+      act_other = best < L.contact_offset ? 1.f : 0.f; o_n = bn; o_t1 = v3(1, 0, 0); o_t2 = v3(0, 1, 0);
+      if (xl::any(act_other > 0.f)) build_slot(other, &act_other, &o_n, &o_t1, &o_t2, L, best, bcb, brad, blink, bn, false);
+      else { _Pragma("unroll") for (int a = 0; a < 3; ++a) other[a].lam = 0.f; }
     }
     // joint limits
-    float h = L.sim_dt, cfm1 = 1.0f + L.cfm;
+    {
+      float h = L.sim_dt, cfm1 = 1.0f + L.cfm;
+      float sgn[3], gap[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      float glo = q[j] - t.lim_lo[j], ghi = t.lim_hi[j] - q[j];
-      float sgn = 0.f, gap = 0.f;
-      if (glo < L.limit_margin) { sgn = 1.f; gap = glo; } else if (ghi < L.limit_margin) { sgn = -1.f; gap = ghi; }
-      LimitRow& r = lr[j];
-      r.active = sgn != 0.f ? 1.f : 0.f; r.lam = 0.f; r.sgn = sgn;
-      r.Z[0] = sgn * ainv(0, j); r.Z[1] = sgn * ainv(1, j); r.Z[2] = sgn * ainv(2, j);
-      SV Tj = sv(sel(j == 0, T1.a, sel(j == 1, T2.a, T3.a)), sel(j == 0, T1.l, sel(j == 1, T2.l, T3.l)));
-      r.G = (-sgn) * Tj;
-      r.H = spd6_mul(Phi, r.G);
-      float d_ = (sgn * r.Z[j] + dot(r.G, r.H)) * cfm1;
-      r.dinv = d_ > 0.f ? 1.0f / d_ : 0.f;
-      float b = gap >= 0.f ? gap / h : gap * L.erp / h; b = fmaxf(b, -10.0f);
-      r.vfb = sgn * qdf[j] + b;
-    }
-    // warm start contribution
-    SV dw = sv(v3(0, 0, 0), v3(0, 0, 0)); z[0] = z[1] = z[2] = 0.f;
+      for (int j = 0; j < 3; ++j) {
+        float glo = q[j] - t.lim_lo[j], ghi = t.lim_hi[j] - q[j];
+        sgn[j] = 0.f; gap[j] = 0.f;
+        if (glo < L.limit_margin) { sgn[j] = 1.f; gap[j] = glo; } else if (ghi < L.limit_margin) { sgn[j] = -1.f; gap[j] = ghi; }
+        act_lim[j] = sgn[j] != 0.f ? 1.f : 0.f; lim[j].lam = 0.f;
+      }
+      if (xl::any(act_lim[0] + act_lim[1] + act_lim[2] > 0.f))
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      float l = cs[0].lam[a];
-      dw = dw + l * cs[0].H[a];
-      z[0] += cs[0].Z[a][0] * l; z[1] += cs[0].Z[a][1] * l; z[2] += cs[0].Z[a][2] * l;
+        for (int j = 0; j < 3; ++j) {
+          const float Jc[3] = {j == 0 ? sgn[j] : 0.f, j == 1 ? sgn[j] : 0.f, j == 2 ? sgn[j] : 0.f};
+          float b = gap[j] >= 0.f ? gap[j] / h : gap[j] * L.erp / h; b = fmaxf(b, -10.0f);
+          build_row(lim[j], Jc, sv(v3(0, 0, 0), v3(0, 0, 0)), cfm1, b, 0.f);
+        }
     }
-    dw_out[0] = dw.a.x; dw_out[1] = dw.a.y; dw_out[2] = dw.a.z; dw_out[3] = dw.l.x; dw_out[4] = dw.l.y; dw_out[5] = dw.l.z;
+    // warm start: the slice of the velocity change the remembered foot impulses produce.  The joint slice (sub-lane 0) is the leg's
+    // own; the base-twist slices are summed over the four legs.
+    float c[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { c[0] += foot[a].Y[0] * foot[a].lam; c[1] += foot[a].Y[1] * foot[a].lam; c[2] += foot[a].Y[2] * foot[a].lam; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const float s = xl::leg_sum(c[k]); x[k] = sub == 0 ? c[k] : s; }
   }
-  GO2_HD bool has_foot() const { return cs[0].active > 0.f; }
-  GO2_HD bool has_other() const { return cs[1].active > 0.f; }
-  GO2_HD bool has_limit() const { return (lr[0].active + lr[1].active + lr[2].active) > 0.f; }
-  GO2_HD void set_w(const float* wsum) { w = sv(v3(wsum[0], wsum[1], wsum[2]), v3(wsum[3], wsum[4], wsum[5])); }
+  GO2_HD bool has_foot() const { return act_foot > 0.f; }
+  GO2_HD bool has_other() const { return act_other > 0.f; }
+  GO2_HD bool has_limit() const { return (act_lim[0] + act_lim[1] + act_lim[2]) > 0.f; }
 
-  // one Gauss-Seidel sweep over this lane's rows; `on` = 1 for the lane whose turn it is, else 0.
-  // do_slot[s] / do_lim are WAVE-UNIFORM hints: false means no lane of the wave has such a row active this substep, so the
-  // group is skipped as a whole (an inactive row contributes exactly +0, so skipping changes no bit of the result).
-  GO2_HD void sweep(float on, float* dw_out, bool do_foot = true, bool do_other = true, bool do_lim = true) {
-    SV dw = sv(v3(0, 0, 0), v3(0, 0, 0));
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      if (!(s == 0 ? do_foot : do_other)) continue;
-      ContactSlot& c = cs[s];
-      float m = on * c.active;
-      {
-        float v = c.vfb[0] + c.Jc[0][0] * z[0] + c.Jc[0][1] * z[1] + c.Jc[0][2] * z[2] + dot(c.G[0], w);
-        float ln = fmaxf(0.f, c.lam[0] - v * c.dinv[0]);
-        float dl = m * (ln - c.lam[0]); c.lam[0] += dl;
-        z[0] += c.Z[0][0] * dl; z[1] += c.Z[0][1] * dl; z[2] += c.Z[0][2] * dl;
-        SV d = dl * c.H[0]; w = w + d; dw = dw + d;
-      }
-      {
-        float v1 = c.vfb[1] + c.Jc[1][0] * z[0] + c.Jc[1][1] * z[1] + c.Jc[1][2] * z[2] + dot(c.G[1], w);
-        float v2 = c.vfb[2] + c.Jc[2][0] * z[0] + c.Jc[2][1] * z[1] + c.Jc[2][2] * z[2] + dot(c.G[2], w);
-        float l1 = c.lam[1] - v1 * c.dinv[1], l2 = c.lam[2] - v2 * c.dinv[2];
-        float lim = c.mu * c.lam[0], nn = sqrtf(l1 * l1 + l2 * l2);
-        if (nn > lim) { float sc = nn > 0.f ? lim / nn : 0.f; l1 *= sc; l2 *= sc; }
-        float d1 = m * (l1 - c.lam[1]), d2 = m * (l2 - c.lam[2]); c.lam[1] += d1; c.lam[2] += d2;
-        z[0] += c.Z[1][0] * d1 + c.Z[2][0] * d2; z[1] += c.Z[1][1] * d1 + c.Z[2][1] * d2; z[2] += c.Z[1][2] * d1 + c.Z[2][2] * d2;
-        SV d = d1 * c.H[1] + d2 * c.H[2]; w = w + d; dw = dw + d;
-      }
+  GO2_HD float row_v(const Row& r) const { return r.vfb + xl::sub_sum(r.J[0] * x[0] + r.J[1] * x[1] + r.J[2] * x[2]); }
+  GO2_HD void row_apply(const Row& r, float dl) { x[0] += r.Y[0] * dl; x[1] += r.Y[1] * dl; x[2] += r.Y[2] * dl; }
+  GO2_HD void sweep_slot(Row* r, float m, float mu_) {
+    {
+      const float v = row_v(r[0]);
+      const float ln = fmaxf(0.f, r[0].lam - v * r[0].dinv);
+      const float dl = m * (ln - r[0].lam); r[0].lam += dl;
+      row_apply(r[0], dl);
     }
+    {
+      const float v1 = row_v(r[1]), v2 = row_v(r[2]);
+      float l1 = r[1].lam - v1 * r[1].dinv, l2 = r[2].lam - v2 * r[2].dinv;
+      const float lim_ = mu_ * r[0].lam, nn = sqrtf(l1 * l1 + l2 * l2);
+      if (nn > lim_) { const float sc = nn > 0.f ? lim_ / nn : 0.f; l1 *= sc; l2 *= sc; }
+      const float d1 = m * (l1 - r[1].lam), d2 = m * (l2 - r[2].lam); r[1].lam += d1; r[2].lam += d2;
+      row_apply(r[1], d1); row_apply(r[2], d2);
+    }
+  }
+  // One Gauss-Seidel turn of leg T: its rows are visited in the fixed order foot (n, t), other (n, t), limits; then the base-twist
+  // slices it has changed reach the other three legs (they contributed nothing during the turn).  do_* are WAVE-UNIFORM hints: false
+  // means no lane of the wave has such a row active this substep, so the group is skipped as a whole (an inactive row moves nothing).
+  GO2_HD void gs_turn(int T, bool do_foot, bool do_other, bool do_lim) {
+    const float on = leg == T ? 1.f : 0.f;
+    if (do_foot) sweep_slot(foot, on * act_foot, mu);
+    if (do_other) sweep_slot(other, on * act_other, mu);
     if (do_lim)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      LimitRow& r = lr[j];
-      float v = r.vfb + r.sgn * z[j] + dot(r.G, w);
-      float ln = fmaxf(0.f, r.lam - v * r.dinv);
-      float dl = on * r.active * (ln - r.lam); r.lam += dl;
-      z[0] += r.Z[0] * dl; z[1] += r.Z[1] * dl; z[2] += r.Z[2] * dl;
-      SV d = dl * r.H; w = w + d; dw = dw + d;
-    }
-    dw_out[0] = dw.a.x; dw_out[1] = dw.a.y; dw_out[2] = dw.a.z; dw_out[3] = dw.l.x; dw_out[4] = dw.l.y; dw_out[5] = dw.l.z;
+      for (int j = 0; j < 3; ++j) {
+        const float v = row_v(lim[j]);
+        const float ln = fmaxf(0.f, lim[j].lam - v * lim[j].dinv);
+        const float dl = on * act_lim[j] * (ln - lim[j].lam); lim[j].lam += dl;
+        row_apply(lim[j], dl);
+      }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const float s = xl::leg_sum(on * x[k]); x[k] = sub == 0 ? x[k] : s; }
   }
-  GO2_HD void add_delta(const float* d) {
-    w.a.x += d[0]; w.a.y += d[1]; w.a.z += d[2]; w.l.x += d[3]; w.l.y += d[4]; w.l.z += d[5];
-  }
-  // after a turn: add what the other lanes contributed (total - own)
-  GO2_HD void add_others(const float* tot, const float* own) {
-    w.a.x += tot[0] - own[0]; w.a.y += tot[1] - own[1]; w.a.z += tot[2] - own[2];
-    w.l.x += tot[3] - own[3]; w.l.y += tot[4] - own[4]; w.l.z += tot[5] - own[5];
+  // after the last turn: every lane gets the whole velocity change of its leg and of the base
+  GO2_HD void gather_solution() {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) z[k] = xl::sub_bcast<0>(x[k]);
+    w.a = v3(xl::sub_bcast<1>(x[0]), xl::sub_bcast<1>(x[1]), xl::sub_bcast<1>(x[2]));
+    w.l = v3(xl::sub_bcast<2>(x[0]), xl::sub_bcast<2>(x[1]), xl::sub_bcast<2>(x[2]));
   }
 
   // ------------------------------------------------------------------------------------------------
@@ -317,7 +361,7 @@ struct LegPhys {
     }
     pw = pw + h * vw;
     float th = sqrtf(dot(ww, ww)) * h; float dx, dy, dz, dwq;
-    if (th > 1e-9f) { float sc = sinf(0.5f * th) / (th / h); dx = ww.x * sc; dy = ww.y * sc; dz = ww.z * sc; dwq = cosf(0.5f * th); }
+    if (th > 1e-9f) { float sh, ch; go2_sincos(0.5f * th, &sh, &ch); float sc = sh / (th / h); dx = ww.x * sc; dy = ww.y * sc; dz = ww.z * sc; dwq = ch; }
     else { dx = ww.x * h * 0.5f; dy = ww.y * h * 0.5f; dz = ww.z * h * 0.5f; dwq = 1.f; }
     float nx = dwq * qx + dx * qw + dy * qz - dz * qy, ny = dwq * qy - dx * qz + dy * qw + dz * qx;
     float nz = dwq * qz + dx * qy - dy * qx + dz * qw, nw_ = dwq * qw - dx * qx - dy * qy - dz * qz;
@@ -326,11 +370,10 @@ struct LegPhys {
 #pragma unroll
     for (int j = 0; j < 3; ++j) { qd[j] = qdp[j]; q[j] += h * qdp[j]; }
     float ih = 1.0f / h;
-    force_foot = cs[0].active * ih * (cs[0].lam[0] * cs[0].nw + cs[0].lam[1] * cs[0].t1w + cs[0].lam[2] * cs[0].t2w);
-    force_other = cs[1].active * ih * (cs[1].lam[0] * cs[1].nw + cs[1].lam[1] * cs[1].t1w + cs[1].lam[2] * cs[1].t2w);
-    other_body = cs[1].body;
+    force_foot = act_foot * ih * (foot[0].lam * f_n + foot[1].lam * f_t1 + foot[2].lam * f_t2);
+    force_other = act_other * ih * (other[0].lam * o_n + other[1].lam * o_t1 + other[2].lam * o_t2);
 #pragma unroll
-    for (int a = 0; a < 3; ++a) lam_foot[a] = cs[0].active * cs[0].lam[a];
+    for (int a = 0; a < 3; ++a) lam_foot[a] = act_foot * foot[a].lam;
   }
 
   // _compute_torques (legged_robot.py:594-618, control_type 'P') then *= motor_strengths (:80-81)

@@ -51,6 +51,15 @@ GO2_HD float go2_mul_inv_rn(float a, double inv_b) { return (float)((double)a * 
 GO2_HD float go2_sqrt_rn(float x) { return sqrtf(x); }
 #endif
 
+// sine and cosine of a joint / half rotation angle (|x| < a few pi).  Device: the hardware's v_sin_f32 / v_cos_f32 on x / 2pi (absolute
+// error ~1e-6 over this range: far below the fp32 noise of the dynamics it feeds; the libm-grade sincosf costs ~130 instructions and
+// there are 21 of them per env step).  Host builds use libm.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void go2_sincos(float x, float* s, float* c) { const float r = x * 0.15915494309189535f; *s = __builtin_amdgcn_sinf(r); *c = __builtin_amdgcn_cosf(r); }
+#else
+GO2_HD void go2_sincos(float x, float* s, float* c) { *s = sinf(x); *c = cosf(x); }
+#endif
+
 struct V3 { float x, y, z; };
 GO2_HD V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
 GO2_HD V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }

@@ -8,13 +8,15 @@
 // _push_robots (:709-724), Go2Robot.compute_observations (go2_env.py:23-53) and the obs clip of step()
 // (:96-99), last_* updates (:140-142).  Ordering quirks of the reference are kept.
 //
-// Work split inside a quad: every per-joint quantity (3 of the 12 DOFs), the leg's 4 bodies and a quarter of
-// the 187 height samples belong to the lane; per-env scalar logic (commands, termination, root reset) is
-// computed redundantly by the 4 lanes (identical inputs, identical results) and written by lane 0.
-// One cross-lane step: the quad-sum of GO2_POST_PARTIALS reward partial sums between postA and postB.
+// Work split inside the 16 lanes of an environment (row lane = leg * 4 + sub, go2_xlane.h): every per-joint quantity (3 of the 12 DOFs)
+// and the leg's 4 bodies belong to the leg's quad (computed by its 4 sub-lanes alike, written by sub-lane 0); a sixteenth of the 187
+// height samples belongs to the lane; per-env scalar logic (commands, termination, root reset) is computed redundantly by the 16 lanes
+// (identical inputs, identical results) and written by lane 0.  Cross-lane steps: the leg sum of GO2_POST_PARTIALS reward partial sums
+// between postA and postB.  No location that several lanes read is written before that sum (a rendezvous of the whole row).
 #pragma once
 #include "go2_math.h"
 #include "go2_tables.h"
+#include "go2_xlane.h"
 
 #define GO2_POST_PARTIALS 24
 
@@ -66,7 +68,7 @@ GO2_HD void go2_step_scalars(const Go2Launch& L, const Go2Dyn& dyn, const float*
 }
 
 struct LegPost {
-  int e, lane, N;
+  int e, lane, sub, lane16, N;     // lane = leg (0..3), sub = sub-lane of the leg, lane16 = leg * 4 + sub
   const Go2PtrsK* P; const Go2Launch* L; const Go2Step* S;
   PhysOut o;
   // env scalars (replicated)
@@ -217,7 +219,7 @@ struct LegPost {
     if (c.measure_heights && c.terrain_mode != 0) {   // on a plane measured_heights stays the all-zero buffer it was created as (:1201-1202)
       // quat_apply_yaw (utils/math.py:8-12): zero x, y, normalise — individually rounded, it feeds the cell index
       const float nn = fmaxf(go2_sqrt_rn(go2_add_rn(go2_mul_rn(qz, qz), go2_mul_rn(qw, qw))), 1e-9f), yz = go2_div_rn(qz, nn), yw = go2_div_rn(qw, nn);
-      for (int i = lane; i < GO2_NUM_HEIGHT_POINTS; i += 4) {
+      for (int i = lane16; i < GO2_NUM_HEIGHT_POINTS; i += 16) {
         const float hv = height_at(i, yz, yw, o.pw.x, o.pw.y);
         const int ix = i / 11, iy = i - 11 * ix;
         F2D(p.heights, i, e) = hv;
@@ -249,15 +251,15 @@ struct LegPost {
     // _reward_base_height (:1245-1259)
     float bh_cnt = 0; V3 bh_pos = v3(0, 0, 0);
     if (c.rew_on[GO2_REW_BASE_HEIGHT]) {
-      bool filt = contact || F2D(p.last_contacts2, lane, e); F2D(p.last_contacts2, lane, e) = contact ? 1 : 0;
+      bool filt = contact || F2D(p.last_contacts2, lane, e); new_lc2 = contact ? 1 : 0;
       if (filt) { bh_cnt = 1; bh_pos = o.foot_pos; }
     }
     // _reward_feet_air_time (:1347-1358)
     float air = 0;
     if (c.rew_on[GO2_REW_FEET_AIR_TIME]) {
-      bool filt = contact || F2D(p.last_contacts, lane, e); F2D(p.last_contacts, lane, e) = contact ? 1 : 0;
+      bool filt = contact || F2D(p.last_contacts, lane, e); new_lc = contact ? 1 : 0;
       float fat = F2D(p.feet_air_time, lane, e); bool first = fat > 0.f && filt; fat += c.dt; air = (fat - 0.5f) * (first ? 1.f : 0.f);
-      F2D(p.feet_air_time, lane, e) = filt ? 0.f : fat;
+      new_fat = filt ? 0.f : fat;
     }
     float stumble = sqrtf(o.Ffoot.x * o.Ffoot.x + o.Ffoot.y * o.Ffoot.y) > 5.f * fabsf(o.Ffoot.z) ? 1.f : 0.f;
     float fcf = fmaxf(fnorm - c.max_contact_force, 0.f);
@@ -272,11 +274,13 @@ struct LegPost {
     part[18] = fabsf(hip - c.q0[3 * lane]);                        // hip_to_default (go2_env.py:55)
     part[19] = lane < 2 ? hip : 0.f; part[20] = lane >= 2 ? hip : 0.f;   // x_command_hip_regular (go2_env.py:62)
     part[21] = lane == 0 ? floc.y : (lane == 1 ? -floc.y : 0.f); part[22] = lane == 2 ? floc.y : (lane == 3 ? -floc.y : 0.f);
-    part[23] = hsum;
+    part[23] = xl::sub_sum(hsum);   // the leg's samples = its four sub-lanes' shares (every other partial is replicated in the quad)
     own_f2b = f2b; own_fvel2 = fvel2;
     rpy[0] = roll; rpy[1] = pitch; rpy[2] = yaw; max_move = mm;
   }
   float own_f2b, own_fvel2, rpy[3], max_move, org_x, org_y, org_z; int64_t tlevel, ttype;
+  bool skip_contact_filters;                   // reset_all runs postB without a postA: nothing to carry over
+  uint8_t new_lc, new_lc2; float new_fat;      // per-leg read-modify-write fields: read by the 4 sub-lanes in postA, written by sub-lane 0 in postB
   // replicated fields that lane 0 rewrites in postB: every lane reads them BEFORE any lane writes
   GO2_HD void load_terrain_fields() {
     const Go2PtrsK& p = *P;
@@ -339,10 +343,10 @@ struct LegPost {
     const bool need_to = c.turn_over && fabsf(rpy[0]) > c.to_roll_thr;      // :263-265
 #pragma unroll
     for (int i = 0; i < GO2_REW_TERMINATION; ++i)
-      if (c.rew_on[i] && !S->initial_reset) { float r = raw[i] * (need_to ? S->rew_to_scale[i] : S->rew_scale[i]); total += r; if (lane == 0) es[(size_t)i * N + e] += r; }
+      if (c.rew_on[i] && !S->initial_reset) { float r = raw[i] * (need_to ? S->rew_to_scale[i] : S->rew_scale[i]); total += r; if (lane16 == 0) es[(size_t)i * N + e] += r; }
     if (c.only_positive && total < 0.f) total = 0.f;
     if (c.rew_on[GO2_REW_TERMINATION] && !S->initial_reset) {
-      float r = ((reset && !time_out) ? 1.f : 0.f) * S->rew_scale[GO2_REW_TERMINATION]; total += r; if (lane == 0) es[(size_t)GO2_REW_TERMINATION * N + e] += r;
+      float r = ((reset && !time_out) ? 1.f : 0.f) * S->rew_scale[GO2_REW_TERMINATION]; total += r; if (lane16 == 0) es[(size_t)GO2_REW_TERMINATION * N + e] += r;
     }
     if (c.rew_on[GO2_REW_ACTION_SMOOTHNESS])
       _Pragma("unroll") for (int j = 0; j < 3; ++j) llast_act[j] = last_act[j];       // :1378 (not zeroed on reset, App. E.9)
@@ -351,11 +355,14 @@ struct LegPost {
     float ox = org_x, oy = org_y, oz = org_z;
     if (reset) {
       // field-major request order (strength x3, offset x3, kp x3, kd x3): 3 Philox groups per lane (go2sim_rng.h)
-      if (c.rand_strength) _Pragma("unroll") for (int j = 0; j < 3; ++j) F2D(p.strength, 3 * lane + j, e) = urange(uni(GO2_U_RESET_STRENGTH + 3 * lane + j), c.strength_rng[0], c.strength_rng[1]);
-      if (c.rand_offset) _Pragma("unroll") for (int j = 0; j < 3; ++j) F2D(p.zero_off, 3 * lane + j, e) = urange(uni(GO2_U_RESET_OFFSET + 3 * lane + j), c.offset_rng[0], c.offset_rng[1]);
-      if (c.rand_pd) {
-        _Pragma("unroll") for (int j = 0; j < 3; ++j) F2D(p.kp_mul, 3 * lane + j, e) = urange(uni(GO2_U_RESET_KP + 3 * lane + j), c.kp_rng[0], c.kp_rng[1]);
-        _Pragma("unroll") for (int j = 0; j < 3; ++j) F2D(p.kd_mul, 3 * lane + j, e) = urange(uni(GO2_U_RESET_KD + 3 * lane + j), c.kd_rng[0], c.kd_rng[1]);
+      // the four per-DOF tables: sub-lane k of a leg draws and writes table k (strength, offset, kp, kd) for the leg's 3 joints
+      {
+        const int tb = sub == 0 ? GO2_U_RESET_STRENGTH : (sub == 1 ? GO2_U_RESET_OFFSET : (sub == 2 ? GO2_U_RESET_KP : GO2_U_RESET_KD));
+        const bool on = sub == 0 ? c.rand_strength : (sub == 1 ? c.rand_offset : c.rand_pd);
+        const float lo = sub == 0 ? c.strength_rng[0] : (sub == 1 ? c.offset_rng[0] : (sub == 2 ? c.kp_rng[0] : c.kd_rng[0]));
+        const float hi = sub == 0 ? c.strength_rng[1] : (sub == 1 ? c.offset_rng[1] : (sub == 2 ? c.kp_rng[1] : c.kd_rng[1]));
+        GO2_AS1 float* dst = sub == 0 ? p.strength : (sub == 1 ? p.zero_off : (sub == 2 ? p.kp_mul : p.kd_mul));
+        if (on) _Pragma("unroll") for (int j = 0; j < 3; ++j) F2D(dst, 3 * lane + j, e) = urange(uni(tb + 3 * lane + j), lo, hi);
       }
       if (c.terrain_curriculum && c.terrain_mode != 0 && !S->initial_reset) {   // _update_terrain_curriculum (:1143-1169)
         float dist = max_move;
@@ -367,7 +374,7 @@ struct LegPost {
         else if (lv < 0) lv = 0;
         const float* og = p.terrain_origins + ((size_t)lv * c.terrain_num_types + ttype) * 3;
         ox = og[0]; oy = og[1]; oz = og[2]; max_move = 0.f;
-        if (lane == 0) { p.terrain_levels[e] = lv; F2D(p.origins, 0, e) = ox; F2D(p.origins, 1, e) = oy; F2D(p.origins, 2, e) = oz; }
+        if (lane16 == 0) { p.terrain_levels[e] = lv; F2D(p.origins, 0, e) = ox; F2D(p.origins, 1, e) = oy; F2D(p.origins, 2, e) = oz; }
       }
 #pragma unroll
       for (int j = 0; j < 3; ++j) {   // _reset_dofs (:620-634)
@@ -391,12 +398,12 @@ struct LegPost {
         o.qx = cy * sr; o.qy = sy * sr; o.qz = sy * cr; o.qw = cy * cr; }
       o.vw = v3(urange(uni(GO2_U_RESET_VEL), -0.5f, 0.5f), urange(uni(GO2_U_RESET_VEL + 1), -0.5f, 0.5f), urange(uni(GO2_U_RESET_VEL + 2), -0.5f, 0.5f));
       o.ww = v3(urange(uni(GO2_U_RESET_VEL + 3), -0.5f, 0.5f), urange(uni(GO2_U_RESET_VEL + 4), -0.5f, 0.5f), urange(uni(GO2_U_RESET_VEL + 5), -0.5f, 0.5f));
-      F2D(p.feet_air_time, lane, e) = 0.f;
-      _Pragma("unroll") for (int a = 0; a < 3; ++a) F3D(p.foot_impulse, 4, lane, a, e) = 0.f;
+      new_fat = 0.f;
+      if (sub == 0) _Pragma("unroll") for (int a = 0; a < 3; ++a) F3D(p.foot_impulse, 4, lane, a, e) = 0.f;
       ep_len = 0;
       timer = c.resampling_time / c.dt; acc[0] = 0.f; acc[1] = 0.f;
       resample(GO2_U_RSB);
-      if (lane == 0) {   // extras["episode"] accumulators (:229-242)
+      if (lane16 == 0) {   // extras["episode"] accumulators (:229-242)
         _Pragma("unroll") for (int i = 0; i < GO2_NUM_REWARDS; ++i) if (c.rew_on[i]) {
 #if defined(__HIP_DEVICE_COMPILE__)
           atomicAdd(&p.ep_accum[i], es[(size_t)i * N + e]);
@@ -422,7 +429,7 @@ struct LegPost {
     float* ob = p.obs + (size_t)e * GO2_NUM_OBS; float* pv = p.priv + (size_t)e * GO2_NUM_PRIV_OBS;
 #define CLIP(x) fminf(fmaxf((x), -cl), cl)
 #define NOISE(i) ((c.add_noise && c.noise_vec[(i)] != 0.f) ? (2.f * uni(GO2_U_NOISE + (i)) - 1.f) * c.noise_vec[(i)] : 0.f)
-    if (lane == 0) {
+    if (lane16 == 0) {
       float s9[9] = {bav.x * c.os_ang, bav.y * c.os_ang, bav.z * c.os_ang, pg.x, pg.y, pg.z, cmd[0] * c.os_lin, cmd[1] * c.os_lin, cmd[2] * c.os_ang};
       pv[0] = CLIP(blv.x * c.os_lin); pv[1] = CLIP(blv.y * c.os_lin); pv[2] = CLIP(blv.z * c.os_lin);
       _Pragma("unroll") for (int i = 0; i < 9; ++i) { pv[3 + i] = CLIP(s9[i]); ob[i] = CLIP(s9[i] + NOISE(i)); }
@@ -430,6 +437,7 @@ struct LegPost {
     float ndp[3], ndv[3];   // noise of this leg's joints: 3 + 3 requests = 2 Philox groups
     _Pragma("unroll") for (int j = 0; j < 3; ++j) ndp[j] = NOISE(9 + 3 * lane + j);
     _Pragma("unroll") for (int j = 0; j < 3; ++j) ndv[j] = NOISE(21 + 3 * lane + j);
+    if (sub == 0)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       int d = 3 * lane + j;
@@ -439,12 +447,12 @@ struct LegPost {
       pv[52 + d] = CLIP(o.tau[j] / t.eff_lim[j]);
       pv[64 + d] = CLIP((last_dv[j] - o.qd[j]) / c.dt * 1e-4f);
     }
-    pv[48 + lane] = CLIP(sqrtf(dot(o.Ffoot, o.Ffoot)) * 1e-3f);
+    if (sub == 0) pv[48 + lane] = CLIP(sqrtf(dot(o.Ffoot, o.Ffoot)) * 1e-3f);
     if (c.terrain_mode == 0 || !c.measure_heights) {      // plane: every sample is 0 (:1201-1202), nothing to read back
       const float hv = CLIP(fminf(fmaxf(o.pw.z - 0.5f, -1.f), 1.f) * c.os_height);
-      for (int i = lane; i < GO2_NUM_HEIGHT_POINTS; i += 4) pv[76 + i] = hv;
+      for (int i = lane16; i < GO2_NUM_HEIGHT_POINTS; i += 16) pv[76 + i] = hv;
     } else {
-      for (int i = lane; i < GO2_NUM_HEIGHT_POINTS; i += 4) {
+      for (int i = lane16; i < GO2_NUM_HEIGHT_POINTS; i += 16) {
         // the samples postA took at the pre-reset pose (App. E.3): this lane wrote exactly these entries of measured_heights there
         float hh = fminf(fmaxf(o.pw.z - 0.5f - F2D(p.heights, i, e), -1.f), 1.f);
         pv[76 + i] = CLIP(hh * c.os_height);
@@ -453,6 +461,12 @@ struct LegPost {
 #undef CLIP
 #undef NOISE
     // ---- write back ---------------------------------------------------------------------------------
+    if (sub == 0) {
+      if (c.rew_on[GO2_REW_BASE_HEIGHT] && !skip_contact_filters) F2D(p.last_contacts2, lane, e) = new_lc2;
+      if (c.rew_on[GO2_REW_FEET_AIR_TIME] && !skip_contact_filters) F2D(p.last_contacts, lane, e) = new_lc;
+      if ((c.rew_on[GO2_REW_FEET_AIR_TIME] && !skip_contact_filters) || reset) F2D(p.feet_air_time, lane, e) = new_fat;
+    }
+    if (sub == 0)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       int d = 3 * lane + j;
@@ -462,7 +476,7 @@ struct LegPost {
       F2D(p.actions, d, e) = act[j];
       F2D(p.dof, d, e) = o.q[j]; F2D(p.dof, 12 + d, e) = o.qd[j];
     }
-    if (lane == 0) {
+    if (lane16 == 0) {
       float r13[13] = {o.pw.x, o.pw.y, o.pw.z, o.qx, o.qy, o.qz, o.qw, o.vw.x, o.vw.y, o.vw.z, o.ww.x, o.ww.y, o.ww.z};
       _Pragma("unroll") for (int k = 0; k < 13; ++k) F2D(p.root, k, e) = r13[k];
       _Pragma("unroll") for (int k = 0; k < 6; ++k) F2D(p.last_root_vel, k, e) = r13[7 + k];   // :142

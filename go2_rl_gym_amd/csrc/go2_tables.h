@@ -13,7 +13,14 @@
 #define GO2_N_CALF_PTS 6
 static_assert(GO2_N_HIP_PTS + GO2_N_THIGH_PTS + GO2_N_CALF_PTS == GO2_NLEG_OTHER, "candidate layout");
 
-// per-leg constant table (one per lane index 0..3); plain floats/ints so it can be memcpy'd into LDS
+// the collision candidates ONE sub-lane of a leg tests (go2_lane.h phaseC).  Five table slots with a fixed link type each, so that the
+// link's pose is known at compile time: slots 0, 1 thigh points, slot 2 a calf point, slot 3 a calf point (sub-lanes 0, 1) or a hip point
+// (sub-lanes 2, 3), slot 4 one of the leg's share of the base / head points (sub-lane k < n_base).  idx = position in the sequential
+// scan order (0..15 leg points, 16.. base points; tie-break), -1 = empty slot.
+#define GO2_SUB_CANDS 5
+struct SubCand { float pt[GO2_SUB_CANDS][4]; int32_t idx[GO2_SUB_CANDS]; int32_t body[GO2_SUB_CANDS]; };
+
+// per-leg constant table (one per leg index 0..3); plain floats/ints so it can be memcpy'd into LDS
 struct LegTab {
   float o1[3], o2[3], o3[3];        // joint origins in the parent link frame (hip origin is in the base frame)
   float body[4][10];                // hip, thigh, calf, foot: {m, h(3), J(6: xx,yy,zz,xy,xz,yz)} about the moving link origin, link axes
@@ -28,6 +35,7 @@ struct LegTab {
   int32_t n_base;
   int32_t body_index[4];            // hip, thigh, calf, foot body indices
   int32_t mass_ratio_index[4];      // index into link_mass_ratio[18] (= body index - 1)
+  SubCand cand[4];                  // the same candidates, dealt to the 4 sub-lanes
 };
 struct BaseTab {
   float m0, c0[3], Ic0[6];          // base body: mass, COM, inertia about COM
@@ -58,7 +66,9 @@ struct Go2Ptrs { GO2_PTRS_BODY() };
 struct Go2PtrsK { GO2_PTRS_BODY(GO2_GLOBAL_AS) };
 static_assert(sizeof(Go2PtrsK) == sizeof(Go2Ptrs), "same layout");
 #define GO2_GENERIC(T, ptr) ((T)(ptr))          /* explicit global -> generic cast for a callee that takes a plain pointer */
+#define GO2_AS1 GO2_GLOBAL_AS
 #else
+#define GO2_AS1
 typedef Go2Ptrs Go2PtrsK;
 #define GO2_GENERIC(T, ptr) (ptr)
 #endif

@@ -2,11 +2,11 @@
 //
 // Built two ways from this one source:
 //   hipcc --offload-arch=gfx950           -> libgo2sim_hip.so : THE PRODUCT.  One HIP kernel per env step
-//       (go2_step_kernel), 64-thread workgroups = 16 envs x 4 leg-lanes, robot tables staged in LDS,
-//       quad reductions with DPP, all per-env state field-major (SoA) in HBM.
-//   g++ -DGO2_EMU                          -> libgo2sim_emu.so : TEST-ONLY host emulation of the very same
-//       lane programs (4 structs per env, reductions as loops), so the kernel arithmetic can be checked
-//       against the oracle on a machine without a GPU.  Never loaded by the product (go2_rl_gym_amd/_lib.py
+//       (go2_step_kernel), 256-thread workgroups = 16 envs x (4 legs x 4 sub-lanes), one DPP row per env, robot tables
+//       staged in LDS, cross-lane sums / exchanges with DPP, all per-env state field-major (SoA) in HBM.
+//   g++ -DGO2_EMU                          -> libgo2sim_emu.so : TEST-ONLY host emulation: the very same kernel body
+//       (go2_step_body) run lane by lane as fibres with the cross-lane primitives as rendezvous (go2_xlane.h), so the
+//       kernel arithmetic can be checked against the oracle on a machine without a GPU.  Never loaded by the product (go2_rl_gym_amd/_lib.py
 //       accepts only a library whose go2sim_is_device_library() is 1).
 #include <math.h>
 #include <stdint.h>
@@ -18,6 +18,7 @@
 #include "../../include/go2sim.h"
 #include "../../include/go2sim_defaults.h"
 #include "../../include/go2sim_rng.h"
+#define GO2_XLANE_IMPLEMENTATION
 #include "go2_lane.h"
 #include "go2_post.h"
 
@@ -35,18 +36,28 @@ static thread_local char g_err[512] = "";
 enum { MODE_PHYS = 1, MODE_POST = 2, MODE_RESET_ALL = 4 };
 
 // ------------------------------------------------------------------------------------------------------
-// the per-quad driver shared by the kernel and the emulation: everything except the cross-lane steps
+// the per-lane driver: ONE function body, go2_step_body<MODE>, is both the HIP kernel (go2_step_kernel) and — run lane by lane as
+// fibres (go2_xlane.h) — the host emulation; only the cross-lane primitives differ between the two builds.
+// Workgroup = 256 threads = 4 waves = 16 environments; one 16-lane DPP row = one environment, row lane = leg * 4 + sub.
 // ------------------------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GO2_ISA_MARKS)
+#define GO2_MARK(n) asm volatile("; GO2MARK " #n)
+#else
+#define GO2_MARK(n) do { } while (0)
+#endif
+#define GO2_WG_ENVS 16
+#define GO2_WG_THREADS (16 * GO2_WG_ENVS)
 // The lane context is kept as THREE separate objects (not one struct): the compiler's scalar-replacement pass gives up on a
 // single 2.4 KB aggregate with thousands of uses and would leave all of it in scratch memory.
 struct LaneAux { float kp[3], kd[3], q0[3], zoff[3], strength[3], act_new[3], act_old[3]; int start; };   // kp/kd: gain x per-env multiplier (loaded once, not per substep)
 #define LANE_PARAMS LegPhys& ph_, LegPost& po_, LaneAux& ax
-#define LANE_ARGS(i) c_ph[i], c_po[i], c_ax[i]
+struct Go2Shared { Go2Tables tab; Go2Step S; };   // LDS: robot link / collision tables (per-lane leg index -> ds_read), this step's scalars
 
-GO2_HD void lane_load_phys(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p, const Go2Launch& L, const Go2Step& S, const float* actions_in, int e, int lane) {
+GO2_HD void lane_load_phys(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p, const Go2Launch& L, const Go2Step& S, const float* actions_in, int e, int lane, int sub) {
   const int N = L.N;
   const LegTab& t = tab.leg[lane];
   LegPhys& ph = ph_;
+  ph.leg = lane; ph.sub = sub;
   ph.pw = v3(F2D(p.root, 0, e), F2D(p.root, 1, e), F2D(p.root, 2, e));
   ph.qx = F2D(p.root, 3, e); ph.qy = F2D(p.root, 4, e); ph.qz = F2D(p.root, 5, e); ph.qw = F2D(p.root, 6, e);
   ph.vw = v3(F2D(p.root, 7, e), F2D(p.root, 8, e), F2D(p.root, 9, e));
@@ -59,7 +70,7 @@ GO2_HD void lane_load_phys(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p,
     ax.zoff[j] = F2D(p.zero_off, d, e); ax.strength[j] = F2D(p.strength, d, e);
     float a = actions_in ? actions_in[(size_t)e * 12 + d] : F2D(p.actions, d, e);
     a = fminf(fmaxf(a, -cl), cl);                  // legged_robot.py:67-68
-    ax.act_new[j] = a; F2D(p.actions, d, e) = a;
+    ax.act_new[j] = a; if (sub == 0) F2D(p.actions, d, e) = a;      // (idempotent: a sub-lane that reads the clipped value back clips it to itself)
     ax.act_old[j] = F2D(p.last_actions, d, e);
     ph.lam_foot[0 + j] = F3D(p.foot_impulse, 4, lane, j, e);
   }
@@ -93,15 +104,16 @@ GO2_HD void quat_mul(const float* a, const float* b, float* o) {  // (x,y,z,w)
   o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
 }
 
-// after the last substep: forward kinematics at the new state, API tensors, PhysOut.  fbase = this lane's
-// contribution to the base / head contact forces (3 bodies x 3), to be quad-summed by the caller.
-GO2_HD void lane_finish_phys(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p, const Go2Launch& L, int e, int lane, float* fbase) {
+// after the last substep: forward kinematics at the new state, API tensors, PhysOut.  fbase = this leg's contribution to the base / head
+// contact forces (3 bodies x 3), to be summed over the legs by the caller.  Inside a leg's quad, sub-lane k writes the row of the leg's
+// body k (hip, thigh, calf, foot) of rigid_body_states / contact_forces; sub-lane 0 writes the leg's DOF state.
+GO2_HD void lane_finish_phys(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p, const Go2Launch& L, int e, int lane, int sub, float* fbase) {
   const int N = L.N;
   const LegTab& t = tab.leg[lane];
   LegPhys& ph = ph_; PhysOut& o = po_.o;
   M3 Rwb = quat_to_m3(ph.qx, ph.qy, ph.qz, ph.qw);
   V3 wb = mulT(Rwb, ph.ww), vb = mulT(Rwb, ph.vw);
-  float s1, c1, s2, c2, s3, c3; sincosf(ph.q[0], &s1, &c1); sincosf(ph.q[1], &s2, &c2); sincosf(ph.q[2], &s3, &c3);
+  float s1, c1, s2, c2, s3, c3; go2_sincos(ph.q[0], &s1, &c1); go2_sincos(ph.q[1], &s2, &c2); go2_sincos(ph.q[2], &s3, &c3);
   float c23 = c2 * c3 - s2 * s3, s23 = s2 * c3 + c2 * s3;
   M3 R1, R2, R3; R1.x = v3(1, 0, 0); R1.y = v3(0, c1, s1); R1.z = v3(0, -s1, c1);
   R2.x = c2 * R1.x - s2 * R1.z; R2.y = R1.y; R2.z = s2 * R1.x + c2 * R1.z;
@@ -112,51 +124,58 @@ GO2_HD void lane_finish_phys(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& 
   SV V0 = sv(wb, vb);
   SV V1 = V0 + ph.qd[0] * sv(a1, cross(p1, a1)), V2 = V1 + ph.qd[1] * sv(a2, cross(p2, a2)), V3l = V2 + ph.qd[2] * sv(a2, cross(p3, a2));
   V3 pf = p3 + mul(R3, v3(t.foot_off[0], t.foot_off[1], t.foot_off[2]));
-  V3 org[4] = {p1, p2, p3, pf}; SV vel[4] = {V1, V2, V3l, V3l};
   float qb[4] = {ph.qx, ph.qy, ph.qz, ph.qw}, qh[4], qt[4], qc[4];
-  float h1[4] = {sinf(0.5f * ph.q[0]), 0, 0, cosf(0.5f * ph.q[0])}, h2[4] = {0, sinf(0.5f * ph.q[1]), 0, cosf(0.5f * ph.q[1])}, h3[4] = {0, sinf(0.5f * ph.q[2]), 0, cosf(0.5f * ph.q[2])};
+  float hs1, hc1, hs2, hc2, hs3, hc3; go2_sincos(0.5f * ph.q[0], &hs1, &hc1); go2_sincos(0.5f * ph.q[1], &hs2, &hc2); go2_sincos(0.5f * ph.q[2], &hs3, &hc3);
+  float h1[4] = {hs1, 0, 0, hc1}, h2[4] = {0, hs2, 0, hc2}, h3[4] = {0, hs3, 0, hc3};
   quat_mul(qb, h1, qh); quat_mul(qh, h2, qt); quat_mul(qt, h3, qc);
-  const float* quats[4] = {qh, qt, qc, qc};
-  _Pragma("unroll") for (int k = 0; k < 4; ++k) {
-    int b = t.body_index[k];
-    V3 pos = ph.pw + mul(Rwb, org[k]);
-    V3 lv = mul(Rwb, vel[k].l + cross(vel[k].a, org[k])), av = mul(Rwb, vel[k].a);
-    float r13[13] = {pos.x, pos.y, pos.z, quats[k][0], quats[k][1], quats[k][2], quats[k][3], lv.x, lv.y, lv.z, av.x, av.y, av.z};
-    if (k == 3 || L.full_body_states) _Pragma("unroll") for (int i = 0; i < 13; ++i) F3D(p.rigid, 19, b, i, e) = r13[i];
-    if (k == 3) { o.foot_pos = pos; o.foot_vel = lv; }
+  {   // body `sub` of this leg: hip, thigh, calf, foot
+    const V3 org = sel(sub == 0, p1, sel(sub == 1, p2, sel(sub == 2, p3, pf)));
+    const SV vel = sv(sel(sub == 0, V1.a, sel(sub == 1, V2.a, V3l.a)), sel(sub == 0, V1.l, sel(sub == 1, V2.l, V3l.l)));
+    float qq[4];
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) qq[i] = sub == 0 ? qh[i] : (sub == 1 ? qt[i] : qc[i]);
+    const int b = t.body_index[0] + sub;
+    const V3 pos = ph.pw + mul(Rwb, org);
+    const V3 lv = mul(Rwb, vel.l + cross(vel.a, org)), av = mul(Rwb, vel.a);
+    const float r13[13] = {pos.x, pos.y, pos.z, qq[0], qq[1], qq[2], qq[3], lv.x, lv.y, lv.z, av.x, av.y, av.z};
+    if (sub == 3 || L.full_body_states) _Pragma("unroll") for (int i = 0; i < 13; ++i) F3D(p.rigid, 19, b, i, e) = r13[i];
   }
-  if (lane < 3 && L.full_body_states) {  // base, Head_upper, Head_lower rows
+  {   // the foot row is what post-physics reads: every sub-lane keeps it
+    const V3 pos = ph.pw + mul(Rwb, pf);
+    o.foot_pos = pos; o.foot_vel = mul(Rwb, V3l.l + cross(V3l.a, pf));
+  }
+  if (lane < 3 && sub == 0 && L.full_body_states) {  // base, Head_upper, Head_lower rows
     V3 off = v3(tab.base.body_off[lane][0], tab.base.body_off[lane][1], tab.base.body_off[lane][2]);
     V3 pos = ph.pw + mul(Rwb, off); V3 lv = mul(Rwb, vb + cross(wb, off));
     float r13[13] = {pos.x, pos.y, pos.z, ph.qx, ph.qy, ph.qz, ph.qw, lv.x, lv.y, lv.z, ph.ww.x, ph.ww.y, ph.ww.z};
     _Pragma("unroll") for (int i = 0; i < 13; ++i) F3D(p.rigid, 19, lane, i, e) = r13[i];
   }
-  // contact forces of this leg's bodies; base/head parts go through the quad sum
+  // contact forces of this leg's bodies; base/head parts go through the leg sum
   V3 zero = v3(0, 0, 0);
   o.Fhip = sel(ph.other_body == t.body_index[0], ph.force_other, zero);
   o.Fthigh = sel(ph.other_body == t.body_index[1], ph.force_other, zero);
   o.Fcalf = sel(ph.other_body == t.body_index[2], ph.force_other, zero);
   o.Ffoot = ph.force_foot;
-  V3 fl[4] = {o.Fhip, o.Fthigh, o.Fcalf, o.Ffoot};
-  _Pragma("unroll") for (int k = 0; k < 4; ++k) { int b = t.body_index[k]; F3D(p.contact, 19, b, 0, e) = fl[k].x; F3D(p.contact, 19, b, 1, e) = fl[k].y; F3D(p.contact, 19, b, 2, e) = fl[k].z; }
+  {
+    const V3 f = sel(sub == 0, o.Fhip, sel(sub == 1, o.Fthigh, sel(sub == 2, o.Fcalf, o.Ffoot)));
+    const int b = t.body_index[0] + sub; F3D(p.contact, 19, b, 0, e) = f.x; F3D(p.contact, 19, b, 1, e) = f.y; F3D(p.contact, 19, b, 2, e) = f.z;
+  }
   _Pragma("unroll") for (int b = 0; b < 3; ++b) { V3 f = sel(ph.other_body == b, ph.force_other, zero); fbase[3 * b] = f.x; fbase[3 * b + 1] = f.y; fbase[3 * b + 2] = f.z; }
   o.pw = ph.pw; o.qx = ph.qx; o.qy = ph.qy; o.qz = ph.qz; o.qw = ph.qw; o.vw = ph.vw; o.ww = ph.ww;
   _Pragma("unroll") for (int j = 0; j < 3; ++j) {
     int d = 3 * lane + j;
     o.q[j] = ph.q[j]; o.qd[j] = ph.qd[j]; o.tau[j] = ph.tau[j];
-    F2D(p.dof, d, e) = ph.q[j]; F2D(p.dof, 12 + d, e) = ph.qd[j]; F2D(p.torques, d, e) = ph.tau[j];
-    F3D(p.foot_impulse, 4, lane, j, e) = ph.lam_foot[j];
+    if (sub == 0) { F2D(p.dof, d, e) = ph.q[j]; F2D(p.dof, 12 + d, e) = ph.qd[j]; F2D(p.torques, d, e) = ph.tau[j]; F3D(p.foot_impulse, 4, lane, j, e) = ph.lam_foot[j]; }
   }
-  if (lane == 0) {
+  if (lane == 0 && sub == 0) {
     float r13[13] = {o.pw.x, o.pw.y, o.pw.z, o.qx, o.qy, o.qz, o.qw, o.vw.x, o.vw.y, o.vw.z, o.ww.x, o.ww.y, o.ww.z};
     _Pragma("unroll") for (int k = 0; k < 13; ++k) F2D(p.root, k, e) = r13[k];
   }
 }
-// fbase_sum = quad-summed base/head forces
-GO2_HD void lane_store_base_forces(LANE_PARAMS, const Go2PtrsK& p, const Go2Launch& L, int e, int lane, const float* fbase_sum) {
+// fbase_sum = leg-summed base/head forces
+GO2_HD void lane_store_base_forces(LANE_PARAMS, const Go2PtrsK& p, const Go2Launch& L, int e, int lane, int sub, const float* fbase_sum) {
   const int N = L.N;
   po_.o.Fbase = v3(fbase_sum[0], fbase_sum[1], fbase_sum[2]);
-  if (lane < 3) for (int k = 0; k < 3; ++k) F3D(p.contact, 19, lane, k, e) = fbase_sum[3 * lane + k];
+  if (lane < 3 && sub == 0) for (int k = 0; k < 3; ++k) F3D(p.contact, 19, lane, k, e) = fbase_sum[3 * lane + k];
 }
 // post-only entry: rebuild PhysOut from the API tensors
 GO2_HD void lane_load_physout(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p, const Go2Launch& L, int e, int lane) {
@@ -171,16 +190,18 @@ GO2_HD void lane_load_physout(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK&
   o.foot_pos = v3(F3D(p.rigid, 19, fb, 0, e), F3D(p.rigid, 19, fb, 1, e), F3D(p.rigid, 19, fb, 2, e));
   o.foot_vel = v3(F3D(p.rigid, 19, fb, 7, e), F3D(p.rigid, 19, fb, 8, e), F3D(p.rigid, 19, fb, 9, e));
 }
-GO2_HD void lane_init_post(LANE_PARAMS, const uint8_t* codes, const Go2PtrsK* p, const Go2Launch* L, const Go2Step* S, int e, int lane) {
+GO2_HD void lane_init_post(LANE_PARAMS, const uint8_t* codes, const Go2PtrsK* p, const Go2Launch* L, const Go2Step* S, int e, int lane, int sub) {
   po_.codes = codes; po_.cg = -1; po_.cw0 = po_.cw1 = po_.cw2 = po_.cw3 = 0u;
-  po_.e = e; po_.lane = lane; po_.N = L->N; po_.P = p; po_.L = L; po_.S = S;
+  po_.e = e; po_.lane = lane; po_.sub = sub; po_.lane16 = lane * 4 + sub; po_.N = L->N; po_.P = p; po_.L = L; po_.S = S;
+  po_.skip_contact_filters = false; po_.new_lc = po_.new_lc2 = 0; po_.new_fat = 0.f;
 }
 // reset_idx(all envs) without a step (base_task.py:82-84): postB's reset branch with reset forced on
-GO2_HD void lane_reset_all(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p, const Go2Launch& L, const Go2Step& S, int e, int lane) {
+GO2_HD void lane_reset_all(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p, const Go2Launch& L, const Go2Step& S, int e, int lane, int sub) {
   const int N = L.N;
   lane_load_physout(ph_, po_, ax, tab, p, L, e, lane);
-  lane_init_post(ph_, po_, ax, tab.slot_code, &p, &L, &S, e, lane);
+  lane_init_post(ph_, po_, ax, tab.slot_code, &p, &L, &S, e, lane, sub);
   LegPost& po = po_;
+  po.skip_contact_filters = true;
   // load what postA would have loaded, without advancing any clock
   po.ep_len = p.ep_len[e]; po.timer = p.cmd_timer[e];
   _Pragma("unroll") for (int k = 0; k < 4; ++k) po.cmd[k] = F2D(p.commands, k, e);
@@ -188,109 +209,103 @@ GO2_HD void lane_reset_all(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p,
   po.stop_heading = p.stop_heading[e]; po.last_limit = p.last_is_limit_vel[e];
   _Pragma("unroll") for (int j = 0; j < 3; ++j) { int d = 3 * lane + j; po.act[j] = 0; po.last_act[j] = 0; po.llast_act[j] = F2D(p.last_last_actions, d, e); po.last_dv[j] = 0; }
   po.max_move = p.max_move[e];
+  po.to_timer = L.turn_over ? p.to_timer[e] : 0.f;
   po.load_terrain_fields();
 }
 
 // ------------------------------------------------------------------------------------------------------
-#ifndef GO2_EMU
-__device__ __forceinline__ float quad_sum(float x) {
-  // DPP quad_perm [1,0,3,2] then [2,3,0,1]: both adds are commutative pairs, so the 4 lanes get bit-identical sums
-  float y = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));
-  return y + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(y), 0x4E, 0xF, 0xF, true));
-}
-
-// value of quad lane T in all 4 lanes of the quad (one DPP quad_perm move)
-template <int T>
-__device__ __forceinline__ float quad_bcast(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), T | (T << 2) | (T << 4) | (T << 6), 0xF, 0xF, true));
-}
-// one Gauss-Seidel turn: leg T of every quad sweeps its rows; its base-velocity delta reaches the other three legs by a quad
-// broadcast (they contributed exactly zero, so this equals the quad sum the oracle's formulation implies)
-template <int T>
-__device__ __forceinline__ void gs_turn(LegPhys& ph, int lane, bool any_foot, bool any_other, bool any_lim) {
-  float dw[6];
-  ph.sweep(lane == T ? 1.f : 0.f, dw, any_foot, any_other, any_lim);
-  const float others = lane == T ? 0.f : 1.f;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) dw[i] = others * quad_bcast<T>(dw[i]);
-  ph.add_delta(dw);
-}
-
+// The kernel body.  `sh` is the workgroup's LDS block; bid / tid = blockIdx.x / threadIdx.x.
 template <int MODE>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) go2_step_kernel(const Go2DevBlock* __restrict__ blk, const float* __restrict__ actions_in, int initial_reset) {
-  __shared__ Go2Tables tab;   // robot link / collision tables staged in LDS (per-lane leg index -> ds_read)
-  __shared__ Go2Step S;       // this step's scalars, computed on device from the device-resident counters
+GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, const float* __restrict__ actions_in, int initial_reset, int bid, int tid) {
   const Go2PtrsK& p = *(const Go2PtrsK*)&blk->p; const Go2Launch& L = blk->L;   // uniform addresses -> scalar loads; pointers typed global
   {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.tables); uint32_t* dst = reinterpret_cast<uint32_t*>(&tab);
-    for (int i = threadIdx.x; i < (int)(sizeof(Go2Tables) / 4); i += 64) dst[i] = src[i];
-    if (threadIdx.x == 0) go2_step_scalars(L, blk->dyn, p.inj_storage, blk->dyn.common_step_counter + ((MODE & MODE_POST) ? 1 : 0), initial_reset, &S);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(GO2_GENERIC(const Go2Tables*, p.tables)); uint32_t* dst = reinterpret_cast<uint32_t*>(&sh.tab);
+    for (int i = tid; i < (int)(sizeof(Go2Tables) / 4); i += GO2_WG_THREADS) dst[i] = src[i];
+    if (tid == 0) go2_step_scalars(L, blk->dyn, GO2_GENERIC(const float*, p.inj_storage), blk->dyn.common_step_counter + ((MODE & MODE_POST) ? 1 : 0), initial_reset, &sh.S);
   }
-  __syncthreads();
-  const int e = blockIdx.x * 16 + (threadIdx.x >> 2), lane = threadIdx.x & 3;
-  if (e >= L.N) return;   // whole quads leave together
-  long long* dbg = p.dbg_clock ? p.dbg_clock + (size_t)blockIdx.x * 16 : nullptr;   // optional phase timestamps (tools/kbench.py)
-#define STAMP(k) do { if (dbg && threadIdx.x == 0) dbg[k] = wall_clock64(); } while (0)
+  xl::sync();
+  const Go2Tables& tab = sh.tab; const Go2Step& S = sh.S;
+  const int e = bid * GO2_WG_ENVS + (tid >> 4), lane = (tid >> 2) & 3, sub = tid & 3;
+  if (e >= L.N) return;   // whole rows (environments) leave together
+#if defined(__HIP_DEVICE_COMPILE__)
+  long long* dbg = p.dbg_clock ? (long long*)p.dbg_clock + (size_t)(bid * 4 + (tid >> 6)) * 8 : nullptr;   // optional phase timestamps per wave (tools/kbench.py)
+#define STAMP(k) do { if (dbg && (tid & 63) == 0) dbg[k] = wall_clock64(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
   STAMP(0);
   LegPhys ph_; LegPost po_; LaneAux ax;
   const LegTab& t = tab.leg[lane];
   if (MODE & MODE_RESET_ALL) {
-    lane_reset_all(ph_, po_, ax, tab, p, L, S, e, lane);
+    lane_reset_all(ph_, po_, ax, tab, p, L, S, e, lane, sub);
     float red[GO2_POST_PARTIALS];
 #pragma unroll
     for (int i = 0; i < GO2_POST_PARTIALS; ++i) red[i] = 0.f;
     po_.reset = 1; po_.time_out = 0;
     po_.blv = v3(0, 0, 0); po_.bav = v3(0, 0, 0); po_.pg = v3(0, 0, -1); po_.rpy[0] = po_.rpy[1] = po_.rpy[2] = 0.f;
     po_.own_f2b = 0.f; po_.own_fvel2 = 0.f;
+    (void)xl::leg_sum(0.f);    // rendezvous of the row: every lane has read the replicated fields before lane 0 rewrites them
     po_.postB(t, red, 0.f);
     return;
   }
   if (MODE & MODE_PHYS) {
-    lane_load_phys(ph_, po_, ax, tab, p, L, S, actions_in, e, lane);
+    lane_load_phys(ph_, po_, ax, tab, p, L, S, actions_in, e, lane, sub);
     STAMP(1);
-    for (int sub = 0; sub < L.decimation; ++sub) {
-      const bool old = L.rand_delay && sub < ax.start;
+    for (int sb = 0; sb < L.decimation; ++sb) {
+      const bool old = L.rand_delay && sb < ax.start;
       const float a[3] = {old ? ax.act_old[0] : ax.act_new[0], old ? ax.act_old[1] : ax.act_new[1], old ? ax.act_old[2] : ax.act_new[2]};
+      GO2_MARK(10);
       ph_.pd(t, L, a, ax.kp, ax.kd, ax.q0, ax.zoff, ax.strength);
       float part[GO2_QUAD_PARTIALS];
       ph_.phaseA(t, L, part);
+      GO2_MARK(11);
 #pragma unroll
-      for (int i = 0; i < GO2_QUAD_PARTIALS; ++i) part[i] = quad_sum(part[i]);
+      for (int i = 0; i < GO2_QUAD_PARTIALS; ++i) part[i] = xl::leg_sum(part[i]);
+      GO2_MARK(12);
       ph_.phaseB(L, part);
-      float dw[6];
-      ph_.phaseC(t, L, p.hf, dw);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) dw[i] = quad_sum(dw[i]);
-      ph_.set_w(dw);
+      GO2_MARK(13);
+      ph_.phaseC(t, L, GO2_GENERIC(const int16_t*, p.hf));
+      GO2_MARK(14);
       // wave-wide row-group activity (ballots -> scalar branches): typically only the foot contacts are live
-      const bool any_foot = __any(ph_.has_foot()), any_other = __any(ph_.has_other()), any_lim = __any(ph_.has_limit());
+      const bool any_foot = xl::any(ph_.has_foot()), any_other = xl::any(ph_.has_other()), any_lim = xl::any(ph_.has_limit());
       for (int it = 0; it < L.solver_iterations; ++it) {
-        gs_turn<0>(ph_, lane, any_foot, any_other, any_lim); gs_turn<1>(ph_, lane, any_foot, any_other, any_lim);
-        gs_turn<2>(ph_, lane, any_foot, any_other, any_lim); gs_turn<3>(ph_, lane, any_foot, any_other, any_lim);
+        ph_.gs_turn(0, any_foot, any_other, any_lim); ph_.gs_turn(1, any_foot, any_other, any_lim);
+        ph_.gs_turn(2, any_foot, any_other, any_lim); ph_.gs_turn(3, any_foot, any_other, any_lim);
       }
+      GO2_MARK(15);
+      ph_.gather_solution();
       ph_.phaseD(t, L);
+      GO2_MARK(16);
     }
     STAMP(2);
     float fb[9];
-    lane_finish_phys(ph_, po_, ax, tab, p, L, e, lane, fb);
+    lane_finish_phys(ph_, po_, ax, tab, p, L, e, lane, sub, fb);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) fb[i] = quad_sum(fb[i]);
-    lane_store_base_forces(ph_, po_, ax, p, L, e, lane, fb);
+    for (int i = 0; i < 9; ++i) fb[i] = xl::leg_sum(fb[i]);
+    lane_store_base_forces(ph_, po_, ax, p, L, e, lane, sub, fb);
   } else {
     lane_load_physout(ph_, po_, ax, tab, p, L, e, lane);
   }
   STAMP(3);
   if (MODE & MODE_POST) {
-    lane_init_post(ph_, po_, ax, tab.slot_code, &p, &L, &S, e, lane);
+    lane_init_post(ph_, po_, ax, tab.slot_code, &p, &L, &S, e, lane, sub);
     float part[GO2_POST_PARTIALS];
     po_.postA(t, part);
     STAMP(4);
 #pragma unroll
-    for (int i = 0; i < GO2_POST_PARTIALS; ++i) part[i] = quad_sum(part[i]);
-    float fr = quad_sum(po_.regulation(part));
+    for (int i = 0; i < GO2_POST_PARTIALS; ++i) part[i] = xl::leg_sum(part[i]);
+    float fr = xl::leg_sum(po_.regulation(part));
     po_.postB(t, part, fr);
     STAMP(5);
   }
+#undef STAMP
+}
+
+#ifndef GO2_EMU
+template <int MODE>
+__global__ void __launch_bounds__(GO2_WG_THREADS) go2_step_kernel(const Go2DevBlock* __restrict__ blk, const float* __restrict__ actions_in, int initial_reset) {
+  __shared__ Go2Shared sh;
+  go2_step_body<MODE>(sh, blk, actions_in, initial_reset, blockIdx.x, threadIdx.x);
 }
 
 // ---- test hooks (declared in include/go2sim.h under "test hooks"; no product path calls them) --------------------------------
@@ -306,7 +321,7 @@ __global__ void __launch_bounds__(64) go2_torque_trace_kernel(const Go2DevBlock*
   const int e = blockIdx.x * 16 + (threadIdx.x >> 2), lane = threadIdx.x & 3, N = L.N;
   if (e >= N) return;
   LegPhys ph_; LegPost po_; LaneAux ax;
-  lane_load_phys(ph_, po_, ax, tab, p, L, S, actions_raw, e, lane);
+  lane_load_phys(ph_, po_, ax, tab, p, L, S, actions_raw, e, lane, 0);
   const LegTab& t = tab.leg[lane];
   for (int sub = 0; sub < L.decimation; ++sub) {
     const bool old = L.rand_delay && sub < ax.start;
@@ -612,6 +627,21 @@ static void fill_tables(Go2Tables* T) {
     for (int i = 0; i < GO2_BASE_PTS; ++i) if ((i & 3) == l) {
       int k = t.n_base++; for (int a = 0; a < 3; ++a) t.base_pt[k][a] = (float)kBase[i].c[a]; t.base_pt[k][3] = (float)kBase[i].r; t.base_body[k] = kBase[i].body;
     }
+    // deal the candidates to the 4 sub-lanes: slots {thigh, thigh, calf, calf|hip, base} (go2_tables.h SubCand)
+    for (int sb = 0; sb < 4; ++sb) {
+      SubCand& sc = t.cand[sb];
+      const int leg_idx[4] = {GO2_N_HIP_PTS + sb, GO2_N_HIP_PTS + 4 + sb, GO2_N_HIP_PTS + GO2_N_THIGH_PTS + sb,
+                              sb < 2 ? GO2_N_HIP_PTS + GO2_N_THIGH_PTS + 4 + sb : sb - 2};
+      for (int k = 0; k < 4; ++k) {
+        const int i = leg_idx[k];
+        for (int a = 0; a < 4; ++a) sc.pt[k][a] = t.other_pt[i][a];
+        sc.idx[k] = i; sc.body[k] = t.other_body[i];
+        const int want = k < 2 ? 2 : (k == 2 ? 3 : (sb < 2 ? 3 : 1));
+        if (t.other_link[i] != want) T->layout_ok = 0;
+      }
+      if (sb < t.n_base) { for (int a = 0; a < 4; ++a) sc.pt[4][a] = t.base_pt[sb][a]; sc.idx[4] = GO2_NLEG_OTHER + sb; sc.body[4] = t.base_body[sb]; }
+      else { for (int a = 0; a < 4; ++a) sc.pt[4][a] = 0.f; sc.idx[4] = -1; sc.body[4] = 0; }
+    }
   }
   T->base.m0 = (float)kMass[0];
   for (int k = 0; k < 3; ++k) T->base.c0[k] = (float)kCom[0][k];
@@ -821,59 +851,21 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
 int go2sim_get_buffers(Go2Sim* s, Go2SimBuffers* out) { if (!s || !out) FAIL(GO2SIM_EINVAL, "null argument"); *out = s->b; return 0; }
 
 #ifdef GO2_EMU
-static float quad_sum4(float a, float b, float c, float d) { return (a + b) + (c + d); }
+struct EmuArgs { Go2Shared* sh; const Go2DevBlock* blk; const float* actions; int initial_reset, bid, mode; };
+static void emu_thread(void* a_, int tid) {
+  EmuArgs& a = *(EmuArgs*)a_;
+  if (a.mode == MODE_RESET_ALL) go2_step_body<MODE_RESET_ALL>(*a.sh, a.blk, a.actions, a.initial_reset, a.bid, tid);
+  else if (a.mode == (MODE_PHYS | MODE_POST)) go2_step_body<MODE_PHYS | MODE_POST>(*a.sh, a.blk, a.actions, a.initial_reset, a.bid, tid);
+  else if (a.mode == MODE_PHYS) go2_step_body<MODE_PHYS>(*a.sh, a.blk, a.actions, a.initial_reset, a.bid, tid);
+  else go2_step_body<MODE_POST>(*a.sh, a.blk, a.actions, a.initial_reset, a.bid, tid);
+}
 static void emu_run(Go2Sim* s, int mode, const float* actions_in, int initial_reset, int counter_inc) {
   Go2DevBlock* blk = s->d_blk;
-  Go2Tables& tab = *s->d_tables; const Go2Ptrs& p = blk->p; const Go2Launch& L = blk->L;
-  Go2Step S; go2_step_scalars(L, blk->dyn, p.inj_storage, blk->dyn.common_step_counter + ((mode & MODE_POST) ? 1 : 0), initial_reset, &S);
-  for (int e = 0; e < L.N; ++e) {
-    static thread_local LegPhys c_ph[4]; static thread_local LegPost c_po[4]; static thread_local LaneAux c_ax[4];
-    if (mode & MODE_RESET_ALL) {
-      float red[GO2_POST_PARTIALS]; for (int i = 0; i < GO2_POST_PARTIALS; ++i) red[i] = 0.f;
-      for (int l = 0; l < 4; ++l) {
-        lane_reset_all(LANE_ARGS(l), tab, p, L, S, e, l); c_po[l].reset = 1; c_po[l].time_out = 0; c_po[l].blv = v3(0, 0, 0); c_po[l].bav = v3(0, 0, 0); c_po[l].pg = v3(0, 0, -1);
-        c_po[l].rpy[0] = c_po[l].rpy[1] = c_po[l].rpy[2] = 0.f; c_po[l].own_f2b = 0; c_po[l].own_fvel2 = 0;
-      }
-      for (int l = 0; l < 4; ++l) c_po[l].postB(tab.leg[l], red, 0.f);
-      continue;
-    }
-    if (mode & MODE_PHYS) {
-      for (int l = 0; l < 4; ++l) lane_load_phys(LANE_ARGS(l), tab, p, L, S, actions_in, e, l);
-      for (int sub = 0; sub < L.decimation; ++sub) {
-        float part[4][GO2_QUAD_PARTIALS], red[GO2_QUAD_PARTIALS], dw[4][6], tot[6];
-        for (int l = 0; l < 4; ++l) {
-          const bool old = L.rand_delay && sub < c_ax[l].start;
-          const float a[3] = {old ? c_ax[l].act_old[0] : c_ax[l].act_new[0], old ? c_ax[l].act_old[1] : c_ax[l].act_new[1], old ? c_ax[l].act_old[2] : c_ax[l].act_new[2]};
-          c_ph[l].pd(tab.leg[l], L, a, c_ax[l].kp, c_ax[l].kd, c_ax[l].q0, c_ax[l].zoff, c_ax[l].strength);
-          c_ph[l].phaseA(tab.leg[l], L, part[l]);
-        }
-        for (int i = 0; i < GO2_QUAD_PARTIALS; ++i) red[i] = quad_sum4(part[0][i], part[1][i], part[2][i], part[3][i]);
-        for (int l = 0; l < 4; ++l) { c_ph[l].phaseB(L, red); c_ph[l].phaseC(tab.leg[l], L, p.hf, dw[l]); }
-        for (int i = 0; i < 6; ++i) tot[i] = quad_sum4(dw[0][i], dw[1][i], dw[2][i], dw[3][i]);
-        for (int l = 0; l < 4; ++l) c_ph[l].set_w(tot);
-        for (int it = 0; it < L.solver_iterations; ++it)
-          for (int turn = 0; turn < 4; ++turn) {
-            for (int l = 0; l < 4; ++l) c_ph[l].sweep(l == turn ? 1.f : 0.f, dw[l]);
-            for (int i = 0; i < 6; ++i) tot[i] = quad_sum4(dw[0][i], dw[1][i], dw[2][i], dw[3][i]);
-            for (int l = 0; l < 4; ++l) c_ph[l].add_others(tot, dw[l]);
-          }
-        for (int l = 0; l < 4; ++l) c_ph[l].phaseD(tab.leg[l], L);
-      }
-      float fb[4][9], fbs[9];
-      for (int l = 0; l < 4; ++l) lane_finish_phys(LANE_ARGS(l), tab, p, L, e, l, fb[l]);
-      for (int i = 0; i < 9; ++i) fbs[i] = quad_sum4(fb[0][i], fb[1][i], fb[2][i], fb[3][i]);
-      for (int l = 0; l < 4; ++l) lane_store_base_forces(LANE_ARGS(l), p, L, e, l, fbs);
-    } else {
-      for (int l = 0; l < 4; ++l) lane_load_physout(LANE_ARGS(l), tab, p, L, e, l);
-    }
-    if (mode & MODE_POST) {
-      float part[4][GO2_POST_PARTIALS], red[GO2_POST_PARTIALS], fr[4];
-      for (int l = 0; l < 4; ++l) { lane_init_post(LANE_ARGS(l), tab.slot_code, &p, &L, &S, e, l); c_po[l].postA(tab.leg[l], part[l]); }
-      for (int i = 0; i < GO2_POST_PARTIALS; ++i) red[i] = quad_sum4(part[0][i], part[1][i], part[2][i], part[3][i]);
-      for (int l = 0; l < 4; ++l) fr[l] = c_po[l].regulation(red);
-      float frs = quad_sum4(fr[0], fr[1], fr[2], fr[3]);
-      for (int l = 0; l < 4; ++l) c_po[l].postB(tab.leg[l], red, frs);
-    }
+  const Go2Ptrs& p = blk->p; const Go2Launch& L = blk->L;
+  static thread_local Go2Shared sh;
+  for (int bid = 0; bid < (L.N + GO2_WG_ENVS - 1) / GO2_WG_ENVS; ++bid) {      // one workgroup at a time, its 256 threads as fibres
+    EmuArgs a = {&sh, blk, actions_in, initial_reset, bid, mode};
+    xl::run_group(GO2_WG_THREADS, emu_thread, &a);
   }
   if (mode != MODE_PHYS) {   // == go2_finish_kernel
     float* acc = p.ep_accum; float cnt = acc[GO2_NUM_REWARDS];
@@ -891,7 +883,7 @@ static int launch(Go2Sim* s, int mode, const float* actions_in, int initial_rese
   (void)stream; emu_run(s, mode, actions_in, initial_reset, counter_inc);
 #else
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid((s->N + 15) / 16), block(64);
+  dim3 grid((s->N + GO2_WG_ENVS - 1) / GO2_WG_ENVS), block(GO2_WG_THREADS);
   bool timed = s->timing != 0;
   { hipStreamCaptureStatus cs = hipStreamCaptureStatusNone; if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) { timed = false; capturing = true; } }
   if (timed) {
@@ -997,7 +989,7 @@ int go2sim_debug_torque_trace(Go2Sim* s, const float* actions_raw, const float* 
   Go2Step S; go2_step_scalars(L, blk->dyn, p.inj_storage, blk->dyn.common_step_counter, 0, &S);
   for (int e = 0; e < N; ++e) for (int lane = 0; lane < 4; ++lane) {
     static thread_local LegPhys ph_; static thread_local LegPost po_; static thread_local LaneAux ax;
-    lane_load_phys(ph_, po_, ax, tab, p, L, S, actions_raw, e, lane);
+    lane_load_phys(ph_, po_, ax, tab, p, L, S, actions_raw, e, lane, 0);
     for (int sub = 0; sub < L.decimation; ++sub) {
       const bool old = L.rand_delay && sub < ax.start;
       const float a[3] = {old ? ax.act_old[0] : ax.act_new[0], old ? ax.act_old[1] : ax.act_new[1], old ? ax.act_old[2] : ax.act_new[2]};

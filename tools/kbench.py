@@ -63,14 +63,14 @@ if __name__ == "__main__":
 
 
 def phase_clocks(steps=50, **kw):
-    """Per-workgroup phase timestamps (wall_clock64, 100 MHz) of the fused kernel: mean and max over the 256 waves."""
+    """Per-wave phase timestamps (wall_clock64, 100 MHz) of the fused kernel: mean and max over the waves."""
     s = DeviceSim(hip, num_envs=N, **kw)
     s.reset_all()
     a = torch.randn(N, 12, device="cuda:0") * 0.5
     for _ in range(80):
         hip.go2sim_step(s.h, C.c_void_p(a.data_ptr()), s._st())
-    nb = (N + 15) // 16
-    buf = torch.zeros(nb, 16, dtype=torch.int64, device="cuda:0")
+    nb = 4 * ((N + 15) // 16)               # one row of 8 stamps per WAVE (4 waves per 16-env workgroup)
+    buf = torch.zeros(nb, 8, dtype=torch.int64, device="cuda:0")
     hip.go2sim_debug_clock.argtypes = [C.c_void_p, C.c_void_p]
     hip.go2sim_debug_clock(s.h, C.c_void_p(buf.data_ptr()))
     acc = []
