@@ -12,7 +12,14 @@ ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "go2sim_impl.cpp")
 OUT = os.path.join(HERE, "libgo2sim_hip.so")
 # -ffast-math: rcp/rsq instead of IEEE division sequences in the 6x6 / 3x3 inverses (kernel 174 -> 148 us); parity tests hold
-EXTRA_FLAGS = os.environ.get("GO2_HIPCC_FLAGS", "-ffast-math").split()
+# -fno-slp-vectorize: REQUIRED for correctness with ROCm 7.2's hipcc — with the SLP vectorizer on (-O2 and up), the lane programs that
+#   mix packed-f32 candidates with DPP cross-lane moves (go2_lane.h: sliced rows / Gauss-Seidel) are miscompiled: contact impulses come
+#   out wrong by orders of magnitude on the device while -O1, or -O3 with this flag, or the same source on the host, agree with the
+#   oracle to 1e-5 (bisected on an MI355X, round 2: tools/debug_parity.py over -O1 / -O2 / -O3 x {slp, no-slp, noinline} builds).
+#   The GPU parity tests (tests/test_gpu_parity.py::test_one_step_parity_vs_oracle) are what catches a regression here.  Packed f32 VALU
+#   is no gain for this latency-bound kernel anyway.
+STRUCTURAL_FLAGS = ["-fno-slp-vectorize"]
+EXTRA_FLAGS = os.environ.get("GO2_HIPCC_FLAGS", "-ffast-math").split() + STRUCTURAL_FLAGS
 
 
 def _deps():
@@ -34,7 +41,7 @@ PRECISE_OUT = os.path.join(ROOT, "tests", "emu", "libgo2sim_hip_precise.so")
 def build_hip_precise(force=False):
     """TEST-ONLY second device build of the same source without -ffast-math (IEEE division / sqrt / no reassociation), next to the host
     emulation under tests/emu/: tests/test_gpu_parity.py uses it to separate fast-math artefacts from fp32 conditioning."""
-    return build_hip(force=force, out=PRECISE_OUT, flags=[])
+    return build_hip(force=force, out=PRECISE_OUT, flags=list(STRUCTURAL_FLAGS))
 
 
 def build_hip(force=False, verbose=False, out=OUT, flags=None):

@@ -161,7 +161,11 @@ struct LegPhys {
 
   // One constraint row from its joint-space row Jc (3) and its base-space row Ec (6): this sub-lane's slices of J = [Jc | G], Y = [Z | H]
   // (G = Ec - sum_j Jc_j T_j, Z = A^-1 Jc, H = Phi G), the inverse diagonal (quad sum of the slice products) and the free velocity.
+#ifdef GO2_DBG_NOINLINE_C
+  __device__ __attribute__((noinline)) void build_row(Row& r, const float* Jc, const SV& Ec, float cfm1, float bias, float lam0) {
+#else
   GO2_HD void build_row(Row& r, const float* Jc, const SV& Ec, float cfm1, float bias, float lam0) {
+#endif
     const SV G = Ec - (Jc[0] * T1 + Jc[1] * T2 + Jc[2] * T3);
     const bool joint = sub == 0 || sub == 3;
     const float x6[6] = {joint ? Jc[0] : G.a.x, joint ? Jc[1] : G.a.y, joint ? Jc[2] : G.a.z, joint ? 0.f : G.l.x, joint ? 0.f : G.l.y, joint ? 0.f : G.l.z};
@@ -323,7 +327,11 @@ struct LegPhys {
   // One Gauss-Seidel turn of leg T: its rows are visited in the fixed order foot (n, t), other (n, t), limits; then the base-twist
   // slices it has changed reach the other three legs (they contributed nothing during the turn).  do_* are WAVE-UNIFORM hints: false
   // means no lane of the wave has such a row active this substep, so the group is skipped as a whole (an inactive row moves nothing).
+#ifdef GO2_DBG_NOINLINE_GS
+  __device__ __attribute__((noinline)) void gs_turn(int T, bool do_foot, bool do_other, bool do_lim) {
+#else
   GO2_HD void gs_turn(int T, bool do_foot, bool do_other, bool do_lim) {
+#endif
     const float on = leg == T ? 1.f : 0.f;
     if (do_foot) sweep_slot(foot, on * act_foot, mu);
     if (do_other) sweep_slot(other, on * act_other, mu);

@@ -23,10 +23,15 @@
 #if defined(__HIP_DEVICE_COMPILE__)
 // ------------------------------------------------------------------------------------------------ device
 namespace xl {
+#ifdef GO2_DBG_NOINLINE_DPP
+#define GO2_DPP_INLINE __attribute__((noinline))
+#else
+#define GO2_DPP_INLINE __forceinline__
+#endif
 template <int CTRL>
-__device__ __forceinline__ float dpp(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true)); }
+__device__ GO2_DPP_INLINE float dpp(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true)); }
 template <int CTRL>
-__device__ __forceinline__ int dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
+__device__ GO2_DPP_INLINE int dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
 template <int A, int B, int C_, int D>
 __device__ __forceinline__ float quad_perm(float x) { return dpp<A | (B << 2) | (C_ << 4) | (D << 6)>(x); }
 template <int A, int B, int C_, int D>
@@ -39,9 +44,27 @@ template <int K>
 __device__ __forceinline__ float row_bcast(float x) { return dpp<0x150 + K>(x); }
 template <int K>
 __device__ __forceinline__ int row_bcast_i(int x) { return dpp_i<0x150 + K>(x); }
+#ifdef GO2_DBG_NOSKIP
+__device__ __forceinline__ bool any(bool p) { return true; }
+#else
 __device__ __forceinline__ bool any(bool p) { return __any(p); }
+#endif
 __device__ __forceinline__ void sync() { __syncthreads(); }
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+}  // namespace xl
+#elif defined(__HIPCC__)
+// ------------------------------------------------------------------------------------------------ host pass of a HIP compilation
+// (the kernel body is a __host__ __device__ function, so its host instantiation must parse; it is never executed in the device library)
+namespace xl {
+template <int A, int B, int C_, int D> __host__ __device__ inline float quad_perm(float x) { return x; }
+template <int A, int B, int C_, int D> __host__ __device__ inline int quad_perm_i(int x) { return x; }
+template <int N> __host__ __device__ inline float row_ror(float x) { return x; }
+template <int N> __host__ __device__ inline float row_shr(float x) { return x; }
+template <int K> __host__ __device__ inline float row_bcast(float x) { return x; }
+template <int K> __host__ __device__ inline int row_bcast_i(int x) { return x; }
+__host__ __device__ inline bool any(bool p) { return p; }
+__host__ __device__ inline void sync() {}
+__host__ __device__ inline int lane_id() { return 0; }
 }  // namespace xl
 #else
 // ------------------------------------------------------------------------------------------------ host: fibres
@@ -183,8 +206,8 @@ inline void sync() {
 #endif
 
 // ---- compositions (same code on both builds) ------------------------------------------------------------------------------------
-#if defined(__HIP_DEVICE_COMPILE__)
-#define GO2_XL __device__ __forceinline__
+#if defined(__HIPCC__)
+#define GO2_XL __host__ __device__ __forceinline__
 #else
 #define GO2_XL inline
 #endif

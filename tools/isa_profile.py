@@ -4,7 +4,7 @@ instructions between them.  No GPU needed.   python tools/isa_profile.py [extra 
 import collections, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = "/tmp/go2_isa.s"
-subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffast-math", "-DGO2_ISA_MARKS", "-S", "--cuda-device-only", "-o", out,
+subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffast-math", "-fno-slp-vectorize", "-DGO2_ISA_MARKS", "-S", "--cuda-device-only", "-o", out,
                 os.path.join(ROOT, "go2_rl_gym_amd", "csrc", "go2sim_impl.cpp")] + sys.argv[1:], check=True, stderr=subprocess.DEVNULL)
 s = open(out).read()
 m = re.search(r'^_Z15go2_step_kernelILi3EEvPK11Go2DevBlockPKfi:.*?\n(.*?)s_endpgm', s, re.S | re.M)
