@@ -272,8 +272,8 @@ struct LegPhys {
       // rows only if some lane of the wave has a candidate inside the contact margin this substep (wave-uniform branch; an inactive
       // slot's rows are never visited by the solver, so skipping their construction changes no result)
       act_other = best < L.contact_offset ? 1.f : 0.f; o_n = bn; o_t1 = v3(1, 0, 0); o_t2 = v3(0, 1, 0);
+      _Pragma("unroll") for (int a = 0; a < 3; ++a) other[a] = Row{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0.f, 0.f, 0.f};
       if (xl::any(act_other > 0.f)) build_slot(other, &act_other, &o_n, &o_t1, &o_t2, L, best, bcb, brad, blink, bn, false);
-      else { _Pragma("unroll") for (int a = 0; a < 3; ++a) other[a].lam = 0.f; }
     }
     // joint limits
     {
@@ -284,7 +284,7 @@ struct LegPhys {
         float glo = q[j] - t.lim_lo[j], ghi = t.lim_hi[j] - q[j];
         sgn[j] = 0.f; gap[j] = 0.f;
         if (glo < L.limit_margin) { sgn[j] = 1.f; gap[j] = glo; } else if (ghi < L.limit_margin) { sgn[j] = -1.f; gap[j] = ghi; }
-        act_lim[j] = sgn[j] != 0.f ? 1.f : 0.f; lim[j].lam = 0.f;
+        act_lim[j] = sgn[j] != 0.f ? 1.f : 0.f; lim[j] = Row{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0.f, 0.f, 0.f};
       }
       if (xl::any(act_lim[0] + act_lim[1] + act_lim[2] > 0.f))
 #pragma unroll

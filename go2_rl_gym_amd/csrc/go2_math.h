@@ -17,6 +17,13 @@
 #define GO2_HD inline
 #endif
 
+// static-profile markers (tools/isa_profile.py): comments in the ISA, nothing at run time
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GO2_ISA_MARKS)
+#define GO2_MARK(n) asm volatile("; GO2MARK " #n)
+#else
+#define GO2_MARK(n) do { } while (0)
+#endif
+
 // ---- individually rounded fp32 operations -------------------------------------------------------------------------------
 // INDEX arithmetic that the reference does in eager torch (one correctly rounded IEEE operation per tensor op) must come out
 // bit-identical here: a sample that lands an ulp on the other side of a cell boundary reads a different height.  The device build

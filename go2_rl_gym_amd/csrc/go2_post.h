@@ -77,19 +77,29 @@ struct LegPost {
   uint8_t reset, time_out;
   float act[3], last_act[3], llast_act[3], last_dv[3];
 
-  // Uniform `slot` of this env-step (contract: include/go2sim_rng.h).  Slots a lane consumes together share a Philox group and
-  // are requested back to back, so a one-entry group cache turns ~10 Philox calls into ~2-4; the hit/miss pattern is the same
-  // in every lane of the wave (the group index differs per lane, the sequence does not), so the refill branch is uniform.
-  const uint8_t* codes; int cg; uint32_t cw0, cw1, cw2, cw3;
-  GO2_HD float uni(int slot) {
+  // Uniform `slot` of this env-step (contract: include/go2sim_rng.h: slot -> (Philox group, word)).  The 16 lanes of an environment
+  // share ONE table of drawn groups in LDS (uc: [GO2_NUM_GROUPS][4] floats of this env): a group is drawn by exactly one lane — fill()
+  // deals up to 16 consecutive groups to the 16 lanes, one Philox call each — and read by whichever lane consumes one of its slots.
+  // The per-step groups (action delay, observation noise) are drawn when the kernel starts; the reset / resample / push groups where
+  // those (per-environment, hence row-uniform) branches are taken.
+  const GO2_AS3 uint8_t* codes; GO2_AS3 float (*uc)[4];      // both live in LDS (ds_read / ds_write, not flat accesses)
+  GO2_HD float uni(int slot) const {
     if (S->injected) return S->injected[(size_t)e * GO2_NUM_UNIFORMS + slot];
-    const int code = codes[slot], g = code >> 2, w = code & 3;
-    if (g != cg) {
-      uint32_t r[4];
-      philox4x32_10((uint32_t)(L->env_offset + e), (uint32_t)g, S->step_lo, S->step_hi, L->seed_lo, L->seed_hi, r);
-      cg = g; cw0 = r[0]; cw1 = r[1]; cw2 = r[2]; cw3 = r[3];
+    const int code = codes[slot];
+    return uc[code >> 2][code & 3];
+  }
+  GO2_HD void draw_group(int g) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)(L->env_offset + e), (uint32_t)g, S->step_lo, S->step_hi, L->seed_lo, L->seed_hi, r);
+    uc[g][0] = u01_from_bits(r[0]); uc[g][1] = u01_from_bits(r[1]); uc[g][2] = u01_from_bits(r[2]); uc[g][3] = u01_from_bits(r[3]);
+  }
+  // groups g0 .. g0+n-1 (n <= 16), lane k of the row draws group g0+k; `extra` >= 0: one more group for lane n.  Called by all 16 lanes.
+  GO2_HD void fill(int g0, int n, int extra = -1) {
+    if (!S->injected) {
+      if (lane16 < n) draw_group(g0 + lane16);
+      else if (lane16 == n && extra >= 0) draw_group(extra);
     }
-    return u01_from_bits(w == 0 ? cw0 : (w == 1 ? cw1 : (w == 2 ? cw2 : cw3)));
+    xl::row_sync();
   }
   GO2_HD static float urange(float u, float lo, float hi) { return (hi - lo) * u + lo; }
   GO2_HD void cmd_range(int which, float* lo, float* hi) const {  // env_command_ranges (:861-907)
@@ -115,10 +125,12 @@ struct LegPost {
       float vlow = fmaxf(remaining / ((L->max_episode_length - epl + 1e-9f) * L->dt), 0.f);
       cmd[0] = sample_disjoint(uni(U + 0), vlow, xl, xh);
       cmd[1] = sample_disjoint(uni(U + 1), vlow, yl, yh);
-      if (L->heading_command) cmd[3] = urange(uni(U + 2), hl, hh); else cmd[2] = urange(uni(U + 2), wl, wh);
+      { const float u2 = uni(U + 2), c3 = urange(u2, hl, hh), c2 = urange(u2, wl, wh);      // (selects, not `if (..) cmd[3] = .. else cmd[2] = ..`: a
+        cmd[3] = L->heading_command ? c3 : cmd[3]; cmd[2] = L->heading_command ? cmd[2] : c2; }  //  conditional INDEX would put cmd[] in scratch memory)
     } else {
       cmd[0] = xl + uni(U + 0) * (xh - xl); cmd[1] = yl + uni(U + 1) * (yh - yl);
-      if (L->heading_command) cmd[3] = hl + uni(U + 2) * (hh - hl); else cmd[2] = wl + uni(U + 2) * (wh - wl);
+      { const float u2 = uni(U + 2), c3 = hl + u2 * (hh - hl), c2 = wl + u2 * (wh - wl);
+        cmd[3] = L->heading_command ? c3 : cmd[3]; cmd[2] = L->heading_command ? cmd[2] : c2; }
       if (!(sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]) > 0.2f)) { cmd[0] = 0; cmd[1] = 0; }
     }
     float p = uni(U + 3), minp = 0.f, maxp = 0.f;
@@ -208,7 +220,7 @@ struct LegPost {
     load_terrain_fields();
     float mm = fmaxf(p.max_move[e], sqrtf((o.pw.x - org_x) * (o.pw.x - org_x) + (o.pw.y - org_y) * (o.pw.y - org_y)));
     // _post_physics_step_callback (:404-421)
-    if (timer <= 0.f && (float)ep_len < c.max_episode_length - 1.f) resample(GO2_U_RSA);
+    if (timer <= 0.f && (float)ep_len < c.max_episode_length - 1.f) { fill(1, 2); resample(GO2_U_RSA); }      // (per-env branch: the whole row takes it)
     if (c.heading_command && !stop_heading) {
       V3 fw = quat_apply(qx, qy, qz, qw, v3(1, 0, 0)); float heading = atan2f(fw.y, fw.x);
       float a = fmodf(cmd[3] - heading, 6.28318530718f); if (a < 0) a += 6.28318530718f; if (a > 3.14159265359f) a -= 6.28318530718f;
@@ -351,10 +363,12 @@ struct LegPost {
     if (c.rew_on[GO2_REW_ACTION_SMOOTHNESS])
       _Pragma("unroll") for (int j = 0; j < 3; ++j) llast_act[j] = last_act[j];       // :1378 (not zeroed on reset, App. E.9)
 
+    GO2_MARK(23);
     // ---- reset_idx (:180-245) ---------------------------------------------------------------------
     float ox = org_x, oy = org_y, oz = org_z;
     if (reset) {
-      // field-major request order (strength x3, offset x3, kp x3, kd x3): 3 Philox groups per lane (go2sim_rng.h)
+      fill(3, 16);                                  // per-DOF reset groups of the 4 legs (go2sim_rng.h: group 3 + 4 leg + g)
+      fill(19, 5, c.turn_over ? 41 : -1);           // terrain / yaw / xy, root velocity (2), resample inside reset (2) [, turn-over]
       // the four per-DOF tables: sub-lane k of a leg draws and writes table k (strength, offset, kp, kd) for the leg's 3 joints
       {
         const int tb = sub == 0 ? GO2_U_RESET_STRENGTH : (sub == 1 ? GO2_U_RESET_OFFSET : (sub == 2 ? GO2_U_RESET_KP : GO2_U_RESET_KD));
@@ -419,35 +433,46 @@ struct LegPost {
 #endif
       }
     }
+    GO2_MARK(24);
     // _push_robots (:709-724): episode clock multiple of the push interval (a fresh reset is pushed at once, App. E.4)
     if (c.push_robots && !S->initial_reset && (ep_len % c.push_interval == 0)) {
+      fill(24, 2);
       o.vw.x = urange(uni(GO2_U_PUSH), -c.push_xy, c.push_xy); o.vw.y = urange(uni(GO2_U_PUSH + 1), -c.push_xy, c.push_xy);
       o.ww = v3(urange(uni(GO2_U_PUSH + 2), -c.push_ang, c.push_ang), urange(uni(GO2_U_PUSH + 3), -c.push_ang, c.push_ang), urange(uni(GO2_U_PUSH + 4), -c.push_ang, c.push_ang));
     }
+    GO2_MARK(25);
     // ---- Go2Robot.compute_observations (go2_env.py:23-53) + clip (:96-99) -----------------------------
+    // Every lane writes a share: sub-lanes 0 / 1 / 2 of a leg its joints' position / velocity / action entries (actor rows with noise,
+    // critic rows without) plus the critic-only torque / acceleration / foot-force entries, sub-lane 3 of legs 0 / 1 / 2 the base angular
+    // velocity / gravity / command triples, sub-lane 3 of leg 3 the critic's base linear velocity; the 187 height entries are dealt round
+    // the 16 lanes.  The noise uniforms were drawn at kernel start, one Philox group per lane.
     float cl = c.clip_obs;
     float* ob = p.obs + (size_t)e * GO2_NUM_OBS; float* pv = p.priv + (size_t)e * GO2_NUM_PRIV_OBS;
 #define CLIP(x) fminf(fmaxf((x), -cl), cl)
-#define NOISE(i) ((c.add_noise && c.noise_vec[(i)] != 0.f) ? (2.f * uni(GO2_U_NOISE + (i)) - 1.f) * c.noise_vec[(i)] : 0.f)
-    if (lane16 == 0) {
-      float s9[9] = {bav.x * c.os_ang, bav.y * c.os_ang, bav.z * c.os_ang, pg.x, pg.y, pg.z, cmd[0] * c.os_lin, cmd[1] * c.os_lin, cmd[2] * c.os_ang};
-      pv[0] = CLIP(blv.x * c.os_lin); pv[1] = CLIP(blv.y * c.os_lin); pv[2] = CLIP(blv.z * c.os_lin);
-      _Pragma("unroll") for (int i = 0; i < 9; ++i) { pv[3 + i] = CLIP(s9[i]); ob[i] = CLIP(s9[i] + NOISE(i)); }
-    }
-    float ndp[3], ndv[3];   // noise of this leg's joints: 3 + 3 requests = 2 Philox groups
-    _Pragma("unroll") for (int j = 0; j < 3; ++j) ndp[j] = NOISE(9 + 3 * lane + j);
-    _Pragma("unroll") for (int j = 0; j < 3; ++j) ndv[j] = NOISE(21 + 3 * lane + j);
-    if (sub == 0)
+    {
+      float v3_[3], w3_[3]; int obase, pbase, wbase, nw;       // 3 values -> ob[obase..] (+noise) and pv[pbase..]; nw extra critic values -> pv[wbase..]
+      if (sub == 0) { _Pragma("unroll") for (int j = 0; j < 3; ++j) { v3_[j] = (o.q[j] - c.q0[3 * lane + j]) * c.os_dof_pos; w3_[j] = o.tau[j] / t.eff_lim[j]; }
+                      obase = 9 + 3 * lane; pbase = 12 + 3 * lane; wbase = 52 + 3 * lane; nw = 3; }
+      else if (sub == 1) { _Pragma("unroll") for (int j = 0; j < 3; ++j) { v3_[j] = o.qd[j] * c.os_dof_vel; w3_[j] = (last_dv[j] - o.qd[j]) / c.dt * 1e-4f; }
+                           obase = 21 + 3 * lane; pbase = 24 + 3 * lane; wbase = 64 + 3 * lane; nw = 3; }
+      else if (sub == 2) { _Pragma("unroll") for (int j = 0; j < 3; ++j) { v3_[j] = act[j]; w3_[j] = 0.f; }
+                           w3_[0] = sqrtf(dot(o.Ffoot, o.Ffoot)) * 1e-3f; obase = 33 + 3 * lane; pbase = 36 + 3 * lane; wbase = 48 + lane; nw = 1; }
+      else {
+        const V3 tr = lane == 0 ? c.os_ang * bav : (lane == 1 ? pg : (lane == 2 ? v3(cmd[0] * c.os_lin, cmd[1] * c.os_lin, cmd[2] * c.os_ang) : c.os_lin * blv));
+        v3_[0] = tr.x; v3_[1] = tr.y; v3_[2] = tr.z; w3_[0] = w3_[1] = w3_[2] = 0.f;
+        obase = lane < 3 ? 3 * lane : -1; pbase = lane < 3 ? 3 + 3 * lane : 0; wbase = 0; nw = 0;
+      }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      int d = 3 * lane + j;
-      float dp = (o.q[j] - c.q0[d]) * c.os_dof_pos, dv = o.qd[j] * c.os_dof_vel;
-      pv[3 + 9 + d] = CLIP(dp); pv[3 + 21 + d] = CLIP(dv); pv[3 + 33 + d] = CLIP(act[j]);
-      ob[9 + d] = CLIP(dp + ndp[j]); ob[21 + d] = CLIP(dv + ndv[j]); ob[33 + d] = CLIP(act[j] + NOISE(33 + d));
-      pv[52 + d] = CLIP(o.tau[j] / t.eff_lim[j]);
-      pv[64 + d] = CLIP((last_dv[j] - o.qd[j]) / c.dt * 1e-4f);
+      for (int j = 0; j < 3; ++j) {
+        pv[pbase + j] = CLIP(v3_[j]);
+        if (obase >= 0) {
+          const int i = obase + j; const float nv = c.noise_vec[i];
+          const float nz = (c.add_noise && nv != 0.f) ? (2.f * uni(GO2_U_NOISE + i) - 1.f) * nv : 0.f;
+          ob[i] = CLIP(v3_[j] + nz);
+        }
+        if (j < nw) pv[wbase + j] = CLIP(w3_[j]);
+      }
     }
-    if (sub == 0) pv[48 + lane] = CLIP(sqrtf(dot(o.Ffoot, o.Ffoot)) * 1e-3f);
     if (c.terrain_mode == 0 || !c.measure_heights) {      // plane: every sample is 0 (:1201-1202), nothing to read back
       const float hv = CLIP(fminf(fmaxf(o.pw.z - 0.5f, -1.f), 1.f) * c.os_height);
       for (int i = lane16; i < GO2_NUM_HEIGHT_POINTS; i += 16) pv[76 + i] = hv;
@@ -459,7 +484,7 @@ struct LegPost {
       }
     }
 #undef CLIP
-#undef NOISE
+    GO2_MARK(26);
     // ---- write back ---------------------------------------------------------------------------------
     if (sub == 0) {
       if (c.rew_on[GO2_REW_BASE_HEIGHT] && !skip_contact_filters) F2D(p.last_contacts2, lane, e) = new_lc2;

@@ -67,8 +67,10 @@ struct Go2PtrsK { GO2_PTRS_BODY(GO2_GLOBAL_AS) };
 static_assert(sizeof(Go2PtrsK) == sizeof(Go2Ptrs), "same layout");
 #define GO2_GENERIC(T, ptr) ((T)(ptr))          /* explicit global -> generic cast for a callee that takes a plain pointer */
 #define GO2_AS1 GO2_GLOBAL_AS
+#define GO2_AS3 __attribute__((address_space(3)))
 #else
 #define GO2_AS1
+#define GO2_AS3
 typedef Go2Ptrs Go2PtrsK;
 #define GO2_GENERIC(T, ptr) (ptr)
 #endif

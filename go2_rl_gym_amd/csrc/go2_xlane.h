@@ -50,6 +50,9 @@ __device__ __forceinline__ bool any(bool p) { return true; }
 __device__ __forceinline__ bool any(bool p) { return __any(p); }
 #endif
 __device__ __forceinline__ void sync() { __syncthreads(); }
+// LDS hand-off between the lanes of ONE wave (a row of 16 lanes in particular): the LDS executes a wave's accesses in order, so a write by
+// one lane is visible to a later read by another lane of the same wave; the fence only stops the compiler from moving the two
+__device__ __forceinline__ void row_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 }  // namespace xl
 #elif defined(__HIPCC__)
@@ -64,6 +67,7 @@ template <int K> __host__ __device__ inline float row_bcast(float x) { return x;
 template <int K> __host__ __device__ inline int row_bcast_i(int x) { return x; }
 __host__ __device__ inline bool any(bool p) { return p; }
 __host__ __device__ inline void sync() {}
+__host__ __device__ inline void row_sync() {}
 __host__ __device__ inline int lane_id() { return 0; }
 }  // namespace xl
 #else
@@ -81,7 +85,10 @@ struct Fiber;
 struct Group {                       // one workgroup under emulation
   int nthreads, live;                // live = fibres that have not returned yet
   int barrier_arrived; unsigned barrier_gen;
-  struct Wave { uint32_t slot[2][64]; int arrived, live; unsigned gen; int any_acc[2]; unsigned opid[2]; } wave[16];
+  // rendezvous scopes: the 16-lane DPP row (quad / row primitives: legal wherever whole rows are convergent, e.g. inside a per-env
+  // branch) and the wave (xl::any)
+  struct Scope { uint32_t slot[2][64]; int arrived, live; unsigned gen; unsigned opid[2]; };
+  Scope wave[16], row[64];
   std::vector<Fiber*> fibers;
 };
 struct Fiber {
@@ -120,7 +127,7 @@ inline void yield() { to_main(); }
 inline void fiber_entry() {
   Fiber* f = sched().cur;
   f->fn(f->arg, f->tid);
-  f->done = true; f->g->live--; f->g->wave[f->tid >> 6].live--;
+  f->done = true; f->g->live--; f->g->wave[f->tid >> 6].live--; f->g->row[f->tid >> 4].live--;
   to_main();
   abort();      // a finished fibre is never resumed
 }
@@ -132,10 +139,10 @@ inline void run_group(int nthreads, void (*fn)(void*, int), void* arg) {
   const size_t STACK = 256 * 1024;
   while ((int)stacks.size() < nthreads) stacks.push_back((char*)malloc(STACK));
   Group g; memset(&g.barrier_arrived, 0, sizeof(int)); g.nthreads = g.live = nthreads; g.barrier_arrived = 0; g.barrier_gen = 0;
-  memset(g.wave, 0, sizeof(g.wave));
+  memset(g.wave, 0, sizeof(g.wave)); memset(g.row, 0, sizeof(g.row));
   std::vector<Fiber> fb(nthreads);
   for (int t = 0; t < nthreads; ++t) {
-    Fiber& f = fb[t]; f.stack = stacks[t]; f.done = false; f.tid = t; f.g = &g; f.fn = fn; f.arg = arg; g.wave[t >> 6].live++;
+    Fiber& f = fb[t]; f.stack = stacks[t]; f.done = false; f.tid = t; f.g = &g; f.fn = fn; f.arg = arg; g.wave[t >> 6].live++; g.row[t >> 4].live++;
 #if defined(__x86_64__)
     uintptr_t top = ((uintptr_t)f.stack + STACK) & ~(uintptr_t)15;
     void** sp = (void**)top;
@@ -156,12 +163,13 @@ inline void run_group(int nthreads, void (*fn)(void*, int), void* arg) {
 inline Fiber* self() { return sched().cur; }
 inline int lane_id() { return self()->tid & 63; }
 
-// deposit `bits`, wait until every live lane of the wave has deposited for this operation, return the whole slot array of the operation
-inline const uint32_t* exchange(uint32_t bits, unsigned opid) {
-  Fiber* f = self(); Group::Wave& w = f->g->wave[f->tid >> 6];
+// deposit `bits`, wait until every live lane of the scope (row: wide = false, wave: wide = true) has deposited for this operation,
+// return the slot array of the operation indexed by lane-in-wave
+inline const uint32_t* exchange(uint32_t bits, unsigned opid, bool wide = false) {
+  Fiber* f = self(); Group::Scope& w = wide ? f->g->wave[f->tid >> 6] : f->g->row[f->tid >> 4];
   const unsigned gen = w.gen; const int par = gen & 1;
   if (w.arrived == 0) w.opid[par] = opid;
-  else if (w.opid[par] != opid) { fprintf(stderr, "go2_xlane: divergent cross-lane operation (lane %d)\n", f->tid); abort(); }
+  else if (w.opid[par] != opid) { fprintf(stderr, "go2_xlane: divergent cross-lane operation (lane %d: op %u vs %u)\n", f->tid, opid, w.opid[par]); abort(); }
   w.slot[par][f->tid & 63] = bits;
   ++w.arrived;
   while (w.gen == gen) {
@@ -186,13 +194,13 @@ inline float row_bcast(float x) { const int l = lane_id(); return f_of(exchange(
 template <int K>
 inline int row_bcast_i(int x) { const int l = lane_id(); return (int)exchange((uint32_t)x, 6)[(l & ~15) | K]; }
 inline bool any(bool p) {
-  Fiber* f = self(); Group::Wave& w = f->g->wave[f->tid >> 6];
-  const uint32_t* s = exchange(p ? 1u : 0u, 7);
+  Fiber* f = self();
+  const uint32_t* s = exchange(p ? 1u : 0u, 7, true);
   bool r = false;
   for (int t = 0; t < 64; ++t) { const int tid = (f->tid & ~63) | t; if (tid < f->g->nthreads && !f->g->fibers[tid]->done && s[t]) r = true; }
-  (void)w;
   return r;
 }
+inline void row_sync() { (void)exchange(0u, 8); }
 inline void sync() {
   Fiber* f = self(); Group* g = f->g;
   const unsigned gen = g->barrier_gen;

@@ -40,20 +40,17 @@ enum { MODE_PHYS = 1, MODE_POST = 2, MODE_RESET_ALL = 4 };
 // fibres (go2_xlane.h) — the host emulation; only the cross-lane primitives differ between the two builds.
 // Workgroup = 256 threads = 4 waves = 16 environments; one 16-lane DPP row = one environment, row lane = leg * 4 + sub.
 // ------------------------------------------------------------------------------------------------------
-#if defined(__HIP_DEVICE_COMPILE__) && defined(GO2_ISA_MARKS)
-#define GO2_MARK(n) asm volatile("; GO2MARK " #n)
-#else
-#define GO2_MARK(n) do { } while (0)
-#endif
 #define GO2_WG_ENVS 16
 #define GO2_WG_THREADS (16 * GO2_WG_ENVS)
 // The lane context is kept as THREE separate objects (not one struct): the compiler's scalar-replacement pass gives up on a
 // single 2.4 KB aggregate with thousands of uses and would leave all of it in scratch memory.
 struct LaneAux { float kp[3], kd[3], q0[3], zoff[3], strength[3], act_new[3], act_old[3]; int start; };   // kp/kd: gain x per-env multiplier (loaded once, not per substep)
 #define LANE_PARAMS LegPhys& ph_, LegPost& po_, LaneAux& ax
-struct Go2Shared { Go2Tables tab; Go2Step S; };   // LDS: robot link / collision tables (per-lane leg index -> ds_read), this step's scalars
+#define GO2_NUM_GROUPS 44     // Philox groups of one env-step (go2sim_rng.h: 0..42) rounded up
+// LDS: robot link / collision tables (per-lane leg index -> ds_read), this step's scalars, and per environment the table of drawn uniforms
+struct Go2Shared { Go2Tables tab; Go2Step S; float ucache[GO2_WG_ENVS][GO2_NUM_GROUPS][4]; };
 
-GO2_HD void lane_load_phys(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p, const Go2Launch& L, const Go2Step& S, const float* actions_in, int e, int lane, int sub) {
+GO2_HD void lane_load_phys(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p, const Go2Launch& L, const Go2Step& S, const float* actions_in, float u_delay, int e, int lane, int sub) {
   const int N = L.N;
   const LegTab& t = tab.leg[lane];
   LegPhys& ph = ph_;
@@ -90,9 +87,7 @@ GO2_HD void lane_load_phys(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p,
   // action delay (legged_robot.py:71-78)
   ax.start = 0;
   if (L.rand_delay) {
-    float u;
-    if (S.injected) u = S.injected[(size_t)e * GO2_NUM_UNIFORMS + GO2_U_DELAY];
-    else u = philox_u01((uint32_t)(L.env_offset + e), 0u, S.step_lo, S.step_hi, L.seed_lo, L.seed_hi, GO2_U_DELAY & 3);
+    const float u = S.injected ? S.injected[(size_t)e * GO2_NUM_UNIFORMS + GO2_U_DELAY] : u_delay;      // slot GO2_U_DELAY = group 0, word 0 (drawn at kernel start)
     ax.start = (int)(u * (float)(L.decimation + 1)); if (ax.start > L.decimation) ax.start = L.decimation;
   }
 }
@@ -190,16 +185,16 @@ GO2_HD void lane_load_physout(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK&
   o.foot_pos = v3(F3D(p.rigid, 19, fb, 0, e), F3D(p.rigid, 19, fb, 1, e), F3D(p.rigid, 19, fb, 2, e));
   o.foot_vel = v3(F3D(p.rigid, 19, fb, 7, e), F3D(p.rigid, 19, fb, 8, e), F3D(p.rigid, 19, fb, 9, e));
 }
-GO2_HD void lane_init_post(LANE_PARAMS, const uint8_t* codes, const Go2PtrsK* p, const Go2Launch* L, const Go2Step* S, int e, int lane, int sub) {
-  po_.codes = codes; po_.cg = -1; po_.cw0 = po_.cw1 = po_.cw2 = po_.cw3 = 0u;
+GO2_HD void lane_init_post(LANE_PARAMS, const GO2_AS3 uint8_t* codes, GO2_AS3 float (*uc)[4], const Go2PtrsK* p, const Go2Launch* L, const Go2Step* S, int e, int lane, int sub) {
+  po_.codes = codes; po_.uc = uc;
   po_.e = e; po_.lane = lane; po_.sub = sub; po_.lane16 = lane * 4 + sub; po_.N = L->N; po_.P = p; po_.L = L; po_.S = S;
   po_.skip_contact_filters = false; po_.new_lc = po_.new_lc2 = 0; po_.new_fat = 0.f;
 }
 // reset_idx(all envs) without a step (base_task.py:82-84): postB's reset branch with reset forced on
-GO2_HD void lane_reset_all(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p, const Go2Launch& L, const Go2Step& S, int e, int lane, int sub) {
+GO2_HD void lane_reset_all(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p, const Go2Launch& L, const Go2Step& S, GO2_AS3 float (*uc)[4], int e, int lane, int sub) {
   const int N = L.N;
   lane_load_physout(ph_, po_, ax, tab, p, L, e, lane);
-  lane_init_post(ph_, po_, ax, tab.slot_code, &p, &L, &S, e, lane, sub);
+  lane_init_post(ph_, po_, ax, (const GO2_AS3 uint8_t*)tab.slot_code, uc, &p, &L, &S, e, lane, sub);
   LegPost& po = po_;
   po.skip_contact_filters = true;
   // load what postA would have loaded, without advancing any clock
@@ -236,8 +231,18 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
   STAMP(0);
   LegPhys ph_; LegPost po_; LaneAux ax;
   const LegTab& t = tab.leg[lane];
+  GO2_AS3 float (*uc)[4] = (GO2_AS3 float (*)[4])sh.ucache[tid >> 4];
+  if (!S.injected) {
+    // the per-step uniforms, one Philox group per lane: observation noise (groups 26..40, go2sim_rng.h) in lanes 0..14, the action delay
+    // (group 0) in lane 15
+    const int r = tid & 15, g = r < 15 ? 26 + r : 0;
+    uint32_t w[4];
+    philox4x32_10((uint32_t)(L.env_offset + e), (uint32_t)g, S.step_lo, S.step_hi, L.seed_lo, L.seed_hi, w);
+    uc[g][0] = u01_from_bits(w[0]); uc[g][1] = u01_from_bits(w[1]); uc[g][2] = u01_from_bits(w[2]); uc[g][3] = u01_from_bits(w[3]);
+  }
+  xl::row_sync();
   if (MODE & MODE_RESET_ALL) {
-    lane_reset_all(ph_, po_, ax, tab, p, L, S, e, lane, sub);
+    lane_reset_all(ph_, po_, ax, tab, p, L, S, uc, e, lane, sub);
     float red[GO2_POST_PARTIALS];
 #pragma unroll
     for (int i = 0; i < GO2_POST_PARTIALS; ++i) red[i] = 0.f;
@@ -249,7 +254,7 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
     return;
   }
   if (MODE & MODE_PHYS) {
-    lane_load_phys(ph_, po_, ax, tab, p, L, S, actions_in, e, lane, sub);
+    lane_load_phys(ph_, po_, ax, tab, p, L, S, actions_in, uc[0][0], e, lane, sub);
     STAMP(1);
     for (int sb = 0; sb < L.decimation; ++sb) {
       const bool old = L.rand_delay && sb < ax.start;
@@ -278,6 +283,7 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
       GO2_MARK(16);
     }
     STAMP(2);
+    GO2_MARK(20);
     float fb[9];
     lane_finish_phys(ph_, po_, ax, tab, p, L, e, lane, sub, fb);
 #pragma unroll
@@ -288,9 +294,11 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
   }
   STAMP(3);
   if (MODE & MODE_POST) {
-    lane_init_post(ph_, po_, ax, tab.slot_code, &p, &L, &S, e, lane, sub);
+    GO2_MARK(21);
+    lane_init_post(ph_, po_, ax, (const GO2_AS3 uint8_t*)tab.slot_code, uc, &p, &L, &S, e, lane, sub);
     float part[GO2_POST_PARTIALS];
     po_.postA(t, part);
+    GO2_MARK(22);
     STAMP(4);
 #pragma unroll
     for (int i = 0; i < GO2_POST_PARTIALS; ++i) part[i] = xl::leg_sum(part[i]);
@@ -321,7 +329,8 @@ __global__ void __launch_bounds__(64) go2_torque_trace_kernel(const Go2DevBlock*
   const int e = blockIdx.x * 16 + (threadIdx.x >> 2), lane = threadIdx.x & 3, N = L.N;
   if (e >= N) return;
   LegPhys ph_; LegPost po_; LaneAux ax;
-  lane_load_phys(ph_, po_, ax, tab, p, L, S, actions_raw, e, lane, 0);
+  const float delay_u = philox_u01((uint32_t)(L.env_offset + e), 0u, S.step_lo, S.step_hi, L.seed_lo, L.seed_hi, GO2_U_DELAY & 3);
+    lane_load_phys(ph_, po_, ax, tab, p, L, S, actions_raw, delay_u, e, lane, 0);
   const LegTab& t = tab.leg[lane];
   for (int sub = 0; sub < L.decimation; ++sub) {
     const bool old = L.rand_delay && sub < ax.start;
@@ -989,7 +998,8 @@ int go2sim_debug_torque_trace(Go2Sim* s, const float* actions_raw, const float* 
   Go2Step S; go2_step_scalars(L, blk->dyn, p.inj_storage, blk->dyn.common_step_counter, 0, &S);
   for (int e = 0; e < N; ++e) for (int lane = 0; lane < 4; ++lane) {
     static thread_local LegPhys ph_; static thread_local LegPost po_; static thread_local LaneAux ax;
-    lane_load_phys(ph_, po_, ax, tab, p, L, S, actions_raw, e, lane, 0);
+    const float delay_u = philox_u01((uint32_t)(L.env_offset + e), 0u, S.step_lo, S.step_hi, L.seed_lo, L.seed_hi, GO2_U_DELAY & 3);
+    lane_load_phys(ph_, po_, ax, tab, p, L, S, actions_raw, delay_u, e, lane, 0);
     for (int sub = 0; sub < L.decimation; ++sub) {
       const bool old = L.rand_delay && sub < ax.start;
       const float a[3] = {old ? ax.act_old[0] : ax.act_new[0], old ? ax.act_old[1] : ax.act_new[1], old ? ax.act_old[2] : ax.act_new[2]};

@@ -24,6 +24,9 @@ def test_creation_and_reset_identical():
     so.reset_all(); se.reset_all()
     for k in ("root_states", "dof_state", "commands", "motor_strengths", "motor_zero_offsets", "p_gains_multiplier", "d_gains_multiplier"):
         np.testing.assert_allclose(np.asarray(getattr(so, k)), np.asarray(getattr(se, k)), atol=1e-6, err_msg=k)
+    # the observations reset() returns (with observation noise drawn from this step's Philox groups)
+    np.testing.assert_allclose(np.asarray(so.obs_buf), np.asarray(se.obs_buf), atol=2e-6, err_msg="obs_buf after reset")
+    np.testing.assert_allclose(np.asarray(so.privileged_obs_buf), np.asarray(se.privileged_obs_buf), atol=2e-6, err_msg="privileged_obs_buf after reset")
 
 
 def test_one_step_parity_through_landing_and_stance():
