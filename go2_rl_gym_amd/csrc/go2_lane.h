@@ -224,6 +224,7 @@ struct LegPhys {
       float gap = (cw.z - hh) * n.z - t.foot_pt[3];
       build_slot(foot, &act_foot, &f_n, &f_t1, &f_t2, L, gap, cb, t.foot_pt[3], 3, n, true);
     }
+    GO2_MARK(30);
     // deepest of the other candidates: this sub-lane tests its quarter of the leg's 16 + the leg's share of the base points (table
     // slots with a fixed link type per slot, go2_tables.h SubCand), then two quad-exchange rounds carry the deepest one — with the
     // base-frame position, radius, link, body and facet normal it needs for its rows — to all four sub-lanes.  Ties go to the lower
@@ -239,20 +240,34 @@ struct LegPhys {
         const bool tk = sc.idx[k] >= 0 && (gap < best || (gap == best && sc.idx[k] < bi)); \
         best = tk ? gap : best; bi = tk ? sc.idx[k] : bi; bn = sel(tk, n, bn); bcb = sel(tk, cbk, bcb); brad = tk ? sc.pt[k][3] : brad; \
         blink = tk ? (LINK) : blink; bbody = tk ? sc.body[k] : bbody; }
-      GO2_CAND(0, R2, q2, 2)
-      GO2_CAND(1, R2, q2, 2)
-      GO2_CAND(2, R3, q3, 3)
-      {   // slot 3: a calf point for sub-lanes 0 and 1, a hip point for sub-lanes 2 and 3
+      // On the plane a whole link group is skipped when none of its spheres can reach the contact margin in ANY lane of the wave: lowest
+      // possible sphere bottom = (link origin height) - sum_axis |world-z component of the link axis| * (group's reach along that axis).
+      // Conservative, so skipping cannot change which candidate is inside the margin (only those matter: an inactive slot has no rows).
+      bool do_hip = true, do_thigh = true, do_calf = true, do_base = true;
+      if (L.terrain_mode == 0) {
+        const V3 gz = v3(Rwb.x.z, Rwb.y.z, Rwb.z.z);        // world z axis in base coordinates
+        auto low = [&](const M3& R, V3 o, const float* ext) {
+          return pw.z + dot(gz, o) - (fabsf(dot(gz, R.x)) * ext[0] + fabsf(dot(gz, R.y)) * ext[1] + fabsf(dot(gz, R.z)) * ext[2]); };
+        const M3 Id = {v3(1, 0, 0), v3(0, 1, 0), v3(0, 0, 1)};
+        do_hip = xl::any(low(R1, p1, t.cull_ext[0]) < L.contact_offset); do_thigh = xl::any(low(R2, p2, t.cull_ext[1]) < L.contact_offset);
+        do_calf = xl::any(low(R3, p3, t.cull_ext[2]) < L.contact_offset); do_base = xl::any(low(Id, v3(0, 0, 0), t.cull_ext[3]) < L.contact_offset);
+      }
+      if (do_thigh) { GO2_CAND(0, R2, q2, 2) GO2_CAND(1, R2, q2, 2) }
+      if (do_calf) GO2_CAND(2, R3, q3, 3)
+      if (do_calf || do_hip) {   // slot 3: a calf point for sub-lanes 0 and 1, a hip point for sub-lanes 2 and 3
         const bool hipk = sub >= 2;
         const M3 Rx = {sel(hipk, R1.x, R3.x), sel(hipk, R1.y, R3.y), sel(hipk, R1.z, R3.z)}; const V3 px = sel(hipk, p1, p3);
         GO2_CAND(3, Rx, px, hipk ? 1 : 3)
       }
-      {   // slot 4: one of the leg's base / head points (sub-lane < number of points of this leg)
+      if (do_base) {   // slot 4: one of the leg's base / head points (sub-lane < number of points of this leg)
         const M3 Id = {v3(1, 0, 0), v3(0, 1, 0), v3(0, 0, 1)}; const V3 o = v3(0, 0, 0);
         GO2_CAND(4, Id, o, 0)
       }
 #undef GO2_CAND
-      // quad tournament: partner sub^1, then sub^2
+      GO2_MARK(31);
+      // quad tournament: partner sub^1, then sub^2 (skipped with the rows when nothing in the wave is inside the margin)
+      const bool any_near = xl::any(best < L.contact_offset);
+      if (any_near) {
 #define GO2_ROUND(PERM) { \
         const float g2 = xl::quad_perm<PERM>(best); const int i2 = xl::quad_perm_i<PERM>(bi); \
         const bool tk = g2 < best || (g2 == best && i2 < bi); \
@@ -265,16 +280,19 @@ struct LegPhys {
 #define GO2_P2 2, 3, 0, 1
       GO2_ROUND(GO2_P1)
       GO2_ROUND(GO2_P2)
+      }
 #undef GO2_P1
 #undef GO2_P2
 #undef GO2_ROUND
+      GO2_MARK(32);
       other_body = bbody;
       // rows only if some lane of the wave has a candidate inside the contact margin this substep (wave-uniform branch; an inactive
       // slot's rows are never visited by the solver, so skipping their construction changes no result)
       act_other = best < L.contact_offset ? 1.f : 0.f; o_n = bn; o_t1 = v3(1, 0, 0); o_t2 = v3(0, 1, 0);
       _Pragma("unroll") for (int a = 0; a < 3; ++a) other[a] = Row{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0.f, 0.f, 0.f};
-      if (xl::any(act_other > 0.f)) build_slot(other, &act_other, &o_n, &o_t1, &o_t2, L, best, bcb, brad, blink, bn, false);
+      if (any_near) build_slot(other, &act_other, &o_n, &o_t1, &o_t2, L, best, bcb, brad, blink, bn, false);
     }
+    GO2_MARK(33);
     // joint limits
     {
       float h = L.sim_dt, cfm1 = 1.0f + L.cfm;
@@ -294,6 +312,7 @@ struct LegPhys {
           build_row(lim[j], Jc, sv(v3(0, 0, 0), v3(0, 0, 0)), cfm1, b, 0.f);
         }
     }
+    GO2_MARK(34);
     // warm start: the slice of the velocity change the remembered foot impulses produce.  The joint slice (sub-lane 0) is the leg's
     // own; the base-twist slices are summed over the four legs.
     float c[3] = {0.f, 0.f, 0.f};
@@ -318,8 +337,10 @@ struct LegPhys {
     {
       const float v1 = row_v(r[1]), v2 = row_v(r[2]);
       float l1 = r[1].lam - v1 * r[1].dinv, l2 = r[2].lam - v2 * r[2].dinv;
-      const float lim_ = mu_ * r[0].lam, nn = sqrtf(l1 * l1 + l2 * l2);
-      if (nn > lim_) { const float sc = nn > 0.f ? lim_ / nn : 0.f; l1 *= sc; l2 *= sc; }
+      // Coulomb cone by radial projection, branch-free: scale = min(1, mu lam_n / |l|)
+      const float lim_ = mu_ * r[0].lam, nn2 = l1 * l1 + l2 * l2;
+      const float sc = fminf(1.f, lim_ * go2_rsqrt(fmaxf(nn2, 1e-30f)));
+      l1 *= sc; l2 *= sc;
       const float d1 = m * (l1 - r[1].lam), d2 = m * (l2 - r[2].lam); r[1].lam += d1; r[2].lam += d2;
       row_apply(r[1], d1); row_apply(r[2], d2);
     }

@@ -67,6 +67,12 @@ __device__ __forceinline__ void go2_sincos(float x, float* s, float* c) { const 
 GO2_HD void go2_sincos(float x, float* s, float* c) { *s = sinf(x); *c = cosf(x); }
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float go2_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+#else
+GO2_HD float go2_rsqrt(float x) { return 1.0f / sqrtf(x); }
+#endif
+
 struct V3 { float x, y, z; };
 GO2_HD V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
 GO2_HD V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }

@@ -36,6 +36,7 @@ struct LegTab {
   int32_t body_index[4];            // hip, thigh, calf, foot body indices
   int32_t mass_ratio_index[4];      // index into link_mass_ratio[18] (= body index - 1)
   SubCand cand[4];                  // the same candidates, dealt to the 4 sub-lanes
+  float cull_ext[4][4];             // per group (hip, thigh, calf, base share): half-extents (+ radius) of the group's spheres along the link axes
 };
 struct BaseTab {
   float m0, c0[3], Ic0[6];          // base body: mass, COM, inertia about COM

@@ -271,11 +271,14 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
       GO2_MARK(13);
       ph_.phaseC(t, L, GO2_GENERIC(const int16_t*, p.hf));
       GO2_MARK(14);
-      // wave-wide row-group activity (ballots -> scalar branches): typically only the foot contacts are live
-      const bool any_foot = xl::any(ph_.has_foot()), any_other = xl::any(ph_.has_other()), any_lim = xl::any(ph_.has_limit());
+      // wave-wide row-group activity PER TURN (ballots -> scalar branches): group g of leg T is swept only if some environment of the wave
+      // has it active on that leg — typically only the foot contacts are live (an inactive row moves nothing, so skipping is exact)
+      bool af[4], ao[4], al[4];
+#pragma unroll
+      for (int T = 0; T < 4; ++T) { const bool mine = lane == T; af[T] = xl::any(mine && ph_.has_foot()); ao[T] = xl::any(mine && ph_.has_other()); al[T] = xl::any(mine && ph_.has_limit()); }
       for (int it = 0; it < L.solver_iterations; ++it) {
-        ph_.gs_turn(0, any_foot, any_other, any_lim); ph_.gs_turn(1, any_foot, any_other, any_lim);
-        ph_.gs_turn(2, any_foot, any_other, any_lim); ph_.gs_turn(3, any_foot, any_other, any_lim);
+        ph_.gs_turn(0, af[0], ao[0], al[0]); ph_.gs_turn(1, af[1], ao[1], al[1]);
+        ph_.gs_turn(2, af[2], ao[2], al[2]); ph_.gs_turn(3, af[3], ao[3], al[3]);
       }
       GO2_MARK(15);
       ph_.gather_solution();
@@ -636,6 +639,10 @@ static void fill_tables(Go2Tables* T) {
     for (int i = 0; i < GO2_BASE_PTS; ++i) if ((i & 3) == l) {
       int k = t.n_base++; for (int a = 0; a < 3; ++a) t.base_pt[k][a] = (float)kBase[i].c[a]; t.base_pt[k][3] = (float)kBase[i].r; t.base_body[k] = kBase[i].body;
     }
+    // per-group axis-aligned reach of the spheres in their link frame (go2_lane.h: conservative cull of whole groups on the plane)
+    for (int g = 0; g < 4; ++g) for (int a = 0; a < 4; ++a) t.cull_ext[g][a] = 0.f;
+    for (int i = 0; i < GO2_LEG_OTHER_PTS; ++i) { const int g = t.other_link[i] - 1; for (int a = 0; a < 3; ++a) t.cull_ext[g][a] = fmaxf(t.cull_ext[g][a], fabsf(t.other_pt[i][a]) + t.other_pt[i][3]); }
+    for (int k = 0; k < t.n_base; ++k) for (int a = 0; a < 3; ++a) t.cull_ext[3][a] = fmaxf(t.cull_ext[3][a], fabsf(t.base_pt[k][a]) + t.base_pt[k][3]);
     // deal the candidates to the 4 sub-lanes: slots {thigh, thigh, calf, calf|hip, base} (go2_tables.h SubCand)
     for (int sb = 0; sb < 4; ++sb) {
       SubCand& sc = t.cand[sb];
