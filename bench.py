@@ -170,23 +170,32 @@ def main():
         k_ms = ms.value / max(n.value, 1)
         algo = ALGO_BYTES_FLAT if "flat" in a.task else ALGO_BYTES_ROUGH
         achieved = algo * N / (k_ms * 1e-3) / 1e9
-        # HBM traffic per launch from the rocprofv3 PMC passes (tools/pmc_pass.sh -> profiles/*_pmc_step_kernel.json; bench.py cannot
-        # collect counters on itself).  Only quoted when the profiled launch shape is the benchmarked one.
-        traffic, traffic_src = None, None
+        # HBM traffic per launch from the rocprofv3 PMC passes (tools/pmc_pass.sh -> profiles/*_pmc_step_kernel.json; bench.py cannot collect
+        # counters on itself).  Quoted ONLY when the profile was taken on exactly the library loaded now (sha256 of the .so), at this size
+        # and task; the counters are corrected by the calibration probe measured in the same pass (known bytes, same access pattern).
         import glob
+        import hashlib
+        from go2_rl_gym_amd import _lib
+        lib_sha = hashlib.sha256(open(_lib.HIP_LIB, "rb").read()).hexdigest()[:16]
+        traffic, traffic_src, traffic_note = None, None, "no PMC profile of this exact library (sha256 %s) in profiles/" % lib_sha
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_step_kernel.json")))[::-1]:
             pm = json.load(open(f))
-            if pm.get("num_envs") == N and pm.get("task", "go2_flat") == a.task:
+            if pm.get("num_envs") == N and pm.get("task", "go2_flat") == a.task and pm.get("lib_sha256_16") == lib_sha:
                 traffic, traffic_src = pm["hbm_bytes_per_launch_corrected"], os.path.relpath(f, ROOT)
+                traffic_note = "FETCH_SIZE %.0f KB / WRITE_SIZE %.0f KB per launch, corrected by the calibration probe's reported/known = %.2f / %.2f" % (
+                    pm["FETCH_SIZE"]["mean_kb"], pm["WRITE_SIZE"]["mean_kb"], pm["calibration_FETCH_SIZE"]["reported_over_known"], pm["calibration_WRITE_SIZE"]["reported_over_known"])
                 break
         # VALU-issue view of the same kernel (what actually binds it): lane-instructions per env-step from the SQ PMC pass
         # (tools/sq_pass.sh -> profiles/*_sq_step_kernel.json) x envs / measured kernel time, against 1024 SIMDs x 16 lanes x 2.4 GHz
         valu = None
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_step_kernel.json")))[::-1]:
             sq = json.load(open(f))
+            if sq.get("lib_sha256_16") != lib_sha or sq.get("num_envs") != N or sq.get("task", "go2_flat") != a.task:
+                continue
             per_env = sq["SQ_INSTS_VALU"] * 64 / sq["num_envs"]
             valu = {"lane_instr_per_env_step": per_env, "achieved_Tlane_ops": per_env * N / (k_ms * 1e-3) / 1e12, "peak_Tlane_ops": 1024 * 16 * 2.4e9 / 1e12,
-                    "frac": per_env * N / (k_ms * 1e-3) / (1024 * 16 * 2.4e9), "source": os.path.relpath(f, ROOT)}
+                    "frac": per_env * N / (k_ms * 1e-3) / (1024 * 16 * 2.4e9), "wave_cycles_waiting_frac": sq.get("SQ_WAIT_ANY", 0) / max(sq.get("SQ_WAVE_CYCLES", 1), 1),
+                    "vgpr": sq.get("vgpr"), "agpr": sq.get("agpr"), "scratch_bytes_per_lane": sq.get("scratch_bytes_per_lane"), "source": os.path.relpath(f, ROOT)}
             break
         out = {
             "metric": "env-steps/sec at 4096 envs (go2 flat); 1/2/4/8-GPU scaling", "value": total_steps / elapsed, "unit": "env-steps/s",
@@ -201,10 +210,9 @@ def main():
             "collectives_per_iteration": {"all_reduce": ncoll["all_reduce"] / max(a.steps, 1),
                                           "what": "1 x 24-byte fp64 advantage-statistics all-reduce (rollout_storage.py:137) + 1 flat gradient+KL bucket per mini-batch step (5 x 4)"},
             "roofline": {"bound": "hbm", "kernel": "go2_step_kernel<PHYS|POST>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo * N, "kernel_ms": k_ms, "launches": n.value, "algorithmic_bytes_per_env_step": algo,
-                         "note": "latency/occupancy-bound by construction: 4096 envs x 4 lanes = 256 waves for 1024 SIMDs; the binding resource is VALU issue, "
-                                 "not HBM: ~32k VALU instr per wave per step at 1 wave/SIMD (profiles/r1_sq_step_kernel.json); kernel-only throughput scales "
-                                 "3.5x from 4096 to 32768 envs at constant latency (profiles/r1_kernel_scaling.txt, DESIGN.md 6)",
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note, "lib_sha256_16": lib_sha, "algorithmic_bytes_per_launch": algo * N, "kernel_ms": k_ms, "launches": n.value, "algorithmic_bytes_per_env_step": algo,
+                         "note": "latency-bound by construction: 4096 envs x 16 lanes = 1024 waves = one wave per SIMD; the binding resource is the dependent-issue "
+                                 "latency of ~25k instructions per wave per step, not HBM (DESIGN.md 6)",
                          "valu_issue": valu},
         }
         if world == 1 and not a.no_cpu_baseline:

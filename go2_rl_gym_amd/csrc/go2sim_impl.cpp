@@ -343,6 +343,17 @@ __global__ void __launch_bounds__(64) go2_torque_trace_kernel(const Go2DevBlock*
     for (int j = 0; j < 3; ++j) { out[((size_t)sub * N + e) * 12 + 3 * lane + j] = ph_.tau[j]; F2D(p.torques, 3 * lane + j, e) = ph_.tau[j]; }
   }
 }
+// HBM-counter calibration probe: the step kernel's access pattern with a KNOWN byte count — 256-thread workgroups of 16 envs, every
+// lane of an env reads the same 4 bytes of each of `nread` field-major fields [f][N] (16-byte runs per wave, 64-byte runs per workgroup)
+// and lane 0 of the env writes `nwrite` fields.  rocprofv3's FETCH_SIZE / WRITE_SIZE over this kernel against nread*N*4 / nwrite*N*4 give
+// the correction factors for THIS pattern (MI355X_MICROARCH.md: "calibrate on a known byte count in your own access pattern").
+__global__ void __launch_bounds__(GO2_WG_THREADS) go2_traffic_probe_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int nread, int nwrite) {
+  const int e = blockIdx.x * GO2_WG_ENVS + (threadIdx.x >> 4);
+  if (e >= N) return;
+  float acc = 0.f;
+  for (int f = 0; f < nread; ++f) acc += in[(size_t)f * N + e];
+  if ((threadIdx.x & 15) == 0) for (int f = 0; f < nwrite; ++f) out[(size_t)f * N + e] = acc + (float)f;
+}
 // the individually rounded operations of go2_math.h over arrays: out[0..4][n] = a*b, a+b, a-b, a/b, sqrt(|a|)
 __global__ void go2_strict_ops_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n, double inv_b0) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1017,6 +1028,17 @@ int go2sim_debug_torque_trace(Go2Sim* s, const float* actions_raw, const float* 
   }
 #else
   hipLaunchKernelGGL(go2_torque_trace_kernel, dim3((s->N + 15) / 16), dim3(64), 0, (hipStream_t)stream, s->d_blk, actions_raw, dof, out);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+int go2sim_debug_traffic_probe(const float* in, float* out, int32_t N, int32_t nread, int32_t nwrite, void* stream) {
+  if (!in || !out || N <= 0 || nread < 0 || nwrite < 0) FAIL(GO2SIM_EINVAL, "bad argument");
+#ifdef GO2_EMU
+  (void)stream;
+  for (int e = 0; e < N; ++e) { float acc = 0.f; for (int f = 0; f < nread; ++f) acc += in[(size_t)f * N + e]; for (int f = 0; f < nwrite; ++f) out[(size_t)f * N + e] = acc + (float)f; }
+#else
+  hipLaunchKernelGGL(go2_traffic_probe_kernel, dim3((N + GO2_WG_ENVS - 1) / GO2_WG_ENVS), dim3(GO2_WG_THREADS), 0, (hipStream_t)stream, in, out, N, nread, nwrite);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

@@ -338,6 +338,10 @@ int  go2sim_debug_torque_trace(Go2Sim* h, const float* actions_raw, const float*
 /* The individually rounded fp32 operations the height-scan INDEX arithmetic is built from (csrc/go2_math.h go2_*_rn) over arrays:
  * out [6][n] = a*b, a+b, a-b, a/b, sqrt(|a|), a/b[0] (through the double-precision reciprocal) — each must equal the IEEE result. */
 int  go2sim_debug_strict_ops(const float* a, const float* b, float* out, int32_t n, void* stream);
+/* Measurement aid: a kernel with the step kernel's HBM access pattern (16 environments per 256-thread workgroup, field-major fields
+ * [f][N], 4 bytes per environment and field) and a known byte count: reads `nread` fields of `in` [nread][N], writes `nwrite` fields of
+ * `out` [nwrite][N].  Profiled with rocprofv3 FETCH_SIZE / WRITE_SIZE it calibrates those counters for this pattern (tools/pmc_pass.sh). */
+int  go2sim_debug_traffic_probe(const float* in, float* out, int32_t N, int32_t nread, int32_t nwrite, void* stream);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* While enabled, every go2sim_step / go2sim_simulate brackets its main kernel with events ON THE STREAM IT

@@ -1178,6 +1178,11 @@ int go2o_torque_trace(Go2Sim* s, const float* actions_raw, const float* dof, flo
 int go2sim_debug_torque_trace(Go2Sim* s, const float* actions_raw, const float* dof, float* out, void* stream) {
   (void)stream; if (!s||!actions_raw||!dof||!out) return GO2SIM_EINVAL; return go2o_torque_trace(s, actions_raw, dof, out);
 }
+int go2sim_debug_traffic_probe(const float* in, float* out, int32_t N, int32_t nread, int32_t nwrite, void* stream) {
+  (void)stream; if (!in||!out||N<=0||nread<0||nwrite<0) return GO2SIM_EINVAL;
+  for (int e=0;e<N;++e) { float acc=0; for (int f=0;f<nread;++f) acc+=in[(size_t)f*N+e]; for (int f=0;f<nwrite;++f) out[(size_t)f*N+e]=acc+(float)f; }
+  return 0;
+}
 /* the IEEE operations themselves (gcc, x86-64 baseline: no FMA contraction, correctly rounded / and sqrt) */
 int go2sim_debug_strict_ops(const float* a, const float* b, float* out, int32_t n, void* stream) {
   (void)stream; if (!a||!b||!out||n<=0) return GO2SIM_EINVAL;
