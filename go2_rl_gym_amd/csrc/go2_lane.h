@@ -141,22 +141,44 @@ struct LegPhys {
       }
   }
 
-  // terrain height and unit normal under world point (x, y)
-  GO2_HD void terrain(const Go2Launch& L, const int16_t* hf, float x, float y, float* hgt, V3* n) const {
-    if (L.terrain_mode == 0) { *hgt = 0.f; *n = v3(0, 0, 1); return; }
-    float fx = (x + L.hf_border) / L.hf_hscale, fy = (y + L.hf_border) / L.hf_hscale;
+  // Contact of a sphere (world centre c, radius r) with the terrain: gap (< 0: penetration) and unit normal of the deepest of
+  //   * the facet under the centre — the cell's two triangles, split along (i,j)-(i+1,j+1), the diagonal of the reference's trimesh
+  //     (terrain_utils triangles (0,3,1),(0,2,3)); gap = (c.z - h) n.z - r;
+  //   * with hf_walls (mesh_type 'trimesh'): the vertical faces on the cell's four edges — a face stands where the NEIGHBOUR cell's heights
+  //     along the common edge exceed this cell's (go2sim.h hf_cells); closest point on the face (bottom .. top at the foot of the
+  //     perpendicular) gives a horizontal normal beside the face and a slanted one over its top edge.
+  GO2_HD void contact_query(const Go2Launch& L, const GO2_AS1 Go2Cell* cells, V3 c, float r, float* gap, V3* n) const {
+    if (L.terrain_mode == 0) { *gap = c.z - r; *n = v3(0, 0, 1); return; }
+    const float hs = L.hf_hscale, vs = L.hf_vscale;
+    float fx = (c.x + L.hf_border) / hs, fy = (c.y + L.hf_border) / hs;
     int i = (int)floorf(fx), j = (int)floorf(fy);
     i = i < 0 ? 0 : (i > L.hf_rows - 2 ? L.hf_rows - 2 : i); j = j < 0 ? 0 : (j > L.hf_cols - 2 ? L.hf_cols - 2 : j);
-    float uu = fminf(fmaxf(fx - i, 0.f), 1.f), vv = fminf(fmaxf(fy - j, 0.f), 1.f);
-    float h00 = hf[i * L.hf_cols + j] * L.hf_vscale, h10 = hf[(i + 1) * L.hf_cols + j] * L.hf_vscale;
-    float h01 = hf[i * L.hf_cols + j + 1] * L.hf_vscale, h11 = hf[(i + 1) * L.hf_cols + j + 1] * L.hf_vscale;
+    const float uu = fminf(fmaxf(fx - i, 0.f), 1.f), vv = fminf(fmaxf(fy - j, 0.f), 1.f);
+    const int nc = L.hf_cols - 1;
+    const Go2Cell q = cells[i * nc + j];
+    const float h00 = q.h[0] * vs, h10 = q.h[1] * vs, h01 = q.h[2] * vs, h11 = q.h[3] * vs;
     float dx, dy;
-    // two triangles per cell split along (i,j)-(i+1,j+1), the diagonal of the reference's trimesh (terrain_utils triangles (0,3,1),(0,2,3))
     if (uu >= vv) { dx = h10 - h00; dy = h11 - h10; }
     else { dx = h11 - h01; dy = h01 - h00; }
-    *hgt = h00 + uu * dx + vv * dy;
-    float nx = -dx / L.hf_hscale, ny = -dy / L.hf_hscale, inv = 1.0f / sqrtf(nx * nx + ny * ny + 1.f);
-    *n = v3(nx * inv, ny * inv, inv);
+    const float hgt = h00 + uu * dx + vv * dy;
+    const float nx = -dx / hs, ny = -dy / hs, inv = 1.0f / sqrtf(nx * nx + ny * ny + 1.f);
+    float g = (c.z - hgt) * inv - r; V3 nn = v3(nx * inv, ny * inv, inv);
+    if (L.hf_walls) {
+      // edge k: neighbour cell, this cell's heights at the edge ends (a0, a1), the neighbour's (its corners k0, k1), parameter along the edge,
+      // distance of the centre from the edge, inward direction
+#define GO2_WALL(INGRID, NBI, NBJ, A0, A1, K0, K1, T, D, NX, NY) if (INGRID) { \
+        const Go2Cell b = cells[(NBI) * nc + (NBJ)]; \
+        const float bot = (A0) + (T) * ((A1) - (A0)), b0 = b.h[K0] * vs, top = b0 + (T) * (b.h[K1] * vs - b0); \
+        if (top - bot > 0.5f * vs) { \
+          const float qz = fminf(fmaxf(c.z, bot), top), dz = c.z - qz, dist = sqrtf((D) * (D) + dz * dz), gw = dist - r; \
+          if (gw < g) { const float iv = 1.0f / fmaxf(dist, 1e-9f); g = gw; nn = dist > 1e-9f ? v3((NX) * (D) * iv, (NY) * (D) * iv, dz * iv) : v3((NX), (NY), 0.f); } } }
+      GO2_WALL(i > 0, i - 1, j, h00, h01, 1, 3, vv, uu * hs, 1.f, 0.f)
+      GO2_WALL(i < L.hf_rows - 2, i + 1, j, h10, h11, 0, 2, vv, (1.f - uu) * hs, -1.f, 0.f)
+      GO2_WALL(j > 0, i, j - 1, h00, h10, 2, 3, uu, vv * hs, 0.f, 1.f)
+      GO2_WALL(j < L.hf_cols - 2, i, j + 1, h01, h11, 0, 1, uu, (1.f - vv) * hs, 0.f, -1.f)
+#undef GO2_WALL
+    }
+    *gap = g; *n = nn;
   }
 
   // One constraint row from its joint-space row Jc (3) and its base-space row Ec (6): this sub-lane's slices of J = [Jc | G], Y = [Z | H]
@@ -189,7 +211,7 @@ struct LegPhys {
     const float h = L.sim_dt, cfm1 = 1.0f + L.cfm;
     const float act = gap < L.contact_offset ? 1.f : 0.f;
     *active = act; *dn = nw;
-    V3 ex = v3(1, 0, 0); float dnx = dot(ex, nw);
+    V3 ex = fabsf(nw.x) < 0.9f ? v3(1, 0, 0) : v3(0, 1, 0); float dnx = dot(ex, nw);      // first tangent: world x made orthogonal to n (world y beside a face that looks along x)
     V3 t1 = ex - dnx * nw; t1 = (1.0f / sqrtf(dot(t1, t1))) * t1;
     *dt1 = t1; *dt2 = cross(nw, t1);
     const V3 dirs[3] = {mulT(Rwb, nw), mulT(Rwb, t1), mulT(Rwb, *dt2)};
@@ -216,12 +238,11 @@ struct LegPhys {
   }
 
   // ------------------------------------------------------------------------------------------------
-  GO2_HD void phaseC(const LegTab& t, const Go2Launch& L, const int16_t* hf) {
+  GO2_HD void phaseC(const LegTab& t, const Go2Launch& L, const GO2_AS1 Go2Cell* cells) {
     // foot
     {
       V3 cb = p3 + mul(R3, v3(t.foot_pt[0], t.foot_pt[1], t.foot_pt[2]));
-      V3 cw = pw + mul(Rwb, cb); float hh; V3 n; terrain(L, hf, cw.x, cw.y, &hh, &n);
-      float gap = (cw.z - hh) * n.z - t.foot_pt[3];
+      V3 cw = pw + mul(Rwb, cb); float gap; V3 n; contact_query(L, cells, cw, t.foot_pt[3], &gap, &n);
       build_slot(foot, &act_foot, &f_n, &f_t1, &f_t2, L, gap, cb, t.foot_pt[3], 3, n, true);
     }
     GO2_MARK(30);
@@ -235,8 +256,7 @@ struct LegPhys {
       const V3 q2 = p2, q3 = p3;
 #define GO2_CAND(k, R, P, LINK) { \
         const V3 c = v3(sc.pt[k][0], sc.pt[k][1], sc.pt[k][2]); const V3 cbk = P + mul(R, c); \
-        const V3 cw = pw + mul(Rwb, cbk); float hh; V3 n; terrain(L, hf, cw.x, cw.y, &hh, &n); \
-        const float gap = (cw.z - hh) * n.z - sc.pt[k][3]; \
+        const V3 cw = pw + mul(Rwb, cbk); float gap; V3 n; contact_query(L, cells, cw, sc.pt[k][3], &gap, &n); \
         const bool tk = sc.idx[k] >= 0 && (gap < best || (gap == best && sc.idx[k] < bi)); \
         best = tk ? gap : best; bi = tk ? sc.idx[k] : bi; bn = sel(tk, n, bn); bcb = sel(tk, cbk, bcb); brad = tk ? sc.pt[k][3] : brad; \
         blink = tk ? (LINK) : blink; bbody = tk ? sc.body[k] : bbody; }

@@ -45,6 +45,10 @@ struct BaseTab {
 };
 struct Go2Tables { LegTab leg[4]; BaseTab base; uint8_t slot_code[GO2_NUM_UNIFORMS]; /* include/go2sim_rng.h */ int32_t layout_ok; };
 
+// the contact surface over one grid cell: heights (vscale units) at the corners (i,j) (i+1,j) (i,j+1) (i+1,j+1) as seen from inside the cell
+// (include/go2sim.h Go2SimCfg.hf_cells); one aligned 8-byte load per contact query
+struct alignas(8) Go2Cell { int16_t h[4]; };
+
 // Device/host pointers of every per-env field.  The HIP library stores per-env fields FIELD-MAJOR (SoA):
 // logical [N, a, b] lives at ((b_idx * A + a_idx) * N + env), i.e. C order of the reversed logical dims,
 // so that consecutive lanes (envs) touch consecutive addresses.  obs_buf and privileged_obs_buf are the
@@ -56,7 +60,7 @@ struct Go2Tables { LegTab leg[4]; BaseTab base; uint8_t slot_code[GO2_NUM_UNIFOR
   G uint8_t *last_contacts, *last_contacts2; G float *strength, *zero_off, *kp_mul, *kd_mul, *origins; G int64_t *terrain_levels, *terrain_types; \
   G float *ep_sums, *friction, *restitution, *added_mass, *added_com, *mass_ratio, *episode_info, *foot_impulse; \
   /* internal */ \
-  G int32_t* terrain_kind; G float* ep_accum /*[NUM_REWARDS+1]*/; const G float* inj_storage; const G int16_t* hf; const G float* terrain_origins; \
+  G int32_t* terrain_kind; G float* ep_accum /*[NUM_REWARDS+1]*/; const G float* inj_storage; const G int16_t* hf; const G Go2Cell* hf_cells; const G float* terrain_origins; \
   const G Go2Tables* tables; G long long* dbg_clock;
 struct Go2Ptrs { GO2_PTRS_BODY() };
 // The kernels read these pointers out of the device block (scalar loads), where the compiler cannot know their address space and would
@@ -82,7 +86,7 @@ struct Go2Launch {
   int32_t N, env_offset, decimation, solver_iterations;
   uint32_t seed_lo, seed_hi;
   float sim_dt, dt, gravity[3], contact_offset, erp, max_depen_vel, bounce_thr, cfm, armature, limit_margin, max_lin_vel, max_ang_vel;
-  int32_t terrain_mode, hf_rows, hf_cols; float hf_hscale, hf_vscale, hf_border, terrain_friction, terrain_restitution;
+  int32_t terrain_mode, hf_walls, hf_rows, hf_cols; float hf_hscale, hf_vscale, hf_border, terrain_friction, terrain_restitution;
   int32_t terrain_num_levels, terrain_num_types, terrain_curriculum, move_down_by_acc, measure_heights, full_body_states; float terrain_length;
   float kp[12], kd[12], q0[12], action_scale, clip_actions, clip_obs, base_init[13];
   int32_t rand_strength, rand_offset, rand_pd, push_robots, push_interval, rand_delay;

@@ -269,7 +269,7 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
       GO2_MARK(12);
       ph_.phaseB(L, part);
       GO2_MARK(13);
-      ph_.phaseC(t, L, GO2_GENERIC(const int16_t*, p.hf));
+      ph_.phaseC(t, L, p.hf_cells);
       GO2_MARK(14);
       // wave-wide row-group activity PER TURN (ballots -> scalar branches): group g of leg T is swept only if some environment of the wave
       // has it active on that leg — typically only the foot contacts are live (an inactive row moves nothing, so skipping is exact)
@@ -342,6 +342,16 @@ __global__ void __launch_bounds__(64) go2_torque_trace_kernel(const Go2DevBlock*
     ph_.pd(t, L, a, ax.kp, ax.kd, ax.q0, ax.zoff, ax.strength);
     for (int j = 0; j < 3; ++j) { out[((size_t)sub * N + e) * 12 + 3 * lane + j] = ph_.tau[j]; F2D(p.torques, 3 * lane + j, e) = ph_.tau[j]; }
   }
+}
+// the contact query of the lane program (go2_lane.h contact_query) over caller-supplied spheres: pts [n][4] = centre x, y, z, radius ->
+// out [n][4] = gap, normal
+__global__ void go2_contact_query_kernel(const Go2DevBlock* __restrict__ blk, const float* __restrict__ pts, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Go2PtrsK& p = *(const Go2PtrsK*)&blk->p;
+  LegPhys ph; float gap; V3 nn;
+  ph.contact_query(blk->L, p.hf_cells, v3(pts[4 * i], pts[4 * i + 1], pts[4 * i + 2]), pts[4 * i + 3], &gap, &nn);
+  out[4 * i] = gap; out[4 * i + 1] = nn.x; out[4 * i + 2] = nn.y; out[4 * i + 3] = nn.z;
 }
 // HBM-counter calibration probe: the step kernel's access pattern with a KNOWN byte count — 256-thread workgroups of 16 envs, every
 // lane of an env reads the same 4 bytes of each of `nread` field-major fields [f][N] (16-byte runs per wave, 64-byte runs per workgroup)
@@ -586,7 +596,7 @@ struct Go2Sim {
   Go2DevBlock* d_blk;       // the block in device memory
   std::vector<void*> allocs;
   float dt, max_episode_length;
-  float* inj_storage; Go2Tables* d_tables; int16_t* d_hf; float* d_torigins;
+  float* inj_storage; Go2Tables* d_tables; int16_t* d_hf; Go2Cell* d_cells; float* d_torigins;
   int timing; double time_ms; int64_t time_launches;
 #ifndef GO2_EMU
   std::vector<hipEvent_t> ev; size_t ev_used;
@@ -739,7 +749,7 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
 #endif
   Go2Sim* s = new Go2Sim();
   s->cfg = *cfg; const int N = s->N = cfg->num_envs;
-  s->d_hf = nullptr; s->d_torigins = nullptr; s->timing = 0; s->time_ms = 0; s->time_launches = 0;
+  s->d_hf = nullptr; s->d_cells = nullptr; s->d_torigins = nullptr; s->timing = 0; s->time_ms = 0; s->time_launches = 0;
 #ifndef GO2_EMU
   s->ev_used = 0;
 #endif
@@ -786,7 +796,7 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
   L.contact_offset = cfg->contact_offset; L.erp = cfg->erp; L.max_depen_vel = cfg->max_depenetration_velocity; L.bounce_thr = cfg->bounce_threshold_velocity;
   L.cfm = cfg->contact_cfm; L.armature = cfg->joint_armature; L.limit_margin = cfg->joint_limit_margin;
   L.max_lin_vel = cfg->max_linear_velocity; L.max_ang_vel = cfg->max_angular_velocity;
-  L.terrain_mode = cfg->terrain_mode; L.hf_rows = cfg->hf_rows; L.hf_cols = cfg->hf_cols; L.hf_hscale = cfg->hf_hscale; L.hf_inv_hscale = cfg->hf_hscale != 0.f ? 1.0 / (double)cfg->hf_hscale : 0.0; L.hf_vscale = cfg->hf_vscale; L.hf_border = cfg->hf_border;
+  L.terrain_mode = cfg->terrain_mode; L.hf_walls = (cfg->terrain_mode != 0 && cfg->hf_cells && cfg->hf_walls) ? 1 : 0; L.hf_rows = cfg->hf_rows; L.hf_cols = cfg->hf_cols; L.hf_hscale = cfg->hf_hscale; L.hf_inv_hscale = cfg->hf_hscale != 0.f ? 1.0 / (double)cfg->hf_hscale : 0.0; L.hf_vscale = cfg->hf_vscale; L.hf_border = cfg->hf_border;
   L.terrain_friction = cfg->terrain_friction; L.terrain_restitution = cfg->terrain_restitution; L.terrain_num_levels = cfg->terrain_num_levels; L.terrain_num_types = cfg->terrain_num_types;
   L.terrain_curriculum = cfg->terrain_curriculum; L.move_down_by_acc = cfg->move_down_by_accumulated_xy_command; L.measure_heights = cfg->measure_heights; L.full_body_states = cfg->full_body_states; L.terrain_length = cfg->terrain_length;
   memcpy(L.kp, cfg->kp, sizeof(L.kp)); memcpy(L.kd, cfg->kd, sizeof(L.kd)); memcpy(L.q0, cfg->default_dof_pos, sizeof(L.q0));
@@ -833,9 +843,21 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
     if (!s->d_hf || !s->d_torigins) { go2sim_destroy(s); FAIL(GO2SIM_ENOMEM, "allocation failed"); }
     dev_upload(s->d_hf, cfg->hf_samples, nh * sizeof(int16_t)); dev_upload(s->d_torigins, cfg->terrain_origins, no * sizeof(float));
     p.hf = s->d_hf; p.terrain_origins = s->d_torigins;
+    {   // the contact surface, cell by cell: the caller's (trimesh: displaced surface with vertical faces) or the continuous one of the samples
+      const size_t nr = (size_t)cfg->hf_rows - 1, nc = (size_t)cfg->hf_cols - 1;
+      std::vector<Go2Cell> cells(nr * nc);
+      for (size_t i = 0; i < nr; ++i) for (size_t j = 0; j < nc; ++j) {
+        Go2Cell& q = cells[i * nc + j];
+        if (cfg->hf_cells) for (int k = 0; k < 4; ++k) q.h[k] = cfg->hf_cells[(i * nc + j) * 4 + k];
+        else { const int16_t* h = cfg->hf_samples; const size_t C_ = (size_t)cfg->hf_cols; q.h[0] = h[i * C_ + j]; q.h[1] = h[(i + 1) * C_ + j]; q.h[2] = h[i * C_ + j + 1]; q.h[3] = h[(i + 1) * C_ + j + 1]; }
+      }
+      s->d_cells = (Go2Cell*)dev_alloc(s, cells.size() * sizeof(Go2Cell));
+      if (!s->d_cells) { go2sim_destroy(s); FAIL(GO2SIM_ENOMEM, "allocation failed"); }
+      dev_upload(s->d_cells, cells.data(), cells.size() * sizeof(Go2Cell)); p.hf_cells = s->d_cells;
+    }
     type_id.assign(cfg->terrain_type_id, cfg->terrain_type_id + cfg->terrain_num_types); torig.assign(cfg->terrain_origins, cfg->terrain_origins + no);
   }
-  s->cfg.hf_samples = nullptr; s->cfg.terrain_origins = nullptr; s->cfg.terrain_type_id = nullptr;
+  s->cfg.hf_samples = nullptr; s->cfg.hf_cells = nullptr; s->cfg.terrain_origins = nullptr; s->cfg.terrain_type_id = nullptr;
 
   // ---- creation-time per-env quantities (legged_robot.py:320-402, :1054-1091), same Philox slots as the oracle ----
   const uint64_t INIT = 0xFFFFFFFFFFFFFFFFull;
@@ -1028,6 +1050,19 @@ int go2sim_debug_torque_trace(Go2Sim* s, const float* actions_raw, const float* 
   }
 #else
   hipLaunchKernelGGL(go2_torque_trace_kernel, dim3((s->N + 15) / 16), dim3(64), 0, (hipStream_t)stream, s->d_blk, actions_raw, dof, out);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+int go2sim_debug_contact_query(Go2Sim* s, const float* pts, float* out, int32_t n, void* stream) {
+  if (!s || !pts || !out || n <= 0) FAIL(GO2SIM_EINVAL, "bad argument");
+#ifdef GO2_EMU
+  (void)stream;
+  for (int i = 0; i < n; ++i) { static thread_local LegPhys ph; float gap; V3 nn;
+    ph.contact_query(s->d_blk->L, s->d_blk->p.hf_cells, v3(pts[4 * i], pts[4 * i + 1], pts[4 * i + 2]), pts[4 * i + 3], &gap, &nn);
+    out[4 * i] = gap; out[4 * i + 1] = nn.x; out[4 * i + 2] = nn.y; out[4 * i + 3] = nn.z; }
+#else
+  hipLaunchKernelGGL(go2_contact_query_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, s->d_blk, pts, out, n);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

@@ -76,8 +76,6 @@ class LeggedRobot(BaseTask):
             c.terrain_mode = 0
         elif mesh in ("heightfield", "trimesh"):
             # create_sim (:292-310): the Terrain is built on the host; the library copies the int16 samples to HBM at create.
-            # 'trimesh' collides against the same triangulated grid (the slope_treshold wall correction of
-            # convert_heightfield_to_trimesh is not applied: DESIGN.md "terrain").
             from ...utils.terrain import Terrain
             self.terrain = Terrain(cfg.terrain, c.num_envs_global)
             hs = np.ascontiguousarray(self.terrain.heightsamples, dtype=np.int16)
@@ -91,6 +89,13 @@ class LeggedRobot(BaseTask):
             if ids.shape[0] != cfg.terrain.num_cols:
                 raise ValueError("terrain.cols2id has %d entries for %d columns" % (ids.shape[0], cfg.terrain.num_cols))
             self._terrain_host = (hs, org, ids)                                    # keep alive until go2sim_create has copied them
+            if mesh == "trimesh":
+                # _create_trimesh (:1127-1141) hands PhysX the mesh convert_heightfield_to_trimesh builds WITH terrain.slope_treshold: steep
+                # edges become vertical faces.  The library's contact query gets that surface cell by cell (utils/terrain.py)
+                cells = np.ascontiguousarray(self.terrain.cell_heights, dtype=np.int16)
+                self._terrain_host = (hs, org, ids, cells)
+                c.hf_cells = cells.ctypes.data_as(type(c.hf_cells))
+                c.hf_walls = 1
             c.terrain_mode = 1
             c.hf_rows, c.hf_cols = self.terrain.tot_rows, self.terrain.tot_cols
             c.hf_samples = hs.ctypes.data_as(type(c.hf_samples))
@@ -282,7 +287,7 @@ class LeggedRobot(BaseTask):
         self.custom_origins = self.cfg.terrain.mesh_type in ("heightfield", "trimesh")
         self._level_groups = None
         if self.custom_origins:                                                      # _create_heightfield/_get_env_origins (:964-1079)
-            hs, org, ids = self._terrain_host
+            hs, org, ids = self._terrain_host[:3]
             self.height_samples = torch.from_numpy(hs).view(self.terrain.tot_rows, self.terrain.tot_cols).to(dev)
             self.terrain_cols2id = torch.from_numpy(ids).to(dev).long()
             if len(self.terrain.cols2id):                                            # (:1074-1075) no terrain_ids attribute without a curriculum layout

@@ -153,16 +153,9 @@ def convert_heightfield_to_trimesh(height_field_raw, horizontal_scale, vertical_
     yy, xx = np.meshgrid(np.linspace(0, (cols - 1) * horizontal_scale, cols), np.linspace(0, (rows - 1) * horizontal_scale, rows))
     if slope_threshold is not None:
         thr = slope_threshold * horizontal_scale / vertical_scale           # in height units per cell
-        h = hf.astype(np.int64)
-        move_x, move_y, move_c = np.zeros((rows, cols)), np.zeros((rows, cols)), np.zeros((rows, cols))
-        move_x[:rows - 1, :] += h[1:, :] - h[:rows - 1, :] > thr
-        move_x[1:, :] -= h[:rows - 1, :] - h[1:, :] > thr
-        move_y[:, :cols - 1] += h[:, 1:] - h[:, :cols - 1] > thr
-        move_y[:, 1:] -= h[:, :cols - 1] - h[:, 1:] > thr
-        move_c[:rows - 1, :cols - 1] += h[1:, 1:] - h[:rows - 1, :cols - 1] > thr
-        move_c[1:, 1:] -= h[:rows - 1, :cols - 1] - h[1:, 1:] > thr
-        xx = xx + (move_x + move_c * (move_x == 0)) * horizontal_scale
-        yy = yy + (move_y + move_c * (move_y == 0)) * horizontal_scale
+        mvx, mvy = _vertex_moves(hf.astype(np.int64), thr)
+        xx = xx + mvx * horizontal_scale
+        yy = yy + mvy * horizontal_scale
     vertices = np.zeros((rows * cols, 3), dtype=np.float32)
     vertices[:, 0], vertices[:, 1], vertices[:, 2] = xx.flatten(), yy.flatten(), hf.flatten() * vertical_scale
     triangles = -np.ones((2 * (rows - 1) * (cols - 1), 3), dtype=np.uint32)
@@ -173,6 +166,77 @@ def convert_heightfield_to_trimesh(height_field_raw, horizontal_scale, vertical_
         triangles[a:b:2, 0], triangles[a:b:2, 1], triangles[a:b:2, 2] = ind0, ind3, ind1
         triangles[a + 1:b:2, 0], triangles[a + 1:b:2, 1], triangles[a + 1:b:2, 2] = ind0, ind2, ind3
     return vertices, triangles
+
+
+def _vertex_moves(h, thr):
+    """Per-vertex displacement (in cells) of convert_heightfield_to_trimesh's slope correction -> (move_x, move_y) int arrays in {-1, 0, 1}."""
+    rows, cols = h.shape
+    move_x, move_y, move_c = np.zeros((rows, cols)), np.zeros((rows, cols)), np.zeros((rows, cols))
+    move_x[:rows - 1, :] += h[1:, :] - h[:rows - 1, :] > thr
+    move_x[1:, :] -= h[:rows - 1, :] - h[1:, :] > thr
+    move_y[:, :cols - 1] += h[:, 1:] - h[:, :cols - 1] > thr
+    move_y[:, 1:] -= h[:, :cols - 1] - h[:, 1:] > thr
+    move_c[:rows - 1, :cols - 1] += h[1:, 1:] - h[:rows - 1, :cols - 1] > thr
+    move_c[1:, 1:] -= h[:rows - 1, :cols - 1] - h[1:, 1:] > thr
+    return (move_x + move_c * (move_x == 0)).astype(np.int64), (move_y + move_c * (move_y == 0)).astype(np.int64)
+
+
+def displaced_cell_heights(height_field_raw, horizontal_scale, vertical_scale, slope_threshold=None):
+    """The surface of the trimesh the reference hands PhysX (convert_heightfield_to_trimesh WITH its slope_treshold vertex displacement,
+    legged_gym/utils/terrain.py:46-49, legged_robot.py:1127-1141) in the form the simulator's contact query reads: for every grid cell
+    (i, j) the heights [h00, h10, h01, h11] of the displaced surface at the cell's four corners AS SEEN FROM INSIDE THE CELL
+    (int16, vertical_scale units) -> int16 [rows-1, cols-1, 4].
+
+    Without displacement the four numbers are the shared vertex samples and neighbouring cells agree on their common edge.  Where the
+    correction moved the lower vertex of a steep edge under the upper one, the 1-cell ramp becomes a flat continuation of the lower level
+    ending in a vertical face: neighbouring cells then DISAGREE on their common edge, and that disagreement is the wall (its bottom = this
+    cell's edge heights, its top = the neighbour's).  Exact wherever the displaced surface over a cell is one plane or two planes split along
+    the cell's own diagonal (stairs, obstacles, stepping stones, gaps, pits, gentle slopes); elsewhere the cell's two facets interpolate
+    the displaced surface at the corners.  Only cells within two cells of a displaced vertex are recomputed (geometrically: the displaced
+    triangle covering a point just inside each corner, highest one if the displacement folded the surface)."""
+    hf = np.asarray(height_field_raw)
+    h = hf.astype(np.int64)
+    rows, cols = h.shape
+    cells = np.stack([h[:-1, :-1], h[1:, :-1], h[:-1, 1:], h[1:, 1:]], axis=-1).astype(np.float64)
+    if slope_threshold is None:
+        return cells.astype(np.int16)
+    mx, my = _vertex_moves(h, slope_threshold * horizontal_scale / vertical_scale)
+    moved = (mx != 0) | (my != 0)
+    if not moved.any():
+        return cells.astype(np.int16)
+    pad = np.pad(moved, 2)
+    aff = np.zeros((rows - 1, cols - 1), bool)
+    for a in range(4):
+        for b in range(4):
+            aff |= pad[1 + a:1 + a + rows - 1, 1 + b:1 + b + cols - 1]
+    ii, jj = np.nonzero(aff)
+    vx, vy, vz = np.arange(rows)[:, None] + mx, np.arange(cols)[None, :] + my, h.astype(np.float64)
+    eps = 1e-3
+    for k, (cx, cy) in enumerate(((0, 0), (1, 0), (0, 1), (1, 1))):
+        px = ii + cx + (eps if cx == 0 else -eps)
+        py = jj + cy + (eps if cy == 0 else -eps)
+        best = np.full(ii.shape, -np.inf)
+        for di in (-1, 0, 1):
+            for dj in (-1, 0, 1):
+                a_, b_ = ii - di, jj - dj
+                ok = (a_ >= 0) & (a_ < rows - 1) & (b_ >= 0) & (b_ < cols - 1)
+                a, b = np.clip(a_, 0, rows - 2), np.clip(b_, 0, cols - 2)
+                for tri in (((0, 0), (1, 1), (0, 1)), ((0, 0), (1, 0), (1, 1))):      # triangles (ind0, ind3, ind1), (ind0, ind2, ind3)
+                    X = [vx[a + o[0], b + o[1]].astype(np.float64) for o in tri]
+                    Y = [vy[a + o[0], b + o[1]].astype(np.float64) for o in tri]
+                    Z = [vz[a + o[0], b + o[1]] for o in tri]
+                    det = (Y[1] - Y[2]) * (X[0] - X[2]) + (X[2] - X[1]) * (Y[0] - Y[2])
+                    good = ok & (np.abs(det) > 1e-9)
+                    det = np.where(good, det, 1.0)
+                    l0 = ((Y[1] - Y[2]) * (px - X[2]) + (X[2] - X[1]) * (py - Y[2])) / det
+                    l1 = ((Y[2] - Y[0]) * (px - X[2]) + (X[0] - X[2]) * (py - Y[2])) / det
+                    l2 = 1.0 - l0 - l1
+                    inside = good & (l0 >= -1e-9) & (l1 >= -1e-9) & (l2 >= -1e-9)
+                    z = l0 * Z[0] + l1 * Z[1] + l2 * Z[2]
+                    best = np.where(inside & (z > best), z, best)
+        found = np.isfinite(best)
+        cells[ii[found], jj[found], k] = best[found]
+    return np.clip(np.rint(cells), -32768, 32767).astype(np.int16)
 
 
 KIND_NAMES = ("wave", "slope", "rough_slope", "stairs_up", "stairs_down", "obstacles", "stepping_stones", "gap", "flat")
@@ -220,6 +284,15 @@ class Terrain:
     @property
     def triangles(self):
         return self._mesh()[1]
+
+    @property
+    def cell_heights(self):
+        """int16 [tot_rows-1, tot_cols-1, 4]: what the simulator's contact query reads for mesh_type 'trimesh' — the displaced mesh's surface,
+        cell by cell (displaced_cell_heights).  For 'heightfield' the library derives the (continuous) cells from the samples itself."""
+        if getattr(self, "_cells", None) is None:
+            thr = self.cfg.slope_treshold if self.type == "trimesh" else None
+            self._cells = displaced_cell_heights(self.height_field_raw, self.cfg.horizontal_scale, self.cfg.vertical_scale, thr)
+        return self._cells
 
     def selected_terrain(self):
         """Every tile from ONE named generator (terrain.py:72-85; the reference's version dereferences attributes that do not

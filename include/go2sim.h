@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GO2SIM_ABI_VERSION 3   /* 3: Go2SimCfg gained max_linear_velocity / max_angular_velocity; go2sim_elu_backward_bias workspace is C*ceil(B/64) */
+#define GO2SIM_ABI_VERSION 4   /* 4: Go2SimCfg gained hf_cells / hf_walls (trimesh wall geometry); test hooks go2sim_debug_*;  3: 3: Go2SimCfg gained max_linear_velocity / max_angular_velocity; go2sim_elu_backward_bias workspace is C*ceil(B/64) */
 
 #define GO2SIM_EINVAL   (-1)  /* bad argument / config */
 #define GO2SIM_ENOMEM   (-2)
@@ -132,6 +132,13 @@ typedef struct Go2SimCfg {
   int32_t  hf_rows, hf_cols;  /* height_samples[hf_rows][hf_cols], x -> rows (legged_robot.py:1213-1220) */
   float    hf_hscale, hf_vscale, hf_border;
   const int16_t* hf_samples;  /* HOST pointer, copied at create; NULL for plane */
+  const int16_t* hf_cells;    /* HOST [hf_rows-1][hf_cols-1][4], copied at create, or NULL: the contact surface cell by cell — heights (vscale units)
+                               * of the surface at the cell's corners (i,j) (i+1,j) (i,j+1) (i+1,j+1) as seen from INSIDE the cell.  NULL = the
+                               * continuous surface of hf_samples (mesh_type 'heightfield').  mesh_type 'trimesh' passes the surface of the mesh
+                               * convert_heightfield_to_trimesh builds with terrain.slope_treshold (legged_gym/utils/terrain.py:46-49,
+                               * legged_robot.py:1127-1141): 1-cell ramps become flat cells ending in a vertical face, i.e. neighbouring cells
+                               * that disagree on their common edge (go2_rl_gym_amd/utils/terrain.py:displaced_cell_heights). */
+  int32_t  hf_walls;          /* 1: the contact query also tests the vertical faces between disagreeing neighbour cells (set with hf_cells) */
   int32_t  terrain_num_levels, terrain_num_types; /* 10 x 20 */
   const float* terrain_origins; /* HOST [levels][types][3]; NULL for plane */
   const int32_t* terrain_type_id; /* HOST [types] -> terrain kind 0..8 (terrain.cols2id); NULL for plane */
@@ -338,6 +345,10 @@ int  go2sim_debug_torque_trace(Go2Sim* h, const float* actions_raw, const float*
 /* The individually rounded fp32 operations the height-scan INDEX arithmetic is built from (csrc/go2_math.h go2_*_rn) over arrays:
  * out [6][n] = a*b, a+b, a-b, a/b, sqrt(|a|), a/b[0] (through the double-precision reciprocal) — each must equal the IEEE result. */
 int  go2sim_debug_strict_ops(const float* a, const float* b, float* out, int32_t n, void* stream);
+/* The simulator's sphere-vs-terrain contact query (what replaces PhysX's mesh / heightfield collision for the robot's collision spheres):
+ * pts [n][4] = world centre x, y, z and radius -> out [n][4] = gap (< 0: penetration) and unit contact normal of the deepest contact
+ * (facet under the centre; with hf_walls also the vertical faces of the trimesh). */
+int  go2sim_debug_contact_query(Go2Sim* h, const float* pts, float* out, int32_t n, void* stream);
 /* Measurement aid: a kernel with the step kernel's HBM access pattern (16 environments per 256-thread workgroup, field-major fields
  * [f][N], 4 bytes per environment and field) and a known byte count: reads `nread` fields of `in` [nread][N], writes `nwrite` fields of
  * `out` [nwrite][N].  Profiled with rocprofv3 FETCH_SIZE / WRITE_SIZE it calibrates those counters for this pattern (tools/pmc_pass.sh). */

@@ -219,7 +219,7 @@ struct Go2Sim {
   Go2SimCfg cfg;
   Go2SimBuffers b;
   int N;
-  int16_t* hf; float* terrain_origins; int32_t* terrain_type_id;
+  int16_t* hf; int16_t* cells; int walls; float* terrain_origins; int32_t* terrain_type_id;
   int32_t* terrain_kind;   /* [N] terrain kind 0..8 of each env, -1 on a plane */
   const float* injected;   /* uniforms for the next step, or NULL */
   float* inj_storage;
@@ -378,22 +378,45 @@ static void aba(const Go2Sim* s, const Kin* k, const R* qd, const R* tau, R* acc
 }
 
 /* ---------------- terrain ------------------------------------------------------------------------ */
-static void terrain_query(const Go2Sim* s, R x, R y, R* h, R* n) {
-  if (s->cfg.terrain_mode == 0) { *h = 0; n[0]=0; n[1]=0; n[2]=1; return; }
+/* Contact of a sphere (world centre c, radius r) with the terrain -> gap (< 0 = penetration) and unit normal n.  The surface is given
+ * cell by cell (s->cells: heights at the corners (i,j) (i+1,j) (i,j+1) (i+1,j+1) as seen from inside the cell, go2sim.h hf_cells); the
+ * contact is the deepest of the facet under the centre (two triangles per cell split along (i,j)-(i+1,j+1), the diagonal
+ * isaacgym.terrain_utils.convert_heightfield_to_trimesh uses) and, with hf_walls, the vertical faces that stand on the cell's edges where
+ * the neighbouring cell's edge is higher (mesh_type 'trimesh' with slope_treshold, legged_robot.py:1127-1141). */
+static R clampR(R x, R lo, R hi) { return x < lo ? lo : (x > hi ? hi : x); }
+static void wall_face(const Go2Sim* s, int inside, int ni, int nj, R a0, R a1, int k0, int k1, R t, R d, R nx, R ny, const R* c, R r, R* g, R* n) {
+  if (!inside) return;
+  R vs = (R)s->cfg.hf_vscale; int nc = s->cfg.hf_cols - 1;
+  const int16_t* b = s->cells + ((size_t)ni*nc + nj)*4;
+  R bot = a0 + t*(a1-a0), b0 = b[k0]*vs, top = b0 + t*(b[k1]*vs - b0);
+  if (!(top - bot > RC(0.5)*vs)) return;
+  R qz = clampR(c[2], bot, top), dz = c[2]-qz, dist = SQRT(d*d + dz*dz), gw = dist - r;
+  if (gw < *g) { *g = gw; if (dist > RC(1e-9)) { n[0] = nx*d/dist; n[1] = ny*d/dist; n[2] = dz/dist; } else { n[0]=nx; n[1]=ny; n[2]=0; } }
+}
+static void contact_query(const Go2Sim* s, const R* c, R r, R* gap, R* n) {
+  if (s->cfg.terrain_mode == 0) { *gap = c[2] - r; n[0]=0; n[1]=0; n[2]=1; return; }
   R hs = (R)s->cfg.hf_hscale, vs = (R)s->cfg.hf_vscale;
-  R fx = (x + (R)s->cfg.hf_border)/hs, fy = (y + (R)s->cfg.hf_border)/hs;
-  int rows = s->cfg.hf_rows, cols = s->cfg.hf_cols;
+  R fx = (c[0] + (R)s->cfg.hf_border)/hs, fy = (c[1] + (R)s->cfg.hf_border)/hs;
+  int rows = s->cfg.hf_rows, cols = s->cfg.hf_cols, nc = cols-1;
   int i = (int)FLOOR(fx), j = (int)FLOOR(fy);
   if (i<0) i=0; if (i>rows-2) i=rows-2; if (j<0) j=0; if (j>cols-2) j=cols-2;
-  R u = fx - i, v = fy - j; if (u<0) u=0; if (u>1) u=1; if (v<0) v=0; if (v>1) v=1;
-  R h00 = s->hf[i*cols+j]*vs, h10 = s->hf[(i+1)*cols+j]*vs, h01 = s->hf[i*cols+j+1]*vs, h11 = s->hf[(i+1)*cols+j+1]*vs;
+  R u = clampR(fx - i, 0, 1), v = clampR(fy - j, 0, 1);
+  const int16_t* q = s->cells + ((size_t)i*nc + j)*4;
+  R h00 = q[0]*vs, h10 = q[1]*vs, h01 = q[2]*vs, h11 = q[3]*vs;
   R dx, dy;
-  /* two triangles per cell, split along (i,j)-(i+1,j+1): the diagonal isaacgym.terrain_utils.convert_heightfield_to_trimesh uses */
   if (u >= v) { dx = h10-h00; dy = h11-h10; }
   else { dx = h11-h01; dy = h01-h00; }
-  *h = h00 + u*dx + v*dy;
+  R h = h00 + u*dx + v*dy;
   R nx = -dx/hs, ny = -dy/hs, inv = 1/SQRT(nx*nx+ny*ny+1);
   n[0]=nx*inv; n[1]=ny*inv; n[2]=inv;
+  R g = (c[2]-h)*inv - r;
+  if (s->walls) {
+    wall_face(s, i > 0,      i-1, j,   h00, h01, 1, 3, v, u*hs,     1, 0, c, r, &g, n);
+    wall_face(s, i < rows-2, i+1, j,   h10, h11, 0, 2, v, (1-u)*hs, -1, 0, c, r, &g, n);
+    wall_face(s, j > 0,      i,   j-1, h00, h10, 2, 3, u, v*hs,     0, 1, c, r, &g, n);
+    wall_face(s, j < cols-2, i,   j+1, h01, h11, 0, 1, u, (1-v)*hs, 0, -1, c, r, &g, n);
+  }
+  *gap = g;
 }
 
 /* ---------------- one physics substep ------------------------------------------------------------ */
@@ -475,14 +498,14 @@ static void physics_substep(Go2Sim* s, int e, R* root, R* q, R* qd, const R* tau
         if (slot==0) p = &kFootPts[lane];
         else if (ci < GO2_LEG_OTHER_PTS) p = &kLegOther[lane][ci];
         else { int bi = ci - GO2_LEG_OTHER_PTS; if ((bi & 3) != lane) continue; p = &kBasePts[bi]; }
-        R c[3], hh, n[3]; sphere_world(&k, p, c); terrain_query(s, c[0], c[1], &hh, n);
-        R gap = (c[2]-hh)*n[2] - (R)p->r;
+        R c[3], gap, n[3]; sphere_world(&k, p, c); contact_query(s, c, (R)p->r, &gap, n);
         if (!best || gap < best_gap) { best = p; best_gap = gap; memcpy(best_c,c,sizeof(c)); memcpy(best_n,n,sizeof(n)); }
       }
       if (best_gap < (R)cfg->contact_offset) {
         r->active = 1; r->body = best->body; r->mu = mu;
         memcpy(r->n, best_n, sizeof(best_n));
-        R ex[3] = {1,0,0}; R dn = dot3(ex, r->n); for (int i=0;i<3;++i) r->t1[i] = ex[i]-dn*r->n[i];
+        R ex[3] = {1,0,0}; if (!(FABS(r->n[0]) < RC(0.9))) { ex[0]=0; ex[1]=1; }   /* world x, or world y beside a face that looks along x */
+        R dn = dot3(ex, r->n); for (int i=0;i<3;++i) r->t1[i] = ex[i]-dn*r->n[i];
         R inv = 1/SQRT(dot3(r->t1,r->t1)); for (int i=0;i<3;++i) r->t1[i]*=inv; cross3(r->n, r->t1, r->t2);
         R pw[3]; for (int i=0;i<3;++i) pw[i] = best_c[i] - (R)best->r*r->n[i];
         R Jw[3][NV]; point_jacobian(&k, best->link, pw, Jw);
@@ -968,10 +991,15 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
       s->height_mask[n] = (ix>=6 && ix<=10 && iy>=4 && iy<=6); /* |x|<=0.2, |y|<=0.15 on the 0.1 grid (fp-safe form) */ s->num_height_mask += s->height_mask[n]; ++n; } }
   if (cfg->terrain_mode != 0) {
     size_t nh=(size_t)cfg->hf_rows*cfg->hf_cols; s->hf=(int16_t*)malloc(nh*sizeof(int16_t)); memcpy(s->hf,cfg->hf_samples,nh*sizeof(int16_t));
+    { size_t nr=(size_t)cfg->hf_rows-1, ncell=(size_t)cfg->hf_cols-1, C_=(size_t)cfg->hf_cols; s->cells=(int16_t*)malloc(nr*ncell*4*sizeof(int16_t));
+      if (cfg->hf_cells) memcpy(s->cells, cfg->hf_cells, nr*ncell*4*sizeof(int16_t));
+      else for (size_t i=0;i<nr;++i) for (size_t j=0;j<ncell;++j) { int16_t* q=s->cells+(i*ncell+j)*4; const int16_t* h=cfg->hf_samples;
+        q[0]=h[i*C_+j]; q[1]=h[(i+1)*C_+j]; q[2]=h[i*C_+j+1]; q[3]=h[(i+1)*C_+j+1]; }
+      s->walls = (cfg->hf_cells && cfg->hf_walls) ? 1 : 0; }
     size_t no=(size_t)cfg->terrain_num_levels*cfg->terrain_num_types*3; s->terrain_origins=(float*)malloc(no*sizeof(float)); for (size_t i=0;i<no;++i) s->terrain_origins[i]=(float)cfg->terrain_origins[i];
     s->terrain_type_id=(int32_t*)malloc(sizeof(int32_t)*cfg->terrain_num_types); memcpy(s->terrain_type_id,cfg->terrain_type_id,sizeof(int32_t)*cfg->terrain_num_types);
   }
-  s->cfg.hf_samples=NULL; s->cfg.terrain_origins=NULL; s->cfg.terrain_type_id=NULL;
+  s->cfg.hf_samples=NULL; s->cfg.hf_cells=NULL; s->cfg.terrain_origins=NULL; s->cfg.terrain_type_id=NULL;
   /* per-env creation-time quantities (legged_robot.py:320-402, :1054-1091) */
   for (int b=0;b<64;++b) s->friction_buckets[b] = urange((R)u01(cfg->seed,GO2_ENV_GLOBAL,(uint32_t)b,GO2_STEP_INIT),(R)cfg->friction_range[0],(R)cfg->friction_range[1]);
   int Ng = cfg->num_envs_global;
@@ -1006,7 +1034,7 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
 void go2sim_destroy(Go2Sim* s) {
   if (!s) return;
   void** p = (void**)&s->b; for (size_t i=0;i<sizeof(Go2SimBuffers)/sizeof(void*);++i) free(p[i]);
-  free(s->hf); free(s->terrain_origins); free(s->terrain_type_id); free(s->terrain_kind); free(s->inj_storage); free(s);
+  free(s->hf); free(s->cells); free(s->terrain_origins); free(s->terrain_type_id); free(s->terrain_kind); free(s->inj_storage); free(s);
 }
 int go2sim_get_buffers(Go2Sim* s, Go2SimBuffers* out) { if (!s||!out) return GO2SIM_EINVAL; *out = s->b; return 0; }
 
@@ -1177,6 +1205,12 @@ int go2o_torque_trace(Go2Sim* s, const float* actions_raw, const float* dof, flo
 
 int go2sim_debug_torque_trace(Go2Sim* s, const float* actions_raw, const float* dof, float* out, void* stream) {
   (void)stream; if (!s||!actions_raw||!dof||!out) return GO2SIM_EINVAL; return go2o_torque_trace(s, actions_raw, dof, out);
+}
+int go2sim_debug_contact_query(Go2Sim* s, const float* pts, float* out, int32_t n, void* stream) {
+  (void)stream; if (!s||!pts||!out||n<=0) return GO2SIM_EINVAL;
+  for (int i=0;i<n;++i) { R c[3]={(R)pts[4*i],(R)pts[4*i+1],(R)pts[4*i+2]}, gap, nn[3]; contact_query(s, c, (R)pts[4*i+3], &gap, nn);
+    out[4*i]=(float)gap; out[4*i+1]=(float)nn[0]; out[4*i+2]=(float)nn[1]; out[4*i+3]=(float)nn[2]; }
+  return 0;
 }
 int go2sim_debug_traffic_probe(const float* in, float* out, int32_t N, int32_t nread, int32_t nwrite, void* stream) {
   (void)stream; if (!in||!out||N<=0||nread<0||nwrite<0) return GO2SIM_EINVAL;

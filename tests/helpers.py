@@ -272,12 +272,13 @@ STEP_STATE = ["root_states", "dof_state", "last_actions", "last_last_actions", "
               "friction_coeffs", "restitution_coeffs", "added_base_mass", "added_base_com", "link_mass_ratio", "env_origins", "terrain_levels"]
 
 
-def heightfield_overrides(num_envs_global, seed=11, **terrain_kw):
-    """Go2SimCfg overrides for the task=go2 rough terrain, built the way LeggedRobot._fill_cfg does (utils/terrain.py on the host)."""
+def heightfield_overrides(num_envs_global, seed=11, mesh_type="heightfield", **terrain_kw):
+    """Go2SimCfg overrides for the task=go2 rough terrain, built the way LeggedRobot._fill_cfg does (utils/terrain.py on the host).
+    mesh_type 'trimesh' (the registered tasks' default) adds the displaced surface with its vertical faces (hf_cells, hf_walls)."""
     from go2_rl_gym_amd.envs.go2.go2_config import GO2Cfg
     from go2_rl_gym_amd.utils.terrain import Terrain
     tc = GO2Cfg().terrain
-    tc.mesh_type = "heightfield"
+    tc.mesh_type = mesh_type
     for k, v in terrain_kw.items():
         setattr(tc, k, v)
     np.random.seed(seed)
@@ -287,4 +288,6 @@ def heightfield_overrides(num_envs_global, seed=11, **terrain_kw):
               terrain_origins=np.ascontiguousarray(t.env_origins, np.float32), terrain_type_id=np.ascontiguousarray(t.cols2id, np.int32),
               terrain_num_levels=tc.num_rows, terrain_num_types=tc.num_cols, terrain_curriculum=int(tc.curriculum),
               max_init_terrain_level=tc.max_init_terrain_level, measure_heights=int(tc.measure_heights))
+    if mesh_type == "trimesh":
+        ov.update(hf_cells=np.ascontiguousarray(t.cell_heights, np.int16), hf_walls=1)
     return t, ov

@@ -87,12 +87,13 @@ def test_one_step_parity_vs_oracle(hip):
     so.close(); sd.close()
 
 
-def test_heightfield_one_step_parity_vs_oracle(hip):
+@pytest.mark.parametrize("mesh_type", ["heightfield", "trimesh"])
+def test_heightfield_one_step_parity_vs_oracle(hip, mesh_type):
     """Same protocol on the rough curriculum map (all 20 terrain columns): contact against sloped / stepped facets,
-    height scan, terrain curriculum."""
+    height scan, terrain curriculum.  trimesh: the displaced mesh with its vertical faces (the registered tasks' default mesh type)."""
     from helpers import heightfield_overrides
     N = 80
-    t, ov = heightfield_overrides(N)
+    t, ov = heightfield_overrides(N, mesh_type=mesh_type)
     so = HostSim(load_oracle(), num_envs=N, **ov)
     sd = DeviceSim(hip, num_envs=N, **ov)
     so.reset_all(); sd.reset_all()
@@ -645,3 +646,34 @@ def test_parity_outliers_are_conditioning_not_fast_math(hip):
         assert excess[b] <= 0.002 * tot * len(tol), (b, excess, worst_ratio)      # (almost) every env is inside max(tol, 8 x its own fp32 conditioning)
     for s_ in [so, s64] + list(sims.values()):
         s_.close()
+
+
+def test_trimesh_walls_on_gpu(hip):
+    """Row f4 on the device: the contact query against the trimesh's vertical faces equals the oracle's on random spheres over a staircase,
+    and the known-answer behaviour of tests/test_trimesh_walls.py (feet pressed into a riser end up resting against its face)."""
+    import torch
+    import test_trimesh_walls as tw
+    from go2_rl_gym_amd.utils.terrain import SubTerrain, displaced_cell_heights, pyramid_stairs_terrain
+    t = SubTerrain("t", width=60, length=60, vertical_scale=tw.VS, horizontal_scale=tw.HS)
+    pyramid_stairs_terrain(t, step_width=0.31, step_height=0.15, platform_size=2.0)
+    hf = np.ascontiguousarray(t.height_field_raw)
+    ov = dict(terrain_mode=1, hf_rows=60, hf_cols=60, hf_hscale=tw.HS, hf_vscale=tw.VS, hf_border=0.0, hf_samples=hf,
+              terrain_origins=np.zeros((1, 1, 3), np.float32), terrain_type_id=np.zeros(1, np.int32), terrain_num_levels=1, terrain_num_types=1,
+              terrain_curriculum=0, max_init_terrain_level=0, hf_cells=np.ascontiguousarray(displaced_cell_heights(hf, tw.HS, tw.VS, 0.75)), hf_walls=1)
+    so, sd = HostSim(load_oracle(), num_envs=1, **ov), DeviceSim(hip, num_envs=1, **ov)
+    rng = np.random.default_rng(2)
+    n = 20000
+    pts = np.stack([rng.uniform(0.3, 5.6, n), rng.uniform(0.3, 5.6, n), rng.uniform(-0.05, 1.3, n), rng.uniform(0.0, 0.05, n)], 1).astype(np.float32)
+    want = tw.query(load_oracle(), so, pts)
+    dp, do = torch.as_tensor(pts, device="cuda:0"), torch.zeros(n, 4, device="cuda:0")
+    assert hip.go2sim_debug_contact_query(sd.h, C.c_void_p(dp.data_ptr()), C.c_void_p(do.data_ptr()), n, sd._st()) == 0
+    torch.cuda.synchronize()
+    got = do.cpu().numpy()
+    d = np.abs(got - want).max(1)
+    # fp32 on both sides; a sphere centre within rounding of a cell boundary or of the two facets' diagonal may be assigned to the other side
+    assert np.quantile(d, 0.999) < 2e-5 and (d > 1e-3).mean() < 2e-3, (float(np.quantile(d, 0.999)), float((d > 1e-3).mean()))
+    assert (want[:, 3] < 0.5).mean() > 0.02           # the sample did hit vertical faces
+    so.close(); sd.close()
+    tri = tw.settle_against_riser(hip, DeviceSim, "trimesh")
+    assert np.all(np.abs(tri[:, 0] + 0.022 - 6.0) < 0.006) and np.all(np.abs(tri[:, 2] - 0.022) < 0.006), tri
+    assert np.all(tw.settle_against_riser(hip, DeviceSim, "heightfield")[:, 0] < 5.93)

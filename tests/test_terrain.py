@@ -225,3 +225,69 @@ def test_terrain_class_exposes_the_trimesh_lazily():
     assert t._trimesh is None
     assert t.vertices.shape == (t.tot_rows * t.tot_cols, 3) and t.triangles.shape == (2 * (t.tot_rows - 1) * (t.tot_cols - 1), 3)
     assert abs(float(t.vertices[:, 2].max()) - float(t.height_field_raw.max()) * tc.vertical_scale) < 1e-6
+
+
+def _raycast_down(vertices, triangles, pts):
+    """Highest intersection of the vertical line through each (x, y) with the triangle mesh (brute force, small meshes only)."""
+    v = vertices.astype(np.float64)
+    t0, t1, t2 = v[triangles[:, 0]], v[triangles[:, 1]], v[triangles[:, 2]]
+    out = np.full(len(pts), -np.inf)
+    for k, (x, y) in enumerate(pts):
+        det = (t1[:, 1] - t2[:, 1]) * (t0[:, 0] - t2[:, 0]) + (t2[:, 0] - t1[:, 0]) * (t0[:, 1] - t2[:, 1])
+        ok = np.abs(det) > 1e-12
+        d = np.where(ok, det, 1.0)
+        l0 = ((t1[:, 1] - t2[:, 1]) * (x - t2[:, 0]) + (t2[:, 0] - t1[:, 0]) * (y - t2[:, 1])) / d
+        l1 = ((t2[:, 1] - t0[:, 1]) * (x - t2[:, 0]) + (t0[:, 0] - t2[:, 0]) * (y - t2[:, 1])) / d
+        l2 = 1 - l0 - l1
+        ins = ok & (l0 >= -1e-9) & (l1 >= -1e-9) & (l2 >= -1e-9)
+        if ins.any():
+            out[k] = (l0 * t0[:, 2] + l1 * t1[:, 2] + l2 * t2[:, 2])[ins].max()
+    return out
+
+
+@pytest.mark.parametrize("kind", ["stairs", "obstacles", "slope"])
+def test_displaced_cell_heights_reproduce_the_trimesh_surface(kind):
+    """utils/terrain.py:displaced_cell_heights (what the contact query reads for mesh_type 'trimesh') against a vertical ray cast onto the
+    mesh convert_heightfield_to_trimesh builds WITH the slope_treshold displacement (legged_gym/utils/terrain.py:46-49): same surface
+    height at random points; risers are vertical faces (neighbouring cells disagree on their common edge), not 1-cell ramps."""
+    from go2_rl_gym_amd.utils.terrain import (SubTerrain, convert_heightfield_to_trimesh, discrete_obstacles_terrain, displaced_cell_heights,
+                                              pyramid_sloped_terrain, pyramid_stairs_terrain)
+    np.random.seed(3)
+    hs, vs, thr = 0.1, 0.005, 0.75
+    t = SubTerrain("t", width=60, length=60, vertical_scale=vs, horizontal_scale=hs)
+    if kind == "stairs":
+        pyramid_stairs_terrain(t, step_width=0.31, step_height=0.15, platform_size=2.0)
+    elif kind == "obstacles":
+        discrete_obstacles_terrain(t, 0.15, 1.0, 2.0, 20, platform_size=2.0)
+    else:
+        pyramid_sloped_terrain(t, slope=0.3, platform_size=2.0)
+    hf = t.height_field_raw
+    cells = displaced_cell_heights(hf, hs, vs, thr)
+    assert cells.shape == (59, 59, 4) and cells.dtype == np.int16
+    verts, tris = convert_heightfield_to_trimesh(hf, hs, vs, thr)
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(0.35, 5.55, size=(400, 2))
+    pts = pts[(np.abs(pts / hs - np.rint(pts / hs)) > 0.02).all(1)]          # not on a grid line (where a wall makes the height two-valued)
+    want = _raycast_down(verts, tris, pts)
+    i, j = np.floor(pts[:, 0] / hs).astype(int), np.floor(pts[:, 1] / hs).astype(int)
+    u, v = pts[:, 0] / hs - i, pts[:, 1] / hs - j
+    c = cells[i, j].astype(np.float64) * vs
+    got = np.where(u >= v, c[:, 0] + u * (c[:, 1] - c[:, 0]) + v * (c[:, 3] - c[:, 1]), c[:, 0] + u * (c[:, 3] - c[:, 2]) + v * (c[:, 2] - c[:, 0]))
+    d = np.abs(got - want)
+    if kind == "slope":
+        assert d.max() < 1e-6                                              # (the mesh vertices are float32)
+    elif kind == "stairs":
+        assert d.max() <= vs * 0.51                                        # planes + vertical faces: exact up to the int16 rounding
+    else:
+        # box corners: the displaced mesh has small skew triangles there that a cell's two facets only interpolate at the corners
+        assert (d <= vs * 0.51).mean() >= 0.97 and d.max() < 0.05, (float((d <= vs * 0.51).mean()), float(d.max()))
+    plain = displaced_cell_heights(hf, hs, vs, None)
+    if kind == "slope":
+        np.testing.assert_array_equal(cells, plain)            # below the threshold nothing moves: continuous cells, no walls
+    else:
+        # walls: some neighbouring cells disagree on their common edge by a whole step; the un-displaced cells never do
+        jump = np.abs(cells[:-1, :, 1].astype(int) - cells[1:, :, 0].astype(int))
+        assert jump.max() >= int(0.15 / vs) - 1 and np.abs(plain[:-1, :, 1].astype(int) - plain[1:, :, 0].astype(int)).max() == 0
+        # and the 1-cell ramps are gone: inside every displaced cell the surface is (nearly) flat where the raw cell was a ramp
+        ramp = (plain.max(-1).astype(int) - plain.min(-1).astype(int)) >= int(0.15 / vs) - 1
+        assert ramp.any() and ((cells.max(-1).astype(int) - cells.min(-1).astype(int))[ramp] <= 1).mean() > 0.75      # (the rest: box-corner cells)

@@ -1,0 +1,183 @@
+"""Scope row f4: mesh_type 'trimesh' — the registered tasks' default (legged_robot_config.py:16) — collides against the mesh the reference
+hands PhysX: convert_heightfield_to_trimesh WITH terrain.slope_treshold (legged_gym/utils/terrain.py:46-49, legged_robot.py:1127-1141), whose
+steep edges are vertical faces, not 1-cell ramps.
+
+  * geometry: the contact query (go2sim_debug_contact_query) on a stair riser — horizontal normal beside the face, vertical on the treads,
+    slanted over the nosing — in the oracle and in the lane emulation of the HIP code, and equal to the exact sphere-to-mesh distance
+    (brute force over the displaced triangles) wherever a face or a tread is the closest feature;
+  * 'heightfield' on the same samples ramps over the same step (what round 1 did for trimesh too);
+  * behaviour: a robot whose front feet are pressed sideways into a 15-cm riser is pushed BACK by it (horizontal contact force on the feet),
+    on the ramp of the heightfield it is pushed up instead.
+CPU only (the HIP run of the same checks: tests/test_gpu_parity.py::test_trimesh_walls_on_gpu)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import HostSim, load_emu, load_oracle
+
+HS, VS, BORDER = 0.1, 0.005, 2.0
+STEP_H = 0.15
+
+
+def riser_world(mesh_type):
+    """A 12 m x 6 m map: level 0 for x < 6 m, one 15-cm step up at x = 6 m (world coordinates, after the border shift)."""
+    from go2_rl_gym_amd.utils.terrain import displaced_cell_heights
+    rows, cols = 161, 101
+    hf = np.zeros((rows, cols), np.int16)
+    k = int(round((6.0 + BORDER) / HS))                      # first sample of the upper level
+    hf[k:, :] = int(round(STEP_H / VS))
+    ov = dict(terrain_mode=1, hf_rows=rows, hf_cols=cols, hf_hscale=HS, hf_vscale=VS, hf_border=BORDER, hf_samples=np.ascontiguousarray(hf),
+              terrain_origins=np.zeros((1, 1, 3), np.float32), terrain_type_id=np.zeros(1, np.int32), terrain_num_levels=1, terrain_num_types=1,
+              terrain_curriculum=0, max_init_terrain_level=0, measure_heights=1)
+    if mesh_type == "trimesh":
+        ov.update(hf_cells=np.ascontiguousarray(displaced_cell_heights(hf, HS, VS, 0.75)), hf_walls=1)
+    return hf, ov
+
+
+def query(lib, s, pts):
+    pts = np.ascontiguousarray(pts, np.float32)
+    out = np.zeros((len(pts), 4), np.float32)
+    assert lib.go2sim_debug_contact_query(s.h, pts.ctypes.data, out.ctypes.data, len(pts), None) == 0
+    return out
+
+
+@pytest.mark.parametrize("which", ["oracle", "lane_emulation"])
+def test_riser_is_a_vertical_face(which):
+    lib = {"oracle": load_oracle, "lane_emulation": load_emu}[which]()
+    r = 0.022                                                   # the foot sphere
+    wall_x = 6.0                                                # the riser's face: the lower vertex was moved under the upper one
+    for mesh, expect_wall in (("trimesh", True), ("heightfield", False)):
+        _, ov = riser_world(mesh)
+        s = HostSim(lib, num_envs=1, **ov)
+        # beside the face, centre 5 cm above the lower tread, 3 cm in front of the face
+        g = query(lib, s, [[wall_x - 0.03, 1.0, 0.05, r]])[0]
+        if expect_wall:
+            np.testing.assert_allclose(g, [0.03 - r, -1.0, 0.0, 0.0], atol=2e-6)        # gap = distance to the face - r, normal horizontal, away from the face
+        else:
+            assert g[3] > 0.5 and g[1] < -0.5 and abs(g[1] + 0.832) < 0.01      # the 1-cell ramp: normal (-3, 0, 2) / sqrt(13)
+        # standing on the lower tread, far from the riser / on the upper tread
+        np.testing.assert_allclose(query(lib, s, [[4.0, 1.0, 0.05, r]])[0], [0.05 - r, 0, 0, 1], atol=2e-6)
+        np.testing.assert_allclose(query(lib, s, [[7.0, 1.0, STEP_H + 0.05, r]])[0], [0.05 - r, 0, 0, 1], atol=2e-6)
+        if expect_wall:
+            # over the nosing: centre above the top edge and 2 cm in front of it -> closest point is the edge, slanted normal
+            g = query(lib, s, [[wall_x - 0.02, 1.0, STEP_H + 0.02, r]])[0]
+            d = np.hypot(0.02, 0.02)
+            np.testing.assert_allclose(g, [d - r, -0.02 / d, 0.0, 0.02 / d], atol=3e-5)        # (fp32 cell coordinates)
+            # in the corner: the face wins over the tread when it is the deeper contact
+            g = query(lib, s, [[wall_x - 0.01, 1.0, 0.03, r]])[0]
+            np.testing.assert_allclose(g, [0.01 - r, -1.0, 0.0, 0.0], atol=2e-6)
+        s.close()
+
+
+def _closest_on_triangles(v, tri, c):
+    """Exact distance from point c to the nearest point of a triangle soup (Ericson, closest point on triangle) -> (dist, unit direction)."""
+    best, bdir = np.inf, None
+    for a, b, cc in v[tri]:
+        ab, ac, ap = b - a, cc - a, c - a
+        d1, d2 = ab @ ap, ac @ ap
+        if d1 <= 0 and d2 <= 0:
+            q = a
+        else:
+            bp = c - b; d3, d4 = ab @ bp, ac @ bp
+            if d3 >= 0 and d4 <= d3:
+                q = b
+            else:
+                vc = d1 * d4 - d3 * d2
+                if vc <= 0 and d1 >= 0 and d3 <= 0:
+                    q = a + ab * (d1 / (d1 - d3))
+                else:
+                    cp = c - cc; d5, d6 = ab @ cp, ac @ cp
+                    if d6 >= 0 and d5 <= d6:
+                        q = cc
+                    else:
+                        vb = d5 * d2 - d1 * d6
+                        if vb <= 0 and d2 >= 0 and d6 <= 0:
+                            q = a + ac * (d2 / (d2 - d6))
+                        else:
+                            va = d3 * d6 - d5 * d4
+                            if va <= 0 and (d4 - d3) >= 0 and (d5 - d6) >= 0:
+                                q = b + (cc - b) * ((d4 - d3) / ((d4 - d3) + (d5 - d6)))
+                            else:
+                                den = 1.0 / (va + vb + vc)
+                                q = a + ab * (vb * den) + ac * (vc * den)
+        d = np.linalg.norm(c - q)
+        if d < best:
+            best, bdir = d, (c - q) / max(d, 1e-12)
+    return best, bdir
+
+
+def test_query_equals_exact_distance_to_the_displaced_mesh_on_stairs():
+    """On a staircase (treads + vertical risers) the contact query's gap and normal equal the exact sphere-to-mesh distance / direction for
+    spheres close to the surface — except in the concave corner band, where the exact closest feature may be the face of ANOTHER cell
+    (the query tests the faces of the centre's own cell only) and on slanted facets (gap is measured along the vertical there)."""
+    from go2_rl_gym_amd.utils.terrain import SubTerrain, convert_heightfield_to_trimesh, displaced_cell_heights, pyramid_stairs_terrain
+    lib = load_oracle()
+    t = SubTerrain("t", width=60, length=60, vertical_scale=VS, horizontal_scale=HS)
+    pyramid_stairs_terrain(t, step_width=0.31, step_height=0.15, platform_size=2.0)
+    hf = np.ascontiguousarray(t.height_field_raw)
+    ov = dict(terrain_mode=1, hf_rows=60, hf_cols=60, hf_hscale=HS, hf_vscale=VS, hf_border=0.0, hf_samples=hf,
+              terrain_origins=np.zeros((1, 1, 3), np.float32), terrain_type_id=np.zeros(1, np.int32), terrain_num_levels=1, terrain_num_types=1,
+              terrain_curriculum=0, max_init_terrain_level=0, hf_cells=np.ascontiguousarray(displaced_cell_heights(hf, HS, VS, 0.75)), hf_walls=1)
+    s = HostSim(lib, num_envs=1, **ov)
+    verts, tris = convert_heightfield_to_trimesh(hf, HS, VS, 0.75)
+    verts = verts.astype(np.float64)
+    rng = np.random.default_rng(1)
+    r = 0.03
+    pts, exact = [], []
+    while len(pts) < 120:
+        x, y = rng.uniform(0.6, 5.2, 2)
+        i, j = int(x / HS), int(y / HS)
+        ztop = hf[max(i - 1, 0):i + 3, max(j - 1, 0):j + 3].max() * VS
+        c = np.array([x, y, rng.uniform(hf[i, j] * VS + 0.005, ztop + 0.06)])
+        near = np.nonzero((np.abs(verts[tris][:, :, 0] - x).min(1) < 0.35) & (np.abs(verts[tris][:, :, 1] - y).min(1) < 0.35))[0]
+        d, n = _closest_on_triangles(verts, tris[near], c)
+        below = False
+        if d < 0.08 and not below:
+            pts.append([x, y, c[2], r]); exact.append([d - r, *n])
+    got, exact = query(lib, s, pts), np.array(exact)
+    err = np.abs(got[:, 0] - exact[:, 0])
+    ok = err < 2e-3
+    # the query never reports a contact shallower than... it may only miss faces of neighbouring cells: it then OVER-estimates the gap
+    assert ok.mean() > 0.85, ok.mean()
+    assert (got[~ok, 0] >= exact[~ok, 0] - 2e-3).all()
+    assert np.abs(got[ok, 1:] - exact[ok, 1:]).max() < 2e-2
+    s.close()
+
+
+def settle_against_riser(lib, sim, mesh, steps=12, **kw):
+    """Robot standing on the lower level facing the 15-cm riser, then teleported so that its front foot spheres start 3 cm INSIDE the
+    riser's face; zero actions.  -> x and z of the two front feet after `steps` policy steps."""
+    _, ov = riser_world(mesh)
+    s = sim(lib, num_envs=2, push_robots=0, add_noise=0, randomize_action_delay=0, **ov, **kw)
+    u = np.full((2, lib.abi.GO2_NUM_UNIFORMS), 0.5, np.float32)
+    s.inject(u); s.reset_all()
+    root = np.asarray(s.root_states).copy(); root[:, 3:7] = [0, 0, 0, 1]; root[:, 7:] = 0; root[:, 0] = 3.0; root[:, 1] = 1.0; root[:, 2] = 0.33
+    s.root_states[:] = root
+    zero = np.zeros((2, 12), np.float32)
+    for _ in range(25):
+        s.step(zero)                                                  # settle into the stance
+    foot_ahead = float(np.asarray(s.rigid_body_states)[0, 6, 0] - np.asarray(s.root_states)[0, 0])
+    root = np.asarray(s.root_states).copy(); root[:, 7:] = 0
+    root[:, 0] = 6.0 - foot_ahead - 0.022 + 0.03
+    s.root_states[:] = root
+    d = np.asarray(s.dof_state).copy(); d[:, :, 1] = 0; s.dof_state[:] = d
+    for _ in range(steps):
+        s.step(zero)
+    feet = np.asarray(s.rigid_body_states)[0][[6, 10]][:, :3].copy()
+    s.close()
+    return feet
+
+
+@pytest.mark.parametrize("which", ["oracle", "lane_emulation"])
+def test_feet_pressed_into_a_riser_are_stopped_by_its_face(which):
+    """Known-answer behaviour.  Front feet start 3 cm inside the face of a 15-cm riser at x = 6 m.  Against the trimesh the
+    depenetration acts horizontally: the feet end up touching the face (sphere surface at x = 6.0) on the lower level.  Against the plain
+    height field the same cell is a 1-cell ramp from x = 5.9 to 6.0, whose slanted normal moves the feet out of the whole cell instead."""
+    lib = {"oracle": load_oracle, "lane_emulation": load_emu}[which]()
+    r = 0.022
+    tri = settle_against_riser(lib, HostSim, "trimesh")
+    assert np.all(np.abs(tri[:, 0] + r - 6.0) < 0.006), tri            # resting against the vertical face
+    assert np.all(np.abs(tri[:, 2] - r) < 0.006), tri                   # on the lower tread, not lifted onto a ramp
+    hfm = settle_against_riser(lib, HostSim, "heightfield")
+    assert np.all(hfm[:, 0] < 5.93), hfm                                # pushed down the ramp, ~8 cm further back than the face
