@@ -556,7 +556,7 @@ __global__ void __launch_bounds__(256) go2_act_head_kernel(const float* __restri
   float lp = 0.f;
   for (int j = 0; j < A; ++j) {
     const size_t k = (size_t)e * A + j;
-    const float m = mu[k], sg = std_[j], a = m + sg * eps[k], d = a - m;
+    const float m = mu[k], sg = std_[j], a = go2_add_rn(m, go2_mul_rn(sg, eps[k])), d = a - m;      // mean + std * eps as torch's two ops (no FMA): bit-equal to the eager formulation
     lp += -(d * d) / (2.f * sg * sg) - logf(sg) - HALF_LOG2PI;
     a_out[k] = a;
     if (a_st) a_st[k] = a;
