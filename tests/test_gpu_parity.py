@@ -56,9 +56,11 @@ def test_reset_all_golden_on_gpu(hip):
 
 
 def test_one_step_parity_vs_oracle(hip):
-    """Each step starts from the oracle's state: 4 substeps (PD, dynamics, contact PGS) + post-physics on the GPU vs the
-    independent CPU derivation.  fp32 tolerances: root 2e-4, dof/torque 2e-3, obs 2e-4, reward 5e-6; a few envs per step may
-    sit on a contact-activation / friction-cone boundary, take the other branch in fp32 and differ by up to 50x tol."""
+    """Each step starts from the oracle's state: 4 substeps (PD, dynamics, contact PGS) + post-physics on the GPU vs the independent CPU
+    derivation.  ONE fp32 bound per tensor for every env of every step (helpers.PLANE_BOUND: root 1e-3, dof 2e-2, torque 1e-2, obs 1e-3,
+    reward 2e-5) and a 10x tighter one for 99 % of them — the size of the fp32 oracle's own error against the fp64 oracle on the same
+    inputs (profiles/r2_parity_probe.txt)."""
+    from helpers import PLANE_BOUND, StepErrors, check_plane_errors
     N = 64
     so = HostSim(load_oracle(), num_envs=N)
     sd = DeviceSim(hip, num_envs=N)
@@ -66,23 +68,22 @@ def test_one_step_parity_vs_oracle(hip):
     so.reset_all(); sd.reset_all()
     rng = np.random.default_rng(0)
     contact_seen = 0
+    err = StepErrors(PLANE_BOUND)
     for it in range(100):
         a = rng.normal(0, 1, (N, 12)).astype(np.float32)
         for k in STEP_STATE:
             getattr(sd, k)[...] = np.asarray(getattr(so, k))
         so.step(a); sd.step(a)
         contact_seen += int((so.contact_forces[:, [6, 10, 14, 18], 2] > 1).sum())
-        for k, tol in (("root_states", 5e-4), ("dof_state", 2e-3), ("torques", 2e-3), ("obs_buf", 2e-4), ("privileged_obs_buf", 2e-4), ("rew_buf", 5e-6)):
-            d = np.sort(np.abs(np.asarray(getattr(so, k), np.float64) - np.asarray(getattr(sd, k), np.float64)).reshape(N, -1).max(1))
-            assert d[int(0.95 * N)] < tol and d[-1] < 50 * tol, (k, it, d[-4:])     # >= 95 % of the envs within tol, every env within 50 tol
+        err.add(so, sd, N)
         fo, fd = np.asarray(so.contact_forces, np.float64), np.asarray(sd.contact_forces, np.float64)
         de = np.abs(fo - fd).reshape(N, -1).max(1)
-        assert np.median(de) < 5e-3 and (de > 1e-3 * max(1.0, np.abs(fo).max()) + 5e-2).sum() <= 3, (it, np.sort(de)[-3:])
+        assert np.median(de) < 5e-3 and de.max() < 2e-3 * max(1.0, np.abs(fo).max()) + 0.5, (it, np.sort(de)[-3:])      # forces are impulse / 5 ms: fp32 noise x200
         np.testing.assert_array_equal(np.asarray(so.reset_buf), np.asarray(sd.reset_buf))
         # feet rows of rigid_body_states (pos, lin vel) - the only rows the reference reads (:1252,1407-1408)
         ro, rd = np.asarray(so.rigid_body_states)[:, [6, 10, 14, 18]][..., [0, 1, 2, 7, 8, 9]], np.asarray(sd.rigid_body_states)[:, [6, 10, 14, 18]][..., [0, 1, 2, 7, 8, 9]]
-        d = np.sort(np.abs(ro - rd).reshape(N, -1).max(1))
-        assert d[int(0.95 * N)] < 2e-3, (it, d[-3:])
+        assert np.abs(ro - rd).max() < 2e-2, (it, float(np.abs(ro - rd).max()))
+    check_plane_errors(err)
     assert contact_seen > 1000
     so.close(); sd.close()
 
@@ -94,27 +95,32 @@ def test_heightfield_one_step_parity_vs_oracle(hip, mesh_type):
     from helpers import heightfield_overrides
     N = 80
     t, ov = heightfield_overrides(N, mesh_type=mesh_type)
-    so = HostSim(load_oracle(), num_envs=N, **ov)
+    from helpers import StepErrors, check_relative_to_conditioning
+    so, s64 = HostSim(load_oracle(), num_envs=N, **ov), HostSim(load_oracle(f64=True), num_envs=N, **ov)
     sd = DeviceSim(hip, num_envs=N, **ov)
-    so.reset_all(); sd.reset_all()
+    so.reset_all(); sd.reset_all(); s64.reset_all()
     rng = np.random.default_rng(2)
     contact_seen = 0
+    floors = {"root_states": 2e-5, "dof_state": 2e-4, "torques": 2e-4, "obs_buf": 2e-5, "privileged_obs_buf": 2e-5, "rew_buf": 2e-7}
+    err, cond = StepErrors(floors), StepErrors(floors)
     for it in range(100):
         a = rng.normal(0, 0.6, (N, 12)).astype(np.float32)
         for k in STEP_STATE:
-            getattr(sd, k)[...] = np.asarray(getattr(so, k))
-        so.step(a); sd.step(a)
+            v = np.asarray(getattr(so, k))
+            getattr(sd, k)[...] = v; getattr(s64, k)[...] = v
+        so.step(a); sd.step(a); s64.step(a.astype(np.float64))
         contact_seen += int((so.contact_forces[:, [6, 10, 14, 18], 2] > 1).sum())
-        for k, tol in (("root_states", 5e-4), ("dof_state", 2e-3), ("torques", 2e-3), ("obs_buf", 2e-4), ("privileged_obs_buf", 2e-4), ("rew_buf", 5e-6),
-                       ("measured_heights", 1e-6)):
-            d = np.sort(np.abs(np.asarray(getattr(so, k), np.float64) - np.asarray(getattr(sd, k), np.float64)).reshape(N, -1).max(1))
-            # >= 90 % of the envs within tol; an env on a contact-activation boundary (a facet edge, a thigh grazing a stair) may take
-            # the other branch in fp32: at most 2 such envs per step, and they stay bounded (one collision-count step of reward)
-            assert d[int(0.9 * N)] < tol and (d > 100 * tol).sum() <= 2 and d[-1] < 0.5, (k, it, d[-4:])
+        err.add(so, sd, N); cond.add(so, s64, N)
         np.testing.assert_array_equal(np.asarray(so.reset_buf), np.asarray(sd.reset_buf))
         np.testing.assert_array_equal(np.asarray(so.terrain_levels), np.asarray(sd.terrain_levels))
+        # the height scan is taken at the pose each library integrated to (1e-5 apart): a point within that of a cell boundary may read the
+        # neighbouring cell; the index arithmetic itself is pinned bit-exactly by the golden sequences (test_golden_sequence_on_gpu)
+        assert (np.abs(np.asarray(so.measured_heights) - np.asarray(sd.measured_heights)) > 1e-6).sum() <= 2
+    # a facet edge / stair face under a sphere makes the step ill-conditioned in fp32 for ANY evaluation order: the kernel's error stays
+    # within 3x of the fp32 oracle's own error against the fp64 oracle on the same inputs (median, 99th percentile, far tail)
+    check_relative_to_conditioning(err, cond, floors)
     assert contact_seen > 2000 and np.abs(np.asarray(so.measured_heights)).max() > 0.05
-    so.close(); sd.close()
+    so.close(); sd.close(); s64.close()
 
 
 def test_train_rough_terrain_on_gpu(hip):
@@ -453,7 +459,7 @@ def test_ragged_batches_on_gpu(hip, N):
             getattr(sd, k)[...] = np.asarray(getattr(so, k))
         so.step(a); sd.step(a)
         d = np.abs(np.asarray(so.obs_buf, np.float64) - np.asarray(sd.obs_buf, np.float64)).max(1)
-        assert np.sort(d)[int(0.98 * (N - 1))] < 2e-4 and d.max() < 5e-2, (it, np.sort(d)[-3:])
+        assert d.max() < 1e-3, (it, np.sort(d)[-3:])                  # helpers.PLANE_BOUND["obs_buf"], every env
         np.testing.assert_array_equal(np.asarray(so.reset_buf), np.asarray(sd.reset_buf))
     so.close(); sd.close()
 
@@ -499,9 +505,10 @@ def test_fine_grained_calls_equal_the_fused_step_on_gpu(hip):
             getattr(b_, k)[...] = np.asarray(getattr(a_, k))
         a_.step(act)
         b_.actions[:] = act; b_.simulate(); b_.post_physics(); b_.torch.cuda.synchronize()
-        for k, tol in (("root_states", 2e-4), ("dof_state", 1e-3), ("obs_buf", 1e-4), ("privileged_obs_buf", 1e-4), ("rew_buf", 5e-6)):
-            d = np.sort(np.abs(np.asarray(getattr(a_, k), np.float64) - np.asarray(getattr(b_, k), np.float64)).reshape(N, -1).max(1))
-            assert d[int(0.97 * N)] < tol, (k, it, d[-4:])
+        from helpers import PLANE_BOUND
+        for k in ("root_states", "dof_state", "obs_buf", "privileged_obs_buf", "rew_buf"):
+            d = np.abs(np.asarray(getattr(a_, k), np.float64) - np.asarray(getattr(b_, k), np.float64)).reshape(N, -1).max(1)
+            assert d.max() < PLANE_BOUND[k], (k, it, np.sort(d)[-4:])
         np.testing.assert_array_equal(np.asarray(a_.reset_buf), np.asarray(b_.reset_buf))
     assert hip.go2sim_get_common_step_counter(a_.h) == hip.go2sim_get_common_step_counter(b_.h) == 10
     a_.close(); b_.close()
@@ -591,29 +598,23 @@ def test_env_shards_equal_slices_of_one_sim_on_gpu(hip, terrain):
         s_.close()
 
 
-def _stats_vs(ref, got, N):
-    return np.abs(np.asarray(ref, np.float64) - np.asarray(got, np.float64)).reshape(N, -1).max(1)
-
-
 def test_parity_outliers_are_conditioning_not_fast_math(hip):
-    """What the percentile gates of the physics parity tests stand on, measured instead of asserted:
-      * the device library built WITHOUT -ffast-math (tests/emu/libgo2sim_hip_precise.so, IEEE division / sqrt, same contraction) shows the
-        same population of outlier envs against the fp32 oracle as the shipped -ffast-math build => they are not fast-math artefacts;
-      * the fp32 oracle itself differs from the fp64 oracle on the same envs with the same magnitude => the outliers are envs whose step is
-        ill-conditioned in fp32 (a contact row switching on/off at gap = contact_offset, a friction cone boundary, a joint-limit row), where
-        ANY two fp32 evaluation orders disagree — the oracle's own included.
-    The bound this yields (and the one the one-step tests use): per env, |HIP - oracle32| <= max(tol, 8 x |oracle32 - oracle64|)."""
+    """What the one-step parity bounds stand on, measured instead of asserted:
+      * the device library built WITHOUT -ffast-math (tests/emu/libgo2sim_hip_precise.so, IEEE division / sqrt) has the same error
+        distribution against the fp32 oracle as the shipped -ffast-math build => the differences are not fast-math artefacts;
+      * the fp32 oracle itself differs from the fp64 oracle on the same inputs by the same amounts => they are the fp32 conditioning of the
+        step (a contact row switching at gap = contact_offset, a friction-cone boundary, a joint-limit row), which ANY two fp32 evaluation
+        orders share.  Both builds pass the plane bounds and the conditioning-relative gate; the report is written to gpurun_out/."""
     import json
-    from helpers import load_hip_precise
+    from helpers import PLANE_BOUND, StepErrors, check_plane_errors, check_relative_to_conditioning, load_hip_precise
     N, steps = 256, 60
     so, s64 = HostSim(load_oracle(), num_envs=N), HostSim(load_oracle(f64=True), num_envs=N)
     sims = {"fast_math": DeviceSim(hip, num_envs=N), "precise": DeviceSim(load_hip_precise(), num_envs=N)}
     for s_ in [so, s64] + list(sims.values()):
         s_.reset_all()
     rng = np.random.default_rng(0)
-    tol = {"root_states": 5e-4, "dof_state": 2e-3, "obs_buf": 2e-4, "rew_buf": 5e-6}
-    count = {b: {k: 0 for k in tol} for b in list(sims) + ["oracle32_vs_64"]}
-    excess, worst_ratio = {b: 0 for b in sims}, {b: 0.0 for b in sims}
+    errs = {b: StepErrors(PLANE_BOUND) for b in sims}
+    cond = StepErrors(PLANE_BOUND)
     for it in range(steps):
         a = rng.normal(0, 1, (N, 12)).astype(np.float32)
         for k in STEP_STATE:
@@ -624,26 +625,21 @@ def test_parity_outliers_are_conditioning_not_fast_math(hip):
         so.step(a); s64.step(a.astype(np.float64))
         for sd in sims.values():
             sd.step(a)
-        for k, t in tol.items():
-            cond = _stats_vs(getattr(s64, k), getattr(so, k), N)          # the fp32 oracle against the fp64 oracle: the step's fp32 conditioning
-            count["oracle32_vs_64"][k] += int((cond > t).sum())
-            for b, sd in sims.items():
-                d = _stats_vs(getattr(so, k), getattr(sd, k), N)
-                count[b][k] += int((d > t).sum())
-                bad = d > np.maximum(t, 8.0 * cond)
-                excess[b] += int(bad.sum())
-                worst_ratio[b] = max(worst_ratio[b], float((d / np.maximum(t, 8.0 * cond)).max()))
-    report = {"envs": N, "steps": steps, "tolerances": tol, "env_steps_above_tol": count, "env_steps_above_max(tol,8*conditioning)": excess, "worst_ratio": worst_ratio}
+        cond.add(so, s64, N)
+        for b, sd in sims.items():
+            errs[b].add(so, sd, N)
+    q = lambda e, k: {"p50": float(np.quantile(e.all(k), 0.5)), "p99": float(np.quantile(e.all(k), 0.99)), "max": float(e.all(k).max())}
+    report = {"envs": N, "steps": steps, "bounds": PLANE_BOUND, "oracle32_vs_oracle64": {k: q(cond, k) for k in PLANE_BOUND},
+              **{b: {k: q(e, k) for k in PLANE_BOUND} for b, e in errs.items()}}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(report, open(os.path.join(ROOT, "gpurun_out", "parity_outliers.json"), "w"), indent=1)
     print(json.dumps(report))
-    tot = N * steps
-    for k in tol:
-        # the precise build does not make the outliers go away (same order of magnitude), and the fp32 oracle has them against fp64 too
-        assert count["precise"][k] >= 0.3 * count["fast_math"][k] - 3, (k, count)
-        assert count["fast_math"][k] <= 0.06 * tot and count["precise"][k] <= 0.06 * tot, (k, count)
-    for b in sims:
-        assert excess[b] <= 0.002 * tot * len(tol), (b, excess, worst_ratio)      # (almost) every env is inside max(tol, 8 x its own fp32 conditioning)
+    floors = {k: v / 500 for k, v in PLANE_BOUND.items()}
+    for b, e in errs.items():
+        check_plane_errors(e)
+        check_relative_to_conditioning(e, cond, floors)
+    for k in PLANE_BOUND:      # the two builds' distributions agree with each other
+        assert 0.5 < np.quantile(errs["fast_math"].all(k), 0.99) / np.quantile(errs["precise"].all(k), 0.99) < 2.0, k
     for s_ in [so, s64] + list(sims.values()):
         s_.close()
 

@@ -112,31 +112,35 @@ def _pair(**kw):
 def test_heightfield_one_step_parity_lanes_vs_oracle():
     """Same protocol as test_lane_emulation, on the rough terrain: slopes, stairs, obstacles under the feet,
     terrain curriculum and the 187-point height scan active."""
+    from helpers import StepErrors, check_relative_to_conditioning
     t, so, se = _pair()
+    s64 = HostSim(load_oracle(f64=True), num_envs=N, **heightfield_overrides(N)[1])
     for k in ("env_origins", "terrain_levels", "terrain_types"):
         np.testing.assert_array_equal(np.asarray(getattr(so, k)), np.asarray(getattr(se, k)), err_msg=k)
     assert len(np.unique(np.asarray(so.terrain_types))) == 20
-    so.reset_all(); se.reset_all()
+    so.reset_all(); se.reset_all(); s64.reset_all()
     rng = np.random.default_rng(1)
     contact_seen = tilted = 0
+    floors = {"root_states": 2e-5, "dof_state": 2e-4, "torques": 2e-4, "obs_buf": 2e-5, "privileged_obs_buf": 2e-5, "rew_buf": 2e-7}
+    err, cond = StepErrors(floors), StepErrors(floors)
     for it in range(90):
         a = rng.normal(0, 0.6, (N, 12)).astype(np.float32)
         for k in STEP_STATE:
-            getattr(se, k)[...] = getattr(so, k)
-        so.step(a); se.step(a)
+            getattr(se, k)[...] = getattr(so, k); getattr(s64, k)[...] = getattr(so, k)
+        so.step(a); se.step(a); s64.step(a.astype(np.float64))
         f = np.asarray(so.contact_forces)[:, [6, 10, 14, 18]]
         contact_seen += int((f[..., 2] > 1).sum())
         tilted += int(((f[..., 2] > 1) & (np.abs(f[..., :2]).max(-1) > 0.2 * f[..., 2])).sum())
-        for k, tol in (("root_states", 5e-4), ("dof_state", 2e-3), ("torques", 2e-3), ("obs_buf", 2e-4), ("privileged_obs_buf", 2e-4), ("rew_buf", 5e-6),
-                       ("measured_heights", 1e-6)):
-            d = np.sort(np.abs(np.asarray(getattr(so, k), np.float64) - np.asarray(getattr(se, k), np.float64)).reshape(N, -1).max(1))
-            # >= 90 % of the envs within tol; an env on a contact-activation boundary (a facet edge, a thigh grazing a stair) may take
-            # the other branch in fp32: at most 2 such envs per step, and they stay bounded (one collision-count step of reward)
-            assert d[int(0.9 * N)] < tol and (d > 100 * tol).sum() <= 2 and d[-1] < 0.5, (k, it, d[-4:])
+        err.add(so, se, N); cond.add(so, s64, N)
+        assert (np.abs(np.asarray(so.measured_heights) - np.asarray(se.measured_heights)) > 1e-6).sum() <= 2      # scan taken at poses 1e-5 apart
         np.testing.assert_array_equal(np.asarray(so.reset_buf), np.asarray(se.reset_buf))
         np.testing.assert_array_equal(np.asarray(so.terrain_levels), np.asarray(se.terrain_levels))
+    # facet edges make a step ill-conditioned in fp32 for any evaluation order: the lane programs' error stays within 3x of the fp32
+    # oracle's own error against the fp64 oracle on the same inputs (helpers.check_relative_to_conditioning)
+    check_relative_to_conditioning(err, cond, floors)
     assert contact_seen > 1000 and tilted > 50        # feet did load non-horizontal facets
     assert np.abs(np.asarray(so.measured_heights)).max() > 0.05
+    s64.close()
 
 
 @pytest.mark.parametrize("which", ["oracle", "lane_emulation"])
