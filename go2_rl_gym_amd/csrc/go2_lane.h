@@ -32,6 +32,46 @@
 // Y = M^-1 J^T = [Z | H.ang | H.lin]; the scalars are replicated in the quad
 struct Row { float J[3], Y[3], dinv, vfb, lam; };
 
+// The launch constants the substep loop reads, snapshotted ONCE per step.  Read straight from the device block they are "invariant scalar
+// loads" to the compiler, which re-issues them at every use instead of keeping them in registers (37 s_load + wait per substep, measured
+// in the ISA); passed through an empty asm statement each value becomes an ordinary register value (SGPR, wave-uniform).
+struct HotL {
+  float sim_dt, gravity[3], contact_offset, erp, max_depen_vel, bounce_thr, cfm, armature, limit_margin, max_lin_vel, max_ang_vel, action_scale;
+  float hf_hscale, hf_vscale, hf_border;
+  int32_t terrain_mode, hf_walls, hf_rows, hf_cols, rand_strength;
+#if defined(__HIP_DEVICE_COMPILE__)
+  static __device__ __forceinline__ float keep(float x) { asm volatile("" : "+s"(x)); return x; }
+  static __device__ __forceinline__ int32_t keep(int32_t x) { asm volatile("" : "+s"(x)); return x; }
+#else
+  static float keep(float x) { return x; }
+  static int32_t keep(int32_t x) { return x; }
+#endif
+  GO2_HD void load(const Go2Launch& L) {
+    sim_dt = keep(L.sim_dt); gravity[0] = keep(L.gravity[0]); gravity[1] = keep(L.gravity[1]); gravity[2] = keep(L.gravity[2]);
+    contact_offset = keep(L.contact_offset); erp = keep(L.erp); max_depen_vel = keep(L.max_depen_vel); bounce_thr = keep(L.bounce_thr);
+    cfm = keep(L.cfm); armature = keep(L.armature); limit_margin = keep(L.limit_margin); max_lin_vel = keep(L.max_lin_vel);
+    max_ang_vel = keep(L.max_ang_vel); action_scale = keep(L.action_scale); hf_hscale = keep(L.hf_hscale); hf_vscale = keep(L.hf_vscale);
+    hf_border = keep(L.hf_border); terrain_mode = keep(L.terrain_mode); hf_walls = keep(L.hf_walls); hf_rows = keep(L.hf_rows);
+    hf_cols = keep(L.hf_cols); rand_strength = keep(L.rand_strength);
+  }
+};
+
+// The per-leg constants the substep loop reads, copied ONCE per step from the LDS table into registers (the loop would otherwise wait on
+// ~50 ds_reads per substep): joint origins, limits, the foot sphere, this sub-lane's candidate spheres, the groups' cull reach.
+struct LegLoop {
+  float o1[3], o2[3], o3[3], lim_lo[3], lim_hi[3], vel_lim[3], eff_lim[3], foot_pt[4], cull_ext[4][3];
+  SubCand sc;
+  GO2_HD void load(const LegTab& t, int sub) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o1[k] = t.o1[k]; o2[k] = t.o2[k]; o3[k] = t.o3[k]; lim_lo[k] = t.lim_lo[k]; lim_hi[k] = t.lim_hi[k]; vel_lim[k] = t.vel_lim[k]; eff_lim[k] = t.eff_lim[k]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { foot_pt[k] = t.foot_pt[k]; cull_ext[k][0] = t.cull_ext[k][0]; cull_ext[k][1] = t.cull_ext[k][1]; cull_ext[k][2] = t.cull_ext[k][2]; }
+    const SubCand& c = t.cand[sub];
+#pragma unroll
+    for (int k = 0; k < GO2_SUB_CANDS; ++k) { sc.pt[k][0] = c.pt[k][0]; sc.pt[k][1] = c.pt[k][1]; sc.pt[k][2] = c.pt[k][2]; sc.pt[k][3] = c.pt[k][3]; sc.idx[k] = c.idx[k]; sc.body[k] = c.body[k]; }
+  }
+};
+
 struct LegPhys {
   int leg, sub;
   // ---- state (persistent over the substeps of one step) ----
@@ -60,7 +100,8 @@ struct LegPhys {
   }
 
   // ------------------------------------------------------------------------------------------------
-  GO2_HD void phaseA(const LegTab& t, const Go2Launch& L, float* part) {
+  template <class LT>
+  GO2_HD void phaseA(const LegLoop& t, const LT& L, float* part) {
     Rwb = quat_to_m3(qx, qy, qz, qw);
     wb = mulT(Rwb, ww); vb = mulT(Rwb, vw);
     V3 gb = mulT(Rwb, v3(L.gravity[0], L.gravity[1], L.gravity[2]));
@@ -113,7 +154,8 @@ struct LegPhys {
   }
 
   // ------------------------------------------------------------------------------------------------
-  GO2_HD void phaseB(const Go2Launch& L, const float* red) {
+  template <class LT>
+  GO2_HD void phaseB(const LT& L, const float* red) {
     RB Ileg; Ileg.m = red[0]; Ileg.h = v3(red[1], red[2], red[3]);
     Ileg.J.xx = red[4]; Ileg.J.yy = red[5]; Ileg.J.zz = red[6]; Ileg.J.xy = red[7]; Ileg.J.xz = red[8]; Ileg.J.yz = red[9];
     RB Itot = Ibase + Ileg;
@@ -147,7 +189,8 @@ struct LegPhys {
   //   * with hf_walls (mesh_type 'trimesh'): the vertical faces on the cell's four edges — a face stands where the NEIGHBOUR cell's heights
   //     along the common edge exceed this cell's (go2sim.h hf_cells); closest point on the face (bottom .. top at the foot of the
   //     perpendicular) gives a horizontal normal beside the face and a slanted one over its top edge.
-  GO2_HD void contact_query(const Go2Launch& L, const GO2_AS1 Go2Cell* cells, V3 c, float r, float* gap, V3* n) const {
+  template <class LT>
+  GO2_HD void contact_query(const LT& L, const GO2_AS1 Go2Cell* cells, V3 c, float r, float* gap, V3* n) const {
     if (L.terrain_mode == 0) { *gap = c.z - r; *n = v3(0, 0, 1); return; }
     const float hs = L.hf_hscale, vs = L.hf_vscale;
     float fx = (c.x + L.hf_border) / hs, fy = (c.y + L.hf_border) / hs;
@@ -207,7 +250,8 @@ struct LegPhys {
   }
 
   // the three rows (normal, two tangents) of a sphere contact: gap, sphere centre cb in the base frame, radius, link (0 base, 1..3), world normal
-  GO2_HD void build_slot(Row* rows, float* active, V3* dn, V3* dt1, V3* dt2, const Go2Launch& L, float gap, V3 cb, float rad, int link, V3 nw, bool warm) {
+  template <class LT>
+  GO2_HD void build_slot(Row* rows, float* active, V3* dn, V3* dt1, V3* dt2, const LT& L, float gap, V3 cb, float rad, int link, V3 nw, bool warm) {
     const float h = L.sim_dt, cfm1 = 1.0f + L.cfm;
     const float act = gap < L.contact_offset ? 1.f : 0.f;
     *active = act; *dn = nw;
@@ -238,7 +282,8 @@ struct LegPhys {
   }
 
   // ------------------------------------------------------------------------------------------------
-  GO2_HD void phaseC(const LegTab& t, const Go2Launch& L, const GO2_AS1 Go2Cell* cells) {
+  template <class LT>
+  GO2_HD void phaseC(const LegLoop& t, const LT& L, const GO2_AS1 Go2Cell* cells) {
     // foot
     {
       V3 cb = p3 + mul(R3, v3(t.foot_pt[0], t.foot_pt[1], t.foot_pt[2]));
@@ -251,7 +296,7 @@ struct LegPhys {
     // base-frame position, radius, link, body and facet normal it needs for its rows — to all four sub-lanes.  Ties go to the lower
     // candidate index (the scan order of the sequential formulation).
     {
-      const SubCand& sc = t.cand[sub];
+      const SubCand& sc = t.sc;
       float best = 1e30f; int bi = 1 << 20; V3 bn = v3(0, 0, 1), bcb = v3(0, 0, 0); float brad = 0.f; int blink = 0, bbody = 0;
       const V3 q2 = p2, q3 = p3;
 #define GO2_CAND(k, R, P, LINK) { \
@@ -396,7 +441,8 @@ struct LegPhys {
   }
 
   // ------------------------------------------------------------------------------------------------
-  GO2_HD void phaseD(const LegTab& t, const Go2Launch& L) {
+  template <class LT>
+  GO2_HD void phaseD(const LegLoop& t, const LT& L) {
     float h = L.sim_dt;
     SV V0p = V0f + w;
     float qdp[3] = {qdf[0] + z[0] - dot(T1, w), qdf[1] + z[1] - dot(T2, w), qdf[2] + z[2] - dot(T3, w)};
@@ -427,7 +473,8 @@ struct LegPhys {
 
   // _compute_torques (legged_robot.py:594-618, control_type 'P') then *= motor_strengths (:80-81)
   // kp/kd arrive already multiplied by the per-env gain multipliers, q0 = default angle of this leg's joints (hoisted out of the substep loop)
-  GO2_HD void pd(const LegTab& t, const Go2Launch& L, const float* act, const float* kp_, const float* kd_, const float* q0, const float* off, const float* strength) {
+  template <class LT>
+  GO2_HD void pd(const LegLoop& t, const LT& L, const float* act, const float* kp_, const float* kd_, const float* q0, const float* off, const float* strength) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       float kp = kp_[j], kd = kd_[j];

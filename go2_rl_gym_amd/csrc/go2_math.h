@@ -67,6 +67,12 @@ __device__ __forceinline__ void go2_sincos(float x, float* s, float* c) { const 
 GO2_HD void go2_sincos(float x, float* s, float* c) { *s = sinf(x); *c = cosf(x); }
 #endif
 
+// a value that is the same in every lane of the wave, as a scalar (lets the compiler branch on it with s_cbranch)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint32_t go2_uniform_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+#else
+GO2_HD uint32_t go2_uniform_u32(uint32_t x) { return x; }
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ float go2_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 #else

@@ -65,6 +65,31 @@ GO2_HD void go2_step_scalars(const Go2Launch& L, const Go2Dyn& dyn, const float*
   }
   S->max_lin_vel = fmaxf(fmaxf(fabsf(S->cmd_ranges[0][0]), fabsf(S->cmd_ranges[0][1])), fmaxf(fabsf(S->cmd_ranges[1][0]), fabsf(S->cmd_ranges[1][1])));
   S->zero_cmd_proba = L.zero_curr_enabled ? go2_current_scale(L.zero_curr, it) : 0.f;
+  uint32_t mask = 0u;
+  _Pragma("unroll") for (int t = 0; t < GO2_NUM_REWARDS; ++t) if (L.rew_on[t]) mask |= 1u << t;
+  S->rew_mask = initial_reset ? 0u : mask; S->rew_mask_all = mask;
+}
+
+// slot -> (Philox group << 2 | word): the mapping of include/go2sim_rng.h (go2_fill_slot_codes) as a constant expression, so that a slot
+// known at compile time costs no table lookup (go2sim_create checks the two against each other for every slot)
+GO2_HD constexpr int go2_slot_code(int s) {
+  return s == GO2_U_DELAY ? 0
+       : (s >= GO2_U_RSA && s < GO2_U_RSA + 4) ? 1 * 4 + (s - GO2_U_RSA)
+       : (s >= GO2_U_RSA + 4 && s < GO2_U_RSA + 7) ? 2 * 4 + (s - GO2_U_RSA - 4)
+       : (s >= GO2_U_RSB && s < GO2_U_RSB + 4) ? 22 * 4 + (s - GO2_U_RSB)
+       : (s >= GO2_U_RSB + 4 && s < GO2_U_RSB + 7) ? 23 * 4 + (s - GO2_U_RSB - 4)
+       : (s >= GO2_U_RESET_STRENGTH && s < GO2_U_RESET_STRENGTH + 12) ? (3 + 4 * ((s - GO2_U_RESET_STRENGTH) / 3) + ((0 + (s - GO2_U_RESET_STRENGTH) % 3) >> 2)) * 4 + ((0 + (s - GO2_U_RESET_STRENGTH) % 3) & 3)
+       : (s >= GO2_U_RESET_OFFSET && s < GO2_U_RESET_OFFSET + 12) ? (3 + 4 * ((s - GO2_U_RESET_OFFSET) / 3) + ((3 + (s - GO2_U_RESET_OFFSET) % 3) >> 2)) * 4 + ((3 + (s - GO2_U_RESET_OFFSET) % 3) & 3)
+       : (s >= GO2_U_RESET_KP && s < GO2_U_RESET_KP + 12) ? (3 + 4 * ((s - GO2_U_RESET_KP) / 3) + ((6 + (s - GO2_U_RESET_KP) % 3) >> 2)) * 4 + ((6 + (s - GO2_U_RESET_KP) % 3) & 3)
+       : (s >= GO2_U_RESET_KD && s < GO2_U_RESET_KD + 12) ? (3 + 4 * ((s - GO2_U_RESET_KD) / 3) + ((9 + (s - GO2_U_RESET_KD) % 3) >> 2)) * 4 + ((9 + (s - GO2_U_RESET_KD) % 3) & 3)
+       : (s >= GO2_U_RESET_DOF && s < GO2_U_RESET_DOF + 12) ? (3 + 4 * ((s - GO2_U_RESET_DOF) / 3) + ((12 + (s - GO2_U_RESET_DOF) % 3) >> 2)) * 4 + ((12 + (s - GO2_U_RESET_DOF) % 3) & 3)
+       : s == GO2_U_RESET_TERRAIN ? 19 * 4 + 0 : s == GO2_U_RESET_YAW ? 19 * 4 + 1 : (s == GO2_U_RESET_XY || s == GO2_U_RESET_XY + 1) ? 19 * 4 + 2 + (s - GO2_U_RESET_XY)
+       : (s >= GO2_U_RESET_VEL && s < GO2_U_RESET_VEL + 6) ? (20 + ((s - GO2_U_RESET_VEL) >> 2)) * 4 + ((s - GO2_U_RESET_VEL) & 3)
+       : (s >= GO2_U_PUSH && s < GO2_U_PUSH + 5) ? (24 + ((s - GO2_U_PUSH) >> 2)) * 4 + ((s - GO2_U_PUSH) & 3)
+       : (s >= GO2_U_NOISE && s < GO2_U_NOISE + 9) ? (26 + (s - GO2_U_NOISE) / 3) * 4 + (s - GO2_U_NOISE) % 3
+       : (s >= GO2_U_NOISE + 9 && s < GO2_U_NOISE + 45) ? (29 + 4 * ((s - GO2_U_NOISE - 9) / 12) + ((s - GO2_U_NOISE - 9) % 12) / 3) * 4 + (s - GO2_U_NOISE - 9) % 3
+       : (s >= GO2_U_TURN && s < GO2_U_TURN + 4) ? 41 * 4 + (s - GO2_U_TURN)
+       : 42 * 4;
 }
 
 struct LegPost {
@@ -85,7 +110,7 @@ struct LegPost {
   const GO2_AS3 uint8_t* codes; GO2_AS3 float (*uc)[4];      // both live in LDS (ds_read / ds_write, not flat accesses)
   GO2_HD float uni(int slot) const {
     if (S->injected) return S->injected[(size_t)e * GO2_NUM_UNIFORMS + slot];
-    const int code = codes[slot];
+    const int code = __builtin_constant_p(slot) ? go2_slot_code(slot) : (int)codes[slot];
     return uc[code >> 2][code & 3];
   }
   GO2_HD void draw_group(int g) {
@@ -350,15 +375,27 @@ struct LegPost {
     { float df = fmaxf(c.min_legs_distance - red[21], 0.f), dr = fmaxf(c.min_legs_distance - red[22], 0.f); raw[GO2_REW_LEGS_DISTANCE] = df * df + dr * dr; }
     raw[GO2_REW_HIP_TO_DEFAULT] = red[18];
     raw[GO2_REW_X_COMMAND_HIP_REGULAR] = (fabsf(red[19]) + fabsf(red[20])) * fabsf(cmd[0]) / sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1] + cmd[2] * cmd[2]);
+    // Sum of the active terms (enum order) and their per-episode sums.  Which terms are active is ONE wave-uniform bit mask (Go2Step),
+    // so every test below is a scalar branch; lane 0 of the environment carries episode_sums through the rest of postB in registers:
+    // all its loads are issued here back to back (one wait instead of one per term), the reset branch reads / zeroes the registers, the
+    // write-back stores them.
     float total = 0.f;
-    float* es = p.ep_sums;  // [R][N] row-major
+    GO2_AS1 float* es = p.ep_sums;  // [R][N] row-major
     const bool need_to = c.turn_over && fabsf(rpy[0]) > c.to_roll_thr;      // :263-265
+    const uint32_t rmask = go2_uniform_u32(S->rew_mask);
+    float esv[GO2_NUM_REWARDS], scl[GO2_NUM_REWARDS];
 #pragma unroll
-    for (int i = 0; i < GO2_REW_TERMINATION; ++i)
-      if (c.rew_on[i] && !S->initial_reset) { float r = raw[i] * (need_to ? S->rew_to_scale[i] : S->rew_scale[i]); total += r; if (lane16 == 0) es[(size_t)i * N + e] += r; }
+    for (int i = 0; i < GO2_NUM_REWARDS; ++i) { esv[i] = 0.f; scl[i] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < GO2_NUM_REWARDS; ++i) if ((rmask >> i) & 1u) {
+      if (lane16 == 0) esv[i] = es[(size_t)i * N + e];
+      scl[i] = (i != GO2_REW_TERMINATION && need_to) ? S->rew_to_scale[i] : S->rew_scale[i];
+    }
+#pragma unroll
+    for (int i = 0; i < GO2_REW_TERMINATION; ++i) if ((rmask >> i) & 1u) { const float r = raw[i] * scl[i]; total += r; esv[i] += r; }
     if (c.only_positive && total < 0.f) total = 0.f;
-    if (c.rew_on[GO2_REW_TERMINATION] && !S->initial_reset) {
-      float r = ((reset && !time_out) ? 1.f : 0.f) * S->rew_scale[GO2_REW_TERMINATION]; total += r; if (lane16 == 0) es[(size_t)GO2_REW_TERMINATION * N + e] += r;
+    if ((rmask >> GO2_REW_TERMINATION) & 1u) {
+      const float r = ((reset && !time_out) ? 1.f : 0.f) * scl[GO2_REW_TERMINATION]; total += r; esv[GO2_REW_TERMINATION] += r;
     }
     if (c.rew_on[GO2_REW_ACTION_SMOOTHNESS])
       _Pragma("unroll") for (int j = 0; j < 3; ++j) llast_act[j] = last_act[j];       // :1378 (not zeroed on reset, App. E.9)
@@ -366,6 +403,7 @@ struct LegPost {
     GO2_MARK(23);
     // ---- reset_idx (:180-245) ---------------------------------------------------------------------
     float ox = org_x, oy = org_y, oz = org_z;
+    bool es_dirty_all = false;
     if (reset) {
       fill(3, 16);                                  // per-DOF reset groups of the 4 legs (go2sim_rng.h: group 3 + 4 leg + g)
       fill(19, 5, c.turn_over ? 41 : -1);           // terrain / yaw / xy, root velocity (2), resample inside reset (2) [, turn-over]
@@ -417,14 +455,16 @@ struct LegPost {
       ep_len = 0;
       timer = c.resampling_time / c.dt; acc[0] = 0.f; acc[1] = 0.f;
       resample(GO2_U_RSB);
-      if (lane16 == 0) {   // extras["episode"] accumulators (:229-242)
-        _Pragma("unroll") for (int i = 0; i < GO2_NUM_REWARDS; ++i) if (c.rew_on[i]) {
+      if (lane16 == 0) {   // extras["episode"] accumulators (:229-242); every term the reference has a sum for, i.e. every computed term
+        const uint32_t amask = go2_uniform_u32(S->rew_mask_all);
+        _Pragma("unroll") for (int i = 0; i < GO2_NUM_REWARDS; ++i) if ((amask >> i) & 1u) {
+          const float v = ((rmask >> i) & 1u) ? esv[i] : es[(size_t)i * N + e];      // (initial reset: nothing was loaded above)
 #if defined(__HIP_DEVICE_COMPILE__)
-          atomicAdd(&p.ep_accum[i], es[(size_t)i * N + e]);
+          atomicAdd(&p.ep_accum[i], v);
 #else
-          p.ep_accum[i] += es[(size_t)i * N + e];
+          p.ep_accum[i] += v;
 #endif
-          es[(size_t)i * N + e] = 0.f;
+          esv[i] = 0.f;
         }
 #if defined(__HIP_DEVICE_COMPILE__)
         atomicAdd(&p.ep_accum[GO2_NUM_REWARDS], 1.0f);
@@ -432,6 +472,7 @@ struct LegPost {
         p.ep_accum[GO2_NUM_REWARDS] += 1.0f;
 #endif
       }
+      es_dirty_all = true;
     }
     GO2_MARK(24);
     // _push_robots (:709-724): episode clock multiple of the push interval (a fresh reset is pushed at once, App. E.4)
@@ -502,6 +543,10 @@ struct LegPost {
       F2D(p.dof, d, e) = o.q[j]; F2D(p.dof, 12 + d, e) = o.qd[j];
     }
     if (lane16 == 0) {
+      {   // episode_sums: the terms summed this step; after a reset every term (zeroed)
+        const uint32_t wmask = es_dirty_all ? go2_uniform_u32(S->rew_mask_all) : rmask;
+        _Pragma("unroll") for (int i = 0; i < GO2_NUM_REWARDS; ++i) if ((wmask >> i) & 1u) es[(size_t)i * N + e] = esv[i];
+      }
       float r13[13] = {o.pw.x, o.pw.y, o.pw.z, o.qx, o.qy, o.qz, o.qw, o.vw.x, o.vw.y, o.vw.z, o.ww.x, o.ww.y, o.ww.z};
       _Pragma("unroll") for (int k = 0; k < 13; ++k) F2D(p.root, k, e) = r13[k];
       _Pragma("unroll") for (int k = 0; k < 6; ++k) F2D(p.last_root_vel, k, e) = r13[7 + k];   // :142

@@ -118,5 +118,7 @@ struct Go2Step {
   float rew_scale[GO2_NUM_REWARDS];  // scale * dt * curriculum
   float rew_to_scale[GO2_NUM_REWARDS];   // turn_over scale * dt * curriculum
   float cmd_ranges[4][2], max_lin_vel, zero_cmd_proba;
+  uint32_t rew_mask;                 // bit t: reward term t is computed (Go2Launch.rew_on[t]); 0 during the initial reset
+  uint32_t rew_mask_all;             // the same, also during the initial reset
 };
 struct Go2DevBlock { Go2Ptrs p; Go2Launch L; Go2Dyn dyn; };

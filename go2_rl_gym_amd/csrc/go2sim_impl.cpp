@@ -255,21 +255,23 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
   }
   if (MODE & MODE_PHYS) {
     lane_load_phys(ph_, po_, ax, tab, p, L, S, actions_in, uc[0][0], e, lane, sub);
+    LegLoop tl; tl.load(t, sub);
+    HotL hl; hl.load(L);
     STAMP(1);
     for (int sb = 0; sb < L.decimation; ++sb) {
       const bool old = L.rand_delay && sb < ax.start;
       const float a[3] = {old ? ax.act_old[0] : ax.act_new[0], old ? ax.act_old[1] : ax.act_new[1], old ? ax.act_old[2] : ax.act_new[2]};
       GO2_MARK(10);
-      ph_.pd(t, L, a, ax.kp, ax.kd, ax.q0, ax.zoff, ax.strength);
+      ph_.pd(tl, hl, a, ax.kp, ax.kd, ax.q0, ax.zoff, ax.strength);
       float part[GO2_QUAD_PARTIALS];
-      ph_.phaseA(t, L, part);
+      ph_.phaseA(tl, hl, part);
       GO2_MARK(11);
 #pragma unroll
       for (int i = 0; i < GO2_QUAD_PARTIALS; ++i) part[i] = xl::leg_sum(part[i]);
       GO2_MARK(12);
-      ph_.phaseB(L, part);
+      ph_.phaseB(hl, part);
       GO2_MARK(13);
-      ph_.phaseC(t, L, p.hf_cells);
+      ph_.phaseC(tl, hl, p.hf_cells);
       GO2_MARK(14);
       // wave-wide row-group activity PER TURN (ballots -> scalar branches): group g of leg T is swept only if some environment of the wave
       // has it active on that leg — typically only the foot contacts are live (an inactive row moves nothing, so skipping is exact)
@@ -282,7 +284,7 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
       }
       GO2_MARK(15);
       ph_.gather_solution();
-      ph_.phaseD(t, L);
+      ph_.phaseD(tl, hl);
       GO2_MARK(16);
     }
     STAMP(2);
@@ -339,7 +341,8 @@ __global__ void __launch_bounds__(64) go2_torque_trace_kernel(const Go2DevBlock*
     const bool old = L.rand_delay && sub < ax.start;
     const float a[3] = {old ? ax.act_old[0] : ax.act_new[0], old ? ax.act_old[1] : ax.act_new[1], old ? ax.act_old[2] : ax.act_new[2]};
     for (int j = 0; j < 3; ++j) { const float* d = dof + (((size_t)sub * N + e) * 12 + 3 * lane + j) * 2; ph_.q[j] = d[0]; ph_.qd[j] = d[1]; }
-    ph_.pd(t, L, a, ax.kp, ax.kd, ax.q0, ax.zoff, ax.strength);
+    LegLoop tl; tl.load(t, 0);
+    ph_.pd(tl, L, a, ax.kp, ax.kd, ax.q0, ax.zoff, ax.strength);
     for (int j = 0; j < 3; ++j) { out[((size_t)sub * N + e) * 12 + 3 * lane + j] = ph_.tau[j]; F2D(p.torques, 3 * lane + j, e) = ph_.tau[j]; }
   }
 }
@@ -686,6 +689,7 @@ static void fill_tables(Go2Tables* T) {
   body10(1, T->base.head[0]); body10(2, T->base.head[1]);
   for (int b = 0; b < 3; ++b) for (int k = 0; k < 3; ++k) T->base.body_off[b][k] = (float)kOff[b][k];
   go2_fill_slot_codes(T->slot_code);
+  for (int sl = 0; sl < GO2_NUM_UNIFORMS; ++sl) if ((int)T->slot_code[sl] != go2_slot_code(sl)) T->layout_ok = 0;      // go2_post.h's constant-expression form of the same mapping
 }
 
 
@@ -782,7 +786,7 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
   s->d_blk = (Go2DevBlock*)dev_alloc(s, sizeof(Go2DevBlock));
   ok = ok && p.terrain_kind && p.ep_accum && s->inj_storage && s->d_tables && s->d_blk;
   if (!ok) { go2sim_destroy(s); FAIL(GO2SIM_ENOMEM, "allocation failed"); }
-  { Go2Tables T; fill_tables(&T); if (!T.layout_ok) FAIL(GO2SIM_EINVAL, "collision candidates are not tabulated hip/thigh/calf (include/go2_model_data.h vs go2_tables.h)");
+  { Go2Tables T; fill_tables(&T); if (!T.layout_ok) FAIL(GO2SIM_EINVAL, "table layout check failed: collision candidates not tabulated hip/thigh/calf (include/go2_model_data.h vs go2_tables.h), or go2_slot_code != go2sim_rng.h");
     dev_upload(s->d_tables, &T, sizeof(T)); p.tables = s->d_tables; }
 
   s->dt = (float)cfg->decimation * cfg->sim_dt;
@@ -1044,7 +1048,8 @@ int go2sim_debug_torque_trace(Go2Sim* s, const float* actions_raw, const float* 
       const bool old = L.rand_delay && sub < ax.start;
       const float a[3] = {old ? ax.act_old[0] : ax.act_new[0], old ? ax.act_old[1] : ax.act_new[1], old ? ax.act_old[2] : ax.act_new[2]};
       for (int j = 0; j < 3; ++j) { const float* d = dof + (((size_t)sub * N + e) * 12 + 3 * lane + j) * 2; ph_.q[j] = d[0]; ph_.qd[j] = d[1]; }
-      ph_.pd(tab.leg[lane], L, a, ax.kp, ax.kd, ax.q0, ax.zoff, ax.strength);
+      LegLoop tl; tl.load(tab.leg[lane], 0);
+      ph_.pd(tl, L, a, ax.kp, ax.kd, ax.q0, ax.zoff, ax.strength);
       for (int j = 0; j < 3; ++j) { out[((size_t)sub * N + e) * 12 + 3 * lane + j] = ph_.tau[j]; F2D(p.torques, 3 * lane + j, e) = ph_.tau[j]; }
     }
   }
