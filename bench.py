@@ -212,7 +212,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "go2_step_kernel<PHYS|POST>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note, "lib_sha256_16": lib_sha, "algorithmic_bytes_per_launch": algo * N, "kernel_ms": k_ms, "launches": n.value, "algorithmic_bytes_per_env_step": algo,
                          "note": "latency-bound by construction: 4096 envs x 16 lanes = 1024 waves = one wave per SIMD; the binding resource is the dependent-issue "
-                                 "latency of ~25k instructions per wave per step, not HBM (DESIGN.md 6)",
+                                 "latency of ~18k dependent VALU instructions per wave per step, not HBM (DESIGN.md 6)",
                          "valu_issue": valu},
         }
         if world == 1 and not a.no_cpu_baseline:

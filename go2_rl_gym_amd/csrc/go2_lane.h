@@ -38,7 +38,7 @@ struct Row { float J[3], Y[3], dinv, vfb, lam; };
 struct HotL {
   float sim_dt, gravity[3], contact_offset, erp, max_depen_vel, bounce_thr, cfm, armature, limit_margin, max_lin_vel, max_ang_vel, action_scale;
   float hf_hscale, hf_vscale, hf_border;
-  int32_t terrain_mode, hf_walls, hf_rows, hf_cols, rand_strength;
+  int32_t terrain_mode, hf_walls, hf_rows, hf_cols, rand_strength, control_type;
 #if defined(__HIP_DEVICE_COMPILE__)
   static __device__ __forceinline__ float keep(float x) { asm volatile("" : "+s"(x)); return x; }
   static __device__ __forceinline__ int32_t keep(int32_t x) { asm volatile("" : "+s"(x)); return x; }
@@ -52,7 +52,7 @@ struct HotL {
     cfm = keep(L.cfm); armature = keep(L.armature); limit_margin = keep(L.limit_margin); max_lin_vel = keep(L.max_lin_vel);
     max_ang_vel = keep(L.max_ang_vel); action_scale = keep(L.action_scale); hf_hscale = keep(L.hf_hscale); hf_vscale = keep(L.hf_vscale);
     hf_border = keep(L.hf_border); terrain_mode = keep(L.terrain_mode); hf_walls = keep(L.hf_walls); hf_rows = keep(L.hf_rows);
-    hf_cols = keep(L.hf_cols); rand_strength = keep(L.rand_strength);
+    hf_cols = keep(L.hf_cols); rand_strength = keep(L.rand_strength); control_type = keep(L.control_type);
   }
 };
 
@@ -474,11 +474,17 @@ struct LegPhys {
   // _compute_torques (legged_robot.py:594-618, control_type 'P') then *= motor_strengths (:80-81)
   // kp/kd arrive already multiplied by the per-env gain multipliers, q0 = default angle of this leg's joints (hoisted out of the substep loop)
   template <class LT>
-  GO2_HD void pd(const LegLoop& t, const LT& L, const float* act, const float* kp_, const float* kd_, const float* q0, const float* off, const float* strength) {
+  // last_dv: buffers.last_dof_vel (the rates at the end of the previous policy step, legged_robot.py:141), read only by control type 'V'
+  GO2_HD void pd(const LegLoop& t, const LT& L, const float* act, const float* kp_, const float* kd_, const float* q0, const float* off, const float* strength,
+                 const GO2_AS1 float* last_dv, int N, int e) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       float kp = kp_[j], kd = kd_[j];
       float tq = kp * (act[j] * L.action_scale + q0[j] - q[j] + off[j]) - kd * qd[j];
+      if (L.control_type != 0) {   // :612-615 (no go2 task; cold)
+        if (L.control_type == 1) tq = kp * (act[j] * L.action_scale - qd[j]) - kd * (qd[j] - last_dv[(size_t)(3 * leg + j) * N + e]) / L.sim_dt;
+        else tq = act[j] * L.action_scale;
+      }
       tq = fminf(fmaxf(tq, -t.eff_lim[j]), t.eff_lim[j]);
       if (L.rand_strength) tq *= strength[j];
       tau[j] = tq;

@@ -48,6 +48,32 @@ GO2_HD float go2_current_scale(const float* c4, float it) {   // get_current_sca
   float pct = (it - c4[0]) / (c4[1] - c4[0]); pct = fminf(fmaxf(pct, 0.f), 1.f);
   return (1.f - pct) * c4[2] + pct * c4[3];
 }
+// command_range_curriculum (legged_robot.py:433-446): the entry with the largest `iter` that has passed, -1 before the first
+GO2_HD int go2_cmd_stage(const Go2Launch& L, float it) {
+  int best = -1;
+  for (int i = 0; i < L.cmd_curr_count; ++i) if (it >= L.cmd_curr[i][0] && (best < 0 || L.cmd_curr[i][0] > L.cmd_curr[best][0])) best = i;
+  return best;
+}
+// End of a pass: command_ranges['lin_vel_x'] as the reference's Python list evolves (go2sim.h cmd_tracking_curriculum).  Every
+// _resample_commands call with >= 1 env first replaces the list when a new command_range_curriculum stage has started (:433-446); the
+// post-physics callback's call (:409-410, `callback_count` envs) comes before reset_idx, whose update_command_curriculum (:728-737)
+// widens the list and whose own _resample_commands call checks the stage again.  `csc` = the counter the pass ran with.
+// (go2sim_create starts the list at commands.ranges.lin_vel_x with no stage seen.)
+GO2_HD void go2_track_cmd_curriculum(const Go2Launch& L, Go2Dyn& dyn, float reset_count, float track_sum, float callback_count, int64_t csc, float* info_lo_hi) {
+  const int stage = go2_cmd_stage(L, (float)(csc / L.num_steps_per_env));
+  for (int call = 0; call < 2; ++call) {
+    if (call == 0 ? callback_count <= 0.f : reset_count <= 0.f) continue;
+    if (call == 1 && L.cmd_track_curr && track_sum / reset_count / L.max_episode_length > 0.8f * L.rew_scale_dt[GO2_REW_TRACKING_LIN_VEL]) {
+      dyn.cmd_x_range[0] = fminf(fmaxf(dyn.cmd_x_range[0] - 0.5f, -L.cmd_max_curr), 0.f);
+      dyn.cmd_x_range[1] = fminf(fmaxf(dyn.cmd_x_range[1] + 0.5f, 0.f), L.cmd_max_curr);
+    }
+    if (stage != dyn.cmd_stage_seen) {
+      dyn.cmd_stage_seen = stage;
+      if (stage >= 0) { dyn.cmd_x_range[0] = L.cmd_curr[stage][1]; dyn.cmd_x_range[1] = L.cmd_curr[stage][2]; }
+    }
+  }
+  info_lo_hi[0] = dyn.cmd_x_range[0]; info_lo_hi[1] = dyn.cmd_x_range[1];
+}
 GO2_HD void go2_step_scalars(const Go2Launch& L, const Go2Dyn& dyn, const float* inj_storage, int64_t csc, int initial_reset, Go2Step* S) {
   S->step_lo = (uint32_t)dyn.step_count; S->step_hi = (uint32_t)(dyn.step_count >> 32);
   S->initial_reset = initial_reset; S->injected = dyn.use_injected ? inj_storage : nullptr;
@@ -57,11 +83,15 @@ GO2_HD void go2_step_scalars(const Go2Launch& L, const Go2Dyn& dyn, const float*
     for (int i = 0; i < L.rew_curr_count; ++i) if (L.rew_curr_term[i] == t) { const float k = go2_current_scale(L.rew_curr[i], it); sc *= k; sct *= k; }
     S->rew_scale[t] = sc; S->rew_to_scale[t] = sct;
   }
-  int best = -1;
-  for (int i = 0; i < L.cmd_curr_count; ++i) if (it >= L.cmd_curr[i][0] && (best < 0 || L.cmd_curr[i][0] > L.cmd_curr[best][0])) best = i;
+  const int best = go2_cmd_stage(L, it);
   _Pragma("unroll") for (int r = 0; r < 4; ++r) {
     S->cmd_ranges[r][0] = best < 0 ? L.cmd_ranges0[r][0] : L.cmd_curr[best][1 + 2 * r];
     S->cmd_ranges[r][1] = best < 0 ? L.cmd_ranges0[r][1] : L.cmd_curr[best][2 + 2 * r];
+  }
+  {
+    const int seen = dyn.cmd_stage_seen < 0 ? -1 : dyn.cmd_stage_seen;      // (-2: no _resample_commands call yet = the configured ranges)
+    S->stage_pending = (L.heading_command && best != seen) ? 1 : 0;
+    S->yaw_range_seen[0] = seen < 0 ? L.cmd_ranges0[2][0] : L.cmd_curr[seen][5]; S->yaw_range_seen[1] = seen < 0 ? L.cmd_ranges0[2][1] : L.cmd_curr[seen][6];
   }
   S->max_lin_vel = fmaxf(fmaxf(fabsf(S->cmd_ranges[0][0]), fabsf(S->cmd_ranges[0][1])), fmaxf(fabsf(S->cmd_ranges[1][0]), fabsf(S->cmd_ranges[1][1])));
   S->zero_cmd_proba = L.zero_curr_enabled ? go2_current_scale(L.zero_curr, it) : 0.f;
@@ -245,11 +275,26 @@ struct LegPost {
     load_terrain_fields();
     float mm = fmaxf(p.max_move[e], sqrtf((o.pw.x - org_x) * (o.pw.x - org_x) + (o.pw.y - org_y) * (o.pw.y - org_y)));
     // _post_physics_step_callback (:404-421)
-    if (timer <= 0.f && (float)ep_len < c.max_episode_length - 1.f) { fill(1, 2); resample(GO2_U_RSA); }      // (per-env branch: the whole row takes it)
+    if (timer <= 0.f && (float)ep_len < c.max_episode_length - 1.f) {      // (per-env branch: the whole row takes it)
+      fill(1, 2); resample(GO2_U_RSA);
+      if ((c.cmd_track_curr || c.heading_command) && lane16 == 0) {      // a _resample_commands call happened before reset_idx (go2_track_cmd_curriculum)
+#if defined(__HIP_DEVICE_COMPILE__)
+        atomicAdd(&p.ep_accum[GO2_NUM_REWARDS + 1], 1.0f);
+#else
+        p.ep_accum[GO2_NUM_REWARDS + 1] += 1.0f;
+#endif
+      }
+    }
     if (c.heading_command && !stop_heading) {
       V3 fw = quat_apply(qx, qy, qz, qw, v3(1, 0, 0)); float heading = atan2f(fw.y, fw.x);
       float a = fmodf(cmd[3] - heading, 6.28318530718f); if (a < 0) a += 6.28318530718f; if (a > 3.14159265359f) a -= 6.28318530718f;
-      float lo, hi; cmd_range(2, &lo, &hi); cmd[2] = fminf(fmaxf(0.5f * a, lo), hi);
+      float lo, hi; cmd_range(2, &lo, &hi);
+      if (yaw_seen) {      // a started stage that no _resample_commands call of this batch has picked up (Go2Step.stage_pending)
+        lo = S->yaw_range_seen[0]; hi = S->yaw_range_seen[1];
+        const int kind = p.terrain_kind[e];
+        if (kind >= 0) { lo = fmaxf(lo, c.terrain_max_cmd[kind][2][0]); hi = fminf(hi, c.terrain_max_cmd[kind][2][1]); }
+      }
+      cmd[2] = fminf(fmaxf(0.5f * a, lo), hi);
     }
     // _get_heights (:1188-1224): this lane samples points lane, lane+4, ...
     float hsum = 0.f;
@@ -317,6 +362,8 @@ struct LegPost {
   }
   float own_f2b, own_fvel2, rpy[3], max_move, org_x, org_y, org_z; int64_t tlevel, ttype;
   bool skip_contact_filters;                   // reset_all runs postB without a postA: nothing to carry over
+  bool yaw_seen;                               // heading clip against the ranges of the stage last picked up (Go2Step.stage_pending)
+  bool api_reset;                              // go2sim_reset_idx: like the reference's reset_idx, leave observations / reward / derived velocities alone
   uint8_t new_lc, new_lc2; float new_fat;      // per-leg read-modify-write fields: read by the 4 sub-lanes in postA, written by sub-lane 0 in postB
   // replicated fields that lane 0 rewrites in postB: every lane reads them BEFORE any lane writes
   GO2_HD void load_terrain_fields() {
@@ -397,7 +444,7 @@ struct LegPost {
     if ((rmask >> GO2_REW_TERMINATION) & 1u) {
       const float r = ((reset && !time_out) ? 1.f : 0.f) * scl[GO2_REW_TERMINATION]; total += r; esv[GO2_REW_TERMINATION] += r;
     }
-    if (c.rew_on[GO2_REW_ACTION_SMOOTHNESS])
+    if (c.rew_on[GO2_REW_ACTION_SMOOTHNESS] && !skip_contact_filters)     // (a reset outside a step computes no reward)
       _Pragma("unroll") for (int j = 0; j < 3; ++j) llast_act[j] = last_act[j];       // :1378 (not zeroed on reset, App. E.9)
 
     GO2_MARK(23);
@@ -416,7 +463,7 @@ struct LegPost {
         GO2_AS1 float* dst = sub == 0 ? p.strength : (sub == 1 ? p.zero_off : (sub == 2 ? p.kp_mul : p.kd_mul));
         if (on) _Pragma("unroll") for (int j = 0; j < 3; ++j) F2D(dst, 3 * lane + j, e) = urange(uni(tb + 3 * lane + j), lo, hi);
       }
-      if (c.terrain_curriculum && c.terrain_mode != 0 && !S->initial_reset) {   // _update_terrain_curriculum (:1143-1169)
+      if (c.terrain_curriculum && c.terrain_mode != 0 && S->initial_reset != 1) {   // _update_terrain_curriculum (:1143-1169)
         float dist = max_move;
         bool up = dist > c.terrain_length * 0.5f, down;
         if (c.move_down_by_acc) down = (dist < sqrtf(acc[0] * acc[0] + acc[1] * acc[1]) * (c.resampling_time * (1.f - S->zero_cmd_proba)) * 0.5f) && !up;
@@ -487,6 +534,7 @@ struct LegPost {
     // critic rows without) plus the critic-only torque / acceleration / foot-force entries, sub-lane 3 of legs 0 / 1 / 2 the base angular
     // velocity / gravity / command triples, sub-lane 3 of leg 3 the critic's base linear velocity; the 187 height entries are dealt round
     // the 16 lanes.  The noise uniforms were drawn at kernel start, one Philox group per lane.
+    if (!api_reset) {
     float cl = c.clip_obs;
     float* ob = p.obs + (size_t)e * GO2_NUM_OBS; float* pv = p.priv + (size_t)e * GO2_NUM_PRIV_OBS;
 #define CLIP(x) fminf(fmaxf((x), -cl), cl)
@@ -525,6 +573,7 @@ struct LegPost {
       }
     }
 #undef CLIP
+    }
     GO2_MARK(26);
     // ---- write back ---------------------------------------------------------------------------------
     if (sub == 0) {
@@ -549,17 +598,20 @@ struct LegPost {
       }
       float r13[13] = {o.pw.x, o.pw.y, o.pw.z, o.qx, o.qy, o.qz, o.qw, o.vw.x, o.vw.y, o.vw.z, o.ww.x, o.ww.y, o.ww.z};
       _Pragma("unroll") for (int k = 0; k < 13; ++k) F2D(p.root, k, e) = r13[k];
-      _Pragma("unroll") for (int k = 0; k < 6; ++k) F2D(p.last_root_vel, k, e) = r13[7 + k];   // :142
+      if (!api_reset) _Pragma("unroll") for (int k = 0; k < 6; ++k) F2D(p.last_root_vel, k, e) = r13[7 + k];   // :142
       p.ep_len[e] = ep_len; p.cmd_timer[e] = timer;
       _Pragma("unroll") for (int k = 0; k < 4; ++k) F2D(p.commands, k, e) = cmd[k];
       F2D(p.cmd_xy_acc, 0, e) = acc[0]; F2D(p.cmd_xy_acc, 1, e) = acc[1];
       p.stop_heading[e] = stop_heading; p.last_is_limit_vel[e] = last_limit;
-      p.reset[e] = reset; p.time_out[e] = time_out; p.rew[e] = total; p.max_move[e] = max_move;
+      p.reset[e] = reset; p.max_move[e] = max_move;
       if (c.turn_over) p.to_timer[e] = to_timer;
+      if (!api_reset) {
+      p.time_out[e] = time_out; p.rew[e] = total;
       F2D(p.base_lin_vel, 0, e) = blv.x; F2D(p.base_lin_vel, 1, e) = blv.y; F2D(p.base_lin_vel, 2, e) = blv.z;
       F2D(p.base_ang_vel, 0, e) = bav.x; F2D(p.base_ang_vel, 1, e) = bav.y; F2D(p.base_ang_vel, 2, e) = bav.z;
       F2D(p.proj_gravity, 0, e) = pg.x; F2D(p.proj_gravity, 1, e) = pg.y; F2D(p.proj_gravity, 2, e) = pg.z;
       F2D(p.rpy, 0, e) = rpy[0]; F2D(p.rpy, 1, e) = rpy[1]; F2D(p.rpy, 2, e) = rpy[2];
+      }
     }
   }
 };

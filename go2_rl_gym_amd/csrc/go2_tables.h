@@ -60,7 +60,7 @@ struct alignas(8) Go2Cell { int16_t h[4]; };
   G uint8_t *last_contacts, *last_contacts2; G float *strength, *zero_off, *kp_mul, *kd_mul, *origins; G int64_t *terrain_levels, *terrain_types; \
   G float *ep_sums, *friction, *restitution, *added_mass, *added_com, *mass_ratio, *episode_info, *foot_impulse; \
   /* internal */ \
-  G int32_t* terrain_kind; G float* ep_accum /*[NUM_REWARDS+1]*/; const G float* inj_storage; const G int16_t* hf; const G Go2Cell* hf_cells; const G float* terrain_origins; \
+  G int32_t* terrain_kind; G uint8_t* reset_mask /*[N], go2sim_reset_idx*/; G float* ep_accum /*[NUM_REWARDS+2]: episode sums of the envs reset in this pass, their number, #envs resampled by the callback*/; const G float* inj_storage; const G int16_t* hf; const G Go2Cell* hf_cells; const G float* terrain_origins; \
   const G Go2Tables* tables; G long long* dbg_clock;
 struct Go2Ptrs { GO2_PTRS_BODY() };
 // The kernels read these pointers out of the device block (scalar loads), where the compiler cannot know their address space and would
@@ -89,6 +89,8 @@ struct Go2Launch {
   int32_t terrain_mode, hf_walls, hf_rows, hf_cols; float hf_hscale, hf_vscale, hf_border, terrain_friction, terrain_restitution;
   int32_t terrain_num_levels, terrain_num_types, terrain_curriculum, move_down_by_acc, measure_heights, full_body_states; float terrain_length;
   float kp[12], kd[12], q0[12], action_scale, clip_actions, clip_obs, base_init[13];
+  int32_t control_type;   // 0 P, 1 V, 2 T (legged_robot.py:607-617)
+  int32_t cmd_track_curr; float cmd_max_curr;   // commands.curriculum / max_curriculum (:728-737)
   int32_t rand_strength, rand_offset, rand_pd, push_robots, push_interval, rand_delay;
   float strength_rng[2], offset_rng[2], kp_rng[2], kd_rng[2], push_xy, push_ang;
   float resampling_time; int32_t heading_command, dynamic_resample; float limit_vel_prob; int32_t limit_invert, stop_heading_at_limit;
@@ -109,15 +111,23 @@ struct Go2Launch {
 
 // counters that live in device memory and are advanced by the device itself, so that a step is a pure
 // enqueue (HIP-graph replayable): nothing the host computes per step is baked into kernel arguments
-struct Go2Dyn { uint64_t step_count; int64_t common_step_counter; int32_t use_injected; int32_t pad; };
+struct Go2Dyn { uint64_t step_count; int64_t common_step_counter; int32_t use_injected;
+                int32_t cmd_stage_seen;   // command_range_curriculum stage whose lin_vel_x the tracked list was last set from (-2: none yet)
+                float cmd_x_range[2]; };  // command_ranges['lin_vel_x'] as update_command_curriculum (:728-737) keeps it
 
 // per-step scalars (what the reference keeps as Python floats), recomputed by every workgroup from
 // Go2Dyn.common_step_counter into LDS: they are pure functions of counter // num_steps_per_env
 struct Go2Step {
-  uint32_t step_lo, step_hi; int32_t initial_reset; const float* injected;
+  uint32_t step_lo, step_hi; int32_t initial_reset /* 0 step, 1 reset_idx(all) before the first step, 2 go2sim_reset_idx */; const float* injected;
   float rew_scale[GO2_NUM_REWARDS];  // scale * dt * curriculum
   float rew_to_scale[GO2_NUM_REWARDS];   // turn_over scale * dt * curriculum
   float cmd_ranges[4][2], max_lin_vel, zero_cmd_proba;
+  // The reference refreshes its command ranges lazily — inside _resample_commands, when called with >= 1 env (legged_robot.py:433-446).  The
+  // resampled commands themselves therefore always see the stage of the current iteration (cmd_ranges above); the heading controller's clip
+  // (:411-419), which runs for every env right after the callback's _resample_commands, sees the new stage only if SOME env of the batch was
+  // resampled by the callback in this step.  stage_pending: a stage has started that no _resample_commands call has picked up yet
+  // (heading_command only) -> the workgroup scans the batch's command timers; yaw_range_seen: ang_vel_yaw of the stage last picked up.
+  int32_t stage_pending; float yaw_range_seen[2];
   uint32_t rew_mask;                 // bit t: reward term t is computed (Go2Launch.rew_on[t]); 0 during the initial reset
   uint32_t rew_mask_all;             // the same, also during the initial reset
 };

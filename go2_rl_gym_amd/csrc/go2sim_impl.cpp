@@ -9,6 +9,7 @@
 //       kernel arithmetic can be checked against the oracle on a machine without a GPU.  Never loaded by the product (go2_rl_gym_amd/_lib.py
 //       accepts only a library whose go2sim_is_device_library() is 1).
 #include <math.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -48,7 +49,10 @@ struct LaneAux { float kp[3], kd[3], q0[3], zoff[3], strength[3], act_new[3], ac
 #define LANE_PARAMS LegPhys& ph_, LegPost& po_, LaneAux& ax
 #define GO2_NUM_GROUPS 44     // Philox groups of one env-step (go2sim_rng.h: 0..42) rounded up
 // LDS: robot link / collision tables (per-lane leg index -> ds_read), this step's scalars, and per environment the table of drawn uniforms
-struct Go2Shared { Go2Tables tab; Go2Step S; float ucache[GO2_WG_ENVS][GO2_NUM_GROUPS][4]; };
+struct Go2Shared {
+  Go2Tables tab; Go2Step S; float ucache[GO2_WG_ENVS][GO2_NUM_GROUPS][4];
+  int32_t cb_any;      // Go2Step.stage_pending: some env of the BATCH is resampled by this step's post-physics callback
+};
 
 GO2_HD void lane_load_phys(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p, const Go2Launch& L, const Go2Step& S, const float* actions_in, float u_delay, int e, int lane, int sub) {
   const int N = L.N;
@@ -188,7 +192,7 @@ GO2_HD void lane_load_physout(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK&
 GO2_HD void lane_init_post(LANE_PARAMS, const GO2_AS3 uint8_t* codes, GO2_AS3 float (*uc)[4], const Go2PtrsK* p, const Go2Launch* L, const Go2Step* S, int e, int lane, int sub) {
   po_.codes = codes; po_.uc = uc;
   po_.e = e; po_.lane = lane; po_.sub = sub; po_.lane16 = lane * 4 + sub; po_.N = L->N; po_.P = p; po_.L = L; po_.S = S;
-  po_.skip_contact_filters = false; po_.new_lc = po_.new_lc2 = 0; po_.new_fat = 0.f;
+  po_.skip_contact_filters = false; po_.api_reset = false; po_.yaw_seen = false; po_.new_lc = po_.new_lc2 = 0; po_.new_fat = 0.f;
 }
 // reset_idx(all envs) without a step (base_task.py:82-84): postB's reset branch with reset forced on
 GO2_HD void lane_reset_all(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p, const Go2Launch& L, const Go2Step& S, GO2_AS3 float (*uc)[4], int e, int lane, int sub) {
@@ -196,7 +200,7 @@ GO2_HD void lane_reset_all(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p,
   lane_load_physout(ph_, po_, ax, tab, p, L, e, lane);
   lane_init_post(ph_, po_, ax, (const GO2_AS3 uint8_t*)tab.slot_code, uc, &p, &L, &S, e, lane, sub);
   LegPost& po = po_;
-  po.skip_contact_filters = true;
+  po.skip_contact_filters = true; po.api_reset = S.initial_reset == 2;
   // load what postA would have loaded, without advancing any clock
   po.ep_len = p.ep_len[e]; po.timer = p.cmd_timer[e];
   _Pragma("unroll") for (int k = 0; k < 4; ++k) po.cmd[k] = F2D(p.commands, k, e);
@@ -216,10 +220,18 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(GO2_GENERIC(const Go2Tables*, p.tables)); uint32_t* dst = reinterpret_cast<uint32_t*>(&sh.tab);
     for (int i = tid; i < (int)(sizeof(Go2Tables) / 4); i += GO2_WG_THREADS) dst[i] = src[i];
-    if (tid == 0) go2_step_scalars(L, blk->dyn, GO2_GENERIC(const float*, p.inj_storage), blk->dyn.common_step_counter + ((MODE & MODE_POST) ? 1 : 0), initial_reset, &sh.S);
+    if (tid == 0) { sh.cb_any = 0; go2_step_scalars(L, blk->dyn, GO2_GENERIC(const float*, p.inj_storage), blk->dyn.common_step_counter + ((MODE & MODE_POST) ? 1 : 0), initial_reset, &sh.S); }
   }
   xl::sync();
   const Go2Tables& tab = sh.tab; const Go2Step& S = sh.S;
+  bool yaw_seen = false;
+  if ((MODE & MODE_POST) && S.stage_pending) {   // rare (the steps between the start of a command_range_curriculum stage and the next resample)
+    bool mine = false;                           // _post_physics_step_callback's resampling_env_ids (:408) over the whole batch
+    for (int i = tid; i < L.N; i += GO2_WG_THREADS) mine = mine || (p.cmd_timer[i] - 1.f <= 0.f && (float)(p.ep_len[i] + 1) < L.max_episode_length - 1.f);
+    if (mine) sh.cb_any = 1;
+    xl::sync();
+    yaw_seen = !sh.cb_any;
+  }
   const int e = bid * GO2_WG_ENVS + (tid >> 4), lane = (tid >> 2) & 3, sub = tid & 3;
   if (e >= L.N) return;   // whole rows (environments) leave together
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -242,6 +254,7 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
   }
   xl::row_sync();
   if (MODE & MODE_RESET_ALL) {
+    if (initial_reset == 2 && !p.reset_mask[e]) return;      // go2sim_reset_idx: only the listed environments (whole rows leave)
     lane_reset_all(ph_, po_, ax, tab, p, L, S, uc, e, lane, sub);
     float red[GO2_POST_PARTIALS];
 #pragma unroll
@@ -262,7 +275,7 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
       const bool old = L.rand_delay && sb < ax.start;
       const float a[3] = {old ? ax.act_old[0] : ax.act_new[0], old ? ax.act_old[1] : ax.act_new[1], old ? ax.act_old[2] : ax.act_new[2]};
       GO2_MARK(10);
-      ph_.pd(tl, hl, a, ax.kp, ax.kd, ax.q0, ax.zoff, ax.strength);
+      ph_.pd(tl, hl, a, ax.kp, ax.kd, ax.q0, ax.zoff, ax.strength, p.last_dof_vel, L.N, e);
       float part[GO2_QUAD_PARTIALS];
       ph_.phaseA(tl, hl, part);
       GO2_MARK(11);
@@ -301,6 +314,7 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
   if (MODE & MODE_POST) {
     GO2_MARK(21);
     lane_init_post(ph_, po_, ax, (const GO2_AS3 uint8_t*)tab.slot_code, uc, &p, &L, &S, e, lane, sub);
+    po_.yaw_seen = yaw_seen;
     float part[GO2_POST_PARTIALS];
     po_.postA(t, part);
     GO2_MARK(22);
@@ -342,7 +356,7 @@ __global__ void __launch_bounds__(64) go2_torque_trace_kernel(const Go2DevBlock*
     const float a[3] = {old ? ax.act_old[0] : ax.act_new[0], old ? ax.act_old[1] : ax.act_new[1], old ? ax.act_old[2] : ax.act_new[2]};
     for (int j = 0; j < 3; ++j) { const float* d = dof + (((size_t)sub * N + e) * 12 + 3 * lane + j) * 2; ph_.q[j] = d[0]; ph_.qd[j] = d[1]; }
     LegLoop tl; tl.load(t, 0);
-    ph_.pd(tl, L, a, ax.kp, ax.kd, ax.q0, ax.zoff, ax.strength);
+    ph_.pd(tl, L, a, ax.kp, ax.kd, ax.q0, ax.zoff, ax.strength, p.last_dof_vel, N, e);
     for (int j = 0; j < 3; ++j) { out[((size_t)sub * N + e) * 12 + 3 * lane + j] = ph_.tau[j]; F2D(p.torques, 3 * lane + j, e) = ph_.tau[j]; }
   }
 }
@@ -379,13 +393,17 @@ __global__ void go2_strict_ops_kernel(const float* __restrict__ a, const float* 
 __global__ void go2_finish_kernel(Go2DevBlock* blk, int counter_inc) {
   float* accum = blk->p.ep_accum; float* info = blk->p.episode_info;
   int i = threadIdx.x;
-  float cnt = accum[GO2_NUM_REWARDS];
+  float cnt = accum[GO2_NUM_REWARDS], track = accum[GO2_REW_TRACKING_LIN_VEL], cb = accum[GO2_NUM_REWARDS + 1];
   __syncthreads();
   if (i <= GO2_NUM_REWARDS) {
     if (cnt > 0.f) info[i] = i < GO2_NUM_REWARDS ? accum[i] / cnt / blk->L.episode_length_s : cnt;
     accum[i] = 0.f;
   }
-  if (i == 0) { blk->dyn.common_step_counter += counter_inc; blk->dyn.step_count += 1; blk->dyn.use_injected = 0; }
+  if (i == 0) {
+    accum[GO2_NUM_REWARDS + 1] = 0.f;
+    go2_track_cmd_curriculum(blk->L, blk->dyn, cnt, track, cb, blk->dyn.common_step_counter + counter_inc, info + GO2_NUM_REWARDS + 1);
+    blk->dyn.common_step_counter += counter_inc; blk->dyn.step_count += 1; blk->dyn.use_injected = 0;
+  }
 }
 __global__ void go2_peek_kernel(float* out, const Go2Tables* tab, int N, int env_offset, uint32_t s0, uint32_t s1, uint32_t k0, uint32_t k1) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -696,9 +714,10 @@ static void fill_tables(Go2Tables* T) {
 
 static void blk_sync_dyn(Go2Sim* s, void* stream) {   // host mirror -> device counters (rare: create, set_counter, inject)
 #ifdef GO2_EMU
-  (void)stream; s->d_blk->dyn = s->h.dyn;
+  // only the counters the host owns: the tracked command list behind them (cmd_stage_seen, cmd_x_range) lives on the device alone
+  (void)stream; memcpy(&s->d_blk->dyn, &s->h.dyn, offsetof(Go2Dyn, cmd_stage_seen));
 #else
-  hipMemcpyAsync(&s->d_blk->dyn, &s->h.dyn, sizeof(Go2Dyn), hipMemcpyHostToDevice, (hipStream_t)stream);
+  hipMemcpyAsync(&s->d_blk->dyn, &s->h.dyn, offsetof(Go2Dyn, cmd_stage_seen), hipMemcpyHostToDevice, (hipStream_t)stream);
 #endif
 }
 
@@ -744,6 +763,7 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
   if (!cfg || !out) FAIL(GO2SIM_EINVAL, "null argument");
   if (cfg->struct_size != sizeof(Go2SimCfg) || cfg->abi_version != GO2SIM_ABI_VERSION) FAIL(GO2SIM_EINVAL, "cfg size/version mismatch (%u vs %zu)", cfg->struct_size, sizeof(Go2SimCfg));
   if (cfg->num_envs <= 0 || cfg->decimation <= 0 || cfg->num_envs_global < cfg->env_offset + cfg->num_envs) FAIL(GO2SIM_EINVAL, "bad num_envs/decimation");
+  if (cfg->control_type < 0 || cfg->control_type > 2) FAIL(GO2SIM_EINVAL, "control_type must be 0 (P), 1 (V) or 2 (T)");
   if (cfg->terrain_mode != 0 && (!cfg->hf_samples || !cfg->terrain_origins || !cfg->terrain_type_id)) FAIL(GO2SIM_EINVAL, "heightfield terrain needs hf_samples, terrain_origins, terrain_type_id");
   if (cfg->limit_vel_comb_count > 36 || cfg->cmd_curriculum_count > 4 || cfg->reward_curriculum_count > 4) FAIL(GO2SIM_EINVAL, "table sizes out of range");
 #ifndef GO2_EMU
@@ -769,7 +789,7 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
   A(motor_strengths, float, N * 12); A(motor_zero_offsets, float, N * 12); A(p_gains_multiplier, float, N * 12); A(d_gains_multiplier, float, N * 12);
   A(env_origins, float, N * 3); A(terrain_levels, int64_t, N); A(terrain_types, int64_t, N); A(episode_sums, float, GO2_NUM_REWARDS * N);
   A(friction_coeffs, float, N); A(restitution_coeffs, float, N); A(added_base_mass, float, N); A(added_base_com, float, N * 3); A(link_mass_ratio, float, N * 18);
-  A(episode_info, float, GO2_NUM_REWARDS + 1); A(foot_impulse, float, N * 12);
+  A(episode_info, float, GO2_EPISODE_INFO_LEN); A(foot_impulse, float, N * 12);
 #undef A
   Go2Ptrs& p = s->h.p; Go2SimBuffers& b = s->b;
   p.root = b.root_states; p.dof = b.dof_state; p.contact = b.contact_forces; p.rigid = b.rigid_body_states; p.obs = b.obs_buf; p.priv = b.privileged_obs_buf; p.rew = b.rew_buf;
@@ -780,11 +800,11 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
   p.last_contacts2 = b.last_contacts2; p.strength = b.motor_strengths; p.zero_off = b.motor_zero_offsets; p.kp_mul = b.p_gains_multiplier; p.kd_mul = b.d_gains_multiplier; p.origins = b.env_origins;
   p.terrain_levels = b.terrain_levels; p.terrain_types = b.terrain_types; p.ep_sums = b.episode_sums; p.friction = b.friction_coeffs; p.restitution = b.restitution_coeffs;
   p.added_mass = b.added_base_mass; p.added_com = b.added_base_com; p.mass_ratio = b.link_mass_ratio; p.episode_info = b.episode_info; p.foot_impulse = b.foot_impulse;
-  p.terrain_kind = (int32_t*)dev_alloc(s, sizeof(int32_t) * N); p.ep_accum = (float*)dev_alloc(s, sizeof(float) * (GO2_NUM_REWARDS + 1));
+  p.terrain_kind = (int32_t*)dev_alloc(s, sizeof(int32_t) * N); p.reset_mask = (uint8_t*)dev_alloc(s, (size_t)N); p.ep_accum = (float*)dev_alloc(s, sizeof(float) * (GO2_NUM_REWARDS + 2));
   s->inj_storage = (float*)dev_alloc(s, sizeof(float) * (size_t)N * GO2_NUM_UNIFORMS); p.inj_storage = s->inj_storage;
   s->d_tables = (Go2Tables*)dev_alloc(s, sizeof(Go2Tables));
   s->d_blk = (Go2DevBlock*)dev_alloc(s, sizeof(Go2DevBlock));
-  ok = ok && p.terrain_kind && p.ep_accum && s->inj_storage && s->d_tables && s->d_blk;
+  ok = ok && p.terrain_kind && p.reset_mask && p.ep_accum && s->inj_storage && s->d_tables && s->d_blk;
   if (!ok) { go2sim_destroy(s); FAIL(GO2SIM_ENOMEM, "allocation failed"); }
   { Go2Tables T; fill_tables(&T); if (!T.layout_ok) FAIL(GO2SIM_EINVAL, "table layout check failed: collision candidates not tabulated hip/thigh/calf (include/go2_model_data.h vs go2_tables.h), or go2_slot_code != go2sim_rng.h");
     dev_upload(s->d_tables, &T, sizeof(T)); p.tables = s->d_tables; }
@@ -804,6 +824,7 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
   L.terrain_friction = cfg->terrain_friction; L.terrain_restitution = cfg->terrain_restitution; L.terrain_num_levels = cfg->terrain_num_levels; L.terrain_num_types = cfg->terrain_num_types;
   L.terrain_curriculum = cfg->terrain_curriculum; L.move_down_by_acc = cfg->move_down_by_accumulated_xy_command; L.measure_heights = cfg->measure_heights; L.full_body_states = cfg->full_body_states; L.terrain_length = cfg->terrain_length;
   memcpy(L.kp, cfg->kp, sizeof(L.kp)); memcpy(L.kd, cfg->kd, sizeof(L.kd)); memcpy(L.q0, cfg->default_dof_pos, sizeof(L.q0));
+  L.control_type = cfg->control_type; L.cmd_track_curr = cfg->cmd_tracking_curriculum; L.cmd_max_curr = cfg->cmd_max_curriculum;
   L.action_scale = cfg->action_scale; L.clip_actions = cfg->clip_actions; L.clip_obs = cfg->clip_observations; memcpy(L.base_init, cfg->base_init_state, sizeof(L.base_init));
   L.rand_strength = cfg->randomize_motor_strength; L.rand_offset = cfg->randomize_motor_zero_offset; L.rand_pd = cfg->randomize_pd_gains; L.push_robots = cfg->push_robots;
   L.push_interval = cfg->push_interval; L.rand_delay = cfg->randomize_action_delay;
@@ -896,6 +917,7 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
   dev_upload(b.root_states, root.data(), 52 * N); dev_upload(b.dof_state, dof.data(), 96 * N); dev_upload(b.terrain_levels, lv.data(), 8 * N); dev_upload(b.terrain_types, ty.data(), 8 * N);
   dev_upload(p.terrain_kind, kind.data(), 4 * N); dev_upload(b.reset_buf, rb.data(), N);
   dev_upload(b.motor_strengths, ones.data(), 48 * N); dev_upload(b.p_gains_multiplier, ones.data(), 48 * N); dev_upload(b.d_gains_multiplier, ones.data(), 48 * N);
+  s->h.dyn.cmd_stage_seen = -2; s->h.dyn.cmd_x_range[0] = cfg->cmd_ranges[0][0]; s->h.dyn.cmd_x_range[1] = cfg->cmd_ranges[0][1];
   dev_upload(s->d_blk, &s->h, sizeof(Go2DevBlock));
   *out = s;
   return 0;
@@ -922,7 +944,10 @@ static void emu_run(Go2Sim* s, int mode, const float* actions_in, int initial_re
   }
   if (mode != MODE_PHYS) {   // == go2_finish_kernel
     float* acc = p.ep_accum; float cnt = acc[GO2_NUM_REWARDS];
+    const float track = acc[GO2_REW_TRACKING_LIN_VEL], cb = acc[GO2_NUM_REWARDS + 1];
     for (int i = 0; i <= GO2_NUM_REWARDS; ++i) { if (cnt > 0.f) p.episode_info[i] = i < GO2_NUM_REWARDS ? acc[i] / cnt / L.episode_length_s : cnt; acc[i] = 0.f; }
+    acc[GO2_NUM_REWARDS + 1] = 0.f;
+    go2_track_cmd_curriculum(L, blk->dyn, cnt, track, cb, blk->dyn.common_step_counter + counter_inc, p.episode_info + GO2_NUM_REWARDS + 1);
     blk->dyn.common_step_counter += counter_inc; blk->dyn.step_count += 1; blk->dyn.use_injected = 0;
   }
 }
@@ -985,6 +1010,25 @@ int go2sim_notify_replayed(Go2Sim* s, int32_t steps) {
   return 0;
 }
 int go2sim_reset_all(Go2Sim* s, void* stream) { if (!s) FAIL(GO2SIM_EINVAL, "null handle"); return launch(s, MODE_RESET_ALL, nullptr, 1, 0, stream); }
+#ifndef GO2_EMU
+__global__ void go2_mark_kernel(uint8_t* mask, const int32_t* ids, int count, int N) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) { const int e = ids[i]; if (e >= 0 && e < N) mask[e] = 1; }
+}
+#endif
+// reset_idx(env_ids) from outside a step: the reset branch of post-physics (go2_post.h) over the listed environments only
+int go2sim_reset_idx(Go2Sim* s, const int32_t* env_ids, int32_t count, void* stream) {
+  if (!s || count < 0 || (count > 0 && !env_ids)) FAIL(GO2SIM_EINVAL, "bad argument");
+  if (count == 0) return 0;                                   // legged_robot.py:189-190
+#ifdef GO2_EMU
+  memset(s->d_blk->p.reset_mask, 0, (size_t)s->N);
+  for (int i = 0; i < count; ++i) if (env_ids[i] >= 0 && env_ids[i] < s->N) s->d_blk->p.reset_mask[env_ids[i]] = 1;
+#else
+  HIPCHK(hipMemsetAsync(s->h.p.reset_mask, 0, (size_t)s->N, (hipStream_t)stream));
+  hipLaunchKernelGGL(go2_mark_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, s->h.p.reset_mask, env_ids, count, s->N);
+#endif
+  return launch(s, MODE_RESET_ALL, nullptr, 2, 0, stream);
+}
 int go2sim_simulate(Go2Sim* s, void* stream) { if (!s) FAIL(GO2SIM_EINVAL, "null handle"); return launch(s, MODE_PHYS, nullptr, 0, 0, stream); }
 int go2sim_post_physics(Go2Sim* s, void* stream) { if (!s) FAIL(GO2SIM_EINVAL, "null handle"); return launch(s, MODE_POST, nullptr, 0, 1, stream); }
 int go2sim_step(Go2Sim* s, const float* actions, void* stream) {
@@ -1049,7 +1093,7 @@ int go2sim_debug_torque_trace(Go2Sim* s, const float* actions_raw, const float* 
       const float a[3] = {old ? ax.act_old[0] : ax.act_new[0], old ? ax.act_old[1] : ax.act_new[1], old ? ax.act_old[2] : ax.act_new[2]};
       for (int j = 0; j < 3; ++j) { const float* d = dof + (((size_t)sub * N + e) * 12 + 3 * lane + j) * 2; ph_.q[j] = d[0]; ph_.qd[j] = d[1]; }
       LegLoop tl; tl.load(tab.leg[lane], 0);
-      ph_.pd(tl, L, a, ax.kp, ax.kd, ax.q0, ax.zoff, ax.strength);
+      ph_.pd(tl, L, a, ax.kp, ax.kd, ax.q0, ax.zoff, ax.strength, p.last_dof_vel, N, e);
       for (int j = 0; j < 3; ++j) { out[((size_t)sub * N + e) * 12 + 3 * lane + j] = ph_.tau[j]; F2D(p.torques, 3 * lane + j, e) = ph_.tau[j]; }
     }
   }

@@ -117,8 +117,9 @@ class LeggedRobot(BaseTask):
             for key in cfg.control.stiffness:
                 if key in name:
                     c.kp[i], c.kd[i] = cfg.control.stiffness[key], cfg.control.damping[key]
-        if cfg.control.control_type != "P":
-            raise NotImplementedError("only control_type 'P' (the go2 tasks) is implemented")
+        if cfg.control.control_type not in ("P", "V", "T"):
+            raise NameError(f"Unknown controller type: {cfg.control.control_type}")          # legged_robot.py:616-617
+        c.control_type = "PVT".index(cfg.control.control_type)
         c.action_scale, c.clip_actions, c.clip_observations = cfg.control.action_scale, cfg.normalization.clip_actions, cfg.normalization.clip_observations
         init = cfg.init_state.pos + cfg.init_state.rot + cfg.init_state.lin_vel + cfg.init_state.ang_vel      # :1000
         for i in range(13):
@@ -145,9 +146,7 @@ class LeggedRobot(BaseTask):
         c.push_robots, c.push_interval, c.max_push_vel_xy, c.max_push_ang_vel = int(d.push_robots), int(d.push_interval), d.max_push_vel_xy, d.max_push_ang_vel
         c.randomize_action_delay = int(d.randomize_action_delay)
         cm = cfg.commands
-        if getattr(cm, "curriculum", False):
-            raise NotImplementedError("commands.curriculum (tracking-reward-driven widening of lin_vel_x, legged_robot.py:728-737) is off in every go2 config "
-                                      "and not built; the iteration-driven command_range_curriculum / zero_command_curriculum are")
+        c.cmd_tracking_curriculum, c.cmd_max_curriculum = int(getattr(cm, "curriculum", False)), float(getattr(cm, "max_curriculum", 1.0))
         c.cmd_resampling_time, c.heading_command, c.dynamic_resample_commands = cm.resampling_time, int(cm.heading_command), int(cm.dynamic_resample_commands)
         c.limit_vel_prob, c.limit_vel_invert_when_continuous, c.stop_heading_at_limit = cm.limit_vel_prob, int(cm.limit_vel_invert_when_continuous), int(cm.stop_heading_at_limit)
         c.limit_ang_vel_at_zero_command_prob = cm.limit_ang_vel_at_zero_command_prob
@@ -267,6 +266,7 @@ class LeggedRobot(BaseTask):
         self._episode_info = b["episode_info"]
         self._info_ring = torch.zeros(32, self._episode_info.shape[0], device=dev)
         self._info_slot = 0
+        self._first_reset_done = False
         self._active_idx = active
         self.extras = {}
         f32 = dict(dtype=torch.float, device=dev)
@@ -352,13 +352,20 @@ class LeggedRobot(BaseTask):
         return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     def reset_idx(self, env_ids):
-        """Only the all-envs form is exposed (base_task.py:82-84 is the reference's sole external caller); per-env resets
-        happen inside the step kernel exactly where post_physics_step does them (:132-133)."""
+        """legged_robot.py:180-245 from OUTSIDE a step (base_task.py:82-84 resets everything before the first step; a caller may reset any
+        subset later).  The per-env resets of a step happen inside the step kernel, exactly where post_physics_step does them (:132-133)."""
         if len(env_ids) == 0:
             return
-        if len(env_ids) != self.num_envs:
-            raise NotImplementedError("reset_idx(subset) from Python: resets are fused into the step kernel")
-        _abi.check(self.lib, self.lib.go2sim_reset_all(self.handle, self._stream()), "go2sim_reset_all")
+        if not self._first_reset_done:
+            if len(env_ids) != self.num_envs:
+                raise ValueError("the first reset_idx must cover every environment (base_task.py:82-84): the buffers are undefined before it")
+            self._first_reset_done = True
+            _abi.check(self.lib, self.lib.go2sim_reset_all(self.handle, self._stream()), "go2sim_reset_all")
+        else:
+            ids = torch.as_tensor(env_ids, device=self.device).to(torch.int32).contiguous()
+            self._reset_ids = ids                               # keep the id tensor alive until the enqueued kernels have run
+            ptr = C.c_void_p(ids.data_ptr())
+            _abi.check(self.lib, self.lib.go2sim_reset_idx(self.handle, ptr, int(ids.numel()), self._stream()), "go2sim_reset_idx")
         self._publish_extras()
 
     def _publish_extras(self):
@@ -377,7 +384,7 @@ class LeggedRobot(BaseTask):
         for i in self._active_idx:
             ep["rew_" + names[i]] = slot[i]
         if self.cfg.commands.curriculum:
-            ep["max_command_x"] = self.command_ranges["lin_vel_x"][1]
+            ep["max_command_x"] = slot[len(names) + 2]          # command_ranges['lin_vel_x'][1] as update_command_curriculum keeps it (:241-242)
         self.extras["episode"] = ep
         if self.cfg.env.send_timeouts:
             self.extras["time_outs"] = self.time_out_buf

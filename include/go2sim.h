@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GO2SIM_ABI_VERSION 4   /* 4: Go2SimCfg gained hf_cells / hf_walls (trimesh wall geometry); test hooks go2sim_debug_*;  3: 3: Go2SimCfg gained max_linear_velocity / max_angular_velocity; go2sim_elu_backward_bias workspace is C*ceil(B/64) */
+#define GO2SIM_ABI_VERSION 5   /* 5: Go2SimCfg gained control_type / cmd_tracking_curriculum / cmd_max_curriculum, go2sim_reset_idx, episode_info is GO2_EPISODE_INFO_LEN long;  4: Go2SimCfg gained hf_cells / hf_walls (trimesh wall geometry); test hooks go2sim_debug_*;  3: 3: Go2SimCfg gained max_linear_velocity / max_angular_velocity; go2sim_elu_backward_bias workspace is C*ceil(B/64) */
 
 #define GO2SIM_EINVAL   (-1)  /* bad argument / config */
 #define GO2SIM_ENOMEM   (-2)
@@ -77,6 +77,7 @@ enum {
   GO2_REW_TERMINATION,          /* :1281, added after the positive clip (:271-274) */
   GO2_NUM_REWARDS
 };
+#define GO2_EPISODE_INFO_LEN (GO2_NUM_REWARDS + 3)   /* Go2SimBuffers.episode_info */
 
 /* Per-env per-step uniform slots.  In normal operation each slot is Philox4x32-10(key = seed,
  * counter = {global env id, slot/4, step_lo, step_hi})[slot%4] mapped to [0,1); in test mode
@@ -155,6 +156,8 @@ typedef struct Go2SimCfg {
   float    kp[12], kd[12];
   float    default_dof_pos[12];
   float    action_scale;      /* 0.25 */
+  int32_t  control_type;      /* _compute_torques (legged_robot.py:607-617): 0 'P' position targets (every go2 task), 1 'V' velocity targets
+                               * tau = Kp (a s - qd) - Kd (qd - last_dof_vel) / sim_dt, 2 'T' tau = a s; all clipped to the torque limits */
   float    clip_actions;      /* 100 */
   float    clip_observations; /* 100 */
 
@@ -188,6 +191,13 @@ typedef struct Go2SimCfg {
   int32_t  cmd_curriculum_count;    /* command_range_curriculum entries (:433-446) */
   float    cmd_curriculum[4][9];    /* {iter, x0,x1, y0,y1, yaw0,yaw1, h0,h1} */
   float    terrain_max_cmd_ranges[9][4][2]; /* per terrain kind (go2_config.py:129-139) */
+  int32_t  cmd_tracking_curriculum; /* commands.curriculum (legged_robot_config.py:44; off in every go2 config): update_command_curriculum
+                                     * (legged_robot.py:728-737) widens command_ranges['lin_vel_x'] by 0.5 per reset step whose mean
+                                     * tracking_lin_vel episode sum exceeds 80 % of the maximum.  In this fork that list only feeds
+                                     * extras['episode']['max_command_x'] (:241-242): _resample_commands samples env_command_ranges, which is
+                                     * rebuilt from command_ranges only when a command_range_curriculum stage starts (:433-446), and the stage
+                                     * overwrites lin_vel_x first.  episode_info[GO2_NUM_REWARDS+1..+2] carry the list's two ends. */
+  float    cmd_max_curriculum;      /* commands.max_curriculum (1.0) */
 
   /* ---- rewards: go2_config.py:156-205 ---- */
   float    reward_scales[GO2_NUM_REWARDS]; /* RAW scales (before x dt); 0 = inactive */
@@ -276,7 +286,8 @@ typedef struct Go2SimBuffers {
   float*   added_base_com;     /* [N,3] */
   float*   link_mass_ratio;    /* [N,18] */
   /* extras["episode"] (legged_robot.py:229-242): mean over the envs reset in the latest step that
-   * had >= 1 reset, divided by max_episode_length_s; [GO2_NUM_REWARDS + 1] (last = #envs reset). */
+   * had >= 1 reset, divided by max_episode_length_s; [GO2_NUM_REWARDS + 3]: then the number of envs reset in that step, then
+   * command_ranges['lin_vel_x'] (lo, hi) as update_command_curriculum keeps it (extras['episode']['max_command_x'] = hi, :241-242). */
   float*   episode_info;
   /* warm-start impulses of the 4 foot contacts */
   float*   foot_impulse;       /* [N,4,3] */
@@ -303,6 +314,12 @@ int  go2sim_get_buffers(Go2Sim* h, Go2SimBuffers* out);
 /* ---- fused fast path ------------------------------------------------------------------------- */
 /* LeggedRobot.reset_idx(all envs) (base_task.py:82-84) without the following step. */
 int  go2sim_reset_all(Go2Sim* h, void* stream);
+/* LeggedRobot.reset_idx(env_ids) (legged_robot.py:180-245) called from OUTSIDE a step, for `count` env ids (int32, in the library's memory
+ * space like `actions`; duplicates allowed, ids outside [0, num_envs) are ignored): domain-randomisation redraws, terrain curriculum,
+ * _reset_dofs / _reset_root_states, the per-env buffers the reference clears, _resample_commands, the extras['episode'] means of the envs
+ * reset by this call, episode sums zeroed.  Like the reference it leaves obs_buf / rew_buf / time_out_buf and the derived base
+ * velocities of those envs as they were.  count == 0 is a no-op (:189-190).  (The per-env resets of a step happen inside go2sim_step.) */
+int  go2sim_reset_idx(Go2Sim* h, const int32_t* env_ids, int32_t count, void* stream);
 /* LeggedRobot.step (legged_robot.py:60-100): clip actions, `decimation` x {delay select, PD torque,
  * clip, strength, articulated-body substep with contact}, post_physics_step, clip observations.
  * `actions` is [N,12] in the library's memory space. */

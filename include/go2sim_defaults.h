@@ -46,6 +46,7 @@ static inline void go2sim_fill_default_cfg(Go2SimCfg* c) {
     for (int i = 0; i < 12; ++i) { c->kp[i] = 20.f; c->kd[i] = 0.5f; c->default_dof_pos[i] = q0[i]; } /* go2_config.py:80-81 */
   }
   c->action_scale = 0.25f;                       /* go2_config.py:83 */
+  c->control_type = 0;                           /* 'P', go2_config.py:78 */
   c->clip_actions = 100.f; c->clip_observations = 100.f; /* :222-223 */
   {
     static const float s0[13] = {0.f, 0.f, 0.42f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; /* go2_config.py:6, :91-93 */
@@ -69,6 +70,7 @@ static inline void go2sim_fill_default_cfg(Go2SimCfg* c) {
   c->limit_vel_invert_when_continuous = 1;       /* :108 */
   c->stop_heading_at_limit = 1;                  /* :110 */
   c->limit_ang_vel_at_zero_command_prob = 0.2f;  /* :106 */
+  c->cmd_tracking_curriculum = 0; c->cmd_max_curriculum = 1.f;   /* go2_config.py:99-100 */
   {
     /* itertools.product([-1,1],[-1,1],[-1,0,1]) (legged_robot.py:827-831, go2_config.py:109) */
     int n = 0;

@@ -132,7 +132,10 @@ def synth_state(rng, N, env, wide_roll=False):
 
 def gen_env_sequence(N=16, T=64, seed=7, mesh_type="plane", turn_over=False, overrides=None):
     rng = np.random.default_rng(seed)
-    env, env_cfg, train_cfg = make_env(N, mesh_type=mesh_type, turn_over=turn_over, overrides=overrides)
+    # (recorded BEFORE the run: update_command_curriculum edits command_ranges['lin_vel_x'] in place, and after a command_range_curriculum
+    #  stage has started that list IS the stage's config entry, legged_robot.py:438,736-737)
+    overrides_json = json.dumps(overrides) if overrides else None
+    env, env_cfg, train_cfg = make_env(N, mesh_type=mesh_type, turn_over=turn_over, overrides=json.loads(overrides_json) if overrides else None)
     hf = mesh_type != "plane"
     fig.patch_torch()
     names_active = list(env.episode_sums.keys())
@@ -180,6 +183,9 @@ def gen_env_sequence(N=16, T=64, seed=7, mesh_type="plane", turn_over=False, ove
     def new_table():
         return rng.uniform(0, 1, (N, NU)).astype(np.float32)
 
+    track_curr = bool((overrides or {}).get("commands.curriculum", False))
+    if track_curr:
+        rec["es_track_in"] = []; rec["cmd_x_range"] = []
     rec_levels0 = env.terrain_levels.numpy().copy() if hf else None
     origins0 = env.env_origins.numpy().copy()
     # ---- reset_idx(all) (base_task.py:82-84) with table 0 ------------------------------------------------
@@ -205,6 +211,11 @@ def gen_env_sequence(N=16, T=64, seed=7, mesh_type="plane", turn_over=False, ove
             env.commands_resampling_step[:] = torch.from_numpy(rng.integers(1, 60, N).astype(np.float32))
             if hf:   # spread the walked distances so the terrain curriculum moves envs up and down (:1154-1169)
                 env.max_move_distance[:] = torch.from_numpy(rng.uniform(0, 7, N).astype(np.float32))
+        if track_curr:
+            # update_command_curriculum (:728-737) compares the mean tracking_lin_vel episode sum of the envs being reset with 80 % of its
+            # maximum (= 0.8 * 0.02 * 1251 = 20.0): spread the sums around that threshold so that both outcomes occur
+            env.episode_sums["tracking_lin_vel"][:] = torch.from_numpy(rng.uniform(8.0, 34.0, N).astype(np.float32))
+            rec["es_track_in"].append(env.episode_sums["tracking_lin_vel"].numpy().copy())
         rec["ep_len_in"].append(env.episode_length_buf.numpy().copy())
         rec["cmd_timer_in"].append(env.commands_resampling_step.numpy().copy())
         rec["max_move_in"].append(env.max_move_distance.numpy().copy())
@@ -236,15 +247,45 @@ def gen_env_sequence(N=16, T=64, seed=7, mesh_type="plane", turn_over=False, ove
         rec["contact_in"].append(contact); rec["feet_in"].append(feet_state)
         rec["torques"].append(np.stack([x.numpy() for x in G.torque_log]))
         snapshot(rebuilt)
+        if track_curr:
+            rec["cmd_x_range"].append(np.array([float(env.command_ranges["lin_vel_x"][0]), float(env.command_ranges["lin_vel_x"][1])], np.float32))
+            if rebuilt:
+                assert float(env.extras["episode"]["max_command_x"]) == float(env.command_ranges["lin_vel_x"][1])
         counters["resets"] += int(env.reset_buf.sum()); counters["time_outs"] += int(env.time_out_buf.sum())
         counters["pushes"] += int((env.episode_length_buf % 200 == 0).sum())
         slots = [s for s, _, _ in fig.INJECT.log]
         counters["resample_cb"] += sum(1 for s in slots if s == fig.U["RSA"] + 3)
         counters["limit"] += sum(1 for s in slots if s in (fig.U["RSA"] + 4, fig.U["RSB"] + 4))
         counters["zero"] += sum(1 for s in slots if s in (fig.U["RSA"] + 5, fig.U["RSB"] + 5))
+    # ---- reset_idx(subset) called from outside a step (legged_robot.py:180-245), on the state the sequence ended in --------------------
+    ids = np.sort(rng.choice(N, size=max(N // 3, 2), replace=False)).astype(np.int64)
+    Ur = new_table()
+    if hf:
+        env.max_move_distance[:] = torch.from_numpy(rng.uniform(0, 7, N).astype(np.float32))
+    ri_in = dict(max_move=env.max_move_distance.numpy().copy())
+    fig.INJECT.table = torch.from_numpy(Ur)
+    env.reset_idx(torch.from_numpy(ids))
+    ri = dict(ids=ids, U=Ur, max_move_in=ri_in["max_move"], root=env.root_states.numpy().copy(), dof=env.dof_state.numpy().reshape(N, 12, 2).copy(),
+              commands=env.commands.numpy().copy(), cmd_timer=env.commands_resampling_step.numpy().copy(), cmd_xy_acc=env.commands_xy_accumulation.numpy().copy(),
+              ep_len=env.episode_length_buf.numpy().copy(), reset=env.reset_buf.numpy().astype(np.uint8), time_out=env.time_out_buf.numpy().astype(np.uint8),
+              obs=env.obs_buf.numpy().copy(), priv=env.privileged_obs_buf.numpy().copy(), rew=env.rew_buf.numpy().copy(),
+              last_actions=env.last_actions.numpy().copy(), last_dof_vel=env.last_dof_vel.numpy().copy(), actions=env.actions.numpy().copy(),
+              feet_air_time=env.feet_air_time.numpy().copy(), base_lin_vel=env.base_lin_vel.numpy().copy(), rpy=env.rpy.numpy().copy(),
+              motor_strengths=env.motor_strengths.numpy().copy(), motor_zero_offsets=env.motor_zero_offsets.numpy().copy(),
+              p_gains_multiplier=env.p_gains_multiplier.numpy().copy(), d_gains_multiplier=env.d_gains_multiplier.numpy().copy(),
+              last_is_limit_vel=env.last_is_limit_vel.numpy().astype(np.uint8), max_move=env.max_move_distance.numpy().copy(),
+              env_origins=env.env_origins.numpy().copy(), terrain_levels=env.terrain_levels.numpy().copy() if hf else np.zeros(N, np.int64),
+              turn_over_timer=env.turn_over_timer.numpy().copy())
+    es = np.zeros((ABI.GO2_NUM_REWARDS, N), np.float32); info = np.zeros(ABI.GO2_NUM_REWARDS, np.float32)
+    for n_, i_ in rew_index.items():
+        es[i_] = env.episode_sums[n_].numpy(); info[i_] = float(env.extras["episode"]["rew_" + n_])
+    ri["episode_sums"] = es; ri["episode_info"] = info
+    if track_curr:
+        ri["cmd_x_range"] = np.array([float(env.command_ranges["lin_vel_x"][0]), float(env.command_ranges["lin_vel_x"][1])], np.float32)
     fig.INJECT.table = None
     fig.unpatch_torch()
     out = {k: np.stack(v) for k, v in rec.items()}
+    out.update({"reset_idx_" + k: v for k, v in ri.items()})
     out.update({"reset_all_" + k: v for k, v in reset_all_out.items()})
     out["U_reset_all"] = U0
     out["start_counter"] = np.int64(start_counter)
@@ -273,7 +314,7 @@ def gen_env_sequence(N=16, T=64, seed=7, mesh_type="plane", turn_over=False, ove
         counters["level_changes"] = int((np.diff(np.concatenate([rec_levels0[None], lv]), axis=0) != 0).sum())
         counters["nonzero_heights"] = float((np.abs(np.stack(rec["measured_heights"])) > 0).mean())
     if overrides:
-        out["cfg_overrides"] = np.array(json.dumps(overrides))
+        out["cfg_overrides"] = np.array(overrides_json)
     if turn_over:
         tt = np.stack(rec["turn_over_timer"])
         counters["timer_running"] = int((tt > 0).sum()); counters["rolled"] = int((np.abs(np.stack(rec["rpy"])[..., 0]) > np.pi / 4).sum())
@@ -598,6 +639,15 @@ def main():
     _save(files, "go2_heightfield_sequence.npz", hfseq)
     _save(files, "go2_turn_over_sequence.npz", gen_env_sequence(N=12, T=40, seed=13, turn_over=True))
     _save(files, "go2_alt_sequence.npz", gen_env_sequence(N=12, T=48, seed=17, mesh_type="heightfield", overrides=ALT_OVERRIDES))
+    # (task_registry.get_cfgs returns the REGISTERED config instance, task_registry.py:24-28, so the ALT overrides above stay applied in this
+    #  process: they are part of these sequences' configuration and are recorded as such)
+    # the branches of the cited line ranges that no go2 task switches on: _compute_torques control types 'V' / 'T' (:612-615) and
+    # commands.curriculum (:225-226,:241-242,:728-737) across the start of a command_range_curriculum stage (:433-446)
+    _save(files, "go2_control_v_sequence.npz", gen_env_sequence(N=8, T=24, seed=19, overrides={**ALT_OVERRIDES, "control.control_type": "V"}))
+    _save(files, "go2_control_t_sequence.npz", gen_env_sequence(N=8, T=24, seed=23, overrides={**ALT_OVERRIDES, "control.control_type": "T"}))
+    _save(files, "go2_cmd_curriculum_sequence.npz", gen_env_sequence(N=12, T=56, seed=29, overrides={
+        **ALT_OVERRIDES, "control.control_type": "P", "commands.curriculum": True, "commands.max_curriculum": 1.5,
+        "commands.command_range_curriculum": [{"iter": 1001, "lin_vel_x": [-1.0, 1.0], "lin_vel_y": [-1.0, 1.0], "ang_vel_yaw": [-1.5, 1.5], "heading": [-1.57, 1.57]}]}))
     _save(files, "terrain.npz", gen_terrain())
     _save(files, "gae.npz", gen_gae())
     _save(files, "ppo_update.npz", gen_ppo())

@@ -234,6 +234,8 @@ struct Go2Sim {
   int reward_has_curr[GO2_NUM_REWARDS];
   R cmd_ranges[4][2]; R max_lin_vel; R zero_command_proba;
   int cmd_curr_done[4];
+  double cmd_x_track[2]; int cmd_stage_seen, cb_resamples;
+  int yaw_seen;            /* this pass: the heading clip (:411-419) still sees the ranges of cmd_stage_seen (see go2sim_post_physics) */   /* command_ranges['lin_vel_x'] under update_command_curriculum (:728-737) */
   R dof_pos_limits[12][2]; /* soft limits (:372-375) */
   R noise_vec[GO2_NUM_OBS];
   R friction_buckets[64];
@@ -461,11 +463,14 @@ static void point_jacobian(const Kin* k, int l, const R* pw, R Jw[3][NV]) {
 }
 
 static void pd_torques(const Go2Sim* s, int e, const R* q, const R* qd, const R* act_in, R* tau) {
-  /* _compute_torques (legged_robot.py:594-618, control_type 'P') then *= motor_strengths (:80-81) */
+  /* _compute_torques (legged_robot.py:594-618) then *= motor_strengths (:80-81) */
   const Go2SimBuffers* b = &s->b;
   for (int j=0;j<12;++j) {
     R kp = (R)s->cfg.kp[j]*(R)b->p_gains_multiplier[12*e+j], kd = (R)s->cfg.kd[j]*(R)b->d_gains_multiplier[12*e+j];
-    R t = kp*(act_in[j]*(R)s->cfg.action_scale + (R)s->cfg.default_dof_pos[j] - q[j] + (R)b->motor_zero_offsets[12*e+j]) - kd*qd[j];
+    R as = act_in[j]*(R)s->cfg.action_scale, t;
+    if (s->cfg.control_type == 1) t = kp*(as - qd[j]) - kd*(qd[j] - (R)b->last_dof_vel[12*e+j])/(R)s->cfg.sim_dt;      /* 'V' :612-613 */
+    else if (s->cfg.control_type == 2) t = as;                                                                          /* 'T' :614-615 */
+    else t = kp*(as + (R)s->cfg.default_dof_pos[j] - q[j] + (R)b->motor_zero_offsets[12*e+j]) - kd*qd[j];               /* 'P' :610-611 */
     R lim = (R)kJointEffort[j];
     if (t > lim) t = lim; if (t < -lim) t = -lim;
     if (s->cfg.randomize_motor_strength) t *= (R)b->motor_strengths[12*e+j];
@@ -908,11 +913,14 @@ static void post_physics_env(Go2Sim* s, int e) {
   quat_rotate_inverse(q,g,o); for (int i=0;i<3;++i) b->projected_gravity[3*e+i]=(float)o[i];
   { R dx=(R)root[0]-(R)b->env_origins[3*e], dy=(R)root[1]-(R)b->env_origins[3*e+1]; R d=SQRT(dx*dx+dy*dy); if (d>(R)b->max_move_distance[e]) b->max_move_distance[e]=(float)d; }
   /* _post_physics_step_callback (:404-421) */
-  if ((R)b->commands_resampling_step[e] <= 0 && (R)b->episode_length_buf[e] < s->max_episode_length-1) resample_commands(s, e, GO2_U_RSA);
+  if ((R)b->commands_resampling_step[e] <= 0 && (R)b->episode_length_buf[e] < s->max_episode_length-1) { resample_commands(s, e, GO2_U_RSA); s->cb_resamples++; }
   if (c->heading_command && !b->stop_heading[e]) {
     R f[3]={1,0,0}, fw[3]; quat_apply(q,f,fw); R heading=ATAN2(fw[1],fw[0]);
     R a=(R)b->commands[4*e+3]-heading; a = FMOD(a, 2*(R)M_PI); if (a<0) a += 2*(R)M_PI; if (a>(R)M_PI) a -= 2*(R)M_PI; /* wrap_to_pi (utils/math.py:15-18) */
-    R lo,hi; env_cmd_range(s,e,2,&lo,&hi); R y=RC(0.5)*a; if (y<lo) y=lo; if (y>hi) y=hi; b->commands[4*e+2]=(float)y; }
+    R lo,hi; env_cmd_range(s,e,2,&lo,&hi);
+    if (s->yaw_seen) { int sn = s->cmd_stage_seen; lo = sn<0 ? (R)c->cmd_ranges[2][0] : (R)c->cmd_curriculum[sn][5]; hi = sn<0 ? (R)c->cmd_ranges[2][1] : (R)c->cmd_curriculum[sn][6];
+      int kind = s->terrain_kind[e]; if (kind >= 0) { R tl=(R)c->terrain_max_cmd_ranges[kind][2][0], th=(R)c->terrain_max_cmd_ranges[kind][2][1]; if (tl>lo) lo=tl; if (th<hi) hi=th; } }
+    R y=RC(0.5)*a; if (y<lo) y=lo; if (y>hi) y=hi; b->commands[4*e+2]=(float)y; }
   if (c->measure_heights) get_heights(s, e);
   /* check_termination (:170-178): termination body = base (index 0) */
   { const float* F=b->contact_forces+(size_t)e*NB*3; int r = !c->turn_over && SQRT((R)F[0]*F[0]+(R)F[1]*F[1]+(R)F[2]*F[2]) > 1;   /* :174 */
@@ -932,6 +940,24 @@ static void finish_episode_info(Go2Sim* s) { /* extras["episode"] (:229-242) */
     for (int t=0;t<GO2_NUM_REWARDS;++t) s->b.episode_info[t] = (float)(s->ep_sum[t]/s->ep_count/(double)s->cfg.episode_length_s);
     s->b.episode_info[GO2_NUM_REWARDS] = (float)s->ep_count;
   }
+  /* The Python list command_ranges['lin_vel_x'] (the reference works on whole batches: callback for all envs, then reset_idx for all
+   * reset envs).  Every _resample_commands call with >= 1 env replaces it when a new command_range_curriculum stage has started
+   * (:433-446): first the post-physics callback's call (:409-410), then — after update_command_curriculum widened it (:728-737) — the
+   * call inside reset_idx.  Nothing samples from the list in this fork (_resample_commands reads env_command_ranges, rebuilt only at a
+   * stage start from the replaced list); it is what extras['episode']['max_command_x'] reports (:241-242). */
+  { int64_t it = s->common_step_counter / s->cfg.num_steps_per_env; int stage = -1;
+    for (int i=0;i<s->cfg.cmd_curriculum_count;++i) if ((double)it >= s->cfg.cmd_curriculum[i][0] && (stage<0 || s->cfg.cmd_curriculum[i][0] > s->cfg.cmd_curriculum[stage][0])) stage=i;
+    for (int call=0; call<2; ++call) {
+      if (call==0 ? s->cb_resamples == 0 : s->ep_count == 0) continue;
+      if (call==1 && s->cfg.cmd_tracking_curriculum &&
+          s->ep_sum[GO2_REW_TRACKING_LIN_VEL]/s->ep_count/(double)s->max_episode_length > 0.8*(double)s->cfg.reward_scales[GO2_REW_TRACKING_LIN_VEL]*(double)s->dt) {
+        double lo = s->cmd_x_track[0]-0.5, hi = s->cmd_x_track[1]+0.5, m = (double)s->cfg.cmd_max_curriculum;
+        s->cmd_x_track[0] = lo < -m ? -m : (lo > 0 ? 0 : lo); s->cmd_x_track[1] = hi < 0 ? 0 : (hi > m ? m : hi);
+      }
+      if (stage != s->cmd_stage_seen) { s->cmd_stage_seen = stage; if (stage >= 0) { s->cmd_x_track[0] = s->cfg.cmd_curriculum[stage][1]; s->cmd_x_track[1] = s->cfg.cmd_curriculum[stage][2]; } }
+    }
+    s->cb_resamples = 0; }
+  s->b.episode_info[GO2_NUM_REWARDS+1] = (float)s->cmd_x_track[0]; s->b.episode_info[GO2_NUM_REWARDS+2] = (float)s->cmd_x_track[1];
   memset(s->ep_sum,0,sizeof(s->ep_sum)); s->ep_count=0;
 }
 
@@ -958,6 +984,7 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
   if (!cfg || !out) { snprintf(g_err,sizeof(g_err),"null argument"); return GO2SIM_EINVAL; }
   if (cfg->struct_size != sizeof(Go2SimCfg) || cfg->abi_version != GO2SIM_ABI_VERSION) { snprintf(g_err,sizeof(g_err),"cfg size/version mismatch (%u vs %zu)", cfg->struct_size, sizeof(Go2SimCfg)); return GO2SIM_EINVAL; }
   if (cfg->num_envs <= 0 || cfg->decimation <= 0 || cfg->num_envs_global < cfg->env_offset + cfg->num_envs) { snprintf(g_err,sizeof(g_err),"bad num_envs/decimation"); return GO2SIM_EINVAL; }
+  if (cfg->control_type < 0 || cfg->control_type > 2) { snprintf(g_err,sizeof(g_err),"control_type must be 0 (P), 1 (V) or 2 (T)"); return GO2SIM_EINVAL; }
   if (cfg->terrain_mode != 0 && (!cfg->hf_samples || !cfg->terrain_origins || !cfg->terrain_type_id)) { snprintf(g_err,sizeof(g_err),"heightfield terrain needs hf_samples, terrain_origins, terrain_type_id"); return GO2SIM_EINVAL; }
   Go2Sim* s = (Go2Sim*)calloc(1,sizeof(Go2Sim)); if (!s) return GO2SIM_ENOMEM;
   s->cfg = *cfg; int N = s->N = cfg->num_envs;
@@ -970,7 +997,7 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
   ALLOC(motor_strengths,float,N*12); ALLOC(motor_zero_offsets,float,N*12); ALLOC(p_gains_multiplier,float,N*12); ALLOC(d_gains_multiplier,float,N*12);
   ALLOC(env_origins,float,N*3); ALLOC(terrain_levels,int64_t,N); ALLOC(terrain_types,int64_t,N); ALLOC(episode_sums,float,GO2_NUM_REWARDS*N);
   ALLOC(friction_coeffs,float,N); ALLOC(restitution_coeffs,float,N); ALLOC(added_base_mass,float,N); ALLOC(added_base_com,float,N*3); ALLOC(link_mass_ratio,float,N*18);
-  ALLOC(turn_over_timer,float,N); ALLOC(episode_info,float,GO2_NUM_REWARDS+1); ALLOC(foot_impulse,float,N*12);
+  ALLOC(turn_over_timer,float,N); ALLOC(episode_info,float,GO2_EPISODE_INFO_LEN); ALLOC(foot_impulse,float,N*12);
   s->terrain_kind = (int32_t*)malloc(sizeof(int32_t)*N); s->inj_storage = (float*)malloc(sizeof(float)*(size_t)N*GO2_NUM_UNIFORMS);
   s->dt = (R)cfg->decimation*(R)cfg->sim_dt;
   s->max_episode_length = (R)ceil((double)cfg->episode_length_s/(double)s->dt - 1e-3); /* np.ceil(25/0.02) = 1250 (:1104); the slack absorbs fp32 dt */
@@ -978,6 +1005,7 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
     s->turn_over_scale_dt[t] = cfg->turn_over ? (R)cfg->turn_over_scales[t]*s->dt : 0; }
   for (int i=0;i<cfg->reward_curriculum_count;++i) { int t=cfg->reward_curriculum_term[i]; s->reward_has_curr[t]=1; s->reward_curr_scale[t]=(R)cfg->reward_curriculum[i][2]; }
   for (int r=0;r<4;++r) { s->cmd_ranges[r][0]=(R)cfg->cmd_ranges[r][0]; s->cmd_ranges[r][1]=(R)cfg->cmd_ranges[r][1]; }
+  s->cmd_x_track[0]=cfg->cmd_ranges[0][0]; s->cmd_x_track[1]=cfg->cmd_ranges[0][1]; s->cmd_stage_seen=-2;
   for (int j=0;j<12;++j) { /* soft limits (:372-375), computed in fp32 like the reference's torch tensors */
     float lo=(float)kJointLower[j], hi=(float)kJointUpper[j]; float m=(lo+hi)/2, r=hi-lo;
     s->dof_pos_limits[j][0]=(R)(m-0.5f*r*(float)cfg->soft_dof_pos_limit); s->dof_pos_limits[j][1]=(R)(m+0.5f*r*(float)cfg->soft_dof_pos_limit); }
@@ -1038,6 +1066,19 @@ void go2sim_destroy(Go2Sim* s) {
 }
 int go2sim_get_buffers(Go2Sim* s, Go2SimBuffers* out) { if (!s||!out) return GO2SIM_EINVAL; *out = s->b; return 0; }
 
+/* reset_idx(env_ids) called from outside a step (legged_robot.py:180-245) */
+int go2sim_reset_idx(Go2Sim* s, const int32_t* env_ids, int32_t count, void* stream) {
+  (void)stream; if (!s || count < 0 || (count > 0 && !env_ids)) return GO2SIM_EINVAL;
+  if (count == 0) return 0;                                   /* :189-190 */
+  update_command_scalars(s);
+  uint8_t* hit = (uint8_t*)calloc((size_t)s->N, 1); if (!hit) return GO2SIM_ENOMEM;
+  for (int i=0;i<count;++i) if (env_ids[i] >= 0 && env_ids[i] < s->N) hit[env_ids[i]] = 1;
+  for (int e=0;e<s->N;++e) if (hit[e]) { reset_env(s, e, 0); s->b.reset_buf[e] = 1; }
+  free(hit);
+  finish_episode_info(s);
+  s->injected=NULL; s->step_count++;
+  return 0;
+}
 int go2sim_reset_all(Go2Sim* s, void* stream) {
   (void)stream; if (!s) return GO2SIM_EINVAL;
   update_command_scalars(s);
@@ -1085,7 +1126,15 @@ int go2sim_post_physics(Go2Sim* s, void* stream) {
   s->common_step_counter += 1;            /* :112 */
   update_reward_curriculum(s, 0);         /* :117 */
   update_command_scalars(s);
+  { /* The reference picks up a started command_range_curriculum stage inside _resample_commands, when called with >= 1 env (:433-446).
+     * Resampled commands therefore always see the current stage (update_command_scalars above); the heading clip (:411-419), applied to
+     * every env right after the callback's _resample_commands(resampling_env_ids) (:408-410), sees it only if that BATCH call had an env. */
+    int64_t it = s->common_step_counter / s->cfg.num_steps_per_env; int stage = -1, any = 0;
+    for (int i=0;i<s->cfg.cmd_curriculum_count;++i) if ((double)it >= s->cfg.cmd_curriculum[i][0] && (stage<0 || s->cfg.cmd_curriculum[i][0] > s->cfg.cmd_curriculum[stage][0])) stage=i;
+    for (int e=0;e<s->N && !any;++e) any = ((R)s->b.commands_resampling_step[e]-1 <= 0) && ((R)(s->b.episode_length_buf[e]+1) < s->max_episode_length-1);
+    s->yaw_seen = s->cfg.heading_command && stage != (s->cmd_stage_seen < 0 ? -1 : s->cmd_stage_seen) && !any; }
   for (int e=0;e<s->N;++e) post_physics_env(s,e);   /* serial: episode-info accumulation order */
+  s->yaw_seen = 0;
   finish_episode_info(s);
   s->injected=NULL; s->step_count++;
   return 0;

@@ -117,6 +117,10 @@ class HostSim:
     def reset_all(self):
         _abi.check(self.lib, self.lib.go2sim_reset_all(self.h, None), "reset_all")
 
+    def reset_idx(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        _abi.check(self.lib, self.lib.go2sim_reset_idx(self.h, ids.ctypes.data, len(ids), None), "reset_idx")
+
     def step(self, actions):
         a = np.ascontiguousarray(actions, dtype=self.real)
         _abi.check(self.lib, self.lib.go2sim_step(self.h, a.ctypes.data, None), "step")
@@ -226,6 +230,11 @@ class DeviceSim:
 
     def reset_all(self):
         _abi.check(self.lib, self.lib.go2sim_reset_all(self.h, self._st()), "reset_all")
+
+    def reset_idx(self, ids):
+        ids = self.torch.as_tensor(np.ascontiguousarray(ids, dtype=np.int32), device=self.device)
+        _abi.check(self.lib, self.lib.go2sim_reset_idx(self.h, C.c_void_p(ids.data_ptr()), int(ids.numel()), self._st()), "reset_idx")
+        self.torch.cuda.synchronize()
 
     def step(self, actions):
         a = self.torch.as_tensor(np.ascontiguousarray(actions, dtype=np.float32), device=self.device)

@@ -21,11 +21,13 @@ def hip():
     return lib
 
 
-@pytest.mark.parametrize("terrain", ["plane", "heightfield", "turn_over", "alt"])
+@pytest.mark.parametrize("terrain", tg.SEQUENCES)
 def test_golden_sequence_on_gpu(hip, terrain):
     """post_physics_step of the reference (golden vectors, injected uniforms) reproduced by the HIP kernel:
     obs / priv obs <= 2e-5, rewards <= 2e-6 (fp32, tolerances in test_oracle_golden.TOL).  heightfield: + the 187-point
-    height scan, terrain curriculum and per-terrain-kind command ranges."""
+    height scan, terrain curriculum and per-terrain-kind command ranges; control_v / control_t:
+    the other two control types of _compute_torques; cmd_curriculum: commands.curriculum across a command_range_curriculum stage start.  Each
+    sequence ends with a reset_idx(subset) from outside a step (go2sim_reset_idx) against the reference's."""
     g = dict(np.load(os.path.join(G, "go2_%s_sequence.npz" % terrain)))
     s = tg._mk(hip, g, sim=DeviceSim)
     n = 0
@@ -36,6 +38,7 @@ def test_golden_sequence_on_gpu(hip, terrain):
         tg.compare_step(s, g, t)
         n += 1
     assert n == g["actions"].shape[0]
+    tg.compare_reset_idx(s, g)
     s.close()
 
 

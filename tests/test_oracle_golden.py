@@ -14,7 +14,10 @@ G = os.path.join(ROOT, "tests", "golden")
 FEET = [6, 10, 14, 18]
 
 
-@pytest.fixture(scope="module", params=["plane", "heightfield", "turn_over", "alt"])
+SEQUENCES = ["plane", "heightfield", "turn_over", "alt", "control_v", "control_t", "cmd_curriculum"]
+
+
+@pytest.fixture(scope="module", params=SEQUENCES)
 def seq(request):
     return dict(np.load(os.path.join(G, "go2_%s_sequence.npz" % request.param)))
 
@@ -166,6 +169,8 @@ def run_sequence(s, lib, g, check):
         s.episode_length_buf[:] = g["ep_len_in"][t]
         s.commands_resampling_step[:] = g["cmd_timer_in"][t]
         s.max_move_distance[:] = g["max_move_in"][t]
+        if "es_track_in" in g:      # commands.curriculum sequence: the generator spreads these sums around update_command_curriculum's threshold
+            s.episode_sums[lib.abi.reward_names.index("tracking_lin_vel")] = g["es_track_in"][t]
         s.inject(g["U"][t])
         # substep i computes its torques from the DOF state left by simulate i-1 (legged_robot.py:79-92):
         # the library's own current state for i = 0, then the injected states
@@ -215,6 +220,41 @@ def compare_step(s, g, t):
     if g["episode_info_valid"][t]:
         n = len(g["episode_info"][t])
         np.testing.assert_allclose(s.episode_info[:n], g["episode_info"][t], atol=1e-6, rtol=1e-4)
+    if "cmd_x_range" in g:          # command_ranges['lin_vel_x'] under update_command_curriculum / a stage start (:728-737, :433-446)
+        np.testing.assert_array_equal(np.asarray(s.episode_info)[-2:], g["cmd_x_range"][t], err_msg="command_ranges['lin_vel_x'] after step %d" % t)
+
+
+def compare_reset_idx(s, g):
+    """reset_idx(env_ids) from outside a step (legged_robot.py:180-245) on the state the sequence ended in: everything the reference's
+    reset_idx writes for the listed envs, and everything it leaves alone — the other envs, and obs / reward / time-outs / derived
+    velocities of the listed ones."""
+    before = {k: np.asarray(getattr(s, k)).copy() for k in ("obs_buf", "privileged_obs_buf", "rew_buf", "time_out_buf", "base_lin_vel", "rpy", "last_root_vel", "last_last_actions")}
+    s.max_move_distance[:] = g["reset_idx_max_move_in"]
+    s.inject(g["reset_idx_U"])
+    s.reset_idx(g["reset_idx_ids"])
+    ids = g["reset_idx_ids"]
+    for k, v in before.items():
+        np.testing.assert_array_equal(np.asarray(getattr(s, k)), v, err_msg=k + " must not change in reset_idx")
+    np.testing.assert_allclose(s.obs_buf, g["reset_idx_obs"], atol=TOL["obs"], rtol=1e-5)
+    np.testing.assert_allclose(s.root_states[ids], g["reset_idx_root"][ids], atol=1e-6)
+    others = np.setdiff1d(np.arange(s.root_states.shape[0]), ids)
+    np.testing.assert_allclose(s.root_states[others, :7], g["reset_idx_root"][others, :7], atol=1e-6)
+    np.testing.assert_allclose(s.dof_state, g["reset_idx_dof"], atol=1e-6)
+    for k, buf, tol in (("commands", "commands", 1e-6), ("cmd_timer", "commands_resampling_step", 1e-3), ("cmd_xy_acc", "commands_xy_accumulation", 1e-5),
+                        ("last_actions", "last_actions", 0), ("actions", "actions", 0), ("last_dof_vel", "last_dof_vel", 0), ("feet_air_time", "feet_air_time", 1e-6),
+                        ("motor_strengths", "motor_strengths", 1e-6), ("motor_zero_offsets", "motor_zero_offsets", 1e-6), ("p_gains_multiplier", "p_gains_multiplier", 1e-6),
+                        ("d_gains_multiplier", "d_gains_multiplier", 1e-6), ("max_move", "max_move_distance", 1e-5), ("env_origins", "env_origins", 1e-6),
+                        ("episode_sums", "episode_sums", 2e-5), ("turn_over_timer", "turn_over_timer", 1e-5)):
+        np.testing.assert_allclose(getattr(s, buf), g["reset_idx_" + k], atol=tol, rtol=1e-5, err_msg="reset_idx: " + k)
+    for k, buf in (("ep_len", "episode_length_buf"), ("reset", "reset_buf"), ("time_out", "time_out_buf"), ("last_is_limit_vel", "last_is_limit_vel")):
+        np.testing.assert_array_equal(getattr(s, buf), g["reset_idx_" + k], err_msg="reset_idx: " + k)
+    if "hf_sha256" in g:
+        np.testing.assert_array_equal(s.terrain_levels, g["reset_idx_terrain_levels"])
+    n = len(g["reset_idx_episode_info"])
+    np.testing.assert_allclose(s.episode_info[:n], g["reset_idx_episode_info"], atol=1e-6, rtol=1e-4)
+    assert s.episode_info[n] == len(ids)
+    if "reset_idx_cmd_x_range" in g:
+        np.testing.assert_array_equal(np.asarray(s.episode_info)[-2:], g["reset_idx_cmd_x_range"])
 
 
 def _libs():
@@ -237,7 +277,11 @@ def test_sequence_matches_reference(seq, which):
         n += 1
     assert n == seq["actions"].shape[0]
     # the sequence exercised every branch we claim to pin
-    assert seq["reset"].sum() >= (6 if "turn_over" in seq else 18) and seq["time_out"].sum() >= 1
+    assert seq["reset"].sum() >= (6 if "turn_over" in seq else 10) and seq["time_out"].sum() >= 1
+    if "cmd_x_range" in seq:
+        hi = seq["cmd_x_range"][:, 1]
+        assert (np.diff(hi) > 0).sum() >= 3 and (np.diff(hi) < 0).sum() == 1      # widened (twice, up to max_curriculum), replaced by the stage, widened again
+    compare_reset_idx(s, seq)
     s.close()
 
 
