@@ -30,7 +30,14 @@ NUM_ENVS = 4096
 
 
 def parse():
-    p = argparse.ArgumentParser()
+    p = argparse.ArgumentParser(
+        description="env-steps/s of full PPO iterations (24 rollout steps + GAE + 5 x 4 mini-batch updates) on the HIP env library; prints ONE JSON line.",
+        epilog="GPU only: there is no --sim_device cpu path (the CPU restatement under oracle/ is test infrastructure).  Fields beyond the driver's "
+               "contract: collection_only (rollout without the update), graphs (whether rollout / update ran as replayed HIP graphs; the run fails "
+               "if capture degraded), rccl_ranks + collectives_per_iteration (process-group size actually used and all-reduces counted in the timed "
+               "region), roofline (HBM view of go2_step_kernel: algorithmic bytes / live HIP-event kernel time; traffic + valu_issue only when "
+               "profiles/ holds counters for the loaded library's sha256), cpu_baseline (oracle env + torch-CPU PPO at num_envs 64 and 4096 on this "
+               "host; a reported baseline, rank 0 at N=1 only).")
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=100)     # 100 iterations = 9.8 M env-steps, ~3 s on one MI355X
     p.add_argument("--warmup", type=int, default=20)     # resets / pushes / resamples reach their steady-state rates
