@@ -234,6 +234,20 @@ GO2_HD void rb_to_s6(const RB& I, float* A) {
   A[S6(3, 3)] = I.m; A[S6(4, 3)] = 0; A[S6(4, 4)] = I.m; A[S6(5, 3)] = 0; A[S6(5, 4)] = 0; A[S6(5, 5)] = I.m;
 }
 
+// sin and cos of |x| <= pi/2 to fp32 round-off (about 1 ulp), branch-free: the reset path's half-angle quaternion must agree with the
+// reference's torch.sin / torch.cos to 1e-6, which the hardware v_sin_f32 / v_cos_f32 (go2_sincos) do not promise.  Reduction to
+// [0, pi/4] by sin(x) = cos(pi/2 - x), then the minimax polynomials of the classic fdlibm float kernels.
+GO2_HD void go2_sincos_half_pi(float x, float* s, float* c) {
+  const float ax = fabsf(x);
+  const bool swap = ax > 0.78539816339744831f;
+  const float y = swap ? (1.57079632679489662f - ax) + (-4.37113883e-8f) : ax;      // pi/2 = fl(pi/2) - 4.37e-8
+  const float z = y * y;
+  const float sn = y + y * z * (-0.166666666416265235595f + z * (0.0083333293858894631756f + z * (-0.000198393348360966317347f + z * 0.0000027183114939898219064f)));
+  const float cs = 1.f + z * (-0.499999997251031003120f + z * (0.0416666233237390631894f + z * (-0.00138867637746099294692f + z * 0.0000243904487962774090654f)));
+  const float sa = swap ? cs : sn;
+  *s = x < 0.f ? -sa : sa; *c = swap ? sn : cs;
+}
+
 // ---- Philox4x32-10 (Salmon et al. SC'11): the same generator, key and counter layout as the oracle ----
 GO2_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
 #pragma unroll

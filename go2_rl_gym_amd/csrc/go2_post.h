@@ -74,15 +74,20 @@ GO2_HD void go2_track_cmd_curriculum(const Go2Launch& L, Go2Dyn& dyn, float rese
   }
   info_lo_hi[0] = dyn.cmd_x_range[0]; info_lo_hi[1] = dyn.cmd_x_range[1];
 }
-GO2_HD void go2_step_scalars(const Go2Launch& L, const Go2Dyn& dyn, const float* inj_storage, int64_t csc, int initial_reset, Go2Step* S) {
-  S->step_lo = (uint32_t)dyn.step_count; S->step_hi = (uint32_t)(dyn.step_count >> 32);
-  S->initial_reset = initial_reset; S->injected = dyn.use_injected ? inj_storage : nullptr;
-  float it = (float)(csc / L.num_steps_per_env);
-  _Pragma("unroll") for (int t = 0; t < GO2_NUM_REWARDS; ++t) {
+// The per-step scalars in GO2_STEP_SCALAR_PARTS independent parts, so that a workgroup computes them with one thread per part instead of
+// ~700 serial instructions in front of its barrier: part t < GO2_NUM_REWARDS = reward term t's scales, part GO2_NUM_REWARDS = the rest.
+#define GO2_STEP_SCALAR_PARTS (GO2_NUM_REWARDS + 1)
+GO2_HD void go2_step_scalars_part(int part, const Go2Launch& L, const Go2Dyn& dyn, const float* inj_storage, int64_t csc, int initial_reset, Go2Step* S) {
+  const float it = (float)(csc / L.num_steps_per_env);
+  if (part < GO2_NUM_REWARDS) {
+    const int t = part;
     float sc = L.rew_scale_dt[t], sct = L.rew_to_scale_dt[t];
     for (int i = 0; i < L.rew_curr_count; ++i) if (L.rew_curr_term[i] == t) { const float k = go2_current_scale(L.rew_curr[i], it); sc *= k; sct *= k; }
     S->rew_scale[t] = sc; S->rew_to_scale[t] = sct;
+    return;
   }
+  S->step_lo = (uint32_t)dyn.step_count; S->step_hi = (uint32_t)(dyn.step_count >> 32);
+  S->initial_reset = initial_reset; S->injected = dyn.use_injected ? inj_storage : nullptr;
   const int best = go2_cmd_stage(L, it);
   _Pragma("unroll") for (int r = 0; r < 4; ++r) {
     S->cmd_ranges[r][0] = best < 0 ? L.cmd_ranges0[r][0] : L.cmd_curr[best][1 + 2 * r];
@@ -95,9 +100,10 @@ GO2_HD void go2_step_scalars(const Go2Launch& L, const Go2Dyn& dyn, const float*
   }
   S->max_lin_vel = fmaxf(fmaxf(fabsf(S->cmd_ranges[0][0]), fabsf(S->cmd_ranges[0][1])), fmaxf(fabsf(S->cmd_ranges[1][0]), fabsf(S->cmd_ranges[1][1])));
   S->zero_cmd_proba = L.zero_curr_enabled ? go2_current_scale(L.zero_curr, it) : 0.f;
-  uint32_t mask = 0u;
-  _Pragma("unroll") for (int t = 0; t < GO2_NUM_REWARDS; ++t) if (L.rew_on[t]) mask |= 1u << t;
-  S->rew_mask = initial_reset ? 0u : mask; S->rew_mask_all = mask;
+  S->rew_mask = initial_reset ? 0u : L.rew_mask_all; S->rew_mask_all = L.rew_mask_all;
+}
+GO2_HD void go2_step_scalars(const Go2Launch& L, const Go2Dyn& dyn, const float* inj_storage, int64_t csc, int initial_reset, Go2Step* S) {
+  for (int part = 0; part < GO2_STEP_SCALAR_PARTS; ++part) go2_step_scalars_part(part, L, dyn, inj_storage, csc, initial_reset, S);
 }
 
 // slot -> (Philox group << 2 | word): the mapping of include/go2sim_rng.h (go2_fill_slot_codes) as a constant expression, so that a slot
@@ -153,6 +159,16 @@ struct LegPost {
     if (!S->injected) {
       if (lane16 < n) draw_group(g0 + lane16);
       else if (lane16 == n && extra >= 0) draw_group(extra);
+    }
+    xl::row_sync();
+  }
+  // the second pass of a reset: terrain / yaw / xy (19), root velocity (20, 21), the resample inside reset (22, 23), the turn-over draws (41)
+  // and — a freshly reset env is pushed in the same step (episode clock 0, App. E.4) — the push groups (24, 25): one group per lane
+  GO2_HD void fill_reset_tail(bool turn_over, bool push) {
+    if (!S->injected) {
+      if (lane16 < 5) draw_group(19 + lane16);
+      else if (lane16 == 5) { if (turn_over) draw_group(41); }
+      else if (lane16 < 8) { if (push) draw_group(24 + (lane16 - 6)); }
     }
     xl::row_sync();
   }
@@ -362,6 +378,12 @@ struct LegPost {
   }
   float own_f2b, own_fvel2, rpy[3], max_move, org_x, org_y, org_z; int64_t tlevel, ttype;
   bool skip_contact_filters;                   // reset_all runs postB without a postA: nothing to carry over
+#if defined(__HIP_DEVICE_COMPILE__)
+  long long* dbg;                              // optional per-wave phase timestamps (tools/kbench.py), null in normal operation
+#define GO2_POST_STAMP(k) do { if (dbg && (lane16 == 0) && ((e & 3) == 0)) dbg[k] = wall_clock64(); } while (0)
+#else
+#define GO2_POST_STAMP(k) do { } while (0)
+#endif
   bool yaw_seen;                               // heading clip against the ranges of the stage last picked up (Go2Step.stage_pending)
   bool api_reset;                              // go2sim_reset_idx: like the reference's reset_idx, leave observations / reward / derived velocities alone
   uint8_t new_lc, new_lc2; float new_fat;      // per-leg read-modify-write fields: read by the 4 sub-lanes in postA, written by sub-lane 0 in postB
@@ -423,37 +445,41 @@ struct LegPost {
     raw[GO2_REW_HIP_TO_DEFAULT] = red[18];
     raw[GO2_REW_X_COMMAND_HIP_REGULAR] = (fabsf(red[19]) + fabsf(red[20])) * fabsf(cmd[0]) / sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1] + cmd[2] * cmd[2]);
     // Sum of the active terms (enum order) and their per-episode sums.  Which terms are active is ONE wave-uniform bit mask (Go2Step),
-    // so every test below is a scalar branch; lane 0 of the environment carries episode_sums through the rest of postB in registers:
-    // all its loads are issued here back to back (one wait instead of one per term), the reset branch reads / zeroes the registers, the
-    // write-back stores them.
+    // so every test below is a scalar branch.  episode_sums: lane k of the environment's row OWNS terms k and k + 16 — one load, one add,
+    // one store per lane, all lanes in parallel — and in the reset branch adds its two sums to the extras accumulators (two atomic
+    // instructions per wave instead of one, with its wave reduction and its wait, per term).
+    static_assert(GO2_NUM_REWARDS + 1 <= 32, "two owned terms per lane");
     float total = 0.f;
     GO2_AS1 float* es = p.ep_sums;  // [R][N] row-major
     const bool need_to = c.turn_over && fabsf(rpy[0]) > c.to_roll_thr;      // :263-265
     const uint32_t rmask = go2_uniform_u32(S->rew_mask);
-    float esv[GO2_NUM_REWARDS], scl[GO2_NUM_REWARDS];
+    const int own0 = lane16, own1 = lane16 + 16;
+    const bool has0 = (rmask >> own0) & 1u, has1 = own1 < GO2_NUM_REWARDS && ((rmask >> own1) & 1u);
+    float es0 = has0 ? es[(size_t)own0 * N + e] : 0.f, es1 = has1 ? es[(size_t)own1 * N + e] : 0.f;
+    float r0 = 0.f, r1 = 0.f;      // this step's value of the two owned terms
 #pragma unroll
-    for (int i = 0; i < GO2_NUM_REWARDS; ++i) { esv[i] = 0.f; scl[i] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < GO2_NUM_REWARDS; ++i) if ((rmask >> i) & 1u) {
-      if (lane16 == 0) esv[i] = es[(size_t)i * N + e];
-      scl[i] = (i != GO2_REW_TERMINATION && need_to) ? S->rew_to_scale[i] : S->rew_scale[i];
+    for (int i = 0; i < GO2_REW_TERMINATION; ++i) if ((rmask >> i) & 1u) {
+      const float r = raw[i] * (need_to ? S->rew_to_scale[i] : S->rew_scale[i]); total += r;
+      if (i < 16) r0 = lane16 == i ? r : r0; else r1 = lane16 == i - 16 ? r : r1;
     }
-#pragma unroll
-    for (int i = 0; i < GO2_REW_TERMINATION; ++i) if ((rmask >> i) & 1u) { const float r = raw[i] * scl[i]; total += r; esv[i] += r; }
     if (c.only_positive && total < 0.f) total = 0.f;
     if ((rmask >> GO2_REW_TERMINATION) & 1u) {
-      const float r = ((reset && !time_out) ? 1.f : 0.f) * scl[GO2_REW_TERMINATION]; total += r; esv[GO2_REW_TERMINATION] += r;
+      const float r = ((reset && !time_out) ? 1.f : 0.f) * S->rew_scale[GO2_REW_TERMINATION]; total += r;
+      if (GO2_REW_TERMINATION < 16) r0 = lane16 == GO2_REW_TERMINATION ? r : r0; else r1 = lane16 == GO2_REW_TERMINATION - 16 ? r : r1;
     }
+    es0 += r0; es1 += r1;
     if (c.rew_on[GO2_REW_ACTION_SMOOTHNESS] && !skip_contact_filters)     // (a reset outside a step computes no reward)
       _Pragma("unroll") for (int j = 0; j < 3; ++j) llast_act[j] = last_act[j];       // :1378 (not zeroed on reset, App. E.9)
 
     GO2_MARK(23);
+    GO2_POST_STAMP(6);
     // ---- reset_idx (:180-245) ---------------------------------------------------------------------
     float ox = org_x, oy = org_y, oz = org_z;
     bool es_dirty_all = false;
     if (reset) {
       fill(3, 16);                                  // per-DOF reset groups of the 4 legs (go2sim_rng.h: group 3 + 4 leg + g)
-      fill(19, 5, c.turn_over ? 41 : -1);           // terrain / yaw / xy, root velocity (2), resample inside reset (2) [, turn-over]
+      fill_reset_tail(c.turn_over, c.push_robots && !S->initial_reset);
+      GO2_POST_STAMP(8);
       // the four per-DOF tables: sub-lane k of a leg draws and writes table k (strength, offset, kp, kd) for the leg's 3 joints
       {
         const int tb = sub == 0 ? GO2_U_RESET_STRENGTH : (sub == 1 ? GO2_U_RESET_OFFSET : (sub == 2 ? GO2_U_RESET_KP : GO2_U_RESET_KD));
@@ -463,6 +489,7 @@ struct LegPost {
         GO2_AS1 float* dst = sub == 0 ? p.strength : (sub == 1 ? p.zero_off : (sub == 2 ? p.kp_mul : p.kd_mul));
         if (on) _Pragma("unroll") for (int j = 0; j < 3; ++j) F2D(dst, 3 * lane + j, e) = urange(uni(tb + 3 * lane + j), lo, hi);
       }
+      GO2_POST_STAMP(9);
       if (c.terrain_curriculum && c.terrain_mode != 0 && S->initial_reset != 1) {   // _update_terrain_curriculum (:1143-1169)
         float dist = max_move;
         bool up = dist > c.terrain_length * 0.5f, down;
@@ -475,6 +502,7 @@ struct LegPost {
         ox = og[0]; oy = og[1]; oz = og[2]; max_move = 0.f;
         if (lane16 == 0) { p.terrain_levels[e] = lv; F2D(p.origins, 0, e) = ox; F2D(p.origins, 1, e) = oy; F2D(p.origins, 2, e) = oz; }
       }
+      GO2_POST_STAMP(10);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {   // _reset_dofs (:620-634)
         int d = 3 * lane + j;
@@ -493,7 +521,8 @@ struct LegPost {
       }
       o.pw = v3(c.base_init[0] + ox, c.base_init[1] + oy, zinit + oz);
       if (c.terrain_mode != 0) { o.pw.x += urange(uni(GO2_U_RESET_XY), -1.f, 1.f); o.pw.y += urange(uni(GO2_U_RESET_XY + 1), -1.f, 1.f); }
-      { const float cy = cosf(0.5f * yaw), sy = sinf(0.5f * yaw), cr = cosf(0.5f * roll), sr = sinf(0.5f * roll);   // quat_from_euler_xyz(roll, 0, yaw)
+      { float cy, sy, cr = 1.f, sr = 0.f; go2_sincos_half_pi(0.5f * yaw, &sy, &cy);       // quat_from_euler_xyz(roll, 0, yaw); |yaw / 2|, |roll / 2| <= pi / 2
+        if (c.turn_over) go2_sincos_half_pi(0.5f * roll, &sr, &cr);
         o.qx = cy * sr; o.qy = sy * sr; o.qz = sy * cr; o.qw = cy * cr; }
       o.vw = v3(urange(uni(GO2_U_RESET_VEL), -0.5f, 0.5f), urange(uni(GO2_U_RESET_VEL + 1), -0.5f, 0.5f), urange(uni(GO2_U_RESET_VEL + 2), -0.5f, 0.5f));
       o.ww = v3(urange(uni(GO2_U_RESET_VEL + 3), -0.5f, 0.5f), urange(uni(GO2_U_RESET_VEL + 4), -0.5f, 0.5f), urange(uni(GO2_U_RESET_VEL + 5), -0.5f, 0.5f));
@@ -501,34 +530,39 @@ struct LegPost {
       if (sub == 0) _Pragma("unroll") for (int a = 0; a < 3; ++a) F3D(p.foot_impulse, 4, lane, a, e) = 0.f;
       ep_len = 0;
       timer = c.resampling_time / c.dt; acc[0] = 0.f; acc[1] = 0.f;
+      GO2_POST_STAMP(11);
       resample(GO2_U_RSB);
-      if (lane16 == 0) {   // extras["episode"] accumulators (:229-242); every term the reference has a sum for, i.e. every computed term
+      GO2_POST_STAMP(12);
+      {   // extras["episode"] accumulators (:229-242); every term the reference has a sum for, i.e. every computed term; [NUM_REWARDS] counts the envs
         const uint32_t amask = go2_uniform_u32(S->rew_mask_all);
-        _Pragma("unroll") for (int i = 0; i < GO2_NUM_REWARDS; ++i) if ((amask >> i) & 1u) {
-          const float v = ((rmask >> i) & 1u) ? esv[i] : es[(size_t)i * N + e];      // (initial reset: nothing was loaded above)
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) {
+          const int t = lane16 + 16 * h;
+          const bool term = t < GO2_NUM_REWARDS && ((amask >> t) & 1u);
+          float v = h ? es1 : es0;
+          if (term && !rmask) v = es[(size_t)t * N + e];      // (a reset outside a step: nothing was loaded above)
+          if (t == GO2_NUM_REWARDS) v = 1.0f;
+          if (term || t == GO2_NUM_REWARDS) {
 #if defined(__HIP_DEVICE_COMPILE__)
-          atomicAdd(&p.ep_accum[i], v);
+            atomicAdd(&p.ep_accum[t], v);
 #else
-          p.ep_accum[i] += v;
+            p.ep_accum[t] += v;
 #endif
-          esv[i] = 0.f;
+          }
         }
-#if defined(__HIP_DEVICE_COMPILE__)
-        atomicAdd(&p.ep_accum[GO2_NUM_REWARDS], 1.0f);
-#else
-        p.ep_accum[GO2_NUM_REWARDS] += 1.0f;
-#endif
+        es0 = 0.f; es1 = 0.f;
       }
       es_dirty_all = true;
+      GO2_POST_STAMP(13);
     }
     GO2_MARK(24);
     // _push_robots (:709-724): episode clock multiple of the push interval (a fresh reset is pushed at once, App. E.4)
     if (c.push_robots && !S->initial_reset && (ep_len % c.push_interval == 0)) {
-      fill(24, 2);
+      if (!reset) fill(24, 2);                      // (a reset drew them with its own groups)
       o.vw.x = urange(uni(GO2_U_PUSH), -c.push_xy, c.push_xy); o.vw.y = urange(uni(GO2_U_PUSH + 1), -c.push_xy, c.push_xy);
       o.ww = v3(urange(uni(GO2_U_PUSH + 2), -c.push_ang, c.push_ang), urange(uni(GO2_U_PUSH + 3), -c.push_ang, c.push_ang), urange(uni(GO2_U_PUSH + 4), -c.push_ang, c.push_ang));
     }
     GO2_MARK(25);
+    GO2_POST_STAMP(7);
     // ---- Go2Robot.compute_observations (go2_env.py:23-53) + clip (:96-99) -----------------------------
     // Every lane writes a share: sub-lanes 0 / 1 / 2 of a leg its joints' position / velocity / action entries (actor rows with noise,
     // critic rows without) plus the critic-only torque / acceleration / foot-force entries, sub-lane 3 of legs 0 / 1 / 2 the base angular
@@ -591,11 +625,12 @@ struct LegPost {
       F2D(p.actions, d, e) = act[j];
       F2D(p.dof, d, e) = o.q[j]; F2D(p.dof, 12 + d, e) = o.qd[j];
     }
+    {   // episode_sums: the terms summed this step; after a reset every term (zeroed) — each lane its two
+      const uint32_t wmask = es_dirty_all ? go2_uniform_u32(S->rew_mask_all) : rmask;
+      if ((wmask >> own0) & 1u) es[(size_t)own0 * N + e] = es0;
+      if (own1 < GO2_NUM_REWARDS && ((wmask >> own1) & 1u)) es[(size_t)own1 * N + e] = es1;
+    }
     if (lane16 == 0) {
-      {   // episode_sums: the terms summed this step; after a reset every term (zeroed)
-        const uint32_t wmask = es_dirty_all ? go2_uniform_u32(S->rew_mask_all) : rmask;
-        _Pragma("unroll") for (int i = 0; i < GO2_NUM_REWARDS; ++i) if ((wmask >> i) & 1u) es[(size_t)i * N + e] = esv[i];
-      }
       float r13[13] = {o.pw.x, o.pw.y, o.pw.z, o.qx, o.qy, o.qz, o.qw, o.vw.x, o.vw.y, o.vw.z, o.ww.x, o.ww.y, o.ww.z};
       _Pragma("unroll") for (int k = 0; k < 13; ++k) F2D(p.root, k, e) = r13[k];
       if (!api_reset) _Pragma("unroll") for (int k = 0; k < 6; ++k) F2D(p.last_root_vel, k, e) = r13[7 + k];   // :142

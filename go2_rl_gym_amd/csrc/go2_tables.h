@@ -99,6 +99,7 @@ struct Go2Launch {
   float rew_scale_dt[GO2_NUM_REWARDS];  // raw scale * dt
   float rew_to_scale_dt[GO2_NUM_REWARDS];   // turn_over_scales * dt (all 0 unless init_state.turn_over)
   int32_t rew_on[GO2_NUM_REWARDS];      // term computed: non-zero in either table (legged_robot.py:927-930)
+  uint32_t rew_mask_all;                // bit t = rew_on[t]
   int32_t turn_over; float to_prop[3], to_height[2][2], to_zero_time[2], to_roll_thr;
   int32_t rew_curr_count, rew_curr_term[4]; float rew_curr[4][4];     // curriculum_rewards (start_iter,end_iter,start,end)
   int32_t cmd_curr_count; float cmd_curr[4][9];                       // command_range_curriculum

@@ -192,6 +192,9 @@ GO2_HD void lane_load_physout(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK&
 GO2_HD void lane_init_post(LANE_PARAMS, const GO2_AS3 uint8_t* codes, GO2_AS3 float (*uc)[4], const Go2PtrsK* p, const Go2Launch* L, const Go2Step* S, int e, int lane, int sub) {
   po_.codes = codes; po_.uc = uc;
   po_.e = e; po_.lane = lane; po_.sub = sub; po_.lane16 = lane * 4 + sub; po_.N = L->N; po_.P = p; po_.L = L; po_.S = S;
+#if defined(__HIP_DEVICE_COMPILE__)
+  po_.dbg = nullptr;
+#endif
   po_.skip_contact_filters = false; po_.api_reset = false; po_.yaw_seen = false; po_.new_lc = po_.new_lc2 = 0; po_.new_fat = 0.f;
 }
 // reset_idx(all envs) without a step (base_task.py:82-84): postB's reset branch with reset forced on
@@ -220,7 +223,8 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(GO2_GENERIC(const Go2Tables*, p.tables)); uint32_t* dst = reinterpret_cast<uint32_t*>(&sh.tab);
     for (int i = tid; i < (int)(sizeof(Go2Tables) / 4); i += GO2_WG_THREADS) dst[i] = src[i];
-    if (tid == 0) { sh.cb_any = 0; go2_step_scalars(L, blk->dyn, GO2_GENERIC(const float*, p.inj_storage), blk->dyn.common_step_counter + ((MODE & MODE_POST) ? 1 : 0), initial_reset, &sh.S); }
+    if (tid == 0) sh.cb_any = 0;
+    if (tid < GO2_STEP_SCALAR_PARTS) go2_step_scalars_part(tid, L, blk->dyn, GO2_GENERIC(const float*, p.inj_storage), blk->dyn.common_step_counter + ((MODE & MODE_POST) ? 1 : 0), initial_reset, &sh.S);
   }
   xl::sync();
   const Go2Tables& tab = sh.tab; const Go2Step& S = sh.S;
@@ -235,7 +239,7 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
   const int e = bid * GO2_WG_ENVS + (tid >> 4), lane = (tid >> 2) & 3, sub = tid & 3;
   if (e >= L.N) return;   // whole rows (environments) leave together
 #if defined(__HIP_DEVICE_COMPILE__)
-  long long* dbg = p.dbg_clock ? (long long*)p.dbg_clock + (size_t)(bid * 4 + (tid >> 6)) * 8 : nullptr;   // optional phase timestamps per wave (tools/kbench.py)
+  long long* dbg = p.dbg_clock ? (long long*)p.dbg_clock + (size_t)(bid * 4 + (tid >> 6)) * 16 : nullptr;   // optional phase timestamps per wave (tools/kbench.py)
 #define STAMP(k) do { if (dbg && (tid & 63) == 0) dbg[k] = wall_clock64(); } while (0)
 #else
 #define STAMP(k) do { } while (0)
@@ -315,6 +319,9 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
     GO2_MARK(21);
     lane_init_post(ph_, po_, ax, (const GO2_AS3 uint8_t*)tab.slot_code, uc, &p, &L, &S, e, lane, sub);
     po_.yaw_seen = yaw_seen;
+#if defined(__HIP_DEVICE_COMPILE__)
+    po_.dbg = dbg;
+#endif
     float part[GO2_POST_PARTIALS];
     po_.postA(t, part);
     GO2_MARK(22);
@@ -834,9 +841,11 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
   L.limit_invert = cfg->limit_vel_invert_when_continuous; L.stop_heading_at_limit = cfg->stop_heading_at_limit; L.limit_ang_zero_prob = cfg->limit_ang_vel_at_zero_command_prob;
   L.comb_count = cfg->limit_vel_comb_count; memcpy(L.comb, cfg->limit_vel_comb, sizeof(L.comb)); memcpy(L.terrain_max_cmd, cfg->terrain_max_cmd_ranges, sizeof(L.terrain_max_cmd));
   memcpy(L.cmd_ranges0, cfg->cmd_ranges, sizeof(L.cmd_ranges0));
+  L.rew_mask_all = 0u;
   for (int t = 0; t < GO2_NUM_REWARDS; ++t) {   // :914-930
     L.rew_scale_dt[t] = cfg->reward_scales[t] * s->dt; L.rew_to_scale_dt[t] = cfg->turn_over ? cfg->turn_over_scales[t] * s->dt : 0.f;
     L.rew_on[t] = (L.rew_scale_dt[t] != 0.f || L.rew_to_scale_dt[t] != 0.f) ? 1 : 0;
+    if (L.rew_on[t]) L.rew_mask_all |= 1u << t;
   }
   L.turn_over = cfg->turn_over; L.to_roll_thr = cfg->turn_over_roll_threshold;
   for (int k = 0; k < 3; ++k) L.to_prop[k] = cfg->turn_over_proportions[k];

@@ -70,23 +70,38 @@ def phase_clocks(steps=50, **kw):
     for _ in range(80):
         hip.go2sim_step(s.h, C.c_void_p(a.data_ptr()), s._st())
     nb = 4 * ((N + 15) // 16)               # one row of 8 stamps per WAVE (4 waves per 16-env workgroup)
-    buf = torch.zeros(nb, 8, dtype=torch.int64, device="cuda:0")
+    buf = torch.zeros(nb, 16, dtype=torch.int64, device="cuda:0")
     hip.go2sim_debug_clock.argtypes = [C.c_void_p, C.c_void_p]
     hip.go2sim_debug_clock(s.h, C.c_void_p(buf.data_ptr()))
     acc = []
     for _ in range(steps):
         hip.go2sim_step(s.h, C.c_void_p(a.data_ptr()), s._st())
         torch.cuda.synchronize()
-        acc.append(buf[:, :6].cpu().numpy().astype(np.float64))
+        acc.append(buf[:, :16].cpu().numpy().astype(np.float64)); buf[:, 8:].zero_()
     hip.go2sim_debug_clock(s.h, None)
     t = np.stack(acc)                       # [steps, blocks, 6]
-    d = np.diff(t, axis=2) / 100.0          # us (100 MHz constant clock)
+    d = np.diff(t[:, :, :6], axis=2) / 100.0          # us (100 MHz constant clock)
     names = ["load", "4 substeps", "finish/FK", "postA", "postB"]
     span = (t[:, :, 5].max(1) - t[:, :, 0].min(1)) / 100.0
     print("phase           mean-over-waves   max-over-waves (mean over steps)")
     for i, nm in enumerate(names):
         print("%-14s %10.1f us %14.1f us" % (nm, d[:, :, i].mean(), d[:, :, i].max(1).mean()))
     print("first start -> last end: %.1f us" % span.mean())
+    # inside postB (stamps 6 / 7 of go2_post.h): rewards + termination | reset_idx + push | observations + write-back
+    r, x, o = (t[:, :, 6] - t[:, :, 4]) / 100.0, (t[:, :, 7] - t[:, :, 6]) / 100.0, (t[:, :, 5] - t[:, :, 7]) / 100.0
+    hot = x > 1.0                            # waves that took the reset / push branch
+    print("postB: rewards %.2f us | reset+push %.2f us mean, %.2f us over the %.1f%% of waves that took it (%.2f otherwise) | obs+store %.2f us"
+          % (r.mean(), x.mean(), x[hot].mean() if hot.any() else 0.0, 100.0 * hot.mean(), x[~hot].mean(), o.mean()))
+    tot = (t[:, :, 5] - t[:, :, 0]) / 100.0
+    print("wave total: mean %.1f us, p99 %.1f us, max %.1f us (mean over steps of the per-step max); waves with reset/push: mean %.1f us"
+          % (tot.mean(), np.quantile(tot, 0.99), tot.max(1).mean(), tot[hot].mean() if hot.any() else 0.0))
+    full = hot & (t[:, :, 8] > 0) & (t[:, :, 13] > 0)        # waves whose FIRST env reset (the stamps inside the reset branch are that env's)
+    if full.any():
+        seq = [6, 8, 9, 10, 11, 12, 13, 7]
+        lab = ["philox fill x2", "DOF tables", "terrain curriculum", "dofs + root state", "resample", "episode atomics", "push (fill + draw)"]
+        print("reset path (%d samples): " % full.sum() + ", ".join("%s %.2f" % (lab[j], ((t[:, :, seq[j + 1]] - t[:, :, seq[j]]) / 100.0)[full].mean()) for j in range(7)))
+    sub_ = d[:, :, 1]
+    print("substeps over waves: p50 %.1f p90 %.1f p99 %.1f max %.1f us" % tuple(np.quantile(sub_, q) for q in (0.5, 0.9, 0.99, 1.0)))
     s.close()
 
 
