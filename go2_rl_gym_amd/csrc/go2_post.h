@@ -384,6 +384,7 @@ struct LegPost {
 #else
 #define GO2_POST_STAMP(k) do { } while (0)
 #endif
+  Go2StepOutputs out;                          // go2sim_step_rollout: redirected observations, fused transition store (all null otherwise)
   bool yaw_seen;                               // heading clip against the ranges of the stage last picked up (Go2Step.stage_pending)
   bool api_reset;                              // go2sim_reset_idx: like the reference's reset_idx, leave observations / reward / derived velocities alone
   uint8_t new_lc, new_lc2; float new_fat;      // per-leg read-modify-write fields: read by the 4 sub-lanes in postA, written by sub-lane 0 in postB
@@ -570,7 +571,8 @@ struct LegPost {
     // the 16 lanes.  The noise uniforms were drawn at kernel start, one Philox group per lane.
     if (!api_reset) {
     float cl = c.clip_obs;
-    float* ob = p.obs + (size_t)e * GO2_NUM_OBS; float* pv = p.priv + (size_t)e * GO2_NUM_PRIV_OBS;
+    GO2_AS1 float* ob = (out.obs_out ? (GO2_AS1 float*)out.obs_out : p.obs) + (size_t)e * GO2_NUM_OBS;
+    GO2_AS1 float* pv = (out.priv_out ? (GO2_AS1 float*)out.priv_out : p.priv) + (size_t)e * GO2_NUM_PRIV_OBS;
 #define CLIP(x) fminf(fmaxf((x), -cl), cl)
     {
       float v3_[3], w3_[3]; int obase, pbase, wbase, nw;       // 3 values -> ob[obase..] (+noise) and pv[pbase..]; nw extra critic values -> pv[wbase..]
@@ -642,6 +644,8 @@ struct LegPost {
       if (c.turn_over) p.to_timer[e] = to_timer;
       if (!api_reset) {
       p.time_out[e] = time_out; p.rew[e] = total;
+      if (out.rewards_out) ((GO2_AS1 float*)out.rewards_out)[e] = total + ((out.values && time_out) ? out.gamma * ((const GO2_AS1 float*)out.values)[e] : 0.f);   // ppo.py:107-108
+      if (out.dones_out) ((GO2_AS1 uint8_t*)out.dones_out)[e] = reset;
       F2D(p.base_lin_vel, 0, e) = blv.x; F2D(p.base_lin_vel, 1, e) = blv.y; F2D(p.base_lin_vel, 2, e) = blv.z;
       F2D(p.base_ang_vel, 0, e) = bav.x; F2D(p.base_ang_vel, 1, e) = bav.y; F2D(p.base_ang_vel, 2, e) = bav.z;
       F2D(p.proj_gravity, 0, e) = pg.x; F2D(p.proj_gravity, 1, e) = pg.y; F2D(p.proj_gravity, 2, e) = pg.z;

@@ -195,7 +195,7 @@ GO2_HD void lane_init_post(LANE_PARAMS, const GO2_AS3 uint8_t* codes, GO2_AS3 fl
 #if defined(__HIP_DEVICE_COMPILE__)
   po_.dbg = nullptr;
 #endif
-  po_.skip_contact_filters = false; po_.api_reset = false; po_.yaw_seen = false; po_.new_lc = po_.new_lc2 = 0; po_.new_fat = 0.f;
+  po_.skip_contact_filters = false; po_.api_reset = false; po_.yaw_seen = false; po_.out = Go2StepOutputs{}; po_.new_lc = po_.new_lc2 = 0; po_.new_fat = 0.f;
 }
 // reset_idx(all envs) without a step (base_task.py:82-84): postB's reset branch with reset forced on
 GO2_HD void lane_reset_all(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p, const Go2Launch& L, const Go2Step& S, GO2_AS3 float (*uc)[4], int e, int lane, int sub) {
@@ -218,7 +218,7 @@ GO2_HD void lane_reset_all(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p,
 // ------------------------------------------------------------------------------------------------------
 // The kernel body.  `sh` is the workgroup's LDS block; bid / tid = blockIdx.x / threadIdx.x.
 template <int MODE>
-GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, const float* __restrict__ actions_in, int initial_reset, int bid, int tid) {
+GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, const float* __restrict__ actions_in, int initial_reset, const Go2StepOutputs& outs, int bid, int tid) {
   const Go2PtrsK& p = *(const Go2PtrsK*)&blk->p; const Go2Launch& L = blk->L;   // uniform addresses -> scalar loads; pointers typed global
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(GO2_GENERIC(const Go2Tables*, p.tables)); uint32_t* dst = reinterpret_cast<uint32_t*>(&sh.tab);
@@ -318,7 +318,7 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
   if (MODE & MODE_POST) {
     GO2_MARK(21);
     lane_init_post(ph_, po_, ax, (const GO2_AS3 uint8_t*)tab.slot_code, uc, &p, &L, &S, e, lane, sub);
-    po_.yaw_seen = yaw_seen;
+    po_.yaw_seen = yaw_seen; po_.out = outs;
 #if defined(__HIP_DEVICE_COMPILE__)
     po_.dbg = dbg;
 #endif
@@ -337,9 +337,9 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
 
 #ifndef GO2_EMU
 template <int MODE>
-__global__ void __launch_bounds__(GO2_WG_THREADS) go2_step_kernel(const Go2DevBlock* __restrict__ blk, const float* __restrict__ actions_in, int initial_reset) {
+__global__ void __launch_bounds__(GO2_WG_THREADS) go2_step_kernel(const Go2DevBlock* __restrict__ blk, const float* __restrict__ actions_in, int initial_reset, const Go2StepOutputs outs) {
   __shared__ Go2Shared sh;
-  go2_step_body<MODE>(sh, blk, actions_in, initial_reset, blockIdx.x, threadIdx.x);
+  go2_step_body<MODE>(sh, blk, actions_in, initial_reset, outs, blockIdx.x, threadIdx.x);
 }
 
 // ---- test hooks (declared in include/go2sim.h under "test hooks"; no product path calls them) --------------------------------
@@ -397,7 +397,7 @@ __global__ void go2_strict_ops_kernel(const float* __restrict__ a, const float* 
 }
 
 // after a step: extras["episode"] means, then advance the device-resident counters
-__global__ void go2_finish_kernel(Go2DevBlock* blk, int counter_inc) {
+__global__ void go2_finish_kernel(Go2DevBlock* blk, int counter_inc, float* info_out) {
   float* accum = blk->p.ep_accum; float* info = blk->p.episode_info;
   int i = threadIdx.x;
   float cnt = accum[GO2_NUM_REWARDS], track = accum[GO2_REW_TRACKING_LIN_VEL], cb = accum[GO2_NUM_REWARDS + 1];
@@ -410,6 +410,10 @@ __global__ void go2_finish_kernel(Go2DevBlock* blk, int counter_inc) {
     accum[GO2_NUM_REWARDS + 1] = 0.f;
     go2_track_cmd_curriculum(blk->L, blk->dyn, cnt, track, cb, blk->dyn.common_step_counter + counter_inc, info + GO2_NUM_REWARDS + 1);
     blk->dyn.common_step_counter += counter_inc; blk->dyn.step_count += 1; blk->dyn.use_injected = 0;
+  }
+  if (info_out) {     // extras['episode'] ring slot (go2sim_step_rollout): this step's vector
+    __syncthreads();
+    if (i < GO2_EPISODE_INFO_LEN) info_out[i] = info[i];
   }
 }
 __global__ void go2_peek_kernel(float* out, const Go2Tables* tab, int N, int env_offset, uint32_t s0, uint32_t s1, uint32_t k0, uint32_t k1) {
@@ -449,6 +453,56 @@ __global__ void go2_normalize_kernel(float* adv, const double* partials, int cou
   float sd = (float)sqrt(var > 0 ? var : 0.0), m = (float)mean;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) adv[i] = (adv[i] - m) / (sd + 1e-8f);
 }
+
+// ---- clip_grad_norm_ + (adaptive-KL learning rate) + Adam over a list of tensors (go2sim.h go2sim_adam_clip_step) -----------------
+// Block b works on one GO2_ADAM_CHUNK-element chunk of one tensor (chunks of tensor i: first[i] .. first[i+1]).
+struct Go2AdamLaunch { Go2AdamTensors t; int32_t first[GO2_ADAM_MAX_TENSORS + 1]; };
+__device__ __forceinline__ int adam_locate(const Go2AdamLaunch& a, int b) { int i = 0; while (i + 1 < a.t.count && b >= a.first[i + 1]) ++i; return i; }
+// stage 1: per-chunk sum of squared gradients -> ws[block]; block 0 also takes the learning-rate decision (ppo.py:140-155)
+__global__ void __launch_bounds__(256) go2_adam_norm_kernel(const Go2AdamLaunch a, float* __restrict__ ws, float* lr, const float* kl_mean, float desired_kl) {
+  __shared__ float sh[4];
+  const int i = adam_locate(a, blockIdx.x), off = (blockIdx.x - a.first[i]) * GO2_ADAM_CHUNK, n = min(GO2_ADAM_CHUNK, a.t.numel[i] - off);
+  const float* g = a.t.grad[i] + off;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < n; k += 256) { const float x = g[k]; s += x * x; }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ws[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    if (blockIdx.x == 0 && kl_mean) {
+      const float kl = *kl_mean, r = *lr;
+      *lr = kl > desired_kl * 2.f ? fmaxf(1e-5f, r / 1.5f) : ((kl < desired_kl / 2.f && kl > 0.f) ? fminf(1e-2f, r * 1.5f) : r);
+    }
+  }
+}
+// stage 2: every block re-reduces the chunk sums in the same fixed order (-> the same norm everywhere), then steps its chunk
+__global__ void __launch_bounds__(256) go2_adam_step_kernel(const Go2AdamLaunch a, const float* __restrict__ ws, const float* __restrict__ lr, float max_norm,
+                                                          double beta1d, double beta2d, float eps) {
+  const float beta2 = (float)beta2d, omb1 = (float)(1.0 - beta1d), omb2 = (float)(1.0 - beta2d);
+  __shared__ float sh[4];
+  const int nb = a.first[a.t.count];
+  float s = 0.f;
+  for (int k = threadIdx.x; k < nb; k += 256) s += ws[k];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float norm = sqrtf((sh[0] + sh[1]) + (sh[2] + sh[3]));
+  const float coef = fminf(max_norm / (norm + 1e-6f), 1.f);
+  const int i = adam_locate(a, blockIdx.x), off = (blockIdx.x - a.first[i]) * GO2_ADAM_CHUNK, n = min(GO2_ADAM_CHUNK, a.t.numel[i] - off);
+  const float t = a.t.step[0][0] + 1.f;                 // (read by every block before block 0 of the LAST tensor's chunk writes: see below)
+  // the bias corrections in fp64, as torch forms them: 1 - 0.999^t cancels to ~1e-3 in the first steps
+  const float bc1 = (float)(1.0 - pow(beta1d, (double)t)), bc2s = (float)sqrt(1.0 - pow(beta2d, (double)t)), step_size = lr[0] / bc1;
+  float* p = a.t.param[i] + off; float* m = a.t.exp_avg[i] + off; float* v = a.t.exp_avg_sq[i] + off; const float* g = a.t.grad[i] + off;
+  for (int k = threadIdx.x; k < n; k += 256) {
+    const float gk = g[k] * coef;
+    const float mk = m[k] + (gk - m[k]) * omb1, vk = beta2 * v[k] + omb2 * gk * gk;
+    m[k] = mk; v[k] = vk;
+    p[k] -= step_size * mk / (sqrtf(vk) / bc2s + eps);
+  }
+}
+// the step counters advance in their own tiny launch: stage 2's blocks all read step[0] while they run
+__global__ void go2_adam_count_kernel(const Go2AdamLaunch a) { const int i = threadIdx.x; if (i < a.t.count) a.t.step[i][0] += 1.f; }
 
 // ---- fused PPO loss head (ppo.py:131-170): one lane per sample, A <= 16 actions in registers ------------------------------
 #define PPO_NSTAT 24   // per-block partials: [0..3] surrogate, value loss, kl, entropy ; [4..4+A) grad_std
@@ -935,20 +989,20 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
 int go2sim_get_buffers(Go2Sim* s, Go2SimBuffers* out) { if (!s || !out) FAIL(GO2SIM_EINVAL, "null argument"); *out = s->b; return 0; }
 
 #ifdef GO2_EMU
-struct EmuArgs { Go2Shared* sh; const Go2DevBlock* blk; const float* actions; int initial_reset, bid, mode; };
+struct EmuArgs { Go2Shared* sh; const Go2DevBlock* blk; const float* actions; int initial_reset, bid, mode; const Go2StepOutputs* outs; };
 static void emu_thread(void* a_, int tid) {
   EmuArgs& a = *(EmuArgs*)a_;
-  if (a.mode == MODE_RESET_ALL) go2_step_body<MODE_RESET_ALL>(*a.sh, a.blk, a.actions, a.initial_reset, a.bid, tid);
-  else if (a.mode == (MODE_PHYS | MODE_POST)) go2_step_body<MODE_PHYS | MODE_POST>(*a.sh, a.blk, a.actions, a.initial_reset, a.bid, tid);
-  else if (a.mode == MODE_PHYS) go2_step_body<MODE_PHYS>(*a.sh, a.blk, a.actions, a.initial_reset, a.bid, tid);
-  else go2_step_body<MODE_POST>(*a.sh, a.blk, a.actions, a.initial_reset, a.bid, tid);
+  if (a.mode == MODE_RESET_ALL) go2_step_body<MODE_RESET_ALL>(*a.sh, a.blk, a.actions, a.initial_reset, *a.outs, a.bid, tid);
+  else if (a.mode == (MODE_PHYS | MODE_POST)) go2_step_body<MODE_PHYS | MODE_POST>(*a.sh, a.blk, a.actions, a.initial_reset, *a.outs, a.bid, tid);
+  else if (a.mode == MODE_PHYS) go2_step_body<MODE_PHYS>(*a.sh, a.blk, a.actions, a.initial_reset, *a.outs, a.bid, tid);
+  else go2_step_body<MODE_POST>(*a.sh, a.blk, a.actions, a.initial_reset, *a.outs, a.bid, tid);
 }
-static void emu_run(Go2Sim* s, int mode, const float* actions_in, int initial_reset, int counter_inc) {
+static void emu_run(Go2Sim* s, int mode, const float* actions_in, int initial_reset, int counter_inc, const Go2StepOutputs& outs) {
   Go2DevBlock* blk = s->d_blk;
   const Go2Ptrs& p = blk->p; const Go2Launch& L = blk->L;
   static thread_local Go2Shared sh;
   for (int bid = 0; bid < (L.N + GO2_WG_ENVS - 1) / GO2_WG_ENVS; ++bid) {      // one workgroup at a time, its 256 threads as fibres
-    EmuArgs a = {&sh, blk, actions_in, initial_reset, bid, mode};
+    EmuArgs a = {&sh, blk, actions_in, initial_reset, bid, mode, &outs};
     xl::run_group(GO2_WG_THREADS, emu_thread, &a);
   }
   if (mode != MODE_PHYS) {   // == go2_finish_kernel
@@ -958,16 +1012,18 @@ static void emu_run(Go2Sim* s, int mode, const float* actions_in, int initial_re
     acc[GO2_NUM_REWARDS + 1] = 0.f;
     go2_track_cmd_curriculum(L, blk->dyn, cnt, track, cb, blk->dyn.common_step_counter + counter_inc, p.episode_info + GO2_NUM_REWARDS + 1);
     blk->dyn.common_step_counter += counter_inc; blk->dyn.step_count += 1; blk->dyn.use_injected = 0;
+    if (outs.episode_info_out) memcpy(outs.episode_info_out, p.episode_info, sizeof(float) * GO2_EPISODE_INFO_LEN);
   }
 }
 #endif
 
 // Enqueue one pass.  Nothing computed on the host enters the kernels: the per-step scalars are derived on the
 // device from the device-resident counters, so the same enqueue can be captured in a HIP graph and replayed.
-static int launch(Go2Sim* s, int mode, const float* actions_in, int initial_reset, int counter_inc, void* stream) {
+static int launch(Go2Sim* s, int mode, const float* actions_in, int initial_reset, int counter_inc, void* stream, const Go2StepOutputs* outs_ = nullptr) {
+  const Go2StepOutputs outs = outs_ ? *outs_ : Go2StepOutputs{};
   bool capturing = false;   // a captured enqueue executes nothing now: the host mirror advances on go2sim_notify_replayed instead
 #ifdef GO2_EMU
-  (void)stream; emu_run(s, mode, actions_in, initial_reset, counter_inc);
+  (void)stream; emu_run(s, mode, actions_in, initial_reset, counter_inc, outs);
 #else
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((s->N + GO2_WG_ENVS - 1) / GO2_WG_ENVS), block(GO2_WG_THREADS);
@@ -977,12 +1033,12 @@ static int launch(Go2Sim* s, int mode, const float* actions_in, int initial_rese
     if (s->ev_used + 2 > s->ev.size()) { size_t n0 = s->ev.size(); s->ev.resize(n0 + 512); for (size_t i = n0; i < s->ev.size(); ++i) HIPCHK(hipEventCreate(&s->ev[i])); }
     HIPCHK(hipEventRecord(s->ev[s->ev_used], st));
   }
-  if (mode == MODE_RESET_ALL) hipLaunchKernelGGL(go2_step_kernel<MODE_RESET_ALL>, grid, block, 0, st, s->d_blk, actions_in, initial_reset);
-  else if (mode == (MODE_PHYS | MODE_POST)) hipLaunchKernelGGL(go2_step_kernel<MODE_PHYS | MODE_POST>, grid, block, 0, st, s->d_blk, actions_in, initial_reset);
-  else if (mode == MODE_PHYS) hipLaunchKernelGGL(go2_step_kernel<MODE_PHYS>, grid, block, 0, st, s->d_blk, actions_in, initial_reset);
-  else hipLaunchKernelGGL(go2_step_kernel<MODE_POST>, grid, block, 0, st, s->d_blk, actions_in, initial_reset);
+  if (mode == MODE_RESET_ALL) hipLaunchKernelGGL(go2_step_kernel<MODE_RESET_ALL>, grid, block, 0, st, s->d_blk, actions_in, initial_reset, outs);
+  else if (mode == (MODE_PHYS | MODE_POST)) hipLaunchKernelGGL(go2_step_kernel<MODE_PHYS | MODE_POST>, grid, block, 0, st, s->d_blk, actions_in, initial_reset, outs);
+  else if (mode == MODE_PHYS) hipLaunchKernelGGL(go2_step_kernel<MODE_PHYS>, grid, block, 0, st, s->d_blk, actions_in, initial_reset, outs);
+  else hipLaunchKernelGGL(go2_step_kernel<MODE_POST>, grid, block, 0, st, s->d_blk, actions_in, initial_reset, outs);
   if (timed) { HIPCHK(hipEventRecord(s->ev[s->ev_used + 1], st)); s->ev_used += 2; }
-  if (mode != MODE_PHYS) hipLaunchKernelGGL(go2_finish_kernel, dim3(1), dim3(64), 0, st, s->d_blk, counter_inc);
+  if (mode != MODE_PHYS) hipLaunchKernelGGL(go2_finish_kernel, dim3(1), dim3(64), 0, st, s->d_blk, counter_inc, outs.episode_info_out);
   HIPCHK(hipGetLastError());
 #endif
   if (mode != MODE_PHYS && !capturing) { s->h.dyn.common_step_counter += counter_inc; s->h.dyn.step_count += 1; s->h.dyn.use_injected = 0; }   // host mirror
@@ -1043,6 +1099,10 @@ int go2sim_post_physics(Go2Sim* s, void* stream) { if (!s) FAIL(GO2SIM_EINVAL, "
 int go2sim_step(Go2Sim* s, const float* actions, void* stream) {
   if (!s || !actions) FAIL(GO2SIM_EINVAL, "null argument");
   return launch(s, MODE_PHYS | MODE_POST, actions, 0, 1, stream);   // counter += 1: legged_robot.py:112
+}
+int go2sim_step_rollout(Go2Sim* s, const float* actions, const Go2StepOutputs* out, void* stream) {
+  if (!s || !actions) FAIL(GO2SIM_EINVAL, "null argument");
+  return launch(s, MODE_PHYS | MODE_POST, actions, 0, 1, stream, out);
 }
 // The API tensors ARE the simulator state in this library, so a write is committed as soon as it is made.
 int go2sim_set_root_state_indexed(Go2Sim* s, const int32_t*, int32_t, void*) { return s ? 0 : GO2SIM_EINVAL; }
@@ -1227,6 +1287,46 @@ int go2sim_elu_backward_bias(const float* gy, const float* y, float* gz, float* 
   const int nr = (B + EB_ROWS - 1) / EB_ROWS;
   hipLaunchKernelGGL(go2_elu_bwd_bias_kernel, dim3((C / 4 + 63) / 64, nr), dim3(256), 0, (hipStream_t)stream, gy, y, gz, workspace, B, C);
   hipLaunchKernelGGL(go2_colsum_finish_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, workspace, gb, nr, C);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+static int adam_check(const Go2AdamTensors* t) {
+  if (!t || t->count <= 0 || t->count > GO2_ADAM_MAX_TENSORS) return 0;
+  for (int i = 0; i < t->count; ++i) if (t->numel[i] <= 0 || !t->param[i] || !t->grad[i] || !t->exp_avg[i] || !t->exp_avg_sq[i] || !t->step[i]) return 0;
+  return 1;
+}
+int go2sim_adam_workspace_len(const Go2AdamTensors* t) {
+  if (!adam_check(t)) return GO2SIM_EINVAL;
+  int nb = 0; for (int i = 0; i < t->count; ++i) nb += (t->numel[i] + GO2_ADAM_CHUNK - 1) / GO2_ADAM_CHUNK;
+  return nb;
+}
+int go2sim_adam_clip_step(const Go2AdamTensors* t, float* lr, const float* kl_mean, float desired_kl, float max_grad_norm, double beta1_, double beta2_, double eps_,
+                          float* workspace, void* stream) {
+  if (!adam_check(t) || !lr || !workspace) FAIL(GO2SIM_EINVAL, "bad argument");
+  const float beta1 = (float)beta1_, beta2 = (float)beta2_, omb1 = (float)(1.0 - beta1_), omb2 = (float)(1.0 - beta2_), eps = (float)eps_;
+#ifdef GO2_EMU
+  (void)stream; (void)workspace;
+  if (kl_mean) { const float kl = *kl_mean, r = *lr; *lr = kl > desired_kl * 2.f ? fmaxf(1e-5f, r / 1.5f) : ((kl < desired_kl / 2.f && kl > 0.f) ? fminf(1e-2f, r * 1.5f) : r); }
+  double ss = 0; for (int i = 0; i < t->count; ++i) for (int k = 0; k < t->numel[i]; ++k) ss += (double)t->grad[i][k] * t->grad[i][k];
+  const float coef = fminf(max_grad_norm / ((float)sqrt(ss) + 1e-6f), 1.f), st = t->step[0][0] + 1.f;
+  const float bc1 = (float)(1.0 - pow(beta1_, (double)st)), bc2s = (float)sqrt(1.0 - pow(beta2_, (double)st)), step_size = *lr / bc1;
+  for (int i = 0; i < t->count; ++i) {
+    for (int k = 0; k < t->numel[i]; ++k) {
+      const float gk = t->grad[i][k] * coef; float& m = t->exp_avg[i][k]; float& v = t->exp_avg_sq[i][k];
+      m += (gk - m) * omb1; v = beta2 * v + omb2 * gk * gk;
+      t->param[i][k] -= step_size * m / (sqrtf(v) / bc2s + eps);
+    }
+    t->step[i][0] += 1.f;
+  }
+#else
+  Go2AdamLaunch a; a.t = *t; a.first[0] = 0;
+  for (int i = 0; i < t->count; ++i) a.first[i + 1] = a.first[i] + (t->numel[i] + GO2_ADAM_CHUNK - 1) / GO2_ADAM_CHUNK;
+  const int nb = a.first[t->count];
+  hipLaunchKernelGGL(go2_adam_norm_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, workspace, lr, kl_mean, desired_kl);
+  hipLaunchKernelGGL(go2_adam_step_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, workspace, lr, max_grad_norm, beta1_, beta2_, eps);
+  hipLaunchKernelGGL(go2_adam_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

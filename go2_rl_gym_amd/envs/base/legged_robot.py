@@ -342,14 +342,40 @@ class LeggedRobot(BaseTask):
         return self._curriculum_state()[2]
 
     # ------------------------------------------------------------------ the hot path
-    def step(self, actions):
-        """LeggedRobot.step (:60-100): one library call = one fused kernel launch."""
+    def step(self, actions, rollout=None):
+        """LeggedRobot.step (:60-100): one library call = one fused kernel launch.
+
+        rollout (optional, this build's runners): dict with the destinations of one policy step's bookkeeping (go2sim_step_rollout) —
+        `obs_out` / `priv_out`: float32 [N,45] / [N,263] tensors (the next rollout-storage rows) that receive the observations INSTEAD of
+        obs_buf / privileged_obs_buf and are what this call returns; `values` [N], `rewards_out` [N], `dones_out` [N] uint8, `gamma`: the
+        transition store with the time-out bootstrap (ppo.py:104-114).  extras['transition_stored'] tells the algorithm it is done."""
         a = actions
         if a.dtype != torch.float32 or not a.is_contiguous() or str(a.device) != str(self.obs_buf.device):
             a = a.to(device=self.obs_buf.device, dtype=torch.float32).contiguous()
-        _abi.check(self.lib, self.lib.go2sim_step(self.handle, C.c_void_p(a.data_ptr()), self._stream()), "go2sim_step")
-        self._publish_extras()
-        return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
+        if rollout is None:
+            _abi.check(self.lib, self.lib.go2sim_step(self.handle, C.c_void_p(a.data_ptr()), self._stream()), "go2sim_step")
+            self._publish_extras()
+            self.extras.pop("transition_stored", None)
+            return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
+        o = self.abi.StepOutputs()
+        fp, bp = C.POINTER(self.abi.real), C.POINTER(C.c_uint8)
+        keep = []
+        for name, ctype in (("obs_out", fp), ("priv_out", fp), ("values", fp), ("rewards_out", fp), ("dones_out", bp)):
+            t = rollout.get(name)
+            if t is not None:
+                assert t.is_contiguous() and t.device == self.obs_buf.device and t.dtype == (torch.uint8 if ctype is bp else torch.float32), name
+                keep.append(t)
+                setattr(o, name, C.cast(C.c_void_p(t.data_ptr()), ctype))
+        o.gamma = float(rollout.get("gamma", 0.0))
+        slot = self._info_ring[self._info_slot]
+        o.episode_info_out = C.cast(C.c_void_p(slot.data_ptr()), fp)
+        self._rollout_keep = keep                               # alive until the enqueued kernels have run
+        _abi.check(self.lib, self.lib.go2sim_step_rollout(self.handle, C.c_void_p(a.data_ptr()), C.byref(o), self._stream()), "go2sim_step_rollout")
+        self._publish_extras(copied=True)
+        self.extras["transition_stored"] = rollout.get("rewards_out") is not None and rollout.get("dones_out") is not None
+        obs = rollout["obs_out"] if rollout.get("obs_out") is not None else self.obs_buf
+        priv = rollout["priv_out"] if rollout.get("priv_out") is not None else self.privileged_obs_buf
+        return obs, priv, self.rew_buf, self.reset_buf, self.extras
 
     def reset_idx(self, env_ids):
         """legged_robot.py:180-245 from OUTSIDE a step (base_task.py:82-84 resets everything before the first step; a caller may reset any
@@ -368,11 +394,12 @@ class LeggedRobot(BaseTask):
             _abi.check(self.lib, self.lib.go2sim_reset_idx(self.handle, ptr, int(ids.numel()), self._stream()), "go2sim_reset_idx")
         self._publish_extras()
 
-    def _publish_extras(self):
+    def _publish_extras(self, copied=False):
         """extras['episode'] / extras['time_outs'] (:229-245) without a host sync: the kernel keeps the means of the
         latest step that reset >= 1 env; each step snapshots them into a ring slot so earlier dicts stay intact."""
         slot = self._info_ring[self._info_slot]
-        slot.copy_(self._episode_info)
+        if not copied:                   # (go2sim_step_rollout writes the ring slot itself)
+            slot.copy_(self._episode_info)
         self._info_slot = (self._info_slot + 1) % self._info_ring.shape[0]
         names = self.abi.reward_names
         if self._level_groups is None:

@@ -47,6 +47,80 @@ class GradBucket:
         return self.extra
 
 
+class FusedClipAdam:
+    """`[adaptive-KL learning rate;] clip_grad_norm_(params, max_norm); optimizer.step()` of one mini-batch step (ppo.py:140-155,178-181) as ONE
+    library call (go2sim_adam_clip_step: two kernels) instead of ~30 element-wise / multi-tensor launches — with HIP-graph replay the update's
+    tail is launch-bound, 180 us of 1.1 ms per mini-batch.  Works on the torch optimizer's OWN state tensors (exp_avg, exp_avg_sq, step), so
+    optimizer.state_dict() / load_state_dict() and the checkpoint format are untouched.  `usable` is False (callers keep the torch path) for
+    anything the kernel does not cover: no library, GO2_FUSED_ADAM=0, weight decay, amsgrad, maximize, differing groups, too many tensors."""
+
+    def __init__(self, lib, optimizer, params, max_grad_norm):
+        self.lib, self.opt, self.params, self.max_norm = lib, optimizer, list(params), float(max_grad_norm)
+        self._ws = None
+        gs = optimizer.param_groups
+        g0 = gs[0]
+        same = all(g["betas"] == g0["betas"] and g["eps"] == g0["eps"] and g["lr"] is g0["lr"] for g in gs)
+        plain = all(g.get("weight_decay", 0) == 0 and not g.get("amsgrad", False) and not g.get("maximize", False) for g in gs)
+        self.usable = bool(lib is not None and hasattr(lib, "go2sim_adam_clip_step") and os.environ.get("GO2_FUSED_ADAM", "1") == "1" and same and plain
+                           and torch.is_tensor(g0["lr"]) and g0["lr"].dtype == torch.float32
+                           and {id(p) for g in gs for p in g["params"]} >= {id(p) for p in self.params})
+
+    def step(self, kl_mean=None, desired_kl=0.0):
+        """-> False if this call could not be served (the caller then runs the torch formulation)"""
+        import ctypes as C
+        ps = [p for p in self.params if p.grad is not None]
+        abi = self.lib.abi
+        if not ps or len(ps) > abi.GO2_ADAM_MAX_TENSORS or any(p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous() for p in ps):
+            return False
+        g0 = self.opt.param_groups[0]
+        t = abi.AdamTensors()
+        t.count = len(ps)
+        fp = C.POINTER(self.lib.abi.real)
+        for i, p in enumerate(ps):
+            st = self.opt.state[p]
+            if len(st) == 0:                    # torch.optim.Adam._init_group (capturable: the step counter is a device tensor)
+                st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if not (torch.is_tensor(st["step"]) and st["step"].device == p.device and st["step"].dtype == torch.float32):
+                return False
+            t.numel[i] = p.numel()
+            for name, ten in (("param", p.data), ("grad", p.grad), ("exp_avg", st["exp_avg"]), ("exp_avg_sq", st["exp_avg_sq"]), ("step", st["step"])):
+                getattr(t, name)[i] = C.cast(C.c_void_p(ten.data_ptr()), fp)
+        n = self.lib.go2sim_adam_workspace_len(C.byref(t))
+        if self._ws is None or self._ws.numel() < n or self._ws.device != ps[0].device:
+            self._ws = torch.empty(max(n, 256), dtype=torch.float32, device=ps[0].device)
+        lr = g0["lr"]
+        stream = C.c_void_p(torch.cuda.current_stream(lr.device).cuda_stream) if lr.is_cuda else None
+        klp = None
+        if kl_mean is not None:
+            self._kl = kl_mean.detach().reshape(-1)[:1].contiguous().float()          # (kept alive until the enqueued kernels have run)
+            klp = C.c_void_p(self._kl.data_ptr())
+        rc = self.lib.go2sim_adam_clip_step(C.byref(t), C.c_void_p(lr.data_ptr()), klp, float(desired_kl), self.max_norm, float(g0["betas"][0]), float(g0["betas"][1]),
+                                            float(g0["eps"]), C.c_void_p(self._ws.data_ptr()), stream)
+        if rc != 0:
+            raise RuntimeError("go2sim_adam_clip_step failed: %s" % self.lib.go2sim_last_error().decode())
+        return True
+
+
+class no_gc:
+    """Python's cyclic garbage collector off for the duration of a stream capture: a collection that happens to run inside the capture may
+    finalise device objects of EARLIER captures / runners (graphs, streams, events), which the HIP runtime answers with an abort.
+    (torch.cuda.graph collects once on entry; garbage created while capturing — ctypes argument structs, autograd nodes — can trigger more.)"""
+
+    def __enter__(self):
+        import gc
+        self._was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        import gc
+        if self._was:
+            gc.enable()
+        return False
+
+
 def strict_graphs():
     """GO2_STRICT_GRAPHS=1 (bench.py sets it): a failed HIP-graph capture raises instead of degrading to eager execution."""
     return os.environ.get("GO2_STRICT_GRAPHS", "0") == "1"
@@ -77,7 +151,7 @@ class CapturedStep:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(g):
+                with no_gc(), torch.cuda.graph(g):
                     self.fn()
             except Exception as e:      # noqa: BLE001 — any capture problem degrades to eager execution (unless GO2_STRICT_GRAPHS=1)
                 if strict_graphs():

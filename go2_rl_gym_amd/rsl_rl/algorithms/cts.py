@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.optim as optim
 
 from ..storage import RolloutStorageCTS
-from ._graph import CapturedStep, GradBucket, ReducedStep, all_captured, collectives_in_graph
+from ._graph import CapturedStep, FusedClipAdam, GradBucket, ReducedStep, all_captured, collectives_in_graph
 from .ppo import _ADAM_IMPL, _collectives_on, _FusedPPOLoss, _RolloutHeads, _world, allreduce_mean_bucket
 
 
@@ -76,6 +76,7 @@ class CTS(_RolloutHeads):
         assert len(self.student_env_idxs) == self.student_num_envs, f"{len(self.student_env_idxs)=} != {self.student_num_envs=}"
         self.surrogate_split = 0            # set per update: teacher rows of a mini-batch (read by _FusedPPOLoss)
         self._steps = None
+        self._fused_adam1 = self._fused_adam2 = None
         if _world() > 1:
             for p in self.model.parameters():
                 dist.broadcast(p.data, src=0)
@@ -289,6 +290,10 @@ class CTS(_RolloutHeads):
             kl_mean = self._kl
             if _collectives_on():          # GO2_GRAPH_COLLECTIVES=1: the all-reduce recorded inside the graph
                 kl_mean = _allreduce_mean_grads(self._params1, _world(), kl_mean if self._adaptive() else None)
+        if self._fused_adam1 is None:
+            self._fused_adam1 = FusedClipAdam(self.lib, self.optimizer1, self._params1, self.max_grad_norm)
+        if self._fused_adam1.usable and self._fused_adam1.step(kl_mean if self._adaptive() else None, self.desired_kl if self._adaptive() else 0.0):
+            return
         if self._adaptive():
             lr = self._lr_t
             kl_mean = kl_mean.reshape(())
@@ -317,6 +322,10 @@ class CTS(_RolloutHeads):
             self._bucket2.unpack(_world())
         elif _collectives_on():
             _allreduce_mean_grads(self._params2, _world())
+        if self._fused_adam2 is None:
+            self._fused_adam2 = FusedClipAdam(self.lib, self.optimizer2, self._params2, self.max_grad_norm)
+        if self._fused_adam2.usable and self._fused_adam2.step():
+            return
         nn.utils.clip_grad_norm_(self._params2, self.max_grad_norm, foreach=True)
         self.optimizer2.step()
 

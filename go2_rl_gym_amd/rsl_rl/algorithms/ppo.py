@@ -23,7 +23,7 @@ import torch.nn as nn
 import torch.optim as optim
 
 from ..storage import RolloutStorage
-from ._graph import CapturedStep, GradBucket, ReducedStep, all_captured, collectives_in_graph
+from ._graph import CapturedStep, FusedClipAdam, GradBucket, ReducedStep, all_captured, collectives_in_graph
 
 
 # Adam as ONE multi-tensor kernel per param group (fused) instead of ~6 foreach launches; GO2_ADAM=foreach restores the latter
@@ -121,7 +121,8 @@ class _FusedPPOLoss(torch.autograd.Function):
     element-wise launches of the eager formulation per mini-batch with 2."""
 
     @staticmethod
-    def forward(ctx, mu, std, value, alg, act_b, tv_b, adv_b, ret_b, old_lp_b, old_mu_b, old_sig_b):
+    def kernel(alg, mu, std, value, act_b, tv_b, adv_b, ret_b, old_lp_b, old_mu_b, old_sig_b):
+        """-> stats [surrogate, value loss, kl, entropy, loss], d loss / d mu, / d std, / d value (shaped like `value`)"""
         import ctypes as C
         B, A = mu.shape
         c = lambda t: t.detach().contiguous().float()
@@ -137,7 +138,12 @@ class _FusedPPOLoss(torch.autograd.Function):
                                  float(alg.entropy_coef), int(alg.use_clipped_value_loss), int(getattr(alg, "surrogate_split", 0)), stream)
         if rc != 0:
             raise RuntimeError("go2sim_ppo_loss failed: %s" % lib.go2sim_last_error().decode())
-        ctx.save_for_backward(gmu, gstd, gval.view_as(value))
+        return stats, gmu, gstd, gval.view_as(value)
+
+    @staticmethod
+    def forward(ctx, mu, std, value, alg, act_b, tv_b, adv_b, ret_b, old_lp_b, old_mu_b, old_sig_b):
+        stats, gmu, gstd, gval = _FusedPPOLoss.kernel(alg, mu, std, value, act_b, tv_b, adv_b, ret_b, old_lp_b, old_mu_b, old_sig_b)
+        ctx.save_for_backward(gmu, gstd, gval)
         ctx.mark_non_differentiable(stats)
         return stats[4].clone(), stats
 
@@ -174,6 +180,7 @@ class PPO(_RolloutHeads):
         self.value_loss_coef, self.entropy_coef, self.gamma, self.lam = value_loss_coef, entropy_coef, gamma, lam
         self.max_grad_norm, self.use_clipped_value_loss = max_grad_norm, use_clipped_value_loss
         self._graph = None
+        self._fused_adam = None
         # the fused loss kernel is the default on the GPU; on the CPU it is opt-in (tests compare it with the eager formulation)
         self.fused_loss = (on_gpu and lib is not None) if fused_loss is None else bool(fused_loss and lib is not None)
         self.fused_rollout = (on_gpu and lib is not None) if fused_rollout is None else bool(fused_rollout and lib is not None)
@@ -211,8 +218,9 @@ class PPO(_RolloutHeads):
         if s >= st.num_transitions_per_env:
             raise AssertionError("Rollout buffer overflow")
         if self.fused_rollout:
-            st.observations[s].copy_(obs)
-            if st.privileged_observations is not None:
+            if obs.data_ptr() != st.observations[s].data_ptr():            # (the env wrote this row itself: LeggedRobot.step(rollout=...))
+                st.observations[s].copy_(obs)
+            if st.privileged_observations is not None and critic_obs.data_ptr() != st.privileged_observations[s].data_ptr():
                 st.privileged_observations[s].copy_(critic_obs)
             t.observations, t.critic_observations = obs, critic_obs
             mu, value = self._pair(lambda: ac.actor(obs), lambda: ac.evaluate(critic_obs), enabled=self._capture)
@@ -233,11 +241,23 @@ class PPO(_RolloutHeads):
         st.sigma[s].copy_(t.action_sigma)
         return t.actions
 
+    def rollout_targets(self):
+        """Destinations for LeggedRobot.step(rollout=...) of the step being collected: the env kernel writes the next observations into the
+        next storage rows and this step's reward / done rows itself (None: not applicable)."""
+        st = self.storage
+        if not self.fused_rollout or st.privileged_observations is None:
+            return None
+        s = st.step
+        nxt = s + 1 < st.num_transitions_per_env
+        return {"obs_out": st.observations[s + 1] if nxt else None, "priv_out": st.privileged_observations[s + 1] if nxt else None,
+                "values": st.values[s].view(-1), "rewards_out": st.rewards[s].view(-1), "dones_out": st.dones[s].view(-1), "gamma": self.gamma}
+
     def process_env_step(self, rewards, dones, infos):
         st, t = self.storage, self.transition
         s = st.step
         if self.fused_rollout:
-            self._store_transition(rewards, dones, infos, s)
+            if not (isinstance(infos, dict) and infos.get("transition_stored")):      # (the env step stored it: go2sim_step_rollout)
+                self._store_transition(rewards, dones, infos, s)
             st.step += 1
             t.clear()
             self.actor_critic.reset(dones)
@@ -323,10 +343,22 @@ class PPO(_RolloutHeads):
         rollout_storage.py:150): 4 chunk gathers per iteration instead of 20 mini-batch gathers.  split: the gradients and the mean
         KL are packed into the all-reduce bucket (more than one rank)."""
         mb = self._mb
-        loss, value_loss, surrogate_loss, kl_mean = self._losses(*(self._perm[k][i * mb:(i + 1) * mb] for k in self._KEYS))
-        self.optimizer.zero_grad(set_to_none=True)
-        loss.backward()
-        self._acc.add_(torch.stack([value_loss.detach(), surrogate_loss.detach()]))
+        batch = [self._perm[k][i * mb:(i + 1) * mb] for k in self._KEYS]
+        if self.fused_loss:
+            # the loss kernel already holds d loss / d (mu, std, value): seed the backward pass of the two networks with them directly
+            # (loss.backward() through the autograd.Function costs a clone and three multiplications by the unit upstream gradient)
+            ac = self.actor_critic
+            mu_b, val_b = self._pair(lambda: ac.actor(batch[0]), lambda: ac.evaluate(batch[1]), enabled=self._capture)
+            stats, gmu, gstd, gval = _FusedPPOLoss.kernel(self, mu_b, ac.std, val_b, *batch[2:])
+            self.optimizer.zero_grad(set_to_none=True)
+            torch.autograd.backward([mu_b, ac.std, val_b], [gmu, gstd.view_as(ac.std), gval])
+            self._acc.add_(stats[:2])             # [surrogate, value loss]; read back swapped in _update_graphs
+            kl_mean = stats[2]
+        else:
+            loss, value_loss, surrogate_loss, kl_mean = self._losses(*batch)
+            self.optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+            self._acc.add_(torch.stack([surrogate_loss.detach(), value_loss.detach()]))
         if split:
             if self._bucket is None:
                 self._bucket = GradBucket(list(self.actor_critic.parameters()), 1 if self._adaptive() else 0)
@@ -346,6 +378,10 @@ class PPO(_RolloutHeads):
             kl_mean = self._kl
             if _collectives_on():          # GO2_GRAPH_COLLECTIVES=1: ONE RCCL all-reduce (gradients + KL) recorded inside the graph
                 kl_mean = self._allreduce_grads(_world(), kl_mean if self._adaptive() else None)
+        if self._fused_adam is None:
+            self._fused_adam = FusedClipAdam(self.lib, self.optimizer, self.actor_critic.parameters(), self.max_grad_norm)
+        if self._fused_adam.usable and self._fused_adam.step(kl_mean if self._adaptive() else None, self.desired_kl if self._adaptive() else 0.0):
+            return
         if self._adaptive():
             lr = self._lr_t
             up = torch.clamp(lr * 1.5, max=1e-2)
@@ -392,7 +428,7 @@ class PPO(_RolloutHeads):
         n = self.num_learning_epochs * nmb
         acc = (self._acc / n).tolist()
         self.learning_rate = float(self._lr_t.item())
-        return acc[0], acc[1]
+        return acc[1], acc[0]
 
     def graphs_captured(self):
         """True iff every mini-batch step of the update is being replayed from a HIP graph (bench.py reports it and refuses to quote a

@@ -20,7 +20,7 @@ import yaml
 
 from ...utils.helpers import class_to_dict
 from ..algorithms import PPO
-from ..algorithms._graph import strict_graphs
+from ..algorithms._graph import no_gc, strict_graphs
 from ..env import missing_members
 from ..modules import ActorCritic
 
@@ -115,6 +115,9 @@ class OnPolicyRunner:
             _enable_tuned_gemms()
         self.use_graphs = bool(on_gpu and self.alg.use_graphs) if use_graphs is None else bool(use_graphs and on_gpu)
         self._rollout_graph, self._graph_ep_infos, self._eager_rollouts = None, None, 0
+        # one policy step = { policy kernels, ONE env library call }: observations land in the next storage rows, the transition store rides in
+        # the step kernel (go2sim_step_rollout); GO2_FUSE_STEP=0 restores copy + store launches
+        self._fuse_step = bool(on_gpu or os.environ.get("GO2_FUSE_STEP") == "1") and os.environ.get("GO2_FUSE_STEP", "1") != "0" and hasattr(self.env, "_info_ring")
         N, T = self.env.num_envs, self.num_steps_per_env
         self._rewbuffer, self._lenbuffer = deque(maxlen=100), deque(maxlen=100)
         z = lambda *s_, **k: torch.zeros(*s_, device=self.device, **k)
@@ -157,7 +160,8 @@ class OnPolicyRunner:
             env._info_slot = 0          # same extras ring slots every iteration (needed for graph replay, harmless otherwise)
         for i in range(T):
             actions = alg.act(obs.to(self.device), critic_obs.to(self.device))
-            obs, privileged_obs, rewards, dones, infos = env.step(actions)
+            tg = alg.rollout_targets() if (self._fuse_step and hasattr(alg, "rollout_targets")) else None
+            obs, privileged_obs, rewards, dones, infos = env.step(actions, rollout=tg) if tg is not None else env.step(actions)
             critic_obs = privileged_obs if privileged_obs is not None else obs
             rewards, dones = rewards.to(self.device), dones.to(self.device)
             alg.process_env_step(rewards, dones, infos)
@@ -201,7 +205,7 @@ class OnPolicyRunner:
                     torch.cuda.synchronize()
                     g = torch.cuda.CUDAGraph()
                     try:
-                        with torch.cuda.graph(g):
+                        with no_gc(), torch.cuda.graph(g):
                             self._graph_ep_infos = self._rollout(bk)
                     except Exception as e:     # noqa: BLE001 — a capture problem must never stop training: fall back to the eager rollout
                         if strict_graphs():    # ... unless the caller asked for it to (bench.py: no number from a silently degraded run)

@@ -325,6 +325,26 @@ int  go2sim_reset_idx(Go2Sim* h, const int32_t* env_ids, int32_t count, void* st
  * `actions` is [N,12] in the library's memory space. */
 int  go2sim_step(Go2Sim* h, const float* actions, void* stream);
 
+/* go2sim_step with the bookkeeping of ONE policy step of the rollout loop fused in (rsl_rl/runners/on_policy_runner.py:135-153,
+ * algorithms/ppo.py:104-114), so that a rollout step is { policy, this call } with no copy / store launches in between:
+ *   obs_out / priv_out: where the step's observations go instead of buffers.obs_buf / privileged_obs_buf ([N,45] / [N,263] row-major; the
+ *       next row of the rollout storage, which the policy then reads in place; NULL = the library's own buffers, whose content is
+ *       unspecified after a call that redirects them);
+ *   rewards_out [N] = rew_buf + gamma * values * time_out_buf (the time-out bootstrap, ppo.py:107-108; values [N] = the critic's values of
+ *       the step's input observations; NULL values = no bootstrap);  dones_out [N] = reset_buf;
+ *   episode_info_out [GO2_EPISODE_INFO_LEN]: a copy of buffers.episode_info as of this step (extras['episode'] ring slot).
+ * Every pointer may be NULL.  go2sim_step(h, a, s) == go2sim_step_rollout(h, a, NULL, s). */
+typedef struct Go2StepOutputs {
+  float*   obs_out;
+  float*   priv_out;
+  const float* values;
+  float*   rewards_out;
+  uint8_t* dones_out;
+  float*   episode_info_out;
+  float    gamma;
+} Go2StepOutputs;
+int  go2sim_step_rollout(Go2Sim* h, const float* actions, const Go2StepOutputs* out, void* stream);
+
 /* ---- fine-grained operations (the Isaac Gym tensor API the reference drives) ------------------- */
 /* legged_robot.py:73-92: only the physics loop of step() (actions must be in buffers.actions). */
 int  go2sim_simulate(Go2Sim* h, void* stream);
@@ -426,6 +446,30 @@ int  go2sim_store_transition(const float* rewards, const uint8_t* dones, const u
  *   gb[c] = sum_b gz[b,c]                    (the Linear's bias gradient; deterministic two-stage reduction)
  * in one pass over the activations instead of two.  workspace: >= C * ceil(B/64) floats.  gz may alias gy. */
 int  go2sim_elu_backward_bias(const float* gy, const float* y, float* gz, float* gb, float* workspace, int32_t B, int32_t C, void* stream);
+
+/* The tail of one mini-batch step of PPO.update / CTS.update (rsl_rl/algorithms/ppo.py:140-155,178-181; cts.py:207-286) over a LIST of
+ * parameter tensors, in two launches instead of the ~30 element-wise / multi-tensor launches of the eager formulation:
+ *   if kl_mean: lr = kl > 2 d ? max(1e-5, lr / 1.5) : (kl < d / 2 && kl > 0 ? min(1e-2, lr * 1.5) : lr)         (:140-155; lr is a device scalar, in place)
+ *   coef = min(1, max_norm / (|| all grads ||_2 + 1e-6))                                                         (torch.nn.utils.clip_grad_norm_, :180)
+ *   per element, torch.optim.Adam (amsgrad off, weight_decay 0):  g = coef grad;  m += (g - m)(1 - b1);  v = b2 v + (1 - b2) g g;
+ *      t = step + 1;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps);  every step[i] += 1                (:181)
+ * The gradient tensors are read, not scaled in place.  The norm is a fixed-order two-stage reduction (deterministic).
+ * Go2AdamTensors is a HOST struct of DEVICE pointers (it travels as a kernel argument: a captured launch keeps the addresses it was
+ * recorded with).  workspace: >= go2sim_adam_workspace_len(t) floats of device memory. */
+#define GO2_ADAM_MAX_TENSORS 48
+#define GO2_ADAM_CHUNK 4096
+typedef struct Go2AdamTensors {
+  int32_t  count;
+  int32_t  numel[GO2_ADAM_MAX_TENSORS];
+  float*   param[GO2_ADAM_MAX_TENSORS];
+  const float* grad[GO2_ADAM_MAX_TENSORS];
+  float*   exp_avg[GO2_ADAM_MAX_TENSORS];
+  float*   exp_avg_sq[GO2_ADAM_MAX_TENSORS];
+  float*   step[GO2_ADAM_MAX_TENSORS];       /* torch keeps one float step counter per parameter; all equal */
+} Go2AdamTensors;
+int  go2sim_adam_workspace_len(const Go2AdamTensors* t);
+int  go2sim_adam_clip_step(const Go2AdamTensors* t, float* lr, const float* kl_mean, float desired_kl, float max_grad_norm,
+                           double beta1, double beta2, double eps, float* workspace, void* stream);   /* (doubles, as torch holds them: 1 - beta is formed in fp64) */
 
 /* Observation-history ring of the CTS runner (on_policy_runner_cts.py:155-156), in place:
  *   history[dones > 0] = 0;  history = cat(history[:, 1:], obs[:, None])      history: float [N,H,D], obs: float [N,D],

@@ -1148,6 +1148,20 @@ int go2sim_step(Go2Sim* s, const float* actions, void* stream) {
   s->injected = inj;
   return go2sim_post_physics(s,stream);
 }
+/* go2sim_step + the rollout loop's bookkeeping of one policy step (on_policy_runner.py:135-153, ppo.py:104-114; see go2sim.h) */
+int go2sim_step_rollout(Go2Sim* s, const float* actions, const Go2StepOutputs* out, void* stream) {
+  int rc = go2sim_step(s, actions, stream);
+  if (rc != 0 || !out) return rc;
+  const Go2SimBuffers* b = &s->b; int N = s->N;
+  if (out->obs_out) memcpy(out->obs_out, b->obs_buf, sizeof(float)*(size_t)N*GO2_NUM_OBS);
+  if (out->priv_out) memcpy(out->priv_out, b->privileged_obs_buf, sizeof(float)*(size_t)N*GO2_NUM_PRIV_OBS);
+  for (int e=0;e<N;++e) {
+    if (out->rewards_out) out->rewards_out[e] = (float)((R)b->rew_buf[e] + ((out->values && b->time_out_buf[e]) ? (R)out->gamma*(R)out->values[e] : 0));
+    if (out->dones_out) out->dones_out[e] = b->reset_buf[e];
+  }
+  if (out->episode_info_out) memcpy(out->episode_info_out, b->episode_info, sizeof(float)*GO2_EPISODE_INFO_LEN);
+  return 0;
+}
 int go2sim_set_root_state_indexed(Go2Sim* s, const int32_t* ids, int32_t count, void* stream) { (void)ids;(void)count;(void)stream; return s ? 0 : GO2SIM_EINVAL; }   /* the API tensors are the state */
 int go2sim_set_dof_state_indexed(Go2Sim* s, const int32_t* ids, int32_t count, void* stream) { (void)ids;(void)count;(void)stream; return s ? 0 : GO2SIM_EINVAL; }
 int go2sim_set_common_step_counter(Go2Sim* s, int64_t v) { if (!s) return GO2SIM_EINVAL; s->common_step_counter=v; return 0; }
@@ -1322,6 +1336,34 @@ int go2sim_elu_backward_bias(const float* gy, const float* y, float* gz, float* 
   for (int r=0;r<B;++r) for (int c=0;c<C;++c) { size_t k=(size_t)r*C+c; float o = gy[k]*(y[k] > 0 ? 1.0f : y[k]+1.0f); gz[k]=o; acc[c]+=o; }
   for (int c=0;c<C;++c) gb[c]=(float)acc[c];
   free(acc);
+  return 0;
+}
+
+/* clip_grad_norm_ + adaptive-KL learning rate + torch.optim.Adam over a list of tensors (go2sim.h; ppo.py:140-155,178-181), plain loops */
+int go2sim_adam_workspace_len(const Go2AdamTensors* t) {
+  if (!t || t->count<=0 || t->count>GO2_ADAM_MAX_TENSORS) return GO2SIM_EINVAL;
+  int nb=0; for (int i=0;i<t->count;++i) { if (t->numel[i]<=0) return GO2SIM_EINVAL; nb += (t->numel[i]+GO2_ADAM_CHUNK-1)/GO2_ADAM_CHUNK; }
+  return nb;
+}
+int go2sim_adam_clip_step(const Go2AdamTensors* t, float* lr, const float* kl_mean, float desired_kl, float max_grad_norm, double beta1, double beta2, double eps,
+                          float* workspace, void* stream) {
+  (void)stream; (void)workspace;
+  if (go2sim_adam_workspace_len(t) < 0 || !lr) return GO2SIM_EINVAL;
+  if (kl_mean) { double kl=*kl_mean, r=*lr, d=desired_kl;
+    if (kl > d*2.0) r = r/1.5 > 1e-5 ? r/1.5 : 1e-5; else if (kl < d/2.0 && kl > 0.0) r = r*1.5 < 1e-2 ? r*1.5 : 1e-2;
+    *lr = (float)r; }
+  double ss=0; for (int i=0;i<t->count;++i) for (int k=0;k<t->numel[i];++k) ss += (double)t->grad[i][k]*(double)t->grad[i][k];
+  double coef = (double)max_grad_norm/(sqrt(ss)+1e-6); if (coef > 1.0) coef = 1.0;
+  double st = (double)t->step[0][0]+1.0, bc1 = 1.0-pow((double)beta1,st), bc2 = 1.0-pow((double)beta2,st), step_size = (double)*lr/bc1;
+  for (int i=0;i<t->count;++i) {
+    for (int k=0;k<t->numel[i];++k) {
+      double g = (double)t->grad[i][k]*coef, m = (double)t->exp_avg[i][k], v = (double)t->exp_avg_sq[i][k];
+      m = m + (g-m)*(1.0-(double)beta1); v = (double)beta2*v + (1.0-(double)beta2)*g*g;
+      t->exp_avg[i][k]=(float)m; t->exp_avg_sq[i][k]=(float)v;
+      t->param[i][k] = (float)((double)t->param[i][k] - step_size*m/(sqrt(v)/sqrt(bc2)+(double)eps));
+    }
+    t->step[i][0] += 1;
+  }
   return 0;
 }
 

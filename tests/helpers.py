@@ -121,6 +121,19 @@ class HostSim:
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         _abi.check(self.lib, self.lib.go2sim_reset_idx(self.h, ids.ctypes.data, len(ids), None), "reset_idx")
 
+    def step_rollout(self, actions, values, gamma):
+        """go2sim_step_rollout with every output redirected -> dict of what it wrote"""
+        A, N, r = self.abi, self.N, self.real
+        a = np.ascontiguousarray(actions, dtype=r); v = np.ascontiguousarray(values, dtype=r)
+        out = {"obs": np.zeros((N, A.GO2_NUM_OBS), r), "priv": np.zeros((N, A.GO2_NUM_PRIV_OBS), r), "rewards": np.zeros(N, r), "dones": np.zeros(N, np.uint8),
+               "info": np.zeros(A.GO2_EPISODE_INFO_LEN, r)}
+        o = A.StepOutputs()
+        fp, bp = C.POINTER(A.real), C.POINTER(C.c_uint8)
+        o.obs_out, o.priv_out, o.values = out["obs"].ctypes.data_as(fp), out["priv"].ctypes.data_as(fp), v.ctypes.data_as(fp)
+        o.rewards_out, o.dones_out, o.episode_info_out, o.gamma = out["rewards"].ctypes.data_as(fp), out["dones"].ctypes.data_as(bp), out["info"].ctypes.data_as(fp), gamma
+        _abi.check(self.lib, self.lib.go2sim_step_rollout(self.h, a.ctypes.data, C.byref(o), None), "step_rollout")
+        return out
+
     def step(self, actions):
         a = np.ascontiguousarray(actions, dtype=self.real)
         _abi.check(self.lib, self.lib.go2sim_step(self.h, a.ctypes.data, None), "step")
@@ -230,6 +243,20 @@ class DeviceSim:
 
     def reset_all(self):
         _abi.check(self.lib, self.lib.go2sim_reset_all(self.h, self._st()), "reset_all")
+
+    def step_rollout(self, actions, values, gamma):
+        t, A, N = self.torch, self.abi, self.N
+        a = t.as_tensor(np.ascontiguousarray(actions, dtype=np.float32), device=self.device); v = t.as_tensor(np.ascontiguousarray(values, dtype=np.float32), device=self.device)
+        out = {"obs": t.zeros(N, A.GO2_NUM_OBS, device=self.device), "priv": t.zeros(N, A.GO2_NUM_PRIV_OBS, device=self.device), "rewards": t.zeros(N, device=self.device),
+               "dones": t.zeros(N, dtype=t.uint8, device=self.device), "info": t.zeros(A.GO2_EPISODE_INFO_LEN, device=self.device)}
+        o = A.StepOutputs()
+        fp, bp = C.POINTER(C.c_float), C.POINTER(C.c_uint8)
+        cast = lambda x, ty: C.cast(C.c_void_p(x.data_ptr()), ty)
+        o.obs_out, o.priv_out, o.values = cast(out["obs"], fp), cast(out["priv"], fp), cast(v, fp)
+        o.rewards_out, o.dones_out, o.episode_info_out, o.gamma = cast(out["rewards"], fp), cast(out["dones"], bp), cast(out["info"], fp), gamma
+        _abi.check(self.lib, self.lib.go2sim_step_rollout(self.h, C.c_void_p(a.data_ptr()), C.byref(o), self._st()), "step_rollout")
+        t.cuda.synchronize()
+        return {k: x.cpu().numpy() for k, x in out.items()}
 
     def reset_idx(self, ids):
         ids = self.torch.as_tensor(np.ascontiguousarray(ids, dtype=np.int32), device=self.device)

@@ -676,3 +676,45 @@ def test_trimesh_walls_on_gpu(hip):
     tri = tw.settle_against_riser(hip, DeviceSim, "trimesh")
     assert np.all(np.abs(tri[:, 0] + 0.022 - 6.0) < 0.006) and np.all(np.abs(tri[:, 2] - 0.022) < 0.006), tri
     assert np.all(tw.settle_against_riser(hip, DeviceSim, "heightfield")[:, 0] < 5.93)
+
+
+def test_step_rollout_on_gpu(hip):
+    """go2sim_step_rollout on the device: redirected observation rows, fused transition store, extras copy == go2sim_step + those operations."""
+    from test_lane_emulation import check_step_rollout
+    check_step_rollout(hip, DeviceSim, 200)
+
+
+def test_fused_clip_adam_matches_torch_on_gpu(hip):
+    """go2sim_adam_clip_step (adaptive-KL learning rate + clip_grad_norm_ + Adam, two kernels) against torch.nn.utils.clip_grad_norm_ +
+    torch.optim.Adam on the same gradients over several steps (ppo.py:140-155,178-181): parameters, both moments, step counters, learning rate."""
+    import torch
+    from go2_rl_gym_amd.rsl_rl.algorithms._graph import FusedClipAdam
+    torch.manual_seed(0)
+    shapes = [(512, 45), (512,), (256, 512), (256,), (128, 256), (128,), (12, 128), (12,), (12,), (5000, 33)]
+    pa = [torch.nn.Parameter(torch.randn(s, device="cuda:0") * 0.1) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    lra, lrb = torch.tensor(1e-3, device="cuda:0"), 1e-3
+    oa = torch.optim.Adam(pa, lr=lra, capturable=True, fused=True)
+    ob = torch.optim.Adam(pb, lr=lrb)
+    fa = FusedClipAdam(hip, oa, pa, 1.0)
+    assert fa.usable
+    for it in range(6):
+        scale = [3.0, 0.01, 1.0, 30.0, 0.3, 1.0][it]              # clipped and unclipped steps
+        kl = [0.05, 0.001, 0.011, 0.0, 0.004, 0.03][it]           # lr down, up, keep, keep (kl == 0), up, down
+        for a, b in zip(pa, pb):
+            g = torch.randn_like(a) * scale * 1e-2
+            a.grad, b.grad = g.clone(), g.clone()
+        assert fa.step(torch.tensor(kl, device="cuda:0"), 0.01)
+        if kl > 0.02: lrb = max(1e-5, lrb / 1.5)
+        elif kl < 0.005 and kl > 0.0: lrb = min(1e-2, lrb * 1.5)
+        for gr in ob.param_groups: gr["lr"] = lrb
+        torch.nn.utils.clip_grad_norm_(pb, 1.0)
+        ob.step()
+        assert abs(float(lra) - lrb) < 1e-9 + 2e-7 * lrb
+        for a, b in zip(pa, pb):
+            np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), atol=2e-7, rtol=2e-6)
+            np.testing.assert_allclose(oa.state[a]["exp_avg"].cpu().numpy(), ob.state[b]["exp_avg"].cpu().numpy(), atol=1e-9, rtol=2e-6)
+            np.testing.assert_allclose(oa.state[a]["exp_avg_sq"].cpu().numpy(), ob.state[b]["exp_avg_sq"].cpu().numpy(), atol=1e-12, rtol=2e-6)
+            assert float(oa.state[a]["step"]) == it + 1
+    sd = oa.state_dict()                                          # the torch optimizer's own state: checkpoints are unchanged
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}

@@ -138,3 +138,37 @@ def test_soak_under_training_like_action_noise():
             assert np.isfinite(np.asarray(getattr(s, k))).all(), k
     assert wmax < 60.0 and resets > 10, (wmax, resets)
     s.close()
+
+
+@pytest.mark.parametrize("which", ["oracle", "lane_emulation"])
+def test_step_rollout_equals_step_plus_bookkeeping(which):
+    """go2sim_step_rollout: redirected observation rows, the transition store with the time-out bootstrap (ppo.py:107-108) and the extras copy
+    equal go2sim_step followed by those operations done by hand (the HIP run: tests/test_gpu_parity.py)."""
+    import ctypes as C
+    lib = load_oracle() if which == "oracle" else load_emu()
+    check_step_rollout(lib, HostSim, 24)
+
+
+def check_step_rollout(lib, sim, n):
+    import ctypes as C
+    a_, b_ = sim(lib, num_envs=n, seed=8), sim(lib, num_envs=n, seed=8)
+    a_.reset_all(); b_.reset_all()
+    el = np.arange(n) % 7 + 1244                            # some envs time out within the run
+    a_.episode_length_buf[:] = el; b_.episode_length_buf[:] = el
+    rng = np.random.default_rng(1)
+    A = lib.abi
+    seen_to = 0
+    for it in range(10):
+        act = rng.normal(0, 1, (n, 12)).astype(np.float32)
+        vals = rng.normal(0, 1, n).astype(np.float32)
+        a_.step(act)
+        out = b_.step_rollout(act, vals, gamma=0.99)
+        to = np.asarray(a_.time_out_buf).astype(bool); seen_to += int(to.sum())
+        np.testing.assert_array_equal(out["obs"], np.asarray(a_.obs_buf)); np.testing.assert_array_equal(out["priv"], np.asarray(a_.privileged_obs_buf))
+        np.testing.assert_allclose(out["rewards"], np.asarray(a_.rew_buf) + np.float32(0.99) * vals * to, atol=1e-7)
+        np.testing.assert_array_equal(out["dones"], np.asarray(a_.reset_buf))
+        np.testing.assert_allclose(out["info"], np.asarray(a_.episode_info), rtol=2e-6, atol=1e-9)      # (sums of float atomics on the device: order-dependent last bits)
+        for k in ("root_states", "dof_state", "rew_buf", "commands"):
+            np.testing.assert_array_equal(np.asarray(getattr(a_, k)), np.asarray(getattr(b_, k)), err_msg=k)
+    assert seen_to > 0
+    a_.close(); b_.close()

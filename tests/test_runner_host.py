@@ -170,3 +170,29 @@ def test_reset_idx_subset_control_types_and_command_curriculum_through_the_host_
     env_cfg.control.control_type = "X"
     with pytest.raises(NameError):
         task_registry.make_env("go2_flat", args, env_cfg=env_cfg, lib=load_oracle())
+
+
+def test_fused_rollout_step_fills_the_same_storage(tmp_path, monkeypatch):
+    """LeggedRobot.step(rollout=...) (go2sim_step_rollout: observations written straight into the next storage rows, reward bootstrap + done
+    rows stored by the env step, extras ring slot filled by the library) against the copy / store formulation of the same rollout
+    (on_policy_runner.py:135-153, ppo.py:90-114): identical storage, identical extras."""
+    res = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("GO2_FUSE_STEP", fuse)
+        torch.manual_seed(3)
+        env, runner, _ = _make(tmp_path / fuse)
+        runner.alg.fused_rollout = True                       # the library heads (default on the GPU only)
+        assert runner._fuse_step == (fuse == "1")
+        env.episode_length_buf[:] = torch.randint(1200, 1250, (env.num_envs,))       # time-outs inside the rollout: the bootstrap term matters
+        torch.manual_seed(4)
+        infos = runner._rollout(None)
+        st = runner.alg.storage
+        res[fuse] = {k: getattr(st, k).clone() for k in ("observations", "privileged_observations", "rewards", "dones", "values", "actions")}
+        res[fuse]["last_obs"] = env.get_observations().clone()
+        res[fuse]["info"] = env._info_ring.clone()
+        res[fuse]["timeouts"] = int(env.time_out_buf.sum()) + int((st.rewards != 0).sum() > 0)
+        env.close()
+    for k in res["0"]:
+        if torch.is_tensor(res["0"][k]):
+            assert torch.equal(res["0"][k], res["1"][k]), k
+    assert res["0"]["dones"].sum() > 0
