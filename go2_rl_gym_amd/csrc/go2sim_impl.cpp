@@ -556,14 +556,23 @@ __global__ void __launch_bounds__(256) go2_ppo_loss_kernel(const float* __restri
 }
 __global__ void go2_ppo_loss_finish_kernel(const float* __restrict__ part, const float* __restrict__ std_, float* __restrict__ gstd, float* __restrict__ stats,
                                            int nblocks, int B, int A, float vcoef, float ecoef) {
-  const int k = threadIdx.x;
-  if (k >= PPO_NSTAT) return;
-  float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * PPO_NSTAT + k];      // fixed order: deterministic
-  if (k < 4) { stats[k] = k == 0 ? s : s / (float)B; }      // the surrogate partials are already weighted
-  else if (k - 4 < A) gstd[k - 4] = s - ecoef / std_[k - 4];
+  // 8 x PPO_NSTAT threads: thread (j, k) sums the blocks j, j + 8, ... of statistic k (independent loads in flight instead of one serial
+  // chain of `nblocks` per statistic), then the 8 sub-sums are added in a fixed order: deterministic
+  __shared__ float sh[8][PPO_NSTAT];
+  const int k = threadIdx.x % PPO_NSTAT, j = threadIdx.x / PPO_NSTAT;
+  if (j < 8) {
+    float s = 0.f;
+    for (int b = j; b < nblocks; b += 8) s += part[(size_t)b * PPO_NSTAT + k];
+    sh[j][k] = s;
+  }
   __syncthreads();
-  if (k == 0) stats[4] = stats[0] + vcoef * stats[1] - ecoef * stats[3];
+  if (threadIdx.x < PPO_NSTAT) {
+    const float s = ((sh[0][k] + sh[1][k]) + (sh[2][k] + sh[3][k])) + ((sh[4][k] + sh[5][k]) + (sh[6][k] + sh[7][k]));
+    if (k < 4) { sh[0][k] = k == 0 ? s : s / (float)B; stats[k] = sh[0][k]; }      // the surrogate partials are already weighted
+    else if (k - 4 < A) gstd[k - 4] = s - ecoef / std_[k - 4];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) stats[4] = sh[0][0] + vcoef * sh[0][1] - ecoef * sh[0][3];
 }
 // ---- ELU backward + bias gradient in one pass.  Block = 64 column-quads (float4) x 4 row lanes over a 256-col x EB_ROWS-row tile; HBM-bound
 // (reads gy, y, writes gz: 12 B per element), so each thread keeps 4 rows = 8 float4 loads in flight.  Column partials per row tile go to a
@@ -647,6 +656,27 @@ __global__ void __launch_bounds__(256) go2_act_head_kernel(const float* __restri
   }
   if (lp_st) lp_st[e] = lp;
   if (v_st) v_st[e] = value[e];
+}
+// A <= 16: 16 lanes per row (coalesced rows, 16x the waves of one thread per row); the log-probability is summed in the same order (j = 0, 1, ..)
+__global__ void __launch_bounds__(256) go2_act_head16_kernel(const float* __restrict__ mu, const float* __restrict__ std_, const float* __restrict__ eps, const float* __restrict__ value,
+    float* __restrict__ a_out, float* __restrict__ a_st, float* __restrict__ mu_st, float* __restrict__ sig_st, float* __restrict__ lp_st, float* __restrict__ v_st, int N, int A) {
+  const int t = blockIdx.x * 256 + threadIdx.x, e = t >> 4, j = t & 15;
+  const bool on = e < N && j < A;
+  const float HALF_LOG2PI = 0.9189385332046727f;
+  float term = 0.f;
+  if (on) {
+    const size_t k = (size_t)e * A + j;
+    const float m = mu[k], sg = std_[j], a = go2_add_rn(m, go2_mul_rn(sg, eps[k])), d = a - m;
+    term = -(d * d) / (2.f * sg * sg) - logf(sg) - HALF_LOG2PI;
+    a_out[k] = a;
+    if (a_st) a_st[k] = a;
+    if (mu_st) mu_st[k] = m;
+    if (sig_st) sig_st[k] = sg;
+  }
+  float lp = 0.f;
+  const int base = (threadIdx.x & 63) & ~15;
+  for (int q = 0; q < A; ++q) lp += __shfl(term, base + q);
+  if (e < N && j == 0) { if (lp_st) lp_st[e] = lp; if (v_st) v_st[e] = value[e]; }
 }
 __global__ void __launch_bounds__(256) go2_store_transition_kernel(const float* __restrict__ rew, const uint8_t* __restrict__ dones, const uint8_t* __restrict__ touts,
     const float* __restrict__ v_st, float* __restrict__ rew_st, uint8_t* __restrict__ dones_st, float gamma, int N) {
@@ -1271,7 +1301,7 @@ int go2sim_ppo_loss(const float* mu, const float* std_, const float* value, cons
 #else
   int nb = (B + 255) / 256;
   hipLaunchKernelGGL(go2_ppo_loss_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, mu, std_, value, actions, old_mu, old_sigma, old_logp, adv, tv, ret, gmu, gval, workspace, B, A, clip, vcoef, use_clip_v, split, w_head, w_tail);
-  hipLaunchKernelGGL(go2_ppo_loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, workspace, std_, gstd, stats, nb, B, A, vcoef, ecoef);
+  hipLaunchKernelGGL(go2_ppo_loss_finish_kernel, dim3(1), dim3(8 * PPO_NSTAT), 0, (hipStream_t)stream, workspace, std_, gstd, stats, nb, B, A, vcoef, ecoef);
   HIPCHK(hipGetLastError());
 #endif
   return 0;
@@ -1348,7 +1378,8 @@ int go2sim_act_head(const float* mu, const float* std_, const float* eps, const 
     if (v_st) v_st[e] = value[e];
   }
 #else
-  hipLaunchKernelGGL(go2_act_head_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, mu, std_, eps, value, a_out, a_st, mu_st, sig_st, lp_st, v_st, N, A);
+  if (A <= 16) hipLaunchKernelGGL(go2_act_head16_kernel, dim3((N * 16 + 255) / 256), dim3(256), 0, (hipStream_t)stream, mu, std_, eps, value, a_out, a_st, mu_st, sig_st, lp_st, v_st, N, A);
+  else hipLaunchKernelGGL(go2_act_head_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, mu, std_, eps, value, a_out, a_st, mu_st, sig_st, lp_st, v_st, N, A);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

@@ -192,9 +192,16 @@ class OnPolicyRunner:
         start_iter = self.current_learning_iteration
         tot_iter = start_iter + num_learning_iterations
         it = start_iter
+        gpu_clock = str(self.device).startswith("cuda")
+        self._sync()
         for it in range(start_iter, tot_iter):
-            self._sync()
+            # collection / learning time as the reference logs them (on_policy_runner.py:133,154-155,162-163).  On the GPU the split point is a
+            # stream EVENT, read after the iteration's one host sync: a device synchronisation between rollout and update would idle the GPU
+            # for ~0.1 ms per iteration
             start = time.time()
+            if gpu_clock:
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                ev[0].record()
             with torch.inference_mode():
                 if self._rollout_graph is not None:
                     self._rollout_graph.replay()                       # 24 x (policy, env step kernel, storage) in ONE launch
@@ -225,16 +232,22 @@ class OnPolicyRunner:
                 else:
                     ep_infos = self._rollout(bk)
                     self._eager_rollouts += 1
-                self._sync()
-                stop = time.time()
-                collection_time = stop - start
-                start = stop
+                if gpu_clock:
+                    ev[1].record()
+                else:
+                    stop = time.time()
+                    collection_time = stop - start
+                    start = stop
                 self._compute_returns()
             losses = self.alg.update()
             mean_value_loss, mean_surrogate_loss = losses[0], losses[1]
             self._sync()
             stop = time.time()
-            learn_time = stop - start
+            if gpu_clock:
+                collection_time = ev[0].elapsed_time(ev[1]) * 1e-3
+                learn_time = max(stop - start - collection_time, 0.0)
+            else:
+                learn_time = stop - start
             if self.log_dir is not None:
                 self._collect_episode_stats(bk)
                 self.log(locals())
