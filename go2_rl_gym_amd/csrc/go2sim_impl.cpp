@@ -220,6 +220,21 @@ GO2_HD void lane_reset_all(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p,
 template <int MODE>
 GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, const float* __restrict__ actions_in, int initial_reset, const Go2StepOutputs& outs, int bid, int tid) {
   const Go2PtrsK& p = *(const Go2PtrsK*)&blk->p; const Go2Launch& L = blk->L;   // uniform addresses -> scalar loads; pointers typed global
+#if defined(__HIP_DEVICE_COMPILE__)
+  // Touch the per-environment state this workgroup is about to read (one 64-byte segment per field-major field: thread k touches field k
+  // for the workgroup's first environment) BEFORE the table staging and its barrier: the HBM latency of the state overlaps the staging, the
+  // loads of the load phase then hit in L2.  The values are not used.
+  float touch = 0.f;
+  if (MODE & MODE_PHYS) {
+    const int N = L.N; const size_t e0 = (size_t)bid * GO2_WG_ENVS;
+#define GO2_TOUCH(base, nf, t0) if (tid >= (t0) && tid < (t0) + (nf)) touch = (base)[(size_t)(tid - (t0)) * N + e0]
+    GO2_TOUCH(p.root, 13, 0); GO2_TOUCH(p.dof, 24, 13); GO2_TOUCH(p.kp_mul, 12, 37); GO2_TOUCH(p.kd_mul, 12, 49); GO2_TOUCH(p.zero_off, 12, 61);
+    GO2_TOUCH(p.strength, 12, 73); GO2_TOUCH(p.last_actions, 12, 85); GO2_TOUCH(p.foot_impulse, 12, 97); GO2_TOUCH(p.mass_ratio, 18, 109);
+    GO2_TOUCH(p.added_com, 3, 127); GO2_TOUCH(p.added_mass, 1, 130); GO2_TOUCH(p.friction, 1, 131); GO2_TOUCH(p.restitution, 1, 132);
+#undef GO2_TOUCH
+    if (actions_in && tid >= 133 && tid < 133 + 3 && e0 * 12 + (size_t)(tid - 133) * 64 < (size_t)N * 12) touch = actions_in[e0 * 12 + (size_t)(tid - 133) * 64];      // [N,12] row-major: the workgroup's 16 rows = 768 B
+  }
+#endif
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(GO2_GENERIC(const Go2Tables*, p.tables)); uint32_t* dst = reinterpret_cast<uint32_t*>(&sh.tab);
     for (int i = tid; i < (int)(sizeof(Go2Tables) / 4); i += GO2_WG_THREADS) dst[i] = src[i];
@@ -227,6 +242,9 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
     if (tid < GO2_STEP_SCALAR_PARTS) go2_step_scalars_part(tid, L, blk->dyn, GO2_GENERIC(const float*, p.inj_storage), blk->dyn.common_step_counter + ((MODE & MODE_POST) ? 1 : 0), initial_reset, &sh.S);
   }
   xl::sync();
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" :: "v"(touch));
+#endif
   const Go2Tables& tab = sh.tab; const Go2Step& S = sh.S;
   bool yaw_seen = false;
   if ((MODE & MODE_POST) && S.stage_pending) {   // rare (the steps between the start of a command_range_curriculum stage and the next resample)
@@ -239,7 +257,7 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
   const int e = bid * GO2_WG_ENVS + (tid >> 4), lane = (tid >> 2) & 3, sub = tid & 3;
   if (e >= L.N) return;   // whole rows (environments) leave together
 #if defined(__HIP_DEVICE_COMPILE__)
-  long long* dbg = p.dbg_clock ? (long long*)p.dbg_clock + (size_t)(bid * 4 + (tid >> 6)) * 16 : nullptr;   // optional phase timestamps per wave (tools/kbench.py)
+  long long* dbg = p.dbg_clock ? (long long*)p.dbg_clock + (size_t)(bid * 4 + (tid >> 6)) * 32 : nullptr;   // optional phase timestamps per wave (tools/kbench.py)
 #define STAMP(k) do { if (dbg && (tid & 63) == 0) dbg[k] = wall_clock64(); } while (0)
 #else
 #define STAMP(k) do { } while (0)
@@ -279,17 +297,22 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
       const bool old = L.rand_delay && sb < ax.start;
       const float a[3] = {old ? ax.act_old[0] : ax.act_new[0], old ? ax.act_old[1] : ax.act_new[1], old ? ax.act_old[2] : ax.act_new[2]};
       GO2_MARK(10);
+      if (sb == 1) STAMP(16);
       ph_.pd(tl, hl, a, ax.kp, ax.kd, ax.q0, ax.zoff, ax.strength, p.last_dof_vel, L.N, e);
       float part[GO2_QUAD_PARTIALS];
       ph_.phaseA(tl, hl, part);
       GO2_MARK(11);
+      if (sb == 1) STAMP(17);
 #pragma unroll
       for (int i = 0; i < GO2_QUAD_PARTIALS; ++i) part[i] = xl::leg_sum(part[i]);
       GO2_MARK(12);
+      if (sb == 1) STAMP(18);
       ph_.phaseB(hl, part);
       GO2_MARK(13);
+      if (sb == 1) STAMP(19);
       ph_.phaseC(tl, hl, p.hf_cells);
       GO2_MARK(14);
+      if (sb == 1) STAMP(20);
       // wave-wide row-group activity PER TURN (ballots -> scalar branches): group g of leg T is swept only if some environment of the wave
       // has it active on that leg — typically only the foot contacts are live (an inactive row moves nothing, so skipping is exact)
       bool af[4], ao[4], al[4];
@@ -300,9 +323,11 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
         ph_.gs_turn(2, af[2], ao[2], al[2]); ph_.gs_turn(3, af[3], ao[3], al[3]);
       }
       GO2_MARK(15);
+      if (sb == 1) STAMP(21);
       ph_.gather_solution();
       ph_.phaseD(tl, hl);
       GO2_MARK(16);
+      if (sb == 1) STAMP(22);
     }
     STAMP(2);
     GO2_MARK(20);

@@ -69,15 +69,15 @@ def phase_clocks(steps=50, **kw):
     a = torch.randn(N, 12, device="cuda:0") * 0.5
     for _ in range(80):
         hip.go2sim_step(s.h, C.c_void_p(a.data_ptr()), s._st())
-    nb = 4 * ((N + 15) // 16)               # one row of 8 stamps per WAVE (4 waves per 16-env workgroup)
-    buf = torch.zeros(nb, 16, dtype=torch.int64, device="cuda:0")
+    nb = 4 * ((N + 15) // 16)               # one row of 32 stamps per WAVE (4 waves per 16-env workgroup)
+    buf = torch.zeros(nb, 32, dtype=torch.int64, device="cuda:0")
     hip.go2sim_debug_clock.argtypes = [C.c_void_p, C.c_void_p]
     hip.go2sim_debug_clock(s.h, C.c_void_p(buf.data_ptr()))
     acc = []
     for _ in range(steps):
         hip.go2sim_step(s.h, C.c_void_p(a.data_ptr()), s._st())
         torch.cuda.synchronize()
-        acc.append(buf[:, :16].cpu().numpy().astype(np.float64)); buf[:, 8:].zero_()
+        acc.append(buf[:, :32].cpu().numpy().astype(np.float64)); buf[:, 8:].zero_()
     hip.go2sim_debug_clock(s.h, None)
     t = np.stack(acc)                       # [steps, blocks, 6]
     d = np.diff(t[:, :, :6], axis=2) / 100.0          # us (100 MHz constant clock)
@@ -100,6 +100,9 @@ def phase_clocks(steps=50, **kw):
         seq = [6, 8, 9, 10, 11, 12, 13, 7]
         lab = ["philox fill x2", "DOF tables", "terrain curriculum", "dofs + root state", "resample", "episode atomics", "push (fill + draw)"]
         print("reset path (%d samples): " % full.sum() + ", ".join("%s %.2f" % (lab[j], ((t[:, :, seq[j + 1]] - t[:, :, seq[j]]) / 100.0)[full].mean()) for j in range(7)))
+    ss = np.diff(t[:, :, 16:23], axis=2) / 100.0
+    print("substep 1 (mean / p99 over waves): " + ", ".join("%s %.2f / %.2f" % (nm, ss[:, :, j].mean(), np.quantile(ss[:, :, j], 0.99))
+          for j, nm in enumerate(["pd+phaseA", "leg sums", "phaseB", "phaseC (contacts, rows)", "Gauss-Seidel", "gather+phaseD"])))
     sub_ = d[:, :, 1]
     print("substeps over waves: p50 %.1f p90 %.1f p99 %.1f max %.1f us" % tuple(np.quantile(sub_, q) for q in (0.5, 0.9, 0.99, 1.0)))
     s.close()
