@@ -123,8 +123,10 @@ class CTS(_RolloutHeads):
         if s >= st.num_transitions_per_env:
             raise AssertionError("Rollout buffer overflow")
         # record what env.step() is about to overwrite (the env's buffers and the runner's history ring are updated in place)
-        st.observations[s].copy_(obs)
-        st.privileged_observations[s].copy_(privileged_obs)
+        if obs.data_ptr() != st.observations[s].data_ptr():                     # (the env wrote this row itself: LeggedRobot.step(rollout=...))
+            st.observations[s].copy_(obs)
+        if privileged_obs.data_ptr() != st.privileged_observations[s].data_ptr():
+            st.privileged_observations[s].copy_(privileged_obs)
         st.history[s].copy_(history)
         latent = self._latent_env_order(privileged_obs, history)
         if self.fused_rollout:

@@ -103,7 +103,20 @@ class _RolloutHeads:
         t.action_mean, t.action_sigma = st.mu[s], st.sigma[s]
         return actions
 
+    def rollout_targets(self):
+        """Destinations for LeggedRobot.step(rollout=...) of the step being collected: the env kernel writes the next observations into the
+        next storage rows and this step's reward / done rows itself (None: not applicable)."""
+        st = self.storage
+        if not self.fused_rollout or st.privileged_observations is None or st.dones.dtype != torch.uint8:
+            return None
+        s = st.step
+        nxt = s + 1 < st.num_transitions_per_env
+        return {"obs_out": st.observations[s + 1] if nxt else None, "priv_out": st.privileged_observations[s + 1] if nxt else None,
+                "values": st.values[s].view(-1), "rewards_out": st.rewards[s].view(-1), "dones_out": st.dones[s].view(-1), "gamma": self.gamma}
+
     def _store_transition(self, rewards, dones, infos, s):
+        if isinstance(infos, dict) and infos.get("transition_stored"):      # (the env step stored it: go2sim_step_rollout)
+            return
         st = self.storage
         touts = infos.get("time_outs") if isinstance(infos, dict) else None
         rewards = rewards.contiguous().float()
@@ -241,23 +254,11 @@ class PPO(_RolloutHeads):
         st.sigma[s].copy_(t.action_sigma)
         return t.actions
 
-    def rollout_targets(self):
-        """Destinations for LeggedRobot.step(rollout=...) of the step being collected: the env kernel writes the next observations into the
-        next storage rows and this step's reward / done rows itself (None: not applicable)."""
-        st = self.storage
-        if not self.fused_rollout or st.privileged_observations is None:
-            return None
-        s = st.step
-        nxt = s + 1 < st.num_transitions_per_env
-        return {"obs_out": st.observations[s + 1] if nxt else None, "priv_out": st.privileged_observations[s + 1] if nxt else None,
-                "values": st.values[s].view(-1), "rewards_out": st.rewards[s].view(-1), "dones_out": st.dones[s].view(-1), "gamma": self.gamma}
-
     def process_env_step(self, rewards, dones, infos):
         st, t = self.storage, self.transition
         s = st.step
         if self.fused_rollout:
-            if not (isinstance(infos, dict) and infos.get("transition_stored")):      # (the env step stored it: go2sim_step_rollout)
-                self._store_transition(rewards, dones, infos, s)
+            self._store_transition(rewards, dones, infos, s)
             st.step += 1
             t.clear()
             self.actor_critic.reset(dones)

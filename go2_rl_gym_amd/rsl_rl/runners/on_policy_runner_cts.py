@@ -65,7 +65,8 @@ class OnPolicyRunnerCTS(OnPolicyRunner):
             env._info_slot = 0
         for i in range(T):
             actions = alg.act(obs, privileged_obs, self.history.flatten(1))
-            obs, privileged_obs, rewards, dones, infos = env.step(actions)
+            tg = alg.rollout_targets() if self._fuse_step else None
+            obs, privileged_obs, rewards, dones, infos = env.step(actions, rollout=tg) if tg is not None else env.step(actions)
             obs, privileged_obs, rewards, dones = obs.to(self.device), privileged_obs.to(self.device), rewards.to(self.device), dones.to(self.device)
             self._push_history(obs, dones)                                         # :155-156
             alg.process_env_step(rewards, dones, infos)
