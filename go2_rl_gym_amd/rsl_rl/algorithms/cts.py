@@ -131,7 +131,7 @@ class CTS(_RolloutHeads):
         latent = self._latent_env_order(privileged_obs, history)
         if self.fused_rollout:
             mu, value = self._pair(lambda: m.policy_mean(latent, obs), lambda: m.evaluate_joint(privileged_obs, latent, obs), enabled=self._capture and not m.heads_share_parameters)
-            return self._act_head(mu, m.std, m._noise(mu), value, s)
+            return self._act_head(mu, m.std, m._noise(mu), value, s)      # (MCP-CTS: state-dependent std, no storage-shaped stand-in for the noise)
         t.actions = m.act_joint(obs, latent).detach()
         t.values = m.evaluate_joint(privileged_obs, latent, obs).detach()
         t.actions_log_prob = m.get_actions_log_prob(t.actions).detach()
@@ -362,8 +362,8 @@ class CTS(_RolloutHeads):
                 for i in range(nmb):
                     steps[i]()
         n = self.num_learning_epochs * nmb
-        out = (self._acc / n).tolist()
-        self.learning_rate = float(self._lr_t.item())
+        out = torch.cat([self._acc / n, self._lr_t.reshape(1)]).tolist()          # ONE device -> host read per update
+        self.learning_rate = float(out.pop())
         return self._ordered(tuple(out))
 
     def graphs_captured(self):

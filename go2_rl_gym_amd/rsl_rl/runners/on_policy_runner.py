@@ -115,6 +115,7 @@ class OnPolicyRunner:
             _enable_tuned_gemms()
         self.use_graphs = bool(on_gpu and self.alg.use_graphs) if use_graphs is None else bool(use_graphs and on_gpu)
         self._rollout_graph, self._graph_ep_infos, self._eager_rollouts = None, None, 0
+        self._returns_graph = None
         # one policy step = { policy kernels, ONE env library call }: observations land in the next storage rows, the transition store rides in
         # the step kernel (go2sim_step_rollout); GO2_FUSE_STEP=0 restores copy + store launches
         self._fuse_step = bool(on_gpu or os.environ.get("GO2_FUSE_STEP") == "1") and os.environ.get("GO2_FUSE_STEP", "1") != "0" and hasattr(self.env, "_info_ring")
@@ -144,6 +145,18 @@ class OnPolicyRunner:
         privileged_obs = self.env.get_privileged_observations()
         critic_obs = (privileged_obs if privileged_obs is not None else obs).to(self.device)
         self.alg.compute_returns(critic_obs)
+
+    def _returns_step(self):
+        """compute_returns (bootstrap value of the last observations, GAE, advantage normalisation: on_policy_runner.py:158, rollout_storage.py:123-137)
+        — replayed from its own small HIP graph when the rollout is (eager it is ~10 launches with host gaps between them); eager whenever a
+        collective sits inside it (more than one rank: the advantage-statistics all-reduce)."""
+        from ..algorithms.ppo import _collectives_on
+        if self._rollout_graph is None or _collectives_on():
+            return self._compute_returns()
+        if self._returns_graph is None:
+            from ..algorithms._graph import CapturedStep
+            self._returns_graph = CapturedStep(self._compute_returns, enabled=True, warmup=1, name="compute_returns")
+        self._returns_graph()
 
     def _sync(self):
         if str(self.device).startswith("cuda"):
@@ -238,7 +251,7 @@ class OnPolicyRunner:
                     stop = time.time()
                     collection_time = stop - start
                     start = stop
-                self._compute_returns()
+                self._returns_step()
             losses = self.alg.update()
             mean_value_loss, mean_surrogate_loss = losses[0], losses[1]
             self._sync()
