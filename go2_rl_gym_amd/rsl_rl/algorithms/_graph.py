@@ -138,8 +138,10 @@ def all_captured(steps):
 
 
 class CapturedStep:
-    def __init__(self, fn, enabled=True, warmup=3, name="step"):
-        self.fn, self.enabled, self.warmup, self.name = fn, enabled, warmup, name
+    def __init__(self, fn, enabled=True, warmup=3, name="step", optional=False):
+        """optional: a failed capture silently keeps this step eager even under GO2_STRICT_GRAPHS (a convenience graph, not one of the halves
+        bench.py reports on)."""
+        self.fn, self.enabled, self.warmup, self.name, self.optional = fn, enabled, warmup, name, optional
         self.graph, self.calls = None, 0
 
     def __call__(self):
@@ -154,7 +156,7 @@ class CapturedStep:
                 with no_gc(), torch.cuda.graph(g):
                     self.fn()
             except Exception as e:      # noqa: BLE001 — any capture problem degrades to eager execution (unless GO2_STRICT_GRAPHS=1)
-                if strict_graphs():
+                if strict_graphs() and not self.optional:
                     raise RuntimeError("HIP-graph capture of %s failed (%s: %s)" % (self.name, type(e).__name__, e)) from e
                 print("[go2_rl_gym_amd] HIP-graph capture of %s failed (%s: %s); continuing eagerly" % (self.name, type(e).__name__, e))
                 self.enabled = False

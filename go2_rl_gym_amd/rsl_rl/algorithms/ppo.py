@@ -418,11 +418,15 @@ class PPO(_RolloutHeads):
                                            enabled=self._capture, warmup=3 if i == 0 else 1, name="PPO mini-batch step %d" % i) for i in range(nmb)]
             else:
                 self._graph = [CapturedStep((lambda i=i: self._graph_step(i)), enabled=self._capture, warmup=3 if i == 0 else 1, name="PPO mini-batch step %d" % i) for i in range(nmb)]
-        self._acc.zero_()
-        # ONE permutation for the whole update, reused by every epoch, as in the reference (rollout_storage.py:150)
-        indices = torch.randperm(nmb * mb, requires_grad=False, device=self.device)
-        for k in self._KEYS:
-            torch.index_select(self._flat[k], 0, indices, out=self._perm[k])
+            # ONE permutation for the whole update, reused by every epoch, as in the reference (rollout_storage.py:150); randperm + the 9 gathers
+            # replayed from a graph (eager, randperm's sort passes leave the device idle for ~0.15 ms between launches)
+            def permute():
+                self._acc.zero_()
+                indices = torch.randperm(nmb * mb, requires_grad=False, device=self.device)
+                for k in self._KEYS:
+                    torch.index_select(self._flat[k], 0, indices, out=self._perm[k])
+            self._permute = CapturedStep(permute, enabled=self._capture, warmup=2, name="PPO rollout permutation", optional=True)
+        self._permute()
         for _ in range(self.num_learning_epochs):
             for i in range(nmb):
                 self._graph[i]()
