@@ -431,6 +431,22 @@ __global__ void go2_finish_kernel(Go2DevBlock* blk, int counter_inc, float* info
     if (cnt > 0.f) info[i] = i < GO2_NUM_REWARDS ? accum[i] / cnt / blk->L.episode_length_s : cnt;
     accum[i] = 0.f;
   }
+  if (cnt > 0.f) {      // terrain_level_all / terrain_level_<kind> (legged_robot.py:231-237): written by reset_idx only, i.e. in passes that reset an env
+    __shared__ float lsum[GO2_NUM_TERRAIN_KINDS + 1], lcnt[GO2_NUM_TERRAIN_KINDS + 1];
+    if (i <= GO2_NUM_TERRAIN_KINDS) { lsum[i] = 0.f; lcnt[i] = 0.f; }
+    __syncthreads();
+    if (blk->L.terrain_mode != 0) {
+      const int N = blk->L.N;
+      for (int e = i; e < N; e += blockDim.x) {
+        const float lv = (float)blk->p.terrain_levels[e]; const int kd = blk->p.terrain_kind[e];
+        atomicAdd(&lsum[0], lv); atomicAdd(&lcnt[0], 1.f);
+        if (kd >= 0 && kd < GO2_NUM_TERRAIN_KINDS) { atomicAdd(&lsum[1 + kd], lv); atomicAdd(&lcnt[1 + kd], 1.f); }
+      }
+    }
+    __syncthreads();
+    if (i <= GO2_NUM_TERRAIN_KINDS)
+      info[GO2_NUM_REWARDS + 3 + i] = blk->L.terrain_mode == 0 ? (i == 0 ? 0.f : __uint_as_float(0x7fc00000u)) : (lcnt[i] > 0.f ? lsum[i] / lcnt[i] : __uint_as_float(0x7fc00000u));
+  }
   if (i == 0) {
     accum[GO2_NUM_REWARDS + 1] = 0.f;
     go2_track_cmd_curriculum(blk->L, blk->dyn, cnt, track, cb, blk->dyn.common_step_counter + counter_inc, info + GO2_NUM_REWARDS + 1);
@@ -1065,6 +1081,11 @@ static void emu_run(Go2Sim* s, int mode, const float* actions_in, int initial_re
     const float track = acc[GO2_REW_TRACKING_LIN_VEL], cb = acc[GO2_NUM_REWARDS + 1];
     for (int i = 0; i <= GO2_NUM_REWARDS; ++i) { if (cnt > 0.f) p.episode_info[i] = i < GO2_NUM_REWARDS ? acc[i] / cnt / L.episode_length_s : cnt; acc[i] = 0.f; }
     acc[GO2_NUM_REWARDS + 1] = 0.f;
+    if (cnt > 0.f) {      // terrain_level_* (:231-237)
+      double ls[GO2_NUM_TERRAIN_KINDS + 1] = {0}, lc[GO2_NUM_TERRAIN_KINDS + 1] = {0};
+      if (L.terrain_mode != 0) for (int e = 0; e < L.N; ++e) { const double lv = (double)p.terrain_levels[e]; const int kd = p.terrain_kind[e]; ls[0] += lv; lc[0] += 1; if (kd >= 0 && kd < GO2_NUM_TERRAIN_KINDS) { ls[1 + kd] += lv; lc[1 + kd] += 1; } }
+      for (int k = 0; k <= GO2_NUM_TERRAIN_KINDS; ++k) p.episode_info[GO2_NUM_REWARDS + 3 + k] = L.terrain_mode == 0 ? (k == 0 ? 0.f : NAN) : (lc[k] > 0 ? (float)(ls[k] / lc[k]) : NAN);
+    }
     go2_track_cmd_curriculum(L, blk->dyn, cnt, track, cb, blk->dyn.common_step_counter + counter_inc, p.episode_info + GO2_NUM_REWARDS + 1);
     blk->dyn.common_step_counter += counter_inc; blk->dyn.step_count += 1; blk->dyn.use_injected = 0;
     if (outs.episode_info_out) memcpy(outs.episode_info_out, p.episode_info, sizeof(float) * GO2_EPISODE_INFO_LEN);
@@ -1093,7 +1114,7 @@ static int launch(Go2Sim* s, int mode, const float* actions_in, int initial_rese
   else if (mode == MODE_PHYS) hipLaunchKernelGGL(go2_step_kernel<MODE_PHYS>, grid, block, 0, st, s->d_blk, actions_in, initial_reset, outs);
   else hipLaunchKernelGGL(go2_step_kernel<MODE_POST>, grid, block, 0, st, s->d_blk, actions_in, initial_reset, outs);
   if (timed) { HIPCHK(hipEventRecord(s->ev[s->ev_used + 1], st)); s->ev_used += 2; }
-  if (mode != MODE_PHYS) hipLaunchKernelGGL(go2_finish_kernel, dim3(1), dim3(64), 0, st, s->d_blk, counter_inc, outs.episode_info_out);
+  if (mode != MODE_PHYS) hipLaunchKernelGGL(go2_finish_kernel, dim3(1), dim3(256), 0, st, s->d_blk, counter_inc, outs.episode_info_out);
   HIPCHK(hipGetLastError());
 #endif
   if (mode != MODE_PHYS && !capturing) { s->h.dyn.common_step_counter += counter_inc; s->h.dyn.step_count += 1; s->h.dyn.use_injected = 0; }   // host mirror

@@ -294,14 +294,11 @@ class LeggedRobot(BaseTask):
                 self.terrain_ids = self.terrain_cols2id[self.terrain_types]
             self.max_terrain_level = self.cfg.terrain.num_rows
             self.terrain_origins = torch.from_numpy(org).to(dev)
-            # extras terrain_level_<name> (:230-235): one [groups, N] membership matrix, applied to terrain_levels per step
-            names = list(self.terrain.name2cols)
-            member = torch.zeros(len(names) + 1, self.num_envs, **f32)
-            member[0] = 1.0
-            for k, name in enumerate(names):
-                cols = torch.tensor(sorted(self.terrain.name2cols[name]), dtype=torch.long, device=dev)
-                member[k + 1] = torch.isin(self.terrain_types, cols).float()
-            self._level_groups = (["all"] + names, member / member.sum(dim=1, keepdim=True))     # 0/0 -> nan like the reference's empty mean
+            # extras terrain_level_<name> (:230-237): the library keeps the mean level of all envs and of the envs on each terrain KIND as of
+            # the latest pass that reset an env (episode_info[NUM_REWARDS + 3 ..]); a name of name2cols is a kind (utils/terrain.py KIND_NAMES)
+            from ...utils.terrain import KIND_NAMES
+            nr = self.abi.GO2_NUM_REWARDS
+            self._level_groups = [("all", nr + 3)] + [(name, nr + 4 + KIND_NAMES.index(name)) for name in self.terrain.name2cols]
         self.add_noise = self.cfg.noise.add_noise
 
     # the runner REPLACES this attribute (on_policy_runner.py:118): copy into the library's buffer instead
@@ -405,9 +402,7 @@ class LeggedRobot(BaseTask):
         if self._level_groups is None:
             ep = {"terrain_level_all": 0.0}
         else:
-            names_l, member = self._level_groups
-            lv = torch.mv(member.nan_to_num(0.0), self.terrain_levels.float()) + (member[:, 0] * 0.0)   # nan rows stay nan
-            ep = {"terrain_level_" + n: lv[k] for k, n in enumerate(names_l)}
+            ep = {"terrain_level_" + n: slot[k] for n, k in self._level_groups}
         for i in self._active_idx:
             ep["rew_" + names[i]] = slot[i]
         if self.cfg.commands.curriculum:

@@ -77,7 +77,8 @@ enum {
   GO2_REW_TERMINATION,          /* :1281, added after the positive clip (:271-274) */
   GO2_NUM_REWARDS
 };
-#define GO2_EPISODE_INFO_LEN (GO2_NUM_REWARDS + 3)   /* Go2SimBuffers.episode_info */
+#define GO2_NUM_TERRAIN_KINDS 9   /* wave, slope, rough slope, stairs up, stairs down, obstacles, stepping stones, gap, flat (go2_config.py:129-139) */
+#define GO2_EPISODE_INFO_LEN (GO2_NUM_REWARDS + 13)   /* Go2SimBuffers.episode_info */
 
 /* Per-env per-step uniform slots.  In normal operation each slot is Philox4x32-10(key = seed,
  * counter = {global env id, slot/4, step_lo, step_hi})[slot%4] mapped to [0,1); in test mode
@@ -190,7 +191,7 @@ typedef struct Go2SimCfg {
   float    cmd_ranges[4][2];        /* lin_vel_x, lin_vel_y, ang_vel_yaw, heading (go2_config.py:142-146) */
   int32_t  cmd_curriculum_count;    /* command_range_curriculum entries (:433-446) */
   float    cmd_curriculum[4][9];    /* {iter, x0,x1, y0,y1, yaw0,yaw1, h0,h1} */
-  float    terrain_max_cmd_ranges[9][4][2]; /* per terrain kind (go2_config.py:129-139) */
+  float    terrain_max_cmd_ranges[GO2_NUM_TERRAIN_KINDS][4][2]; /* per terrain kind (go2_config.py:129-139) */
   int32_t  cmd_tracking_curriculum; /* commands.curriculum (legged_robot_config.py:44; off in every go2 config): update_command_curriculum
                                      * (legged_robot.py:728-737) widens command_ranges['lin_vel_x'] by 0.5 per reset step whose mean
                                      * tracking_lin_vel episode sum exceeds 80 % of the maximum.  In this fork that list only feeds
@@ -286,8 +287,10 @@ typedef struct Go2SimBuffers {
   float*   added_base_com;     /* [N,3] */
   float*   link_mass_ratio;    /* [N,18] */
   /* extras["episode"] (legged_robot.py:229-242): mean over the envs reset in the latest step that
-   * had >= 1 reset, divided by max_episode_length_s; [GO2_NUM_REWARDS + 3]: then the number of envs reset in that step, then
-   * command_ranges['lin_vel_x'] (lo, hi) as update_command_curriculum keeps it (extras['episode']['max_command_x'] = hi, :241-242). */
+   * had >= 1 reset, divided by max_episode_length_s; then [GO2_NUM_REWARDS] the number of envs reset in that step, [+1, +2]
+   * command_ranges['lin_vel_x'] (lo, hi) as update_command_curriculum keeps it (extras['episode']['max_command_x'] = hi, :241-242),
+   * [+3] terrain_level_all = mean(terrain_levels) and [+4 + k] the mean level of the envs on terrain kind k (NaN if none), all as of that
+   * same step (:231-237: written by reset_idx only; 0 / NaN on a plane).  GO2_EPISODE_INFO_LEN floats. */
   float*   episode_info;
   /* warm-start impulses of the 4 foot contacts */
   float*   foot_impulse;       /* [N,4,3] */

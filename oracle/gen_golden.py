@@ -150,7 +150,20 @@ def gen_env_sequence(N=16, T=64, seed=7, mesh_type="plane", turn_over=False, ove
                            "time_out", "commands", "cmd_timer", "cmd_xy_acc", "last_is_limit_vel", "ep_len", "episode_sums",
                            "root_out", "dof_out", "last_actions", "last_last_actions", "last_dof_vel", "base_lin_vel", "base_ang_vel",
                            "projected_gravity", "rpy", "motor_strengths", "motor_zero_offsets", "p_gains_multiplier", "d_gains_multiplier",
-                           "max_move_distance", "episode_info", "episode_info_valid", "ep_len_in", "cmd_timer_in", "max_move_in", "terrain_levels", "env_origins_out", "measured_heights", "turn_over_timer")}
+                           "max_move_distance", "episode_info", "episode_info_valid", "terrain_level_info", "ep_len_in", "cmd_timer_in", "max_move_in", "terrain_levels", "env_origins_out", "measured_heights", "turn_over_timer")}
+
+    KINDS = ("wave", "slope", "rough_slope", "stairs_up", "stairs_down", "obstacles", "stepping_stones", "gap", "flat")
+
+    def level_info():
+        """extras['episode']['terrain_level_all'] and ['terrain_level_<name>'] (legged_robot.py:231-237) -> [all, 9 kinds]; NaN where the reference
+        has no such entry (a terrain name that does not occur) or its group is empty"""
+        ep = env.extras["episode"]
+        out = np.full(10, np.nan, np.float32)
+        out[0] = float(ep["terrain_level_all"])
+        for k, nm in enumerate(KINDS):
+            if "terrain_level_" + nm in ep:
+                out[1 + k] = float(ep["terrain_level_" + nm])
+        return out
 
     def snapshot(t_extras_rebuilt):
         rec["obs"].append(env.obs_buf.numpy().copy()); rec["priv"].append(env.privileged_obs_buf.numpy().copy())
@@ -179,6 +192,7 @@ def gen_env_sequence(N=16, T=64, seed=7, mesh_type="plane", turn_over=False, ove
             for n, i in rew_index.items():
                 info[i] = float(env.extras["episode"]["rew_" + n])
         rec["episode_info"].append(info); rec["episode_info_valid"].append(np.uint8(t_extras_rebuilt))
+        rec["terrain_level_info"].append(level_info() if t_extras_rebuilt else np.full(10, np.nan, np.float32))
 
     def new_table():
         return rng.uniform(0, 1, (N, NU)).astype(np.float32)
@@ -279,7 +293,7 @@ def gen_env_sequence(N=16, T=64, seed=7, mesh_type="plane", turn_over=False, ove
     es = np.zeros((ABI.GO2_NUM_REWARDS, N), np.float32); info = np.zeros(ABI.GO2_NUM_REWARDS, np.float32)
     for n_, i_ in rew_index.items():
         es[i_] = env.episode_sums[n_].numpy(); info[i_] = float(env.extras["episode"]["rew_" + n_])
-    ri["episode_sums"] = es; ri["episode_info"] = info
+    ri["episode_sums"] = es; ri["episode_info"] = info; ri["terrain_level_info"] = level_info()
     if track_curr:
         ri["cmd_x_range"] = np.array([float(env.command_ranges["lin_vel_x"][0]), float(env.command_ranges["lin_vel_x"][1])], np.float32)
     fig.INJECT.table = None

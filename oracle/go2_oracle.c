@@ -939,6 +939,10 @@ static void finish_episode_info(Go2Sim* s) { /* extras["episode"] (:229-242) */
   if (s->ep_count > 0) {
     for (int t=0;t<GO2_NUM_REWARDS;++t) s->b.episode_info[t] = (float)(s->ep_sum[t]/s->ep_count/(double)s->cfg.episode_length_s);
     s->b.episode_info[GO2_NUM_REWARDS] = (float)s->ep_count;
+    { /* terrain_level_all / terrain_level_<name> (:231-237): mean level of all envs / of the envs on each terrain kind, NaN for an empty group */
+      double ls[GO2_NUM_TERRAIN_KINDS+1] = {0}, lc[GO2_NUM_TERRAIN_KINDS+1] = {0};
+      if (s->cfg.terrain_mode != 0) for (int e=0;e<s->N;++e) { double lv=(double)s->b.terrain_levels[e]; int kd=s->terrain_kind[e]; ls[0]+=lv; lc[0]+=1; if (kd>=0 && kd<GO2_NUM_TERRAIN_KINDS) { ls[1+kd]+=lv; lc[1+kd]+=1; } }
+      for (int k=0;k<=GO2_NUM_TERRAIN_KINDS;++k) s->b.episode_info[GO2_NUM_REWARDS+3+k] = s->cfg.terrain_mode == 0 ? (k==0 ? 0.0f : (float)NAN) : (lc[k]>0 ? (float)(ls[k]/lc[k]) : (float)NAN); }
   }
   /* The Python list command_ranges['lin_vel_x'] (the reference works on whole batches: callback for all envs, then reset_idx for all
    * reset envs).  Every _resample_commands call with >= 1 env replaces it when a new command_range_curriculum stage has started

@@ -220,8 +220,10 @@ def compare_step(s, g, t):
     if g["episode_info_valid"][t]:
         n = len(g["episode_info"][t])
         np.testing.assert_allclose(s.episode_info[:n], g["episode_info"][t], atol=1e-6, rtol=1e-4)
+        if "terrain_level_info" in g:     # extras['episode']['terrain_level_all' | 'terrain_level_<name>'] (:231-237); NaN = the reference has no such group / an empty one
+            np.testing.assert_allclose(np.asarray(s.episode_info)[n + 3:n + 13], g["terrain_level_info"][t], atol=1e-6, equal_nan=True, err_msg="terrain levels at step %d" % t)
     if "cmd_x_range" in g:          # command_ranges['lin_vel_x'] under update_command_curriculum / a stage start (:728-737, :433-446)
-        np.testing.assert_array_equal(np.asarray(s.episode_info)[-2:], g["cmd_x_range"][t], err_msg="command_ranges['lin_vel_x'] after step %d" % t)
+        np.testing.assert_array_equal(np.asarray(s.episode_info)[n + 1:n + 3] if g["episode_info_valid"][t] else np.asarray(s.episode_info)[len(g["episode_info"][t]) + 1:len(g["episode_info"][t]) + 3], g["cmd_x_range"][t], err_msg="command_ranges['lin_vel_x'] after step %d" % t)
 
 
 def compare_reset_idx(s, g):
@@ -253,8 +255,10 @@ def compare_reset_idx(s, g):
     n = len(g["reset_idx_episode_info"])
     np.testing.assert_allclose(s.episode_info[:n], g["reset_idx_episode_info"], atol=1e-6, rtol=1e-4)
     assert s.episode_info[n] == len(ids)
+    if "reset_idx_terrain_level_info" in g:
+        np.testing.assert_allclose(np.asarray(s.episode_info)[n + 3:n + 13], g["reset_idx_terrain_level_info"], atol=1e-6, equal_nan=True)
     if "reset_idx_cmd_x_range" in g:
-        np.testing.assert_array_equal(np.asarray(s.episode_info)[-2:], g["reset_idx_cmd_x_range"])
+        np.testing.assert_array_equal(np.asarray(s.episode_info)[n + 1:n + 3], g["reset_idx_cmd_x_range"])
 
 
 def _libs():

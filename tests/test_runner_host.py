@@ -195,5 +195,5 @@ def test_fused_rollout_step_fills_the_same_storage(tmp_path, monkeypatch, task):
         env.close()
     for k in res["0"]:
         if torch.is_tensor(res["0"][k]):
-            assert torch.equal(res["0"][k], res["1"][k]), k
+            assert torch.equal(res["0"][k].float().nan_to_num(-7.0), res["1"][k].float().nan_to_num(-7.0)), k      # (NaN = terrain kinds without envs)
     assert res["0"]["dones"].sum() > 0

@@ -176,6 +176,7 @@ def test_rough_task_through_the_host_layer():
     np.testing.assert_array_equal(env.terrain_ids.numpy(), np.array(env.terrain.cols2id)[env.terrain_types.numpy()])
     np.testing.assert_allclose(env.env_origins.numpy(), env.terrain_origins.numpy()[env.terrain_levels.numpy(), env.terrain_types.numpy()])
     a = torch.zeros(40, 12)
+    env.reset()                                   # (extras['episode'] is written by reset_idx only, legged_robot.py:229-237)
     for _ in range(5):
         obs, priv, rew, done, extras = env.step(a)
     ep = extras["episode"]
