@@ -432,17 +432,27 @@ __global__ void go2_finish_kernel(Go2DevBlock* blk, int counter_inc, float* info
     accum[i] = 0.f;
   }
   if (cnt > 0.f) {      // terrain_level_all / terrain_level_<kind> (legged_robot.py:231-237): written by reset_idx only, i.e. in passes that reset an env
-    __shared__ float lsum[GO2_NUM_TERRAIN_KINDS + 1], lcnt[GO2_NUM_TERRAIN_KINDS + 1];
-    if (i <= GO2_NUM_TERRAIN_KINDS) { lsum[i] = 0.f; lcnt[i] = 0.f; }
-    __syncthreads();
+    // per-thread sums in registers (levels are small integers: exact in fp32, order-free), wave shuffles, then one LDS slot per wave
+    __shared__ float lsum[GO2_NUM_TERRAIN_KINDS + 1], lcnt[GO2_NUM_TERRAIN_KINDS + 1], wsum[4][GO2_NUM_TERRAIN_KINDS + 1], wcnt[4][GO2_NUM_TERRAIN_KINDS + 1];
+    float ps[GO2_NUM_TERRAIN_KINDS + 1], pc[GO2_NUM_TERRAIN_KINDS + 1];
+#pragma unroll
+    for (int k = 0; k <= GO2_NUM_TERRAIN_KINDS; ++k) { ps[k] = 0.f; pc[k] = 0.f; }
     if (blk->L.terrain_mode != 0) {
       const int N = blk->L.N;
       for (int e = i; e < N; e += blockDim.x) {
         const float lv = (float)blk->p.terrain_levels[e]; const int kd = blk->p.terrain_kind[e];
-        atomicAdd(&lsum[0], lv); atomicAdd(&lcnt[0], 1.f);
-        if (kd >= 0 && kd < GO2_NUM_TERRAIN_KINDS) { atomicAdd(&lsum[1 + kd], lv); atomicAdd(&lcnt[1 + kd], 1.f); }
+        ps[0] += lv; pc[0] += 1.f;
+#pragma unroll
+        for (int k = 0; k < GO2_NUM_TERRAIN_KINDS; ++k) { const bool in = kd == k; ps[1 + k] += in ? lv : 0.f; pc[1 + k] += in ? 1.f : 0.f; }
       }
     }
+#pragma unroll
+    for (int k = 0; k <= GO2_NUM_TERRAIN_KINDS; ++k) {
+      for (int o = 32; o > 0; o >>= 1) { ps[k] += __shfl_down(ps[k], o); pc[k] += __shfl_down(pc[k], o); }
+      if ((i & 63) == 0 && (i >> 6) < 4) { wsum[i >> 6][k] = ps[k]; wcnt[i >> 6][k] = pc[k]; }
+    }
+    __syncthreads();
+    if (i <= GO2_NUM_TERRAIN_KINDS) { lsum[i] = (wsum[0][i] + wsum[1][i]) + (wsum[2][i] + wsum[3][i]); lcnt[i] = (wcnt[0][i] + wcnt[1][i]) + (wcnt[2][i] + wcnt[3][i]); }
     __syncthreads();
     if (i <= GO2_NUM_TERRAIN_KINDS)
       info[GO2_NUM_REWARDS + 3 + i] = blk->L.terrain_mode == 0 ? (i == 0 ? 0.f : __uint_as_float(0x7fc00000u)) : (lcnt[i] > 0.f ? lsum[i] / lcnt[i] : __uint_as_float(0x7fc00000u));
