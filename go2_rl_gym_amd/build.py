@@ -35,6 +35,7 @@ def hipcc_path():
     raise RuntimeError("hipcc not found (need ROCm): the HIP library is the only compute path of this package")
 
 
+KBENCH_OUT = os.path.join(ROOT, "tests", "emu", "libgo2sim_hip_kbench.so")
 PRECISE_OUT = os.path.join(ROOT, "tests", "emu", "libgo2sim_hip_precise.so")
 
 
@@ -42,6 +43,11 @@ def build_hip_precise(force=False):
     """TEST-ONLY second device build of the same source without -ffast-math (IEEE division / sqrt / no reassociation), next to the host
     emulation under tests/emu/: tests/test_gpu_parity.py uses it to separate fast-math artefacts from fp32 conditioning."""
     return build_hip(force=force, out=PRECISE_OUT, flags=list(STRUCTURAL_FLAGS))
+
+
+def build_hip_kbench(force=False):
+    """TOOL-ONLY device build with the per-wave phase timestamps compiled in (tools/kbench.py, go2sim_debug_clock); the product build carries none."""
+    return build_hip(force=force, out=KBENCH_OUT, flags=EXTRA_FLAGS + ["-DGO2_KBENCH_STAMPS"])
 
 
 def build_hip(force=False, verbose=False, out=OUT, flags=None):

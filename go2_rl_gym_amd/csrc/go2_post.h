@@ -378,8 +378,8 @@ struct LegPost {
   }
   float own_f2b, own_fvel2, rpy[3], max_move, org_x, org_y, org_z; int64_t tlevel, ttype;
   bool skip_contact_filters;                   // reset_all runs postB without a postA: nothing to carry over
-#if defined(__HIP_DEVICE_COMPILE__)
-  long long* dbg;                              // optional per-wave phase timestamps (tools/kbench.py), null in normal operation
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GO2_KBENCH_STAMPS)
+  long long* dbg;                              // per-wave phase timestamps: only in the tools/kbench.py build (-DGO2_KBENCH_STAMPS)
 #define GO2_POST_STAMP(k) do { if (dbg && (lane16 == 0) && ((e & 3) == 0)) dbg[k] = wall_clock64(); } while (0)
 #else
 #define GO2_POST_STAMP(k) do { } while (0)

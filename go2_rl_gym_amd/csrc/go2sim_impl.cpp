@@ -192,7 +192,7 @@ GO2_HD void lane_load_physout(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK&
 GO2_HD void lane_init_post(LANE_PARAMS, const GO2_AS3 uint8_t* codes, GO2_AS3 float (*uc)[4], const Go2PtrsK* p, const Go2Launch* L, const Go2Step* S, int e, int lane, int sub) {
   po_.codes = codes; po_.uc = uc;
   po_.e = e; po_.lane = lane; po_.sub = sub; po_.lane16 = lane * 4 + sub; po_.N = L->N; po_.P = p; po_.L = L; po_.S = S;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GO2_KBENCH_STAMPS)
   po_.dbg = nullptr;
 #endif
   po_.skip_contact_filters = false; po_.api_reset = false; po_.yaw_seen = false; po_.out = Go2StepOutputs{}; po_.new_lc = po_.new_lc2 = 0; po_.new_fat = 0.f;
@@ -256,7 +256,7 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
   }
   const int e = bid * GO2_WG_ENVS + (tid >> 4), lane = (tid >> 2) & 3, sub = tid & 3;
   if (e >= L.N) return;   // whole rows (environments) leave together
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GO2_KBENCH_STAMPS)
   long long* dbg = p.dbg_clock ? (long long*)p.dbg_clock + (size_t)(bid * 4 + (tid >> 6)) * 32 : nullptr;   // optional phase timestamps per wave (tools/kbench.py)
 #define STAMP(k) do { if (dbg && (tid & 63) == 0) dbg[k] = wall_clock64(); } while (0)
 #else
@@ -344,7 +344,7 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
     GO2_MARK(21);
     lane_init_post(ph_, po_, ax, (const GO2_AS3 uint8_t*)tab.slot_code, uc, &p, &L, &S, e, lane, sub);
     po_.yaw_seen = yaw_seen; po_.out = outs;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GO2_KBENCH_STAMPS)
     po_.dbg = dbg;
 #endif
     float part[GO2_POST_PARTIALS];

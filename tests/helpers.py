@@ -291,6 +291,14 @@ def load_hip():
     return _lib.load_hip()
 
 
+def load_hip_kbench():
+    """The device library with the per-wave phase timestamps compiled in (build.py:build_hip_kbench) — tools/kbench.py only."""
+    from go2_rl_gym_amd import _lib, build  # noqa: F401  (imports torch first)
+    lib = _abi.bind(build.build_hip_kbench(), C.c_float)
+    assert lib.go2sim_is_device_library() == 1
+    return lib
+
+
 def load_hip_precise():
     """The device library built WITHOUT -ffast-math (go2_rl_gym_amd/build.py:build_hip_precise): a TEST-ONLY second build of the same
     source, used to show which parity differences are fast-math artefacts and which are not.  Never loaded by the product."""

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch
-from helpers import DeviceSim, load_hip
+from helpers import DeviceSim, load_hip, load_hip_kbench
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 hip = load_hip()
@@ -63,7 +63,9 @@ if __name__ == "__main__":
 
 
 def phase_clocks(steps=50, **kw):
-    """Per-wave phase timestamps (wall_clock64, 100 MHz) of the fused kernel: mean and max over the waves."""
+    """Per-wave phase timestamps (wall_clock64, 100 MHz) of the fused kernel: mean and max over the waves.  Uses the STAMPED build of the
+    library (build.py:build_hip_kbench, -DGO2_KBENCH_STAMPS); the timings above are of the product build, which carries no stamps."""
+    hip = load_hip_kbench()
     s = DeviceSim(hip, num_envs=N, **kw)
     s.reset_all()
     a = torch.randn(N, 12, device="cuda:0") * 0.5
