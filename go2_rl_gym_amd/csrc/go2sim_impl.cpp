@@ -439,11 +439,17 @@ __global__ void go2_finish_kernel(Go2DevBlock* blk, int counter_inc, float* info
     for (int k = 0; k <= GO2_NUM_TERRAIN_KINDS; ++k) { ps[k] = 0.f; pc[k] = 0.f; }
     if (blk->L.terrain_mode != 0) {
       const int N = blk->L.N;
-      for (int e = i; e < N; e += blockDim.x) {
-        const float lv = (float)blk->p.terrain_levels[e]; const int kd = blk->p.terrain_kind[e];
-        ps[0] += lv; pc[0] += 1.f;
+      for (int e0 = i; e0 < N; e0 += 8 * (int)blockDim.x) {      // 8 environments per thread and trip: all 16 loads in flight before the first use
+        long long lv8[8]; int kd8[8];
 #pragma unroll
-        for (int k = 0; k < GO2_NUM_TERRAIN_KINDS; ++k) { const bool in = kd == k; ps[1 + k] += in ? lv : 0.f; pc[1 + k] += in ? 1.f : 0.f; }
+        for (int u = 0; u < 8; ++u) { const int e = e0 + u * (int)blockDim.x; lv8[u] = e < N ? blk->p.terrain_levels[e] : 0; kd8[u] = e < N ? blk->p.terrain_kind[e] : -2; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float lv = (float)lv8[u]; const int kd = kd8[u];
+          ps[0] += kd != -2 ? lv : 0.f; pc[0] += kd != -2 ? 1.f : 0.f;
+#pragma unroll
+          for (int k = 0; k < GO2_NUM_TERRAIN_KINDS; ++k) { const bool in = kd == k; ps[1 + k] += in ? lv : 0.f; pc[1 + k] += in ? 1.f : 0.f; }
+        }
       }
     }
 #pragma unroll

@@ -110,8 +110,8 @@ class CTS(_RolloutHeads):
     # ------------------------------------------------------------------ rollout half (:112-166), env order
     def _latent_env_order(self, privileged_obs, history):
         m, ti, si = self.model, self.teacher_env_idxs, self.student_env_idxs
-        lt = m.teacher_encoder(privileged_obs[ti])
-        ls = m.student_latent(history[si])[0]
+        # the two encoders are independent: on two HIP streams in the captured rollout (they are launch-bound chains of small kernels)
+        lt, ls = self._pair(lambda: m.teacher_encoder(privileged_obs[ti]), lambda: m.student_latent(history[si])[0], enabled=self._capture)
         latent = torch.empty(privileged_obs.shape[0], lt.shape[1], device=lt.device, dtype=lt.dtype)
         latent.index_copy_(0, ti, lt.detach())
         latent.index_copy_(0, si, ls.detach())
