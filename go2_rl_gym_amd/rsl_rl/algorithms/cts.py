@@ -167,7 +167,7 @@ class CTS(_RolloutHeads):
     def _policy_losses(self, obs_b, priv_b, hist_b, act_b, tv_b, adv_b, ret_b, old_lp_b, old_mu_b, old_sig_b, n_t):
         """-> loss, value_loss, surrogate_loss, entropy_mean, kl_mean   (rows [0,n_t) teacher, the rest student)"""
         m = self.model
-        latent = m.latents(priv_b, hist_b, n_t)
+        latent = m.latents(priv_b, hist_b, n_t, pair=(lambda f, g: self._pair(f, g, enabled=self._capture)))
         if self.fused_loss:
             mu_b, (val_b, aux) = self._pair(lambda: m.policy_mean(latent, obs_b), lambda: m.value(latent, obs_b, priv_b), enabled=self._capture and not m.heads_share_parameters)
             self.surrogate_split = n_t

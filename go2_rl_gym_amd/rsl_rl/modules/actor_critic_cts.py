@@ -126,10 +126,13 @@ class ActorCriticCTS(nn.Module):
         return self.value(latent, None, privileged_obs)[0]
 
     # -- whole-batch surface: rows [0, n_teacher) are teacher rows, the rest student rows --------------------
-    def latents(self, privileged_obs, history, n_teacher):
-        lt = self.teacher_encoder(privileged_obs[:n_teacher])
-        with torch.no_grad():                                          # the policy loss never reaches the student encoder (:145), and its
-            ls = self.student_latent(history[n_teacher:])[0]           # parameters are not in optimizer1: no activations kept for a backward
+    def latents(self, privileged_obs, history, n_teacher, pair=None):
+        """pair (optional): callable (f, g) -> (f(), g()) that may run g on a second stream (the two encoders are independent chains)."""
+        def student():
+            with torch.no_grad():                                      # the policy loss never reaches the student encoder (:145), and its
+                return self.student_latent(history[n_teacher:])[0]     # parameters are not in optimizer1: no activations kept for a backward
+        teacher = lambda: self.teacher_encoder(privileged_obs[:n_teacher])
+        lt, ls = pair(teacher, student) if pair is not None else (teacher(), student())
         return torch.cat([lt, ls], dim=0)
 
     def act_joint(self, obs, latent):
