@@ -172,3 +172,32 @@ def check_step_rollout(lib, sim, n):
             np.testing.assert_array_equal(np.asarray(getattr(a_, k)), np.asarray(getattr(b_, k)), err_msg=k)
     assert seen_to > 0
     a_.close(); b_.close()
+
+
+def test_reset_idx_subsets_against_the_oracle():
+    """go2sim_reset_idx over random subsets (duplicates, out-of-range ids, the empty list, every env) on ragged batch sizes: the lane programs'
+    masked reset pass equals the oracle's per-env reset, and nothing outside the listed envs moves."""
+    rng = np.random.default_rng(4)
+    for n in (1, 5, 16, 37):
+        so, se = HostSim(load_oracle(), num_envs=n, seed=3), HostSim(load_emu(), num_envs=n, seed=3)
+        so.reset_all(); se.reset_all()
+        a = rng.normal(0, 1, (n, 12)).astype(np.float32)
+        for _ in range(3):
+            so.step(a); se.step(a)
+        for k in STEP_STATE:
+            getattr(se, k)[...] = getattr(so, k)
+        for trial in range(4):
+            ids = [np.array([], np.int32), np.arange(n, dtype=np.int32), rng.integers(0, n, max(n // 2, 1)).astype(np.int32),
+                   np.concatenate([rng.integers(0, n, 2), [n + 3, -1]]).astype(np.int32)][trial]
+            before = {k: np.asarray(getattr(se, k)).copy() for k in ("root_states", "dof_state", "obs_buf", "episode_length_buf", "commands")}
+            so.reset_idx(ids); se.reset_idx(ids)
+            hit = np.zeros(n, bool); hit[ids[(ids >= 0) & (ids < n)]] = True
+            for k in ("root_states", "dof_state", "commands", "motor_strengths", "p_gains_multiplier", "commands_resampling_step"):
+                np.testing.assert_allclose(np.asarray(getattr(so, k)), np.asarray(getattr(se, k)), atol=2e-6, err_msg="%s n=%d trial=%d" % (k, n, trial))
+            np.testing.assert_array_equal(np.asarray(so.episode_length_buf), np.asarray(se.episode_length_buf))
+            np.testing.assert_array_equal(np.asarray(se.obs_buf), before["obs_buf"])
+            for k in ("root_states", "dof_state", "episode_length_buf", "commands"):
+                np.testing.assert_array_equal(np.asarray(getattr(se, k))[~hit], before[k][~hit], err_msg="untouched envs: " + k)
+            if hit.any():
+                assert (np.asarray(se.episode_length_buf)[hit] == 0).all() and (np.asarray(se.reset_buf)[hit] == 1).all()
+        so.close(); se.close()
