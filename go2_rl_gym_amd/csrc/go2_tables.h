@@ -114,7 +114,8 @@ struct Go2Launch {
 // enqueue (HIP-graph replayable): nothing the host computes per step is baked into kernel arguments
 struct Go2Dyn { uint64_t step_count; int64_t common_step_counter; int32_t use_injected;
                 int32_t cmd_stage_seen;   // command_range_curriculum stage whose lin_vel_x the tracked list was last set from (-2: none yet)
-                float cmd_x_range[2]; };  // command_ranges['lin_vel_x'] as update_command_curriculum (:728-737) keeps it
+                float cmd_x_range[2];     // command_ranges['lin_vel_x'] as update_command_curriculum (:728-737) keeps it
+                int32_t cb_any, pad2; };  // heading_command only: some env of the batch is resampled by the coming step's callback (go2_cb_scan_kernel)
 
 // per-step scalars (what the reference keeps as Python floats), recomputed by every workgroup from
 // Go2Dyn.common_step_counter into LDS: they are pure functions of counter // num_steps_per_env
@@ -127,7 +128,8 @@ struct Go2Step {
   // resampled commands themselves therefore always see the stage of the current iteration (cmd_ranges above); the heading controller's clip
   // (:411-419), which runs for every env right after the callback's _resample_commands, sees the new stage only if SOME env of the batch was
   // resampled by the callback in this step.  stage_pending: a stage has started that no _resample_commands call has picked up yet
-  // (heading_command only) -> the workgroup scans the batch's command timers; yaw_range_seen: ang_vel_yaw of the stage last picked up.
+  // (heading_command only) -> Go2Dyn.cb_any, scanned from the batch's command timers by a small kernel in FRONT of the step kernel (inside
+  // it, other workgroups would already be rewriting the timers); yaw_range_seen: ang_vel_yaw of the stage last picked up.
   int32_t stage_pending; float yaw_range_seen[2];
   uint32_t rew_mask;                 // bit t: reward term t is computed (Go2Launch.rew_on[t]); 0 during the initial reset
   uint32_t rew_mask_all;             // the same, also during the initial reset

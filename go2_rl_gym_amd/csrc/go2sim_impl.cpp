@@ -51,7 +51,6 @@ struct LaneAux { float kp[3], kd[3], q0[3], zoff[3], strength[3], act_new[3], ac
 // LDS: robot link / collision tables (per-lane leg index -> ds_read), this step's scalars, and per environment the table of drawn uniforms
 struct Go2Shared {
   Go2Tables tab; Go2Step S; float ucache[GO2_WG_ENVS][GO2_NUM_GROUPS][4];
-  int32_t cb_any;      // Go2Step.stage_pending: some env of the BATCH is resampled by this step's post-physics callback
 };
 
 GO2_HD void lane_load_phys(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p, const Go2Launch& L, const Go2Step& S, const float* actions_in, float u_delay, int e, int lane, int sub) {
@@ -238,7 +237,6 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(GO2_GENERIC(const Go2Tables*, p.tables)); uint32_t* dst = reinterpret_cast<uint32_t*>(&sh.tab);
     for (int i = tid; i < (int)(sizeof(Go2Tables) / 4); i += GO2_WG_THREADS) dst[i] = src[i];
-    if (tid == 0) sh.cb_any = 0;
     if (tid < GO2_STEP_SCALAR_PARTS) go2_step_scalars_part(tid, L, blk->dyn, GO2_GENERIC(const float*, p.inj_storage), blk->dyn.common_step_counter + ((MODE & MODE_POST) ? 1 : 0), initial_reset, &sh.S);
   }
   xl::sync();
@@ -246,14 +244,7 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
   asm volatile("" :: "v"(touch));
 #endif
   const Go2Tables& tab = sh.tab; const Go2Step& S = sh.S;
-  bool yaw_seen = false;
-  if ((MODE & MODE_POST) && S.stage_pending) {   // rare (the steps between the start of a command_range_curriculum stage and the next resample)
-    bool mine = false;                           // _post_physics_step_callback's resampling_env_ids (:408) over the whole batch
-    for (int i = tid; i < L.N; i += GO2_WG_THREADS) mine = mine || (p.cmd_timer[i] - 1.f <= 0.f && (float)(p.ep_len[i] + 1) < L.max_episode_length - 1.f);
-    if (mine) sh.cb_any = 1;
-    xl::sync();
-    yaw_seen = !sh.cb_any;
-  }
+  const bool yaw_seen = (MODE & MODE_POST) && S.stage_pending && !blk->dyn.cb_any;      // (rare: Go2Step.stage_pending)
   const int e = bid * GO2_WG_ENVS + (tid >> 4), lane = (tid >> 2) & 3, sub = tid & 3;
   if (e >= L.N) return;   // whole rows (environments) leave together
 #if defined(__HIP_DEVICE_COMPILE__) && defined(GO2_KBENCH_STAMPS)
@@ -421,6 +412,22 @@ __global__ void go2_strict_ops_kernel(const float* __restrict__ a, const float* 
   out[3 * (size_t)n + i] = go2_div_rn(a[i], b[i]); out[4 * (size_t)n + i] = go2_sqrt_rn(fabsf(a[i])); out[5 * (size_t)n + i] = go2_mul_inv_rn(a[i], inv_b0);
 }
 
+// heading_command only, in FRONT of a pass with post-physics: will _post_physics_step_callback's _resample_commands (:408-410) be called with
+// >= 1 env in this pass?  (It decides whether the heading clip already sees a command_range_curriculum stage that has just started.)
+__global__ void __launch_bounds__(256) go2_cb_scan_kernel(Go2DevBlock* blk) {
+  __shared__ int any;
+  if (threadIdx.x == 0) any = 0;
+  __syncthreads();
+  const Go2Launch& L = blk->L;
+  const int seen = blk->dyn.cmd_stage_seen < 0 ? -1 : blk->dyn.cmd_stage_seen;
+  if (go2_cmd_stage(L, (float)((blk->dyn.common_step_counter + 1) / L.num_steps_per_env)) != seen) {      // uniform
+    bool mine = false;
+    for (int i = threadIdx.x; i < L.N; i += 256) mine = mine || (blk->p.cmd_timer[i] - 1.f <= 0.f && (float)(blk->p.ep_len[i] + 1) < L.max_episode_length - 1.f);
+    if (mine) any = 1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) blk->dyn.cb_any = any;
+}
 // after a step: extras["episode"] means, then advance the device-resident counters
 __global__ void go2_finish_kernel(Go2DevBlock* blk, int counter_inc, float* info_out) {
   float* accum = blk->p.ep_accum; float* info = blk->p.episode_info;
@@ -1088,6 +1095,12 @@ static void emu_run(Go2Sim* s, int mode, const float* actions_in, int initial_re
   Go2DevBlock* blk = s->d_blk;
   const Go2Ptrs& p = blk->p; const Go2Launch& L = blk->L;
   static thread_local Go2Shared sh;
+  if ((mode & MODE_POST) && L.heading_command) {      // == go2_cb_scan_kernel
+    int any = 0; const int seen = blk->dyn.cmd_stage_seen < 0 ? -1 : blk->dyn.cmd_stage_seen;
+    if (go2_cmd_stage(L, (float)((blk->dyn.common_step_counter + 1) / L.num_steps_per_env)) != seen)
+      for (int i = 0; i < L.N && !any; ++i) any = p.cmd_timer[i] - 1.f <= 0.f && (float)(p.ep_len[i] + 1) < L.max_episode_length - 1.f;
+    blk->dyn.cb_any = any;
+  }
   for (int bid = 0; bid < (L.N + GO2_WG_ENVS - 1) / GO2_WG_ENVS; ++bid) {      // one workgroup at a time, its 256 threads as fibres
     EmuArgs a = {&sh, blk, actions_in, initial_reset, bid, mode, &outs};
     xl::run_group(GO2_WG_THREADS, emu_thread, &a);
@@ -1125,6 +1138,7 @@ static int launch(Go2Sim* s, int mode, const float* actions_in, int initial_rese
     if (s->ev_used + 2 > s->ev.size()) { size_t n0 = s->ev.size(); s->ev.resize(n0 + 512); for (size_t i = n0; i < s->ev.size(); ++i) HIPCHK(hipEventCreate(&s->ev[i])); }
     HIPCHK(hipEventRecord(s->ev[s->ev_used], st));
   }
+  if ((mode & MODE_POST) && s->h.L.heading_command) hipLaunchKernelGGL(go2_cb_scan_kernel, dim3(1), dim3(256), 0, st, s->d_blk);
   if (mode == MODE_RESET_ALL) hipLaunchKernelGGL(go2_step_kernel<MODE_RESET_ALL>, grid, block, 0, st, s->d_blk, actions_in, initial_reset, outs);
   else if (mode == (MODE_PHYS | MODE_POST)) hipLaunchKernelGGL(go2_step_kernel<MODE_PHYS | MODE_POST>, grid, block, 0, st, s->d_blk, actions_in, initial_reset, outs);
   else if (mode == MODE_PHYS) hipLaunchKernelGGL(go2_step_kernel<MODE_PHYS>, grid, block, 0, st, s->d_blk, actions_in, initial_reset, outs);
