@@ -127,8 +127,8 @@ def main():
 
     runner.learn(a.warmup, init_at_random_ep_len=True)        # untimed: also brings resets/pushes/resamples to steady state
     extra = 0
-    while not all(runner.graphs_captured().values()) and extra < 6:     # a --warmup shorter than the capture schedule (rollout: 3rd iteration,
-        runner.learn(1); extra += 1                                      # update slot 0: its 4th call): finish capturing, still untimed
+    while (not all(runner.graphs_captured().values()) or a.warmup + extra < 5) and extra < 8:     # a --warmup shorter than the capture schedule (rollout graph:
+        runner.learn(1); extra += 1                                      # 3rd iteration; compute_returns graph: 4th; permutation graph: 3rd): finish capturing, still untimed
 
     # every RCCL collective issued from Python inside the timed region is counted (the driver can check that RCCL saw N ranks and how often)
     ncoll = {"all_reduce": 0}
