@@ -88,6 +88,7 @@ struct LegPhys {
   float Msub[3][6];          // this sub-lane's rows of the response map: sub 0 [A^-1 | 0], sub 1 Phi rows 0..2, sub 2 Phi rows 3..5
   Row foot[3], other[3], lim[3];
   float act_foot, act_other, act_lim[3];
+  float s_act;               // how firmly this leg's rows are active, in [0, 1] (solve_omega): 0 at the activation boundary, 1 a quarter margin inside
   V3 f_n, f_t1, f_t2, o_n, o_t1, o_t2;     // world directions of the two contact frames
   float x[3];                // this sub-lane's slice of the velocity change: sub 0 z, sub 1 w.ang, sub 2 w.lin
   SV w; float z[3];          // the gathered velocity change (after the solve)
@@ -289,6 +290,7 @@ struct LegPhys {
       V3 cb = p3 + mul(R3, v3(t.foot_pt[0], t.foot_pt[1], t.foot_pt[2]));
       V3 cw = pw + mul(Rwb, cb); float gap; V3 n; contact_query(L, cells, cw, t.foot_pt[3], &gap, &n);
       build_slot(foot, &act_foot, &f_n, &f_t1, &f_t2, L, gap, cb, t.foot_pt[3], 3, n, true);
+      s_act = fminf(fmaxf((L.contact_offset - gap) / (0.25f * L.contact_offset), 0.f), 1.f);
     }
     GO2_MARK(30);
     // deepest of the other candidates: this sub-lane tests its quarter of the leg's 16 + the leg's share of the base points (table
@@ -354,6 +356,7 @@ struct LegPhys {
       // rows only if some lane of the wave has a candidate inside the contact margin this substep (wave-uniform branch; an inactive
       // slot's rows are never visited by the solver, so skipping their construction changes no result)
       act_other = best < L.contact_offset ? 1.f : 0.f; o_n = bn; o_t1 = v3(1, 0, 0); o_t2 = v3(0, 1, 0);
+      s_act = fmaxf(s_act, fminf(fmaxf((L.contact_offset - best) / (0.25f * L.contact_offset), 0.f), 1.f));
       _Pragma("unroll") for (int a = 0; a < 3; ++a) other[a] = Row{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0.f, 0.f, 0.f};
       if (any_near) build_slot(other, &act_other, &o_n, &o_t1, &o_t2, L, best, bcb, brad, blink, bn, false);
     }
@@ -368,6 +371,7 @@ struct LegPhys {
         sgn[j] = 0.f; gap[j] = 0.f;
         if (glo < L.limit_margin) { sgn[j] = 1.f; gap[j] = glo; } else if (ghi < L.limit_margin) { sgn[j] = -1.f; gap[j] = ghi; }
         act_lim[j] = sgn[j] != 0.f ? 1.f : 0.f; lim[j] = Row{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0.f, 0.f, 0.f};
+        if (sgn[j] != 0.f) s_act = fmaxf(s_act, fminf(fmaxf((L.limit_margin - gap[j]) / (0.25f * L.limit_margin), 0.f), 1.f));
       }
       if (xl::any(act_lim[0] + act_lim[1] + act_lim[2] > 0.f))
 #pragma unroll
@@ -410,28 +414,47 @@ struct LegPhys {
       row_apply(r[1], d1); row_apply(r[2], d2);
     }
   }
-  // One Gauss-Seidel turn of leg T: its rows are visited in the fixed order foot (n, t), other (n, t), limits; then the base-twist
-  // slices it has changed reach the other three legs (they contributed nothing during the turn).  do_* are WAVE-UNIFORM hints: false
-  // means no lane of the wave has such a row active this substep, so the group is skipped as a whole (an inactive row moves nothing).
+  // One iteration of the contact / limit solve: the rows of a leg are a block, visited in the fixed order foot (n, t),
+  // other (n, t), limits (Gauss-Seidel inside the block); ALL FOUR LEGS sweep their blocks at once, each from the same state — a leg's
+  // sub-lanes hold its own copy of the base-twist slices — and then impulses and velocity change move by omega = 1 / (number of legs with
+  // active rows) of each leg's proposal: z <- z0 + omega (z - z0) for the leg's joint slice, w <- w0 + omega sum_legs (w_leg - w0) for the
+  // base slices (one leg sum per slice instead of one per leg turn).  A convex combination of block-coordinate steps: the constraint energy
+  // does not increase and the impulses stay in their cones.  do_* are WAVE-UNIFORM hints: false means no lane of the wave has such a row
+  // active this substep, so the group is skipped as a whole (an inactive row moves nothing).
 #ifdef GO2_DBG_NOINLINE_GS
-  __device__ __attribute__((noinline)) void gs_turn(int T, bool do_foot, bool do_other, bool do_lim) {
+  __device__ __attribute__((noinline)) void solve_iteration(bool do_foot, bool do_other, bool do_lim, float omega) {
 #else
-  GO2_HD void gs_turn(int T, bool do_foot, bool do_other, bool do_lim) {
+  GO2_HD void solve_iteration(bool do_foot, bool do_other, bool do_lim, float omega) {
 #endif
-    const float on = leg == T ? 1.f : 0.f;
-    if (do_foot) sweep_slot(foot, on * act_foot, mu);
-    if (do_other) sweep_slot(other, on * act_other, mu);
+    const float x0[3] = {x[0], x[1], x[2]};
+    if (do_foot) {
+      const float l0[3] = {foot[0].lam, foot[1].lam, foot[2].lam};
+      sweep_slot(foot, act_foot, mu);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) foot[a].lam = l0[a] + omega * (foot[a].lam - l0[a]);
+    }
+    if (do_other) {
+      const float l0[3] = {other[0].lam, other[1].lam, other[2].lam};
+      sweep_slot(other, act_other, mu);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) other[a].lam = l0[a] + omega * (other[a].lam - l0[a]);
+    }
     if (do_lim)
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const float v = row_v(lim[j]);
         const float ln = fmaxf(0.f, lim[j].lam - v * lim[j].dinv);
-        const float dl = on * act_lim[j] * (ln - lim[j].lam); lim[j].lam += dl;
+        const float dl = act_lim[j] * (ln - lim[j].lam);
+        lim[j].lam += omega * dl;
         row_apply(lim[j], dl);
       }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { const float s = xl::leg_sum(on * x[k]); x[k] = sub == 0 ? x[k] : s; }
+    for (int k = 0; k < 3; ++k) { const float d = x[k] - x0[k], s = xl::leg_sum(d); x[k] = x0[k] + omega * (sub == 0 ? d : s); }
   }
+  // omega of solve_iteration for this environment: 1 / (number of legs with active rows), the count taken SMOOTHLY — a leg whose rows have
+  // only just become active (gap within a quarter margin of the activation threshold, where its rows still do nothing) counts in proportion —
+  // so that the step stays a continuous function of the state; 1 for fewer than one leg
+  GO2_HD float solve_omega() const { return 1.f / fmaxf(xl::leg_sum(s_act), 1.f); }
   // after the last turn: every lane gets the whole velocity change of its leg and of the base
   GO2_HD void gather_solution() {
 #pragma unroll

@@ -304,15 +304,11 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
       ph_.phaseC(tl, hl, p.hf_cells);
       GO2_MARK(14);
       if (sb == 1) STAMP(20);
-      // wave-wide row-group activity PER TURN (ballots -> scalar branches): group g of leg T is swept only if some environment of the wave
-      // has it active on that leg — typically only the foot contacts are live (an inactive row moves nothing, so skipping is exact)
-      bool af[4], ao[4], al[4];
-#pragma unroll
-      for (int T = 0; T < 4; ++T) { const bool mine = lane == T; af[T] = xl::any(mine && ph_.has_foot()); ao[T] = xl::any(mine && ph_.has_other()); al[T] = xl::any(mine && ph_.has_limit()); }
-      for (int it = 0; it < L.solver_iterations; ++it) {
-        ph_.gs_turn(0, af[0], ao[0], al[0]); ph_.gs_turn(1, af[1], ao[1], al[1]);
-        ph_.gs_turn(2, af[2], ao[2], al[2]); ph_.gs_turn(3, af[3], ao[3], al[3]);
-      }
+      // wave-wide row-group activity (ballots -> scalar branches): a group is swept only if some environment of the wave has it active on
+      // some leg — typically only the foot contacts are live (an inactive row moves nothing, so skipping is exact)
+      const bool af = xl::any(ph_.has_foot()), ao = xl::any(ph_.has_other()), al = xl::any(ph_.has_limit());
+      const float omega = ph_.solve_omega();
+      for (int it = 0; it < L.solver_iterations; ++it) ph_.solve_iteration(af, ao, al, omega);
       GO2_MARK(15);
       if (sb == 1) STAMP(21);
       ph_.gather_solution();

@@ -424,7 +424,7 @@ static void contact_query(const Go2Sim* s, const R* c, R r, R* gap, R* n) {
 /* ---------------- one physics substep ------------------------------------------------------------ */
 typedef struct {
   int active; int kind;          /* kind 0 = contact triple head (n), handled with its two tangents; 1 = limit */
-  R J[3][NV]; R Y[3][NV]; R d[3]; R b; R mu; R lam[3];
+  R J[3][NV]; R Y[3][NV]; R d[3]; R b; R mu; R lam[3]; R sact;   /* sact: how firmly the row is active, 0 at its activation threshold .. 1 */
   int body; R n[3], t1[3], t2[3];
 } Row;
 
@@ -508,6 +508,7 @@ static void physics_substep(Go2Sim* s, int e, R* root, R* q, R* qd, const R* tau
       }
       if (best_gap < (R)cfg->contact_offset) {
         r->active = 1; r->body = best->body; r->mu = mu;
+        { R sa = ((R)cfg->contact_offset - best_gap)/(RC(0.25)*(R)cfg->contact_offset); r->sact = sa < 0 ? 0 : (sa > 1 ? 1 : sa); }
         memcpy(r->n, best_n, sizeof(best_n));
         R ex[3] = {1,0,0}; if (!(FABS(r->n[0]) < RC(0.9))) { ex[0]=0; ex[1]=1; }   /* world x, or world y beside a face that looks along x */
         R dn = dot3(ex, r->n); for (int i=0;i<3;++i) r->t1[i] = ex[i]-dn*r->n[i];
@@ -532,6 +533,7 @@ static void physics_substep(Go2Sim* s, int e, R* root, R* q, R* qd, const R* tau
       if (glo < (R)cfg->joint_limit_margin) { sgn = 1; gap = glo; } else if (ghi < (R)cfg->joint_limit_margin) { sgn = -1; gap = ghi; }
       if (sgn != 0) {
         r->active=1; memset(r->J, 0, sizeof(r->J)); r->J[0][6+j] = sgn;
+        { R sa = ((R)cfg->joint_limit_margin - gap)/(RC(0.25)*(R)cfg->joint_limit_margin); r->sact = sa < 0 ? 0 : (sa > 1 ? 1 : sa); }
         R b = gap >= 0 ? gap/h : gap*(R)cfg->erp/h; if (b < -RC(10.0)) b = -RC(10.0);
         r->b = b;
       }
@@ -549,21 +551,39 @@ static void physics_substep(Go2Sim* s, int e, R* root, R* q, R* qd, const R* tau
       for (int c=0;c<NV;++c) dnu[c] += r->Y[a][c]*r->lam[a];
     }
   }
-  for (int it=0; it<cfg->solver_iterations; ++it)
-    for (int lane=0;lane<4;++lane) for (int ri=0;ri<5;++ri) {
-      Row* r = &rows[lane][ri]; if (!r->active) continue;
-      { R v=0; for (int c=0;c<NV;++c) v += r->J[0][c]*(nu_free[c]+dnu[c]);
-        R ln = r->lam[0] - (v + r->b)/r->d[0]; if (ln < 0) ln = 0;
-        R dl = ln - r->lam[0]; r->lam[0] = ln; for (int c=0;c<NV;++c) dnu[c] += r->Y[0][c]*dl; }
-      if (r->kind==0) {
-        R v1=0, v2=0; for (int c=0;c<NV;++c) { v1 += r->J[1][c]*(nu_free[c]+dnu[c]); v2 += r->J[2][c]*(nu_free[c]+dnu[c]); }
-        R l1 = r->lam[1] - v1/r->d[1], l2 = r->lam[2] - v2/r->d[2];
-        R lim = r->mu*r->lam[0], nn = SQRT(l1*l1+l2*l2);
-        if (nn > lim) { R sc = nn > 0 ? lim/nn : 0; l1*=sc; l2*=sc; }
-        R d1 = l1-r->lam[1], d2 = l2-r->lam[2]; r->lam[1]=l1; r->lam[2]=l2;
-        for (int c=0;c<NV;++c) dnu[c] += r->Y[1][c]*d1 + r->Y[2][c]*d2;
+  /* Projected block iteration over the LEGS: the constraint rows of a leg form a block (foot n,t; other n,t; limits, visited in
+   * that order, Gauss-Seidel inside the block); per iteration every leg with active rows sweeps its block starting from the SAME state, then
+   * impulses and velocity change move by omega = 1 / (number of such legs) of each leg's proposal.  A convex combination of the legs'
+   * block-coordinate steps: the constraint energy cannot increase, impulses stay inside their cones, and the legs do not wait for each other. */
+  int legact[4]; R nsm = 0;      /* the number of legs with active rows, counted smoothly: a row that has only just become active (within a quarter
+                                  * margin of its activation threshold, where it still does nothing) counts in proportion, so omega is continuous */
+  for (int lane=0;lane<4;++lane) { legact[lane]=0; R sl=0; for (int ri=0;ri<5;++ri) if (rows[lane][ri].active) { legact[lane]=1; if (rows[lane][ri].sact > sl) sl = rows[lane][ri].sact; } nsm += sl; }
+  R omega = 1/(nsm > 1 ? nsm : 1);
+  for (int it=0; it<cfg->solver_iterations; ++it) {
+    R dnu0[NV], acc[NV]; memcpy(dnu0, dnu, sizeof(dnu)); memset(acc, 0, sizeof(acc));
+    for (int lane=0;lane<4;++lane) {
+      if (!legact[lane]) continue;
+      R dl_[NV]; memcpy(dl_, dnu0, sizeof(dnu0));      /* this leg's view of the velocity change */
+      for (int ri=0;ri<5;++ri) {
+        Row* r = &rows[lane][ri]; if (!r->active) continue;
+        R lam0[3] = {r->lam[0], r->lam[1], r->lam[2]};
+        { R v=0; for (int c=0;c<NV;++c) v += r->J[0][c]*(nu_free[c]+dl_[c]);
+          R ln = r->lam[0] - (v + r->b)/r->d[0]; if (ln < 0) ln = 0;
+          R dl = ln - r->lam[0]; r->lam[0] = ln; for (int c=0;c<NV;++c) dl_[c] += r->Y[0][c]*dl; }
+        if (r->kind==0) {
+          R v1=0, v2=0; for (int c=0;c<NV;++c) { v1 += r->J[1][c]*(nu_free[c]+dl_[c]); v2 += r->J[2][c]*(nu_free[c]+dl_[c]); }
+          R l1 = r->lam[1] - v1/r->d[1], l2 = r->lam[2] - v2/r->d[2];
+          R lim = r->mu*r->lam[0], nn = SQRT(l1*l1+l2*l2);
+          if (nn > lim) { R sc = nn > 0 ? lim/nn : 0; l1*=sc; l2*=sc; }
+          R d1 = l1-r->lam[1], d2 = l2-r->lam[2]; r->lam[1]=l1; r->lam[2]=l2;
+          for (int c=0;c<NV;++c) dl_[c] += r->Y[1][c]*d1 + r->Y[2][c]*d2;
+        }
+        for (int a=0;a<3;++a) r->lam[a] = lam0[a] + omega*(r->lam[a]-lam0[a]);
       }
+      for (int c=0;c<NV;++c) acc[c] += dl_[c]-dnu0[c];
     }
+    for (int c=0;c<NV;++c) dnu[c] = dnu0[c] + omega*acc[c];
+  }
   /* outputs: contact forces per body (world), warm start */
   memset(body_force, 0, sizeof(R)*NB*3);
   for (int lane=0;lane<4;++lane) for (int slot=0;slot<2;++slot) {
