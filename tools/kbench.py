@@ -104,7 +104,7 @@ def phase_clocks(steps=50, **kw):
         print("reset path (%d samples): " % full.sum() + ", ".join("%s %.2f" % (lab[j], ((t[:, :, seq[j + 1]] - t[:, :, seq[j]]) / 100.0)[full].mean()) for j in range(7)))
     ss = np.diff(t[:, :, 16:23], axis=2) / 100.0
     print("substep 1 (mean / p99 over waves): " + ", ".join("%s %.2f / %.2f" % (nm, ss[:, :, j].mean(), np.quantile(ss[:, :, j], 0.99))
-          for j, nm in enumerate(["pd+phaseA", "leg sums", "phaseB", "phaseC (contacts, rows)", "Gauss-Seidel", "gather+phaseD"])))
+          for j, nm in enumerate(["pd+phaseA", "leg sums", "phaseB", "phaseC (contacts, rows)", "contact / limit solve", "gather+phaseD"])))
     sub_ = d[:, :, 1]
     print("substeps over waves: p50 %.1f p90 %.1f p99 %.1f max %.1f us" % tuple(np.quantile(sub_, q) for q in (0.5, 0.9, 0.99, 1.0)))
     s.close()
