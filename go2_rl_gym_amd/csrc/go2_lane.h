@@ -30,7 +30,7 @@
 
 // one constraint row as THIS sub-lane sees it: its 3-number slice of the row vector J = [Jc | G.ang | G.lin] and of the response
 // Y = M^-1 J^T = [Z | H.ang | H.lin]; the scalars are replicated in the quad
-struct Row { float J[3], Y[3], dinv, vfb, lam; };
+struct Row { float J[3], Y[3], dinv /* until solve_prepare: this sub-lane's part J . Y of the diagonal */, vfb, lam; };
 
 // The launch constants the substep loop reads, snapshotted ONCE per step.  Read straight from the device block they are "invariant scalar
 // loads" to the compiler, which re-issues them at every use instead of keeping them in registers (37 s_load + wait per substep, measured
@@ -88,7 +88,8 @@ struct LegPhys {
   float Msub[3][6];          // this sub-lane's rows of the response map: sub 0 [A^-1 | 0], sub 1 Phi rows 0..2, sub 2 Phi rows 3..5
   Row foot[3], other[3], lim[3];
   float act_foot, act_other, act_lim[3];
-  float s_act;               // how firmly this leg's rows are active, in [0, 1] (solve_omega): 0 at the activation boundary, 1 a quarter margin inside
+  float nsplit, yscale;      // solve_prepare: the split n of the base, and this sub-lane's factor on a response slice (1 joint slice, n base slices)
+  float s_act;               // how firmly this leg's rows are active, in [0, 1] (solve_prepare: the smooth count of legs sharing the base): 0 at the activation boundary, 1 a quarter margin inside
   V3 f_n, f_t1, f_t2, o_n, o_t1, o_t2;     // world directions of the two contact frames
   float x[3];                // this sub-lane's slice of the velocity change: sub 0 z, sub 1 w.ang, sub 2 w.lin
   SV w; float z[3];          // the gathered velocity change (after the solve)
@@ -244,8 +245,7 @@ struct LegPhys {
       r.Y[i] = live * s;
     }
     r.J[0] = live * (sub == 2 ? G.l.x : x6[0]); r.J[1] = live * (sub == 2 ? G.l.y : x6[1]); r.J[2] = live * (sub == 2 ? G.l.z : x6[2]);
-    const float d_ = xl::sub_sum(r.J[0] * r.Y[0] + r.J[1] * r.Y[1] + r.J[2] * r.Y[2]) * cfm1;
-    r.dinv = d_ > 0.f ? 1.0f / d_ : 0.f;
+    r.dinv = (r.J[0] * r.Y[0] + r.J[1] * r.Y[1] + r.J[2] * r.Y[2]) * cfm1;      // (this sub-lane's part; summed, with the split base, in solve_prepare)
     r.vfb = dot(Ec, V0f) + Jc[0] * qdf[0] + Jc[1] * qdf[1] + Jc[2] * qdf[2] + bias;
     r.lam = lam0;
   }
@@ -395,7 +395,7 @@ struct LegPhys {
   GO2_HD bool has_limit() const { return (act_lim[0] + act_lim[1] + act_lim[2]) > 0.f; }
 
   GO2_HD float row_v(const Row& r) const { return r.vfb + xl::sub_sum(r.J[0] * x[0] + r.J[1] * x[1] + r.J[2] * x[2]); }
-  GO2_HD void row_apply(const Row& r, float dl) { x[0] += r.Y[0] * dl; x[1] += r.Y[1] * dl; x[2] += r.Y[2] * dl; }
+  GO2_HD void row_apply(const Row& r, float dl) { const float d = dl * yscale; x[0] += r.Y[0] * d; x[1] += r.Y[1] * d; x[2] += r.Y[2] * d; }      // (the leg's view: base slices x n)
   GO2_HD void sweep_slot(Row* r, float m, float mu_) {
     {
       const float v = row_v(r[0]);
@@ -414,47 +414,44 @@ struct LegPhys {
       row_apply(r[1], d1); row_apply(r[2], d2);
     }
   }
-  // One iteration of the contact / limit solve: the rows of a leg are a block, visited in the fixed order foot (n, t),
-  // other (n, t), limits (Gauss-Seidel inside the block); ALL FOUR LEGS sweep their blocks at once, each from the same state — a leg's
-  // sub-lanes hold its own copy of the base-twist slices — and then impulses and velocity change move by omega = 1 / (number of legs with
-  // active rows) of each leg's proposal: z <- z0 + omega (z - z0) for the leg's joint slice, w <- w0 + omega sum_legs (w_leg - w0) for the
-  // base slices (one leg sum per slice instead of one per leg turn).  A convex combination of block-coordinate steps: the constraint energy
-  // does not increase and the impulses stay in their cones.  do_* are WAVE-UNIFORM hints: false means no lane of the wave has such a row
-  // active this substep, so the group is skipped as a whole (an inactive row moves nothing).
+  // The contact / limit solve: projected block iteration over the LEGS with mass splitting at the base.  The rows of a
+  // leg are a block, visited in the fixed order foot (n, t), other (n, t), limits (Gauss-Seidel inside the block); ALL FOUR LEGS sweep their
+  // blocks at once, each from the same state, on its own copy of the base-twist slices.  Legs interact only through the base, and each leg is
+  // given 1 / n of it: in ITS view the base slices of every response (sub-lanes 1, 2: H = Phi G) are n times larger, the joint slice (sub-lane
+  // 0: Z = A^-1 Jc, the leg's own joints with the base held fixed) is as it is.  Committed are the true responses: z as swept, w <- w0 +
+  // (1 / n) sum_legs (w_leg - w0) — one leg sum per slice instead of one per leg turn.  n = the number of legs with active rows, counted
+  // smoothly (s_act), so the step stays a continuous function of the state.
+  // solve_prepare: n, and the rows' inverse diagonals J . Y_view (1 + cfm) with it.
+  GO2_HD void solve_prepare(bool do_foot, bool do_other, bool do_lim) {
+    nsplit = fmaxf(xl::leg_sum(s_act), 1.f);
+    yscale = sub == 0 ? 1.f : nsplit;
+    auto fin = [&](Row& r) { const float d_ = xl::sub_sum(r.dinv * yscale); r.dinv = d_ > 0.f ? 1.0f / d_ : 0.f; };
+    if (do_foot) { fin(foot[0]); fin(foot[1]); fin(foot[2]); }
+    if (do_other) { fin(other[0]); fin(other[1]); fin(other[2]); }
+    if (do_lim) { fin(lim[0]); fin(lim[1]); fin(lim[2]); }
+  }
+  // do_* are WAVE-UNIFORM hints: false means no lane of the wave has such a row active this substep, so the group is skipped as a whole
+  // (an inactive row moves nothing).
 #ifdef GO2_DBG_NOINLINE_GS
-  __device__ __attribute__((noinline)) void solve_iteration(bool do_foot, bool do_other, bool do_lim, float omega) {
+  __device__ __attribute__((noinline)) void solve_iteration(bool do_foot, bool do_other, bool do_lim) {
 #else
-  GO2_HD void solve_iteration(bool do_foot, bool do_other, bool do_lim, float omega) {
+  GO2_HD void solve_iteration(bool do_foot, bool do_other, bool do_lim) {
 #endif
     const float x0[3] = {x[0], x[1], x[2]};
-    if (do_foot) {
-      const float l0[3] = {foot[0].lam, foot[1].lam, foot[2].lam};
-      sweep_slot(foot, act_foot, mu);
-#pragma unroll
-      for (int a = 0; a < 3; ++a) foot[a].lam = l0[a] + omega * (foot[a].lam - l0[a]);
-    }
-    if (do_other) {
-      const float l0[3] = {other[0].lam, other[1].lam, other[2].lam};
-      sweep_slot(other, act_other, mu);
-#pragma unroll
-      for (int a = 0; a < 3; ++a) other[a].lam = l0[a] + omega * (other[a].lam - l0[a]);
-    }
+    if (do_foot) sweep_slot(foot, act_foot, mu);
+    if (do_other) sweep_slot(other, act_other, mu);
     if (do_lim)
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const float v = row_v(lim[j]);
         const float ln = fmaxf(0.f, lim[j].lam - v * lim[j].dinv);
-        const float dl = act_lim[j] * (ln - lim[j].lam);
-        lim[j].lam += omega * dl;
+        const float dl = act_lim[j] * (ln - lim[j].lam); lim[j].lam += dl;
         row_apply(lim[j], dl);
       }
+    const float inv_n = 1.f / nsplit;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { const float d = x[k] - x0[k], s = xl::leg_sum(d); x[k] = x0[k] + omega * (sub == 0 ? d : s); }
+    for (int k = 0; k < 3; ++k) { const float s = xl::leg_sum(x[k] - x0[k]); x[k] = sub == 0 ? x[k] : x0[k] + inv_n * s; }
   }
-  // omega of solve_iteration for this environment: 1 / (number of legs with active rows), the count taken SMOOTHLY — a leg whose rows have
-  // only just become active (gap within a quarter margin of the activation threshold, where its rows still do nothing) counts in proportion —
-  // so that the step stays a continuous function of the state; 1 for fewer than one leg
-  GO2_HD float solve_omega() const { return 1.f / fmaxf(xl::leg_sum(s_act), 1.f); }
   // after the last turn: every lane gets the whole velocity change of its leg and of the base
   GO2_HD void gather_solution() {
 #pragma unroll

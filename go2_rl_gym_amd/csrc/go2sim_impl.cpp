@@ -307,8 +307,8 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
       // wave-wide row-group activity (ballots -> scalar branches): a group is swept only if some environment of the wave has it active on
       // some leg — typically only the foot contacts are live (an inactive row moves nothing, so skipping is exact)
       const bool af = xl::any(ph_.has_foot()), ao = xl::any(ph_.has_other()), al = xl::any(ph_.has_limit());
-      const float omega = ph_.solve_omega();
-      for (int it = 0; it < L.solver_iterations; ++it) ph_.solve_iteration(af, ao, al, omega);
+      ph_.solve_prepare(af, ao, al);
+      for (int it = 0; it < L.solver_iterations; ++it) ph_.solve_iteration(af, ao, al);
       GO2_MARK(15);
       if (sb == 1) STAMP(21);
       ph_.gather_solution();

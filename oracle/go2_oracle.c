@@ -486,7 +486,10 @@ static void physics_substep(Go2Sim* s, int e, R* root, R* q, R* qd, const R* tau
   R nu[NV]; for (int i=0;i<6;++i) nu[i] = k.v[0][i]; for (int j=0;j<12;++j) nu[6+j] = qd[j];
   R nu_free[NV]; for (int i=0;i<NV;++i) nu_free[i] = nu[i] + h*acc[i];
   /* dense inverse inertia for the constraint rows */
-  R M[NV*NV]; mass_matrix(s, &k, M); chol_factor(M, NV);
+  R M[NV*NV]; mass_matrix(s, &k, M);
+  R Mll[4][3][3];   /* joint-space inertia of each leg with the base held fixed = the leg's diagonal block of M */
+  for (int l=0;l<4;++l) for (int i=0;i<3;++i) for (int j=0;j<3;++j) Mll[l][i][j] = M[(6+3*l+i)*NV + 6+3*l+j];
+  chol_factor(M, NV);
 
   R mu = RC(0.5)*((R)cfg->terrain_friction + (R)s->b.friction_coeffs[e]);
   R rest = RC(0.5)*((R)cfg->terrain_restitution + (R)s->b.restitution_coeffs[e]);
@@ -551,14 +554,30 @@ static void physics_substep(Go2Sim* s, int e, R* root, R* q, R* qd, const R* tau
       for (int c=0;c<NV;++c) dnu[c] += r->Y[a][c]*r->lam[a];
     }
   }
-  /* Projected block iteration over the LEGS: the constraint rows of a leg form a block (foot n,t; other n,t; limits, visited in
-   * that order, Gauss-Seidel inside the block); per iteration every leg with active rows sweeps its block starting from the SAME state, then
-   * impulses and velocity change move by omega = 1 / (number of such legs) of each leg's proposal.  A convex combination of the legs'
-   * block-coordinate steps: the constraint energy cannot increase, impulses stay inside their cones, and the legs do not wait for each other. */
-  int legact[4]; R nsm = 0;      /* the number of legs with active rows, counted smoothly: a row that has only just become active (within a quarter
-                                  * margin of its activation threshold, where it still does nothing) counts in proportion, so omega is continuous */
+  /* Projected block iteration over the LEGS with MASS SPLITTING at the base (Tonge et al. 2012).  The constraint rows of a
+   * leg form a block (foot n,t; other n,t; limits, visited in that order, Gauss-Seidel inside the block).  Per iteration every leg sweeps its
+   * block starting from the SAME state; the legs interact only through the base, and each leg is given 1/n of it: in ITS view the base-mediated
+   * part of every response, Y - Y_L, is n times larger, the fixed-base part Y_L = M_ll^-1 J_l^T (the leg's own joints) is as it is.  What is
+   * committed are the TRUE responses Y dlam of the impulses the legs arrive at.  n = the number of legs with active rows, counted smoothly
+   * (a row that has only just become active — within a quarter margin of its threshold, where it still does nothing — counts in
+   * proportion), so that the step is a continuous function of the state. */
+  int legact[4]; R nsm = 0;
   for (int lane=0;lane<4;++lane) { legact[lane]=0; R sl=0; for (int ri=0;ri<5;++ri) if (rows[lane][ri].active) { legact[lane]=1; if (rows[lane][ri].sact > sl) sl = rows[lane][ri].sact; } nsm += sl; }
-  R omega = 1/(nsm > 1 ? nsm : 1);
+  const R nsplit = nsm > 1 ? nsm : 1;
+  static _Thread_local R Yv[4][5][3][NV], dv[4][5][3];      /* the leg's view: responses and diagonals with the split base */
+  for (int lane=0;lane<4;++lane) for (int ri=0;ri<5;++ri) {
+    Row* r=&rows[lane][ri]; if (!r->active) continue;
+    int nr = r->kind==0 ? 3 : 1;
+    for (int a=0;a<nr;++a) {
+      R A[3][3], bb[3], y[3]; memcpy(A, Mll[lane], sizeof(A)); for (int i=0;i<3;++i) bb[i] = r->J[a][6+3*lane+i];
+      R det = A[0][0]*(A[1][1]*A[2][2]-A[1][2]*A[2][1]) - A[0][1]*(A[1][0]*A[2][2]-A[1][2]*A[2][0]) + A[0][2]*(A[1][0]*A[2][1]-A[1][1]*A[2][0]);
+      for (int c=0;c<3;++c) { R B_[3][3]; memcpy(B_, A, sizeof(A)); for (int i=0;i<3;++i) B_[i][c]=bb[i];      /* Cramer */
+        y[c] = (B_[0][0]*(B_[1][1]*B_[2][2]-B_[1][2]*B_[2][1]) - B_[0][1]*(B_[1][0]*B_[2][2]-B_[1][2]*B_[2][0]) + B_[0][2]*(B_[1][0]*B_[2][1]-B_[1][1]*B_[2][0]))/det; }
+      for (int c=0;c<NV;++c) { R yl = (c>=6+3*lane && c<9+3*lane) ? y[c-6-3*lane] : 0; Yv[lane][ri][a][c] = yl + nsplit*(r->Y[a][c]-yl); }
+      R w=0; for (int c=0;c<NV;++c) w += r->J[a][c]*Yv[lane][ri][a][c];
+      dv[lane][ri][a] = w*(1+(R)cfg->contact_cfm);
+    }
+  }
   for (int it=0; it<cfg->solver_iterations; ++it) {
     R dnu0[NV], acc[NV]; memcpy(dnu0, dnu, sizeof(dnu)); memset(acc, 0, sizeof(acc));
     for (int lane=0;lane<4;++lane) {
@@ -568,21 +587,21 @@ static void physics_substep(Go2Sim* s, int e, R* root, R* q, R* qd, const R* tau
         Row* r = &rows[lane][ri]; if (!r->active) continue;
         R lam0[3] = {r->lam[0], r->lam[1], r->lam[2]};
         { R v=0; for (int c=0;c<NV;++c) v += r->J[0][c]*(nu_free[c]+dl_[c]);
-          R ln = r->lam[0] - (v + r->b)/r->d[0]; if (ln < 0) ln = 0;
-          R dl = ln - r->lam[0]; r->lam[0] = ln; for (int c=0;c<NV;++c) dl_[c] += r->Y[0][c]*dl; }
+          R ln = r->lam[0] - (v + r->b)/dv[lane][ri][0]; if (ln < 0) ln = 0;
+          R dl = ln - r->lam[0]; r->lam[0] = ln; for (int c=0;c<NV;++c) dl_[c] += Yv[lane][ri][0][c]*dl; }
         if (r->kind==0) {
           R v1=0, v2=0; for (int c=0;c<NV;++c) { v1 += r->J[1][c]*(nu_free[c]+dl_[c]); v2 += r->J[2][c]*(nu_free[c]+dl_[c]); }
-          R l1 = r->lam[1] - v1/r->d[1], l2 = r->lam[2] - v2/r->d[2];
+          R l1 = r->lam[1] - v1/dv[lane][ri][1], l2 = r->lam[2] - v2/dv[lane][ri][2];
           R lim = r->mu*r->lam[0], nn = SQRT(l1*l1+l2*l2);
           if (nn > lim) { R sc = nn > 0 ? lim/nn : 0; l1*=sc; l2*=sc; }
           R d1 = l1-r->lam[1], d2 = l2-r->lam[2]; r->lam[1]=l1; r->lam[2]=l2;
-          for (int c=0;c<NV;++c) dl_[c] += r->Y[1][c]*d1 + r->Y[2][c]*d2;
+          for (int c=0;c<NV;++c) dl_[c] += Yv[lane][ri][1][c]*d1 + Yv[lane][ri][2][c]*d2;
         }
-        for (int a=0;a<3;++a) r->lam[a] = lam0[a] + omega*(r->lam[a]-lam0[a]);
+        int nr = r->kind==0 ? 3 : 1;
+        for (int a=0;a<nr;++a) for (int c=0;c<NV;++c) acc[c] += r->Y[a][c]*(r->lam[a]-lam0[a]);      /* the true response of what the leg arrived at */
       }
-      for (int c=0;c<NV;++c) acc[c] += dl_[c]-dnu0[c];
     }
-    for (int c=0;c<NV;++c) dnu[c] = dnu0[c] + omega*acc[c];
+    for (int c=0;c<NV;++c) dnu[c] = dnu0[c] + acc[c];
   }
   /* outputs: contact forces per body (world), warm start */
   memset(body_force, 0, sizeof(R)*NB*3);
