@@ -95,6 +95,8 @@ class HostSim:
     def set_cfg(self, cfg, k, v):
         cur = getattr(cfg, k)
         if isinstance(v, np.ndarray) and isinstance(cur, C._Pointer):
+            if v.dtype.kind == "f":         # the fp64 oracle build widens every `float*` of the ABI (terrain_origins) to double*
+                v = np.ascontiguousarray(v, _NP[type(cur)._type_])
             self._keep.append(v)
             setattr(cfg, k, v.ctypes.data_as(type(cur)))
         elif hasattr(cur, "__len__"):
@@ -357,7 +359,8 @@ class StepErrors:
 
     PENALISED = [4, 5, 8, 9, 12, 13, 16, 17]      # thigh / calf bodies of _reward_collision (legged_robot.py:1277-1279)
 
-    def add(self, a, b, N):
+    def add(self, a, b, N, ref64=None):
+        """a: fp32 oracle, b: the library under test, ref64 (optional): the fp64 oracle stepped from the same state"""
         for k in self.d:
             d = np.abs(np.asarray(getattr(a, k), np.float64) - np.asarray(getattr(b, k), np.float64)).reshape(N, -1).max(1)
             if k == "rew_buf":
@@ -369,10 +372,32 @@ class StepErrors:
                 edge = ((np.abs(fa - 0.1) < 0.05) | (np.abs(fb - 0.1) < 0.05)).any(1)
                 self.edge = getattr(self, "edge", 0) + int(edge.sum()); self.rows = getattr(self, "rows", 0) + N
                 d = np.where(edge, 0.0, d)
+            if ref64 is not None:
+                # Conditioning-aware: an env-step at which the fp32 ORACLE itself differs from the fp64 oracle (same inputs) by more than half
+                # the bound is an ill-conditioned step (e.g. a robot lying on foot + hip of one leg: two strongly coupled contacts, 4 iterations)
+                # and cannot bound a third evaluation; such env-steps are excluded from the fixed bound and counted (check_plane_errors: rare).
+                c = np.abs(np.asarray(getattr(a, k), np.float64) - np.asarray(getattr(ref64, k), np.float64)).reshape(N, -1).max(1)
+                bound = PLANE_BOUND.get(k)
+                if bound is not None:
+                    ill = c > bound / 2
+                    self.ill = getattr(self, "ill", 0) + int(ill.sum())
+                    d = np.where(ill, 0.0, d)
             self.d[k].append(d)
+        self.steps_seen = getattr(self, "steps_seen", 0) + N
 
     def all(self, k):
         return np.concatenate(self.d[k])
+
+
+def ill_conditioned_envs(so, s64):
+    """-> boolean [N]: envs whose step is ill-conditioned in fp32 — the fp32 ORACLE's result differs from the fp64 oracle's (same inputs) by more
+    than half of PLANE_BOUND in root state, joint state or observations.  Rare (~1e-4 of env-steps under random actions, e.g. a robot lying on
+    the foot and the hip of one leg); such an env-step cannot bound a third evaluation and is left out of per-env bounds."""
+    bad = np.zeros(np.asarray(so.root_states).shape[0], bool)
+    for k in ("root_states", "dof_state", "obs_buf"):
+        d = np.abs(np.asarray(getattr(so, k), np.float64) - np.asarray(getattr(s64, k), np.float64))
+        bad |= d.reshape(d.shape[0], -1).max(1) > PLANE_BOUND[k] / 2
+    return bad
 
 
 def check_plane_errors(err):
@@ -380,6 +405,8 @@ def check_plane_errors(err):
         v = err.all(k)
         assert v.max() < bound, (k, float(v.max()), bound)                                   # every env of every step
         assert np.quantile(v, 0.99) < bound / 10, (k, float(np.quantile(v, 0.99)), bound / 10)
+    if getattr(err, "ill", 0):      # ill-conditioned env-steps (see StepErrors.add): at most 1 in 1000 per tensor, counted over all tensors
+        assert err.ill <= max(2 * len(PLANE_BOUND), 0.001 * len(PLANE_BOUND) * err.steps_seen), ("ill-conditioned env-steps", err.ill, err.steps_seen)
     if "rew_buf" in PLANE_BOUND and getattr(err, "rows", 0):
         assert err.edge <= 0.01 * err.rows, ("env-steps at the 0.1 N threshold of _reward_collision", err.edge, err.rows)
 
