@@ -108,12 +108,21 @@ def main():
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product has no CPU path)")
+    backend = os.environ.get("GO2_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        # Rehearsal of the N-rank code path on FEWER GPUs than ranks (tests/test_gpu_parity.py: 2 ranks on the one GPU of a test box; RCCL
+        # refuses two ranks on one device, gloo stages the collectives through the host).  Same shards, same captured halves, same collective
+        # sequence; its throughput means nothing and the line says so ("backend").
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
     if world > 1 or os.environ.get("GO2_FORCE_COLLECTIVES", "0") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))      # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))      # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     from go2_rl_gym_amd.envs import task_registry  # noqa: F401
     from go2_rl_gym_amd.utils import get_args
@@ -213,7 +222,7 @@ def main():
                        "num_envs_per_gpu": N, "num_steps_per_env": 24, "parallelism": "env-sharded dp%d" % world},
             "collection_only": world * N * 24 * a.steps / col,
             "graphs": graphs,      # both halves of every timed iteration were replayed from HIP graphs (bench.py exits non-zero otherwise)
-            "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+            "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1, "backend": (dist.get_backend() if dist.is_initialized() else None),
             "collectives_per_iteration": {"all_reduce": ncoll["all_reduce"] / max(a.steps, 1),
                                           "what": "1 x 24-byte fp64 advantage-statistics all-reduce (rollout_storage.py:137) + 1 flat gradient+KL bucket per mini-batch step (5 x 4)"},
             "roofline": {"bound": "hbm", "kernel": "go2_step_kernel<PHYS|POST>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

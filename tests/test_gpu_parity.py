@@ -727,3 +727,28 @@ def test_fused_clip_adam_matches_torch_on_gpu(hip):
             assert float(oa.state[a]["step"]) == it + 1
     sd = oa.state_dict()                                          # the torch optimizer's own state: checkpoints are unchanged
     assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+def test_two_rank_bench_rehearsal_on_one_gpu(hip):
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank), rehearsed on the ONE GPU of a test
+    box: GO2_DIST_BACKEND=gloo lets both ranks share cuda:0 (RCCL refuses two ranks on one device).  Exercises on the real library what a
+    node would: env shards at env_offset 0 / N of 2N, the policy broadcast, the advantage-statistics all-reduce, the two captured halves of
+    every mini-batch step with the eager gradient all-reduce between them, the barrier / MAX-over-ranks timing and the single JSON line."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, GO2_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "3", "--num-envs", "1024"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                    # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["backend"] == "gloo" and out["scaling"] == "weak"
+    assert out["graphs"]["rollout"] and out["graphs"]["update"]
+    assert out["collectives_per_iteration"]["all_reduce"] == 21            # 1 advantage statistics + 5 epochs x 4 mini-batches
+    assert out["value"] > 0 and abs(out["value"] - 2 * 1024 * 24 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    assert "cpu_baseline" not in out                                       # rank 0 at N = 1 only
