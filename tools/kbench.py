@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel micro-benchmark: time go2_step_kernel alone (HIP events inside the library) for a few configurations.
-   python tools/kbench.py [N]"""
+   python tools/kbench.py [N] [rough]        (rough: the task=go2 trimesh terrain instead of the plane)"""
 import ctypes as C
 import os
 import sys
@@ -13,10 +13,14 @@ from helpers import DeviceSim, load_hip, load_hip_kbench
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 hip = load_hip()
+TERRAIN = {}
+if len(sys.argv) > 2 and sys.argv[2] == "rough":
+    from helpers import heightfield_overrides
+    TERRAIN = heightfield_overrides(N, mesh_type="trimesh")[1]
 
 
 def run(label, steps=300, settle=80, **kw):
-    s = DeviceSim(hip, num_envs=N, **kw)
+    s = DeviceSim(hip, num_envs=N, **dict(TERRAIN, **kw))
     s.reset_all()
     a = torch.randn(N, 12, device="cuda:0") * 0.5
     for _ in range(settle):
@@ -36,7 +40,7 @@ def run(label, steps=300, settle=80, **kw):
 
 
 def run_split(steps=300, label="", **kw):
-    s = DeviceSim(hip, num_envs=N, **kw)
+    s = DeviceSim(hip, num_envs=N, **dict(TERRAIN, **kw))
     s.reset_all()
     a = torch.randn(N, 12, device="cuda:0") * 0.5
     for _ in range(80):
@@ -66,7 +70,7 @@ def phase_clocks(steps=50, **kw):
     """Per-wave phase timestamps (wall_clock64, 100 MHz) of the fused kernel: mean and max over the waves.  Uses the STAMPED build of the
     library (build.py:build_hip_kbench, -DGO2_KBENCH_STAMPS); the timings above are of the product build, which carries no stamps."""
     hip = load_hip_kbench()
-    s = DeviceSim(hip, num_envs=N, **kw)
+    s = DeviceSim(hip, num_envs=N, **dict(TERRAIN, **kw))
     s.reset_all()
     a = torch.randn(N, 12, device="cuda:0") * 0.5
     for _ in range(80):
