@@ -103,6 +103,20 @@ class FusedClipAdam:
         return True
 
 
+def load_optimizer_state(optimizer, state_dict):
+    """optimizer.load_state_dict(state_dict) that KEEPS the addresses of state tensors which already exist (exp_avg, exp_avg_sq, step): the
+    loaded values are copied into them.  torch's load_state_dict installs fresh tensors; a HIP graph captured earlier (the fused clip+Adam
+    kernels, or torch's capturable Adam) would go on updating the old, by then freed, buffers."""
+    old = {p: dict(st) for p, st in optimizer.state.items()}
+    optimizer.load_state_dict(state_dict)
+    for p, st in optimizer.state.items():
+        for k, v in old.get(p, {}).items():
+            new = st.get(k)
+            if torch.is_tensor(v) and torch.is_tensor(new) and new is not v and new.shape == v.shape:
+                v.copy_(new)
+                st[k] = v
+
+
 class no_gc:
     """Python's cyclic garbage collector off for the duration of a stream capture: a collection that happens to run inside the capture may
     finalise device objects of EARLIER captures / runners (graphs, streams, events), which the HIP runtime answers with an abort.

@@ -20,7 +20,7 @@ import yaml
 
 from ...utils.helpers import class_to_dict
 from ..algorithms import PPO
-from ..algorithms._graph import no_gc, strict_graphs
+from ..algorithms._graph import load_optimizer_state, no_gc, strict_graphs
 from ..env import missing_members
 from ..modules import ActorCritic
 
@@ -344,7 +344,7 @@ class OnPolicyRunner:
         d = torch.load(path, map_location=self.device)
         self.alg.actor_critic.load_state_dict(d["model_state_dict"])
         if load_optimizer:
-            self.alg.optimizer.load_state_dict(d["optimizer_state_dict"])
+            load_optimizer_state(self.alg.optimizer, d["optimizer_state_dict"])
             self.alg.rebind_lr()
         self.current_learning_iteration = d["iter"]
         return d["infos"]

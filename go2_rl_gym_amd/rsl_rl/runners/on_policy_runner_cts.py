@@ -12,6 +12,7 @@ import torch
 
 from ..algorithms import CTS, ACMoECTS, DualMoECTS, MCPCTS, MoECTS, MoENGCTS
 from ..modules import ActorCriticACMoECTS, ActorCriticCTS, ActorCriticDualMoECTS, ActorCriticMCPCTS, ActorCriticMoECTS, ActorCriticMoENGCTS
+from ..algorithms._graph import load_optimizer_state
 from .on_policy_runner import OnPolicyRunner
 
 _POLICIES = {"ActorCriticCTS": ActorCriticCTS, "ActorCriticMoECTS": ActorCriticMoECTS, "ActorCriticMoENGCTS": ActorCriticMoENGCTS,
@@ -110,8 +111,8 @@ class OnPolicyRunnerCTS(OnPolicyRunner):
         d = torch.load(path, map_location=self.device)
         self.alg.model.load_state_dict(d["model_state_dict"])
         if load_optimizer:
-            self.alg.optimizer1.load_state_dict(d["optimizer1_state_dict"])
-            self.alg.optimizer2.load_state_dict(d["optimizer2_state_dict"])
+            load_optimizer_state(self.alg.optimizer1, d["optimizer1_state_dict"])
+            load_optimizer_state(self.alg.optimizer2, d["optimizer2_state_dict"])
             self.alg.rebind_lr()
         self.current_learning_iteration = d["iter"]
         return d["infos"]

@@ -57,3 +57,29 @@ def test_unsupported_configurations_fall_back():
     for q in many:
         q.grad = torch.randn_like(q)
     assert f.usable and f.step() is False                                                                 # more tensors than GO2_ADAM_MAX_TENSORS
+
+
+def test_load_optimizer_state_keeps_addresses():
+    """A checkpoint loaded into a runner that has already trained (captured HIP graphs hold the addresses of exp_avg / exp_avg_sq / step):
+    the values are the checkpoint's, the tensors are the ones that existed (runners/on_policy_runner.py:load)."""
+    import torch
+    from go2_rl_gym_amd.rsl_rl.algorithms._graph import load_optimizer_state
+    torch.manual_seed(0)
+    net = torch.nn.Linear(5, 3)
+    lr = torch.tensor(1e-3)
+    opt = torch.optim.Adam(net.parameters(), lr=lr, capturable=False)
+    for _ in range(3):
+        net(torch.randn(7, 5)).square().sum().backward(); opt.step(); opt.zero_grad()
+    saved = {k: ({kk: (vv.clone() if torch.is_tensor(vv) else vv) for kk, vv in v.items()} if isinstance(v, dict) else v) for k, v in opt.state_dict()["state"].items()}
+    sd = {"state": saved, "param_groups": opt.state_dict()["param_groups"]}
+    for _ in range(2):
+        net(torch.randn(7, 5)).square().sum().backward(); opt.step(); opt.zero_grad()
+    before = {p: {k: v for k, v in st.items()} for p, st in opt.state.items()}
+    load_optimizer_state(opt, sd)
+    for i, (p, st) in enumerate(opt.state.items()):
+        for k, v in st.items():
+            assert v is before[p][k], (i, k)                                  # same tensor object, same address
+            assert torch.equal(v, saved[i][k]), (i, k)                        # the checkpoint's values
+    fresh = torch.optim.Adam(torch.nn.Linear(5, 3).parameters(), lr=1e-3)     # no state yet: plain load_state_dict behaviour
+    load_optimizer_state(fresh, sd)
+    assert all(torch.equal(st["exp_avg"], saved[i]["exp_avg"]) for i, st in enumerate(fresh.state.values()))
