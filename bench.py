@@ -48,7 +48,7 @@ def parse():
     return p.parse_args()
 
 
-CPU_THREADS = 16
+CPU_THREADS = 16          # default OpenMP / torch thread count outside the sweep (N = 64: more only oversubscribes 64 envs)
 
 
 def _cpu_model():
@@ -61,24 +61,63 @@ def _cpu_model():
     return "unknown"
 
 
+def _physical_cores():
+    """distinct (physical id, core id) pairs of /proc/cpuinfo; os.cpu_count() when that cannot be read"""
+    try:
+        seen, phys = set(), None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                seen.add((phys, line.split(":", 1)[1].strip()))
+        return len(seen) or (os.cpu_count() or 1)
+    except OSError:
+        return os.cpu_count() or 1
+
+
+def _set_cpu_threads(n):
+    """OpenMP threads of the oracle (libgomp is already loaded: omp_set_num_threads, not the environment) and torch's intra-op threads"""
+    import torch
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+    except OSError:
+        pass
+    torch.set_num_threads(int(n))
+
+
 def cpu_baseline(task="go2_flat", sizes=(64, NUM_ENVS), iters=3):
     """The same PPO iteration on the host CPU: the plain-C oracle (OpenMP over envs) as the env + torch-CPU PPO, at
-    N = 64 (BASELINE config 1) and N = 4096 (the headline size), `iters` timed iterations each after one warm-up iteration, collection-only
-    and total.  The reference's own --sim_device=cpu path cannot run anywhere (Isaac Gym is absent), so this is the build's CPU
-    restatement of the same path ("kind": "port").  Test-infrastructure code, timed only here, never inside the GPU region."""
+    N = 64 (BASELINE config 1) and N = 4096 (the headline size), collection-only and total.  The reference's own --sim_device=cpu path
+    cannot run anywhere (Isaac Gym is absent), so this is the build's CPU restatement of the same path ("kind": "port").
+    At the headline size the thread count is SWEPT (16 / 64 / physical cores / all hardware threads, whichever exist): one warm-up + one timed
+    iteration each, then `iters` timed iterations at the best — the reported value is the host's best, with its thread count next to nproc.
+    Test-infrastructure code, timed only here, never inside the GPU region."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import load_oracle
     from go2_rl_gym_amd.envs import task_registry  # noqa: F401
     from go2_rl_gym_amd.utils import get_args
-    cores = min(os.cpu_count() or 1, CPU_THREADS)     # threads actually used: more only oversubscribes these small problems
-    torch.set_num_threads(cores)
-    per_size = {}
+    nproc, phys = os.cpu_count() or 1, _physical_cores()
+    per_size, sweep = {}, {}
+    best_threads = min(nproc, CPU_THREADS)
     for n in sizes:
         args = get_args(["--task", task, "--num_envs", str(n), "--sim_device", "cpu", "--rl_device", "cpu", "--headless"])
         env, _ = task_registry.make_env(task, args, lib=load_oracle())
         runner, _ = task_registry.make_alg_runner(env, task, args, log_root=None)
-        runner.learn(1, init_at_random_ep_len=True)
+        threads = min(nproc, CPU_THREADS)
+        if n >= 1024:
+            for th in sorted({min(nproc, c) for c in (16, 64, phys, nproc)}):
+                _set_cpu_threads(th)
+                runner.learn(1, init_at_random_ep_len=(not sweep))
+                t0 = time.perf_counter()
+                runner.learn(1)
+                dt = time.perf_counter() - t0
+                sweep[str(th)] = {"env_steps_per_s": n * 24 / dt, "collection_only_env_steps_per_s": n * 24 / runner.last_collection_time}
+            threads = best_threads = int(max(sweep, key=lambda k: sweep[k]["env_steps_per_s"]))
+            _set_cpu_threads(threads)
+        else:
+            _set_cpu_threads(threads)
+            runner.learn(1, init_at_random_ep_len=True)
         tot = col = 0.0
         for _ in range(iters):
             t0 = time.perf_counter()
@@ -86,12 +125,14 @@ def cpu_baseline(task="go2_flat", sizes=(64, NUM_ENVS), iters=3):
             tot += time.perf_counter() - t0
             col += runner.last_collection_time
         env.close()
-        per_size[str(n)] = {"env_steps_per_s": n * 24 * iters / tot, "collection_only_env_steps_per_s": n * 24 * iters / col, "iterations": iters, "seconds": tot}
+        per_size[str(n)] = {"env_steps_per_s": n * 24 * iters / tot, "collection_only_env_steps_per_s": n * 24 * iters / col, "iterations": iters, "seconds": tot, "threads": threads}
     head = per_size[str(sizes[-1])]
-    return {"value": head["env_steps_per_s"], "unit": "env-steps/s", "cores": cores, "kind": "port", "nproc": os.cpu_count(), "omp_threads": int(os.environ.get("OMP_NUM_THREADS", cores)),
-            "torch_threads": cores, "cpu_model": _cpu_model(), "collection_only": head["collection_only_env_steps_per_s"], "per_num_envs": per_size,
-            "sample": "oracle env (plain C, OpenMP) + torch-CPU PPO; full PPO iterations (24 steps + GAE + 5x4 mini-batches), %d timed after 1 warm-up, at num_envs = %s; "
-                      "value = the num_envs=%d line (the headline size)" % (iters, " and ".join(str(n) for n in sizes), sizes[-1])}
+    return {"value": head["env_steps_per_s"], "unit": "env-steps/s", "cores": best_threads, "kind": "port", "nproc": nproc, "physical_cores": phys, "omp_threads": best_threads,
+            "torch_threads": best_threads, "cpu_model": _cpu_model(), "collection_only": head["collection_only_env_steps_per_s"], "per_num_envs": per_size,
+            "thread_sweep_at_%d" % sizes[-1]: sweep,
+            "sample": "oracle env (plain C, OpenMP) + torch-CPU PPO; full PPO iterations (24 steps + GAE + 5x4 mini-batches) at num_envs = %s; at num_envs=%d the "
+                      "OpenMP/torch thread count is swept (1 warm-up + 1 timed iteration each) and value = %d timed iterations at the best count (`cores`); "
+                      "num_envs=64 runs with %d threads" % (" and ".join(str(n) for n in sizes), sizes[-1], iters, min(nproc, CPU_THREADS))}
 
 
 def main():
@@ -211,8 +252,11 @@ def main():
             per_env = sq["SQ_INSTS_VALU"] * 64 / sq["num_envs"]
             valu = {"lane_instr_per_env_step": per_env, "achieved_Tlane_ops": per_env * N / (k_ms * 1e-3) / 1e12, "peak_Tlane_ops": 1024 * 16 * 2.4e9 / 1e12,
                     "frac": per_env * N / (k_ms * 1e-3) / (1024 * 16 * 2.4e9), "wave_cycles_waiting_frac": sq.get("SQ_WAIT_ANY", 0) / max(sq.get("SQ_WAVE_CYCLES", 1), 1),
-                    "vgpr": sq.get("vgpr"), "agpr": sq.get("agpr"), "scratch_bytes_per_lane": sq.get("scratch_bytes_per_lane"), "source": os.path.relpath(f, ROOT)}
+                    "source": os.path.relpath(f, ROOT)}
             break
+        # registers / scratch / LDS as the loaded library's CODE OBJECT states them (llvm-readelf --notes of the unbundled gfx950 object)
+        from go2_rl_gym_amd import build as _build
+        code_object = _build.kernel_resources(_lib.HIP_LIB)
         out = {
             "metric": "env-steps/sec at 4096 envs (go2 flat); 1/2/4/8-GPU scaling", "value": total_steps / elapsed, "unit": "env-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
@@ -228,8 +272,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "go2_step_kernel<PHYS|POST>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note, "lib_sha256_16": lib_sha, "algorithmic_bytes_per_launch": algo * N, "kernel_ms": k_ms, "launches": n.value, "algorithmic_bytes_per_env_step": algo,
                          "note": "latency-bound by construction: 4096 envs x 16 lanes = 1024 waves = one wave per SIMD; the binding resource is the dependent-issue "
-                                 "latency of ~18k dependent VALU instructions per wave per step, not HBM (DESIGN.md 6)",
-                         "valu_issue": valu},
+                                 "latency of the ~16k instructions a wave executes per step, not HBM (DESIGN.md 6)",
+                         "code_object": code_object, "valu_issue": valu},
         }
         if world == 1 and not a.no_cpu_baseline:
             try:

@@ -18,7 +18,10 @@ OUT = os.path.join(HERE, "libgo2sim_hip.so")
 #   oracle to 1e-5 (bisected on an MI355X, round 2: tools/debug_parity.py over -O1 / -O2 / -O3 x {slp, no-slp, noinline} builds).
 #   The GPU parity tests (tests/test_gpu_parity.py::test_one_step_parity_vs_oracle) are what catches a regression here.  Packed f32 VALU
 #   is no gain for this latency-bound kernel anyway.
-STRUCTURAL_FLAGS = ["-fno-slp-vectorize"]
+# -cuid=go2sim: hipcc derives a "compilation unit id" from the source PATH and bakes it into ~750 bytes of symbol names; fixed, the library is
+#   byte-identical wherever the tree is checked out, so the sha256 that keys profiles/*_pmc / *_sq files to a binary (bench.py
+#   roofline.lib_sha256_16) is reproducible by anyone who rebuilds (checked: /root/repo vs a copy under /tmp).
+STRUCTURAL_FLAGS = ["-fno-slp-vectorize", "-cuid=go2sim"]
 EXTRA_FLAGS = os.environ.get("GO2_HIPCC_FLAGS", "-ffast-math").split() + STRUCTURAL_FLAGS
 
 
@@ -66,5 +69,41 @@ def build_hip(force=False, verbose=False, out=OUT, flags=None):
     return OUT
 
 
+def kernel_resources(so_path=OUT, match="go2_step_kernelILi3E"):
+    """Register / scratch / LDS use of a kernel as the CODE OBJECT inside the shared library states it (the .note metadata the loader and
+    the dispatcher act on): unbundle the gfx950 code object (llvm-objdump --offloading), read its notes (llvm-readelf --notes).
+    -> {"vgpr_count" (the unified VGPR + AGPR allocation request), "agpr_count", "arch_vgpr_count", "sgpr_count", "scratch_bytes_per_lane",
+        "lds_bytes_per_workgroup", "waves_per_simd"} of the first kernel whose mangled name contains `match`, or None when the LLVM tools are missing."""
+    import re
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    objdump, readelf = os.path.join(llvm, "llvm-objdump"), os.path.join(llvm, "llvm-readelf")
+    if not (os.path.exists(objdump) and os.path.exists(readelf) and os.path.exists(so_path)):
+        return None
+    with tempfile.TemporaryDirectory() as td:
+        tmp = os.path.join(td, "lib.so")
+        shutil.copy(so_path, tmp)
+        if subprocess.run([objdump, "--offloading", tmp], capture_output=True, text=True, cwd=td).returncode != 0:
+            return None
+        co = [f for f in os.listdir(td) if "amdgcn" in f]
+        if not co:
+            return None
+        notes = subprocess.run([readelf, "--notes", os.path.join(td, co[0])], capture_output=True, text=True).stdout
+    # the metadata is a YAML list of kernels; one entry runs from "- .agpr_count" (keys are sorted) to the next
+    for ent in re.split(r"\n\s*- \.agpr_count:", "\n" + notes)[1:]:
+        ent = ".agpr_count:" + ent
+        name = re.search(r"\.name:\s+(\S+)", ent)
+        if not name or match not in name.group(1):
+            continue
+        g = lambda key: int(re.search(r"\.%s:\s+(\d+)" % key, ent).group(1))
+        total, agpr = g("vgpr_count"), g("agpr_count")
+        alloc = (total + 7) // 8 * 8
+        return {"kernel": name.group(1), "vgpr_count": total, "agpr_count": agpr, "arch_vgpr_count": total - agpr, "sgpr_count": g("sgpr_count"),
+                "scratch_bytes_per_lane": g("private_segment_fixed_size"), "lds_bytes_per_workgroup": g("group_segment_fixed_size"),
+                "waves_per_simd": max(1, min(8, 512 // alloc))}
+    return None
+
+
 if __name__ == "__main__":
     print(build_hip(force=True, verbose=True))
+    print(kernel_resources())

@@ -19,7 +19,8 @@
 //              unconstrained end-of-substep velocities; each sub-lane keeps ITS 3 rows of the map row -> response ([A^-1 | 0], Phi rows)
 //   C. (lane)  contact candidates (foot sphere; deepest of the other leg/base spheres), joint-limit rows; per row the lane's slice of
 //              J = [Jc | G] and Y = [Z | H] (Z = A^-1 Jc^T, G = Ec + Jc N, H = Phi G), the diagonal by a quad sum
-//      (row)   projected Gauss-Seidel, legs take turns, the base-twist slices broadcast to the other legs after each turn
+//      (row)   projected block iteration: all four legs sweep their own rows (Gauss-Seidel inside a leg) at once, each on its copy of the
+//              base-twist slices with the base split n ways (mass splitting); one leg sum per slice and iteration commits the true responses
 //   D. (lane, replicated) velocities, semi-implicit Euler integration, contact forces
 #pragma once
 #include "go2_math.h"

@@ -550,7 +550,7 @@ __global__ void __launch_bounds__(256) go2_adam_step_kernel(const Go2AdamLaunch 
   const float norm = sqrtf((sh[0] + sh[1]) + (sh[2] + sh[3]));
   const float coef = fminf(max_norm / (norm + 1e-6f), 1.f);
   const int i = adam_locate(a, blockIdx.x), off = (blockIdx.x - a.first[i]) * GO2_ADAM_CHUNK, n = min(GO2_ADAM_CHUNK, a.t.numel[i] - off);
-  const float t = a.t.step[0][0] + 1.f;                 // (read by every block before block 0 of the LAST tensor's chunk writes: see below)
+  const float t = a.t.step[i][0] + 1.f;                 // this tensor's own step count, as torch.optim.Adam keeps it (advanced by go2_adam_count_kernel afterwards)
   // the bias corrections in fp64, as torch forms them: 1 - 0.999^t cancels to ~1e-3 in the first steps
   const float bc1 = (float)(1.0 - pow(beta1d, (double)t)), bc2s = (float)sqrt(1.0 - pow(beta2d, (double)t)), step_size = lr[0] / bc1;
   float* p = a.t.param[i] + off; float* m = a.t.exp_avg[i] + off; float* v = a.t.exp_avg_sq[i] + off; const float* g = a.t.grad[i] + off;
@@ -1412,9 +1412,10 @@ int go2sim_adam_clip_step(const Go2AdamTensors* t, float* lr, const float* kl_me
   (void)stream; (void)workspace;
   if (kl_mean) { const float kl = *kl_mean, r = *lr; *lr = kl > desired_kl * 2.f ? fmaxf(1e-5f, r / 1.5f) : ((kl < desired_kl / 2.f && kl > 0.f) ? fminf(1e-2f, r * 1.5f) : r); }
   double ss = 0; for (int i = 0; i < t->count; ++i) for (int k = 0; k < t->numel[i]; ++k) ss += (double)t->grad[i][k] * t->grad[i][k];
-  const float coef = fminf(max_grad_norm / ((float)sqrt(ss) + 1e-6f), 1.f), st = t->step[0][0] + 1.f;
-  const float bc1 = (float)(1.0 - pow(beta1_, (double)st)), bc2s = (float)sqrt(1.0 - pow(beta2_, (double)st)), step_size = *lr / bc1;
+  const float coef = fminf(max_grad_norm / ((float)sqrt(ss) + 1e-6f), 1.f);
   for (int i = 0; i < t->count; ++i) {
+    const float st = t->step[i][0] + 1.f;
+    const float bc1 = (float)(1.0 - pow(beta1_, (double)st)), bc2s = (float)sqrt(1.0 - pow(beta2_, (double)st)), step_size = *lr / bc1;
     for (int k = 0; k < t->numel[i]; ++k) {
       const float gk = t->grad[i][k] * coef; float& m = t->exp_avg[i][k]; float& v = t->exp_avg_sq[i][k];
       m += (gk - m) * omb1; v = beta2 * v + omb2 * gk * gk;

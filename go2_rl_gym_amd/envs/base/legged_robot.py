@@ -345,10 +345,21 @@ class LeggedRobot(BaseTask):
         rollout (optional, this build's runners): dict with the destinations of one policy step's bookkeeping (go2sim_step_rollout) —
         `obs_out` / `priv_out`: float32 [N,45] / [N,263] tensors (the next rollout-storage rows) that receive the observations INSTEAD of
         obs_buf / privileged_obs_buf and are what this call returns; `values` [N], `rewards_out` [N], `dones_out` [N] uint8, `gamma`: the
-        transition store with the time-out bootstrap (ppo.py:104-114).  extras['transition_stored'] tells the algorithm it is done."""
+        transition store with the time-out bootstrap (ppo.py:104-114).  extras['transition_stored'] tells the algorithm it is done.
+        The bootstrap `+ gamma * V * time_out` is applied only with cfg.env.send_timeouts, i.e. when the reference's infos carry
+        'time_outs' (ppo.py:107).  CONTRACT of the redirected form: obs_buf / privileged_obs_buf are NOT written by such a step (the
+        rows handed in are), so get_observations() is stale until a plain step() or the last step of the rollout, which has no next row.
+        A destination this call cannot write in place (other device, dtype or stride) makes it fall back to the plain step(); the
+        caller then sees extras without 'transition_stored' and does its own copies."""
         a = actions
         if a.dtype != torch.float32 or not a.is_contiguous() or str(a.device) != str(self.obs_buf.device):
             a = a.to(device=self.obs_buf.device, dtype=torch.float32).contiguous()
+        if rollout is not None:
+            for name in ("obs_out", "priv_out", "values", "rewards_out", "dones_out"):
+                t = rollout.get(name)
+                if t is not None and not (t.is_contiguous() and t.device == self.obs_buf.device and t.dtype == (torch.uint8 if name == "dones_out" else torch.float32)):
+                    rollout = None
+                    break
         if rollout is None:
             _abi.check(self.lib, self.lib.go2sim_step(self.handle, C.c_void_p(a.data_ptr()), self._stream()), "go2sim_step")
             self._publish_extras()
@@ -359,8 +370,9 @@ class LeggedRobot(BaseTask):
         keep = []
         for name, ctype in (("obs_out", fp), ("priv_out", fp), ("values", fp), ("rewards_out", fp), ("dones_out", bp)):
             t = rollout.get(name)
+            if name == "values" and not self.cfg.env.send_timeouts:
+                t = None                                        # no 'time_outs' in infos -> no bootstrap (ppo.py:107-108)
             if t is not None:
-                assert t.is_contiguous() and t.device == self.obs_buf.device and t.dtype == (torch.uint8 if ctype is bp else torch.float32), name
                 keep.append(t)
                 setattr(o, name, C.cast(C.c_void_p(t.data_ptr()), ctype))
         o.gamma = float(rollout.get("gamma", 0.0))

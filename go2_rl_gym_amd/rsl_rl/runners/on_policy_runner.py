@@ -118,7 +118,11 @@ class OnPolicyRunner:
         self._returns_graph = None
         # one policy step = { policy kernels, ONE env library call }: observations land in the next storage rows, the transition store rides in
         # the step kernel (go2sim_step_rollout); GO2_FUSE_STEP=0 restores copy + store launches
-        self._fuse_step = bool(on_gpu or os.environ.get("GO2_FUSE_STEP") == "1") and os.environ.get("GO2_FUSE_STEP", "1") != "0" and hasattr(self.env, "_info_ring")
+        # (only when the storage rows are tensors the env kernel can write: same device as the env; LeggedRobot.step falls back to the plain
+        # step for any destination it cannot write in place)
+        same_dev = torch.device(device) == torch.device(getattr(env, "device", device))
+        self._fuse_step = (bool(on_gpu or os.environ.get("GO2_FUSE_STEP") == "1") and os.environ.get("GO2_FUSE_STEP", "1") != "0" and hasattr(self.env, "_info_ring")
+                           and same_dev)
         N, T = self.env.num_envs, self.num_steps_per_env
         self._rewbuffer, self._lenbuffer = deque(maxlen=100), deque(maxlen=100)
         z = lambda *s_, **k: torch.zeros(*s_, device=self.device, **k)
@@ -206,6 +210,7 @@ class OnPolicyRunner:
         tot_iter = start_iter + num_learning_iterations
         it = start_iter
         gpu_clock = str(self.device).startswith("cuda")
+        self._tot_time_at_start = self.tot_time         # tot_time accumulates over learn() calls; the ETA is about THIS call
         self._sync()
         for it in range(start_iter, tot_iter):
             # collection / learning time as the reference logs them (on_policy_runner.py:133,154-155,162-163).  On the GPU the split point is a
@@ -333,7 +338,7 @@ class OnPolicyRunner:
         s += ep_string
         s += (f"""{'-' * width}\n{'Total timesteps:':>{pad}} {self.tot_timesteps}\n{'Iteration time:':>{pad}} {iteration_time:.2f}s\n"""
               f"""{'Total time:':>{pad}} {self.tot_time:.2f}s\n"""
-              f"""{'ETA:':>{pad}} {self.tot_time / (locs['it'] - locs['start_iter'] + 1) * (locs['tot_iter'] - locs['it']):.1f}s\n""")
+              f"""{'ETA:':>{pad}} {(self.tot_time - self._tot_time_at_start) / (locs['it'] - locs['start_iter'] + 1) * (locs['tot_iter'] - locs['it'] - 1):.1f}s\n""")
         print(s)
 
     def save(self, path, it=None, last_model=False, infos=None):

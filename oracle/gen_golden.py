@@ -679,7 +679,10 @@ def main():
         ref = subprocess.run(["git", "-C", "/root/reference", "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or "snapshot 2026-02-20 (no git metadata)"
     except Exception:
         ref = "snapshot 2026-02-20"
-    json.dump({"generator": "oracle/gen_golden.py", "reference": "wty-yy/go2_rl_gym @ " + ref, "torch": torch.__version__, "numpy": np.__version__, "files": files},
+    notes = {"pretrained_go2_cts_150k.npz": "holds the reference's TRAINED policy weights (deploy/pre_train/go2/go2_cts_150k.pt: student_encoder + actor tensors) next to its "
+             "input/output vectors — fixture DATA for the behavioural test of the physics model (tests/test_export.py, tests/test_gpu_parity.py: a PhysX-trained policy walks "
+             "in this simulator); read only by tests, never by anything under go2_rl_gym_amd/, bench.py's timed region or smoke()'s product path"}
+    json.dump({"generator": "oracle/gen_golden.py", "reference": "wty-yy/go2_rl_gym @ " + ref, "torch": torch.__version__, "numpy": np.__version__, "files": files, "notes": notes},
               open(os.path.join(OUT, "MANIFEST.json"), "w"), indent=1)
     for f in files:
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

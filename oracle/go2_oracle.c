@@ -1397,8 +1397,9 @@ int go2sim_adam_clip_step(const Go2AdamTensors* t, float* lr, const float* kl_me
     *lr = (float)r; }
   double ss=0; for (int i=0;i<t->count;++i) for (int k=0;k<t->numel[i];++k) ss += (double)t->grad[i][k]*(double)t->grad[i][k];
   double coef = (double)max_grad_norm/(sqrt(ss)+1e-6); if (coef > 1.0) coef = 1.0;
-  double st = (double)t->step[0][0]+1.0, bc1 = 1.0-pow((double)beta1,st), bc2 = 1.0-pow((double)beta2,st), step_size = (double)*lr/bc1;
   for (int i=0;i<t->count;++i) {
+    /* every tensor's own step count, as torch.optim.Adam keeps it (a parameter that got no gradient in some step lags behind) */
+    double st = (double)t->step[i][0]+1.0, bc1 = 1.0-pow((double)beta1,st), bc2 = 1.0-pow((double)beta2,st), step_size = (double)*lr/bc1;
     for (int k=0;k<t->numel[i];++k) {
       double g = (double)t->grad[i][k]*coef, m = (double)t->exp_avg[i][k], v = (double)t->exp_avg_sq[i][k];
       m = m + (g-m)*(1.0-(double)beta1); v = (double)beta2*v + (1.0-(double)beta2)*g*g;

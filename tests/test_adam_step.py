@@ -45,6 +45,31 @@ def test_fused_clip_adam_matches_torch(which):
     assert set(oa.state_dict()["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}      # the torch optimizer's own state: checkpoints unchanged
 
 
+@pytest.mark.parametrize("which", ["oracle", "lane_emulation"])
+def test_per_tensor_step_counters(which):
+    """A parameter that gets no gradient in some step (an unused branch under zero_grad(set_to_none=True)) keeps its own step count in
+    torch.optim.Adam, and with it its own bias corrections: the fused kernel reads step[i] per tensor."""
+    lib = load_oracle() if which == "oracle" else load_emu()
+    torch.manual_seed(1)
+    pa = [torch.nn.Parameter(torch.randn(40, 7) * 0.1), torch.nn.Parameter(torch.randn(9) * 0.1), torch.nn.Parameter(torch.randn(5, 5) * 0.1)]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = torch.optim.Adam(pa, lr=torch.tensor(1e-3), foreach=False)
+    ob = torch.optim.Adam(pb, lr=1e-3)
+    fa = FusedClipAdam(lib, oa, pa, 1e9)
+    for it in range(5):
+        for k, (a, b) in enumerate(zip(pa, pb)):
+            if k == 1 and it in (1, 2):              # tensor 1 sits out two steps
+                a.grad = b.grad = None
+                continue
+            g = torch.randn_like(a) * 1e-2
+            a.grad, b.grad = g.clone(), g.clone()
+        assert fa.step()
+        ob.step()
+        for a, b in zip(pa, pb):
+            np.testing.assert_allclose(a.detach().numpy(), b.detach().numpy(), atol=2e-7, rtol=2e-6)
+    assert [float(oa.state[a]["step"]) for a in pa] == [5.0, 3.0, 5.0]
+
+
 def test_unsupported_configurations_fall_back():
     lib = load_oracle()
     p = [torch.nn.Parameter(torch.randn(8))]

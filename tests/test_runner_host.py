@@ -12,9 +12,11 @@ from go2_rl_gym_amd.utils import get_args
 from go2_rl_gym_amd.utils.helpers import get_load_path
 
 
-def _make(tmp, *extra, task="go2_flat"):
+def _make(tmp, *extra, task="go2_flat", send_timeouts=True):
     args = get_args(["--task", task, "--num_envs", "16", "--headless", "--sim_device", "cpu", "--rl_device", "cpu", "--seed", "5", *extra])
-    env, _ = task_registry.make_env(task, args, lib=load_oracle())
+    env_cfg, _ = task_registry.get_cfgs(task)
+    env_cfg.env.send_timeouts = send_timeouts
+    env, _ = task_registry.make_env(task, args, env_cfg=env_cfg, lib=load_oracle())
     runner, train_cfg = task_registry.make_alg_runner(env, task, args, log_root=str(tmp))
     return env, runner, train_cfg
 
@@ -172,8 +174,8 @@ def test_reset_idx_subset_control_types_and_command_curriculum_through_the_host_
         task_registry.make_env("go2_flat", args, env_cfg=env_cfg, lib=load_oracle())
 
 
-@pytest.mark.parametrize("task", ["go2_flat", "go2_flat_cts"])
-def test_fused_rollout_step_fills_the_same_storage(tmp_path, monkeypatch, task):
+@pytest.mark.parametrize("task,send_timeouts", [("go2_flat", True), ("go2_flat_cts", True), ("go2_flat", False)])
+def test_fused_rollout_step_fills_the_same_storage(tmp_path, monkeypatch, task, send_timeouts):
     """LeggedRobot.step(rollout=...) (go2sim_step_rollout: observations written straight into the next storage rows, reward bootstrap + done
     rows stored by the env step, extras ring slot filled by the library) against the copy / store formulation of the same rollout
     (on_policy_runner.py:135-153, ppo.py:90-114): identical storage, identical extras."""
@@ -181,7 +183,8 @@ def test_fused_rollout_step_fills_the_same_storage(tmp_path, monkeypatch, task):
     for fuse in ("0", "1"):
         monkeypatch.setenv("GO2_FUSE_STEP", fuse)
         torch.manual_seed(3)
-        env, runner, _ = _make(tmp_path / fuse, task=task)
+        env, runner, _ = _make(tmp_path / fuse, task=task, send_timeouts=send_timeouts)
+        assert ("time_outs" in env.extras) == send_timeouts   # without it the reference does not bootstrap (ppo.py:107): neither may the fused store
         runner.alg.fused_rollout = True                       # the library heads (default on the GPU only)
         assert runner._fuse_step == (fuse == "1")
         env.episode_length_buf[:] = torch.randint(1200, 1250, (env.num_envs,))       # time-outs inside the rollout: the bootstrap term matters
@@ -197,3 +200,5 @@ def test_fused_rollout_step_fills_the_same_storage(tmp_path, monkeypatch, task):
         if torch.is_tensor(res["0"][k]):
             assert torch.equal(res["0"][k].float().nan_to_num(-7.0), res["1"][k].float().nan_to_num(-7.0)), k      # (NaN = terrain kinds without envs)
     assert res["0"]["dones"].sum() > 0
+    if not send_timeouts:     # the rewards stored are the env's own: no gamma * V added on the time-outs
+        assert res["1"]["timeouts"] > 0
