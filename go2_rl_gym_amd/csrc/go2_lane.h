@@ -17,8 +17,11 @@
 //      (row)   sum {Ic_leg (10), K (21), F_leg (6), r (6)} over the 4 legs                     <- DPP row rotations
 //   B. (lane, replicated) base articulated inertia IA = I_base + sum Ic - sum K, Phi = IA^-1, base and joint accelerations,
 //              unconstrained end-of-substep velocities; each sub-lane keeps ITS 3 rows of the map row -> response ([A^-1 | 0], Phi rows)
-//   C. (lane)  contact candidates (foot sphere; deepest of the other leg/base spheres), joint-limit rows; per row the lane's slice of
-//              J = [Jc | G] and Y = [Z | H] (Z = A^-1 Jc^T, G = Ec + Jc N, H = Phi G), the diagonal by a quad sum
+//   C. (lane)  contact candidates — per leg one slot per BODY GROUP: the foot sphere, the deepest calf sphere, the deepest thigh point, the
+//              deepest hip sphere, the deepest of the leg's share of the base / head points (so a base contact is never shadowed by a leg
+//              link and thigh / calf report independently) — and joint-limit rows; per row the lane's slice of J = [Jc | G] and
+//              Y = [Z | H] (Z = A^-1 Jc^T, G = Ec + Jc N, H = Phi G), the diagonal by a quad sum.  The foot's rows stay in registers; the
+//              other slots' rows are parked in LDS (Go2RowsLds) and pass through ONE register-resident slot while they are swept
 //      (row)   projected block iteration: all four legs sweep their own rows (Gauss-Seidel inside a leg) at once, each on its copy of the
 //              base-twist slices with the base split n ways (mass splitting); one leg sum per slice and iteration commits the true responses
 //   D. (lane, replicated) velocities, semi-implicit Euler integration, contact forces
@@ -73,6 +76,29 @@ struct LegLoop {
   }
 };
 
+// one collision candidate as the tournaments carry it: gap, scan-order index (tie-break), facet normal (world), sphere centre in the base
+// frame, radius, body index
+struct Cand {
+  float g; int i; V3 n, c; float r; int b;
+  GO2_HD void clear() { g = 1e30f; i = 1 << 20; n = v3(0, 0, 1); c = v3(0, 0, 0); r = 0.f; b = 0; }
+  // keep the deeper of the two; ties go to the lower scan-order index (the order of the sequential formulation)
+  GO2_HD void take(bool ok, const Cand& o) {
+    const bool tk = ok && (o.g < g || (o.g == g && o.i < i));
+    g = tk ? o.g : g; i = tk ? o.i : i; n = sel(tk, o.n, n); c = sel(tk, o.c, c); r = tk ? o.r : r; b = tk ? o.b : b;
+  }
+  template <int A, int B, int C_, int D>
+  GO2_HD Cand perm() const {
+    Cand o;
+    o.g = xl::quad_perm<A, B, C_, D>(g); o.i = xl::quad_perm_i<A, B, C_, D>(i);
+    o.n = v3(xl::quad_perm<A, B, C_, D>(n.x), xl::quad_perm<A, B, C_, D>(n.y), xl::quad_perm<A, B, C_, D>(n.z));
+    o.c = v3(xl::quad_perm<A, B, C_, D>(c.x), xl::quad_perm<A, B, C_, D>(c.y), xl::quad_perm<A, B, C_, D>(c.z));
+    o.r = xl::quad_perm<A, B, C_, D>(r); o.b = xl::quad_perm_i<A, B, C_, D>(b);
+    return o;
+  }
+  // two quad-exchange rounds (partner sub ^ 1, then sub ^ 2) carry the deepest candidate of the four sub-lanes to all of them
+  GO2_HD void tournament() { take(true, perm<1, 0, 3, 2>()); take(true, perm<2, 3, 0, 1>()); }
+};
+
 struct LegPhys {
   int leg, sub;
   // ---- state (persistent over the substeps of one step) ----
@@ -87,15 +113,19 @@ struct LegPhys {
   float Ainv[6];  // 11 12 13 22 23 33
   float u[3], qdf[3];
   float Msub[3][6];          // this sub-lane's rows of the response map: sub 0 [A^-1 | 0], sub 1 Phi rows 0..2, sub 2 Phi rows 3..5
-  Row foot[3], other[3], lim[3];
-  float act_foot, act_other, act_lim[3];
+  Row foot[3], cur[3], lim[3];     // cur: the non-foot slot being built / swept (its rows live in LDS otherwise)
+  float act_foot, act_t[GO2_NTYPE], act_lim[3];
+  float lam_t[GO2_NTYPE][3];       // impulses of the non-foot slots (replicated in the quad, like Row.lam)
+  bool near_t[GO2_NTYPE];          // WAVE-UNIFORM: some lane of the wave has a candidate of this group inside the contact margin (rows were built)
+  int32_t base_body;               // body (base, Head_upper, Head_lower) of the base-share slot's contact
+  GO2_AS3 Go2RowsLds* rl; int tid, lid;      // the workgroup's row storage, this lane's index in it and its leg's (tid >> 2)
   float nsplit, yscale;      // solve_prepare: the split n of the base, and this sub-lane's factor on a response slice (1 joint slice, n base slices)
   float s_act;               // how firmly this leg's rows are active, in [0, 1] (solve_prepare: the smooth count of legs sharing the base): 0 at the activation boundary, 1 a quarter margin inside
-  V3 f_n, f_t1, f_t2, o_n, o_t1, o_t2;     // world directions of the two contact frames
+  V3 f_n, f_t1, f_t2;     // world directions of the foot's contact frame
   float x[3];                // this sub-lane's slice of the velocity change: sub 0 z, sub 1 w.ang, sub 2 w.lin
   SV w; float z[3];          // the gathered velocity change (after the solve)
   float tau[3];
-  V3 force_foot, force_other; int32_t other_body;
+  V3 force_foot;
 
   GO2_HD float ainv(int i, int j) const {
     const int idx[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
@@ -251,15 +281,20 @@ struct LegPhys {
     r.lam = lam0;
   }
 
+  // the two tangents of a contact frame: world x made orthogonal to n (world y beside a face that looks along x), and n x t1
+  GO2_HD static void tangents(V3 nw, V3* t1, V3* t2) {
+    const V3 ex = fabsf(nw.x) < 0.9f ? v3(1, 0, 0) : v3(0, 1, 0); const float dnx = dot(ex, nw);
+    V3 t = ex - dnx * nw; t = (1.0f / sqrtf(dot(t, t))) * t;
+    *t1 = t; *t2 = cross(nw, t);
+  }
   // the three rows (normal, two tangents) of a sphere contact: gap, sphere centre cb in the base frame, radius, link (0 base, 1..3), world normal
   template <class LT>
   GO2_HD void build_slot(Row* rows, float* active, V3* dn, V3* dt1, V3* dt2, const LT& L, float gap, V3 cb, float rad, int link, V3 nw, bool warm) {
     const float h = L.sim_dt, cfm1 = 1.0f + L.cfm;
     const float act = gap < L.contact_offset ? 1.f : 0.f;
     *active = act; *dn = nw;
-    V3 ex = fabsf(nw.x) < 0.9f ? v3(1, 0, 0) : v3(0, 1, 0); float dnx = dot(ex, nw);      // first tangent: world x made orthogonal to n (world y beside a face that looks along x)
-    V3 t1 = ex - dnx * nw; t1 = (1.0f / sqrtf(dot(t1, t1))) * t1;
-    *dt1 = t1; *dt2 = cross(nw, t1);
+    V3 t1; tangents(nw, &t1, dt2);
+    *dt1 = t1;
     const V3 dirs[3] = {mulT(Rwb, nw), mulT(Rwb, t1), mulT(Rwb, *dt2)};
     const V3 rb = cb - rad * dirs[0];
     const V3 zero3 = v3(0, 0, 0);
@@ -283,6 +318,47 @@ struct LegPhys {
     }
   }
 
+  // A non-foot slot (body group T): tournament, rows, and the rows' way into LDS
+  template <int T, class LT>
+  GO2_HD void finish_type(const LT& L, Cand b, int link) {
+    near_t[T] = xl::any(b.g < L.contact_offset);
+    act_t[T] = 0.f; lam_t[T][0] = lam_t[T][1] = lam_t[T][2] = 0.f;
+    if (near_t[T]) {
+      b.tournament();
+      s_act = fmaxf(s_act, fminf(fmaxf((L.contact_offset - b.g) / (0.25f * L.contact_offset), 0.f), 1.f));
+      if (T == GO2_T_BASE) base_body = b.b;
+      V3 dn, dt1, dt2;
+      build_slot(cur, &act_t[T], &dn, &dt1, &dt2, L, b.g, b.c, b.r, link, b.n, false);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { rl->jy[T][a][k][tid] = cur[a].J[k]; rl->jy[T][a][3 + k][tid] = cur[a].Y[k]; }
+        rl->dp[T][a][tid] = cur[a].dinv;
+        if (sub == 0) rl->sc[T][a][0][lid] = cur[a].vfb;
+      }
+      if (sub == 0) { rl->nrm[T][0][lid] = dn.x; rl->nrm[T][1][lid] = dn.y; rl->nrm[T][2][lid] = dn.z; }
+    }
+  }
+  template <int T>
+  GO2_HD void load_rows() {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { cur[a].J[k] = rl->jy[T][a][k][tid]; cur[a].Y[k] = rl->jy[T][a][3 + k][tid]; }
+      cur[a].vfb = rl->sc[T][a][0][lid]; cur[a].dinv = rl->sc[T][a][1][lid]; cur[a].lam = lam_t[T][a];
+    }
+  }
+  // net contact force of the slot (world), from its impulses and the stored normal; wave-uniformly skipped when no lane has the slot active
+  template <int T>
+  GO2_HD V3 type_force(float h) const {
+    V3 f = v3(0, 0, 0);
+    if (near_t[T] && xl::any(act_t[T] > 0.f)) {
+      const V3 n = v3(rl->nrm[T][0][lid], rl->nrm[T][1][lid], rl->nrm[T][2][lid]); V3 t1, t2; tangents(n, &t1, &t2);
+      f = (act_t[T] / h) * (lam_t[T][0] * n + lam_t[T][1] * t1 + lam_t[T][2] * t2);
+    }
+    return f;
+  }
+
   // ------------------------------------------------------------------------------------------------
   template <class LT>
   GO2_HD void phaseC(const LegLoop& t, const LT& L, const GO2_AS1 Go2Cell* cells) {
@@ -294,20 +370,13 @@ struct LegPhys {
       s_act = fminf(fmaxf((L.contact_offset - gap) / (0.25f * L.contact_offset), 0.f), 1.f);
     }
     GO2_MARK(30);
-    // deepest of the other candidates: this sub-lane tests its quarter of the leg's 16 + the leg's share of the base points (table
-    // slots with a fixed link type per slot, go2_tables.h SubCand), then two quad-exchange rounds carry the deepest one — with the
-    // base-frame position, radius, link, body and facet normal it needs for its rows — to all four sub-lanes.  Ties go to the lower
-    // candidate index (the scan order of the sequential formulation).
+    // The other body groups.  Each sub-lane tests its quarter of the leg's 16 non-foot spheres and one of the leg's share of the base / head
+    // points (table slots with a fixed link type per slot, go2_tables.h SubCand: thigh, thigh, calf, calf | hip, base), keeps the deepest PER
+    // GROUP, and a 2-round quad tournament per group carries the group's deepest — with the base-frame position, radius, body and facet
+    // normal its rows need — to all four sub-lanes.  Ties go to the lower candidate index (the scan order of the sequential formulation).
     {
       const SubCand& sc = t.sc;
-      float best = 1e30f; int bi = 1 << 20; V3 bn = v3(0, 0, 1), bcb = v3(0, 0, 0); float brad = 0.f; int blink = 0, bbody = 0;
       const V3 q2 = p2, q3 = p3;
-#define GO2_CAND(k, R, P, LINK) { \
-        const V3 c = v3(sc.pt[k][0], sc.pt[k][1], sc.pt[k][2]); const V3 cbk = P + mul(R, c); \
-        const V3 cw = pw + mul(Rwb, cbk); float gap; V3 n; contact_query(L, cells, cw, sc.pt[k][3], &gap, &n); \
-        const bool tk = sc.idx[k] >= 0 && (gap < best || (gap == best && sc.idx[k] < bi)); \
-        best = tk ? gap : best; bi = tk ? sc.idx[k] : bi; bn = sel(tk, n, bn); bcb = sel(tk, cbk, bcb); brad = tk ? sc.pt[k][3] : brad; \
-        blink = tk ? (LINK) : blink; bbody = tk ? sc.body[k] : bbody; }
       // On the plane a whole link group is skipped when none of its spheres can reach the contact margin in ANY lane of the wave: lowest
       // possible sphere bottom = (link origin height) - sum_axis |world-z component of the link axis| * (group's reach along that axis).
       // Conservative, so skipping cannot change which candidate is inside the margin (only those matter: an inactive slot has no rows).
@@ -320,46 +389,32 @@ struct LegPhys {
         do_hip = xl::any(low(R1, p1, t.cull_ext[0]) < L.contact_offset); do_thigh = xl::any(low(R2, p2, t.cull_ext[1]) < L.contact_offset);
         do_calf = xl::any(low(R3, p3, t.cull_ext[2]) < L.contact_offset); do_base = xl::any(low(Id, v3(0, 0, 0), t.cull_ext[3]) < L.contact_offset);
       }
-      if (do_thigh) { GO2_CAND(0, R2, q2, 2) GO2_CAND(1, R2, q2, 2) }
-      if (do_calf) GO2_CAND(2, R3, q3, 3)
+      auto eval = [&](int k, const M3& R, V3 P) {
+        Cand o; o.c = P + mul(R, v3(sc.pt[k][0], sc.pt[k][1], sc.pt[k][2]));
+        contact_query(L, cells, pw + mul(Rwb, o.c), sc.pt[k][3], &o.g, &o.n);
+        o.i = sc.idx[k]; o.r = sc.pt[k][3]; o.b = sc.body[k];
+        return o; };
+      Cand thigh, calf, hip, base; thigh.clear(); calf.clear(); hip.clear(); base.clear();
+      if (do_thigh) { thigh.take(sc.idx[0] >= 0, eval(0, R2, q2)); thigh.take(sc.idx[1] >= 0, eval(1, R2, q2)); }
+      if (do_calf) calf.take(sc.idx[2] >= 0, eval(2, R3, q3));
       if (do_calf || do_hip) {   // slot 3: a calf point for sub-lanes 0 and 1, a hip point for sub-lanes 2 and 3
         const bool hipk = sub >= 2;
         const M3 Rx = {sel(hipk, R1.x, R3.x), sel(hipk, R1.y, R3.y), sel(hipk, R1.z, R3.z)}; const V3 px = sel(hipk, p1, p3);
-        GO2_CAND(3, Rx, px, hipk ? 1 : 3)
+        const Cand c3 = eval(3, Rx, px);
+        calf.take(!hipk && sc.idx[3] >= 0, c3); hip.take(hipk && sc.idx[3] >= 0, c3);
       }
       if (do_base) {   // slot 4: one of the leg's base / head points (sub-lane < number of points of this leg)
-        const M3 Id = {v3(1, 0, 0), v3(0, 1, 0), v3(0, 0, 1)}; const V3 o = v3(0, 0, 0);
-        GO2_CAND(4, Id, o, 0)
+        const M3 Id = {v3(1, 0, 0), v3(0, 1, 0), v3(0, 0, 1)};
+        base.take(sc.idx[4] >= 0, eval(4, Id, v3(0, 0, 0)));
       }
-#undef GO2_CAND
       GO2_MARK(31);
-      // quad tournament: partner sub^1, then sub^2 (skipped with the rows when nothing in the wave is inside the margin)
-      const bool any_near = xl::any(best < L.contact_offset);
-      if (any_near) {
-#define GO2_ROUND(PERM) { \
-        const float g2 = xl::quad_perm<PERM>(best); const int i2 = xl::quad_perm_i<PERM>(bi); \
-        const bool tk = g2 < best || (g2 == best && i2 < bi); \
-        const float nx = xl::quad_perm<PERM>(bn.x), ny = xl::quad_perm<PERM>(bn.y), nz = xl::quad_perm<PERM>(bn.z); \
-        const float cx = xl::quad_perm<PERM>(bcb.x), cy = xl::quad_perm<PERM>(bcb.y), cz = xl::quad_perm<PERM>(bcb.z); \
-        const float r2 = xl::quad_perm<PERM>(brad); const int l2 = xl::quad_perm_i<PERM>(blink), b2 = xl::quad_perm_i<PERM>(bbody); \
-        best = tk ? g2 : best; bi = tk ? i2 : bi; bn = sel(tk, v3(nx, ny, nz), bn); bcb = sel(tk, v3(cx, cy, cz), bcb); \
-        brad = tk ? r2 : brad; blink = tk ? l2 : blink; bbody = tk ? b2 : bbody; }
-#define GO2_P1 1, 0, 3, 2
-#define GO2_P2 2, 3, 0, 1
-      GO2_ROUND(GO2_P1)
-      GO2_ROUND(GO2_P2)
-      }
-#undef GO2_P1
-#undef GO2_P2
-#undef GO2_ROUND
+      // per group: rows only if some lane of the wave has a candidate inside the contact margin this substep (wave-uniform branch; an
+      // inactive slot's rows are never visited by the solver, so skipping tournament and construction changes no result)
+      finish_type<GO2_T_CALF>(L, calf, 3);
+      finish_type<GO2_T_THIGH>(L, thigh, 2);
+      finish_type<GO2_T_HIP>(L, hip, 1);
+      finish_type<GO2_T_BASE>(L, base, 0);
       GO2_MARK(32);
-      other_body = bbody;
-      // rows only if some lane of the wave has a candidate inside the contact margin this substep (wave-uniform branch; an inactive
-      // slot's rows are never visited by the solver, so skipping their construction changes no result)
-      act_other = best < L.contact_offset ? 1.f : 0.f; o_n = bn; o_t1 = v3(1, 0, 0); o_t2 = v3(0, 1, 0);
-      s_act = fmaxf(s_act, fminf(fmaxf((L.contact_offset - best) / (0.25f * L.contact_offset), 0.f), 1.f));
-      _Pragma("unroll") for (int a = 0; a < 3; ++a) other[a] = Row{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0.f, 0.f, 0.f};
-      if (any_near) build_slot(other, &act_other, &o_n, &o_t1, &o_t2, L, best, bcb, brad, blink, bn, false);
     }
     GO2_MARK(33);
     // joint limits
@@ -392,7 +447,7 @@ struct LegPhys {
     for (int k = 0; k < 3; ++k) { const float s = xl::leg_sum(c[k]); x[k] = sub == 0 ? c[k] : s; }
   }
   GO2_HD bool has_foot() const { return act_foot > 0.f; }
-  GO2_HD bool has_other() const { return act_other > 0.f; }
+  template <int T> GO2_HD bool has_type() const { return act_t[T] > 0.f; }
   GO2_HD bool has_limit() const { return (act_lim[0] + act_lim[1] + act_lim[2]) > 0.f; }
 
   GO2_HD float row_v(const Row& r) const { return r.vfb + xl::sub_sum(r.J[0] * x[0] + r.J[1] * x[1] + r.J[2] * x[2]); }
@@ -416,31 +471,54 @@ struct LegPhys {
     }
   }
   // The contact / limit solve: projected block iteration over the LEGS with mass splitting at the base.  The rows of a
-  // leg are a block, visited in the fixed order foot (n, t), other (n, t), limits (Gauss-Seidel inside the block); ALL FOUR LEGS sweep their
+  // leg are a block, visited in the fixed order foot, calf, thigh, hip, base share (n, t each), limits (Gauss-Seidel inside the block); ALL FOUR LEGS sweep their
   // blocks at once, each from the same state, on its own copy of the base-twist slices.  Legs interact only through the base, and each leg is
   // given 1 / n of it: in ITS view the base slices of every response (sub-lanes 1, 2: H = Phi G) are n times larger, the joint slice (sub-lane
   // 0: Z = A^-1 Jc, the leg's own joints with the base held fixed) is as it is.  Committed are the true responses: z as swept, w <- w0 +
   // (1 / n) sum_legs (w_leg - w0) — one leg sum per slice instead of one per leg turn.  n = the number of legs with active rows, counted
   // smoothly (s_act), so the step stays a continuous function of the state.
   // solve_prepare: n, and the rows' inverse diagonals J . Y_view (1 + cfm) with it.
-  GO2_HD void solve_prepare(bool do_foot, bool do_other, bool do_lim) {
+  // do_t[T]: the slot of body group T (must imply near_t[T]: its rows were built)
+  template <int T>
+  GO2_HD void prepare_type() {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float d_ = xl::sub_sum(rl->dp[T][a][tid] * yscale), di = d_ > 0.f ? 1.0f / d_ : 0.f;
+      if (sub == 0) rl->sc[T][a][1][lid] = di;
+    }
+  }
+  GO2_HD void solve_prepare(bool do_foot, const bool* do_t, bool do_lim) {
     nsplit = fmaxf(xl::leg_sum(s_act), 1.f);
     yscale = sub == 0 ? 1.f : nsplit;
     auto fin = [&](Row& r) { const float d_ = xl::sub_sum(r.dinv * yscale); r.dinv = d_ > 0.f ? 1.0f / d_ : 0.f; };
     if (do_foot) { fin(foot[0]); fin(foot[1]); fin(foot[2]); }
-    if (do_other) { fin(other[0]); fin(other[1]); fin(other[2]); }
+    if (do_t[GO2_T_CALF]) prepare_type<GO2_T_CALF>();
+    if (do_t[GO2_T_THIGH]) prepare_type<GO2_T_THIGH>();
+    if (do_t[GO2_T_HIP]) prepare_type<GO2_T_HIP>();
+    if (do_t[GO2_T_BASE]) prepare_type<GO2_T_BASE>();
     if (do_lim) { fin(lim[0]); fin(lim[1]); fin(lim[2]); }
+    // what sub-lane 0 of a leg parked in LDS (free velocities in phase C, inverse diagonals here) is read by the leg's other sub-lanes
+    if (do_t[0] || do_t[1] || do_t[2] || do_t[3]) xl::row_sync();
+  }
+  template <int T>
+  GO2_HD void sweep_type() {
+    load_rows<T>();
+    sweep_slot(cur, act_t[T], mu);
+    lam_t[T][0] = cur[0].lam; lam_t[T][1] = cur[1].lam; lam_t[T][2] = cur[2].lam;
   }
   // do_* are WAVE-UNIFORM hints: false means no lane of the wave has such a row active this substep, so the group is skipped as a whole
   // (an inactive row moves nothing).
 #ifdef GO2_DBG_NOINLINE_GS
-  __device__ __attribute__((noinline)) void solve_iteration(bool do_foot, bool do_other, bool do_lim) {
+  __device__ __attribute__((noinline)) void solve_iteration(bool do_foot, const bool* do_t, bool do_lim) {
 #else
-  GO2_HD void solve_iteration(bool do_foot, bool do_other, bool do_lim) {
+  GO2_HD void solve_iteration(bool do_foot, const bool* do_t, bool do_lim) {
 #endif
     const float x0[3] = {x[0], x[1], x[2]};
     if (do_foot) sweep_slot(foot, act_foot, mu);
-    if (do_other) sweep_slot(other, act_other, mu);
+    if (do_t[GO2_T_CALF]) sweep_type<GO2_T_CALF>();
+    if (do_t[GO2_T_THIGH]) sweep_type<GO2_T_THIGH>();
+    if (do_t[GO2_T_HIP]) sweep_type<GO2_T_HIP>();
+    if (do_t[GO2_T_BASE]) sweep_type<GO2_T_BASE>();
     if (do_lim)
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
@@ -487,7 +565,6 @@ struct LegPhys {
     for (int j = 0; j < 3; ++j) { qd[j] = qdp[j]; q[j] += h * qdp[j]; }
     float ih = 1.0f / h;
     force_foot = act_foot * ih * (foot[0].lam * f_n + foot[1].lam * f_t1 + foot[2].lam * f_t2);
-    force_other = act_other * ih * (other[0].lam * o_n + other[1].lam * o_t1 + other[2].lam * o_t2);
 #pragma unroll
     for (int a = 0; a < 3; ++a) lam_foot[a] = act_foot * foot[a].lam;
   }

@@ -6,7 +6,8 @@
 #include "../../include/go2_model_data.h"
 
 #define GO2_NLEG_OTHER GO2_LEG_OTHER_PTS
-#define GO2_LANE_BASE_PTS 3
+#define GO2_LANE_BASE_PTS 4   // the base / head points are dealt to the 4 legs (i & 3 == leg) and there to the 4 sub-lanes
+static_assert(GO2_BASE_PTS <= 4 * GO2_LANE_BASE_PTS, "one base point per (leg, sub-lane)");
 // the per-leg candidates are tabulated link by link (gen_go2_model.py emits hip, thigh, calf in this order; checked at create)
 #define GO2_N_HIP_PTS 2
 #define GO2_N_THIGH_PTS 8
@@ -44,6 +45,26 @@ struct BaseTab {
   float body_off[3][4];             // frame origins of base, Head_upper, Head_lower in the base frame
 };
 struct Go2Tables { LegTab leg[4]; BaseTab base; uint8_t slot_code[GO2_NUM_UNIFORMS]; /* include/go2sim_rng.h */ int32_t layout_ok; };
+
+// The contact slots of a leg besides the foot, one per BODY GROUP (go2_lane.h phaseC): the deepest calf sphere, the deepest thigh point, the
+// deepest hip sphere, the deepest of the leg's share of the base / head points.  Their constraint rows live in LDS between their construction
+// and the end of the substep's solve (only the foot's rows and one slot being swept are in registers):
+//   jy  per lane : this sub-lane's 3-number slices J, Y of the slot's three rows (normal, two tangents)
+//   dp  per lane : this sub-lane's part of the row's diagonal (summed over the quad, with the split base, in solve_prepare)
+//   sc  per leg  : [0] free velocity + bias, [1] inverse diagonal (written by solve_prepare)
+//   nrm per leg  : world contact normal (the tangents follow from it)
+#define GO2_NTYPE 4
+#define GO2_T_CALF 0
+#define GO2_T_THIGH 1
+#define GO2_T_HIP 2
+#define GO2_T_BASE 3
+#define GO2_WG_LANES 256
+struct Go2RowsLds {
+  float jy[GO2_NTYPE][3][6][GO2_WG_LANES];
+  float dp[GO2_NTYPE][3][GO2_WG_LANES];
+  float sc[GO2_NTYPE][3][2][GO2_WG_LANES / 4];
+  float nrm[GO2_NTYPE][3][GO2_WG_LANES / 4];
+};
 
 // the contact surface over one grid cell: heights (vscale units) at the corners (i,j) (i+1,j) (i,j+1) (i+1,j+1) as seen from inside the cell
 // (include/go2sim.h Go2SimCfg.hf_cells); one aligned 8-byte load per contact query

@@ -42,6 +42,9 @@ enum { MODE_PHYS = 1, MODE_POST = 2, MODE_RESET_ALL = 4 };
 // Workgroup = 256 threads = 4 waves = 16 environments; one 16-lane DPP row = one environment, row lane = leg * 4 + sub.
 // ------------------------------------------------------------------------------------------------------
 #define GO2_WG_ENVS 16
+#ifndef GO2_OCC2_MIN_ENVS
+#define GO2_OCC2_MIN_ENVS (1 << 30)      // (set from the measured crossover, profiles/r3_kernel_scaling.txt)
+#endif
 #define GO2_WG_THREADS (16 * GO2_WG_ENVS)
 // The lane context is kept as THREE separate objects (not one struct): the compiler's scalar-replacement pass gives up on a
 // single 2.4 KB aggregate with thousands of uses and would leave all of it in scratch memory.
@@ -51,7 +54,9 @@ struct LaneAux { float kp[3], kd[3], q0[3], zoff[3], strength[3], act_new[3], ac
 // LDS: robot link / collision tables (per-lane leg index -> ds_read), this step's scalars, and per environment the table of drawn uniforms
 struct Go2Shared {
   Go2Tables tab; Go2Step S; float ucache[GO2_WG_ENVS][GO2_NUM_GROUPS][4];
+  Go2RowsLds rows;      // constraint rows of the non-foot contact slots (go2_tables.h)
 };
+static_assert(GO2_WG_LANES == GO2_WG_THREADS, "row storage is per lane of the workgroup");
 
 GO2_HD void lane_load_phys(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p, const Go2Launch& L, const Go2Step& S, const float* actions_in, float u_delay, int e, int lane, int sub) {
   const int N = L.N;
@@ -147,17 +152,18 @@ GO2_HD void lane_finish_phys(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& 
     float r13[13] = {pos.x, pos.y, pos.z, ph.qx, ph.qy, ph.qz, ph.qw, lv.x, lv.y, lv.z, ph.ww.x, ph.ww.y, ph.ww.z};
     _Pragma("unroll") for (int i = 0; i < 13; ++i) F3D(p.rigid, 19, lane, i, e) = r13[i];
   }
-  // contact forces of this leg's bodies; base/head parts go through the leg sum
+  // contact forces of this leg's bodies (one slot per body group, go2_lane.h phaseC); base/head parts go through the leg sum
   V3 zero = v3(0, 0, 0);
-  o.Fhip = sel(ph.other_body == t.body_index[0], ph.force_other, zero);
-  o.Fthigh = sel(ph.other_body == t.body_index[1], ph.force_other, zero);
-  o.Fcalf = sel(ph.other_body == t.body_index[2], ph.force_other, zero);
+  o.Fhip = ph.type_force<GO2_T_HIP>(L.sim_dt);
+  o.Fthigh = ph.type_force<GO2_T_THIGH>(L.sim_dt);
+  o.Fcalf = ph.type_force<GO2_T_CALF>(L.sim_dt);
+  const V3 Fbase_share = ph.type_force<GO2_T_BASE>(L.sim_dt);
   o.Ffoot = ph.force_foot;
   {
     const V3 f = sel(sub == 0, o.Fhip, sel(sub == 1, o.Fthigh, sel(sub == 2, o.Fcalf, o.Ffoot)));
     const int b = t.body_index[0] + sub; F3D(p.contact, 19, b, 0, e) = f.x; F3D(p.contact, 19, b, 1, e) = f.y; F3D(p.contact, 19, b, 2, e) = f.z;
   }
-  _Pragma("unroll") for (int b = 0; b < 3; ++b) { V3 f = sel(ph.other_body == b, ph.force_other, zero); fbase[3 * b] = f.x; fbase[3 * b + 1] = f.y; fbase[3 * b + 2] = f.z; }
+  _Pragma("unroll") for (int b = 0; b < 3; ++b) { V3 f = sel(ph.base_body == b, Fbase_share, zero); fbase[3 * b] = f.x; fbase[3 * b + 1] = f.y; fbase[3 * b + 2] = f.z; }
   o.pw = ph.pw; o.qx = ph.qx; o.qy = ph.qy; o.qz = ph.qz; o.qw = ph.qw; o.vw = ph.vw; o.ww = ph.ww;
   _Pragma("unroll") for (int j = 0; j < 3; ++j) {
     int d = 3 * lane + j;
@@ -255,6 +261,8 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
 #endif
   STAMP(0);
   LegPhys ph_; LegPost po_; LaneAux ax;
+  ph_.rl = (GO2_AS3 Go2RowsLds*)&sh.rows; ph_.tid = tid; ph_.lid = tid >> 2; ph_.base_body = 0;
+  _Pragma("unroll") for (int T = 0; T < GO2_NTYPE; ++T) { ph_.near_t[T] = false; ph_.act_t[T] = 0.f; ph_.lam_t[T][0] = ph_.lam_t[T][1] = ph_.lam_t[T][2] = 0.f; }
   const LegTab& t = tab.leg[lane];
   GO2_AS3 float (*uc)[4] = (GO2_AS3 float (*)[4])sh.ucache[tid >> 4];
   if (!S.injected) {
@@ -306,9 +314,11 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
       if (sb == 1) STAMP(20);
       // wave-wide row-group activity (ballots -> scalar branches): a group is swept only if some environment of the wave has it active on
       // some leg — typically only the foot contacts are live (an inactive row moves nothing, so skipping is exact)
-      const bool af = xl::any(ph_.has_foot()), ao = xl::any(ph_.has_other()), al = xl::any(ph_.has_limit());
-      ph_.solve_prepare(af, ao, al);
-      for (int it = 0; it < L.solver_iterations; ++it) ph_.solve_iteration(af, ao, al);
+      const bool af = xl::any(ph_.has_foot()), al = xl::any(ph_.has_limit());
+      const bool at[GO2_NTYPE] = {ph_.near_t[0] && xl::any(ph_.has_type<0>()), ph_.near_t[1] && xl::any(ph_.has_type<1>()),
+                                  ph_.near_t[2] && xl::any(ph_.has_type<2>()), ph_.near_t[3] && xl::any(ph_.has_type<3>())};
+      ph_.solve_prepare(af, at, al);
+      for (int it = 0; it < L.solver_iterations; ++it) ph_.solve_iteration(af, at, al);
       GO2_MARK(15);
       if (sb == 1) STAMP(21);
       ph_.gather_solution();
@@ -352,6 +362,14 @@ template <int MODE>
 __global__ void __launch_bounds__(GO2_WG_THREADS) go2_step_kernel(const Go2DevBlock* __restrict__ blk, const float* __restrict__ actions_in, int initial_reset, const Go2StepOutputs outs) {
   __shared__ Go2Shared sh;
   go2_step_body<MODE>(sh, blk, actions_in, initial_reset, outs, blockIdx.x, threadIdx.x);
+}
+// The SAME lane programs under a 256-register budget (two waves per SIMD; what does not fit goes to scratch memory): the mapping for batches
+// of more than one wave per SIMD (> 4096 envs per GPU), where a second resident wave hides the dependent-issue latency that the one-wave
+// build exposes.  Selected by num_envs at go2sim_create (Go2Sim.variant; GO2_STEP_VARIANT overrides), same source, same results.
+__global__ void __launch_bounds__(GO2_WG_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
+go2_step_kernel_occ2(const Go2DevBlock* __restrict__ blk, const float* __restrict__ actions_in, int initial_reset, const Go2StepOutputs outs) {
+  __shared__ Go2Shared sh;
+  go2_step_body<MODE_PHYS | MODE_POST>(sh, blk, actions_in, initial_reset, outs, blockIdx.x, threadIdx.x);
 }
 
 // ---- test hooks (declared in include/go2sim.h under "test hooks"; no product path calls them) --------------------------------
@@ -770,6 +788,7 @@ struct Go2Sim {
   float dt, max_episode_length;
   float* inj_storage; Go2Tables* d_tables; int16_t* d_hf; Go2Cell* d_cells; float* d_torigins;
   int timing; double time_ms; int64_t time_launches;
+  int variant;              // which build of the step kernel go2sim_step launches: 1 = one wave per SIMD (all registers), 2 = two waves per SIMD
 #ifndef GO2_EMU
   std::vector<hipEvent_t> ev; size_t ev_used;
 #endif
@@ -925,6 +944,12 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
   Go2Sim* s = new Go2Sim();
   s->cfg = *cfg; const int N = s->N = cfg->num_envs;
   s->d_hf = nullptr; s->d_cells = nullptr; s->d_torigins = nullptr; s->timing = 0; s->time_ms = 0; s->time_launches = 0;
+  { // lane mapping / register budget by batch size: up to GO2_OCC2_MIN_ENVS - 1 envs the one-wave-per-SIMD build, above it the
+    // two-wave build; GO2_STEP_VARIANT=1|2 forces one (tools/kscale.py measures both)
+    s->variant = N >= GO2_OCC2_MIN_ENVS ? 2 : 1;
+    const char* v = getenv("GO2_STEP_VARIANT");
+    if (v && (v[0] == '1' || v[0] == '2') && v[1] == 0) s->variant = v[0] - '0';
+  }
 #ifndef GO2_EMU
   s->ev_used = 0;
 #endif
@@ -1136,6 +1161,7 @@ static int launch(Go2Sim* s, int mode, const float* actions_in, int initial_rese
   }
   if ((mode & MODE_POST) && s->h.L.heading_command) hipLaunchKernelGGL(go2_cb_scan_kernel, dim3(1), dim3(256), 0, st, s->d_blk);
   if (mode == MODE_RESET_ALL) hipLaunchKernelGGL(go2_step_kernel<MODE_RESET_ALL>, grid, block, 0, st, s->d_blk, actions_in, initial_reset, outs);
+  else if (mode == (MODE_PHYS | MODE_POST) && s->variant == 2) hipLaunchKernelGGL(go2_step_kernel_occ2, grid, block, 0, st, s->d_blk, actions_in, initial_reset, outs);
   else if (mode == (MODE_PHYS | MODE_POST)) hipLaunchKernelGGL(go2_step_kernel<MODE_PHYS | MODE_POST>, grid, block, 0, st, s->d_blk, actions_in, initial_reset, outs);
   else if (mode == MODE_PHYS) hipLaunchKernelGGL(go2_step_kernel<MODE_PHYS>, grid, block, 0, st, s->d_blk, actions_in, initial_reset, outs);
   else hipLaunchKernelGGL(go2_step_kernel<MODE_POST>, grid, block, 0, st, s->d_blk, actions_in, initial_reset, outs);

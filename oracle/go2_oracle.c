@@ -428,6 +428,8 @@ typedef struct {
   int body; R n[3], t1[3], t2[3];
 } Row;
 
+#define NSLOT 5        /* contact slots per leg: foot, calf, thigh, hip, base share */
+#define NR (NSLOT+3)   /* + the leg's three joint-limit rows */
 /* candidate -> world position of the sphere centre */
 static void sphere_world(const Kin* k, const Sph* p, R* c) {
   R l[3] = {(R)p->c[0], (R)p->c[1], (R)p->c[2]}, t[3]; mat3_vec(k->Rw[p->link], l, t);
@@ -494,22 +496,26 @@ static void physics_substep(Go2Sim* s, int e, R* root, R* q, R* qd, const R* tau
   R mu = RC(0.5)*((R)cfg->terrain_friction + (R)s->b.friction_coeffs[e]);
   R rest = RC(0.5)*((R)cfg->terrain_restitution + (R)s->b.restitution_coeffs[e]);
 
-  /* rows: per lane (leg) [foot n,t1,t2][other n,t1,t2][limit x3] */
-  static _Thread_local Row rows[4][5];
+  /* rows: per lane (leg) NSLOT contact slots [n,t1,t2] + [limit x3].  The contact set a leg reports: one contact per BODY
+   * GROUP — slot 0 the foot sphere, slot 1 the deepest calf sphere, slot 2 the deepest thigh point, slot 3 the deepest hip sphere, slot 4 the
+   * deepest of the leg's share of the base / head points — so that a base contact is never shadowed by a leg link (check_termination reads
+   * the base force, legged_robot.py:170-173) and thigh and calf report independently (_reward_collision counts 8 bodies, :1277-1279). */
+  static _Thread_local Row rows[4][NR];
   for (int lane=0; lane<4; ++lane) {
-    for (int slot=0; slot<2; ++slot) {
+    for (int slot=0; slot<NSLOT; ++slot) {
       Row* r = &rows[lane][slot]; r->active = 0; r->kind = 0; r->lam[0]=r->lam[1]=r->lam[2]=0;
       const Sph* best = NULL; R best_gap = 0, best_c[3], best_n[3];
-      int ncand = slot==0 ? 1 : GO2_LEG_OTHER_PTS + GO2_BASE_PTS;
+      static const int slot_link[NSLOT] = {0, 3, 2, 1, 0};      /* leg-local link of the slot's candidates: calf 3, thigh 2, hip 1 */
+      int ncand = slot==0 ? 1 : (slot==NSLOT-1 ? GO2_BASE_PTS : GO2_LEG_OTHER_PTS);
       for (int ci=0; ci<ncand; ++ci) {
         const Sph* p;
         if (slot==0) p = &kFootPts[lane];
-        else if (ci < GO2_LEG_OTHER_PTS) p = &kLegOther[lane][ci];
-        else { int bi = ci - GO2_LEG_OTHER_PTS; if ((bi & 3) != lane) continue; p = &kBasePts[bi]; }
+        else if (slot==NSLOT-1) { if ((ci & 3) != lane) continue; p = &kBasePts[ci]; }
+        else { p = &kLegOther[lane][ci]; if (p->link - 3*lane != slot_link[slot]) continue; }
         R c[3], gap, n[3]; sphere_world(&k, p, c); contact_query(s, c, (R)p->r, &gap, n);
         if (!best || gap < best_gap) { best = p; best_gap = gap; memcpy(best_c,c,sizeof(c)); memcpy(best_n,n,sizeof(n)); }
       }
-      if (best_gap < (R)cfg->contact_offset) {
+      if (best && best_gap < (R)cfg->contact_offset) {
         r->active = 1; r->body = best->body; r->mu = mu;
         { R sa = ((R)cfg->contact_offset - best_gap)/(RC(0.25)*(R)cfg->contact_offset); r->sact = sa < 0 ? 0 : (sa > 1 ? 1 : sa); }
         memcpy(r->n, best_n, sizeof(best_n));
@@ -530,7 +536,7 @@ static void physics_substep(Go2Sim* s, int e, R* root, R* q, R* qd, const R* tau
       } else if (slot==0) { for (int a=0;a<3;++a) s->b.foot_impulse[(4*e+lane)*3+a] = 0; }
     }
     for (int jj=0;jj<3;++jj) {
-      Row* r = &rows[lane][2+jj]; int j = 3*lane+jj; r->active=0; r->kind=1; r->lam[0]=r->lam[1]=r->lam[2]=0;
+      Row* r = &rows[lane][NSLOT+jj]; int j = 3*lane+jj; r->active=0; r->kind=1; r->lam[0]=r->lam[1]=r->lam[2]=0;
       R glo = q[j]-(R)kJointLower[j], ghi = (R)kJointUpper[j]-q[j];
       R sgn = 0, gap = 0;
       if (glo < (R)cfg->joint_limit_margin) { sgn = 1; gap = glo; } else if (ghi < (R)cfg->joint_limit_margin) { sgn = -1; gap = ghi; }
@@ -544,7 +550,7 @@ static void physics_substep(Go2Sim* s, int e, R* root, R* q, R* qd, const R* tau
   }
   /* Y = M^-1 J^T, diagonal, warm start */
   R dnu[NV]; memset(dnu, 0, sizeof(dnu));
-  for (int lane=0;lane<4;++lane) for (int ri=0;ri<5;++ri) {
+  for (int lane=0;lane<4;++lane) for (int ri=0;ri<NR;++ri) {
     Row* r = &rows[lane][ri]; if (!r->active) continue;
     int nr = r->kind==0 ? 3 : 1;
     for (int a=0;a<nr;++a) {
@@ -555,17 +561,17 @@ static void physics_substep(Go2Sim* s, int e, R* root, R* q, R* qd, const R* tau
     }
   }
   /* Projected block iteration over the LEGS with MASS SPLITTING at the base (Tonge et al. 2012).  The constraint rows of a
-   * leg form a block (foot n,t; other n,t; limits, visited in that order, Gauss-Seidel inside the block).  Per iteration every leg sweeps its
+   * leg form a block (foot n,t; calf n,t; thigh n,t; hip n,t; base share n,t; limits, visited in that order, Gauss-Seidel inside the block).  Per iteration every leg sweeps its
    * block starting from the SAME state; the legs interact only through the base, and each leg is given 1/n of it: in ITS view the base-mediated
    * part of every response, Y - Y_L, is n times larger, the fixed-base part Y_L = M_ll^-1 J_l^T (the leg's own joints) is as it is.  What is
    * committed are the TRUE responses Y dlam of the impulses the legs arrive at.  n = the number of legs with active rows, counted smoothly
    * (a row that has only just become active — within a quarter margin of its threshold, where it still does nothing — counts in
    * proportion), so that the step is a continuous function of the state. */
   int legact[4]; R nsm = 0;
-  for (int lane=0;lane<4;++lane) { legact[lane]=0; R sl=0; for (int ri=0;ri<5;++ri) if (rows[lane][ri].active) { legact[lane]=1; if (rows[lane][ri].sact > sl) sl = rows[lane][ri].sact; } nsm += sl; }
+  for (int lane=0;lane<4;++lane) { legact[lane]=0; R sl=0; for (int ri=0;ri<NR;++ri) if (rows[lane][ri].active) { legact[lane]=1; if (rows[lane][ri].sact > sl) sl = rows[lane][ri].sact; } nsm += sl; }
   const R nsplit = nsm > 1 ? nsm : 1;
-  static _Thread_local R Yv[4][5][3][NV], dv[4][5][3];      /* the leg's view: responses and diagonals with the split base */
-  for (int lane=0;lane<4;++lane) for (int ri=0;ri<5;++ri) {
+  static _Thread_local R Yv[4][NR][3][NV], dv[4][NR][3];      /* the leg's view: responses and diagonals with the split base */
+  for (int lane=0;lane<4;++lane) for (int ri=0;ri<NR;++ri) {
     Row* r=&rows[lane][ri]; if (!r->active) continue;
     int nr = r->kind==0 ? 3 : 1;
     for (int a=0;a<nr;++a) {
@@ -583,7 +589,7 @@ static void physics_substep(Go2Sim* s, int e, R* root, R* q, R* qd, const R* tau
     for (int lane=0;lane<4;++lane) {
       if (!legact[lane]) continue;
       R dl_[NV]; memcpy(dl_, dnu0, sizeof(dnu0));      /* this leg's view of the velocity change */
-      for (int ri=0;ri<5;++ri) {
+      for (int ri=0;ri<NR;++ri) {
         Row* r = &rows[lane][ri]; if (!r->active) continue;
         R lam0[3] = {r->lam[0], r->lam[1], r->lam[2]};
         { R v=0; for (int c=0;c<NV;++c) v += r->J[0][c]*(nu_free[c]+dl_[c]);
@@ -605,7 +611,7 @@ static void physics_substep(Go2Sim* s, int e, R* root, R* q, R* qd, const R* tau
   }
   /* outputs: contact forces per body (world), warm start */
   memset(body_force, 0, sizeof(R)*NB*3);
-  for (int lane=0;lane<4;++lane) for (int slot=0;slot<2;++slot) {
+  for (int lane=0;lane<4;++lane) for (int slot=0;slot<NSLOT;++slot) {
     Row* r = &rows[lane][slot]; if (!r->active) continue;
     for (int i=0;i<3;++i) body_force[3*r->body+i] += (r->n[i]*r->lam[0] + r->t1[i]*r->lam[1] + r->t2[i]*r->lam[2])/h;
     if (slot==0) for (int a=0;a<3;++a) s->b.foot_impulse[(4*e+lane)*3+a] = (float)r->lam[a];

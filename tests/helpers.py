@@ -420,3 +420,33 @@ def check_relative_to_conditioning(err, cond, floors, factor=3.0):
             assert np.quantile(e, q) <= factor * np.quantile(c, q) + floor, (k, q, float(np.quantile(e, q)), float(np.quantile(c, q)))
         far = 1000 * floor
         assert (e > far).mean() <= 2.0 * (c > far).mean() + 2e-3, (k, "tail", float((e > far).mean()), float((c > far).mean()))
+
+
+# ---- the contact set of a fallen robot (one slot per body group of a leg) ------------------------------------------------
+BASE_B, THIGH_B, CALF_B, HIP_B, FOOT_B = 0, [4, 8, 12, 16], [5, 9, 13, 17], [3, 7, 11, 15], [6, 10, 14, 18]
+
+
+LYING_KW = dict(turn_over=1, turn_over_proportions=np.array([0.0, 0.0, 1.0], np.float32), push_robots=0, seed=3, kp=[0.0] * 12, kd=[0.5] * 12, randomize_action_delay=0)
+
+
+def lying_robot_batch(sim, rng):
+    """Put every env of `sim` (created with LYING_KW: termination off via init_state.turn_over with no env flipped, limp joints) into a random
+    LYING pose: trunk 5-9 cm above the plane, roll / pitch within 0.3 rad, every joint anywhere inside its limits, sinking at 0.3 m/s — poses in
+    which the trunk box, hips, thighs, calves and feet touch the ground in many combinations at once (about one env in ten has the base AND both
+    the thigh and the calf of one leg in contact; up to 14 of the 19 bodies).  The simultaneous contact set the reference reads from PhysX:
+    termination on the base force (legged_robot.py:170-173), _reward_collision over 8 thigh / calf bodies (:1277-1279), feet (:1252)."""
+    N = sim.N
+    lo = np.array([-1.0472, -1.5708, -2.7227] * 2 + [-1.0472, -0.5236, -2.7227] * 2); hi = np.array([1.0472, 3.4907, -0.83776] * 2 + [1.0472, 4.5379, -0.83776] * 2)
+    sim.dof_state[:, :, 0] = rng.uniform(lo + 0.06, hi - 0.06, (N, 12)); sim.dof_state[:, :, 1] = 0
+    r, p, y = rng.uniform(-0.3, 0.3, N), rng.uniform(-0.3, 0.3, N), rng.uniform(-3, 3, N)
+    cr, sr, cp, sp, cy, sy = np.cos(r / 2), np.sin(r / 2), np.cos(p / 2), np.sin(p / 2), np.cos(y / 2), np.sin(y / 2)
+    sim.root_states[:, 3:7] = np.stack([sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy], 1)
+    sim.root_states[:, 2] = rng.uniform(0.05, 0.09, N); sim.root_states[:, 7:13] = 0; sim.root_states[:, 9] = -0.3
+    sim.foot_impulse[...] = 0
+
+
+def three_body_envs(forces):
+    """envs of contact_forces [N,19,3] whose base reports > 1 N (the termination threshold) and, for at least one leg, thigh AND calf > 0.5 N"""
+    f = np.linalg.norm(np.asarray(forces, np.float64), axis=2)
+    both = (f[:, THIGH_B] > 0.5) & (f[:, CALF_B] > 0.5)
+    return np.nonzero((f[:, BASE_B] > 1.0) & both.any(1))[0], f

@@ -1,0 +1,127 @@
+"""BASELINE.json configs 4 and 5 at their full env counts, on ONE MI355X (config 4 = task go2, 32768 envs = 8 x 4096;
+config 5 = task go2_moe_cts, 8192 envs = 8 x 1024).  What a single GPU can show of an 8-GPU configuration:
+  * the product path runs at the full size (finite, counters advance, HIP-graph mode for >= 3 iterations) — and at the per-GPU shard size;
+  * 8 shards stepped with env_offset r * n are, bit for bit, the rows [r n, (r+1) n) of the one full-size simulator for a whole rollout
+    (24 steps) on the tasks' own trimesh terrain: what a rank computes does not depend on how the envs are partitioned;
+  * the two builds of the step kernel that go2sim_create selects between by num_envs (go2sim_impl.cpp: one / two waves per SIMD) give
+    the same results on the same state.
+Run with -m gpu."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from helpers import DeviceSim, heightfield_overrides, load_hip  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def hip():
+    lib = load_hip()
+    assert lib.go2sim_is_device_library() == 1
+    return lib
+
+
+@pytest.mark.parametrize("task,N", [("go2", 32768), ("go2", 4096), ("go2_moe_cts", 8192), ("go2_moe_cts", 1024)])
+def test_baseline_config_runs_at_full_size_in_graph_mode(hip, task, N):
+    """task_registry -> LeggedRobot (HIP library) -> OnPolicyRunner / OnPolicyRunnerCTS at the configuration's env count: 6 iterations, the
+    last >= 3 of them replayed from HIP graphs (rollout + every mini-batch step)."""
+    import torch
+    from go2_rl_gym_amd.envs import task_registry  # noqa: F401
+    from go2_rl_gym_amd.utils import get_args
+    args = get_args(["--task", task, "--num_envs", str(N), "--headless", "--seed", "1"])
+    env, env_cfg = task_registry.make_env(task, args)
+    assert env.num_envs == N and env_cfg.terrain.mesh_type == "trimesh" and env.custom_origins
+    if task == "go2_moe_cts":
+        _, tc = task_registry.get_cfgs(task)
+        assert tc.runner.algorithm_class_name == "MoECTS" and (N != 8192 or task_registry.get_cfgs(task)[0].env.num_envs == 8192)      # go2_config.py:33
+    torch.manual_seed(1)
+    runner, _ = task_registry.make_alg_runner(env, task, args, log_root=None)
+    env.common_step_counter = 0
+    runner.learn(3, init_at_random_ep_len=True)
+    for _ in range(3):
+        runner.learn(1)
+        torch.cuda.synchronize()
+    g = runner.graphs_captured()
+    assert g["rollout"] and g["update"], g
+    assert env.common_step_counter == 6 * 24
+    model = runner.alg.actor_critic if hasattr(runner.alg, "actor_critic") else runner.alg.model
+    params = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    assert torch.isfinite(params).all() and torch.isfinite(env.obs_buf).all() and torch.isfinite(env.privileged_obs_buf).all() and torch.isfinite(env.rew_buf).all()
+    assert torch.isfinite(env.root_states).all() and float(env.root_states[:, 2].median()) > 0.1
+    assert env.measured_heights.abs().max() > 0.02 and runner.last_fps > 0
+    # the terrain curriculum round robin covered every level row / type column the task starts on, at this size
+    assert int(env.terrain_types.max()) == env_cfg.terrain.num_cols - 1 and int(env.terrain_levels.min()) == 0
+    print("%s N=%d: %.2f M env-steps/s (collection %.1f ms, learn %.1f ms)" % (task, N, runner.last_fps / 1e6, 1e3 * runner.last_collection_time, 1e3 * runner.last_learn_time))
+    env.close()
+
+
+KEYS = ("root_states", "dof_state", "obs_buf", "privileged_obs_buf", "rew_buf", "reset_buf", "time_out_buf", "commands", "env_origins", "friction_coeffs", "link_mass_ratio",
+        "added_base_mass", "motor_strengths", "episode_length_buf", "terrain_levels", "terrain_types", "contact_forces", "measured_heights", "episode_sums", "torques")
+
+
+@pytest.mark.parametrize("Ng,n", [(32768, 4096), (8192, 1024)])
+def test_eight_shards_are_slices_of_the_full_size_simulator(hip, Ng, n):
+    """configs 4 / 5 as the 8 ranks hold them (env_offset = rank * n, num_envs_global = Ng) against ONE simulator of Ng envs: after create,
+    reset and each of 24 steps (one rollout) every compared tensor of shard r equals rows [r n, (r+1) n) of the whole, bit for bit."""
+    import torch
+    ov = heightfield_overrides(Ng, mesh_type="trimesh")[1]
+    whole = DeviceSim(hip, num_envs=Ng, seed=5, **ov)
+    parts = [DeviceSim(hip, num_envs=n, env_offset=r * n, num_envs_global=Ng, seed=5, **ov) for r in range(Ng // n)]
+    assert len(parts) == 8
+
+    def same(tag):
+        for k in KEYS:
+            w = whole.t[k]
+            for r, prt in enumerate(parts):
+                sl = w[:, r * n:(r + 1) * n] if k == "episode_sums" else w[r * n:(r + 1) * n]
+                assert torch.equal(sl, prt.t[k]), "%s: %s differs between shard %d and the slice of the %d-env simulator" % (tag, k, r, Ng)
+    same("create")
+    for s_ in [whole] + parts:
+        s_.reset_all()
+    torch.cuda.synchronize()
+    same("reset")
+    g = torch.Generator(device="cuda:0"); g.manual_seed(0)
+    nreset = 0
+    for it in range(24):
+        a = torch.randn(Ng, 12, device="cuda:0", generator=g)
+        hip.go2sim_step(whole.h, C.c_void_p(a.data_ptr()), whole._st())
+        for r, prt in enumerate(parts):
+            ar = a[r * n:(r + 1) * n].contiguous()
+            hip.go2sim_step(prt.h, C.c_void_p(ar.data_ptr()), prt._st())
+        torch.cuda.synchronize()
+        same("step %d" % it)
+        nreset += int(whole.t["reset_buf"].sum())
+    assert torch.isfinite(whole.t["privileged_obs_buf"]).all() and float(whole.t["contact_forces"].abs().max()) > 1.0
+    assert nreset > 0 and float(whole.t["measured_heights"].abs().max()) > 0.02      # resets and rough ground were part of what was compared
+    for s_ in [whole] + parts:
+        s_.close()
+
+
+@pytest.mark.parametrize("terrain", ["plane", "trimesh"])
+def test_step_kernel_builds_agree(hip, terrain, monkeypatch):
+    """The two builds of the lane programs the library carries (go2sim_create picks by num_envs; GO2_STEP_VARIANT forces one): same source,
+    different register budget (all 512 registers and one wave per SIMD / 256 registers and two) — the arithmetic is the same instruction
+    stream, so 24 steps from the same state give the same bits."""
+    import torch
+    N = 4096
+    ov = heightfield_overrides(N, mesh_type="trimesh")[1] if terrain == "trimesh" else {}
+    sims = {}
+    for v in ("1", "2"):
+        monkeypatch.setenv("GO2_STEP_VARIANT", v)
+        sims[v] = DeviceSim(hip, num_envs=N, seed=9, **ov)
+        sims[v].reset_all()
+    monkeypatch.delenv("GO2_STEP_VARIANT")
+    g = torch.Generator(device="cuda:0"); g.manual_seed(1)
+    for it in range(24):
+        a = torch.randn(N, 12, device="cuda:0", generator=g)
+        for s in sims.values():
+            hip.go2sim_step(s.h, C.c_void_p(a.data_ptr()), s._st())
+        torch.cuda.synchronize()
+        for k in KEYS:
+            x, y = sims["1"].t[k], sims["2"].t[k]
+            assert torch.equal(x, y), "step %d: %s differs between the builds (max |d| %.3e)" % (it, k, float((x.float() - y.float()).abs().max()))
+    for s in sims.values():
+        s.close()

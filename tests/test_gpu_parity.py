@@ -752,3 +752,36 @@ def test_two_rank_bench_rehearsal_on_one_gpu(hip):
     assert out["collectives_per_iteration"]["all_reduce"] == 21            # 1 advantage statistics + 5 epochs x 4 mini-batches
     assert out["value"] > 0 and abs(out["value"] - 2 * 1024 * 24 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
     assert "cpu_baseline" not in out                                       # rank 0 at N = 1 only
+
+
+def test_fallen_robot_contact_set_on_gpu(hip):
+    """GPU twin of tests/test_lane_emulation.py::test_fallen_robot_reports_base_thigh_and_calf_at_once: robots lying on the trunk and on the
+    thigh AND the calf of one leg report all three body forces in one step on the HIP kernel (one contact slot per body group of a leg, the
+    non-foot slots' rows parked in LDS), and the 19 body forces equal the oracle's from the same inputs."""
+    from helpers import BASE_B, CALF_B, LYING_KW, THIGH_B, lying_robot_batch, three_body_envs
+    M = 256
+    so, sd = HostSim(load_oracle(), num_envs=M, **LYING_KW), DeviceSim(hip, num_envs=M, **LYING_KW)
+    so.reset_all(); sd.reset_all()
+    rng = np.random.default_rng(0)
+    seen3 = most = 0
+    for trial in range(3):
+        lying_robot_batch(so, rng)
+        for k in STEP_STATE:
+            getattr(sd, k)[...] = np.asarray(getattr(so, k))
+        a = np.zeros((M, 12), np.float32)
+        so.step(a); sd.step(a)
+        ids, no = three_body_envs(so.contact_forces)
+        _, nd = three_body_envs(np.asarray(sd.contact_forces))
+        for e in ids:
+            legs = [l for l in range(4) if no[e, THIGH_B[l]] > 0.5 and no[e, CALF_B[l]] > 0.5]
+            for b in [BASE_B] + [THIGH_B[l] for l in legs] + [CALF_B[l] for l in legs]:
+                assert nd[e, b] > 0.25 * min(no[e, b], 4.0), (e, b, no[e, b], nd[e, b])
+        seen3 += len(ids); most = max(most, int((nd > 0.1).sum(1).max()))
+        assert ((nd[:, THIGH_B] > 0.1).sum(1) + (nd[:, CALF_B] > 0.1).sum(1)).max() >= 5      # _reward_collision counts past the round-2 model's 4
+        fo, fd = np.asarray(so.contact_forces, np.float64), np.asarray(sd.contact_forces, np.float64)
+        d = np.abs(fo - fd).reshape(M, -1).max(1) / (1.0 + np.abs(fo).reshape(M, -1).max(1))
+        assert np.median(d) < 1e-4 and np.quantile(d, 0.99) < 1e-2, np.sort(d)[-4:]          # relative to each env's force scale (impulse / 5 ms)
+        np.testing.assert_allclose(np.asarray(so.root_states), np.asarray(sd.root_states), atol=5e-3)
+        np.testing.assert_array_equal(np.asarray(so.reset_buf), np.asarray(sd.reset_buf))
+    assert seen3 >= 30 and most >= 10, (seen3, most)
+    so.close(); sd.close()

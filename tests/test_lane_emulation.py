@@ -203,3 +203,37 @@ def test_reset_idx_subsets_against_the_oracle():
             if hit.any():
                 assert (np.asarray(se.episode_length_buf)[hit] == 0).all() and (np.asarray(se.reset_buf)[hit] == 1).all()
         so.close(); se.close()
+
+
+def test_fallen_robot_reports_base_thigh_and_calf_at_once():
+    """The contact set of DESIGN.md 4 (one slot per body group of a leg: foot, calf, thigh, hip, base share): a robot lying on its trunk AND on
+    the thigh and the calf of one leg reports three non-zero body forces in the same step — the base force check_termination reads
+    (legged_robot.py:170-173) is not shadowed by a deeper leg link, and _reward_collision (:1277-1279) sees both links of the leg.  Oracle and the
+    host build of the lane programs from the same inputs."""
+    from helpers import BASE_B, CALF_B, LYING_KW, THIGH_B, lying_robot_batch, three_body_envs
+    M = 96
+    so, se = HostSim(load_oracle(), num_envs=M, **LYING_KW), HostSim(load_emu(), num_envs=M, **LYING_KW)
+    so.reset_all(); se.reset_all()
+    rng = np.random.default_rng(0)
+    seen3 = most = 0
+    for trial in range(3):
+        lying_robot_batch(so, rng)
+        for k in STEP_STATE:
+            getattr(se, k)[...] = getattr(so, k)
+        a = np.zeros((M, 12), np.float32)
+        so.step(a); se.step(a)
+        ids, no = three_body_envs(so.contact_forces)
+        _, ne = three_body_envs(se.contact_forces)
+        for e in ids:
+            legs = [l for l in range(4) if no[e, THIGH_B[l]] > 0.5 and no[e, CALF_B[l]] > 0.5]
+            for b in [BASE_B] + [THIGH_B[l] for l in legs] + [CALF_B[l] for l in legs]:
+                assert ne[e, b] > 0.25 * min(no[e, b], 4.0), (e, b, no[e, b], ne[e, b])          # the same three bodies report in the lane programs
+        seen3 += len(ids); most = max(most, int((no > 0.1).sum(1).max()))
+        assert ((no[:, THIGH_B] > 0.1).sum(1) + (no[:, CALF_B] > 0.1).sum(1)).max() >= 5      # _reward_collision can count past the old model's 4
+        # all 19 body forces agree (impulse / 5 ms, so relative to the force scale; lying robots are the ill-conditioned case of DESIGN.md 3)
+        fo, fe = np.asarray(so.contact_forces, np.float64), np.asarray(se.contact_forces, np.float64)
+        d = np.abs(fo - fe).reshape(M, -1).max(1) / (1.0 + np.abs(fo).reshape(M, -1).max(1))
+        assert np.median(d) < 1e-4 and np.quantile(d, 0.99) < 1e-2, np.sort(d)[-4:]          # relative to each env's force scale (impulse / 5 ms)
+        np.testing.assert_allclose(np.asarray(so.root_states), np.asarray(se.root_states), atol=5e-3)
+    assert seen3 >= 10 and most >= 10, (seen3, most)       # many bodies of one robot at once (the round-2 model held at most 8 + the base)
+    so.close(); se.close()

@@ -131,13 +131,21 @@ for ln in link_order:
                 for b_ in (-1, 1):
                     for c_ in (-1, 1):
                         spheres.append((body, mi, tw + Rw @ np.array([a * sx / 2, b_ * sy / 2, c_ * sz / 2]), 0.0, 2))
+            if mi == 0 and BODY_NAMES[body] == "base":
+                # The trunk box is the one primitive long enough (0.376 m) for the ground to reach it BETWEEN its corners — a stair nosing or
+                # an obstacle edge under the belly (mesh_type 'trimesh').  Extra surface samples, appended after all other base points below
+                # (kind 3): the bottom face centre and the midpoints of the four long edges.  On a plane a box's lowest point is a corner, so
+                # nothing changes there (ties go to the corner, which comes first in the scan order).
+                for a, b_, c_ in ((0, 0, -1), (0, -1, -1), (0, 1, -1), (0, -1, 1), (0, 1, 1)):
+                    spheres.append((body, mi, tw + Rw @ np.array([a * sx / 2, b_ * sy / 2, c_ * sz / 2]), 0.0, 3))
         else:
             raise ValueError(g.tag)
 # group: feet first (one per leg), then per-leg non-foot, then base-attached
 feet = [s for s in spheres if BODY_NAMES[s[0]].endswith("foot")]
 assert len(feet) == 4
 leg_other = [[s for s in spheres if (1 + 3 * l) <= s[1] <= (3 + 3 * l) and not BODY_NAMES[s[0]].endswith("foot")] for l in range(4)]
-base_pts = [s for s in spheres if s[1] == 0]
+base_pts = [s for s in spheres if s[1] == 0 and s[4] != 3] + [s for s in spheres if s[1] == 0 and s[4] == 3]
+assert len(base_pts) <= 16, "the lane programs deal the base points to 4 legs x 4 sub-lanes (go2_tables.h)"
 n_leg_other = len(leg_other[0]); assert all(len(x) == n_leg_other for x in leg_other)
 
 def f(x): return repr(float(np.float64(x))) if abs(x) > 0 else "0.0"
