@@ -17,11 +17,12 @@
 //      (row)   sum {Ic_leg (10), K (21), F_leg (6), r (6)} over the 4 legs                     <- DPP row rotations
 //   B. (lane, replicated) base articulated inertia IA = I_base + sum Ic - sum K, Phi = IA^-1, base and joint accelerations,
 //              unconstrained end-of-substep velocities; each sub-lane keeps ITS 3 rows of the map row -> response ([A^-1 | 0], Phi rows)
-//   C. (lane)  contact candidates — per leg one slot per BODY GROUP: the foot sphere, the deepest calf sphere, the deepest thigh point, the
-//              deepest hip sphere, the deepest of the leg's share of the base / head points (so a base contact is never shadowed by a leg
-//              link and thigh / calf report independently) — and joint-limit rows; per row the lane's slice of J = [Jc | G] and
-//              Y = [Z | H] (Z = A^-1 Jc^T, G = Ec + Jc N, H = Phi G), the diagonal by a quad sum.  The foot's rows stay in registers; the
-//              other slots' rows are parked in LDS (Go2RowsLds) and pass through ONE register-resident slot while they are swept
+//   C. (lane)  contact candidates — per leg the foot sphere and ONE candidate per body group: the deepest calf sphere, the deepest thigh
+//              point, the deepest hip sphere, the deepest of the leg's share of the base / head points (so a base contact is never shadowed
+//              by a leg link and thigh / calf report independently); the groups in contact are compacted into virtual slots 0..3
+//              (go2_tables.h); joint-limit rows; per row the lane's slice of J = [Jc | G] and Y = [Z | H] (Z = A^-1 Jc^T, G = Ec + Jc N,
+//              H = Phi G), the diagonal by a quad sum.  The rows of the foot and of virtual slot 0 stay in registers; further virtual
+//              slots and the limit rows are parked in LDS and pass through ONE register-resident slot while they are swept
 //      (row)   projected block iteration: all four legs sweep their own rows (Gauss-Seidel inside a leg) at once, each on its copy of the
 //              base-twist slices with the base split n ways (mass splitting); one leg sum per slice and iteration commits the true responses
 //   D. (lane, replicated) velocities, semi-implicit Euler integration, contact forces
@@ -61,18 +62,16 @@ struct HotL {
 };
 
 // The per-leg constants the substep loop reads, copied ONCE per step from the LDS table into registers (the loop would otherwise wait on
-// ~50 ds_reads per substep): joint origins, limits, the foot sphere, this sub-lane's candidate spheres, the groups' cull reach.
+// ~20 ds_reads per substep): joint origins, limits, the foot sphere.
 struct LegLoop {
-  float o1[3], o2[3], o3[3], lim_lo[3], lim_hi[3], vel_lim[3], eff_lim[3], foot_pt[4], cull_ext[4][3];
-  SubCand sc;
+  float o1[3], o2[3], o3[3], lim_lo[3], lim_hi[3], vel_lim[3], eff_lim[3], foot_pt[4];
   GO2_HD void load(const LegTab& t, int sub) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) { o1[k] = t.o1[k]; o2[k] = t.o2[k]; o3[k] = t.o3[k]; lim_lo[k] = t.lim_lo[k]; lim_hi[k] = t.lim_hi[k]; vel_lim[k] = t.vel_lim[k]; eff_lim[k] = t.eff_lim[k]; }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { foot_pt[k] = t.foot_pt[k]; cull_ext[k][0] = t.cull_ext[k][0]; cull_ext[k][1] = t.cull_ext[k][1]; cull_ext[k][2] = t.cull_ext[k][2]; }
-    const SubCand& c = t.cand[sub];
-#pragma unroll
-    for (int k = 0; k < GO2_SUB_CANDS; ++k) { sc.pt[k][0] = c.pt[k][0]; sc.pt[k][1] = c.pt[k][1]; sc.pt[k][2] = c.pt[k][2]; sc.pt[k][3] = c.pt[k][3]; sc.idx[k] = c.idx[k]; sc.body[k] = c.body[k]; }
+    for (int k = 0; k < 4; ++k) foot_pt[k] = t.foot_pt[k];
+    (void)sub;      // (the sub-lane's candidate spheres and the cull reach are read from the LDS table where phase C uses them: 42 registers that
+                    //  would otherwise be live through the whole substep loop — the kernel is at the register file's limit)
   }
 };
 
@@ -86,17 +85,6 @@ struct Cand {
     const bool tk = ok && (o.g < g || (o.g == g && o.i < i));
     g = tk ? o.g : g; i = tk ? o.i : i; n = sel(tk, o.n, n); c = sel(tk, o.c, c); r = tk ? o.r : r; b = tk ? o.b : b;
   }
-  template <int A, int B, int C_, int D>
-  GO2_HD Cand perm() const {
-    Cand o;
-    o.g = xl::quad_perm<A, B, C_, D>(g); o.i = xl::quad_perm_i<A, B, C_, D>(i);
-    o.n = v3(xl::quad_perm<A, B, C_, D>(n.x), xl::quad_perm<A, B, C_, D>(n.y), xl::quad_perm<A, B, C_, D>(n.z));
-    o.c = v3(xl::quad_perm<A, B, C_, D>(c.x), xl::quad_perm<A, B, C_, D>(c.y), xl::quad_perm<A, B, C_, D>(c.z));
-    o.r = xl::quad_perm<A, B, C_, D>(r); o.b = xl::quad_perm_i<A, B, C_, D>(b);
-    return o;
-  }
-  // two quad-exchange rounds (partner sub ^ 1, then sub ^ 2) carry the deepest candidate of the four sub-lanes to all of them
-  GO2_HD void tournament() { take(true, perm<1, 0, 3, 2>()); take(true, perm<2, 3, 0, 1>()); }
 };
 
 struct LegPhys {
@@ -113,11 +101,12 @@ struct LegPhys {
   float Ainv[6];  // 11 12 13 22 23 33
   float u[3], qdf[3];
   float Msub[3][6];          // this sub-lane's rows of the response map: sub 0 [A^-1 | 0], sub 1 Phi rows 0..2, sub 2 Phi rows 3..5
-  Row foot[3], cur[3], lim[3];     // cur: the non-foot slot being built / swept (its rows live in LDS otherwise)
-  float act_foot, act_t[GO2_NTYPE], act_lim[3];
-  float lam_t[GO2_NTYPE][3];       // impulses of the non-foot slots (replicated in the quad, like Row.lam)
-  bool near_t[GO2_NTYPE];          // WAVE-UNIFORM: some lane of the wave has a candidate of this group inside the contact margin (rows were built)
-  int32_t base_body;               // body (base, Head_upper, Head_lower) of the base-share slot's contact
+  Row foot[3], v0[3], tmp[3];      // v0: virtual slot 0; tmp: the parked row set (virtual slots 1..3, joint limits) being built / swept
+  float act_foot, act_v[GO2_NTYPE], act_lim[3];
+  float lam_v[GO2_NTYPE - 1][3], lam_lim[3];      // impulses of the parked rows (replicated in the quad, like Row.lam)
+  bool has_v[GO2_NTYPE];           // WAVE-UNIFORM: some leg of the wave has more than k body groups in contact (virtual slot k was built)
+  int32_t body_v[GO2_NTYPE];       // body the contact of virtual slot k belongs to
+  V3 v0_n;                         // world normal of virtual slot 0
   GO2_AS3 Go2RowsLds* rl; int tid, lid;      // the workgroup's row storage, this lane's index in it and its leg's (tid >> 2)
   float nsplit, yscale;      // solve_prepare: the split n of the base, and this sub-lane's factor on a response slice (1 joint slice, n base slices)
   float s_act;               // how firmly this leg's rows are active, in [0, 1] (solve_prepare: the smooth count of legs sharing the base): 0 at the activation boundary, 1 a quarter margin inside
@@ -318,50 +307,87 @@ struct LegPhys {
     }
   }
 
-  // A non-foot slot (body group T): tournament, rows, and the rows' way into LDS
+  // One body group T of the leg: the deepest candidate of the four sub-lanes (a 2-round quad tournament on gap and scan-order index
+  // only; ties go to the lower index); the sub-lane that holds it leaves its data — gap, facet normal, centre in the base frame, radius,
+  // body — in LDS for the whole leg.  Skipped (wave-uniform) when no lane of the wave has such a candidate inside the contact margin.
+  // -> the group is in contact for this leg
   template <int T, class LT>
-  GO2_HD void finish_type(const LT& L, Cand b, int link) {
-    near_t[T] = xl::any(b.g < L.contact_offset);
-    act_t[T] = 0.f; lam_t[T][0] = lam_t[T][1] = lam_t[T][2] = 0.f;
-    if (near_t[T]) {
-      b.tournament();
-      s_act = fmaxf(s_act, fminf(fmaxf((L.contact_offset - b.g) / (0.25f * L.contact_offset), 0.f), 1.f));
-      if (T == GO2_T_BASE) base_body = b.b;
-      V3 dn, dt1, dt2;
-      build_slot(cur, &act_t[T], &dn, &dt1, &dt2, L, b.g, b.c, b.r, link, b.n, false);
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { rl->jy[T][a][k][tid] = cur[a].J[k]; rl->jy[T][a][3 + k][tid] = cur[a].Y[k]; }
-        rl->dp[T][a][tid] = cur[a].dinv;
-        if (sub == 0) rl->sc[T][a][0][lid] = cur[a].vfb;
+  GO2_HD bool group_winner(const LT& L, const Cand& b) {
+    bool act = false;
+    if (xl::any(b.g < L.contact_offset)) {
+      float wg = b.g; int wi = b.i;
+      { const float g2 = xl::quad_perm<1, 0, 3, 2>(wg); const int i2 = xl::quad_perm_i<1, 0, 3, 2>(wi); const bool tk = g2 < wg || (g2 == wg && i2 < wi); wg = tk ? g2 : wg; wi = tk ? i2 : wi; }
+      { const float g2 = xl::quad_perm<2, 3, 0, 1>(wg); const int i2 = xl::quad_perm_i<2, 3, 0, 1>(wi); const bool tk = g2 < wg || (g2 == wg && i2 < wi); wg = tk ? g2 : wg; wi = tk ? i2 : wi; }
+      act = wg < L.contact_offset;
+      s_act = fmaxf(s_act, fminf(fmaxf((L.contact_offset - wg) / (0.25f * L.contact_offset), 0.f), 1.f));
+      if (act && b.i == wi) {      // (candidate indices are unique within a leg: exactly one sub-lane)
+        rl->win[T][0][lid] = b.g; rl->win[T][1][lid] = b.n.x; rl->win[T][2][lid] = b.n.y; rl->win[T][3][lid] = b.n.z;
+        rl->win[T][4][lid] = b.c.x; rl->win[T][5][lid] = b.c.y; rl->win[T][6][lid] = b.c.z; rl->win[T][7][lid] = b.r; rl->win[T][8][lid] = (float)b.b;
       }
-      if (sub == 0) { rl->nrm[T][0][lid] = dn.x; rl->nrm[T][1][lid] = dn.y; rl->nrm[T][2][lid] = dn.z; }
     }
+    return act;
   }
-  template <int T>
-  GO2_HD void load_rows() {
+  // rows of a slot on their way into a parked row set P / back into `tmp`
+  template <int P>
+  GO2_HD void park_rows() {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { cur[a].J[k] = rl->jy[T][a][k][tid]; cur[a].Y[k] = rl->jy[T][a][3 + k][tid]; }
-      cur[a].vfb = rl->sc[T][a][0][lid]; cur[a].dinv = rl->sc[T][a][1][lid]; cur[a].lam = lam_t[T][a];
+      for (int k = 0; k < 3; ++k) { rl->jy[P][a][k][tid] = tmp[a].J[k]; rl->jy[P][a][3 + k][tid] = tmp[a].Y[k]; }
+      rl->dp[P][a][tid] = tmp[a].dinv;
+      if (sub == 0) rl->sc[P][a][0][lid] = tmp[a].vfb;
     }
   }
-  // net contact force of the slot (world), from its impulses and the stored normal; wave-uniformly skipped when no lane has the slot active
-  template <int T>
-  GO2_HD V3 type_force(float h) const {
+  template <int P>
+  GO2_HD void load_rows(const float* lam) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { tmp[a].J[k] = rl->jy[P][a][k][tid]; tmp[a].Y[k] = rl->jy[P][a][3 + k][tid]; }
+      tmp[a].vfb = rl->sc[P][a][0][lid]; tmp[a].dinv = rl->sc[P][a][1][lid]; tmp[a].lam = lam[a];
+    }
+  }
+  // Virtual slot K: the K-th body group (canonical order calf, thigh, hip, base share) that is in contact for this leg — none for a leg
+  // with fewer; built wave-uniformly while some leg of the wave has more than K.
+  template <int K, class LT>
+  GO2_HD void build_virtual(const LT& L, const bool* act, const int* rank) {
+    int Tk = -1;
+#pragma unroll
+    for (int T = GO2_NTYPE - 1; T >= 0; --T) Tk = (act[T] && rank[T] == K) ? T : Tk;
+    const bool on = Tk >= 0; const int Ts = on ? Tk : 0;
+    // (a group that was not in contact left nothing, or something stale, in its LDS cell: a leg without a K-th contact builds from a harmless
+    //  dummy instead — far away, so inactive — and its rows, multiplied by act = 0, move nothing)
+    const float g = on ? rl->win[Ts][0][lid] : 1e30f;
+    const V3 n = on ? v3(rl->win[Ts][1][lid], rl->win[Ts][2][lid], rl->win[Ts][3][lid]) : v3(0, 0, 1);
+    const V3 c = on ? v3(rl->win[Ts][4][lid], rl->win[Ts][5][lid], rl->win[Ts][6][lid]) : v3(0, 0, 0);
+    const float r = on ? rl->win[Ts][7][lid] : 0.f;
+    const int link = Tk == GO2_T_CALF ? 3 : (Tk == GO2_T_THIGH ? 2 : (Tk == GO2_T_HIP ? 1 : 0));
+    body_v[K] = Tk == GO2_T_BASE ? (int)rl->win[GO2_T_BASE][8][lid] : (on ? 3 + 4 * leg + (2 - Tk) : -1);      // bodies of a leg: hip 3 + 4 leg, thigh, calf, foot (go2_model_data.h)
+    V3 dn, dt1, dt2;
+    if (K == 0) { build_slot(v0, &act_v[0], &dn, &dt1, &dt2, L, g, c, r, link, n, false); v0_n = dn; }
+    else {
+      build_slot(tmp, &act_v[K], &dn, &dt1, &dt2, L, g, c, r, link, n, false);
+      park_rows<(K == 0 ? 0 : K - 1)>();
+      if (sub == 0) { rl->nrm[K == 0 ? 0 : K - 1][0][lid] = dn.x; rl->nrm[K == 0 ? 0 : K - 1][1][lid] = dn.y; rl->nrm[K == 0 ? 0 : K - 1][2][lid] = dn.z; }
+      lam_v[K == 0 ? 0 : K - 1][0] = lam_v[K == 0 ? 0 : K - 1][1] = lam_v[K == 0 ? 0 : K - 1][2] = 0.f;
+    }
+  }
+  // net contact force of virtual slot K (world): impulses / dt along the slot's frame
+  template <int K>
+  GO2_HD V3 virtual_force(float h) const {
     V3 f = v3(0, 0, 0);
-    if (near_t[T] && xl::any(act_t[T] > 0.f)) {
-      const V3 n = v3(rl->nrm[T][0][lid], rl->nrm[T][1][lid], rl->nrm[T][2][lid]); V3 t1, t2; tangents(n, &t1, &t2);
-      f = (act_t[T] / h) * (lam_t[T][0] * n + lam_t[T][1] * t1 + lam_t[T][2] * t2);
+    if (has_v[K] && xl::any(act_v[K] > 0.f)) {
+      const V3 n = K == 0 ? v0_n : v3(rl->nrm[K == 0 ? 0 : K - 1][0][lid], rl->nrm[K == 0 ? 0 : K - 1][1][lid], rl->nrm[K == 0 ? 0 : K - 1][2][lid]);
+      V3 t1, t2; tangents(n, &t1, &t2);
+      const float l0 = K == 0 ? v0[0].lam : lam_v[K == 0 ? 0 : K - 1][0], l1 = K == 0 ? v0[1].lam : lam_v[K == 0 ? 0 : K - 1][1], l2 = K == 0 ? v0[2].lam : lam_v[K == 0 ? 0 : K - 1][2];
+      f = (act_v[K] / h) * (l0 * n + l1 * t1 + l2 * t2);
     }
     return f;
   }
 
   // ------------------------------------------------------------------------------------------------
   template <class LT>
-  GO2_HD void phaseC(const LegLoop& t, const LT& L, const GO2_AS1 Go2Cell* cells) {
+  GO2_HD void phaseC(const LegLoop& t, const LegTab& tt, const LT& L, const GO2_AS1 Go2Cell* cells) {
     // foot
     {
       V3 cb = p3 + mul(R3, v3(t.foot_pt[0], t.foot_pt[1], t.foot_pt[2]));
@@ -375,7 +401,7 @@ struct LegPhys {
     // GROUP, and a 2-round quad tournament per group carries the group's deepest — with the base-frame position, radius, body and facet
     // normal its rows need — to all four sub-lanes.  Ties go to the lower candidate index (the scan order of the sequential formulation).
     {
-      const SubCand& sc = t.sc;
+      const SubCand& sc = tt.cand[sub];
       const V3 q2 = p2, q3 = p3;
       // On the plane a whole link group is skipped when none of its spheres can reach the contact margin in ANY lane of the wave: lowest
       // possible sphere bottom = (link origin height) - sum_axis |world-z component of the link axis| * (group's reach along that axis).
@@ -386,38 +412,58 @@ struct LegPhys {
         auto low = [&](const M3& R, V3 o, const float* ext) {
           return pw.z + dot(gz, o) - (fabsf(dot(gz, R.x)) * ext[0] + fabsf(dot(gz, R.y)) * ext[1] + fabsf(dot(gz, R.z)) * ext[2]); };
         const M3 Id = {v3(1, 0, 0), v3(0, 1, 0), v3(0, 0, 1)};
-        do_hip = xl::any(low(R1, p1, t.cull_ext[0]) < L.contact_offset); do_thigh = xl::any(low(R2, p2, t.cull_ext[1]) < L.contact_offset);
-        do_calf = xl::any(low(R3, p3, t.cull_ext[2]) < L.contact_offset); do_base = xl::any(low(Id, v3(0, 0, 0), t.cull_ext[3]) < L.contact_offset);
+        do_hip = xl::any(low(R1, p1, tt.cull_ext[0]) < L.contact_offset); do_thigh = xl::any(low(R2, p2, tt.cull_ext[1]) < L.contact_offset);
+        do_calf = xl::any(low(R3, p3, tt.cull_ext[2]) < L.contact_offset); do_base = xl::any(low(Id, v3(0, 0, 0), tt.cull_ext[3]) < L.contact_offset);
       }
       auto eval = [&](int k, const M3& R, V3 P) {
         Cand o; o.c = P + mul(R, v3(sc.pt[k][0], sc.pt[k][1], sc.pt[k][2]));
         contact_query(L, cells, pw + mul(Rwb, o.c), sc.pt[k][3], &o.g, &o.n);
         o.i = sc.idx[k]; o.r = sc.pt[k][3]; o.b = sc.body[k];
         return o; };
-      Cand thigh, calf, hip, base; thigh.clear(); calf.clear(); hip.clear(); base.clear();
-      if (do_thigh) { thigh.take(sc.idx[0] >= 0, eval(0, R2, q2)); thigh.take(sc.idx[1] >= 0, eval(1, R2, q2)); }
-      if (do_calf) calf.take(sc.idx[2] >= 0, eval(2, R3, q3));
-      if (do_calf || do_hip) {   // slot 3: a calf point for sub-lanes 0 and 1, a hip point for sub-lanes 2 and 3
-        const bool hipk = sub >= 2;
-        const M3 Rx = {sel(hipk, R1.x, R3.x), sel(hipk, R1.y, R3.y), sel(hipk, R1.z, R3.z)}; const V3 px = sel(hipk, p1, p3);
-        const Cand c3 = eval(3, Rx, px);
-        calf.take(!hipk && sc.idx[3] >= 0, c3); hip.take(hipk && sc.idx[3] >= 0, c3);
+      // group by group, so that only one or two candidates' data are live at a time: which groups are in contact for this leg, and the
+      // winners' data into LDS
+      bool act[GO2_NTYPE];
+      {
+        Cand thigh; thigh.clear();
+        if (do_thigh) { thigh.take(sc.idx[0] >= 0, eval(0, R2, q2)); thigh.take(sc.idx[1] >= 0, eval(1, R2, q2)); }
+        act[GO2_T_THIGH] = group_winner<GO2_T_THIGH>(L, thigh);
       }
-      if (do_base) {   // slot 4: one of the leg's base / head points (sub-lane < number of points of this leg)
-        const M3 Id = {v3(1, 0, 0), v3(0, 1, 0), v3(0, 0, 1)};
-        base.take(sc.idx[4] >= 0, eval(4, Id, v3(0, 0, 0)));
+      {
+        Cand calf, hip; calf.clear(); hip.clear();
+        if (do_calf) calf.take(sc.idx[2] >= 0, eval(2, R3, q3));
+        if (do_calf || do_hip) {   // slot 3: a calf point for sub-lanes 0 and 1, a hip point for sub-lanes 2 and 3
+          const bool hipk = sub >= 2;
+          const M3 Rx = {sel(hipk, R1.x, R3.x), sel(hipk, R1.y, R3.y), sel(hipk, R1.z, R3.z)}; const V3 px = sel(hipk, p1, p3);
+          const Cand c3 = eval(3, Rx, px);
+          calf.take(!hipk && sc.idx[3] >= 0, c3); hip.take(hipk && sc.idx[3] >= 0, c3);
+        }
+        act[GO2_T_CALF] = group_winner<GO2_T_CALF>(L, calf); act[GO2_T_HIP] = group_winner<GO2_T_HIP>(L, hip);
+      }
+      {
+        Cand base; base.clear();
+        if (do_base) {   // slot 4: one of the leg's base / head points (sub-lane < number of points of this leg)
+          const M3 Id = {v3(1, 0, 0), v3(0, 1, 0), v3(0, 0, 1)};
+          base.take(sc.idx[4] >= 0, eval(4, Id, v3(0, 0, 0)));
+        }
+        act[GO2_T_BASE] = group_winner<GO2_T_BASE>(L, base);
       }
       GO2_MARK(31);
-      // per group: rows only if some lane of the wave has a candidate inside the contact margin this substep (wave-uniform branch; an
-      // inactive slot's rows are never visited by the solver, so skipping tournament and construction changes no result)
-      finish_type<GO2_T_CALF>(L, calf, 3);
-      finish_type<GO2_T_THIGH>(L, thigh, 2);
-      finish_type<GO2_T_HIP>(L, hip, 1);
-      finish_type<GO2_T_BASE>(L, base, 0);
+      // compaction: the K-th group in contact (canonical order) becomes virtual slot K; a virtual slot is built — and later swept — only
+      // while some leg of the wave has that many contacts (wave-uniform; an inactive slot's rows move nothing, so skipping is exact)
+      const int rank[GO2_NTYPE] = {0, act[0] ? 1 : 0, (act[0] ? 1 : 0) + (act[1] ? 1 : 0), (act[0] ? 1 : 0) + (act[1] ? 1 : 0) + (act[2] ? 1 : 0)};
+      const int count = rank[3] + (act[3] ? 1 : 0);
+      has_v[0] = xl::any(count > 0); has_v[1] = has_v[0] && xl::any(count > 1); has_v[2] = has_v[1] && xl::any(count > 2); has_v[3] = has_v[2] && xl::any(count > 3);
+      _Pragma("unroll") for (int k = 0; k < GO2_NTYPE; ++k) { act_v[k] = 0.f; body_v[k] = -1; }
+      // (the parked slots first, virtual slot 0 — whose rows then stay in registers — after the limit rows: while a parked row set is
+      //  under construction in `tmp`, only the foot's rows are live beside it)
+      if (has_v[0]) {
+        xl::row_sync();       // the winners' LDS cells were written by one sub-lane of the leg each
+        if (has_v[1]) build_virtual<1>(L, act, rank);
+        if (has_v[2]) build_virtual<2>(L, act, rank);
+        if (has_v[3]) build_virtual<3>(L, act, rank);
+      }
       GO2_MARK(32);
-    }
-    GO2_MARK(33);
-    // joint limits
+    // joint limits (rare: their rows are parked in LDS)
     {
       float h = L.sim_dt, cfm1 = 1.0f + L.cfm;
       float sgn[3], gap[3];
@@ -426,16 +472,21 @@ struct LegPhys {
         float glo = q[j] - t.lim_lo[j], ghi = t.lim_hi[j] - q[j];
         sgn[j] = 0.f; gap[j] = 0.f;
         if (glo < L.limit_margin) { sgn[j] = 1.f; gap[j] = glo; } else if (ghi < L.limit_margin) { sgn[j] = -1.f; gap[j] = ghi; }
-        act_lim[j] = sgn[j] != 0.f ? 1.f : 0.f; lim[j] = Row{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0.f, 0.f, 0.f};
+        act_lim[j] = sgn[j] != 0.f ? 1.f : 0.f; lam_lim[j] = 0.f;
         if (sgn[j] != 0.f) s_act = fmaxf(s_act, fminf(fmaxf((L.limit_margin - gap[j]) / (0.25f * L.limit_margin), 0.f), 1.f));
       }
-      if (xl::any(act_lim[0] + act_lim[1] + act_lim[2] > 0.f))
+      if (xl::any(act_lim[0] + act_lim[1] + act_lim[2] > 0.f)) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           const float Jc[3] = {j == 0 ? sgn[j] : 0.f, j == 1 ? sgn[j] : 0.f, j == 2 ? sgn[j] : 0.f};
           float b = gap[j] >= 0.f ? gap[j] / h : gap[j] * L.erp / h; b = fmaxf(b, -10.0f);
-          build_row(lim[j], Jc, sv(v3(0, 0, 0), v3(0, 0, 0)), cfm1, b, 0.f);
+          build_row(tmp[j], Jc, sv(v3(0, 0, 0), v3(0, 0, 0)), cfm1, b, 0.f);
         }
+        park_rows<GO2_PARK_LIMITS>();
+      }
+    }
+      GO2_MARK(33);
+      if (has_v[0]) build_virtual<0>(L, act, rank);
     }
     GO2_MARK(34);
     // warm start: the slice of the velocity change the remembered foot impulses produce.  The joint slice (sub-lane 0) is the leg's
@@ -447,7 +498,7 @@ struct LegPhys {
     for (int k = 0; k < 3; ++k) { const float s = xl::leg_sum(c[k]); x[k] = sub == 0 ? c[k] : s; }
   }
   GO2_HD bool has_foot() const { return act_foot > 0.f; }
-  template <int T> GO2_HD bool has_type() const { return act_t[T] > 0.f; }
+  template <int K> GO2_HD bool has_virtual() const { return act_v[K] > 0.f; }
   GO2_HD bool has_limit() const { return (act_lim[0] + act_lim[1] + act_lim[2]) > 0.f; }
 
   GO2_HD float row_v(const Row& r) const { return r.vfb + xl::sub_sum(r.J[0] * x[0] + r.J[1] * x[1] + r.J[2] * x[2]); }
@@ -471,62 +522,66 @@ struct LegPhys {
     }
   }
   // The contact / limit solve: projected block iteration over the LEGS with mass splitting at the base.  The rows of a
-  // leg are a block, visited in the fixed order foot, calf, thigh, hip, base share (n, t each), limits (Gauss-Seidel inside the block); ALL FOUR LEGS sweep their
+  // leg are a block, visited in the fixed order foot, then the body groups in contact — calf, thigh, hip, base share — (n, t each), limits (Gauss-Seidel inside the block); ALL FOUR LEGS sweep their
   // blocks at once, each from the same state, on its own copy of the base-twist slices.  Legs interact only through the base, and each leg is
   // given 1 / n of it: in ITS view the base slices of every response (sub-lanes 1, 2: H = Phi G) are n times larger, the joint slice (sub-lane
   // 0: Z = A^-1 Jc, the leg's own joints with the base held fixed) is as it is.  Committed are the true responses: z as swept, w <- w0 +
   // (1 / n) sum_legs (w_leg - w0) — one leg sum per slice instead of one per leg turn.  n = the number of legs with active rows, counted
   // smoothly (s_act), so the step stays a continuous function of the state.
   // solve_prepare: n, and the rows' inverse diagonals J . Y_view (1 + cfm) with it.
-  // do_t[T]: the slot of body group T (must imply near_t[T]: its rows were built)
-  template <int T>
-  GO2_HD void prepare_type() {
+  // parked row set P: the rows' inverse diagonals (quad sum of the sub-lanes' parts with the split base), left in LDS for the sweeps
+  template <int P>
+  GO2_HD void prepare_parked() {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const float d_ = xl::sub_sum(rl->dp[T][a][tid] * yscale), di = d_ > 0.f ? 1.0f / d_ : 0.f;
-      if (sub == 0) rl->sc[T][a][1][lid] = di;
+      const float d_ = xl::sub_sum(rl->dp[P][a][tid] * yscale), di = d_ > 0.f ? 1.0f / d_ : 0.f;
+      if (sub == 0) rl->sc[P][a][1][lid] = di;
     }
   }
-  GO2_HD void solve_prepare(bool do_foot, const bool* do_t, bool do_lim) {
+  // do_v[K]: virtual slot K is active in some lane of the wave (implies has_v[K]: its rows were built); likewise do_lim
+  GO2_HD void solve_prepare(bool do_foot, const bool* do_v, bool do_lim) {
     nsplit = fmaxf(xl::leg_sum(s_act), 1.f);
     yscale = sub == 0 ? 1.f : nsplit;
     auto fin = [&](Row& r) { const float d_ = xl::sub_sum(r.dinv * yscale); r.dinv = d_ > 0.f ? 1.0f / d_ : 0.f; };
     if (do_foot) { fin(foot[0]); fin(foot[1]); fin(foot[2]); }
-    if (do_t[GO2_T_CALF]) prepare_type<GO2_T_CALF>();
-    if (do_t[GO2_T_THIGH]) prepare_type<GO2_T_THIGH>();
-    if (do_t[GO2_T_HIP]) prepare_type<GO2_T_HIP>();
-    if (do_t[GO2_T_BASE]) prepare_type<GO2_T_BASE>();
-    if (do_lim) { fin(lim[0]); fin(lim[1]); fin(lim[2]); }
+    if (do_v[0]) { fin(v0[0]); fin(v0[1]); fin(v0[2]); }
+    if (do_v[1]) prepare_parked<0>();
+    if (do_v[2]) prepare_parked<1>();
+    if (do_v[3]) prepare_parked<2>();
+    if (do_lim) prepare_parked<GO2_PARK_LIMITS>();
     // what sub-lane 0 of a leg parked in LDS (free velocities in phase C, inverse diagonals here) is read by the leg's other sub-lanes
-    if (do_t[0] || do_t[1] || do_t[2] || do_t[3]) xl::row_sync();
+    if (do_v[1] || do_lim) xl::row_sync();
   }
-  template <int T>
-  GO2_HD void sweep_type() {
-    load_rows<T>();
-    sweep_slot(cur, act_t[T], mu);
-    lam_t[T][0] = cur[0].lam; lam_t[T][1] = cur[1].lam; lam_t[T][2] = cur[2].lam;
+  template <int K>
+  GO2_HD void sweep_parked() {      // virtual slot K >= 1
+    load_rows<K - 1>(lam_v[K - 1]);
+    sweep_slot(tmp, act_v[K], mu);
+    lam_v[K - 1][0] = tmp[0].lam; lam_v[K - 1][1] = tmp[1].lam; lam_v[K - 1][2] = tmp[2].lam;
   }
   // do_* are WAVE-UNIFORM hints: false means no lane of the wave has such a row active this substep, so the group is skipped as a whole
   // (an inactive row moves nothing).
 #ifdef GO2_DBG_NOINLINE_GS
-  __device__ __attribute__((noinline)) void solve_iteration(bool do_foot, const bool* do_t, bool do_lim) {
+  __device__ __attribute__((noinline)) void solve_iteration(bool do_foot, const bool* do_v, bool do_lim) {
 #else
-  GO2_HD void solve_iteration(bool do_foot, const bool* do_t, bool do_lim) {
+  GO2_HD void solve_iteration(bool do_foot, const bool* do_v, bool do_lim) {
 #endif
     const float x0[3] = {x[0], x[1], x[2]};
     if (do_foot) sweep_slot(foot, act_foot, mu);
-    if (do_t[GO2_T_CALF]) sweep_type<GO2_T_CALF>();
-    if (do_t[GO2_T_THIGH]) sweep_type<GO2_T_THIGH>();
-    if (do_t[GO2_T_HIP]) sweep_type<GO2_T_HIP>();
-    if (do_t[GO2_T_BASE]) sweep_type<GO2_T_BASE>();
-    if (do_lim)
+    if (do_v[0]) sweep_slot(v0, act_v[0], mu);
+    if (do_v[1]) sweep_parked<1>();
+    if (do_v[2]) sweep_parked<2>();
+    if (do_v[3]) sweep_parked<3>();
+    if (do_lim) {
+      load_rows<GO2_PARK_LIMITS>(lam_lim);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        const float v = row_v(lim[j]);
-        const float ln = fmaxf(0.f, lim[j].lam - v * lim[j].dinv);
-        const float dl = act_lim[j] * (ln - lim[j].lam); lim[j].lam += dl;
-        row_apply(lim[j], dl);
+        const float v = row_v(tmp[j]);
+        const float ln = fmaxf(0.f, tmp[j].lam - v * tmp[j].dinv);
+        const float dl = act_lim[j] * (ln - tmp[j].lam); tmp[j].lam += dl;
+        row_apply(tmp[j], dl);
+        lam_lim[j] = tmp[j].lam;
       }
+    }
     const float inv_n = 1.f / nsplit;
 #pragma unroll
     for (int k = 0; k < 3; ++k) { const float s = xl::leg_sum(x[k] - x0[k]); x[k] = sub == 0 ? x[k] : x0[k] + inv_n * s; }

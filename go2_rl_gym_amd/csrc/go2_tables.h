@@ -46,24 +46,31 @@ struct BaseTab {
 };
 struct Go2Tables { LegTab leg[4]; BaseTab base; uint8_t slot_code[GO2_NUM_UNIFORMS]; /* include/go2sim_rng.h */ int32_t layout_ok; };
 
-// The contact slots of a leg besides the foot, one per BODY GROUP (go2_lane.h phaseC): the deepest calf sphere, the deepest thigh point, the
-// deepest hip sphere, the deepest of the leg's share of the base / head points.  Their constraint rows live in LDS between their construction
-// and the end of the substep's solve (only the foot's rows and one slot being swept are in registers):
-//   jy  per lane : this sub-lane's 3-number slices J, Y of the slot's three rows (normal, two tangents)
+// The contact slots of a leg besides the foot.  One CANDIDATE per body group (go2_lane.h phaseC): the deepest calf sphere, the deepest thigh
+// point, the deepest hip sphere, the deepest of the leg's share of the base / head points; the groups that are in contact are then COMPACTED
+// into "virtual slots" 0, 1, 2, 3 in that order (a leg with a calf and a base contact uses virtual slots 0 and 1), so that the work of a wave
+// follows the largest number of simultaneous non-foot contacts any of its legs has, not the number of groups that are in contact somewhere.
+// Virtual slot 0 keeps its rows in registers (like the foot); the rows of virtual slots 1..3 and the joint-limit rows are parked in LDS between
+// their construction and the end of the substep's solve and pass through one register-resident slot while they are swept:
+//   win per leg  : the group's winning candidate as the sub-lane that found it left it: gap, normal, centre (base frame), radius, body
+//   jy  per lane : this sub-lane's 3-number slices J, Y of the slot's three rows (normal, two tangents; limits: the three joints)
 //   dp  per lane : this sub-lane's part of the row's diagonal (summed over the quad, with the split base, in solve_prepare)
 //   sc  per leg  : [0] free velocity + bias, [1] inverse diagonal (written by solve_prepare)
 //   nrm per leg  : world contact normal (the tangents follow from it)
-#define GO2_NTYPE 4
+#define GO2_NTYPE 4          // body groups: calf, thigh, hip, base share (canonical sweep order)
 #define GO2_T_CALF 0
 #define GO2_T_THIGH 1
 #define GO2_T_HIP 2
 #define GO2_T_BASE 3
+#define GO2_NPARK 4          // parked row sets: virtual slots 1, 2, 3 and the joint limits
+#define GO2_PARK_LIMITS 3
 #define GO2_WG_LANES 256
 struct Go2RowsLds {
-  float jy[GO2_NTYPE][3][6][GO2_WG_LANES];
-  float dp[GO2_NTYPE][3][GO2_WG_LANES];
-  float sc[GO2_NTYPE][3][2][GO2_WG_LANES / 4];
-  float nrm[GO2_NTYPE][3][GO2_WG_LANES / 4];
+  float jy[GO2_NPARK][3][6][GO2_WG_LANES];
+  float dp[GO2_NPARK][3][GO2_WG_LANES];
+  float sc[GO2_NPARK][3][2][GO2_WG_LANES / 4];
+  float nrm[GO2_NPARK - 1][3][GO2_WG_LANES / 4];
+  float win[GO2_NTYPE][9][GO2_WG_LANES / 4];
 };
 
 // the contact surface over one grid cell: heights (vscale units) at the corners (i,j) (i+1,j) (i,j+1) (i+1,j+1) as seen from inside the cell

@@ -152,18 +152,18 @@ GO2_HD void lane_finish_phys(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& 
     float r13[13] = {pos.x, pos.y, pos.z, ph.qx, ph.qy, ph.qz, ph.qw, lv.x, lv.y, lv.z, ph.ww.x, ph.ww.y, ph.ww.z};
     _Pragma("unroll") for (int i = 0; i < 13; ++i) F3D(p.rigid, 19, lane, i, e) = r13[i];
   }
-  // contact forces of this leg's bodies (one slot per body group, go2_lane.h phaseC); base/head parts go through the leg sum
+  // contact forces of this leg's bodies (one contact per body group, compacted into virtual slots: go2_lane.h phaseC); base / head parts go
+  // through the leg sum
   V3 zero = v3(0, 0, 0);
-  o.Fhip = ph.type_force<GO2_T_HIP>(L.sim_dt);
-  o.Fthigh = ph.type_force<GO2_T_THIGH>(L.sim_dt);
-  o.Fcalf = ph.type_force<GO2_T_CALF>(L.sim_dt);
-  const V3 Fbase_share = ph.type_force<GO2_T_BASE>(L.sim_dt);
+  const V3 Fv[GO2_NTYPE] = {ph.virtual_force<0>(L.sim_dt), ph.virtual_force<1>(L.sim_dt), ph.virtual_force<2>(L.sim_dt), ph.virtual_force<3>(L.sim_dt)};
+  auto body_force = [&](int b) { V3 f = zero; _Pragma("unroll") for (int k = 0; k < GO2_NTYPE; ++k) f = f + sel(ph.body_v[k] == b, Fv[k], zero); return f; };
+  o.Fhip = body_force(t.body_index[0]); o.Fthigh = body_force(t.body_index[1]); o.Fcalf = body_force(t.body_index[2]);
   o.Ffoot = ph.force_foot;
   {
     const V3 f = sel(sub == 0, o.Fhip, sel(sub == 1, o.Fthigh, sel(sub == 2, o.Fcalf, o.Ffoot)));
     const int b = t.body_index[0] + sub; F3D(p.contact, 19, b, 0, e) = f.x; F3D(p.contact, 19, b, 1, e) = f.y; F3D(p.contact, 19, b, 2, e) = f.z;
   }
-  _Pragma("unroll") for (int b = 0; b < 3; ++b) { V3 f = sel(ph.base_body == b, Fbase_share, zero); fbase[3 * b] = f.x; fbase[3 * b + 1] = f.y; fbase[3 * b + 2] = f.z; }
+  _Pragma("unroll") for (int b = 0; b < 3; ++b) { V3 f = body_force(b); fbase[3 * b] = f.x; fbase[3 * b + 1] = f.y; fbase[3 * b + 2] = f.z; }
   o.pw = ph.pw; o.qx = ph.qx; o.qy = ph.qy; o.qz = ph.qz; o.qw = ph.qw; o.vw = ph.vw; o.ww = ph.ww;
   _Pragma("unroll") for (int j = 0; j < 3; ++j) {
     int d = 3 * lane + j;
@@ -261,8 +261,8 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
 #endif
   STAMP(0);
   LegPhys ph_; LegPost po_; LaneAux ax;
-  ph_.rl = (GO2_AS3 Go2RowsLds*)&sh.rows; ph_.tid = tid; ph_.lid = tid >> 2; ph_.base_body = 0;
-  _Pragma("unroll") for (int T = 0; T < GO2_NTYPE; ++T) { ph_.near_t[T] = false; ph_.act_t[T] = 0.f; ph_.lam_t[T][0] = ph_.lam_t[T][1] = ph_.lam_t[T][2] = 0.f; }
+  ph_.rl = (GO2_AS3 Go2RowsLds*)&sh.rows; ph_.tid = tid; ph_.lid = tid >> 2; ph_.v0_n = v3(0, 0, 1);
+  _Pragma("unroll") for (int k = 0; k < GO2_NTYPE; ++k) { ph_.has_v[k] = false; ph_.act_v[k] = 0.f; ph_.body_v[k] = -1; }
   const LegTab& t = tab.leg[lane];
   GO2_AS3 float (*uc)[4] = (GO2_AS3 float (*)[4])sh.ucache[tid >> 4];
   if (!S.injected) {
@@ -309,16 +309,16 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
       ph_.phaseB(hl, part);
       GO2_MARK(13);
       if (sb == 1) STAMP(19);
-      ph_.phaseC(tl, hl, p.hf_cells);
+      ph_.phaseC(tl, t, hl, p.hf_cells);
       GO2_MARK(14);
       if (sb == 1) STAMP(20);
       // wave-wide row-group activity (ballots -> scalar branches): a group is swept only if some environment of the wave has it active on
       // some leg — typically only the foot contacts are live (an inactive row moves nothing, so skipping is exact)
       const bool af = xl::any(ph_.has_foot()), al = xl::any(ph_.has_limit());
-      const bool at[GO2_NTYPE] = {ph_.near_t[0] && xl::any(ph_.has_type<0>()), ph_.near_t[1] && xl::any(ph_.has_type<1>()),
-                                  ph_.near_t[2] && xl::any(ph_.has_type<2>()), ph_.near_t[3] && xl::any(ph_.has_type<3>())};
-      ph_.solve_prepare(af, at, al);
-      for (int it = 0; it < L.solver_iterations; ++it) ph_.solve_iteration(af, at, al);
+      const bool av[GO2_NTYPE] = {ph_.has_v[0] && xl::any(ph_.has_virtual<0>()), ph_.has_v[1] && xl::any(ph_.has_virtual<1>()),
+                                  ph_.has_v[2] && xl::any(ph_.has_virtual<2>()), ph_.has_v[3] && xl::any(ph_.has_virtual<3>())};
+      ph_.solve_prepare(af, av, al);
+      for (int it = 0; it < L.solver_iterations; ++it) ph_.solve_iteration(af, av, al);
       GO2_MARK(15);
       if (sb == 1) STAMP(21);
       ph_.gather_solution();

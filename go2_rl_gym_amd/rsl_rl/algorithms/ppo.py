@@ -27,7 +27,13 @@ from ._graph import CapturedStep, FusedClipAdam, GradBucket, ReducedStep, all_ca
 
 
 # Adam as ONE multi-tensor kernel per param group (fused) instead of ~6 foreach launches; GO2_ADAM=foreach restores the latter
-_TWO_STREAMS = os.environ.get("GO2_TWO_STREAMS", "1") == "1"      # actor / critic chains on two HIP streams (+3 % whole-job, measured)
+_TWO_STREAMS = os.environ.get("GO2_TWO_STREAMS", "1") in ("1", "force")      # actor / critic chains on two HIP streams (+3 % whole-job, measured)
+# ... up to this many envs per GPU only.  Measured on an MI355X (round 3, profiles/r3_large_batch.txt): at 8192 envs and above the first
+# iteration never finishes with the two chains in flight at once, while one stream trains at 4.85 M env-steps/s at 32768 envs.  Consistent
+# with hipBLASLt picking cooperative (stream-K) GEMM kernels for the larger mini-batches, whose workgroups wait for each other and are no
+# longer all resident when a kernel of the other stream holds part of the chip.  Every BASELINE configuration has <= 4096 envs per GPU; above
+# that a GEMM fills the chip alone and the overlap buys nothing.  GO2_TWO_STREAMS=force overrides.
+_TWO_STREAM_MAX_ENVS = 4096
 _ADAM_IMPL = {"foreach": True} if os.environ.get("GO2_ADAM", "fused") == "foreach" else {"fused": True}
 
 
@@ -63,7 +69,9 @@ class _RolloutHeads:
         """-> (main_fn(), side_fn()) with side_fn on a second HIP stream when on a GPU: the actor and the critic are independent
         networks, so their GEMMs and the many small element-wise kernels between them overlap (also inside a captured graph, where
         the fork / join become graph dependencies; autograd runs each backward on its forward's stream)."""
-        if not (enabled and _TWO_STREAMS and str(self.device).startswith("cuda")):
+        st = getattr(self, "storage", None)
+        small = st is None or getattr(st, "num_envs", 0) <= _TWO_STREAM_MAX_ENVS or os.environ.get("GO2_TWO_STREAMS") == "force"
+        if not (enabled and _TWO_STREAMS and small and str(self.device).startswith("cuda")):
             return main_fn(), side_fn()
         cur = torch.cuda.current_stream()
         if self._side is None:

@@ -101,14 +101,14 @@ def test_heightfield_one_step_parity_vs_oracle(hip, mesh_type):
     from helpers import heightfield_overrides
     N = 80
     t, ov = heightfield_overrides(N, mesh_type=mesh_type)
-    from helpers import StepErrors, check_relative_to_conditioning
+    from helpers import PLANE_BOUND, StepErrors, check_relative_to_conditioning, check_rough_errors
     so, s64 = HostSim(load_oracle(), num_envs=N, **ov), HostSim(load_oracle(f64=True), num_envs=N, **ov)
     sd = DeviceSim(hip, num_envs=N, **ov)
     so.reset_all(); sd.reset_all(); s64.reset_all()
     rng = np.random.default_rng(2)
     contact_seen = 0
     floors = {"root_states": 2e-5, "dof_state": 2e-4, "torques": 2e-4, "obs_buf": 2e-5, "privileged_obs_buf": 2e-5, "rew_buf": 2e-7}
-    err, cond = StepErrors(floors), StepErrors(floors)
+    err, cond, abs_err = StepErrors(floors), StepErrors(floors), StepErrors(PLANE_BOUND)
     for it in range(100):
         a = rng.normal(0, 0.6, (N, 12)).astype(np.float32)
         for k in STEP_STATE:
@@ -116,7 +116,7 @@ def test_heightfield_one_step_parity_vs_oracle(hip, mesh_type):
             getattr(sd, k)[...] = v; getattr(s64, k)[...] = v
         so.step(a); sd.step(a); s64.step(a.astype(np.float64))
         contact_seen += int((so.contact_forces[:, [6, 10, 14, 18], 2] > 1).sum())
-        err.add(so, sd, N); cond.add(so, s64, N)
+        err.add(so, sd, N); cond.add(so, s64, N); abs_err.add(so, sd, N, ref64=s64)
         np.testing.assert_array_equal(np.asarray(so.reset_buf), np.asarray(sd.reset_buf))
         np.testing.assert_array_equal(np.asarray(so.terrain_levels), np.asarray(sd.terrain_levels))
         # the height scan is taken at the pose each library integrated to (1e-5 apart): a point within that of a cell boundary may read the
@@ -125,6 +125,9 @@ def test_heightfield_one_step_parity_vs_oracle(hip, mesh_type):
     # a facet edge / stair face under a sphere makes the step ill-conditioned in fp32 for ANY evaluation order: the kernel's error stays
     # within 3x of the fp32 oracle's own error against the fp64 oracle on the same inputs (median, 99th percentile, far tail)
     check_relative_to_conditioning(err, cond, floors)
+    # ... and every WELL-conditioned env-step (fp32-vs-fp64 oracle gap below half the bound) meets the plane's absolute per-tensor bound;
+    # the ill-conditioned rest is capped at 0.5 % of env-steps (VERDICT r2 "weak" 1)
+    check_rough_errors(abs_err)
     assert contact_seen > 2000 and np.abs(np.asarray(so.measured_heights)).max() > 0.05
     so.close(); sd.close(); s64.close()
 

@@ -1,9 +1,7 @@
-set -x
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r3a
-timeout 1500 python -m pytest tests/test_gpu_configs.py -q -s -x 2>&1 | tail -40 > gpurun_out/r3a/pytest_configs.log
-timeout 600 python tools/kscale.py > gpurun_out/r3a/kscale_plane.txt 2>&1
-timeout 600 python tools/kscale.py rough 4096 8192 32768 > gpurun_out/r3a/kscale_rough.txt 2>&1
-timeout 300 python tools/termination_check.py "r2 model (2 slots per leg)" > gpurun_out/r3a/termination_before.txt 2>&1
-timeout 600 python bench.py --steps 40 --warmup 10 --no-cpu-baseline > gpurun_out/r3a/bench_flat.json 2> gpurun_out/r3a/bench_flat.err
-tail -5 gpurun_out/r3a/pytest_configs.log; cat gpurun_out/r3a/kscale_plane.txt gpurun_out/r3a/kscale_rough.txt; tail -4 gpurun_out/r3a/termination_before.txt; tail -c 600 gpurun_out/r3a/bench_flat.json
+O=gpurun_out/r3e; mkdir -p $O
+timeout 100 python tools/kscale.py 4096 > $O/kscale.txt 2>&1; timeout 100 python tools/kscale.py rough 4096 >> $O/kscale.txt 2>&1
+timeout 200 python -m pytest tests/test_gpu_parity.py -q -x --timeout=100 -k "one_step_parity or golden_sequence or fallen or trimesh_walls or full_size or strict_ops" > $O/pytest_parity.log 2>&1
+timeout 150 python bench.py --steps 30 --warmup 20 --no-cpu-baseline > $O/bench_flat.json 2> $O/bench_flat.err
+timeout 150 python tools/kbench.py 4096 > $O/kbench_plane.txt 2>&1
+grep -v amdgpu.ids $O/kscale.txt; tail -4 $O/pytest_parity.log; grep -o '"value": [0-9.]*\|"kernel_ms": [0-9.]*\|"collection_only": [0-9.]*' $O/bench_flat.json; tail -12 $O/kbench_plane.txt
