@@ -42,9 +42,6 @@ enum { MODE_PHYS = 1, MODE_POST = 2, MODE_RESET_ALL = 4 };
 // Workgroup = 256 threads = 4 waves = 16 environments; one 16-lane DPP row = one environment, row lane = leg * 4 + sub.
 // ------------------------------------------------------------------------------------------------------
 #define GO2_WG_ENVS 16
-#ifndef GO2_OCC2_MIN_ENVS
-#define GO2_OCC2_MIN_ENVS (1 << 30)      // (set from the measured crossover, profiles/r3_kernel_scaling.txt)
-#endif
 #define GO2_WG_THREADS (16 * GO2_WG_ENVS)
 // The lane context is kept as THREE separate objects (not one struct): the compiler's scalar-replacement pass gives up on a
 // single 2.4 KB aggregate with thousands of uses and would leave all of it in scratch memory.
@@ -363,15 +360,6 @@ __global__ void __launch_bounds__(GO2_WG_THREADS) go2_step_kernel(const Go2DevBl
   __shared__ Go2Shared sh;
   go2_step_body<MODE>(sh, blk, actions_in, initial_reset, outs, blockIdx.x, threadIdx.x);
 }
-// The SAME lane programs under a 256-register budget (two waves per SIMD; what does not fit goes to scratch memory): the mapping for batches
-// of more than one wave per SIMD (> 4096 envs per GPU), where a second resident wave hides the dependent-issue latency that the one-wave
-// build exposes.  Selected by num_envs at go2sim_create (Go2Sim.variant; GO2_STEP_VARIANT overrides), same source, same results.
-__global__ void __launch_bounds__(GO2_WG_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
-go2_step_kernel_occ2(const Go2DevBlock* __restrict__ blk, const float* __restrict__ actions_in, int initial_reset, const Go2StepOutputs outs) {
-  __shared__ Go2Shared sh;
-  go2_step_body<MODE_PHYS | MODE_POST>(sh, blk, actions_in, initial_reset, outs, blockIdx.x, threadIdx.x);
-}
-
 // ---- test hooks (declared in include/go2sim.h under "test hooks"; no product path calls them) --------------------------------
 // legged_robot.py:67-81 on the kernel's own pd() / delay select with caller-supplied DOF states per substep ("fake physics"): what the
 // oracle's go2o_torque_trace does, so the reference's golden torques can be compared with the HIP arithmetic directly.
@@ -788,7 +776,6 @@ struct Go2Sim {
   float dt, max_episode_length;
   float* inj_storage; Go2Tables* d_tables; int16_t* d_hf; Go2Cell* d_cells; float* d_torigins;
   int timing; double time_ms; int64_t time_launches;
-  int variant;              // which build of the step kernel go2sim_step launches: 1 = one wave per SIMD (all registers), 2 = two waves per SIMD
 #ifndef GO2_EMU
   std::vector<hipEvent_t> ev; size_t ev_used;
 #endif
@@ -944,12 +931,6 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
   Go2Sim* s = new Go2Sim();
   s->cfg = *cfg; const int N = s->N = cfg->num_envs;
   s->d_hf = nullptr; s->d_cells = nullptr; s->d_torigins = nullptr; s->timing = 0; s->time_ms = 0; s->time_launches = 0;
-  { // lane mapping / register budget by batch size: up to GO2_OCC2_MIN_ENVS - 1 envs the one-wave-per-SIMD build, above it the
-    // two-wave build; GO2_STEP_VARIANT=1|2 forces one (tools/kscale.py measures both)
-    s->variant = N >= GO2_OCC2_MIN_ENVS ? 2 : 1;
-    const char* v = getenv("GO2_STEP_VARIANT");
-    if (v && (v[0] == '1' || v[0] == '2') && v[1] == 0) s->variant = v[0] - '0';
-  }
 #ifndef GO2_EMU
   s->ev_used = 0;
 #endif
@@ -1161,7 +1142,6 @@ static int launch(Go2Sim* s, int mode, const float* actions_in, int initial_rese
   }
   if ((mode & MODE_POST) && s->h.L.heading_command) hipLaunchKernelGGL(go2_cb_scan_kernel, dim3(1), dim3(256), 0, st, s->d_blk);
   if (mode == MODE_RESET_ALL) hipLaunchKernelGGL(go2_step_kernel<MODE_RESET_ALL>, grid, block, 0, st, s->d_blk, actions_in, initial_reset, outs);
-  else if (mode == (MODE_PHYS | MODE_POST) && s->variant == 2) hipLaunchKernelGGL(go2_step_kernel_occ2, grid, block, 0, st, s->d_blk, actions_in, initial_reset, outs);
   else if (mode == (MODE_PHYS | MODE_POST)) hipLaunchKernelGGL(go2_step_kernel<MODE_PHYS | MODE_POST>, grid, block, 0, st, s->d_blk, actions_in, initial_reset, outs);
   else if (mode == MODE_PHYS) hipLaunchKernelGGL(go2_step_kernel<MODE_PHYS>, grid, block, 0, st, s->d_blk, actions_in, initial_reset, outs);
   else hipLaunchKernelGGL(go2_step_kernel<MODE_POST>, grid, block, 0, st, s->d_blk, actions_in, initial_reset, outs);

