@@ -1,0 +1,138 @@
+"""ctypes binding of include/go2nn.h (the policy-side MFMA kernels) and the small host object the algorithms use.
+
+`load_nn()` loads go2_rl_gym_amd/libgo2nn_hip.so and raises if it is missing — like _lib.load_hip there is no CPU fallback in the product;
+tests hand `PolicyKernel` the host build (tests/emu/libgo2nn_emu.so) explicitly."""
+import ctypes as C
+import os
+
+import torch
+import torch.nn as nn
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+NN_LIB = os.path.join(_HERE, "libgo2nn_hip.so")
+GO2NN_MAX_LAYERS, GO2NN_MAX_WIDTH, GO2NN_ABI_VERSION = 6, 512, 1
+_cached = None
+
+
+class Go2nnMlp(C.Structure):
+    _fields_ = [("num_layers", C.c_int32), ("dims", C.c_int32 * (GO2NN_MAX_LAYERS + 1)),
+                ("weight", C.c_void_p * GO2NN_MAX_LAYERS), ("bias", C.c_void_p * GO2NN_MAX_LAYERS)]
+
+
+def bind(path):
+    lib = C.CDLL(path)
+    lib.go2nn_last_error.restype = C.c_char_p
+    lib.go2nn_packed_floats.restype = C.c_int64
+    lib.go2nn_packed_floats.argtypes = [C.POINTER(Go2nnMlp)]
+    lib.go2nn_pack.argtypes = [C.POINTER(Go2nnMlp), C.c_void_p, C.c_void_p]
+    lib.go2nn_mlp_forward.argtypes = [C.POINTER(Go2nnMlp), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.go2nn_policy_act.argtypes = [C.POINTER(Go2nnMlp), C.c_void_p, C.POINTER(Go2nnMlp), C.c_void_p] + [C.c_void_p] * 10 + [C.c_int32, C.c_void_p]
+    if lib.go2nn_abi_version() != GO2NN_ABI_VERSION:
+        raise RuntimeError("%s: ABI version %d, expected %d" % (path, lib.go2nn_abi_version(), GO2NN_ABI_VERSION))
+    return lib
+
+
+def load_nn():
+    global _cached
+    if _cached is None:
+        if not os.path.exists(NN_LIB):
+            raise RuntimeError("%s is missing: build it with `python -m go2_rl_gym_amd.build` (hipcc --offload-arch=gfx950). There is no CPU fallback." % NN_LIB)
+        torch.cuda.is_available()            # torch's HIP runtime first (see _lib.py)
+        lib = bind(NN_LIB)
+        if lib.go2nn_is_device_library() != 1:
+            raise RuntimeError("%s is not the HIP device library" % NN_LIB)
+        _cached = lib
+    return _cached
+
+
+def mlp_layers(seq):
+    """[(weight, bias)] of an nn.Sequential that is Linear, ELU(alpha=1), ..., Linear (rsl_rl/modules/actor_critic.py:_mlp), else None."""
+    mods = list(seq)
+    if len(mods) % 2 != 1:
+        return None
+    out = []
+    for k, m in enumerate(mods):
+        if k % 2 == 0:
+            if not isinstance(m, nn.Linear) or m.bias is None or m.weight.dtype != torch.float32:
+                return None
+            out.append((m.weight, m.bias))
+        elif not (isinstance(m, nn.ELU) and m.alpha == 1.0):
+            return None
+    dims = [out[0][0].shape[1]] + [w.shape[0] for w, _ in out]
+    if len(out) > GO2NN_MAX_LAYERS or max(dims) > GO2NN_MAX_WIDTH:
+        return None
+    return out
+
+
+class PackedMlp:
+    """One MLP's parameters as the kernels read them: the Go2nnMlp descriptor (pointers to the LIVE parameter tensors) and the packed operand
+    buffer, refreshed by pack() — one small launch — whenever the parameters have changed (once per rollout: they only change in update())."""
+
+    def __init__(self, lib, seq):
+        layers = mlp_layers(seq)
+        if layers is None:
+            raise ValueError("not a Linear/ELU MLP the kernel supports")
+        self.lib, self.layers = lib, layers
+        self.desc = Go2nnMlp()
+        self.desc.num_layers = len(layers)
+        self.desc.dims[0] = layers[0][0].shape[1]
+        for l, (w, b) in enumerate(layers):
+            assert w.is_contiguous() and b.is_contiguous()
+            self.desc.dims[l + 1] = w.shape[0]
+            self.desc.weight[l], self.desc.bias[l] = w.data_ptr(), b.data_ptr()
+        n = lib.go2nn_packed_floats(C.byref(self.desc))
+        if n <= 0:
+            raise ValueError(lib.go2nn_last_error().decode())
+        self.packed = torch.zeros(int(n), dtype=torch.float32, device=layers[0][0].device)
+        self.in_dim, self.out_dim = int(self.desc.dims[0]), int(self.desc.dims[len(layers)])
+
+    def _stream(self):
+        d = self.packed.device
+        return C.c_void_p(torch.cuda.current_stream(d).cuda_stream) if d.type == "cuda" else None
+
+    def still_valid(self):
+        return all(self.desc.weight[l] == w.data_ptr() and self.desc.bias[l] == b.data_ptr() for l, (w, b) in enumerate(self.layers))
+
+    def pack(self):
+        rc = self.lib.go2nn_pack(C.byref(self.desc), C.c_void_p(self.packed.data_ptr()), self._stream())
+        if rc != 0:
+            raise RuntimeError("go2nn_pack failed: %s" % self.lib.go2nn_last_error().decode())
+
+    def forward(self, x):
+        x = x.detach().contiguous().float()
+        y = torch.empty(x.shape[0], self.out_dim, dtype=torch.float32, device=x.device)
+        rc = self.lib.go2nn_mlp_forward(C.byref(self.desc), C.c_void_p(self.packed.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), x.shape[0], self._stream())
+        if rc != 0:
+            raise RuntimeError("go2nn_mlp_forward failed: %s" % self.lib.go2nn_last_error().decode())
+        return y
+
+
+class PolicyKernel:
+    """PPO.act (rsl_rl/algorithms/ppo.py:90-102) for an ActorCritic of two Linear/ELU MLPs and a state-independent std, as one launch."""
+
+    def __init__(self, lib, actor_critic):
+        self.lib, self.ac = lib, actor_critic
+        self.actor, self.critic = PackedMlp(lib, actor_critic.actor), PackedMlp(lib, actor_critic.critic)
+        if self.actor.out_dim > 32 or self.critic.out_dim != 1:
+            raise ValueError("head: up to 32 actions and a scalar value")
+
+    @staticmethod
+    def supports(actor_critic):
+        return (hasattr(actor_critic, "actor") and hasattr(actor_critic, "critic") and hasattr(actor_critic, "std") and mlp_layers(actor_critic.actor) is not None
+                and mlp_layers(actor_critic.critic) is not None and actor_critic.std.dim() == 1)
+
+    def pack(self):
+        self.actor.pack(); self.critic.pack()
+
+    def act(self, obs, critic_obs, eps, a_st=None, mu_st=None, sig_st=None, lp_st=None, v_st=None):
+        """-> actions [N, A]; the *_st tensors (storage rows of this step) are filled in place"""
+        N, A = obs.shape[0], self.actor.out_dim
+        actions = torch.empty(N, A, dtype=torch.float32, device=obs.device)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        for t in (obs, critic_obs, eps, a_st, mu_st, sig_st, lp_st, v_st):
+            assert t is None or (t.is_contiguous() and t.dtype == torch.float32), "contiguous float32 tensors"
+        rc = self.lib.go2nn_policy_act(C.byref(self.actor.desc), p(self.actor.packed), C.byref(self.critic.desc), p(self.critic.packed), p(obs), p(critic_obs),
+                                       p(self.ac.std.detach()), p(eps), p(actions), p(a_st), p(mu_st), p(sig_st), p(lp_st), p(v_st), N, self.actor._stream())
+        if rc != 0:
+            raise RuntimeError("go2nn_policy_act failed: %s" % self.lib.go2nn_last_error().decode())
+        return actions

@@ -69,6 +69,24 @@ def build_hip(force=False, verbose=False, out=OUT, flags=None):
     return OUT
 
 
+NN_SRC = os.path.join(HERE, "csrc", "go2nn_impl.cpp")
+NN_OUT = os.path.join(HERE, "libgo2nn_hip.so")
+
+
+def build_nn(force=False):
+    """The policy-side MFMA kernels (include/go2nn.h) -> go2_rl_gym_amd/libgo2nn_hip.so.  A library of its own, so that the sha256 that keys the
+    step kernel's counter profiles to libgo2sim_hip.so does not move when this one changes.  No -ffast-math (the head's log-probability and
+    ELU follow the eager formulation's arithmetic)."""
+    deps = [NN_SRC, os.path.join(ROOT, "include", "go2nn.h")]
+    if not force and os.path.exists(NN_OUT) and os.path.getmtime(NN_OUT) >= max(os.path.getmtime(p) for p in deps):
+        return NN_OUT
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-cuid=go2nn", "-o", NN_OUT, NN_SRC]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stderr[-4000:])
+    return NN_OUT
+
+
 def kernel_resources(so_path=OUT, match="go2_step_kernelILi3E"):
     """Register / scratch / LDS use of a kernel as the CODE OBJECT inside the shared library states it (the .note metadata the loader and
     the dispatcher act on): unbundle the gfx950 code object (llvm-objdump --offloading), read its notes (llvm-readelf --notes).
@@ -107,3 +125,5 @@ def kernel_resources(so_path=OUT, match="go2_step_kernelILi3E"):
 if __name__ == "__main__":
     print(build_hip(force=True, verbose=True))
     print(kernel_resources())
+    print(build_nn(force=True))
+    print(kernel_resources(NN_OUT, match="go2nn_mlp_kernel"))

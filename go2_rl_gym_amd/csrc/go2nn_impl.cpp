@@ -1,0 +1,361 @@
+// go2nn_impl.cpp — the C ABI of include/go2nn.h: the rollout's policy evaluation (PPO.act, rsl_rl/rsl_rl/algorithms/ppo.py:90-102) as ONE
+// fp32-MFMA kernel.
+//
+// Built two ways, like go2sim_impl.cpp:
+//   hipcc --offload-arch=gfx950  -> libgo2nn_hip.so : the product
+//   g++ -DGO2_EMU                -> libgo2nn_emu.so : TEST-ONLY host build; the same packed operand buffer read in the same order by plain
+//                                                     loops (checks the packing / padding / index arithmetic and the host side without a GPU)
+//
+// Kernel: grid = (ceil(N / 32), networks), 256 threads = 4 waves.  A workgroup carries 32 rows through every layer of ONE network:
+//   * activations: two [32][516] fp32 tiles in LDS (ping-pong; row pitch 516 floats = 4 banks off a multiple of 64: the per-lane 16-byte
+//     A-operand reads of 16 consecutive rows hit 64 different banks)
+//   * weights: streamed from L2 in the operand order of v_mfma_f32_32x32x2_f32, pre-packed by go2nn_pack: for output tile t (32 columns)
+//     and k-block kb (8 inputs) one 1-KiB wave load = lane (j = l & 31, g = l >> 5) -> W[32 t + j][8 kb + 4 g .. + 3]; the four elements
+//     feed four MFMAs whose k index (0 / 1 = the lane's g) then means input 8 kb + 4 g + e — the A operand is read from LDS with the
+//     same permutation, one ds_read_b128 per k-block shared by all the wave's tiles
+//   * a wave owns the output tiles wave, wave + 4, ... of a layer (4 accumulator tiles = 64 registers at width 512); bias + ELU in the
+//     epilogue, written to the other LDS tile as the next layer's input
+//   * the last layer's tile is the head: actor -> mu; a = mu + std * eps, log-probability, storage rows; critic -> value
+// No vendor GEMM library; fp32 in, fp32 accumulate (bit-wise a k-ordered fmaf chain per output, MI355X guide).
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/go2nn.h"
+
+#ifndef GO2_EMU
+#include <hip/hip_runtime.h>
+#endif
+
+static thread_local char g_err[256] = "";
+#define FAIL(code, ...) do { snprintf(g_err, sizeof(g_err), __VA_ARGS__); return (code); } while (0)
+
+#define NN_ROWS 32              // rows per workgroup (= the M of the MFMA tile)
+#define NN_LD (GO2NN_MAX_WIDTH + 4)
+#ifndef NN_THREADS
+#define NN_THREADS 512         // 8 waves = two per SIMD: one wave's load / LDS waits are filled with the other's MFMAs (measured: 256 -> 65 us, 512 -> see profiles/r3_policy_kernel.txt)
+#endif
+#define NN_WAVES (NN_THREADS / 64)
+
+// what the kernel needs of one network: padded shapes and the offsets of its layers in the packed buffer
+struct NetDesc {
+  int32_t nl, in_dim, out_dim;
+  int32_t K[GO2NN_MAX_LAYERS], N[GO2NN_MAX_LAYERS];      // true input / output width of layer l
+  int32_t KB[GO2NN_MAX_LAYERS], NT[GO2NN_MAX_LAYERS];    // k-blocks of 8, output tiles of 32
+  int64_t woff[GO2NN_MAX_LAYERS], boff[GO2NN_MAX_LAYERS];
+  const float* packed; const float* x;
+};
+struct NNArgs {
+  NetDesc net[2];
+  const float *std_, *eps; float *a_out, *a_st, *mu_st, *sig_st, *lp_st, *v_st; float* y;
+  int32_t N, A, mode;           // mode 0: forward of net[0] into y; mode 1: policy act (net[0] actor, net[1] critic)
+};
+
+static int describe(const Go2nnMlp* m, NetDesc* d, int64_t* total) {
+  if (!m || m->num_layers <= 0 || m->num_layers > GO2NN_MAX_LAYERS) return 0;
+  int64_t off = 0;
+  d->nl = m->num_layers; d->in_dim = m->dims[0]; d->out_dim = m->dims[m->num_layers];
+  for (int l = 0; l <= m->num_layers; ++l) if (m->dims[l] <= 0 || m->dims[l] > GO2NN_MAX_WIDTH) return 0;
+  for (int l = 0; l < m->num_layers; ++l) {
+    d->K[l] = m->dims[l]; d->N[l] = m->dims[l + 1];
+    d->KB[l] = (d->K[l] + 31) / 32 * 4; d->NT[l] = (d->N[l] + 31) / 32;      // k-blocks padded to a multiple of 4 = 32 inputs (zero weights): branch-free loops, and 32 NT[l-1] = 8 KB[l]
+    d->woff[l] = off; off += (int64_t)d->NT[l] * d->KB[l] * 64 * 4;
+    d->boff[l] = off; off += (int64_t)d->NT[l] * 32;
+  }
+  if (total) *total = off;
+  return 1;
+}
+
+#define HALF_LOG2PI 0.9189385332046727f
+
+#ifndef GO2_EMU
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) go2nn_pack_kernel(const float* __restrict__ W, const float* __restrict__ b, float* __restrict__ out_w, float* __restrict__ out_b,
+                                                         int K, int N, int KB, int NT) {
+  const int64_t nw = (int64_t)NT * KB * 256;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < nw + NT * 32; idx += (int64_t)gridDim.x * 256) {
+    if (idx < nw) {
+      const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63); const int64_t blk = idx >> 8;
+      const int kb = (int)(blk % KB), t = (int)(blk / KB);
+      const int n = 32 * t + (lane & 31), k = 8 * kb + 4 * (lane >> 5) + e;
+      out_w[idx] = (n < N && k < K) ? W[(int64_t)n * K + k] : 0.f;
+    } else {
+      const int n = (int)(idx - nw);
+      out_b[n] = n < N ? b[n] : 0.f;
+    }
+  }
+}
+
+// ELU(alpha = 1): exp(v) - 1 through the hardware exponential (v_exp_f32, ~1 ulp of exp): absolute error <= 1.2e-7 — fp32 round-off of the
+// activations' own scale; libm's expm1f costs ~40 instructions and the epilogue of a 512-wide layer evaluates it 64 times per lane
+__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : __expf(v) - 1.0f; }
+// a * b and a + b as two separately rounded operations (hipcc contracts `a + b * c`, and HIP's __fmul_rn is a plain product, into an FMA)
+__device__ __forceinline__ float mul_rn(float a, float b) { float r; asm("v_mul_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float add_rn(float a, float b) { float r; asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// One layer for one wave: NTW output tiles (t = first + NN_WAVES j), weights prefetched D k-blocks ahead through a register ring, the A operand
+// of the next k-block read from LDS while this one's MFMAs issue.  The loop body is branch-free (k-blocks are padded to a multiple of 4, tile
+// and block indices are clamped instead of tested) so that the compiler can count outstanding loads exactly: a wave waits for the OLDEST
+// wave load only, D NTW - NTW newer ones stay in flight (the one-tile layers have only 4 MFMAs = 256 cycles of work per k-block).
+template <int NTW>
+__device__ __forceinline__ void run_layer(const float* __restrict__ A, float* __restrict__ B, const float4* __restrict__ Wp, const float* __restrict__ bp,
+                                          int KB, int NT, int first, int lane, bool last) {
+  constexpr int D = NTW == 4 ? 2 : 4;
+  const int i = lane & 31, g = lane >> 5;
+  f32x16 acc[NTW];
+  const float4* wt[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int t = first + NN_WAVES * j < NT ? first + NN_WAVES * j : NT - 1;      // (a tile past the layer's last is a clamped duplicate whose result is dropped)
+    wt[j] = Wp + (int64_t)t * KB * 64 + lane;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  }
+  float4 ring[D][NTW];
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) ring[s][j] = wt[j][s * 64];
+  const float* arow = &A[i * NN_LD + 4 * g];
+  float4 a_next = *reinterpret_cast<const float4*>(arow);
+  for (int kb0 = 0; kb0 < KB; kb0 += D) {
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+      const int kb = kb0 + s;
+      float4 bc[NTW];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        // the block is consumed as ONE 16-byte value (empty asm on the register quad): left to itself the compiler splits the wave load
+        // into four 4-byte loads, one per MFMA, which quarters the efficiency of the L2 -> CU path
+        f32x4 q = {ring[s][j].x, ring[s][j].y, ring[s][j].z, ring[s][j].w};
+        asm volatile("" : "+v"(q));
+        bc[j] = make_float4(q[0], q[1], q[2], q[3]);
+      }
+      const int kn = kb + D < KB ? kb + D : KB - 1;
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) ring[s][j] = wt[j][kn * 64];
+      const float4 a4 = a_next;
+      a_next = *reinterpret_cast<const float4*>(arow + 8 * (kb + 1 < KB ? kb + 1 : KB - 1));
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bc[j].x, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bc[j].y, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bc[j].z, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bc[j].w, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  // epilogue: C/D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) if (first + NN_WAVES * j < NT) {
+    const int n = 32 * (first + NN_WAVES * j) + i; const float bias = bp[n];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
+      const float v = acc[j][r] + bias;
+      B[row * NN_LD + n] = last ? v : elu1(v);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(NN_THREADS) go2nn_mlp_kernel(const NNArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * NN_ROWS * NN_LD];
+  const NetDesc& nd = a.net[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63, row0 = blockIdx.x * NN_ROWS;
+  // which of a layer's tiles a wave takes is free (tiles are independent outputs): rotated by the workgroup index, so that the workgroups
+  // of the chip, which run in step, do not all ask the L2 for the same weight block at the same moment
+  const int wave = __builtin_amdgcn_readfirstlane(((tid >> 6) + (int)blockIdx.x) & (NN_WAVES - 1));
+  float* A = lds; float* B = lds + NN_ROWS * NN_LD;
+#ifdef GO2NN_STAMPS
+  long long* dbg = (a.mode == 1 && a.y) ? (long long*)a.y + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;      // tools/policy_bench.py --stamps
+#define NN_STAMP(k) do { if (dbg && tid == 0) dbg[k] = wall_clock64(); } while (0)
+#else
+#define NN_STAMP(k) do { } while (0)
+#endif
+  NN_STAMP(0);
+  {   // stage the workgroup's input rows, zero-padded to the first layer's k-blocks
+    // (a wave takes its share of the rows, its lanes run along the row: coalesced, no division; all of a thread's loads are in flight together)
+    const int Kp = nd.KB[0] * 8, K0 = nd.in_dim, w = tid >> 6;
+#pragma unroll
+    for (int r = 0; r < NN_ROWS / NN_WAVES; ++r) {
+      const int i = w * (NN_ROWS / NN_WAVES) + r; const bool live = row0 + i < a.N;
+      const float* __restrict__ src = nd.x + (int64_t)(live ? row0 + i : 0) * K0;
+      for (int k = lane; k < Kp; k += 64) A[i * NN_LD + k] = (live && k < K0) ? src[k] : 0.f;
+    }
+  }
+  __syncthreads();
+  NN_STAMP(1);
+  for (int l = 0; l < nd.nl; ++l) {
+    const int KB = nd.KB[l], NT = nd.NT[l];
+    const float4* __restrict__ Wp = reinterpret_cast<const float4*>(nd.packed + nd.woff[l]);
+    const float* __restrict__ bp = nd.packed + nd.boff[l];
+    const bool last = l == nd.nl - 1;
+    if (wave < NT) {
+      if (NT > 2 * NN_WAVES) run_layer<4>(A, B, Wp, bp, KB, NT, wave, lane, last);
+      else if (NT > NN_WAVES) run_layer<2>(A, B, Wp, bp, KB, NT, wave, lane, last);
+      else run_layer<1>(A, B, Wp, bp, KB, NT, wave, lane, last);
+    }
+    __syncthreads();
+    NN_STAMP(2 + l);
+    float* t_ = A; A = B; B = t_;
+  }
+  // A now holds the network's output tile [32][32 NT_last]
+  if (a.mode == 0) {
+    const int No = nd.out_dim;
+    for (int idx = tid; idx < NN_ROWS * No; idx += NN_THREADS) {
+      const int r = idx / No, n = idx - r * No;
+      if (row0 + r < a.N) a.y[(int64_t)(row0 + r) * No + n] = A[r * NN_LD + n];
+    }
+    return;
+  }
+  if (tid < NN_ROWS) {
+    const int e = row0 + tid;
+    if (e >= a.N) return;
+    if (blockIdx.y == 0) {      // actor: the sampling head (ppo.py:90-102; go2sim_act_head's arithmetic: a = mu + std * eps as two rounded operations)
+      float lp = 0.f;
+      for (int j = 0; j < a.A; ++j) {
+        const int64_t k = (int64_t)e * a.A + j;
+        const float m = A[tid * NN_LD + j], sg = a.std_[j], act = add_rn(m, mul_rn(sg, a.eps[k])), d = act - m;
+        lp += -(d * d) / (2.f * sg * sg) - logf(sg) - HALF_LOG2PI;
+        a.a_out[k] = act;
+        if (a.a_st) a.a_st[k] = act;
+        if (a.mu_st) a.mu_st[k] = m;
+        if (a.sig_st) a.sig_st[k] = sg;
+      }
+      if (a.lp_st) a.lp_st[e] = lp;
+    } else if (a.v_st) {
+      a.v_st[e] = A[tid * NN_LD];
+    }
+  }
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) FAIL(GO2NN_EDEVICE, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
+#endif  // !GO2_EMU
+
+#ifdef GO2_EMU
+// host restatement: the SAME packed buffer, read in the operand order the kernel uses
+static void emu_forward(const NetDesc& nd, int N, int row0, float out[NN_ROWS][GO2NN_MAX_WIDTH]) {
+  static thread_local float A[NN_ROWS][NN_LD], B[NN_ROWS][NN_LD];
+  memset(A, 0, sizeof(A));
+  for (int i = 0; i < NN_ROWS; ++i) for (int k = 0; k < nd.in_dim; ++k) A[i][k] = row0 + i < N ? nd.x[(int64_t)(row0 + i) * nd.in_dim + k] : 0.f;
+  for (int l = 0; l < nd.nl; ++l) {
+    const float* Wp = nd.packed + nd.woff[l]; const float* bp = nd.packed + nd.boff[l];
+    memset(B, 0, sizeof(B));
+    for (int t = 0; t < nd.NT[l]; ++t) for (int i = 0; i < NN_ROWS; ++i) for (int j = 0; j < 32; ++j) {
+      float acc = 0.f;
+      for (int kb = 0; kb < nd.KB[l]; ++kb) for (int e = 0; e < 4; ++e) for (int g = 0; g < 2; ++g)
+        acc = fmaf(A[i][8 * kb + 4 * g + e], Wp[(((int64_t)t * nd.KB[l] + kb) * 64 + (g * 32 + j)) * 4 + e], acc);
+      const float v = acc + bp[32 * t + j];
+      B[i][32 * t + j] = l == nd.nl - 1 ? v : (v > 0.f ? v : expm1f(v));
+    }
+    memcpy(A, B, sizeof(A));
+  }
+  for (int i = 0; i < NN_ROWS; ++i) for (int n = 0; n < nd.out_dim; ++n) out[i][n] = A[i][n];
+}
+#endif
+
+extern "C" {
+
+int go2nn_abi_version(void) { return GO2NN_ABI_VERSION; }
+const char* go2nn_last_error(void) { return g_err; }
+int go2nn_is_device_library(void) {
+#ifdef GO2_EMU
+  return 0;
+#else
+  return 1;
+#endif
+}
+
+int64_t go2nn_packed_floats(const Go2nnMlp* m) {
+  NetDesc d; int64_t total = 0;
+  if (!describe(m, &d, &total)) FAIL(GO2NN_EINVAL, "unsupported MLP shape (1..%d layers, widths 1..%d)", GO2NN_MAX_LAYERS, GO2NN_MAX_WIDTH);
+  return total;
+}
+
+int go2nn_pack(const Go2nnMlp* m, float* packed, void* stream) {
+  NetDesc d;
+  if (!packed || !describe(m, &d, nullptr)) FAIL(GO2NN_EINVAL, "bad argument");
+  for (int l = 0; l < d.nl; ++l) {
+    if (!m->weight[l] || !m->bias[l]) FAIL(GO2NN_EINVAL, "null weight / bias of layer %d", l);
+#ifdef GO2_EMU
+    (void)stream;
+    float* ow = packed + d.woff[l]; float* ob = packed + d.boff[l];
+    for (int t = 0; t < d.NT[l]; ++t) for (int kb = 0; kb < d.KB[l]; ++kb) for (int lane = 0; lane < 64; ++lane) for (int e = 0; e < 4; ++e) {
+      const int n = 32 * t + (lane & 31), k = 8 * kb + 4 * (lane >> 5) + e;
+      ow[(((int64_t)t * d.KB[l] + kb) * 64 + lane) * 4 + e] = (n < d.N[l] && k < d.K[l]) ? m->weight[l][(int64_t)n * d.K[l] + k] : 0.f;
+    }
+    for (int n = 0; n < d.NT[l] * 32; ++n) ob[n] = n < d.N[l] ? m->bias[l][n] : 0.f;
+#else
+    const int64_t total = (int64_t)d.NT[l] * d.KB[l] * 256 + d.NT[l] * 32;
+    int blocks = (int)((total + 255) / 256); blocks = blocks > 1024 ? 1024 : blocks;
+    hipLaunchKernelGGL(go2nn_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, m->weight[l], m->bias[l], packed + d.woff[l], packed + d.boff[l], d.K[l], d.N[l], d.KB[l], d.NT[l]);
+#endif
+  }
+#ifndef GO2_EMU
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+static int run(NNArgs& a, int nets, void* stream) {
+#ifdef GO2_EMU
+  (void)stream;
+  static thread_local float out[2][NN_ROWS][GO2NN_MAX_WIDTH];
+  for (int row0 = 0; row0 < a.N; row0 += NN_ROWS) {
+    for (int y = 0; y < nets; ++y) emu_forward(a.net[y], a.N, row0, out[y]);
+    for (int r = 0; r < NN_ROWS && row0 + r < a.N; ++r) {
+      const int e = row0 + r;
+      if (a.mode == 0) { for (int n = 0; n < a.net[0].out_dim; ++n) a.y[(int64_t)e * a.net[0].out_dim + n] = out[0][r][n]; continue; }
+      float lp = 0.f;
+      for (int j = 0; j < a.A; ++j) {
+        const int64_t k = (int64_t)e * a.A + j;
+        const float m = out[0][r][j], sg = a.std_[j]; volatile float p = sg * a.eps[k]; const float act = m + p, d = act - m;
+        lp += -(d * d) / (2.f * sg * sg) - logf(sg) - HALF_LOG2PI;
+        a.a_out[k] = act; if (a.a_st) a.a_st[k] = act; if (a.mu_st) a.mu_st[k] = m; if (a.sig_st) a.sig_st[k] = sg;
+      }
+      if (a.lp_st) a.lp_st[e] = lp;
+      if (a.v_st) a.v_st[e] = out[1][r][0];
+    }
+  }
+#else
+  hipLaunchKernelGGL(go2nn_mlp_kernel, dim3((a.N + NN_ROWS - 1) / NN_ROWS, nets), dim3(NN_THREADS), 0, (hipStream_t)stream, a);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+int go2nn_mlp_forward(const Go2nnMlp* m, const float* packed, const float* x, float* y, int32_t N, void* stream) {
+  NNArgs a; memset(&a, 0, sizeof(a));
+  if (!packed || !x || !y || N <= 0 || !describe(m, &a.net[0], nullptr)) FAIL(GO2NN_EINVAL, "bad argument");
+  a.net[0].packed = packed; a.net[0].x = x; a.y = y; a.N = N; a.mode = 0;
+  return run(a, 1, stream);
+}
+
+int go2nn_policy_act(const Go2nnMlp* actor, const float* actor_packed, const Go2nnMlp* critic, const float* critic_packed,
+                     const float* obs, const float* critic_obs, const float* std_, const float* eps,
+                     float* a_out, float* a_st, float* mu_st, float* sig_st, float* lp_st, float* v_st, int32_t N, void* stream) {
+  NNArgs a; memset(&a, 0, sizeof(a));
+  if (!actor_packed || !critic_packed || !obs || !critic_obs || !std_ || !eps || !a_out || N <= 0 || !describe(actor, &a.net[0], nullptr) || !describe(critic, &a.net[1], nullptr))
+    FAIL(GO2NN_EINVAL, "bad argument");
+  if (a.net[0].out_dim > 32 || a.net[1].out_dim != 1) FAIL(GO2NN_EINVAL, "the head handles up to 32 actions and a scalar value (got %d, %d)", a.net[0].out_dim, a.net[1].out_dim);
+  a.net[0].packed = actor_packed; a.net[0].x = obs; a.net[1].packed = critic_packed; a.net[1].x = critic_obs;
+  a.std_ = std_; a.eps = eps; a.a_out = a_out; a.a_st = a_st; a.mu_st = mu_st; a.sig_st = sig_st; a.lp_st = lp_st; a.v_st = v_st;
+  a.N = N; a.A = a.net[0].out_dim; a.mode = 1;
+  return run(a, 2, stream);
+}
+
+#ifdef GO2NN_STAMPS
+// TOOL-ONLY (tools/policy_bench.py --stamps): go2nn_policy_act with a per-workgroup timestamp buffer [2 * ceil(N / 32)][8] int64
+int go2nn_policy_act_stamped(const Go2nnMlp* actor, const float* actor_packed, const Go2nnMlp* critic, const float* critic_packed,
+                             const float* obs, const float* critic_obs, const float* std_, const float* eps, float* a_out, void* stamps, int32_t N, void* stream) {
+  NNArgs a; memset(&a, 0, sizeof(a));
+  if (!describe(actor, &a.net[0], nullptr) || !describe(critic, &a.net[1], nullptr)) return GO2NN_EINVAL;
+  a.net[0].packed = actor_packed; a.net[0].x = obs; a.net[1].packed = critic_packed; a.net[1].x = critic_obs;
+  a.std_ = std_; a.eps = eps; a.a_out = a_out; a.y = (float*)stamps; a.N = N; a.A = a.net[0].out_dim; a.mode = 1;
+  return run(a, 2, stream);
+}
+#endif
+
+}  // extern "C"

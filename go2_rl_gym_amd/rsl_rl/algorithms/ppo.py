@@ -202,6 +202,10 @@ class PPO(_RolloutHeads):
         self.max_grad_norm, self.use_clipped_value_loss = max_grad_norm, use_clipped_value_loss
         self._graph = None
         self._fused_adam = None
+        # PPO.act as ONE fp32-MFMA launch (include/go2nn.h): both MLPs + the sampling head; on the GPU by default when the modules are plain
+        # Linear / ELU stacks (GO2_FUSED_POLICY=0 restores the hipBLASLt chains + go2sim_act_head).  nn_lib: tests hand in the host build.
+        self.nn_lib, self._pk = None, None
+        self._pk_on = on_gpu and lib is not None and os.environ.get("GO2_FUSED_POLICY", "1") == "1"
         # the fused loss kernel is the default on the GPU; on the CPU it is opt-in (tests compare it with the eager formulation)
         self.fused_loss = (on_gpu and lib is not None) if fused_loss is None else bool(fused_loss and lib is not None)
         self.fused_rollout = (on_gpu and lib is not None) if fused_rollout is None else bool(fused_rollout and lib is not None)
@@ -244,6 +248,14 @@ class PPO(_RolloutHeads):
             if st.privileged_observations is not None and critic_obs.data_ptr() != st.privileged_observations[s].data_ptr():
                 st.privileged_observations[s].copy_(critic_obs)
             t.observations, t.critic_observations = obs, critic_obs
+            pk = self._policy_kernel()
+            if pk is not None and obs.is_contiguous() and critic_obs.is_contiguous() and obs.dtype == torch.float32 and critic_obs.dtype == torch.float32:
+                if s == 0:
+                    pk.pack()                  # the parameters only change in update(): once per rollout (inside the captured rollout graph too)
+                actions = pk.act(obs, critic_obs, ac._noise(st.actions[s]), st.actions[s], st.mu[s], st.sigma[s], st.actions_log_prob[s].view(-1), st.values[s].view(-1))
+                t.actions, t.values, t.actions_log_prob = actions, st.values[s], st.actions_log_prob[s].view(-1)
+                t.action_mean, t.action_sigma = st.mu[s], st.sigma[s]
+                return actions
             mu, value = self._pair(lambda: ac.actor(obs), lambda: ac.evaluate(critic_obs), enabled=self._capture)
             return self._act_head(mu, ac.std, ac._noise(mu), value, s)      # (drawing the noise before the fork was measured: 1 % slower)
         t.actions = ac.act(obs).detach()
@@ -261,6 +273,22 @@ class PPO(_RolloutHeads):
         st.mu[s].copy_(t.action_mean)
         st.sigma[s].copy_(t.action_sigma)
         return t.actions
+
+    def _policy_kernel(self):
+        """-> the fused policy kernel for this actor-critic, or None (not asked for / modules it does not cover).  On a GPU the library must
+        be there: a missing libgo2nn_hip.so raises (no silent fallback to the slower path)."""
+        if self._pk is not None:
+            return self._pk if self._pk is not False else None
+        lib = self.nn_lib
+        if lib is None and self._pk_on:
+            from ... import _nn
+            lib = _nn.load_nn()
+        ok = False
+        if lib is not None:
+            from ... import _nn
+            ok = _nn.PolicyKernel.supports(self.actor_critic) and self.storage is not None and self.storage.privileged_observations is not None
+        self._pk = _nn.PolicyKernel(lib, self.actor_critic) if ok else False
+        return self._pk if self._pk is not False else None
 
     def process_env_step(self, rewards, dones, infos):
         st, t = self.storage, self.transition

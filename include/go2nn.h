@@ -1,0 +1,60 @@
+/* go2nn.h — C ABI of the policy-side MFMA kernels (libgo2nn_hip.so, gfx950).
+ *
+ * What it replaces, in the rollout of OnPolicyRunner.learn (rsl_rl/rsl_rl/runners/on_policy_runner.py:135-153): PPO.act
+ * (rsl_rl/rsl_rl/algorithms/ppo.py:90-102) = ActorCritic.act + evaluate + get_actions_log_prob
+ * (rsl_rl/rsl_rl/modules/actor_critic.py:119-136): two 4-layer MLPs (Linear, ELU, ..., Linear; :50-75), a Gaussian sample
+ * a = mu + std * eps, its log-probability, and the rows PPO.act keeps for RolloutStorage.add_transitions
+ * (rsl_rl/rsl_rl/storage/rollout_storage.py:88-101).  In PyTorch that is ~30 launches per env step (8 GEMMs, 6 ELUs, the sampling head)
+ * at M = 4096 rows — launch-latency-bound; here it is ONE launch: a workgroup carries 32 rows through all layers of one network with
+ * fp32 MFMA (v_mfma_f32_32x32x2_f32), activations in LDS, weights streamed from L2 in a pre-packed operand order.
+ *
+ * Plain pointers and sizes, no torch types; asynchronous on the given HIP stream; 0 = ok, negative = error (go2nn_last_error).
+ * All pointers are device pointers unless stated. */
+#ifndef GO2NN_H
+#define GO2NN_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GO2NN_ABI_VERSION 1
+#define GO2NN_MAX_LAYERS 6
+#define GO2NN_MAX_WIDTH 512      /* widest layer input / output (LDS holds two 32-row activation tiles of this width) */
+#define GO2NN_EINVAL (-22)
+#define GO2NN_EDEVICE (-5)
+
+/* An MLP as torch.nn.Sequential(Linear, ELU(alpha=1), ..., Linear) holds it: weight[l] is [dims[l+1], dims[l]] row-major (out x in),
+ * bias[l] is [dims[l+1]].  Host struct with device pointers. */
+typedef struct Go2nnMlp {
+  int32_t num_layers;
+  int32_t dims[GO2NN_MAX_LAYERS + 1];
+  const float* weight[GO2NN_MAX_LAYERS];
+  const float* bias[GO2NN_MAX_LAYERS];
+} Go2nnMlp;
+
+int go2nn_abi_version(void);
+const char* go2nn_last_error(void);
+
+/* Number of floats of the packed operand buffer of `m` (weights in MFMA B-operand order, zero-padded to 32 x 8 tiles, + padded biases);
+ * negative on an unsupported shape (more than GO2NN_MAX_LAYERS layers, a dimension above GO2NN_MAX_WIDTH). */
+int64_t go2nn_packed_floats(const Go2nnMlp* m);
+/* Re-pack the CURRENT weights of `m` into `packed` (call after every optimizer step that the next forward must see; one small launch). */
+int go2nn_pack(const Go2nnMlp* m, float* packed, void* stream);
+
+/* y[N, dims[last]] = m(x[N, dims[0]]) — one launch (ActorCritic.act_inference / evaluate, actor_critic.py:131-136). */
+int go2nn_mlp_forward(const Go2nnMlp* m, const float* packed, const float* x, float* y, int32_t N, void* stream);
+
+/* PPO.act for one policy step (ppo.py:90-102), one launch:
+ *   mu = actor(obs), value = critic(critic_obs), a = mu + std * eps (two separately rounded operations, like the eager formulation),
+ *   log_prob = sum_j [-(a_j - mu_j)^2 / (2 std_j^2) - log std_j - log sqrt(2 pi)]   (j ascending)
+ * a_out [N,A] receives the actions (the tensor env.step gets); the *_st pointers receive the storage rows of this step and may be NULL:
+ * actions [N,A], mu [N,A], sigma [N,A], log-prob [N], value [N].  eps [N,A] are standard-normal draws supplied by the caller. */
+int go2nn_policy_act(const Go2nnMlp* actor, const float* actor_packed, const Go2nnMlp* critic, const float* critic_packed,
+                     const float* obs, const float* critic_obs, const float* std, const float* eps,
+                     float* a_out, float* a_st, float* mu_st, float* sig_st, float* lp_st, float* v_st, int32_t N, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -468,3 +468,18 @@ def three_body_envs(forces):
     f = np.linalg.norm(np.asarray(forces, np.float64), axis=2)
     both = (f[:, THIGH_B] > 0.5) & (f[:, CALF_B] > 0.5)
     return np.nonzero((f[:, BASE_B] > 1.0) & both.any(1))[0], f
+
+
+# ---- the policy-side MFMA kernels (include/go2nn.h) -----------------------------------------------------------------------------------
+def load_nn_emu():
+    """TEST-ONLY host build of go2_rl_gym_amd/csrc/go2nn_impl.cpp (g++ -DGO2_EMU): same packed operand buffer, same read order, plain loops."""
+    from go2_rl_gym_amd import _nn
+    out = os.path.join(ROOT, "tests", "emu", "libgo2nn_emu.so")
+    src = os.path.join(ROOT, "go2_rl_gym_amd", "csrc", "go2nn_impl.cpp")
+    deps = [src, os.path.join(ROOT, "include", "go2nn.h")]
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-DGO2_EMU", "-w", "-o", out, src], check=True)
+    lib = _nn.bind(out)
+    assert lib.go2nn_is_device_library() == 0
+    return lib

@@ -1,0 +1,43 @@
+"""The fp32-MFMA policy kernel (include/go2nn.h, go2_rl_gym_amd/csrc/go2nn_impl.cpp) on a real MI355X against plain PyTorch fp32 of the same
+modules (actor / critic MLPs, Normal log-prob).  Run with -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from go2_rl_gym_amd import _nn  # noqa: E402
+from test_policy_kernel import _ac, reference_act  # noqa: E402
+
+
+@pytest.mark.parametrize("N", [1, 31, 32, 1000, 4096])
+@pytest.mark.parametrize("dims", [(512, 256, 128), (40, 24)])
+def test_policy_act_on_gpu(N, dims):
+    lib = _nn.load_nn()
+    ac = _ac(dims=dims).to("cuda:0")
+    pk = _nn.PolicyKernel(lib, ac); pk.pack()
+    g = torch.Generator(device="cuda:0").manual_seed(1)
+    obs, priv, eps = torch.randn(N, 45, device="cuda:0", generator=g), torch.randn(N, 263, device="cuda:0", generator=g) * 2, torch.randn(N, 12, device="cuda:0", generator=g)
+    st = {k: torch.zeros(N, 12, device="cuda:0") for k in ("a", "mu", "sig")}; lp, v = torch.zeros(N, device="cuda:0"), torch.zeros(N, device="cuda:0")
+    actions = pk.act(obs, priv, eps, st["a"], st["mu"], st["sig"], lp, v)
+    torch.cuda.synchronize()
+    a_ref, mu_ref, lp_ref, v_ref = reference_act(ac, obs, priv, eps)
+    # fp32 MFMA = a k-ordered fmaf chain per output; hipBLASLt sums in another order: a few ulp of the activations' scale
+    np.testing.assert_allclose(st["mu"].cpu().numpy(), mu_ref.cpu().numpy(), atol=5e-6, rtol=5e-6)
+    np.testing.assert_allclose(v.cpu().numpy(), v_ref.cpu().numpy(), atol=5e-6, rtol=5e-6)
+    np.testing.assert_allclose(actions.cpu().numpy(), a_ref.cpu().numpy(), atol=5e-6, rtol=5e-6)
+    np.testing.assert_allclose(lp.cpu().numpy(), lp_ref.cpu().numpy(), atol=5e-5, rtol=5e-6)
+    assert torch.equal(actions, st["a"]) and torch.equal(actions, st["mu"] + ac.std.detach() * eps)      # the eager formulation's two rounded operations
+
+
+def test_asymmetric_weights_catch_a_transposed_tile_on_gpu():
+    """A = identity-like input with an asymmetric weight matrix: a kernel whose C-tile rows / columns are swapped cannot pass."""
+    lib = _nn.load_nn()
+    torch.manual_seed(0)
+    seq = torch.nn.Sequential(torch.nn.Linear(64, 96), torch.nn.ELU(), torch.nn.Linear(96, 40)).to("cuda:0")
+    with torch.no_grad():
+        seq[0].weight.copy_(torch.arange(96 * 64, device="cuda:0").float().view(96, 64) / 1000.0 - 3.0); seq[0].bias.zero_()
+    m = _nn.PackedMlp(lib, seq); m.pack()
+    x = torch.eye(64, device="cuda:0")[:50].contiguous()
+    with torch.no_grad():
+        np.testing.assert_allclose(m.forward(x).cpu().numpy(), seq(x).cpu().numpy(), atol=2e-5, rtol=1e-5)
