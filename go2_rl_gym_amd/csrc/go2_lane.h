@@ -42,7 +42,7 @@ struct Row { float J[3], Y[3], dinv /* until solve_prepare: this sub-lane's part
 // in the ISA); passed through an empty asm statement each value becomes an ordinary register value (SGPR, wave-uniform).
 struct HotL {
   float sim_dt, gravity[3], contact_offset, erp, max_depen_vel, bounce_thr, cfm, armature, limit_margin, max_lin_vel, max_ang_vel, action_scale;
-  float hf_hscale, hf_vscale, hf_border;
+  float hf_hscale, hf_vscale, hf_border, hf_nzmin; int32_t hf_trows, hf_tcols;
   int32_t terrain_mode, hf_walls, hf_rows, hf_cols, rand_strength, control_type;
 #if defined(__HIP_DEVICE_COMPILE__)
   static __device__ __forceinline__ float keep(float x) { asm volatile("" : "+s"(x)); return x; }
@@ -58,19 +58,20 @@ struct HotL {
     max_ang_vel = keep(L.max_ang_vel); action_scale = keep(L.action_scale); hf_hscale = keep(L.hf_hscale); hf_vscale = keep(L.hf_vscale);
     hf_border = keep(L.hf_border); terrain_mode = keep(L.terrain_mode); hf_walls = keep(L.hf_walls); hf_rows = keep(L.hf_rows);
     hf_cols = keep(L.hf_cols); rand_strength = keep(L.rand_strength); control_type = keep(L.control_type);
+    hf_nzmin = keep(L.hf_nzmin); hf_trows = keep(L.hf_trows); hf_tcols = keep(L.hf_tcols);
   }
 };
 
 // The per-leg constants the substep loop reads, copied ONCE per step from the LDS table into registers (the loop would otherwise wait on
 // ~20 ds_reads per substep): joint origins, limits, the foot sphere.
 struct LegLoop {
-  float o1[3], o2[3], o3[3], lim_lo[3], lim_hi[3], vel_lim[3], eff_lim[3], foot_pt[4];
+  float o1[3], o2[3], o3[3], eff_lim[3], foot_pt[4];
   GO2_HD void load(const LegTab& t, int sub) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { o1[k] = t.o1[k]; o2[k] = t.o2[k]; o3[k] = t.o3[k]; lim_lo[k] = t.lim_lo[k]; lim_hi[k] = t.lim_hi[k]; vel_lim[k] = t.vel_lim[k]; eff_lim[k] = t.eff_lim[k]; }
+    for (int k = 0; k < 3; ++k) { o1[k] = t.o1[k]; o2[k] = t.o2[k]; o3[k] = t.o3[k]; eff_lim[k] = t.eff_lim[k]; }
 #pragma unroll
     for (int k = 0; k < 4; ++k) foot_pt[k] = t.foot_pt[k];
-    (void)sub;      // (the sub-lane's candidate spheres and the cull reach are read from the LDS table where phase C uses them: 42 registers that
+    (void)sub;      // (the sub-lane's candidate spheres, the cull reach, the joint limits and rate limits are read from the LDS table where phase C / D use them: 51 registers that
                     //  would otherwise be live through the whole substep loop — the kernel is at the register file's limit)
   }
 };
@@ -221,6 +222,15 @@ struct LegPhys {
     const float uu = fminf(fmaxf(fx - i, 0.f), 1.f), vv = fminf(fmaxf(fy - j, 0.f), 1.f);
     const int nc = L.hf_cols - 1;
     const Go2Cell q = cells[i * nc + j];
+    // (with hf_walls) the four neighbour cells are loaded TOGETHER with the cell itself, before any of them is looked at (indices clamped
+    // into the grid: a neighbour outside it is the cell itself and is ignored below) — issued where they are tested, each behind its branch
+    // and behind the facet arithmetic, a query waits for several L2 round trips in a row instead of one
+    const int rows2 = L.hf_rows - 2, cols2 = L.hf_cols - 2;
+    Go2Cell bxm = q, bxp = q, bym = q, byp = q;
+    if (L.hf_walls) {
+      bxm = cells[(i > 0 ? i - 1 : i) * nc + j]; bxp = cells[(i < rows2 ? i + 1 : i) * nc + j];
+      bym = cells[i * nc + (j > 0 ? j - 1 : j)]; byp = cells[i * nc + (j < cols2 ? j + 1 : j)];
+    }
     const float h00 = q.h[0] * vs, h10 = q.h[1] * vs, h01 = q.h[2] * vs, h11 = q.h[3] * vs;
     float dx, dy;
     if (uu >= vv) { dx = h10 - h00; dy = h11 - h10; }
@@ -231,16 +241,15 @@ struct LegPhys {
     if (L.hf_walls) {
       // edge k: neighbour cell, this cell's heights at the edge ends (a0, a1), the neighbour's (its corners k0, k1), parameter along the edge,
       // distance of the centre from the edge, inward direction
-#define GO2_WALL(INGRID, NBI, NBJ, A0, A1, K0, K1, T, D, NX, NY) if (INGRID) { \
-        const Go2Cell b = cells[(NBI) * nc + (NBJ)]; \
-        const float bot = (A0) + (T) * ((A1) - (A0)), b0 = b.h[K0] * vs, top = b0 + (T) * (b.h[K1] * vs - b0); \
-        if (top - bot > 0.5f * vs) { \
+#define GO2_WALL(INGRID, NB, A0, A1, K0, K1, T, D, NX, NY) { \
+        const float bot = (A0) + (T) * ((A1) - (A0)), b0 = (NB).h[K0] * vs, top = b0 + (T) * ((NB).h[K1] * vs - b0); \
+        if ((INGRID) && top - bot > 0.5f * vs) { \
           const float qz = fminf(fmaxf(c.z, bot), top), dz = c.z - qz, dist = sqrtf((D) * (D) + dz * dz), gw = dist - r; \
           if (gw < g) { const float iv = 1.0f / fmaxf(dist, 1e-9f); g = gw; nn = dist > 1e-9f ? v3((NX) * (D) * iv, (NY) * (D) * iv, dz * iv) : v3((NX), (NY), 0.f); } } }
-      GO2_WALL(i > 0, i - 1, j, h00, h01, 1, 3, vv, uu * hs, 1.f, 0.f)
-      GO2_WALL(i < L.hf_rows - 2, i + 1, j, h10, h11, 0, 2, vv, (1.f - uu) * hs, -1.f, 0.f)
-      GO2_WALL(j > 0, i, j - 1, h00, h10, 2, 3, uu, vv * hs, 0.f, 1.f)
-      GO2_WALL(j < L.hf_cols - 2, i, j + 1, h01, h11, 0, 1, uu, (1.f - vv) * hs, 0.f, -1.f)
+      GO2_WALL(i > 0, bxm, h00, h01, 1, 3, vv, uu * hs, 1.f, 0.f)
+      GO2_WALL(i < rows2, bxp, h10, h11, 0, 2, vv, (1.f - uu) * hs, -1.f, 0.f)
+      GO2_WALL(j > 0, bym, h00, h10, 2, 3, uu, vv * hs, 0.f, 1.f)
+      GO2_WALL(j < cols2, byp, h01, h11, 0, 1, uu, (1.f - vv) * hs, 0.f, -1.f)
 #undef GO2_WALL
     }
     *gap = g; *n = nn;
@@ -387,7 +396,7 @@ struct LegPhys {
 
   // ------------------------------------------------------------------------------------------------
   template <class LT>
-  GO2_HD void phaseC(const LegLoop& t, const LegTab& tt, const LT& L, const GO2_AS1 Go2Cell* cells) {
+  GO2_HD void phaseC(const LegLoop& t, const LegTab& tt, const LT& L, const GO2_AS1 Go2Cell* cells, const GO2_AS1 int16_t* top) {
     // foot
     {
       V3 cb = p3 + mul(R3, v3(t.foot_pt[0], t.foot_pt[1], t.foot_pt[2]));
@@ -403,17 +412,28 @@ struct LegPhys {
     {
       const SubCand& sc = tt.cand[sub];
       const V3 q2 = p2, q3 = p3;
-      // On the plane a whole link group is skipped when none of its spheres can reach the contact margin in ANY lane of the wave: lowest
+      // A whole link group is skipped when none of its spheres can reach the contact margin in ANY lane of the wave.  On the plane: lowest
       // possible sphere bottom = (link origin height) - sum_axis |world-z component of the link axis| * (group's reach along that axis).
       // Conservative, so skipping cannot change which candidate is inside the margin (only those matter: an inactive slot has no rows).
+      // On the height field the same test runs against the highest surface NEAR the leg (hf_top: a coarse map of the highest cell corner
+      // within 0.8 m, which covers every wall top too): a sphere whose bottom is d above everything around it has a gap of at least
+      // d * (smallest facet n_z of the map) to any facet and of at least d to any wall face.
       bool do_hip = true, do_thigh = true, do_calf = true, do_base = true;
-      if (L.terrain_mode == 0) {
+      {
         const V3 gz = v3(Rwb.x.z, Rwb.y.z, Rwb.z.z);        // world z axis in base coordinates
         auto low = [&](const M3& R, V3 o, const float* ext) {
           return pw.z + dot(gz, o) - (fabsf(dot(gz, R.x)) * ext[0] + fabsf(dot(gz, R.y)) * ext[1] + fabsf(dot(gz, R.z)) * ext[2]); };
         const M3 Id = {v3(1, 0, 0), v3(0, 1, 0), v3(0, 0, 1)};
-        do_hip = xl::any(low(R1, p1, tt.cull_ext[0]) < L.contact_offset); do_thigh = xl::any(low(R2, p2, tt.cull_ext[1]) < L.contact_offset);
-        do_calf = xl::any(low(R3, p3, tt.cull_ext[2]) < L.contact_offset); do_base = xl::any(low(Id, v3(0, 0, 0), tt.cull_ext[3]) < L.contact_offset);
+        float top_leg = 0.f, top_base = 0.f, slope = 1.f;
+        if (L.terrain_mode != 0) {
+          auto top_at = [&](V3 pt) {
+            int bi = (int)floorf((pt.x + L.hf_border) / (L.hf_hscale * GO2_TOP_CELL)), bj = (int)floorf((pt.y + L.hf_border) / (L.hf_hscale * GO2_TOP_CELL));
+            bi = bi < 0 ? 0 : (bi > L.hf_trows - 1 ? L.hf_trows - 1 : bi); bj = bj < 0 ? 0 : (bj > L.hf_tcols - 1 ? L.hf_tcols - 1 : bj);
+            return (float)top[bi * L.hf_tcols + bj] * L.hf_vscale; };
+          top_leg = top_at(pw + mul(Rwb, p1)); top_base = top_at(pw); slope = L.hf_nzmin;
+        }
+        do_hip = xl::any((low(R1, p1, tt.cull_ext[0]) - top_leg) * slope < L.contact_offset); do_thigh = xl::any((low(R2, p2, tt.cull_ext[1]) - top_leg) * slope < L.contact_offset);
+        do_calf = xl::any((low(R3, p3, tt.cull_ext[2]) - top_leg) * slope < L.contact_offset); do_base = xl::any((low(Id, v3(0, 0, 0), tt.cull_ext[3]) - top_base) * slope < L.contact_offset);
       }
       auto eval = [&](int k, const M3& R, V3 P) {
         Cand o; o.c = P + mul(R, v3(sc.pt[k][0], sc.pt[k][1], sc.pt[k][2]));
@@ -469,7 +489,7 @@ struct LegPhys {
       float sgn[3], gap[3];
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        float glo = q[j] - t.lim_lo[j], ghi = t.lim_hi[j] - q[j];
+        float glo = q[j] - tt.lim_lo[j], ghi = tt.lim_hi[j] - q[j];
         sgn[j] = 0.f; gap[j] = 0.f;
         if (glo < L.limit_margin) { sgn[j] = 1.f; gap[j] = glo; } else if (ghi < L.limit_margin) { sgn[j] = -1.f; gap[j] = ghi; }
         act_lim[j] = sgn[j] != 0.f ? 1.f : 0.f; lam_lim[j] = 0.f;
@@ -596,7 +616,7 @@ struct LegPhys {
 
   // ------------------------------------------------------------------------------------------------
   template <class LT>
-  GO2_HD void phaseD(const LegLoop& t, const LT& L) {
+  GO2_HD void phaseD(const LegTab& t, const LT& L) {
     float h = L.sim_dt;
     SV V0p = V0f + w;
     float qdp[3] = {qdf[0] + z[0] - dot(T1, w), qdf[1] + z[1] - dot(T2, w), qdf[2] + z[2] - dot(T3, w)};

@@ -144,6 +144,7 @@ struct LegPost {
   // The per-step groups (action delay, observation noise) are drawn when the kernel starts; the reset / resample / push groups where
   // those (per-environment, hence row-uniform) branches are taken.
   const GO2_AS3 uint8_t* codes; GO2_AS3 float (*uc)[4];      // both live in LDS (ds_read / ds_write, not flat accesses)
+  GO2_AS3 float* hc;                                         // this env's height samples of postA, kept in LDS for postB's observation rows (the lane that wrote entry i reads entry i)
   GO2_HD float uni(int slot) const {
     if (S->injected) return S->injected[(size_t)e * GO2_NUM_UNIFORMS + slot];
     const int code = __builtin_constant_p(slot) ? go2_slot_code(slot) : (int)codes[slot];
@@ -320,7 +321,7 @@ struct LegPost {
       for (int i = lane16; i < GO2_NUM_HEIGHT_POINTS; i += 16) {
         const float hv = height_at(i, yz, yw, o.pw.x, o.pw.y);
         const int ix = i / 11, iy = i - 11 * ix;
-        F2D(p.heights, i, e) = hv;
+        F2D(p.heights, i, e) = hv; hc[i] = hv;
         if (ix >= 6 && ix <= 10 && iy >= 4 && iy <= 6) hsum += hv;   // base_height_scan_mask (:790-796)
       }
     }
@@ -603,8 +604,8 @@ struct LegPost {
       for (int i = lane16; i < GO2_NUM_HEIGHT_POINTS; i += 16) pv[76 + i] = hv;
     } else {
       for (int i = lane16; i < GO2_NUM_HEIGHT_POINTS; i += 16) {
-        // the samples postA took at the pre-reset pose (App. E.3): this lane wrote exactly these entries of measured_heights there
-        float hh = fminf(fmaxf(o.pw.z - 0.5f - F2D(p.heights, i, e), -1.f), 1.f);
+        // the samples postA took at the pre-reset pose (App. E.3): this lane wrote exactly these entries of measured_heights there (and kept them in LDS)
+        float hh = fminf(fmaxf(o.pw.z - 0.5f - (skip_contact_filters ? F2D(p.heights, i, e) : hc[i]), -1.f), 1.f);      // (a reset outside a step has no postA: the buffer's values)
         pv[76 + i] = CLIP(hh * c.os_height);
       }
     }

@@ -73,6 +73,9 @@ struct Go2RowsLds {
   float win[GO2_NTYPE][9][GO2_WG_LANES / 4];
 };
 
+#define GO2_TOP_CELL 4        // cells per side of a block of the coarse "highest surface nearby" map
+#define GO2_TOP_REACH 8       // ... dilated by this many cells (0.8 m at the tasks' 0.1 m grid: a leg's spheres stay within 0.6 m of its hip joint,
+                              //     the base / head points within 0.4 m of the base origin)
 // the contact surface over one grid cell: heights (vscale units) at the corners (i,j) (i+1,j) (i,j+1) (i+1,j+1) as seen from inside the cell
 // (include/go2sim.h Go2SimCfg.hf_cells); one aligned 8-byte load per contact query
 struct alignas(8) Go2Cell { int16_t h[4]; };
@@ -88,7 +91,7 @@ struct alignas(8) Go2Cell { int16_t h[4]; };
   G uint8_t *last_contacts, *last_contacts2; G float *strength, *zero_off, *kp_mul, *kd_mul, *origins; G int64_t *terrain_levels, *terrain_types; \
   G float *ep_sums, *friction, *restitution, *added_mass, *added_com, *mass_ratio, *episode_info, *foot_impulse; \
   /* internal */ \
-  G int32_t* terrain_kind; G uint8_t* reset_mask /*[N], go2sim_reset_idx*/; G float* ep_accum /*[NUM_REWARDS+2]: episode sums of the envs reset in this pass, their number, #envs resampled by the callback*/; const G float* inj_storage; const G int16_t* hf; const G Go2Cell* hf_cells; const G float* terrain_origins; \
+  G int32_t* terrain_kind; G uint8_t* reset_mask /*[N], go2sim_reset_idx*/; G float* ep_accum /*[NUM_REWARDS+2]: episode sums of the envs reset in this pass, their number, #envs resampled by the callback*/; const G float* inj_storage; const G int16_t* hf; const G Go2Cell* hf_cells; const G int16_t* hf_top /*[hf_trows][hf_tcols]: coarse map of the highest surface near a point (go2sim_create)*/; const G float* terrain_origins; \
   const G Go2Tables* tables; G long long* dbg_clock;
 struct Go2Ptrs { GO2_PTRS_BODY() };
 // The kernels read these pointers out of the device block (scalar loads), where the compiler cannot know their address space and would
@@ -115,6 +118,9 @@ struct Go2Launch {
   uint32_t seed_lo, seed_hi;
   float sim_dt, dt, gravity[3], contact_offset, erp, max_depen_vel, bounce_thr, cfm, armature, limit_margin, max_lin_vel, max_ang_vel;
   int32_t terrain_mode, hf_walls, hf_rows, hf_cols; float hf_hscale, hf_vscale, hf_border, terrain_friction, terrain_restitution;
+  // candidate cull on the height field (go2_lane.h phaseC): hf_top[i][j] = highest corner of any cell within GO2_TOP_REACH cells of the
+  // GO2_TOP_CELL x GO2_TOP_CELL block (i, j); hf_nzmin = smallest z component of any facet normal of the map
+  int32_t hf_trows, hf_tcols; float hf_nzmin;
   int32_t terrain_num_levels, terrain_num_types, terrain_curriculum, move_down_by_acc, measure_heights, full_body_states; float terrain_length;
   float kp[12], kd[12], q0[12], action_scale, clip_actions, clip_obs, base_init[13];
   int32_t control_type;   // 0 P, 1 V, 2 T (legged_robot.py:607-617)

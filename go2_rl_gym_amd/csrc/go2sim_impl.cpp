@@ -52,6 +52,7 @@ struct LaneAux { float kp[3], kd[3], q0[3], zoff[3], strength[3], act_new[3], ac
 struct Go2Shared {
   Go2Tables tab; Go2Step S; float ucache[GO2_WG_ENVS][GO2_NUM_GROUPS][4];
   Go2RowsLds rows;      // constraint rows of the non-foot contact slots (go2_tables.h)
+  float hcache[GO2_WG_ENVS][GO2_NUM_HEIGHT_POINTS + 5];      // postA's height samples, read back by postB's observation rows
 };
 static_assert(GO2_WG_LANES == GO2_WG_THREADS, "row storage is per lane of the workgroup");
 
@@ -191,8 +192,8 @@ GO2_HD void lane_load_physout(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK&
   o.foot_pos = v3(F3D(p.rigid, 19, fb, 0, e), F3D(p.rigid, 19, fb, 1, e), F3D(p.rigid, 19, fb, 2, e));
   o.foot_vel = v3(F3D(p.rigid, 19, fb, 7, e), F3D(p.rigid, 19, fb, 8, e), F3D(p.rigid, 19, fb, 9, e));
 }
-GO2_HD void lane_init_post(LANE_PARAMS, const GO2_AS3 uint8_t* codes, GO2_AS3 float (*uc)[4], const Go2PtrsK* p, const Go2Launch* L, const Go2Step* S, int e, int lane, int sub) {
-  po_.codes = codes; po_.uc = uc;
+GO2_HD void lane_init_post(LANE_PARAMS, const GO2_AS3 uint8_t* codes, GO2_AS3 float (*uc)[4], GO2_AS3 float* hc, const Go2PtrsK* p, const Go2Launch* L, const Go2Step* S, int e, int lane, int sub) {
+  po_.codes = codes; po_.uc = uc; po_.hc = hc;
   po_.e = e; po_.lane = lane; po_.sub = sub; po_.lane16 = lane * 4 + sub; po_.N = L->N; po_.P = p; po_.L = L; po_.S = S;
 #if defined(__HIP_DEVICE_COMPILE__) && defined(GO2_KBENCH_STAMPS)
   po_.dbg = nullptr;
@@ -200,10 +201,10 @@ GO2_HD void lane_init_post(LANE_PARAMS, const GO2_AS3 uint8_t* codes, GO2_AS3 fl
   po_.skip_contact_filters = false; po_.api_reset = false; po_.yaw_seen = false; po_.out = Go2StepOutputs{}; po_.new_lc = po_.new_lc2 = 0; po_.new_fat = 0.f;
 }
 // reset_idx(all envs) without a step (base_task.py:82-84): postB's reset branch with reset forced on
-GO2_HD void lane_reset_all(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p, const Go2Launch& L, const Go2Step& S, GO2_AS3 float (*uc)[4], int e, int lane, int sub) {
+GO2_HD void lane_reset_all(LANE_PARAMS, const Go2Tables& tab, const Go2PtrsK& p, const Go2Launch& L, const Go2Step& S, GO2_AS3 float (*uc)[4], GO2_AS3 float* hc, int e, int lane, int sub) {
   const int N = L.N;
   lane_load_physout(ph_, po_, ax, tab, p, L, e, lane);
-  lane_init_post(ph_, po_, ax, (const GO2_AS3 uint8_t*)tab.slot_code, uc, &p, &L, &S, e, lane, sub);
+  lane_init_post(ph_, po_, ax, (const GO2_AS3 uint8_t*)tab.slot_code, uc, hc, &p, &L, &S, e, lane, sub);
   LegPost& po = po_;
   po.skip_contact_filters = true; po.api_reset = S.initial_reset == 2;
   // load what postA would have loaded, without advancing any clock
@@ -262,6 +263,7 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
   _Pragma("unroll") for (int k = 0; k < GO2_NTYPE; ++k) { ph_.has_v[k] = false; ph_.act_v[k] = 0.f; ph_.body_v[k] = -1; }
   const LegTab& t = tab.leg[lane];
   GO2_AS3 float (*uc)[4] = (GO2_AS3 float (*)[4])sh.ucache[tid >> 4];
+  GO2_AS3 float* hc = (GO2_AS3 float*)sh.hcache[tid >> 4];
   if (!S.injected) {
     // the per-step uniforms, one Philox group per lane: observation noise (groups 26..40, go2sim_rng.h) in lanes 0..14, the action delay
     // (group 0) in lane 15
@@ -273,7 +275,7 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
   xl::row_sync();
   if (MODE & MODE_RESET_ALL) {
     if (initial_reset == 2 && !p.reset_mask[e]) return;      // go2sim_reset_idx: only the listed environments (whole rows leave)
-    lane_reset_all(ph_, po_, ax, tab, p, L, S, uc, e, lane, sub);
+    lane_reset_all(ph_, po_, ax, tab, p, L, S, uc, hc, e, lane, sub);
     float red[GO2_POST_PARTIALS];
 #pragma unroll
     for (int i = 0; i < GO2_POST_PARTIALS; ++i) red[i] = 0.f;
@@ -306,7 +308,7 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
       ph_.phaseB(hl, part);
       GO2_MARK(13);
       if (sb == 1) STAMP(19);
-      ph_.phaseC(tl, t, hl, p.hf_cells);
+      ph_.phaseC(tl, t, hl, p.hf_cells, p.hf_top);
       GO2_MARK(14);
       if (sb == 1) STAMP(20);
       // wave-wide row-group activity (ballots -> scalar branches): a group is swept only if some environment of the wave has it active on
@@ -319,7 +321,7 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
       GO2_MARK(15);
       if (sb == 1) STAMP(21);
       ph_.gather_solution();
-      ph_.phaseD(tl, hl);
+      ph_.phaseD(t, hl);
       GO2_MARK(16);
       if (sb == 1) STAMP(22);
     }
@@ -336,7 +338,7 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
   STAMP(3);
   if (MODE & MODE_POST) {
     GO2_MARK(21);
-    lane_init_post(ph_, po_, ax, (const GO2_AS3 uint8_t*)tab.slot_code, uc, &p, &L, &S, e, lane, sub);
+    lane_init_post(ph_, po_, ax, (const GO2_AS3 uint8_t*)tab.slot_code, uc, hc, &p, &L, &S, e, lane, sub);
     po_.yaw_seen = yaw_seen; po_.out = outs;
 #if defined(__HIP_DEVICE_COMPILE__) && defined(GO2_KBENCH_STAMPS)
     po_.dbg = dbg;
@@ -1038,6 +1040,31 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
       s->d_cells = (Go2Cell*)dev_alloc(s, cells.size() * sizeof(Go2Cell));
       if (!s->d_cells) { go2sim_destroy(s); FAIL(GO2SIM_ENOMEM, "allocation failed"); }
       dev_upload(s->d_cells, cells.data(), cells.size() * sizeof(Go2Cell)); p.hf_cells = s->d_cells;
+      // the candidate cull's view of the map (go2_lane.h phaseC): per GO2_TOP_CELL^2 block the highest cell corner within GO2_TOP_REACH
+      // cells around it (separable running maximum), and the smallest facet n_z of the whole map
+      const int B = GO2_TOP_CELL, R = GO2_TOP_REACH; const int tr = (int)((nr + B - 1) / B), tc = (int)((nc + B - 1) / B);
+      std::vector<int16_t> cmax(nr * nc), rowmax((size_t)nr * tc), top((size_t)tr * tc);
+      double nzmin = 1.0; const double hs = cfg->hf_hscale, vs = cfg->hf_vscale;
+      for (size_t i = 0; i < nr * nc; ++i) {
+        const int16_t* h = cells[i].h; int16_t m = h[0]; for (int k = 1; k < 4; ++k) m = h[k] > m ? h[k] : m; cmax[i] = m;
+        // the cell's two triangles, split along (i,j)-(i+1,j+1): slopes (h10 - h00, h11 - h10) and (h11 - h01, h01 - h00)
+        const double s[2][2] = {{(h[1] - h[0]) * vs / hs, (h[3] - h[1]) * vs / hs}, {(h[3] - h[2]) * vs / hs, (h[2] - h[0]) * vs / hs}};
+        for (int k = 0; k < 2; ++k) { const double nz = 1.0 / sqrt(s[k][0] * s[k][0] + s[k][1] * s[k][1] + 1.0); nzmin = nz < nzmin ? nz : nzmin; }
+      }
+      for (size_t i = 0; i < nr; ++i) for (int bj = 0; bj < tc; ++bj) {
+        int16_t m = INT16_MIN; const long j0 = (long)bj * B - R, j1 = (long)(bj + 1) * B + R;
+        for (long j = j0 < 0 ? 0 : j0; j < j1 && j < (long)nc; ++j) m = cmax[i * nc + j] > m ? cmax[i * nc + j] : m;
+        rowmax[i * tc + bj] = m;
+      }
+      for (int bi = 0; bi < tr; ++bi) for (int bj = 0; bj < tc; ++bj) {
+        int16_t m = INT16_MIN; const long i0 = (long)bi * B - R, i1 = (long)(bi + 1) * B + R;
+        for (long i = i0 < 0 ? 0 : i0; i < i1 && i < (long)nr; ++i) m = rowmax[i * tc + bj] > m ? rowmax[i * tc + bj] : m;
+        top[(size_t)bi * tc + bj] = m;
+      }
+      int16_t* d_top = (int16_t*)dev_alloc(s, top.size() * sizeof(int16_t));
+      if (!d_top) { go2sim_destroy(s); FAIL(GO2SIM_ENOMEM, "allocation failed"); }
+      dev_upload(d_top, top.data(), top.size() * sizeof(int16_t)); p.hf_top = d_top;
+      L.hf_trows = tr; L.hf_tcols = tc; L.hf_nzmin = (float)(nzmin * (1.0 - 1e-6));
     }
     type_id.assign(cfg->terrain_type_id, cfg->terrain_type_id + cfg->terrain_num_types); torig.assign(cfg->terrain_origins, cfg->terrain_origins + no);
   }

@@ -262,3 +262,38 @@ def test_rough_terrain_one_step_parity(mesh_type):
     assert np.abs(np.asarray(so.measured_heights)).max() > 0.02
     for s_ in (so, s64, se):
         s_.close()
+
+
+@pytest.mark.parametrize("mesh_type", ["heightfield", "trimesh"])
+def test_candidate_cull_is_conservative_on_rough_terrain(mesh_type):
+    """The lane programs skip a body group's collision candidates when the group provably cannot reach the contact margin — on the height
+    field against the highest surface within 0.8 m (go2sim_create's hf_top map) scaled by the map's steepest facet.  The oracle tests every
+    candidate.  Robots dropped low and tilted all over the curriculum map (every terrain type and level: slopes, stairs, obstacles, gaps),
+    where trunk, hips, thighs and calves touch steps and walls: same contact forces and states from the same inputs."""
+    from helpers import LYING_KW, heightfield_overrides, lying_robot_batch
+    M = 160
+    _, ov = heightfield_overrides(M, mesh_type=mesh_type, max_init_terrain_level=9)
+    kw = dict(LYING_KW, **ov)
+    so, se = HostSim(load_oracle(), num_envs=M, **kw), HostSim(load_emu(), num_envs=M, **kw)
+    so.reset_all(); se.reset_all()
+    rng = np.random.default_rng(5)
+    nonfoot = 0
+    for trial in range(3):
+        lying_robot_batch(so, rng)
+        # onto the env's own piece of terrain: the reset pose's xy (origin + U(-1, 1)), 4-25 cm above the terrain origin's height
+        so.root_states[:, 0:2] = np.asarray(so.env_origins)[:, 0:2] + rng.uniform(-1.5, 1.5, (M, 2))
+        so.root_states[:, 2] = np.asarray(so.env_origins)[:, 2] + rng.uniform(0.04, 0.25, M)
+        for k in STEP_STATE:
+            getattr(se, k)[...] = getattr(so, k)
+        a = np.zeros((M, 12), np.float32)
+        so.step(a); se.step(a)
+        fo, fe = np.asarray(so.contact_forces, np.float64), np.asarray(se.contact_forces, np.float64)
+        d = np.abs(fo - fe).reshape(M, -1).max(1) / (1.0 + np.abs(fo).reshape(M, -1).max(1))
+        # (a facet / wall switch at a cell boundary is the model's own discontinuity: a handful of env-steps may differ, DESIGN.md 3)
+        assert np.median(d) < 1e-4 and (d > 1e-2).sum() <= 3, np.sort(d)[-5:]
+        # the SAME set of bodies is in contact: a culled group that should have been tested would show up as a missing body
+        miss = ((np.linalg.norm(fo, axis=2) > 1.0) & (np.linalg.norm(fe, axis=2) == 0.0)).sum()
+        assert miss <= 1, miss
+        nonfoot += int((np.linalg.norm(fo[:, [0, 1, 2, 3, 4, 5, 7, 8, 9, 11, 12, 13, 15, 16, 17]], axis=2) > 1.0).sum())
+    assert nonfoot > 200      # trunk / hip / thigh / calf contacts were what was compared
+    so.close(); se.close()
