@@ -416,6 +416,72 @@ def gen_ppo(seed=5):
     return out
 
 
+def full_size_weights(state_dict_keys_shapes, seed=9):
+    """Initial weights of the FULL-SIZE go2 actor-critic (45-512-256-128-12 / 263-512-256-128-1) as a pure function of numpy's PCG64 stream, so
+    that a test can rebuild them bit for bit instead of the fixture carrying 2 MB of them: U(-b, b), b = 1 / sqrt(fan_in), tensor after tensor
+    in state_dict order; std = 1."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = {}
+    for k, shp in state_dict_keys_shapes:
+        if k == "std":
+            out[k] = np.ones(shp, np.float32)
+        else:
+            fan_in = shp[1] if len(shp) == 2 else None
+            b = 1.0 / np.sqrt(fan_in if fan_in else (512 if shp[0] == 512 else shp[0]))
+            out[k] = rng.uniform(-b, b, shp).astype(np.float32)
+    return out
+
+
+def gen_ppo_full(seed=9):
+    """One PPO.update (ppo.py:120-187) of the reference on the FULL-SIZE networks of task go2 (go2_config.py:219-221: 512-256-128), 4 Adam steps on
+    96-row mini-batches.  The fixture holds the inputs, the rollout statistics, and of the 488 857 final weights a fixed sample (every element of
+    the small tensors, 20 000 per large one) plus each tensor's sum — a test compares those element by element."""
+    from rsl_rl.algorithms import PPO
+    from rsl_rl.modules import ActorCritic
+    torch.manual_seed(seed)
+    T, N = 6, 32
+    ac = ActorCritic(45, 263, 12, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128], activation="elu", init_noise_std=1.0)
+    w0 = full_size_weights([(k, tuple(v.shape)) for k, v in ac.state_dict().items()], seed)
+    ac.load_state_dict({k: torch.from_numpy(v) for k, v in w0.items()})
+    alg = PPO(ac, num_learning_epochs=2, num_mini_batches=2, clip_param=0.2, gamma=0.99, lam=0.95, value_loss_coef=1.0, entropy_coef=0.01,
+              learning_rate=1e-3, max_grad_norm=1.0, use_clipped_value_loss=True, schedule="adaptive", desired_kl=0.01, device="cpu")
+    alg.init_storage(N, T, [45], [263], [12])
+    g = torch.Generator().manual_seed(seed)
+    obs = torch.randn(T + 1, N, 45, generator=g); cobs = torch.randn(T + 1, N, 263, generator=g)
+    rew = torch.randn(T, N, generator=g) * 0.05; dones = torch.rand(T, N, generator=g) < 0.1; touts = dones & (torch.rand(T, N, generator=g) < 0.5)
+    noise = torch.randn(T, N, 12, generator=g)
+    acts, vals, logps = [], [], []
+    for t in range(T):
+        ac.update_distribution(obs[t])
+        a = (ac.action_mean + ac.action_std * noise[t]).detach()
+        alg.transition.actions = a
+        alg.transition.values = ac.evaluate(cobs[t]).detach()
+        alg.transition.actions_log_prob = ac.get_actions_log_prob(a).detach()
+        alg.transition.action_mean = ac.action_mean.detach(); alg.transition.action_sigma = ac.action_std.detach()
+        alg.transition.observations = obs[t]; alg.transition.critic_observations = cobs[t]
+        acts.append(a.numpy().copy()); vals.append(alg.transition.values.numpy().copy()); logps.append(alg.transition.actions_log_prob.numpy().copy())
+        alg.process_env_step(rew[t], dones[t], {"time_outs": touts[t]})
+    alg.compute_returns(cobs[T])
+    perm = torch.randperm(T * N, generator=torch.Generator().manual_seed(seed + 1))
+    orig_randperm = torch.randperm
+    torch.randperm = lambda n, **kw: perm
+    try:
+        mvl, msl = alg.update()
+    finally:
+        torch.randperm = orig_randperm
+    out = dict(seed=np.int64(seed), obs=obs.numpy(), cobs=cobs.numpy(), rew=rew.numpy(), dones=dones.numpy().astype(np.uint8), time_outs=touts.numpy().astype(np.uint8),
+               noise=noise.numpy(), actions=np.stack(acts), values=np.stack(vals), logp=np.stack(logps), returns=alg.storage.returns.numpy().copy(),
+               advantages=alg.storage.advantages.numpy().copy(), perm=perm.numpy(), mean_value_loss=np.float64(mvl), mean_surrogate_loss=np.float64(msl),
+               final_lr=np.float64(alg.learning_rate))
+    pick = np.random.Generator(np.random.PCG64(seed + 2))
+    for k, v in ac.state_dict().items():
+        w1 = v.detach().numpy().reshape(-1)
+        idx = np.arange(w1.size) if w1.size <= 20000 else np.sort(pick.choice(w1.size, 20000, replace=False))
+        out["idx_" + k] = idx.astype(np.int32); out["w1_" + k] = w1[idx].copy(); out["sum1_" + k] = np.float64(w1.astype(np.float64).sum())
+        out["step_" + k] = np.float32(np.abs(w1 - w0[k].reshape(-1)).max())       # how far the 4 Adam steps moved the tensor (a test must see the same scale)
+    return out
+
+
 def gen_pretrained(seed=31):
     """I/O vectors of the reference's own pretrained deployment policy (deploy/pre_train/go2/go2_cts_150k.pt, a TorchScript export of
     a CTS student) plus its tensors, so the build's loader/exporter and the behavioural walking test can run where the reference
@@ -665,6 +731,7 @@ def main():
     _save(files, "terrain.npz", gen_terrain())
     _save(files, "gae.npz", gen_gae())
     _save(files, "ppo_update.npz", gen_ppo())
+    _save(files, "ppo_update_full.npz", gen_ppo_full())
     _save(files, "ppo_runner_log.npz", gen_ppo_runner())
     _save(files, "pretrained_go2_cts_150k.npz", gen_pretrained())
     _save(files, "cts_iteration.npz", gen_cts("CTS"))
