@@ -89,8 +89,8 @@ def cpu_baseline(task="go2_flat", sizes=(64, NUM_ENVS), iters=3):
     """The same PPO iteration on the host CPU: the plain-C oracle (OpenMP over envs) as the env + torch-CPU PPO, at
     N = 64 (BASELINE config 1) and N = 4096 (the headline size), collection-only and total.  The reference's own --sim_device=cpu path
     cannot run anywhere (Isaac Gym is absent), so this is the build's CPU restatement of the same path ("kind": "port").
-    At the headline size the thread count is SWEPT (16 / 64 / physical cores / all hardware threads, whichever exist): one warm-up + one timed
-    iteration each, then `iters` timed iterations at the best — the reported value is the host's best, with its thread count next to nproc.
+    At the headline size the thread count is SWEPT upwards (8 / 16 / 32 / 64 / physical cores, stopping where it stops paying): one warm-up + one
+    timed iteration each, then `iters` timed iterations at the best — the reported value is the host's best, with its thread count next to nproc.
     Test-infrastructure code, timed only here, never inside the GPU region."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -106,13 +106,20 @@ def cpu_baseline(task="go2_flat", sizes=(64, NUM_ENVS), iters=3):
         runner, _ = task_registry.make_alg_runner(env, task, args, log_root=None)
         threads = min(nproc, CPU_THREADS)
         if n >= 1024:
-            for th in sorted({min(nproc, c) for c in (16, 64, phys, nproc)}):
+            # ascending thread counts; the sweep stops at the first count that is slower than the best so far or whose iteration takes more
+            # than 12 s (a container may report more hardware threads than its CPU quota gives it: oversubscribed OpenMP pools crawl), and
+            # in any case after 60 s — bench.py has to finish within minutes
+            t_sweep = time.perf_counter()
+            for th in sorted({min(nproc, c) for c in (8, 16, 32, 64, phys)}):
                 _set_cpu_threads(th)
                 runner.learn(1, init_at_random_ep_len=(not sweep))
                 t0 = time.perf_counter()
                 runner.learn(1)
                 dt = time.perf_counter() - t0
                 sweep[str(th)] = {"env_steps_per_s": n * 24 / dt, "collection_only_env_steps_per_s": n * 24 / runner.last_collection_time}
+                best = max(v["env_steps_per_s"] for v in sweep.values())
+                if sweep[str(th)]["env_steps_per_s"] < 0.9 * best or dt > 12.0 or time.perf_counter() - t_sweep > 60.0:
+                    break
             threads = best_threads = int(max(sweep, key=lambda k: sweep[k]["env_steps_per_s"]))
             _set_cpu_threads(threads)
         else:

@@ -4,13 +4,17 @@ N(0, 1) actions for 600 steps on the plane and records, for every episode that e
 had been LOW (z < 0.12 m: the trunk box, half height 0.057, touches or is about to) before the reset — the latency a contact model that
 under-reports base contacts would show — plus how many robots lie low without a reset, and how many of the 8 penalised bodies
 (thigh / calf, _reward_collision :1277-1279) report a force among the low robots.
-   python tools/termination_check.py [tag]   (GPU; appends a table to stdout)"""
+   python tools/termination_check.py [tag [library.so]]   (GPU)"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, ctypes as C
 from helpers import DeviceSim, load_hip
-hip = load_hip()
+if len(sys.argv) > 2:      # another build of the library (e.g. build/variants/r2model_1wave.so: the round-2 contact model, two slots per leg)
+    from go2_rl_gym_amd import _abi
+    hip = _abi.bind(os.path.abspath(sys.argv[2]), C.c_float)
+else:
+    hip = load_hip()
 N = 4096
 s = DeviceSim(hip, num_envs=N, seed=5)
 s.reset_all()
