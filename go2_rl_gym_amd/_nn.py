@@ -10,8 +10,12 @@ import torch.nn as nn
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 NN_LIB = os.path.join(_HERE, "libgo2nn_hip.so")
-GO2NN_MAX_LAYERS, GO2NN_MAX_WIDTH, GO2NN_ABI_VERSION = 6, 512, 1
+GO2NN_MAX_LAYERS, GO2NN_MAX_WIDTH, GO2NN_ABI_VERSION = 6, 512, 2
 _cached = None
+
+
+class Go2nnSumJob(C.Structure):
+    _fields_ = [("part", C.c_void_p), ("out", C.c_void_p), ("nrows", C.c_int32), ("ncols", C.c_int32)]
 
 
 class Go2nnMlp(C.Structure):
@@ -27,6 +31,17 @@ def bind(path):
     lib.go2nn_pack.argtypes = [C.POINTER(Go2nnMlp), C.c_void_p, C.c_void_p]
     lib.go2nn_mlp_forward.argtypes = [C.POINTER(Go2nnMlp), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.go2nn_policy_act.argtypes = [C.POINTER(Go2nnMlp), C.c_void_p, C.POINTER(Go2nnMlp), C.c_void_p] + [C.c_void_p] * 10 + [C.c_int32, C.c_void_p]
+    lib.go2nn_head_backward_workspace.restype = C.c_int64
+    lib.go2nn_head_backward_workspace.argtypes = [C.c_int32] * 3
+    lib.go2nn_head_backward.argtypes = [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_void_p]
+    lib.go2nn_linear_elu_forward.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_void_p]
+    lib.go2nn_linear_backward_workspace.restype = C.c_int64
+    lib.go2nn_linear_backward_workspace.argtypes = [C.c_int32] * 3
+    lib.go2nn_linear_backward_input.argtypes = [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_void_p]
+    lib.go2nn_linear_backward_weight.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_void_p]
+    lib.go2nn_sum_rows.argtypes = [C.POINTER(Go2nnSumJob), C.c_int32, C.c_void_p]
+    lib.go2nn_head_backward_rows.argtypes = [C.c_int32] * 3
+    lib.go2nn_linear_backward_input_rows.argtypes = [C.c_int32] * 3
     if lib.go2nn_abi_version() != GO2NN_ABI_VERSION:
         raise RuntimeError("%s: ABI version %d, expected %d" % (path, lib.go2nn_abi_version(), GO2NN_ABI_VERSION))
     return lib

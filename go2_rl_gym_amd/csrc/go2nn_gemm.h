@@ -1,0 +1,291 @@
+// go2nn_gemm.h — fp32-MFMA GEMMs with the learner's element-wise work in their epilogues (included by go2nn_impl.cpp).
+//
+// PPO.update (rsl_rl/rsl_rl/algorithms/ppo.py:120-187) is, per mini-batch of M = 24576 rows and per network, three hidden layers
+//   y = elu(x W^T + b)                                            (modules/actor_critic.py:50-75)
+// forward and backward.  With vendor GEMMs every layer is followed by element-wise passes over the [M, N] activations — ELU, ELU', the bias
+// gradient's column sums and their second stage, the sum over the row splits of the weight gradient: a quarter of the update's kernel time
+// (profiles/r3_bench_kernel_stats.csv) spent re-reading tensors a GEMM just wrote.  Here those passes are epilogues:
+//   forward        Y  = elu(X W^T + b)                                             EPI_BIAS_ELU
+//   input grad     Gp = (G W) * elu'(Yp), column partial sums of Gp               EPI_DELU_COLSUM   (the previous layer's pre-activation gradient + bias gradient)
+//   weight grad    dW = G^T X  as row-split partials                              EPI_STORE         (+ go2nn_sum_splits_kernel, fixed order)
+//
+// One kernel template: C[M,N] = sum_k A(m,k) B(n,k), v_mfma_f32_32x32x2_f32, 256 threads = 4 waves as 2 x 2, a wave owns TM x TN 32x32 tiles
+// (workgroup tile 64 TM x 64 TN), k-tiles of 32 double-buffered through LDS.  Each operand is either "k-contiguous" (rows of k: X, W in the forward
+// pass) or "k-strided" (k runs over rows: W in the input gradient, G and X in the weight gradient); LDS keeps the operand's own orientation:
+//   k-contiguous: tile [rows][32]      — fragment = one ds_read_b128 per lane at [row][8 kb + 4 g]: the lane's four values feed four MFMAs whose
+//                 k index (the lane's g) then stands for input 8 kb + 4 g + e, the same permutation on both operands (as in go2nn_mlp_kernel);
+//                 no padding, the 16-byte quads of a row are XOR-swizzled by the row index instead (GmStage)
+//   k-strided:    tile [32][rows + 8]  — fragment = four ds_read_b32 at [8 kb + 4 g + e][row]; pitch = 8 mod 16: the two half-waves (g = 0 / 1,
+//                 four k-rows apart) fall on disjoint halves of the 64 banks
+// No vendor GEMM library.  fp32 in, fp32 accumulate.
+#pragma once
+
+#define GM_BK 32
+#define GM_THREADS 256
+enum { EPI_STORE = 0, EPI_BIAS_ELU = 1, EPI_DELU_COLSUM = 2 };
+
+struct GemmArgs {
+  const float *A, *B; float* C;
+  const float* bias;          // EPI_BIAS_ELU: [N]
+  const float* Y;             // EPI_DELU_COLSUM: the ELU output [M][ldc] whose derivative multiplies the product
+  float* part;                // EPI_DELU_COLSUM: column partial sums [nbm][N]
+  int M, N, K, lda, ldb, ldc;
+  int kchunk;                 // contraction range per blockIdx.z (a multiple of 32); K when not split
+  long long c_split_stride;   // C of split z starts at C + z * c_split_stride
+  int nbm, nbn;
+  int c_vec;                  // C (and Y) rows are a multiple of 4 floats long and 16-byte aligned: 16-byte epilogue accesses
+  long long* stamps;          // tools only (-DGM_STAMPS)
+  int debug;                  // tools only (GO2NN_GEMM_DEBUG): 1 = no epilogue stores, 2 = every workgroup reads tile (0, 0), 4 = no MFMAs
+};
+
+#ifndef GO2_EMU
+__device__ __forceinline__ float gm_keep(float v, bool ok) { return __uint_as_float(__float_as_uint(v) & (ok ? 0xffffffffu : 0u)); }
+__device__ __forceinline__ int gm_opaque(int v) { asm volatile("" : "+v"(v)); return v; }      // (the compiler must not see that a clamped index implies the in-range test: it would turn the load back into a branch)
+__device__ __forceinline__ float4 gm_masked(const float4 v, unsigned m) {
+  return make_float4(gm_keep(v.x, m & 1), gm_keep(v.y, m & 2), gm_keep(v.z, m & 4), gm_keep(v.w, m & 8));
+}
+
+// One operand's staging state of a thread: global -> registers -> LDS for k-tiles of 32.
+//   k-contiguous operand (KC): R rows x 32 k; thread = (k quad kq = tid & 7, rows tid >> 3 + 32 p).  LDS tile [R][32] with the quad index XOR-ed
+//     by (row >> 1) & 7: 16 consecutive rows at one k quad — what a ds_read_b128 serves per cycle — fall on 16 distinct bank quads, and so do
+//     the 2 rows x 8 quads that 16 consecutive threads write (no padding: the 64 x 128 tile's two stages are 48 KB, three workgroups per CU)
+//   k-strided operand:   32 k-rows x R columns; thread = (column quad tid % (R/4), k-rows tid / (R/4) + (1024/R) p).  LDS tile [32][R + 8].
+// Loads are branch-free: clamped (valid) addresses, zeroed by a select on the way to LDS — and only in workgroups that touch an edge.
+template <int R, bool KC, bool VEC>
+struct GmStage {
+  static constexpr int P = R / 32, QR = R / 4, KP = GM_THREADS / QR, LDS_FLOATS = KC ? R * GM_BK : GM_BK * (R + 8);
+  const float* base; int ld, kend; bool edge;
+  const float* rowp[P];      // KC: the thread's (clamped) rows
+  unsigned rowok;            // KC: bit p = row p in range;  k-strided: 4 column bits
+  int c0, ncols;             // k-strided: the thread's (clamped) first column
+  float4 buf[P]; unsigned okm;
+  __device__ __forceinline__ void init(const float* src, int ld_, int r0, int n, int kend_, int tid) {
+    base = src; ld = ld_; kend = kend_; rowok = 0;
+    if (KC) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) { const int row = r0 + (tid >> 3) + 32 * p; rowp[p] = src + (size_t)gm_opaque(min(row, n - 1)) * ld_; rowok |= (unsigned)(row < n) << p; }
+      edge = r0 + R > n;
+    } else {
+      const int col = r0 + 4 * (tid % QR);
+      ncols = n; c0 = gm_opaque(VEC ? min(col, n - 4) : min(col, n - 1));
+      rowok = VEC ? (col < n ? 15u : 0u) : ((unsigned)(col < n) | (unsigned)(col + 1 < n) << 1 | (unsigned)(col + 2 < n) << 2 | (unsigned)(col + 3 < n) << 3);
+      edge = r0 + R > n;
+    }
+  }
+  // one 16-byte piece (p < P) of the k-tile starting at k0; the pieces of a tile are issued one by one BETWEEN the MFMA groups of the previous tile
+  // (see the kernel): issued together, the loads of all the workgroups of the chip — which run in step — form a burst that saturates the L2 -> CU path,
+  // every wave sits in its load-issue stall while the MFMA pipes idle, and then every wave multiplies while the memory path idles
+  template <int p>
+  __device__ __forceinline__ void load_piece(int k0, int tid) {
+    if (p == 0) okm = 0;
+    if (KC) {
+      const int k = k0 + 4 * (tid & 7);
+      if (VEC) {
+        const int kc = gm_opaque(min(k, kend - 4));
+        buf[p] = *reinterpret_cast<const float4*>(rowp[p] + kc); okm |= ((rowok >> p & 1) && k < kend ? 15u : 0u) << (4 * p);
+      } else {
+        const int k1 = gm_opaque(min(k, kend - 1)), k2 = gm_opaque(min(k + 1, kend - 1)), k3 = gm_opaque(min(k + 2, kend - 1)), k4 = gm_opaque(min(k + 3, kend - 1));
+        const unsigned km = (unsigned)(k < kend) | (unsigned)(k + 1 < kend) << 1 | (unsigned)(k + 2 < kend) << 2 | (unsigned)(k + 3 < kend) << 3;
+        buf[p] = make_float4(rowp[p][k1], rowp[p][k2], rowp[p][k3], rowp[p][k4]); okm |= ((rowok >> p & 1) ? km : 0u) << (4 * p);
+      }
+    } else {
+      const int k = k0 + tid / QR + KP * p;
+      const float* q = base + (size_t)gm_opaque(min(k, kend - 1)) * ld + c0;
+      if (VEC) buf[p] = *reinterpret_cast<const float4*>(q);
+      else { const int n1 = ncols - 1 - c0; buf[p] = make_float4(q[0], q[min(1, n1)], q[min(2, n1)], q[min(3, n1)]); }
+      okm |= (k < kend ? rowok : 0u) << (4 * p);
+    }
+  }
+  template <int p = 0>
+  __device__ __forceinline__ void load(int k0, int tid) {
+    if constexpr (p < P) { load_piece<p>(k0, tid); load<p + 1>(k0, tid); }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ lds, int k0, int tid) const {
+    const bool masked = edge || k0 + GM_BK > kend;          // workgroup-uniform
+    if (KC) {
+      const int kq = tid & 7, r = tid >> 3;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int row = r + 32 * p;
+        *reinterpret_cast<float4*>(lds + row * GM_BK + 4 * (kq ^ ((row >> 1) & 7))) = masked ? gm_masked(buf[p], okm >> (4 * p)) : buf[p];
+      }
+    } else {
+      const int rq = tid % QR, kk = tid / QR;
+#pragma unroll
+      for (int p = 0; p < P; ++p) *reinterpret_cast<float4*>(lds + (kk + KP * p) * (R + 8) + 4 * rq) = masked ? gm_masked(buf[p], okm >> (4 * p)) : buf[p];
+    }
+  }
+  // the MFMA fragment of tile row `r` for k-block kb (8 inputs), lane half g: element e stands for input 8 kb + 4 g + e
+  static __device__ __forceinline__ float4 frag(const float* __restrict__ lds, int r, int kb, int g) {
+    if (KC) return *reinterpret_cast<const float4*>(lds + r * GM_BK + 4 * ((2 * kb + g) ^ ((r >> 1) & 7)));
+    const float* q = lds + (8 * kb + 4 * g) * (R + 8) + r;
+    return make_float4(q[0], q[R + 8], q[2 * (R + 8)], q[3 * (R + 8)]);
+  }
+};
+
+#ifdef GM_STAMPS
+// TOOL-ONLY (tools/gemm_bench.py --stamps): shader-clock stamps of every workgroup's wave 0 -> g.stamps[workgroup][8]:
+// entry, prologue done, k-loop done, end, and the k-loop's time split into load issue / MFMA block / LDS store / barrier wait
+#define GM_DECL() long long t0 = 0, t1 = 0, t2 = 0, tl0 = 0, tl1 = 0, tl2 = 0, tl3 = 0, tl4 = 0, s_ld = 0, s_mm = 0, s_st = 0, s_ba = 0
+#define GM_T(x) do { __builtin_amdgcn_sched_barrier(0); x = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define GM_ACC() do { s_ld += tl1 - tl0; s_mm += tl2 - tl1; s_st += tl3 - tl2; s_ba += tl4 - tl3; } while (0)
+#define GM_OUT() do { if (g.stamps && tid == 0) { long long* o = g.stamps + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8; o[0] = t0; o[1] = t1; o[2] = t2; o[3] = clock64(); o[4] = s_ld; o[5] = s_mm; o[6] = s_st; o[7] = s_ba; } } while (0)
+#else
+#define GM_DECL() do { } while (0)
+#define GM_T(x) do { } while (0)
+#define GM_ACC() do { } while (0)
+#define GM_OUT() do { } while (0)
+#endif
+template <int V> struct GmInt { static constexpr int value = V; };
+template <int J0, int J1, class SA, class SB>
+__device__ __forceinline__ void gm_issue(SA& sa, SB& sb, int k0, int tid) {
+  if constexpr (J0 < J1) {
+    if constexpr (J0 < SA::P) sa.template load_piece<J0>(k0, tid); else sb.template load_piece<J0 - SA::P>(k0, tid);
+    gm_issue<J0 + 1, J1>(sa, sb, k0, tid);
+  }
+}
+
+template <int TM, int TN, bool AKC, bool BKC, int EPI, bool VEC>
+__global__ void __launch_bounds__(GM_THREADS) go2nn_gemm_kernel(const GemmArgs g) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  using SA = GmStage<BM, AKC, VEC>; using SB = GmStage<BN, BKC, VEC>;
+  constexpr int ASZ = SA::LDS_FLOATS, BSZ = SB::LDS_FLOATS;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (ASZ + BSZ)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, gk = lane >> 5, wm = wave & 1, wn = wave >> 1;
+  // workgroup -> tile: consecutive workgroup ids go round the 8 XCDs; a XCD gets a contiguous run of tiles (n fastest: the tiles of one row block
+  // share their A rows in that XCD's L2)
+  const int nb = g.nbm * g.nbn;
+  int t = blockIdx.x;
+  if ((nb & 7) == 0) t = (t & 7) * (nb >> 3) + (t >> 3);
+  const int bm = t / g.nbn, bn = t - bm * g.nbn;
+  const int row0 = bm * BM, col0 = bn * BN;
+  const int lrow0 = (g.debug & 2) ? 0 : row0, lcol0 = (g.debug & 2) ? 0 : col0;
+  const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+  const int nk = (kend - kbeg + GM_BK - 1) / GM_BK;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  GM_DECL();
+  GM_T(t0);
+  SA sa; SB sb;
+  sa.init(g.A, g.lda, lrow0, g.M, kend, tid); sb.init(g.B, g.ldb, lcol0, g.N, kend, tid);
+  if (nk > 0) { sa.load(kbeg, tid); sb.load(kbeg, tid); sa.store(lds, kbeg, tid); sb.store(lds + ASZ, kbeg, tid); }
+  __syncthreads();
+  GM_T(t1);
+  constexpr int NPIECE = SA::P + SB::P, NKB = GM_BK / 8;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1, knext = kbeg + (kt + 1) * GM_BK;
+    const bool more = kt + 1 < nk;
+    const float* As = lds + cur * (ASZ + BSZ); const float* Bs = As + ASZ;
+    GM_T(tl0);
+    if (more) { sa.load(knext, tid); sb.load(knext, tid); }          // the next k-tile's global loads fly while this one is multiplied
+    GM_T(tl1);
+    if (!(g.debug & 4))
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      float4 af[TM], bf[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) af[a] = SA::frag(As, wm * 32 * TM + a * 32 + i, kb, gk);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bf[b] = SB::frag(Bs, wn * 32 * TN + b * 32 + i, kb, gk);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].x, bf[b].x, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].y, bf[b].y, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].z, bf[b].z, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
+        }
+    }
+    GM_T(tl2);
+    if (kt + 1 < nk) { float* An = lds + (cur ^ 1) * (ASZ + BSZ); sa.store(An, knext, tid); sb.store(An + ASZ, knext, tid); }
+    GM_T(tl3);
+    __syncthreads();
+    GM_T(tl4);
+    GM_ACC();
+  }
+  GM_T(t2);
+
+  // epilogue.  The accumulators leave in the MFMA's C/D layout (column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)): stored as they
+  // are that is 16 dword stores per 32x32 tile, each two 128-byte row segments — store-issue-bound, and the input gradient's ELU' operand would come
+  // in by as many dword loads.  Instead every wave turns ITS 32 TM x 32 TN tile through its quarter of the (now free) LDS and works on rows: a lane
+  // owns four consecutive columns, reads / writes 16 bytes at a time, 256-byte row segments per 16 lanes.  Column bit 5 is flipped by row bit 2
+  // (the half-wave's rows): the two half-waves' dword writes fall on different bank halves without padding.
+  {
+    constexpr int RT = 32 * TM, CT = 32 * TN, LPR = CT / 4, RPI = 64 / LPR, NI = RT / RPI;      // lanes per row, rows per instruction, instructions
+    float* wl = lds + wave * (RT * CT);
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * gk;
+          wl[row * CT + ((b * 32 + i) ^ (gk << 5 & (CT - 1)))] = acc[a][b][r];
+        }
+    float* __restrict__ Cz = g.C + (size_t)blockIdx.z * g.c_split_stride;
+    const int lc = (lane % LPR) * 4, lr = lane / LPR;
+    const int col = col0 + wn * CT + lc, rbase = row0 + wm * RT + lr;
+    const bool cv = g.c_vec != 0 && col + 3 < g.N;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI == EPI_BIAS_ELU) {
+      const int c1 = min(col, g.N - 1), c2 = min(col + 1, g.N - 1), c3 = min(col + 2, g.N - 1), c4 = min(col + 3, g.N - 1);
+      bias4 = make_float4(g.bias[c1], g.bias[c2], g.bias[c3], g.bias[c4]);
+    }
+    float4 y4[NI];
+    if (EPI == EPI_DELU_COLSUM) {      // all of the lane's ELU outputs in flight together (clamped addresses; edge values are dropped below)
+#pragma unroll
+      for (int n = 0; n < NI; ++n) {
+        const float* q = g.Y + (size_t)min(rbase + n * RPI, g.M - 1) * g.ldc;
+        if (cv) y4[n] = *reinterpret_cast<const float4*>(q + col);
+        else y4[n] = make_float4(q[min(col, g.N - 1)], q[min(col + 1, g.N - 1)], q[min(col + 2, g.N - 1)], q[min(col + 3, g.N - 1)]);
+      }
+    }
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+      const int lrow = lr + n * RPI, row = rbase + n * RPI;
+      float4 v = *reinterpret_cast<const float4*>(wl + lrow * CT + (lc ^ ((lrow >> 2 & 1) << 5 & (CT - 1))));
+      if (EPI == EPI_BIAS_ELU) v = make_float4(elu1(v.x + bias4.x), elu1(v.y + bias4.y), elu1(v.z + bias4.z), elu1(v.w + bias4.w));
+      if (EPI == EPI_DELU_COLSUM) {
+        const float4 y = y4[n];
+        v.x *= y.x > 0.f ? 1.f : y.x + 1.f; v.y *= y.y > 0.f ? 1.f : y.y + 1.f; v.z *= y.z > 0.f ? 1.f : y.z + 1.f; v.w *= y.w > 0.f ? 1.f : y.w + 1.f;
+        if (row < g.M) { cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w; }
+      }
+      if (row < g.M && !(g.debug & 1)) {
+        float* o = Cz + (size_t)row * g.ldc + col;
+        if (cv) *reinterpret_cast<float4*>(o) = v;
+        else { if (col < g.N) o[0] = v.x; if (col + 1 < g.N) o[1] = v.y; if (col + 2 < g.N) o[2] = v.z; if (col + 3 < g.N) o[3] = v.w; }
+      }
+    }
+    if (EPI == EPI_DELU_COLSUM) {
+      // column partial sums of this row block: a lane's rows in order -> the lanes that share its columns (xor tree) -> the two row waves; a fixed order
+#pragma unroll
+      for (int d = LPR; d < 64; d <<= 1) { cs.x += __shfl_xor(cs.x, d); cs.y += __shfl_xor(cs.y, d); cs.z += __shfl_xor(cs.z, d); cs.w += __shfl_xor(cs.w, d); }
+      __syncthreads();                      // every wave is done with its LDS quarter
+      float* shs = lds;                     // [2][BN]
+      if (lane < LPR) *reinterpret_cast<float4*>(shs + wm * BN + wn * CT + lc) = cs;
+      __syncthreads();
+      if (tid < BN && col0 + tid < g.N) g.part[(size_t)bm * g.N + col0 + tid] = shs[tid] + shs[BN + tid];
+    }
+  }
+  GM_OUT();
+}
+
+#endif  // !GO2_EMU
+
+// tile shape (TM, TN in 32x32 tiles per wave; workgroup tile 64 TM x 64 TN) for an M x N output with M large: 64 x 128 (48 KB of LDS: three
+// workgroups per CU, and at M = 24576 the workgroup count is a multiple of 3 x 256) unless the output is narrow or 128 columns would mostly be padding
+static inline int gm_pick(int n) { return (n + 127) / 128 * 128 <= (n + 63) / 64 * 64 ? 2 : 1; }
+static inline void gemm_tile(int M, int N, int* tm, int* tn) {
+  if (const char* e = getenv("GO2NN_TILE")) { if (e[0] >= '1' && e[0] <= '2' && e[1] >= '1' && e[1] <= '2') { *tm = e[0] - '0'; *tn = e[1] - '0'; return; } }   // tools/gemm_bench.py: tile sweep
+  (void)M;
+  *tm = 1; *tn = N > 128 ? gm_pick(N) : 1;
+}

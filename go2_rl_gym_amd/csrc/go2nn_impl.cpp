@@ -21,6 +21,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "../../include/go2nn.h"
 
@@ -234,6 +235,9 @@ __global__ void __launch_bounds__(NN_THREADS) go2nn_mlp_kernel(const NNArgs a) {
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) FAIL(GO2NN_EDEVICE, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
 #endif  // !GO2_EMU
 
+#include "go2nn_train.h"
+#include "go2nn_gemm.h"
+
 #ifdef GO2_EMU
 // host restatement: the SAME packed buffer, read in the operand order the kernel uses
 static void emu_forward(const NetDesc& nd, int N, int row0, float out[NN_ROWS][GO2NN_MAX_WIDTH]) {
@@ -255,6 +259,43 @@ static void emu_forward(const NetDesc& nd, int N, int row0, float out[NN_ROWS][G
   for (int i = 0; i < NN_ROWS; ++i) for (int n = 0; n < nd.out_dim; ++n) out[i][n] = A[i][n];
 }
 #endif
+
+// ---- the hidden layers of the learner: MFMA GEMMs with fused epilogues (go2nn_gemm.h) ------------------------------------------------
+#ifndef GO2_EMU
+#ifdef GM_STAMPS
+static long long* g_gemm_stamps = nullptr;
+extern "C" void go2nn_debug_gemm_stamps(long long* p) { g_gemm_stamps = p; }      // TOOL-ONLY: device buffer [workgroups][8] of the next launches
+#endif
+template <bool AKC, bool BKC, int EPI, bool VEC>
+static void gemm_dispatch2(int tm, int tn, const GemmArgs& g, int splits, hipStream_t st) {
+  const dim3 grid(g.nbm * g.nbn, 1, splits), blk(GM_THREADS);
+  if (tm == 2 && tn == 2)      hipLaunchKernelGGL((go2nn_gemm_kernel<2, 2, AKC, BKC, EPI, VEC>), grid, blk, 0, st, g);
+  else if (tm == 1 && tn == 2) hipLaunchKernelGGL((go2nn_gemm_kernel<1, 2, AKC, BKC, EPI, VEC>), grid, blk, 0, st, g);
+  else if (tm == 2 && tn == 1) hipLaunchKernelGGL((go2nn_gemm_kernel<2, 1, AKC, BKC, EPI, VEC>), grid, blk, 0, st, g);
+  else                         hipLaunchKernelGGL((go2nn_gemm_kernel<1, 1, AKC, BKC, EPI, VEC>), grid, blk, 0, st, g);
+}
+template <bool AKC, bool BKC, int EPI>
+static void gemm_dispatch(int tm, int tn, GemmArgs& g, int splits, bool vec, hipStream_t st) {
+  if (const char* e = getenv("GO2NN_GEMM_DEBUG")) g.debug = atoi(e);
+#ifdef GM_STAMPS
+  g.stamps = g_gemm_stamps;
+#endif
+  if (vec) gemm_dispatch2<AKC, BKC, EPI, true>(tm, tn, g, splits, st); else gemm_dispatch2<AKC, BKC, EPI, false>(tm, tn, g, splits, st);
+}
+static inline int aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+#endif
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// row splits of the weight gradient dW [C, Kin] = G^T X over M rows: enough workgroups for two per CU, at least 256 rows each
+static inline void wgrad_shape(int M, int C, int Kin, int* tm, int* tn, int* splits, int* kchunk) {
+  *tm = gm_pick(C); *tn = gm_pick(Kin);              // (no minimum workgroup count here: the row splits supply the parallelism)
+  if (const char* e = getenv("GO2NN_WTILE")) { if (e[0] >= '1' && e[0] <= '2' && e[1] >= '1' && e[1] <= '2') { *tm = e[0] - '0'; *tn = e[1] - '0'; } }
+  int target = 512; if (const char* e = getenv("GO2NN_WSPLIT_WGS")) target = atoi(e);
+  const int tiles = cdiv(C, 64 * *tm) * cdiv(Kin, 64 * *tn);
+  int s = target / tiles; if (s < 1) s = 1;
+  int kc = cdiv(cdiv(M, s), GM_BK) * GM_BK; if (kc < 256) kc = 256;
+  *kchunk = kc; *splits = cdiv(M, kc);
+}
+static int lin_check(int M, int C, int Kin) { return M > 0 && C > 0 && Kin > 0 && C <= 4096 && Kin <= 4096; }
 
 extern "C" {
 
@@ -344,6 +385,163 @@ int go2nn_policy_act(const Go2nnMlp* actor, const float* actor_packed, const Go2
   a.std_ = std_; a.eps = eps; a.a_out = a_out; a.a_st = a_st; a.mu_st = mu_st; a.sig_st = sig_st; a.lp_st = lp_st; a.v_st = v_st;
   a.N = N; a.A = a.net[0].out_dim; a.mode = 1;
   return run(a, 2, stream);
+}
+
+int go2nn_sum_rows(const Go2nnSumJob* jobs, int32_t njobs, void* stream) {
+  if (!jobs || njobs <= 0 || njobs > 16) FAIL(GO2NN_EINVAL, "sum rows: 1..16 jobs");
+  for (int j = 0; j < njobs; ++j) if (!jobs[j].part || !jobs[j].out || jobs[j].nrows <= 0 || jobs[j].ncols <= 0) FAIL(GO2NN_EINVAL, "sum rows: bad job %d", j);
+#ifdef GO2_EMU
+  (void)stream;
+  for (int j = 0; j < njobs; ++j) for (int c = 0; c < jobs[j].ncols; ++c) {
+    float s = 0.f;
+    for (int r = 0; r < jobs[j].nrows; ++r) s += jobs[j].part[(int64_t)r * jobs[j].ncols + c];
+    jobs[j].out[c] = s;
+  }
+#else
+  SumRowsArgs a; memset(&a, 0, sizeof(a));
+  a.njobs = njobs; a.first_block[0] = 0;
+  for (int j = 0; j < njobs; ++j) {
+    a.part[j] = jobs[j].part; a.out[j] = jobs[j].out; a.nrows[j] = jobs[j].nrows; a.ncols[j] = jobs[j].ncols;
+    a.first_block[j + 1] = a.first_block[j] + (jobs[j].nrows <= 32 ? (jobs[j].ncols + 255) / 256 : (jobs[j].ncols + 15) / 16);
+  }
+  hipLaunchKernelGGL(go2nn_sum_rows_kernel, dim3(a.first_block[njobs]), dim3(256), 0, (hipStream_t)stream, a);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+int32_t go2nn_head_backward_rows(int32_t B, int32_t C, int32_t K) {
+  if (go2nn_head_backward_workspace(B, C, K) < 0) return GO2NN_EINVAL;
+#ifdef GO2_EMU
+  return 1;
+#else
+  int q, rows, nwg; head_bwd_shape(B, K, &q, &rows, &nwg); return nwg;
+#endif
+}
+int32_t go2nn_linear_backward_input_rows(int32_t M, int32_t C, int32_t Kin) {
+  if (!lin_check(M, C, Kin)) FAIL(GO2NN_EINVAL, "linear backward: bad shape");
+#ifdef GO2_EMU
+  return 1;
+#else
+  int tm, tn; gemm_tile(M, Kin, &tm, &tn); return cdiv(M, 64 * tm);
+#endif
+}
+
+int64_t go2nn_head_backward_workspace(int32_t B, int32_t C, int32_t K) {
+  if (B <= 0 || C <= 0 || C > HB_MAX_C || K <= 0 || K > GO2NN_MAX_WIDTH || (K & 3)) FAIL(GO2NN_EINVAL, "head backward: 1 <= C <= %d, K a multiple of 4 up to %d", HB_MAX_C, GO2NN_MAX_WIDTH);
+  int q, rows, nwg; head_bwd_shape(B, K, &q, &rows, &nwg);
+  return (int64_t)nwg * ((int64_t)(C + 1) * K + C);
+}
+
+int go2nn_head_backward(const float* gy, const float* y, const float* w, float* gz, float* sums, float* workspace, int32_t B, int32_t C, int32_t K, void* stream) {
+  if (!gy || !y || !w || !gz || !workspace || go2nn_head_backward_workspace(B, C, K) < 0) FAIL(GO2NN_EINVAL, "head backward: bad argument");
+#ifdef GO2_EMU
+  (void)stream;
+  const int64_t ns = (int64_t)(C + 1) * K + C;
+  if (!sums) sums = workspace;           // partials only: the host build has ONE partial row (go2nn_head_backward_rows = 1)
+  for (int64_t i = 0; i < ns; ++i) sums[i] = 0.f;
+  for (int r = 0; r < B; ++r) {
+    for (int c = 0; c < C; ++c) sums[(int64_t)(C + 1) * K + c] += gy[(int64_t)r * C + c];
+    for (int k = 0; k < K; ++k) {
+      const float v = y[(int64_t)r * K + k];
+      float s = 0.f;
+      for (int c = 0; c < C; ++c) { const float g = gy[(int64_t)r * C + c]; s = fmaf(g, w[(int64_t)c * K + k], s); sums[(int64_t)c * K + k] = fmaf(g, v, sums[(int64_t)c * K + k]); }
+      const float o = s * (v > 0.f ? 1.f : v + 1.f);
+      gz[(int64_t)r * K + k] = o; sums[(int64_t)C * K + k] += o;
+    }
+  }
+#else
+  int q, rows, nwg; head_bwd_shape(B, K, &q, &rows, &nwg);
+  const int ncols = (C + 1) * K + C;
+  hipStream_t st = (hipStream_t)stream;
+  if (C == 1)       hipLaunchKernelGGL(go2nn_head_bwd_kernel<1>,  dim3(nwg), dim3(HB_THREADS), 0, st, gy, y, w, gz, workspace, B, C, K, q, rows);
+  else if (C <= 4)  hipLaunchKernelGGL(go2nn_head_bwd_kernel<4>,  dim3(nwg), dim3(HB_THREADS), 0, st, gy, y, w, gz, workspace, B, C, K, q, rows);
+  else if (C <= 8)  hipLaunchKernelGGL(go2nn_head_bwd_kernel<8>,  dim3(nwg), dim3(HB_THREADS), 0, st, gy, y, w, gz, workspace, B, C, K, q, rows);
+  else if (C <= 12) hipLaunchKernelGGL(go2nn_head_bwd_kernel<12>, dim3(nwg), dim3(HB_THREADS), 0, st, gy, y, w, gz, workspace, B, C, K, q, rows);
+  else              hipLaunchKernelGGL(go2nn_head_bwd_kernel<16>, dim3(nwg), dim3(HB_THREADS), 0, st, gy, y, w, gz, workspace, B, C, K, q, rows);
+  HIPCHK(hipGetLastError());
+  if (sums) { const Go2nnSumJob job = {workspace, sums, nwg, ncols}; return go2nn_sum_rows(&job, 1, stream); }
+#endif
+  return 0;
+}
+
+int go2nn_linear_elu_forward(const float* x, const float* w, const float* b, float* y, int32_t M, int32_t K, int32_t N, void* stream) {
+  if (!x || !w || !b || !y || !lin_check(M, N, K)) FAIL(GO2NN_EINVAL, "linear forward: bad argument");
+#ifdef GO2_EMU
+  (void)stream;
+  for (int m = 0; m < M; ++m) for (int n = 0; n < N; ++n) {
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc = fmaf(x[(int64_t)m * K + k], w[(int64_t)n * K + k], acc);
+    const float v = acc + b[n];
+    y[(int64_t)m * N + n] = v > 0.f ? v : expm1f(v);
+  }
+#else
+  GemmArgs g; memset(&g, 0, sizeof(g));
+  int tm, tn; gemm_tile(M, N, &tm, &tn);
+  g.A = x; g.B = w; g.C = y; g.bias = b; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N;
+  const bool vec = (K % 4 == 0) && aligned16(x) && aligned16(w);
+  g.kchunk = cdiv(K, GM_BK) * GM_BK; g.nbm = cdiv(M, 64 * tm); g.nbn = cdiv(N, 64 * tn);
+  g.c_vec = (N % 4 == 0) && aligned16(y);
+  gemm_dispatch<true, true, EPI_BIAS_ELU>(tm, tn, g, 1, vec, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+int64_t go2nn_linear_backward_workspace(int32_t M, int32_t C, int32_t Kin) {
+  if (!lin_check(M, C, Kin)) FAIL(GO2NN_EINVAL, "linear backward: bad shape");
+  int tm, tn, s, kc; wgrad_shape(M, C, Kin, &tm, &tn, &s, &kc);
+  const int64_t wg = (int64_t)s * C * Kin;
+  gemm_tile(M, Kin, &tm, &tn);
+  const int64_t ig = (int64_t)cdiv(M, 64 * tm) * Kin;
+  return wg > ig ? wg : ig;
+}
+
+int go2nn_linear_backward_input(const float* gz, const float* w, const float* y_prev, float* gz_prev, float* gb_prev, float* workspace,
+                                int32_t M, int32_t C, int32_t Kin, void* stream) {
+  if (!gz || !w || !y_prev || !gz_prev || !workspace || !lin_check(M, C, Kin)) FAIL(GO2NN_EINVAL, "linear backward (input): bad argument");
+#ifdef GO2_EMU
+  (void)stream;
+  if (!gb_prev) gb_prev = workspace;     // partials only (one partial row in the host build)
+  for (int k = 0; k < Kin; ++k) gb_prev[k] = 0.f;
+  for (int m = 0; m < M; ++m) for (int k = 0; k < Kin; ++k) {
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) acc = fmaf(gz[(int64_t)m * C + c], w[(int64_t)c * Kin + k], acc);
+    const float yv = y_prev[(int64_t)m * Kin + k], o = acc * (yv > 0.f ? 1.f : yv + 1.f);
+    gz_prev[(int64_t)m * Kin + k] = o; gb_prev[k] += o;
+  }
+#else
+  GemmArgs g; memset(&g, 0, sizeof(g));
+  int tm, tn; gemm_tile(M, Kin, &tm, &tn);
+  g.A = gz; g.B = w; g.C = gz_prev; g.Y = y_prev; g.part = workspace; g.M = M; g.N = Kin; g.K = C; g.lda = C; g.ldb = Kin; g.ldc = Kin;
+  const bool vec = (C % 4 == 0) && (Kin % 4 == 0) && aligned16(gz) && aligned16(w);
+  g.kchunk = cdiv(C, GM_BK) * GM_BK; g.nbm = cdiv(M, 64 * tm); g.nbn = cdiv(Kin, 64 * tn);
+  g.c_vec = (Kin % 4 == 0) && aligned16(gz_prev) && aligned16(y_prev);
+  gemm_dispatch<true, false, EPI_DELU_COLSUM>(tm, tn, g, 1, vec, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  if (gb_prev) { const Go2nnSumJob job = {workspace, gb_prev, g.nbm, Kin}; return go2nn_sum_rows(&job, 1, stream); }
+#endif
+  return 0;
+}
+
+int go2nn_linear_backward_weight(const float* gz, const float* x, float* dw, float* workspace, int32_t M, int32_t C, int32_t Kin, void* stream) {
+  if (!gz || !x || !dw || !workspace || !lin_check(M, C, Kin)) FAIL(GO2NN_EINVAL, "linear backward (weight): bad argument");
+#ifdef GO2_EMU
+  (void)stream; (void)workspace;
+  for (int64_t i = 0; i < (int64_t)C * Kin; ++i) dw[i] = 0.f;
+  for (int m = 0; m < M; ++m) for (int c = 0; c < C; ++c) { const float gv = gz[(int64_t)m * C + c]; for (int k = 0; k < Kin; ++k) dw[(int64_t)c * Kin + k] = fmaf(gv, x[(int64_t)m * Kin + k], dw[(int64_t)c * Kin + k]); }
+#else
+  GemmArgs g; memset(&g, 0, sizeof(g));
+  int tm, tn, s, kc; wgrad_shape(M, C, Kin, &tm, &tn, &s, &kc);
+  g.A = gz; g.B = x; g.C = s > 1 ? workspace : dw; g.M = C; g.N = Kin; g.K = M; g.lda = C; g.ldb = Kin; g.ldc = Kin;
+  const bool vec = (C % 4 == 0) && (Kin % 4 == 0) && aligned16(gz) && aligned16(x);
+  g.kchunk = kc; g.c_split_stride = (long long)C * Kin; g.nbm = cdiv(C, 64 * tm); g.nbn = cdiv(Kin, 64 * tn);
+  g.c_vec = (Kin % 4 == 0) && aligned16(g.C);
+  gemm_dispatch<false, false, EPI_STORE>(tm, tn, g, s, vec, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  if (s > 1) { const Go2nnSumJob job = {workspace, dw, s, C * Kin}; return go2nn_sum_rows(&job, 1, stream); }
+#endif
+  return 0;
 }
 
 #ifdef GO2NN_STAMPS

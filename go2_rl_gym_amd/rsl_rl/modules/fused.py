@@ -7,6 +7,12 @@ The weight gradients dW = gz^T x (a [C, K] output reduced over the 24576 rows of
 split over the rows — one batched GEMM + a sum over S — instead of one mm: for these shapes hipBLASLt's own split-K launches ~60
 workgroups on 256 CUs (tools/wgrad_bench.py: 166 -> 70 us at 512x263, 325 -> 58 us at 256x512).  Fixed order: deterministic.
 
+The TAIL of an MLP — Linear -> ELU -> Linear with a narrow output (the 12-wide action mean, the 1-wide value) — is one autograd node whose
+backward starts with go2nn_head_backward (include/go2nn.h): the head's input gradient, its weight and bias gradients, the ELU backward and the
+hidden layer's bias gradient in ONE streaming pass, in place of two degenerate GEMMs (58 us for the value head's [1,128] weight gradient),
+a split-K fix-up, two column-sum launches and the element-wise pass (profiles/r2_timeline_rollout_step_and_minibatch.txt: the head of the
+critic's chain, which is the critical path of a mini-batch).
+
 Per process through set_library(lib) — the algorithms call it when they run on the GPU with the HIP library."""
 import ctypes as C
 import os
@@ -16,7 +22,10 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 _LIB = None
+_NN = None
 _WGRAD_SPLIT = int(os.environ.get("GO2_WGRAD_SPLIT", "8"))       # 1 = plain mm
+_MLP_NODE = os.environ.get("GO2_MLP_NODE", "1") == "1"       # 0: per-layer autograd nodes (_LinearELU / _LinearELUHead) instead of the whole-MLP node
+_DEFER_SUMS = os.environ.get("GO2_MLP_DEFER", "1") == "1"
 _WGRAD_MIN_ROWS = 256       # rows per split below which the plain mm is used (tests lower it to drive the split path with small goldens)
 
 
@@ -30,8 +39,50 @@ def _wgrad(gz, x):
 
 
 def set_library(lib):
-    global _LIB
+    """lib: the go2sim library (HIP on the GPU; tests pass the oracle).  With the HIP library the learner-side go2nn kernels come along —
+    load_nn raises when libgo2nn_hip.so is missing (no silent fallback to the GEMM formulation on a GPU box)."""
+    global _LIB, _NN
     _LIB = lib
+    if lib is not None and lib.go2sim_is_device_library() == 1 and _NN is None and os.environ.get("GO2_FUSED_HEAD", "1") == "1":
+        from ..._nn import load_nn
+        _NN = load_nn()
+
+
+def set_nn_library(nn_lib):
+    """The go2nn library for the MLP tails (tests hand in the host build; None switches the fused tail off)."""
+    global _NN
+    _NN = nn_lib
+
+
+def _check(rc, what, lib):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s" % (what, lib.go2nn_last_error().decode()))
+
+
+class _LinearELUHead(torch.autograd.Function):
+    """x -> Linear(w1, b1) -> ELU -> Linear(w2, b2) with out_features(w2) <= 16, as one node (see the module docstring)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        y = F.elu_(torch.addmm(b1, x, w1.t()))
+        ctx.save_for_backward(x, w1, y, w2)
+        return torch.addmm(b2, y, w2.t())
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, w1, y, w2 = ctx.saved_tensors
+        gout = gout.contiguous()
+        B, K = y.shape
+        Cn = w2.shape[0]
+        n = _NN.go2nn_head_backward_workspace(B, Cn, K)
+        if n < 0:
+            raise RuntimeError("go2nn_head_backward_workspace: %s" % _NN.go2nn_last_error().decode())
+        gz, sums, ws = torch.empty_like(y), torch.empty((Cn + 1) * K + Cn, device=y.device, dtype=y.dtype), torch.empty(int(n), device=y.device, dtype=y.dtype)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        stream = C.c_void_p(torch.cuda.current_stream(y.device).cuda_stream) if y.is_cuda else None
+        _check(_NN.go2nn_head_backward(p(gout), p(y), p(w2.contiguous()), p(gz), p(sums), p(ws), B, Cn, K, stream), "go2nn_head_backward", _NN)
+        gx = gz.mm(w1) if ctx.needs_input_grad[0] else None
+        return gx, _wgrad(gz, x), sums[Cn * K:(Cn + 1) * K], sums[:Cn * K].view(Cn, K), sums[(Cn + 1) * K:]
 
 
 class _LinearELU(torch.autograd.Function):
@@ -73,6 +124,131 @@ class _Linear(torch.autograd.Function):
         return gx, _wgrad(gy, x), gy.sum(0)
 
 
+def _is_tail(l1, act, l2):
+    return (isinstance(l1, nn.Linear) and isinstance(act, nn.ELU) and act.alpha == 1.0 and isinstance(l2, nn.Linear) and l1.bias is not None and l2.bias is not None
+            and l1.weight.requires_grad and l2.weight.requires_grad and l2.out_features <= 16 and l1.out_features % 4 == 0 and l1.out_features <= 512)
+
+
+# Which of a hidden layer's three products go to the go2nn MFMA kernels (include/go2nn.h go2nn_linear_*) and which stay on hipBLASLt + the element-wise
+# kernels.  Measured per shape at M = 24576 on one MI355X, alone and as the actor / critic pair on two streams (tools/gemm_bench.py), and — what
+# decides — as the whole job with one rule switched at a time, in ONE session on one GPU (profiles/r3_mlp_kernel_choice.txt; boxes differ by a few %):
+#   forward:      own for the 256 -> 128 layer (23 us against addmm + elu_ 28; as the pair 57 against 85-130); the 512-wide layers are at parity alone
+#                 (65 us) and lose as the pair; rows that are not a multiple of 16 bytes (the 45- and 263-wide inputs) take the 4-byte load path and lose
+#   input grad:   own is faster alone (85 against 93 us, 35 against 41) but the whole job is 4 % slower with it (two of these kernels on two streams
+#                 slow each other down more than a hipBLASLt pair does) -> vendor GEMM + go2sim_elu_backward_bias
+#   weight grad:  hipBLASLt's row-split bmm (60 us against 88); its sum over the splits joins the deferred reductions
+# GO2_MLP_OWN_F / _I / _W = all | none | auto | k256 override the three rules (A/B runs).
+_OWN = {k: os.environ.get("GO2_MLP_OWN_" + k.upper(), "auto") for k in ("f", "i", "w")}
+
+
+def _own(kind, K, N):
+    """kind 'f': y[M,N] = elu(x[M,K] W^T + b); 'i': input gradient of a layer with N outputs, K inputs; 'w': its weight gradient"""
+    mode = _OWN[kind]
+    if mode == "k256":
+        return K <= 256
+    if mode != "auto":
+        return mode == "all"
+    return kind == "f" and N <= 128 and K % 4 == 0
+
+
+class _FusedMLP(torch.autograd.Function):
+    """x -> [Linear -> ELU] x H -> Linear (narrow) as ONE autograd node: every product of the forward and backward pass is an explicit kernel call,
+    so each can go to the kernel that is fastest for its shape, and the element-wise work between the layers rides in GEMM epilogues where the
+    GEMM is ours (ELU in the forward; ELU' + the bias gradient's column sums in the input gradient) or in the one fused pass that follows a
+    vendor GEMM (go2sim_elu_backward_bias).  args: x, w1, b1, ..., wH, bH, w_out, b_out."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        ws, bs = params[0::2], params[1::2]
+        H = len(ws) - 1
+        p = lambda t: C.c_void_p(t.data_ptr())
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream) if x.is_cuda else None
+        acts = [x]
+        for l in range(H):
+            h, w, b = acts[-1], ws[l], bs[l]
+            if _own("f", w.shape[1], w.shape[0]):
+                y = torch.empty(h.shape[0], w.shape[0], device=h.device, dtype=h.dtype)
+                _check(_NN.go2nn_linear_elu_forward(p(h), p(w), p(b), p(y), h.shape[0], w.shape[1], w.shape[0], stream), "go2nn_linear_elu_forward", _NN)
+            else:
+                y = F.elu_(torch.addmm(b, h, w.t()))
+            acts.append(y)
+        ctx.save_for_backward(*acts, *ws)
+        ctx.H = H
+        return torch.addmm(bs[H], acts[-1], ws[H].t())
+
+    @staticmethod
+    def backward(ctx, gout):
+        from ..._nn import Go2nnSumJob
+        H = ctx.H
+        acts, ws = ctx.saved_tensors[:H + 1], ctx.saved_tensors[H + 1:]
+        dev, dt = gout.device, gout.dtype
+        p = lambda t: C.c_void_p(t.data_ptr())
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if gout.is_cuda else None
+        new = lambda *shape: torch.empty(*shape, device=dev, dtype=dt)
+        gout = gout.contiguous()
+        B = gout.shape[0]
+        jobs = []          # (partial rows, result, nrows, ncols): every fixed-order reduction of this pass, finished by ONE go2nn_sum_rows launch at the end
+        # the head: input gradient, ELU', weight / bias gradients and the last hidden layer's bias gradient in one pass
+        y, w_out = acts[H], ws[H]
+        Cn, K = w_out.shape
+        n = _NN.go2nn_head_backward_workspace(B, Cn, K)
+        if n < 0:
+            raise RuntimeError("go2nn_head_backward_workspace: %s" % _NN.go2nn_last_error().decode())
+        gz, sums, wk = torch.empty_like(y), new((Cn + 1) * K + Cn), new(int(n))
+        _check(_NN.go2nn_head_backward(p(gout), p(y), p(w_out), p(gz), None, p(wk), B, Cn, K, stream), "go2nn_head_backward", _NN)
+        jobs.append((wk, sums, _NN.go2nn_head_backward_rows(B, Cn, K), (Cn + 1) * K + Cn))
+        grads = [None] * (2 * (H + 1))
+        grads[2 * H], grads[2 * H + 1] = sums[:Cn * K].view(Cn, K), sums[(Cn + 1) * K:]
+        gb = sums[Cn * K:(Cn + 1) * K]
+        for l in range(H - 1, -1, -1):          # gz: gradient at layer l's pre-activation; gb: its column sums
+            w, h = ws[l], acts[l]                # h: the layer's input (= the ELU output of the layer before, or x)
+            Co, Ki = w.shape
+            S = _WGRAD_SPLIT
+            if _own("w", Ki, Co):
+                dw, wk = torch.empty_like(w), new(int(_NN.go2nn_linear_backward_workspace(B, Co, Ki)))
+                _check(_NN.go2nn_linear_backward_weight(p(gz), p(h), p(dw), p(wk), B, Co, Ki, stream), "go2nn_linear_backward_weight", _NN)
+            elif S > 1 and gz.is_cuda and B % S == 0 and B // S >= _WGRAD_MIN_ROWS:
+                parts = torch.bmm(gz.view(S, B // S, Co).transpose(1, 2), h.view(S, B // S, Ki))       # the row splits of _wgrad, summed with the rest below
+                dw = torch.empty_like(w)
+                jobs.append((parts, dw, S, Co * Ki))
+            else:
+                dw = gz.t().mm(h)
+            grads[2 * l], grads[2 * l + 1] = dw, gb
+            if l > 0:
+                gzp, gbp = torch.empty_like(h), new(Ki)
+                if _own("i", Ki, Co):
+                    wk = new(int(_NN.go2nn_linear_backward_workspace(B, Co, Ki)))
+                    _check(_NN.go2nn_linear_backward_input(p(gz), p(w), p(h), p(gzp), None, p(wk), B, Co, Ki, stream), "go2nn_linear_backward_input", _NN)
+                    jobs.append((wk, gbp, _NN.go2nn_linear_backward_input_rows(B, Co, Ki), Ki))
+                else:
+                    gx = gz.mm(w)
+                    wk2 = new(Ki * ((B + 63) // 64))
+                    rc = _LIB.go2sim_elu_backward_bias(p(gx), p(h), p(gzp), p(gbp), p(wk2), B, Ki, stream)
+                    if rc != 0:
+                        raise RuntimeError("go2sim_elu_backward_bias failed: %s" % _LIB.go2sim_last_error().decode())
+                gz, gb = gzp, gbp
+        gx = gz.mm(ws[0]) if ctx.needs_input_grad[0] else None
+        step = 16 if _DEFER_SUMS else 1          # (GO2_MLP_DEFER=0: one launch per reduction, for the A/B)
+        for k in range(0, len(jobs), step):
+            chunk = jobs[k:k + step]
+            arr = (Go2nnSumJob * len(chunk))(*[Go2nnSumJob(t[0].data_ptr(), t[1].data_ptr(), t[2], t[3]) for t in chunk])
+            _check(_NN.go2nn_sum_rows(arr, len(chunk), stream), "go2nn_sum_rows", _NN)
+        return (gx, *grads)
+
+
+def _whole_mlp(mods):
+    """[(Linear, ELU)] * H + [Linear narrow] with H >= 1 -> the Linear modules, else None"""
+    if len(mods) < 3 or len(mods) % 2 == 0 or not _is_tail(mods[-3], mods[-2], mods[-1]):
+        return None
+    lins = []
+    for k in range(0, len(mods) - 1, 2):
+        m, a = mods[k], mods[k + 1]
+        if not (isinstance(m, nn.Linear) and isinstance(a, nn.ELU) and a.alpha == 1.0 and m.bias is not None and m.weight.requires_grad and m.out_features % 4 == 0):
+            return None
+        lins.append(m)
+    return lins + [mods[-1]]
+
+
 class FusedSequential(nn.Sequential):
     """nn.Sequential whose (Linear, ELU(alpha=1)) pairs take the fused path when gradients are being recorded."""
 
@@ -80,10 +256,17 @@ class FusedSequential(nn.Sequential):
         mods = list(self)
         fuse = (_LIB is not None and torch.is_grad_enabled() and x.dim() == 2 and x.dtype == torch.float32
                 and (x.is_cuda or _LIB.go2sim_is_device_library() == 0))
+        if fuse and _NN is not None and (x.is_cuda or _NN.go2nn_is_device_library() == 0) and _MLP_NODE:
+            lins = _whole_mlp(mods)
+            if lins is not None:
+                return _FusedMLP.apply(x if x.is_contiguous() else x.contiguous(), *[t for m in lins for t in (m.weight, m.bias)])
         i = 0
         while i < len(mods):
             m = mods[i]
-            if (fuse and isinstance(m, nn.Linear) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ELU) and mods[i + 1].alpha == 1.0
+            if (fuse and _NN is not None and i + 3 == len(mods) and _is_tail(mods[i], mods[i + 1], mods[i + 2]) and (x.is_cuda or _NN.go2nn_is_device_library() == 0)):
+                x = _LinearELUHead.apply(x if x.is_contiguous() else x.contiguous(), m.weight, m.bias, mods[i + 2].weight, mods[i + 2].bias)
+                i += 3
+            elif (fuse and isinstance(m, nn.Linear) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ELU) and mods[i + 1].alpha == 1.0
                     and m.bias is not None and m.out_features % 4 == 0 and m.weight.requires_grad):
                 x = _LinearELU.apply(x if x.is_contiguous() else x.contiguous(), m.weight, m.bias)
                 i += 2

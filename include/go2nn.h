@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define GO2NN_ABI_VERSION 1
+#define GO2NN_ABI_VERSION 2      /* 2: + the learner-side kernels (go2nn_head_backward, go2nn_linear_*) */
 #define GO2NN_MAX_LAYERS 6
 #define GO2NN_MAX_WIDTH 512      /* widest layer input / output (LDS holds two 32-row activation tiles of this width) */
 #define GO2NN_EINVAL (-22)
@@ -53,6 +53,41 @@ int go2nn_mlp_forward(const Go2nnMlp* m, const float* packed, const float* x, fl
 int go2nn_policy_act(const Go2nnMlp* actor, const float* actor_packed, const Go2nnMlp* critic, const float* critic_packed,
                      const float* obs, const float* critic_obs, const float* std, const float* eps,
                      float* a_out, float* a_st, float* mu_st, float* sig_st, float* lp_st, float* v_st, int32_t N, void* stream);
+
+/* ---- learner side: PPO.update's backward pass (rsl_rl/rsl_rl/algorithms/ppo.py:120-187; autograd over modules/actor_critic.py:50-75) ----
+ *
+ * Backward of an MLP's tail  h -> Linear -> ELU(alpha=1) -> y [B,K] -> Linear(W [C,K], b [C]) -> out [B,C]  for a NARROW output (C <= 16: the
+ * 12-wide action mean, the 1-wide value), given gy = dLoss/d out [B,C], in one streaming pass over y:
+ *   gz [B,K]  = (gy W) * (y > 0 ? 1 : y + 1)      the gradient at the hidden layer's PRE-activation (torch: mm + elu_backward(is_result))
+ *   sums      = [ dW [C,K] = gy^T y | gb [K] = column sums of gz (the hidden Linear's bias gradient) | db [C] = column sums of gy ]
+ * i.e. what autograd computes with two GEMMs of degenerate shape, a split-K fix-up, two column-sum reductions and an element-wise pass.
+ * Sums are formed in a fixed order (per-workgroup partials, then a fixed tree): bit-reproducible from run to run.
+ * K a multiple of 4, K <= GO2NN_MAX_WIDTH.  workspace: go2nn_head_backward_workspace(B, C, K) floats (negative: unsupported shape). */
+/* Second stage of the fixed-order reductions: out[c] = sum_r part[r][c] (part [nrows, ncols] row-major) for up to 16 jobs in ONE launch.
+ * go2nn_head_backward (sums == NULL) and go2nn_linear_backward_input (gb_prev == NULL) then leave their per-workgroup partial rows in `workspace` —
+ * go2nn_*_rows rows of (C + 1) K + C resp. Kin columns — and the caller finishes all of a backward pass's reductions (and the row splits of its
+ * weight gradients) with one go2nn_sum_rows call, off the chain of dependent GEMMs. */
+typedef struct Go2nnSumJob { const float* part; float* out; int32_t nrows, ncols; } Go2nnSumJob;
+int go2nn_sum_rows(const Go2nnSumJob* jobs, int32_t njobs, void* stream);
+int32_t go2nn_head_backward_rows(int32_t B, int32_t C, int32_t K);
+int32_t go2nn_linear_backward_input_rows(int32_t M, int32_t C, int32_t Kin);
+int64_t go2nn_head_backward_workspace(int32_t B, int32_t C, int32_t K);
+int go2nn_head_backward(const float* gy, const float* y, const float* w, float* gz, float* sums, float* workspace, int32_t B, int32_t C, int32_t K, void* stream);
+
+/* The hidden layers  y = elu(x W^T + b)  of the same MLPs, forward and backward, as fp32-MFMA GEMMs whose epilogues do the element-wise work that
+ * follows a vendor GEMM as separate passes over the [M, N] activations (torch: addmm + elu_; mm + elu_backward + sum(0); a row-split bmm + sum(0)).
+ * x [M,K], W [N,K] (torch.nn.Linear layout), b [N], y [M,N]; all row-major and dense.  Any M, N, K >= 1 (ragged edges are masked; 16-byte loads
+ * are used when a row length is a multiple of 4).  ELU through the hardware exponential as in go2nn_policy_act. */
+int go2nn_linear_elu_forward(const float* x, const float* w, const float* b, float* y, int32_t M, int32_t K, int32_t N, void* stream);
+/* Backward of a layer with C outputs and Kin inputs, given gz [M,C] = the gradient at ITS pre-activation:
+ *   go2nn_linear_backward_input:  gz_prev [M,Kin] = (gz W) * (y_prev > 0 ? 1 : y_prev + 1)   where y_prev [M,Kin] = the layer's input = the previous
+ *                                 layer's ELU output; gb_prev [Kin] = column sums of gz_prev (the previous layer's bias gradient)
+ *   go2nn_linear_backward_weight: dw [C,Kin] = gz^T x                                          (x [M,Kin] = the layer's input)
+ * both with fixed-order sums (bit-reproducible).  workspace: go2nn_linear_backward_workspace(M, C, Kin) floats serve either call. */
+int64_t go2nn_linear_backward_workspace(int32_t M, int32_t C, int32_t Kin);
+int go2nn_linear_backward_input(const float* gz, const float* w, const float* y_prev, float* gz_prev, float* gb_prev, float* workspace,
+                                int32_t M, int32_t C, int32_t Kin, void* stream);
+int go2nn_linear_backward_weight(const float* gz, const float* x, float* dw, float* workspace, int32_t M, int32_t C, int32_t Kin, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,54 @@
+"""go2nn_head_backward (HIP, go2_rl_gym_amd/csrc/go2nn_train.h) on a real MI355X against float64 torch ops, and the fused MLP tail of
+modules/fused.py against plain autograd at the real mini-batch shape.  Run with -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import load_hip  # noqa: E402
+from go2_rl_gym_amd import _nn  # noqa: E402
+from test_mlp_tail import check_head_backward, tail_vs_autograd  # noqa: E402
+
+
+@pytest.mark.parametrize("B,Cn,K", [(1, 1, 4), (37, 12, 128), (24576, 12, 128), (24576, 1, 128), (4099, 3, 260), (1000, 16, 512), (98304, 12, 128), (257, 8, 64), (6144, 12, 128)])
+def test_head_backward_on_gpu(B, Cn, K):
+    """ragged row counts (not a multiple of the workgroup's rows / of the unroll), every template width, K not a power of two; and the sums are
+    bit-reproducible from launch to launch (fixed-order reduction, no atomics)."""
+    lib = _nn.load_nn()
+    a = check_head_backward(lib, B, Cn, K, device="cuda:0")
+    b = check_head_backward(lib, B, Cn, K, device="cuda:0")
+    torch.cuda.synchronize()
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("dims", [(45, 512, 256, 128, 12), (263, 512, 256, 128, 1)])
+@pytest.mark.parametrize("node,own", [(False, "auto"), (True, "auto"), (True, "all"), (True, "none")])
+def test_fused_tail_on_gpu(dims, node, own):
+    tail_vs_autograd(_nn.load_nn(), load_hip(), "cuda:0", B=24576, dims=dims, atol=2e-6, node=node, own=own)
+
+
+from test_mlp_tail import check_linear  # noqa: E402
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 1, 1), (65, 8, 33), (70, 37, 70), (1000, 45, 512), (24576, 45, 512), (24576, 263, 512), (24576, 512, 256), (24576, 256, 128),
+                                   (4099, 260, 132), (6144, 512, 256), (300, 100, 300), (8192, 128, 64)])
+def test_linear_layer_on_gpu(M, K, N):
+    """every tile shape (128x128, 64x128, 64x64), 16-byte and 4-byte load paths (K = 45 / 263 / 37), ragged edges in M, N and K, split and unsplit
+    weight gradients; bit-reproducible from launch to launch"""
+    lib = _nn.load_nn()
+    a = check_linear(lib, M, K, N, device="cuda:0")
+    b = check_linear(lib, M, K, N, device="cuda:0")
+    torch.cuda.synchronize()
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
+def test_sum_rows_on_gpu():
+    from test_mlp_tail import check_sum_rows
+    lib = _nn.load_nn()
+    a = check_sum_rows(lib, "cuda:0"); b = check_sum_rows(lib, "cuda:0")
+    torch.cuda.synchronize()
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)

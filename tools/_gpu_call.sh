@@ -1,10 +1,18 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r3final; mkdir -p $O
-( time timeout 400 python bench.py > $O/bench.json 2> $O/bench.err ) 2> $O/bench_time.txt; cat $O/bench_time.txt | tail -3
-timeout 120 python tools/termination_check.py "round-2 model (two contact slots per leg, commit 2c3c234)" build/variants/r2model_1wave.so > $O/termination_check_r2model.txt 2>&1
-tail -3 $O/termination_check_r2model.txt; python - <<'PY'
+O=gpurun_out/r3m12; mkdir -p $O
+run() { n=$1; shift
+  env "$@" timeout 200 python bench.py --steps 40 --warmup 20 --no-cpu-baseline > $O/bench_$n.json 2> $O/bench_$n.err
+  python - <<PY
 import json
-for l in open('gpurun_out/r3final/bench.json'):
+for l in open('$O/bench_$n.json'):
     if l.startswith('{'):
-        d=json.loads(l); print(d['value'], d['ms_per_step'], d['collection_only'], d['roofline']['kernel_ms'], d['roofline']['traffic'], d['cpu_baseline']['value'], d['cpu_baseline']['cores'], d['cpu_baseline'].get('thread_sweep_at_4096'))
+        d=json.loads(l); print('$n', round(d['value']/1e6,3), round(d['ms_per_step'],2), round(d['roofline']['kernel_ms']*1e3,1))
 PY
+}
+for rep in a b; do
+run head0$rep GO2_FUSED_HEAD=0
+run inone$rep GO2_MLP_OWN_I=none
+run auto$rep A=1
+run fnone_inone$rep GO2_MLP_OWN_I=none GO2_MLP_OWN_F=none
+run i256$rep GO2_MLP_OWN_I=k256
+done
