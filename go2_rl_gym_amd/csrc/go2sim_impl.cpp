@@ -526,23 +526,50 @@ __global__ void go2_normalize_kernel(float* adv, const double* partials, int cou
 // Block b works on one GO2_ADAM_CHUNK-element chunk of one tensor (chunks of tensor i: first[i] .. first[i+1]).
 struct Go2AdamLaunch { Go2AdamTensors t; int32_t first[GO2_ADAM_MAX_TENSORS + 1]; };
 __device__ __forceinline__ int adam_locate(const Go2AdamLaunch& a, int b) { int i = 0; while (i + 1 < a.t.count && b >= a.first[i + 1]) ++i; return i; }
-// stage 1: per-chunk sum of squared gradients -> ws[block]; block 0 also takes the learning-rate decision (ppo.py:140-155)
-__global__ void __launch_bounds__(256) go2_adam_norm_kernel(const Go2AdamLaunch a, float* __restrict__ ws, float* lr, const float* kl_mean, float desired_kl) {
-  __shared__ float sh[4];
-  const int i = adam_locate(a, blockIdx.x), off = (blockIdx.x - a.first[i]) * GO2_ADAM_CHUNK, n = min(GO2_ADAM_CHUNK, a.t.numel[i] - off);
-  const float* g = a.t.grad[i] + off;
-  float s = 0.f;
-  for (int k = threadIdx.x; k < n; k += 256) { const float x = g[k]; s += x * x; }
+// A chunk is 1024 quads: a thread owns quads tid, tid + 256, ... and has all of its 16-byte loads in flight before the first use (these launches
+// sit on the critical path of every mini-batch, between the backward and the next forward pass: latency, not bandwidth, is what they cost).
+// Tensors whose four arrays are not 16-byte aligned, and a chunk's last n % 4 elements, go element by element.
+__device__ __forceinline__ bool adam_vec(const Go2AdamLaunch& a, int i) {
+  return ((((uintptr_t)a.t.param[i]) | ((uintptr_t)a.t.grad[i]) | ((uintptr_t)a.t.exp_avg[i]) | ((uintptr_t)a.t.exp_avg_sq[i])) & 15) == 0;
+}
+__device__ __forceinline__ float adam_block_sum(float s, float* sh) {
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
   __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+// stage 1: per-chunk sum of squared gradients -> ws[block]; block 0 also takes the learning-rate decision (ppo.py:140-155) and advances the
+// tensors' step counters (stage 2 reads the advanced value: t = step, as torch.optim.Adam increments before it forms the bias corrections)
+__global__ void __launch_bounds__(256) go2_adam_norm_kernel(const Go2AdamLaunch a, float* __restrict__ ws, float* lr, const float* kl_mean, float desired_kl) {
+  __shared__ float sh[4];
+  const int i = adam_locate(a, blockIdx.x), off = (blockIdx.x - a.first[i]) * GO2_ADAM_CHUNK, n = min(GO2_ADAM_CHUNK, a.t.numel[i] - off);
+  const float* __restrict__ g = a.t.grad[i] + off;
+  float s = 0.f;
+  if (adam_vec(a, i)) {
+    const int nq = n >> 2;
+    float4 x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x[u] = reinterpret_cast<const float4*>(g)[min((int)threadIdx.x + 256 * u, max(nq - 1, 0))];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if ((int)threadIdx.x + 256 * u < nq) s += (x[u].x * x[u].x + x[u].y * x[u].y) + (x[u].z * x[u].z + x[u].w * x[u].w);
+    if ((int)threadIdx.x < (n & 3)) { const float y = g[4 * nq + threadIdx.x]; s += y * y; }
+  } else {
+    for (int k = threadIdx.x; k < n; k += 256) { const float y = g[k]; s += y * y; }
+  }
+  s = adam_block_sum(s, sh);
   if (threadIdx.x == 0) {
-    ws[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    ws[blockIdx.x] = s;
     if (blockIdx.x == 0 && kl_mean) {
       const float kl = *kl_mean, r = *lr;
       *lr = kl > desired_kl * 2.f ? fmaxf(1e-5f, r / 1.5f) : ((kl < desired_kl / 2.f && kl > 0.f) ? fminf(1e-2f, r * 1.5f) : r);
     }
   }
+  if (blockIdx.x == 0 && (int)threadIdx.x < a.t.count) a.t.step[threadIdx.x][0] += 1.f;
+}
+__device__ __forceinline__ void adam_one(float& p, float& m, float& v, float g, float coef, float omb1, float beta2, float omb2, float step_size, float bc2s, float eps) {
+  const float gk = g * coef;
+  m = m + (gk - m) * omb1; v = beta2 * v + omb2 * gk * gk;
+  p -= step_size * m / (sqrtf(v) / bc2s + eps);
 }
 // stage 2: every block re-reduces the chunk sums in the same fixed order (-> the same norm everywhere), then steps its chunk
 __global__ void __launch_bounds__(256) go2_adam_step_kernel(const Go2AdamLaunch a, const float* __restrict__ ws, const float* __restrict__ lr, float max_norm,
@@ -550,77 +577,113 @@ __global__ void __launch_bounds__(256) go2_adam_step_kernel(const Go2AdamLaunch 
   const float beta2 = (float)beta2d, omb1 = (float)(1.0 - beta1d), omb2 = (float)(1.0 - beta2d);
   __shared__ float sh[4];
   const int nb = a.first[a.t.count];
+  const int i = adam_locate(a, blockIdx.x), off = (blockIdx.x - a.first[i]) * GO2_ADAM_CHUNK, n = min(GO2_ADAM_CHUNK, a.t.numel[i] - off);
+  float* __restrict__ p = a.t.param[i] + off; float* __restrict__ m = a.t.exp_avg[i] + off; float* __restrict__ v = a.t.exp_avg_sq[i] + off; const float* __restrict__ g = a.t.grad[i] + off;
+  const bool vec = adam_vec(a, i);
+  const int nq = n >> 2;
+  float4 g4[4], m4[4], v4[4], p4[4];
+  if (vec) {        // the chunk's loads go out before the norm is re-reduced: they do not depend on it
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = min((int)threadIdx.x + 256 * u, max(nq - 1, 0));
+      g4[u] = reinterpret_cast<const float4*>(g)[q]; m4[u] = reinterpret_cast<const float4*>(m)[q]; v4[u] = reinterpret_cast<const float4*>(v)[q]; p4[u] = reinterpret_cast<const float4*>(p)[q];
+    }
+  }
   float s = 0.f;
   for (int k = threadIdx.x; k < nb; k += 256) s += ws[k];
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-  __syncthreads();
-  const float norm = sqrtf((sh[0] + sh[1]) + (sh[2] + sh[3]));
+  const float norm = sqrtf(adam_block_sum(s, sh));
   const float coef = fminf(max_norm / (norm + 1e-6f), 1.f);
-  const int i = adam_locate(a, blockIdx.x), off = (blockIdx.x - a.first[i]) * GO2_ADAM_CHUNK, n = min(GO2_ADAM_CHUNK, a.t.numel[i] - off);
-  const float t = a.t.step[i][0] + 1.f;                 // this tensor's own step count, as torch.optim.Adam keeps it (advanced by go2_adam_count_kernel afterwards)
+  const float t = a.t.step[i][0];                       // this tensor's own step count, as torch.optim.Adam keeps it (advanced by stage 1)
   // the bias corrections in fp64, as torch forms them: 1 - 0.999^t cancels to ~1e-3 in the first steps
   const float bc1 = (float)(1.0 - pow(beta1d, (double)t)), bc2s = (float)sqrt(1.0 - pow(beta2d, (double)t)), step_size = lr[0] / bc1;
-  float* p = a.t.param[i] + off; float* m = a.t.exp_avg[i] + off; float* v = a.t.exp_avg_sq[i] + off; const float* g = a.t.grad[i] + off;
-  for (int k = threadIdx.x; k < n; k += 256) {
-    const float gk = g[k] * coef;
-    const float mk = m[k] + (gk - m[k]) * omb1, vk = beta2 * v[k] + omb2 * gk * gk;
-    m[k] = mk; v[k] = vk;
-    p[k] -= step_size * mk / (sqrtf(vk) / bc2s + eps);
+  if (vec) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = threadIdx.x + 256 * u;
+      if (q < nq) {
+        adam_one(p4[u].x, m4[u].x, v4[u].x, g4[u].x, coef, omb1, beta2, omb2, step_size, bc2s, eps); adam_one(p4[u].y, m4[u].y, v4[u].y, g4[u].y, coef, omb1, beta2, omb2, step_size, bc2s, eps);
+        adam_one(p4[u].z, m4[u].z, v4[u].z, g4[u].z, coef, omb1, beta2, omb2, step_size, bc2s, eps); adam_one(p4[u].w, m4[u].w, v4[u].w, g4[u].w, coef, omb1, beta2, omb2, step_size, bc2s, eps);
+        reinterpret_cast<float4*>(m)[q] = m4[u]; reinterpret_cast<float4*>(v)[q] = v4[u]; reinterpret_cast<float4*>(p)[q] = p4[u];
+      }
+    }
+    const int k = 4 * nq + threadIdx.x;
+    if ((int)threadIdx.x < (n & 3)) adam_one(p[k], m[k], v[k], g[k], coef, omb1, beta2, omb2, step_size, bc2s, eps);
+  } else {
+    for (int k = threadIdx.x; k < n; k += 256) adam_one(p[k], m[k], v[k], g[k], coef, omb1, beta2, omb2, step_size, bc2s, eps);
   }
 }
-// the step counters advance in their own tiny launch: stage 2's blocks all read step[0] while they run
-__global__ void go2_adam_count_kernel(const Go2AdamLaunch a) { const int i = threadIdx.x; if (i < a.t.count) a.t.step[i][0] += 1.f; }
 
-// ---- fused PPO loss head (ppo.py:131-170): one lane per sample, A <= 16 actions in registers ------------------------------
+// ---- fused PPO loss head (ppo.py:131-170).  One 16-lane group per sample row, one lane per action dimension (A <= 16): the per-action terms of
+// the log-probability, the entropy and the KL divergence are formed side by side and summed over the row by an xor tree, instead of a 12-long
+// dependent chain per thread — this launch sits between the forward and the backward pass of every mini-batch, its latency is what it costs.
+// A block of 256 threads takes PPO_ROWS rows (4 per group, all their loads issued before the first use). ----------------------------------------
 #define PPO_NSTAT 24   // per-block partials: [0..3] surrogate, value loss, kl, entropy ; [4..4+A) grad_std
+#define PPO_ROWS 64
+__device__ __forceinline__ float row16_sum(float x) {
+  x += __shfl_xor(x, 8, 16); x += __shfl_xor(x, 4, 16); x += __shfl_xor(x, 2, 16); x += __shfl_xor(x, 1, 16);
+  return x;
+}
 __global__ void __launch_bounds__(256) go2_ppo_loss_kernel(const float* __restrict__ mu, const float* __restrict__ std_, const float* __restrict__ value,
     const float* __restrict__ actions, const float* __restrict__ old_mu, const float* __restrict__ old_sigma, const float* __restrict__ old_logp,
     const float* __restrict__ adv, const float* __restrict__ tv, const float* __restrict__ ret, float* __restrict__ gmu, float* __restrict__ gval,
     float* __restrict__ part, int B, int A, float clip, float vcoef, int use_clip_v, int split, float w_head, float w_tail) {
-  __shared__ float sh[4][PPO_NSTAT];
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  float acc[PPO_NSTAT];
+  __shared__ float sh[16][PPO_NSTAT];
+  constexpr int U = PPO_ROWS / 16;
+  const int j = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const bool on = j < A;
+  const int jc = on ? j : 0;
+  const float LOG2PI = 1.8378770664093453f;
+  const float sg = std_[jc], ls = logf(sg), isg2 = 1.f / (sg * sg);
+  float a_[U], m_[U], so_[U], mo_[U], olp[U], ad[U], vv[U], tvv[U], rt[U];
+  int row[U];
 #pragma unroll
-  for (int k = 0; k < PPO_NSTAT; ++k) acc[k] = 0.f;
-  if (i < B) {
-    const float LOG2PI = 1.8378770664093453f;
-    float lp = 0.f, kl = 0.f, ent = 0.f;
-    for (int j = 0; j < A; ++j) {
-      float sg = std_[j], d = actions[(size_t)i * A + j] - mu[(size_t)i * A + j], ls = logf(sg);
-      lp += -d * d / (2.f * sg * sg) - ls - 0.5f * LOG2PI;
-      ent += 0.5f + 0.5f * LOG2PI + ls;
-      float so = old_sigma[(size_t)i * A + j], dm = old_mu[(size_t)i * A + j] - mu[(size_t)i * A + j];
-      kl += logf(sg / so + 1e-5f) + (so * so + dm * dm) / (2.f * sg * sg) - 0.5f;
-    }
-    float ratio = expf(lp - old_logp[i]), a = adv[i];
-    float lo = 1.f - clip, hi = 1.f + clip, rc = fminf(fmaxf(ratio, lo), hi); float in = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
-    float s1 = -a * ratio, s2 = -a * rc, sur = fmaxf(s1, s2);
-    float w = s1 > s2 ? 1.f : (s1 < s2 ? in : 0.5f + 0.5f * in);     // torch.max splits ties evenly; clamp passes gradient inside [lo, hi]
+  for (int u = 0; u < U; ++u) {
+    row[u] = blockIdx.x * PPO_ROWS + grp * U + u;
+    const int r = min(row[u], B - 1); const size_t k = (size_t)r * A + jc;
+    a_[u] = actions[k]; m_[u] = mu[k]; so_[u] = old_sigma[k]; mo_[u] = old_mu[k];
+    olp[u] = old_logp[r]; ad[u] = adv[r]; vv[u] = value[r]; tvv[u] = tv[r]; rt[u] = ret[r];
+  }
+  float s_sur = 0.f, s_vl = 0.f, s_kl = 0.f, s_ent = 0.f, s_gs = 0.f;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const float d = a_[u] - m_[u], dm = mo_[u] - m_[u];
+    const float lp = row16_sum(on ? -d * d * (0.5f * isg2) - ls - 0.5f * LOG2PI : 0.f);
+    const float ent = row16_sum(on ? 0.5f + 0.5f * LOG2PI + ls : 0.f);
+    const float kl = row16_sum(on ? logf(sg / so_[u] + 1e-5f) + (so_[u] * so_[u] + dm * dm) * (0.5f * isg2) - 0.5f : 0.f);
+    const int i = row[u];
+    const float ratio = expf(lp - olp[u]), a = ad[u];
+    const float lo = 1.f - clip, hi = 1.f + clip, rc = fminf(fmaxf(ratio, lo), hi), in = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
+    const float s1 = -a * ratio, s2 = -a * rc, sur = fmaxf(s1, s2);
+    const float w = s1 > s2 ? 1.f : (s1 < s2 ? in : 0.5f + 0.5f * in);     // torch.max splits ties evenly; clamp passes gradient inside [lo, hi]
     const float wr = i < split ? w_head : w_tail;     // plain PPO: 1/B for every row; CTS: 1/teacher rows, 1/student rows
-    float g_lp = -a * w * ratio * wr;
-    float v = value[i], dv = v - tv[i], vl, gv;
+    const float g_lp = -a * w * ratio * wr;
+    const float v = vv[u], dv = v - tvv[u];
+    float vl, gv;
     if (use_clip_v) {
-      float dc = fminf(fmaxf(dv, -clip), clip), vin = (dv >= -clip && dv <= clip) ? 1.f : 0.f, vc = tv[i] + dc;
-      float l1 = (v - ret[i]) * (v - ret[i]), l2 = (vc - ret[i]) * (vc - ret[i]); vl = fmaxf(l1, l2);
-      float g1 = 2.f * (v - ret[i]), g2 = 2.f * (vc - ret[i]) * vin; gv = l1 > l2 ? g1 : (l1 < l2 ? g2 : 0.5f * g1 + 0.5f * g2);
-    } else { vl = (ret[i] - v) * (ret[i] - v); gv = 2.f * (v - ret[i]); }
-    gval[i] = vcoef * gv / (float)B;
-    for (int j = 0; j < A; ++j) {
-      float sg = std_[j], d = actions[(size_t)i * A + j] - mu[(size_t)i * A + j];
-      gmu[(size_t)i * A + j] = g_lp * d / (sg * sg);
-      if (j < PPO_NSTAT - 4) acc[4 + j] = g_lp * (d * d / (sg * sg * sg) - 1.f / sg);
+      const float dc = fminf(fmaxf(dv, -clip), clip), vin = (dv >= -clip && dv <= clip) ? 1.f : 0.f, vc = tvv[u] + dc;
+      const float l1 = (v - rt[u]) * (v - rt[u]), l2 = (vc - rt[u]) * (vc - rt[u]); vl = fmaxf(l1, l2);
+      const float g1 = 2.f * (v - rt[u]), g2 = 2.f * (vc - rt[u]) * vin; gv = l1 > l2 ? g1 : (l1 < l2 ? g2 : 0.5f * g1 + 0.5f * g2);
+    } else { vl = (rt[u] - v) * (rt[u] - v); gv = 2.f * (v - rt[u]); }
+    if (i < B) {
+      if (j == 0) gval[i] = vcoef * gv / (float)B;
+      if (on) { gmu[(size_t)i * A + j] = g_lp * d * isg2; s_gs += g_lp * (d * d * isg2 / sg - 1.f / sg); }
+      s_sur += sur * wr; s_vl += vl; s_kl += kl; s_ent += ent;
     }
-    acc[0] = sur * wr; acc[1] = vl; acc[2] = kl; acc[3] = ent;
   }
-#pragma unroll
-  for (int k = 0; k < PPO_NSTAT; ++k) {
-    float x = acc[k];
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = x;
-  }
+  // the block's 16 groups, added in a fixed order
+  if (j == 0) { sh[grp][0] = s_sur; sh[grp][1] = s_vl; sh[grp][2] = s_kl; sh[grp][3] = s_ent; }
+  if (j < PPO_NSTAT - 4) sh[grp][4 + j] = on ? s_gs : 0.f;
   __syncthreads();
-  if (threadIdx.x < PPO_NSTAT) part[(size_t)blockIdx.x * PPO_NSTAT + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+  if (threadIdx.x < PPO_NSTAT) {
+    float t[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t[g] = sh[g][threadIdx.x];
+#pragma unroll
+    for (int wd = 8; wd >= 1; wd >>= 1)
+#pragma unroll
+      for (int g = 0; g < wd; ++g) t[g] += t[g + wd];
+    part[(size_t)blockIdx.x * PPO_NSTAT + threadIdx.x] = t[0];
+  }
 }
 __global__ void go2_ppo_loss_finish_kernel(const float* __restrict__ part, const float* __restrict__ std_, float* __restrict__ gstd, float* __restrict__ stats,
                                            int nblocks, int B, int A, float vcoef, float ecoef) {
@@ -1380,8 +1443,8 @@ int go2sim_ppo_loss(const float* mu, const float* std_, const float* value, cons
   if (split < 0 || split >= B) split = 0;
   const float w_head = split ? 1.f / (float)split : 1.f / (float)B, w_tail = split ? 1.f / (float)(B - split) : 1.f / (float)B;
   if (!split) split = B;
-  if (!mu || !std_ || !value || !actions || !old_mu || !old_sigma || !old_logp || !adv || !tv || !ret || !gmu || !gstd || !gval || !stats || !workspace || B <= 0 || A <= 0 || A > 20)
-    FAIL(GO2SIM_EINVAL, "bad argument");
+  if (!mu || !std_ || !value || !actions || !old_mu || !old_sigma || !old_logp || !adv || !tv || !ret || !gmu || !gstd || !gval || !stats || !workspace || B <= 0 || A <= 0 || A > 16)
+    FAIL(GO2SIM_EINVAL, "bad argument (1 <= A <= 16)");
 #ifdef GO2_EMU
   (void)stream; (void)workspace;
   double s_sur = 0, s_vl = 0, s_kl = 0, s_ent = 0; double gs[20]; for (int j = 0; j < A; ++j) gs[j] = 0;
@@ -1404,7 +1467,7 @@ int go2sim_ppo_loss(const float* mu, const float* std_, const float* value, cons
   for (int j = 0; j < A; ++j) gstd[j] = (float)(gs[j] - ecoef / std_[j]);
   stats[0] = (float)s_sur; stats[1] = (float)(s_vl / B); stats[2] = (float)(s_kl / B); stats[3] = (float)(s_ent / B); stats[4] = stats[0] + vcoef * stats[1] - ecoef * stats[3];
 #else
-  int nb = (B + 255) / 256;
+  int nb = (B + PPO_ROWS - 1) / PPO_ROWS;
   hipLaunchKernelGGL(go2_ppo_loss_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, mu, std_, value, actions, old_mu, old_sigma, old_logp, adv, tv, ret, gmu, gval, workspace, B, A, clip, vcoef, use_clip_v, split, w_head, w_tail);
   hipLaunchKernelGGL(go2_ppo_loss_finish_kernel, dim3(1), dim3(8 * PPO_NSTAT), 0, (hipStream_t)stream, workspace, std_, gstd, stats, nb, B, A, vcoef, ecoef);
   HIPCHK(hipGetLastError());
@@ -1462,7 +1525,6 @@ int go2sim_adam_clip_step(const Go2AdamTensors* t, float* lr, const float* kl_me
   const int nb = a.first[t->count];
   hipLaunchKernelGGL(go2_adam_norm_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, workspace, lr, kl_mean, desired_kl);
   hipLaunchKernelGGL(go2_adam_step_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, workspace, lr, max_grad_norm, beta1_, beta2_, eps);
-  hipLaunchKernelGGL(go2_adam_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

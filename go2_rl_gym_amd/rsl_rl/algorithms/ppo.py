@@ -151,7 +151,7 @@ class _FusedPPOLoss(torch.autograd.Function):
         args = [mu_c, std_c, val_c, c(act_b), c(old_mu_b), c(old_sig_b), c(old_lp_b).view(-1), c(adv_b).view(-1), c(tv_b).view(-1), c(ret_b).view(-1)]
         gmu, gstd, gval = torch.empty_like(mu_c), torch.empty_like(std_c), torch.empty_like(val_c)
         stats = torch.empty(5, device=mu.device)
-        ws = torch.empty(24 * ((B + 255) // 256), device=mu.device)
+        ws = torch.empty(24 * ((B + 63) // 64), device=mu.device)       # (go2sim.h: 24 floats per block of 64 rows)
         lib = alg.lib
         stream = C.c_void_p(torch.cuda.current_stream(mu.device).cuda_stream) if mu.is_cuda else None
         p = lambda t: C.c_void_p(t.data_ptr())
@@ -388,8 +388,12 @@ class PPO(_RolloutHeads):
             mu_b, val_b = self._pair(lambda: ac.actor(batch[0]), lambda: ac.evaluate(batch[1]), enabled=self._capture)
             stats, gmu, gstd, gval = _FusedPPOLoss.kernel(self, mu_b, ac.std, val_b, *batch[2:])
             self.optimizer.zero_grad(set_to_none=True)
-            torch.autograd.backward([mu_b, ac.std, val_b], [gmu, gstd.view_as(ac.std), gval])
-            self._acc.add_(stats[:2])             # [surrogate, value loss]; read back swapped in _update_graphs
+            self._acc.add_(stats[:2])             # [surrogate, value loss]; read back swapped in _update_graphs (issued before the backward pass: off its tail)
+            if ac.std.requires_grad and ac.std.grad_fn is None:
+                ac.std.grad = gstd.view_as(ac.std)             # a leaf: the kernel's gradient IS its .grad (autograd would copy it there with one more launch)
+                torch.autograd.backward([mu_b, val_b], [gmu, gval])
+            else:
+                torch.autograd.backward([mu_b, ac.std, val_b], [gmu, gstd.view_as(ac.std), gval])
             kl_mean = stats[2]
         else:
             loss, value_loss, surrogate_loss, kl_mean = self._losses(*batch)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GO2SIM_ABI_VERSION 5   /* 5: Go2SimCfg gained control_type / cmd_tracking_curriculum / cmd_max_curriculum, go2sim_reset_idx, episode_info is GO2_EPISODE_INFO_LEN long;  4: Go2SimCfg gained hf_cells / hf_walls (trimesh wall geometry); test hooks go2sim_debug_*;  3: 3: Go2SimCfg gained max_linear_velocity / max_angular_velocity; go2sim_elu_backward_bias workspace is C*ceil(B/64) */
+#define GO2SIM_ABI_VERSION 6   /* 6: go2sim_ppo_loss: workspace 24*ceil(B/64) floats (was B/256), A <= 16;  5: Go2SimCfg gained control_type / cmd_tracking_curriculum / cmd_max_curriculum, go2sim_reset_idx, episode_info is GO2_EPISODE_INFO_LEN long;  4: Go2SimCfg gained hf_cells / hf_walls (trimesh wall geometry); test hooks go2sim_debug_*;  3: 3: Go2SimCfg gained max_linear_velocity / max_angular_velocity; go2sim_elu_backward_bias workspace is C*ceil(B/64) */
 
 #define GO2SIM_EINVAL   (-1)  /* bad argument / config */
 #define GO2SIM_ENOMEM   (-2)
@@ -417,7 +417,7 @@ int  go2sim_normalize_advantages(float* advantages, const double* partials, int3
  * per-sample log-prob, ratio, clipped surrogate, clipped value loss, entropy, KL(old || new), and the ANALYTIC gradients
  * of   loss = mean(surrogate) + value_coef * mean(value_loss) - entropy_coef * mean(entropy)
  * w.r.t. mu [B,A], the state-independent std [A] and value [B] in one pass (what autograd spreads over ~150 launches).
- * stats[5] = {surrogate_loss, value_loss, kl_mean, entropy_mean, loss}.  workspace: >= 24*ceil(B/256) floats.
+ * stats[5] = {surrogate_loss, value_loss, kl_mean, entropy_mean, loss}.  workspace: >= 24*ceil(B/64) floats.  A <= 16.
  * surrogate_split: 0 = plain PPO.  0 < split < B = the Concurrent-Teacher-Student surrogate (algorithms/cts.py:228-231):
  *   mean(surrogate[:split]) + mean(surrogate[split:]) — teacher rows first, student rows after; value loss / entropy / KL
  *   stay means over all B rows.

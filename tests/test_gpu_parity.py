@@ -226,7 +226,7 @@ def test_fused_ppo_loss_kernel_on_gpu(hip):
     res = {}
     for name, lib, dev in (("oracle", lo, "cpu"), ("hip", hip, "cuda:0")):
         t = [torch.as_tensor(np.ascontiguousarray(x), device=dev) for x in ins]
-        gmu, gstd, gval, stats, ws = (torch.zeros(B, A, device=dev), torch.zeros(A, device=dev), torch.zeros(B, device=dev), torch.zeros(5, device=dev), torch.zeros(24 * 96, device=dev))
+        gmu, gstd, gval, stats, ws = (torch.zeros(B, A, device=dev), torch.zeros(A, device=dev), torch.zeros(B, device=dev), torch.zeros(5, device=dev), torch.zeros(24 * ((B + 63) // 64), device=dev))
         p = lambda x: C.c_void_p(x.data_ptr())
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream) if dev != "cpu" else None
         assert lib.go2sim_ppo_loss(*[p(x) for x in t], p(gmu), p(gstd), p(gval), p(stats), p(ws), B, A, 0.2, 1.0, 0.01, 1, 0, st) == 0
@@ -292,7 +292,7 @@ def test_cts_kernels_on_gpu(hip):
     res = {}
     for name, lib, dev in (("oracle", load_oracle(), "cpu"), ("hip", hip, "cuda:0")):
         t = [torch.as_tensor(np.ascontiguousarray(x), device=dev) for x in ins]
-        gmu, gstd, gval, stats, ws = (torch.zeros(B, A, device=dev), torch.zeros(A, device=dev), torch.zeros(B, device=dev), torch.zeros(5, device=dev), torch.zeros(24 * 96, device=dev))
+        gmu, gstd, gval, stats, ws = (torch.zeros(B, A, device=dev), torch.zeros(A, device=dev), torch.zeros(B, device=dev), torch.zeros(5, device=dev), torch.zeros(24 * ((B + 63) // 64), device=dev))
         p = lambda x: C.c_void_p(x.data_ptr())
         assert lib.go2sim_ppo_loss(*[p(x) for x in t], p(gmu), p(gstd), p(gval), p(stats), p(ws), B, A, 0.2, 1.0, 0.01, 1, split, st if dev != "cpu" else None) == 0
         if dev != "cpu":
