@@ -45,15 +45,17 @@ __device__ __forceinline__ float4 gm_masked(const float4 v, unsigned m) {
   return make_float4(gm_keep(v.x, m & 1), gm_keep(v.y, m & 2), gm_keep(v.z, m & 4), gm_keep(v.w, m & 8));
 }
 
-// One operand's staging state of a thread: global -> registers -> LDS for k-tiles of 32.
+// One operand's staging state of a thread: global -> registers -> LDS for k-tiles of BK = 32 or 16 (described for 32).
 //   k-contiguous operand (KC): R rows x 32 k; thread = (k quad kq = tid & 7, rows tid >> 3 + 32 p).  LDS tile [R][32] with the quad index XOR-ed
-//     by (row >> 1) & 7: 16 consecutive rows at one k quad — what a ds_read_b128 serves per cycle — fall on 16 distinct bank quads, and so do
+//     by (row >> 1) & 7 (BK = 16: four quads per row, XOR-ed by (row >> 2) & 3): 16 consecutive rows at one k quad — what a ds_read_b128 serves per cycle — fall on 16 distinct bank quads, and so do
 //     the 2 rows x 8 quads that 16 consecutive threads write (no padding: the 64 x 128 tile's two stages are 48 KB, three workgroups per CU)
 //   k-strided operand:   32 k-rows x R columns; thread = (column quad tid % (R/4), k-rows tid / (R/4) + (1024/R) p).  LDS tile [32][R + 8].
 // Loads are branch-free: clamped (valid) addresses, zeroed by a select on the way to LDS — and only in workgroups that touch an edge.
-template <int R, bool KC, bool VEC>
+template <int R, bool KC, bool VEC, int BK>
 struct GmStage {
-  static constexpr int P = R / 32, QR = R / 4, KP = GM_THREADS / QR, LDS_FLOATS = KC ? R * GM_BK : GM_BK * (R + 8);
+  // k-contiguous: QK k-quads per row, RPP rows per pass of the 256 threads; k-strided: QR column quads per k-row, KP k-rows per pass
+  static constexpr int QK = BK / 4, RPP = GM_THREADS / QK, QR = R / 4, KP = GM_THREADS / QR, P = KC ? R / RPP : BK / KP, LDS_FLOATS = KC ? R * BK : BK * (R + 8);
+  static constexpr int SWS = BK == 32 ? 1 : 2;      // swizzle: quad ^= (row >> SWS) & (QK - 1)
   const float* base; int ld, kend; bool edge;
   const float* rowp[P];      // KC: the thread's (clamped) rows
   unsigned rowok;            // KC: bit p = row p in range;  k-strided: 4 column bits
@@ -63,7 +65,7 @@ struct GmStage {
     base = src; ld = ld_; kend = kend_; rowok = 0;
     if (KC) {
 #pragma unroll
-      for (int p = 0; p < P; ++p) { const int row = r0 + (tid >> 3) + 32 * p; rowp[p] = src + (size_t)gm_opaque(min(row, n - 1)) * ld_; rowok |= (unsigned)(row < n) << p; }
+      for (int p = 0; p < P; ++p) { const int row = r0 + tid / QK + RPP * p; rowp[p] = src + (size_t)gm_opaque(min(row, n - 1)) * ld_; rowok |= (unsigned)(row < n) << p; }
       edge = r0 + R > n;
     } else {
       const int col = r0 + 4 * (tid % QR);
@@ -79,7 +81,7 @@ struct GmStage {
   __device__ __forceinline__ void load_piece(int k0, int tid) {
     if (p == 0) okm = 0;
     if (KC) {
-      const int k = k0 + 4 * (tid & 7);
+      const int k = k0 + 4 * (tid % QK);
       if (VEC) {
         const int kc = gm_opaque(min(k, kend - 4));
         buf[p] = *reinterpret_cast<const float4*>(rowp[p] + kc); okm |= ((rowok >> p & 1) && k < kend ? 15u : 0u) << (4 * p);
@@ -101,13 +103,13 @@ struct GmStage {
     if constexpr (p < P) { load_piece<p>(k0, tid); load<p + 1>(k0, tid); }
   }
   __device__ __forceinline__ void store(float* __restrict__ lds, int k0, int tid) const {
-    const bool masked = edge || k0 + GM_BK > kend;          // workgroup-uniform
+    const bool masked = edge || k0 + BK > kend;          // workgroup-uniform
     if (KC) {
-      const int kq = tid & 7, r = tid >> 3;
+      const int kq = tid % QK, r = tid / QK;
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        const int row = r + 32 * p;
-        *reinterpret_cast<float4*>(lds + row * GM_BK + 4 * (kq ^ ((row >> 1) & 7))) = masked ? gm_masked(buf[p], okm >> (4 * p)) : buf[p];
+        const int row = r + RPP * p;
+        *reinterpret_cast<float4*>(lds + row * BK + 4 * (kq ^ ((row >> SWS) & (QK - 1)))) = masked ? gm_masked(buf[p], okm >> (4 * p)) : buf[p];
       }
     } else {
       const int rq = tid % QR, kk = tid / QR;
@@ -117,7 +119,7 @@ struct GmStage {
   }
   // the MFMA fragment of tile row `r` for k-block kb (8 inputs), lane half g: element e stands for input 8 kb + 4 g + e
   static __device__ __forceinline__ float4 frag(const float* __restrict__ lds, int r, int kb, int g) {
-    if (KC) return *reinterpret_cast<const float4*>(lds + r * GM_BK + 4 * ((2 * kb + g) ^ ((r >> 1) & 7)));
+    if (KC) return *reinterpret_cast<const float4*>(lds + r * BK + 4 * ((2 * kb + g) ^ ((r >> SWS) & (QK - 1))));
     const float* q = lds + (8 * kb + 4 * g) * (R + 8) + r;
     return make_float4(q[0], q[R + 8], q[2 * (R + 8)], q[3 * (R + 8)]);
   }
@@ -145,10 +147,11 @@ __device__ __forceinline__ void gm_issue(SA& sa, SB& sb, int k0, int tid) {
   }
 }
 
-template <int TM, int TN, bool AKC, bool BKC, int EPI, bool VEC>
-__global__ void __launch_bounds__(GM_THREADS) go2nn_gemm_kernel(const GemmArgs g) {
+template <int TM, int TN, bool AKC, bool BKC, int EPI, bool VEC, int BK>
+__global__ void __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(3))) go2nn_gemm_kernel(const GemmArgs g) {      // (>= 3 waves per SIMD: the 128 x 128 tile's
+                                                                                                                                        // 64 accumulators + staging would otherwise take 184 registers = 2 waves)
   constexpr int BM = 64 * TM, BN = 64 * TN;
-  using SA = GmStage<BM, AKC, VEC>; using SB = GmStage<BN, BKC, VEC>;
+  using SA = GmStage<BM, AKC, VEC, BK>; using SB = GmStage<BN, BKC, VEC, BK>;
   constexpr int ASZ = SA::LDS_FLOATS, BSZ = SB::LDS_FLOATS;
   __shared__ __attribute__((aligned(16))) float lds[2 * (ASZ + BSZ)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, gk = lane >> 5, wm = wave & 1, wn = wave >> 1;
@@ -161,7 +164,7 @@ __global__ void __launch_bounds__(GM_THREADS) go2nn_gemm_kernel(const GemmArgs g
   const int row0 = bm * BM, col0 = bn * BN;
   const int lrow0 = (g.debug & 2) ? 0 : row0, lcol0 = (g.debug & 2) ? 0 : col0;
   const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
-  const int nk = (kend - kbeg + GM_BK - 1) / GM_BK;
+  const int nk = (kend - kbeg + BK - 1) / BK;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -178,9 +181,9 @@ __global__ void __launch_bounds__(GM_THREADS) go2nn_gemm_kernel(const GemmArgs g
   if (nk > 0) { sa.load(kbeg, tid); sb.load(kbeg, tid); sa.store(lds, kbeg, tid); sb.store(lds + ASZ, kbeg, tid); }
   __syncthreads();
   GM_T(t1);
-  constexpr int NPIECE = SA::P + SB::P, NKB = GM_BK / 8;
+  constexpr int NKB = BK / 8;
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1, knext = kbeg + (kt + 1) * GM_BK;
+    const int cur = kt & 1, knext = kbeg + (kt + 1) * BK;
     const bool more = kt + 1 < nk;
     const float* As = lds + cur * (ASZ + BSZ); const float* Bs = As + ASZ;
     GM_T(tl0);
@@ -215,54 +218,56 @@ __global__ void __launch_bounds__(GM_THREADS) go2nn_gemm_kernel(const GemmArgs g
 
   // epilogue.  The accumulators leave in the MFMA's C/D layout (column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)): stored as they
   // are that is 16 dword stores per 32x32 tile, each two 128-byte row segments — store-issue-bound, and the input gradient's ELU' operand would come
-  // in by as many dword loads.  Instead every wave turns ITS 32 TM x 32 TN tile through its quarter of the (now free) LDS and works on rows: a lane
+  // in by as many dword loads.  Instead every wave turns its tile, 32 rows at a time, through its share of the (now free) LDS and works on rows: a lane
   // owns four consecutive columns, reads / writes 16 bytes at a time, 256-byte row segments per 16 lanes.  Column bit 5 is flipped by row bit 2
   // (the half-wave's rows): the two half-waves' dword writes fall on different bank halves without padding.
   {
-    constexpr int RT = 32 * TM, CT = 32 * TN, LPR = CT / 4, RPI = 64 / LPR, NI = RT / RPI;      // lanes per row, rows per instruction, instructions
-    float* wl = lds + wave * (RT * CT);
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-      for (int b = 0; b < TN; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * gk;
-          wl[row * CT + ((b * 32 + i) ^ (gk << 5 & (CT - 1)))] = acc[a][b][r];
-        }
+    constexpr int CT = 32 * TN, LPR = CT / 4, RPI = 64 / LPR, NI = 32 / RPI;      // lanes per row, rows per instruction, instructions per 32-row slab
+    float* wl = lds + wave * (32 * CT);                                            // one 32-row slab at a time: 4 x 32 x CT floats fit the k-loop's LDS of every shape
     float* __restrict__ Cz = g.C + (size_t)blockIdx.z * g.c_split_stride;
     const int lc = (lane % LPR) * 4, lr = lane / LPR;
-    const int col = col0 + wn * CT + lc, rbase = row0 + wm * RT + lr;
+    const int col = col0 + wn * CT + lc;
     const bool cv = g.c_vec != 0 && col + 3 < g.N;
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (EPI == EPI_BIAS_ELU) {
       const int c1 = min(col, g.N - 1), c2 = min(col + 1, g.N - 1), c3 = min(col + 2, g.N - 1), c4 = min(col + 3, g.N - 1);
       bias4 = make_float4(g.bias[c1], g.bias[c2], g.bias[c3], g.bias[c4]);
     }
-    float4 y4[NI];
-    if (EPI == EPI_DELU_COLSUM) {      // all of the lane's ELU outputs in flight together (clamped addresses; edge values are dropped below)
-#pragma unroll
-      for (int n = 0; n < NI; ++n) {
-        const float* q = g.Y + (size_t)min(rbase + n * RPI, g.M - 1) * g.ldc;
-        if (cv) y4[n] = *reinterpret_cast<const float4*>(q + col);
-        else y4[n] = make_float4(q[min(col, g.N - 1)], q[min(col + 1, g.N - 1)], q[min(col + 2, g.N - 1)], q[min(col + 3, g.N - 1)]);
-      }
-    }
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int n = 0; n < NI; ++n) {
-      const int lrow = lr + n * RPI, row = rbase + n * RPI;
-      float4 v = *reinterpret_cast<const float4*>(wl + lrow * CT + (lc ^ ((lrow >> 2 & 1) << 5 & (CT - 1))));
-      if (EPI == EPI_BIAS_ELU) v = make_float4(elu1(v.x + bias4.x), elu1(v.y + bias4.y), elu1(v.z + bias4.z), elu1(v.w + bias4.w));
-      if (EPI == EPI_DELU_COLSUM) {
-        const float4 y = y4[n];
-        v.x *= y.x > 0.f ? 1.f : y.x + 1.f; v.y *= y.y > 0.f ? 1.f : y.y + 1.f; v.z *= y.z > 0.f ? 1.f : y.z + 1.f; v.w *= y.w > 0.f ? 1.f : y.w + 1.f;
-        if (row < g.M) { cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w; }
+    for (int a = 0; a < TM; ++a) {
+      const int rbase = row0 + wm * 32 * TM + a * 32 + lr;
+      float4 y4[NI];
+      if (EPI == EPI_DELU_COLSUM) {      // the slab's ELU outputs in flight together (clamped addresses; edge values are dropped below)
+#pragma unroll
+        for (int n = 0; n < NI; ++n) {
+          const float* q = g.Y + (size_t)min(rbase + n * RPI, g.M - 1) * g.ldc;
+          if (cv) y4[n] = *reinterpret_cast<const float4*>(q + col);
+          else y4[n] = make_float4(q[min(col, g.N - 1)], q[min(col + 1, g.N - 1)], q[min(col + 2, g.N - 1)], q[min(col + 3, g.N - 1)]);
+        }
       }
-      if (row < g.M && !(g.debug & 1)) {
-        float* o = Cz + (size_t)row * g.ldc + col;
-        if (cv) *reinterpret_cast<float4*>(o) = v;
-        else { if (col < g.N) o[0] = v.x; if (col + 1 < g.N) o[1] = v.y; if (col + 2 < g.N) o[2] = v.z; if (col + 3 < g.N) o[3] = v.w; }
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * gk;
+          wl[row * CT + ((b * 32 + i) ^ (gk << 5 & (CT - 1)))] = acc[a][b][r];
+        }
+#pragma unroll
+      for (int n = 0; n < NI; ++n) {
+        const int lrow = lr + n * RPI, row = rbase + n * RPI;
+        float4 v = *reinterpret_cast<const float4*>(wl + lrow * CT + (lc ^ ((lrow >> 2 & 1) << 5 & (CT - 1))));
+        if (EPI == EPI_BIAS_ELU) v = make_float4(elu1(v.x + bias4.x), elu1(v.y + bias4.y), elu1(v.z + bias4.z), elu1(v.w + bias4.w));
+        if (EPI == EPI_DELU_COLSUM) {
+          const float4 y = y4[n];
+          v.x *= y.x > 0.f ? 1.f : y.x + 1.f; v.y *= y.y > 0.f ? 1.f : y.y + 1.f; v.z *= y.z > 0.f ? 1.f : y.z + 1.f; v.w *= y.w > 0.f ? 1.f : y.w + 1.f;
+          if (row < g.M) { cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w; }
+        }
+        if (row < g.M && !(g.debug & 1)) {
+          float* o = Cz + (size_t)row * g.ldc + col;
+          if (cv) *reinterpret_cast<float4*>(o) = v;
+          else { if (col < g.N) o[0] = v.x; if (col + 1 < g.N) o[1] = v.y; if (col + 2 < g.N) o[2] = v.z; if (col + 3 < g.N) o[3] = v.w; }
+        }
       }
     }
     if (EPI == EPI_DELU_COLSUM) {
@@ -281,11 +286,12 @@ __global__ void __launch_bounds__(GM_THREADS) go2nn_gemm_kernel(const GemmArgs g
 
 #endif  // !GO2_EMU
 
-// tile shape (TM, TN in 32x32 tiles per wave; workgroup tile 64 TM x 64 TN) for an M x N output with M large: 64 x 128 (48 KB of LDS: three
-// workgroups per CU, and at M = 24576 the workgroup count is a multiple of 3 x 256) unless the output is narrow or 128 columns would mostly be padding
+// tile shape (TM, TN in 32x32 tiles per wave; workgroup tile 64 TM x 64 TN) for an M x N output with M large: 128 x 128 (16-deep k-tiles, 32 KB of LDS)
+// for outputs of >= 512 columns — at M = 24576 that is 768 workgroups = 3 per CU, all resident, at 8 B / clk / CU from the L2; 64 x 128 (48 KB: three
+// workgroups per CU, 768 of them for 256 columns) below that; 64 x 64 for narrow outputs or when 128 columns would mostly be padding
 static inline int gm_pick(int n) { return (n + 127) / 128 * 128 <= (n + 63) / 64 * 64 ? 2 : 1; }
 static inline void gemm_tile(int M, int N, int* tm, int* tn) {
   if (const char* e = getenv("GO2NN_TILE")) { if (e[0] >= '1' && e[0] <= '2' && e[1] >= '1' && e[1] <= '2') { *tm = e[0] - '0'; *tn = e[1] - '0'; return; } }   // tools/gemm_bench.py: tile sweep
-  (void)M;
-  *tm = 1; *tn = N > 128 ? gm_pick(N) : 1;
+  *tn = N > 128 ? gm_pick(N) : 1;
+  *tm = (*tn == 2 && N >= 512 && M >= 512) ? 2 : 1;
 }

@@ -266,13 +266,22 @@ static void emu_forward(const NetDesc& nd, int N, int row0, float out[NN_ROWS][G
 static long long* g_gemm_stamps = nullptr;
 extern "C" void go2nn_debug_gemm_stamps(long long* p) { g_gemm_stamps = p; }      // TOOL-ONLY: device buffer [workgroups][8] of the next launches
 #endif
+// k-tile depth: 16 for the 128 x 128 tile (two stages = 32 KB of LDS: four workgroups per CU, and its k-tile then carries the same 32 MFMAs per wave as
+// the 64 x 128 tile's 32-deep one), 32 otherwise.  GO2NN_BK overrides (tools/gemm_bench.py).
+static inline int gemm_bk(int tm, int tn) {
+  if (const char* e = getenv("GO2NN_BK")) { const int b = atoi(e); if (b == 16 || b == 32) return b; }
+  return tm == 2 && tn == 2 ? 16 : 32;
+}
 template <bool AKC, bool BKC, int EPI, bool VEC>
 static void gemm_dispatch2(int tm, int tn, const GemmArgs& g, int splits, hipStream_t st) {
   const dim3 grid(g.nbm * g.nbn, 1, splits), blk(GM_THREADS);
-  if (tm == 2 && tn == 2)      hipLaunchKernelGGL((go2nn_gemm_kernel<2, 2, AKC, BKC, EPI, VEC>), grid, blk, 0, st, g);
-  else if (tm == 1 && tn == 2) hipLaunchKernelGGL((go2nn_gemm_kernel<1, 2, AKC, BKC, EPI, VEC>), grid, blk, 0, st, g);
-  else if (tm == 2 && tn == 1) hipLaunchKernelGGL((go2nn_gemm_kernel<2, 1, AKC, BKC, EPI, VEC>), grid, blk, 0, st, g);
-  else                         hipLaunchKernelGGL((go2nn_gemm_kernel<1, 1, AKC, BKC, EPI, VEC>), grid, blk, 0, st, g);
+  const int bk = gemm_bk(tm, tn);
+  if (tm == 2 && tn == 2 && bk == 16)      hipLaunchKernelGGL((go2nn_gemm_kernel<2, 2, AKC, BKC, EPI, VEC, 16>), grid, blk, 0, st, g);
+  else if (tm == 2 && tn == 2)             hipLaunchKernelGGL((go2nn_gemm_kernel<2, 2, AKC, BKC, EPI, VEC, 32>), grid, blk, 0, st, g);
+  else if (tm == 1 && tn == 2 && bk == 16) hipLaunchKernelGGL((go2nn_gemm_kernel<1, 2, AKC, BKC, EPI, VEC, 16>), grid, blk, 0, st, g);
+  else if (tm == 1 && tn == 2)             hipLaunchKernelGGL((go2nn_gemm_kernel<1, 2, AKC, BKC, EPI, VEC, 32>), grid, blk, 0, st, g);
+  else if (tm == 2 && tn == 1)             hipLaunchKernelGGL((go2nn_gemm_kernel<2, 1, AKC, BKC, EPI, VEC, 32>), grid, blk, 0, st, g);
+  else                                     hipLaunchKernelGGL((go2nn_gemm_kernel<1, 1, AKC, BKC, EPI, VEC, 32>), grid, blk, 0, st, g);
 }
 template <bool AKC, bool BKC, int EPI>
 static void gemm_dispatch(int tm, int tn, GemmArgs& g, int splits, bool vec, hipStream_t st) {

@@ -134,8 +134,9 @@ def _is_tail(l1, act, l2):
 # decides — as the whole job with one rule switched at a time, in ONE session on one GPU (profiles/r3_mlp_kernel_choice.txt; boxes differ by a few %):
 #   forward:      own for the 256 -> 128 layer (23 us against addmm + elu_ 28; as the pair 57 against 85-130); the 512-wide layers are at parity alone
 #                 (65 us) and lose as the pair; rows that are not a multiple of 16 bytes (the 45- and 263-wide inputs) take the 4-byte load path and lose
-#   input grad:   own is faster alone (85 against 93 us, 35 against 41) but the whole job is 4 % slower with it (two of these kernels on two streams
-#                 slow each other down more than a hipBLASLt pair does) -> vendor GEMM + go2sim_elu_backward_bias
+#   input grad:   own (128 x 128 tiles, 16-deep k-tiles for the 512-wide output: 76 us against mm + go2sim_elu_backward_bias 95; 64 x 128 for the 256-wide
+#                 one: 34 against 42; as pairs 159 against 191 and 70 against 81-108): whole job 5.10 -> 5.18 M env-steps/s.  (Before the kernels were
+#                 held to 3 waves per SIMD — 184 registers — the same choice cost 4 %.)
 #   weight grad:  hipBLASLt's row-split bmm (60 us against 88); its sum over the splits joins the deferred reductions
 # GO2_MLP_OWN_F / _I / _W = all | none | auto | k256 override the three rules (A/B runs).
 _OWN = {k: os.environ.get("GO2_MLP_OWN_" + k.upper(), "auto") for k in ("f", "i", "w")}
@@ -146,9 +147,13 @@ def _own(kind, K, N):
     mode = _OWN[kind]
     if mode == "k256":
         return K <= 256
+    if mode == "l3a1":
+        return N <= 128 or K <= 64
     if mode != "auto":
         return mode == "all"
-    return kind == "f" and N <= 128 and K % 4 == 0
+    if kind == "f":
+        return N <= 128 and K % 4 == 0
+    return kind == "i"
 
 
 class _FusedMLP(torch.autograd.Function):

@@ -1,6 +1,5 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r3m14; mkdir -p $O
-timeout 400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_update_golden.py tests/test_gpu_mlp_tail.py -x -q --timeout 150 -k "loss or adam or golden or fused or tail or graph or abi" > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -5 $O/pytest.log
+O=gpurun_out/r3m18; mkdir -p $O
 run() { n=$1; shift
   env "$@" timeout 200 python bench.py --steps 40 --warmup 20 --no-cpu-baseline > $O/bench_$n.json 2> $O/bench_$n.err
   python - <<PY
@@ -10,9 +9,10 @@ for l in open('$O/bench_$n.json'):
         d=json.loads(l); print('$n', round(d['value']/1e6,3), round(d['ms_per_step'],2), round(d['roofline']['kernel_ms']*1e3,1))
 PY
 }
-run head0 GO2_FUSED_HEAD=0
-run auto A=1
-run head0b GO2_FUSED_HEAD=0
-run autob A=1
-cd /tmp && export TMPDIR=/tmp && timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 6 --no-cpu-baseline > /dev/null 2>&1
-cd $GRAFT_REPO_ROOT && python tools/trace_timeline.py /tmp/kt/kt_kernel_trace.csv > $O/timeline.txt 2>&1; grep -n "update:\|one mini-batch" $O/timeline.txt
+for rep in a b; do
+run auto$rep A=1
+run inone$rep GO2_MLP_OWN_I=none
+run fl3a1$rep GO2_MLP_OWN_F=l3a1
+run wk256$rep GO2_MLP_OWN_W=k256
+run wall$rep GO2_MLP_OWN_W=all
+done

@@ -81,4 +81,5 @@ for what, label, a, b in (("f", "layer 1 forward", "A1", "C1"), ("f", "layer 2 f
                           ("w", "layer 1 weight grad", "A1", "C1"), ("w", "layer 2 weight grad", "L2", "L2"), ("w", "layer 3 weight grad", "L3", "L3")):
     o = timed(pair(fns[a][what][0], fns[b][what][0]))
     r = timed(pair(fns[a][what][1], fns[b][what][1]))
-    print("%-24s own %7.1f   torch %7.1f" % (label, o, r))
+    mx = timed(pair(fns[a][what][0], fns[b][what][1]))          # the actor's on the own kernel, the critic's on the vendor path
+    print("%-24s own %7.1f   torch %7.1f   own | torch %7.1f" % (label, o, r, mx))
