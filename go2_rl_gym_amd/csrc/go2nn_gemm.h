@@ -39,6 +39,9 @@ struct GemmArgs {
 };
 
 #ifndef GO2_EMU
+// a 16-byte load from a 4-byte-aligned address (gfx950 takes it as one global_load_dwordx4): rows whose length is not a multiple of 4 floats
+typedef float GmF4u __attribute__((ext_vector_type(4), aligned(4)));      // (a vector type: a struct of four floats is split into four loads before the backend sees it)
+__device__ __forceinline__ float4 gm_ldu(const float* p) { const GmF4u v = *reinterpret_cast<const GmF4u*>(p); return make_float4(v[0], v[1], v[2], v[3]); }
 __device__ __forceinline__ float gm_keep(float v, bool ok) { return __uint_as_float(__float_as_uint(v) & (ok ? 0xffffffffu : 0u)); }
 __device__ __forceinline__ int gm_opaque(int v) { asm volatile("" : "+v"(v)); return v; }      // (the compiler must not see that a clamped index implies the in-range test: it would turn the load back into a branch)
 __device__ __forceinline__ float4 gm_masked(const float4 v, unsigned m) {
@@ -85,7 +88,9 @@ struct GmStage {
       if (VEC) {
         const int kc = gm_opaque(min(k, kend - 4));
         buf[p] = *reinterpret_cast<const float4*>(rowp[p] + kc); okm |= ((rowok >> p & 1) && k < kend ? 15u : 0u) << (4 * p);
-      } else {
+      } else if (k0 + BK <= kend) {        // (workgroup-uniform) a full k-tile of unaligned rows: still one 16-byte load per piece
+        buf[p] = gm_ldu(rowp[p] + k); okm |= ((rowok >> p & 1) ? 15u : 0u) << (4 * p);
+      } else {                              // the ragged last k-tile: element by element, clamped inside the row
         const int k1 = gm_opaque(min(k, kend - 1)), k2 = gm_opaque(min(k + 1, kend - 1)), k3 = gm_opaque(min(k + 2, kend - 1)), k4 = gm_opaque(min(k + 3, kend - 1));
         const unsigned km = (unsigned)(k < kend) | (unsigned)(k + 1 < kend) << 1 | (unsigned)(k + 2 < kend) << 2 | (unsigned)(k + 3 < kend) << 3;
         buf[p] = make_float4(rowp[p][k1], rowp[p][k2], rowp[p][k3], rowp[p][k4]); okm |= ((rowok >> p & 1) ? km : 0u) << (4 * p);
@@ -94,6 +99,7 @@ struct GmStage {
       const int k = k0 + tid / QR + KP * p;
       const float* q = base + (size_t)gm_opaque(min(k, kend - 1)) * ld + c0;
       if (VEC) buf[p] = *reinterpret_cast<const float4*>(q);
+      else if (!edge) buf[p] = gm_ldu(q);        // (workgroup-uniform) an interior column tile of unaligned rows
       else { const int n1 = ncols - 1 - c0; buf[p] = make_float4(q[0], q[min(1, n1)], q[min(2, n1)], q[min(3, n1)]); }
       okm |= (k < kend ? rowok : 0u) << (4 * p);
     }

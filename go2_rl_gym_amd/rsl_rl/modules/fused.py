@@ -132,8 +132,10 @@ def _is_tail(l1, act, l2):
 # Which of a hidden layer's three products go to the go2nn MFMA kernels (include/go2nn.h go2nn_linear_*) and which stay on hipBLASLt + the element-wise
 # kernels.  Measured per shape at M = 24576 on one MI355X, alone and as the actor / critic pair on two streams (tools/gemm_bench.py), and — what
 # decides — as the whole job with one rule switched at a time, in ONE session on one GPU (profiles/r3_mlp_kernel_choice.txt; boxes differ by a few %):
-#   forward:      own for the 256 -> 128 layer (23 us against addmm + elu_ 28; as the pair 57 against 85-130); the 512-wide layers are at parity alone
-#                 (65 us) and lose as the pair; rows that are not a multiple of 16 bytes (the 45- and 263-wide inputs) take the 4-byte load path and lose
+#   forward:      own for the 256 -> 128 layer (23 us against addmm + elu_ 28; as the pair 58-64 against 84-130) and for the two input layers, whose rows
+#                 (45 / 263 floats) are not a multiple of 16 bytes: 27 against 52 us and 79 against 89, 130 against 133 as the pair — gfx950 takes a 16-byte
+#                 load from a 4-byte-aligned address as ONE instruction (before that: four loads per quad, and the vendor kernels won).  The 512 -> 256
+#                 layer is at parity alone (65 us) and loses as the pair (147 against 139): vendor GEMM + elu_
 #   input grad:   own (128 x 128 tiles, 16-deep k-tiles for the 512-wide output: 76 us against mm + go2sim_elu_backward_bias 95; 64 x 128 for the 256-wide
 #                 one: 34 against 42; as pairs 159 against 191 and 70 against 81-108): whole job 5.10 -> 5.18 M env-steps/s.  (Before the kernels were
 #                 held to 3 waves per SIMD — 184 registers — the same choice cost 4 %.)
@@ -149,10 +151,12 @@ def _own(kind, K, N):
         return K <= 256
     if mode == "l3a1":
         return N <= 128 or K <= 64
+    if mode == "l3l1":
+        return N <= 128 or K % 4 != 0
     if mode != "auto":
         return mode == "all"
     if kind == "f":
-        return N <= 128 and K % 4 == 0
+        return N <= 128 or K % 4 != 0 or K <= 64
     return kind == "i"
 
 
