@@ -111,12 +111,28 @@ __global__ void __launch_bounds__(256) go2nn_sum_rows_kernel(const SumRowsArgs a
   const int nrows = a.nrows[j], ncols = a.ncols[j], blk = blockIdx.x - a.first_block[j];
   if (nrows <= 32) {
     const int c = blk * 256 + threadIdx.x;
-    if (c < ncols) { float s = part[c]; for (int r = 1; r < nrows; ++r) s += part[(size_t)r * ncols + c]; out[c] = s; }
+    if (c < ncols) {
+      float s = 0.f;
+      for (int r0 = 0; r0 < nrows; r0 += 8) {       // eight rows' loads in flight, added in ascending order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)min(r0 + u, nrows - 1) * ncols + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (r0 + u < nrows) s += v[u];
+      }
+      out[c] = s;
+    }
     return;
   }
   const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4, c = blk * 16 + cl;
   float s = 0.f;
-  if (c < ncols) for (int r = rg; r < nrows; r += 16) s += part[(size_t)r * ncols + c];
+  if (c < ncols) for (int r0 = rg; r0 < nrows; r0 += 64) {          // four of the thread's rows in flight
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = part[(size_t)min(r0 + 16 * u, nrows - 1) * ncols + c];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (r0 + 16 * u < nrows) s += v[u];
+  }
   sh[rg][cl] = s;
   __syncthreads();
   if (rg == 0 && c < ncols) {

@@ -687,18 +687,32 @@ __global__ void __launch_bounds__(256) go2_ppo_loss_kernel(const float* __restri
 }
 __global__ void go2_ppo_loss_finish_kernel(const float* __restrict__ part, const float* __restrict__ std_, float* __restrict__ gstd, float* __restrict__ stats,
                                            int nblocks, int B, int A, float vcoef, float ecoef) {
-  // 8 x PPO_NSTAT threads: thread (j, k) sums the blocks j, j + 8, ... of statistic k (independent loads in flight instead of one serial
-  // chain of `nblocks` per statistic), then the 8 sub-sums are added in a fixed order: deterministic
-  __shared__ float sh[8][PPO_NSTAT];
+  // 16 x PPO_NSTAT threads: thread (j, k) sums the blocks j, j + 16, ... of statistic k, four loads in flight at a time (this launch sits between the
+  // loss kernel and the backward pass: a serial chain of `nblocks` dependent loads per statistic is all it would be), then the 16 sub-sums are added in a
+  // fixed order: deterministic
+  __shared__ float sh[16][PPO_NSTAT];
   const int k = threadIdx.x % PPO_NSTAT, j = threadIdx.x / PPO_NSTAT;
-  if (j < 8) {
+  if (j < 16) {
     float s = 0.f;
-    for (int b = j; b < nblocks; b += 8) s += part[(size_t)b * PPO_NSTAT + k];
+    for (int b0 = j; b0 < nblocks; b0 += 64) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = part[(size_t)min(b0 + 16 * u, nblocks - 1) * PPO_NSTAT + k];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (b0 + 16 * u < nblocks) s += v[u];
+    }
     sh[j][k] = s;
   }
   __syncthreads();
   if (threadIdx.x < PPO_NSTAT) {
-    const float s = ((sh[0][k] + sh[1][k]) + (sh[2][k] + sh[3][k])) + ((sh[4][k] + sh[5][k]) + (sh[6][k] + sh[7][k]));
+    float t[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t[g] = sh[g][k];
+#pragma unroll
+    for (int wd = 8; wd >= 1; wd >>= 1)
+#pragma unroll
+      for (int g = 0; g < wd; ++g) t[g] += t[g + wd];
+    const float s = t[0];
     if (k < 4) { sh[0][k] = k == 0 ? s : s / (float)B; stats[k] = sh[0][k]; }      // the surrogate partials are already weighted
     else if (k - 4 < A) gstd[k - 4] = s - ecoef / std_[k - 4];
   }
@@ -1469,7 +1483,7 @@ int go2sim_ppo_loss(const float* mu, const float* std_, const float* value, cons
 #else
   int nb = (B + PPO_ROWS - 1) / PPO_ROWS;
   hipLaunchKernelGGL(go2_ppo_loss_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, mu, std_, value, actions, old_mu, old_sigma, old_logp, adv, tv, ret, gmu, gval, workspace, B, A, clip, vcoef, use_clip_v, split, w_head, w_tail);
-  hipLaunchKernelGGL(go2_ppo_loss_finish_kernel, dim3(1), dim3(8 * PPO_NSTAT), 0, (hipStream_t)stream, workspace, std_, gstd, stats, nb, B, A, vcoef, ecoef);
+  hipLaunchKernelGGL(go2_ppo_loss_finish_kernel, dim3(1), dim3(16 * PPO_NSTAT), 0, (hipStream_t)stream, workspace, std_, gstd, stats, nb, B, A, vcoef, ecoef);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

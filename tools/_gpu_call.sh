@@ -1,7 +1,6 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r3m19; mkdir -p $O
-timeout 300 python -m pytest tests/test_gpu_mlp_tail.py -x -q --timeout 120 > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.log
-timeout 100 python tools/gemm_bench.py 2>&1 | grep -v amdgpu.ids | tee $O/gemm_bench.txt
+O=gpurun_out/r3m21; mkdir -p $O
+timeout 400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_update_golden.py tests/test_gpu_mlp_tail.py -x -q --timeout 150 -k "loss or adam or golden or sum_rows or graph" > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.log
 run() { n=$1; shift
   env "$@" timeout 200 python bench.py --steps 40 --warmup 20 --no-cpu-baseline > $O/bench_$n.json 2> $O/bench_$n.err
   python - <<PY
@@ -11,8 +10,6 @@ for l in open('$O/bench_$n.json'):
         d=json.loads(l); print('$n', round(d['value']/1e6,3), round(d['ms_per_step'],2), round(d['roofline']['kernel_ms']*1e3,1))
 PY
 }
-for rep in a b; do
-run auto$rep A=1
-run fl1$rep GO2_MLP_OWN_F=l3l1
-run fall$rep GO2_MLP_OWN_F=all
-done
+run autoa A=1
+run head0 GO2_FUSED_HEAD=0
+run autob A=1
