@@ -270,12 +270,16 @@ extern "C" void go2nn_debug_gemm_stamps(long long* p) { g_gemm_stamps = p; }    
 // the 64 x 128 tile's 32-deep one), 32 otherwise.  GO2NN_BK overrides (tools/gemm_bench.py).
 static inline int gemm_bk(int tm, int tn) {
   if (const char* e = getenv("GO2NN_BK")) { const int b = atoi(e); if (b == 16 || b == 32) return b; }
-  return tm == 2 && tn == 2 ? 16 : 32;
+  return tm >= 2 && tn == 2 ? 16 : 32;
 }
 template <bool AKC, bool BKC, int EPI, bool VEC>
 static void gemm_dispatch2(int tm, int tn, const GemmArgs& g, int splits, hipStream_t st) {
   const dim3 grid(g.nbm * g.nbn, 1, splits), blk(GM_THREADS);
   const int bk = gemm_bk(tm, tn);
+  if constexpr (AKC) {        // 192-row tiles: only with a k-contiguous A operand (a k-strided one is staged R / 4 column quads per k-row: 192 / 4 does not divide 256 threads)
+    if (tm == 3 && tn == 2 && bk == 16) { hipLaunchKernelGGL((go2nn_gemm_kernel<3, 2, AKC, BKC, EPI, VEC, 16>), grid, blk, 0, st, g); return; }
+    if (tm == 3 && tn == 2)             { hipLaunchKernelGGL((go2nn_gemm_kernel<3, 2, AKC, BKC, EPI, VEC, 32>), grid, blk, 0, st, g); return; }
+  }
   if (tm == 2 && tn == 2 && bk == 16)      hipLaunchKernelGGL((go2nn_gemm_kernel<2, 2, AKC, BKC, EPI, VEC, 16>), grid, blk, 0, st, g);
   else if (tm == 2 && tn == 2)             hipLaunchKernelGGL((go2nn_gemm_kernel<2, 2, AKC, BKC, EPI, VEC, 32>), grid, blk, 0, st, g);
   else if (tm == 1 && tn == 2 && bk == 16) hipLaunchKernelGGL((go2nn_gemm_kernel<1, 2, AKC, BKC, EPI, VEC, 16>), grid, blk, 0, st, g);

@@ -1,17 +1,17 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r3fb; mkdir -p $O
-bash tools/pmc_pass.sh 4096 100 go2_flat > $O/pmc_flat.log 2>&1
-bash tools/pmc_pass.sh 4096 100 go2 > $O/pmc_go2.log 2>&1
-bash tools/sq_pass.sh 4096 60 go2_flat > $O/sq_flat.log 2>&1
-bash tools/sq_pass.sh 4096 60 go2 > $O/sq_go2.log 2>&1
-cp gpurun_out/pmc/*.json gpurun_out/pmc/*.csv $O/ 2>/dev/null
-timeout 150 python tools/kbench.py 4096 > $O/kbench.txt 2>&1
-timeout 150 python tools/kbench.py 4096 rough > $O/kbench_rough.txt 2>&1
-timeout 120 python tools/kscale.py 1024 4096 8192 32768 > $O/kscale.txt 2>&1
-timeout 100 python tools/policy_bench.py 4096 > $O/policy_bench.txt 2>&1
-timeout 100 python tools/gemm_bench.py > $O/gemm_bench.txt 2>&1
-timeout 100 python tools/gemm_stamps.py f 512 256 > $O/gemm_stamps.txt 2>&1
-timeout 100 python tools/gemm_stamps.py i 512 256 >> $O/gemm_stamps.txt 2>&1
-bash tools/gemm_pmc.sh L2i i 512 256 > $O/gemm_pmc_L2i.json 2>/dev/null
-timeout 200 python bench.py --steps 40 --warmup 20 --no-cpu-baseline | grep -o '"traffic": [0-9.a-z]*\|"value": [0-9.]*' | head -3
-ls $O | tr '\n' ' '
+O=gpurun_out/r3m25; mkdir -p $O
+run() { n=$1; shift
+  env "$@" timeout 200 python bench.py --steps 40 --warmup 20 --no-cpu-baseline > $O/bench_$n.json 2> $O/bench_$n.err
+  python - <<PY
+import json
+ok=False
+for l in open('$O/bench_$n.json'):
+    if l.startswith('{'):
+        d=json.loads(l); ok=True; print('$n', round(d['value']/1e6,3), round(d['ms_per_step'],2))
+if not ok: print('$n FAILED'); print(open('$O/bench_$n.err').read()[-600:])
+PY
+}
+run none A=1
+run serial GO2_FORCE_COLLECTIVES=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29511
+run overlap GO2_FORCE_COLLECTIVES=1 GO2_OVERLAP_ALLREDUCE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29512
+run none2 A=1
