@@ -1,17 +1,4 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r3m25; mkdir -p $O
-run() { n=$1; shift
-  env "$@" timeout 200 python bench.py --steps 40 --warmup 20 --no-cpu-baseline > $O/bench_$n.json 2> $O/bench_$n.err
-  python - <<PY
-import json
-ok=False
-for l in open('$O/bench_$n.json'):
-    if l.startswith('{'):
-        d=json.loads(l); ok=True; print('$n', round(d['value']/1e6,3), round(d['ms_per_step'],2))
-if not ok: print('$n FAILED'); print(open('$O/bench_$n.err').read()[-600:])
-PY
-}
-run none A=1
-run serial GO2_FORCE_COLLECTIVES=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29511
-run overlap GO2_FORCE_COLLECTIVES=1 GO2_OVERLAP_ALLREDUCE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29512
-run none2 A=1
+O=gpurun_out/r3m26; mkdir -p $O
+( echo "task go2_flat (PPO, plane)"; timeout 200 python tools/train_curve.py go2_flat 600 100 2>&1 | grep "^it "; echo; echo "task go2 (PPO, rough curriculum terrain, trimesh walls)"; timeout 200 python tools/train_curve.py go2 600 100 2>&1 | grep "^it "; echo; echo "task go2_cts (CTS, rough)"; timeout 200 python tools/train_curve.py go2_cts 300 100 2>&1 | grep "^it " ) > $O/learning_curves.txt 2>&1
+cat $O/learning_curves.txt
