@@ -297,7 +297,8 @@ __global__ void __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu
 // workgroups per CU, 768 of them for 256 columns) below that; 64 x 64 for narrow outputs or when 128 columns would mostly be padding
 static inline int gm_pick(int n) { return (n + 127) / 128 * 128 <= (n + 63) / 64 * 64 ? 2 : 1; }
 static inline void gemm_tile(int M, int N, int* tm, int* tn) {
-  if (const char* e = getenv("GO2NN_TILE")) { if (e[0] >= '1' && e[0] <= '3' && e[1] >= '1' && e[1] <= '2') { *tm = e[0] - '0'; *tn = e[1] - '0'; return; } }   // tools/gemm_bench.py: tile sweep
+  static const char* const env = getenv("GO2NN_TILE");        // tools/gemm_bench.py: tile sweep (read once)
+  if (env && env[0] >= '1' && env[0] <= '3' && env[1] >= '1' && env[1] <= '2') { *tm = env[0] - '0'; *tn = env[1] - '0'; return; }
   *tn = N > 128 ? gm_pick(N) : 1;
   *tm = (*tn == 2 && N >= 512 && M >= 512) ? 2 : 1;
 }

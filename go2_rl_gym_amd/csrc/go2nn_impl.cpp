@@ -269,7 +269,8 @@ extern "C" void go2nn_debug_gemm_stamps(long long* p) { g_gemm_stamps = p; }    
 // k-tile depth: 16 for the 128 x 128 tile (two stages = 32 KB of LDS: four workgroups per CU, and its k-tile then carries the same 32 MFMAs per wave as
 // the 64 x 128 tile's 32-deep one), 32 otherwise.  GO2NN_BK overrides (tools/gemm_bench.py).
 static inline int gemm_bk(int tm, int tn) {
-  if (const char* e = getenv("GO2NN_BK")) { const int b = atoi(e); if (b == 16 || b == 32) return b; }
+  static const int env = getenv("GO2NN_BK") ? atoi(getenv("GO2NN_BK")) : 0;       // (read once)
+  if (env == 16 || env == 32) return env;
   return tm >= 2 && tn == 2 ? 16 : 32;
 }
 template <bool AKC, bool BKC, int EPI, bool VEC>
@@ -289,7 +290,8 @@ static void gemm_dispatch2(int tm, int tn, const GemmArgs& g, int splits, hipStr
 }
 template <bool AKC, bool BKC, int EPI>
 static void gemm_dispatch(int tm, int tn, GemmArgs& g, int splits, bool vec, hipStream_t st) {
-  if (const char* e = getenv("GO2NN_GEMM_DEBUG")) g.debug = atoi(e);
+  static const int dbg = getenv("GO2NN_GEMM_DEBUG") ? atoi(getenv("GO2NN_GEMM_DEBUG")) : 0;      // tools/gemm_bench.py only (read once)
+  g.debug = dbg;
 #ifdef GM_STAMPS
   g.stamps = g_gemm_stamps;
 #endif
@@ -301,8 +303,10 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // row splits of the weight gradient dW [C, Kin] = G^T X over M rows: enough workgroups for two per CU, at least 256 rows each
 static inline void wgrad_shape(int M, int C, int Kin, int* tm, int* tn, int* splits, int* kchunk) {
   *tm = gm_pick(C); *tn = gm_pick(Kin);              // (no minimum workgroup count here: the row splits supply the parallelism)
-  if (const char* e = getenv("GO2NN_WTILE")) { if (e[0] >= '1' && e[0] <= '2' && e[1] >= '1' && e[1] <= '2') { *tm = e[0] - '0'; *tn = e[1] - '0'; } }
-  int target = 512; if (const char* e = getenv("GO2NN_WSPLIT_WGS")) target = atoi(e);
+  static const char* const wt = getenv("GO2NN_WTILE");                                             // tools/gemm_bench.py sweeps (read once)
+  static const int wtarget = getenv("GO2NN_WSPLIT_WGS") ? atoi(getenv("GO2NN_WSPLIT_WGS")) : 512;
+  if (wt && wt[0] >= '1' && wt[0] <= '2' && wt[1] >= '1' && wt[1] <= '2') { *tm = wt[0] - '0'; *tn = wt[1] - '0'; }
+  const int target = wtarget;
   const int tiles = cdiv(C, 64 * *tm) * cdiv(Kin, 64 * *tn);
   int s = target / tiles; if (s < 1) s = 1;
   int kc = cdiv(cdiv(M, s), GM_BK) * GM_BK; if (kc < 256) kc = 256;
