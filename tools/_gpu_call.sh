@@ -1,4 +1,11 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r3m26; mkdir -p $O
-( echo "task go2_flat (PPO, plane)"; timeout 200 python tools/train_curve.py go2_flat 600 100 2>&1 | grep "^it "; echo; echo "task go2 (PPO, rough curriculum terrain, trimesh walls)"; timeout 200 python tools/train_curve.py go2 600 100 2>&1 | grep "^it "; echo; echo "task go2_cts (CTS, rough)"; timeout 200 python tools/train_curve.py go2_cts 300 100 2>&1 | grep "^it " ) > $O/learning_curves.txt 2>&1
-cat $O/learning_curves.txt
+O=gpurun_out/r3fc; mkdir -p $O
+timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider --timeout 200 > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log; tail -4 $O/pytest_gpu.log | cut -c1-200
+( time timeout 400 python bench.py > $O/bench.json 2> $O/bench.err ) 2> $O/bench_time.txt; tail -3 $O/bench_time.txt
+python - <<PY
+import json
+for l in open('$O/bench.json'):
+    if l.startswith('{'):
+        d=json.loads(l); print(d['value'], d['ms_per_step'], d['collection_only'], d['roofline']['kernel_ms'], d['roofline']['traffic'], d['roofline'].get('traffic_source'), d['cpu_baseline']['value'], d['cpu_baseline']['cores'])
+PY
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
