@@ -180,3 +180,30 @@ def check_sum_rows(lib, device="cpu"):
 
 def test_sum_rows_matches_torch():
     check_sum_rows(load_nn_emu())
+
+
+def test_whole_mlp_node_edge_cases():
+    """one hidden layer, an input that needs no gradient, a non-contiguous input, a second backward through the same parameters (gradient
+    accumulation): the whole-MLP node behaves like plain autograd"""
+    from go2_rl_gym_amd.rsl_rl.modules import fused
+    from go2_rl_gym_amd.rsl_rl.modules.actor_critic import _mlp
+    torch.manual_seed(7)
+    net = _mlp(10, [8], 2, "elu")
+    xw = torch.randn(33, 20)
+    x = xw[:, ::2]                                     # non-contiguous view
+    assert not x.is_contiguous()
+    ref = torch.nn.Sequential(*net.children())        # the same modules under plain autograd
+    ref(x).pow(2).sum().backward()
+    ref(2 * x).pow(2).sum().backward()                 # accumulates
+    want = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad()
+    fused.set_library(load_oracle()); fused.set_nn_library(load_nn_emu())
+    try:
+        out = net(x)
+        assert type(out.grad_fn).__name__ == "_FusedMLPBackward"
+        out.pow(2).sum().backward()
+        net(2 * x).pow(2).sum().backward()
+    finally:
+        fused.set_library(None); fused.set_nn_library(None)
+    for a, b in zip(want, [p.grad for p in net.parameters()]):
+        np.testing.assert_allclose(b.numpy(), a.numpy(), atol=2e-5, rtol=1e-4)

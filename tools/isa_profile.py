@@ -7,7 +7,7 @@ out = "/tmp/go2_isa.s"
 subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffast-math", "-fno-slp-vectorize", "-DGO2_ISA_MARKS", "-S", "--cuda-device-only", "-o", out,
                 os.path.join(ROOT, "go2_rl_gym_amd", "csrc", "go2sim_impl.cpp")] + sys.argv[1:], check=True, stderr=subprocess.DEVNULL)
 s = open(out).read()
-m = re.search(r'^_Z15go2_step_kernelILi3EEvPK11Go2DevBlockPKfi:.*?\n(.*?)s_endpgm', s, re.S | re.M)
+m = re.search(r'^_Z15go2_step_kernelILi3EEvPK11Go2DevBlockPKfi14Go2StepOutputs:.*?\n(.*?)s_endpgm', s, re.S | re.M)
 cur, acc = "pre", collections.OrderedDict()
 for l in m.group(1).split("\n"):
     t = l.strip()
