@@ -13,7 +13,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 dev = "cuda:0"
 ac = ActorCritic(45, 263, 12, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128], activation="elu").to(dev)
 obs, priv, eps = torch.randn(N, 45, device=dev), torch.randn(N, 263, device=dev), torch.randn(N, 12, device=dev)
-pk = _nn.PolicyKernel(_nn.load_nn(), ac); pk.pack()
+pk = _nn.PolicyKernel(_nn.bind(os.environ["GO2NN_LIB"]) if os.environ.get("GO2NN_LIB") else _nn.load_nn(), ac); pk.pack()      # GO2NN_LIB: a build variant (A/B of kernel edits)
 rows = [torch.zeros(N, 12, device=dev) for _ in range(3)] + [torch.zeros(N, device=dev), torch.zeros(N, device=dev)]
 side = torch.cuda.Stream()
 def torch_path():
