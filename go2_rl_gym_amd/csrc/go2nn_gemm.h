@@ -7,17 +7,18 @@
 // (profiles/r3_bench_kernel_stats.csv) spent re-reading tensors a GEMM just wrote.  Here those passes are epilogues:
 //   forward        Y  = elu(X W^T + b)                                             EPI_BIAS_ELU
 //   input grad     Gp = (G W) * elu'(Yp), column partial sums of Gp               EPI_DELU_COLSUM   (the previous layer's pre-activation gradient + bias gradient)
-//   weight grad    dW = G^T X  as row-split partials                              EPI_STORE         (+ go2nn_sum_splits_kernel, fixed order)
+//   weight grad    dW = G^T X  as row-split partials                              EPI_STORE         (summed in a fixed order by go2nn_sum_rows)
 //
 // One kernel template: C[M,N] = sum_k A(m,k) B(n,k), v_mfma_f32_32x32x2_f32, 256 threads = 4 waves as 2 x 2, a wave owns TM x TN 32x32 tiles
-// (workgroup tile 64 TM x 64 TN), k-tiles of 32 double-buffered through LDS.  Each operand is either "k-contiguous" (rows of k: X, W in the forward
+// (workgroup tile 64 TM x 64 TN), k-tiles of 32 or 16 double-buffered through LDS.  Each operand is either "k-contiguous" (rows of k: X, W in the forward
 // pass) or "k-strided" (k runs over rows: W in the input gradient, G and X in the weight gradient); LDS keeps the operand's own orientation:
 //   k-contiguous: tile [rows][32]      — fragment = one ds_read_b128 per lane at [row][8 kb + 4 g]: the lane's four values feed four MFMAs whose
 //                 k index (the lane's g) then stands for input 8 kb + 4 g + e, the same permutation on both operands (as in go2nn_mlp_kernel);
 //                 no padding, the 16-byte quads of a row are XOR-swizzled by the row index instead (GmStage)
 //   k-strided:    tile [32][rows + 8]  — fragment = four ds_read_b32 at [8 kb + 4 g + e][row]; pitch = 8 mod 16: the two half-waves (g = 0 / 1,
 //                 four k-rows apart) fall on disjoint halves of the 64 banks
-// No vendor GEMM library.  fp32 in, fp32 accumulate.
+// No vendor GEMM library.  fp32 in, fp32 accumulate.  Which of a layer's products run here and which on hipBLASLt is decided per shape by measurement
+// (go2_rl_gym_amd/rsl_rl/modules/fused.py:_own, profiles/r3_mlp_kernel_choice.txt).
 #pragma once
 
 #define GM_BK 32

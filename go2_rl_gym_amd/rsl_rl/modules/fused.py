@@ -1,17 +1,20 @@
-"""Linear -> ELU pairs of the policy MLPs with a fused backward (go2sim_elu_backward_bias): the activation gradient and the
-Linear's bias gradient come out of ONE pass over the [B, C] activations instead of an elu_backward pass plus a column-sum
-pass.  Forward and the two GEMMs of the backward stay on PyTorch-ROCm (hipBLASLt via TunableOp); same fp32 arithmetic,
-parameters and state-dict names untouched (the container is still an nn.Sequential of Linear / ELU children).
+"""The policy MLPs' forward and backward pass as explicit kernel calls (PPO.update, rsl_rl/rsl_rl/algorithms/ppo.py:120-187 -> autograd over
+rsl_rl/rsl_rl/modules/actor_critic.py:50-75).  Parameters and state-dict names are untouched: the container is still an nn.Sequential of Linear / ELU
+children; only what runs when gradients are recorded changes.
 
-The weight gradients dW = gz^T x (a [C, K] output reduced over the 24576 rows of a mini-batch) are computed as an explicit S-way
-split over the rows — one batched GEMM + a sum over S — instead of one mm: for these shapes hipBLASLt's own split-K launches ~60
-workgroups on 256 CUs (tools/wgrad_bench.py: 166 -> 70 us at 512x263, 325 -> 58 us at 256x512).  Fixed order: deterministic.
+* _FusedMLP (default when the MLP is [Linear, ELU] x H + a narrow Linear): ONE autograd node per MLP.  Every product of the two passes is a call the node
+  issues itself, so each goes to the faster of two kernels (the fp32-MFMA GEMMs of include/go2nn.h with their ELU / ELU' + bias-gradient epilogues, or
+  hipBLASLt + the element-wise kernels; _own below holds the measured choice), the backward pass starts with go2nn_head_backward (the narrow head's input,
+  weight and bias gradients, the ELU backward and the last hidden layer's bias gradient in one streaming pass instead of two degenerate GEMMs — 58 us for the
+  value head's [1,128] weight gradient —, a split-K fix-up, two column-sum launches and an element-wise pass at the head of the critic's chain), and every
+  fixed-order reduction of the pass (those partials, the input gradients' column partials, the sums over the weight gradients' row splits) is finished by ONE
+  go2nn_sum_rows launch at the end instead of six small launches along the chain of dependent GEMMs.
+* _LinearELU / _Linear / _LinearELUHead (MLPs of other shapes, GO2_MLP_NODE=0): per-layer nodes; the ELU backward and the Linear's bias gradient in one pass
+  over the activations (go2sim_elu_backward_bias) instead of an elu_backward pass plus a column-sum pass.
 
-The TAIL of an MLP — Linear -> ELU -> Linear with a narrow output (the 12-wide action mean, the 1-wide value) — is one autograd node whose
-backward starts with go2nn_head_backward (include/go2nn.h): the head's input gradient, its weight and bias gradients, the ELU backward and the
-hidden layer's bias gradient in ONE streaming pass, in place of two degenerate GEMMs (58 us for the value head's [1,128] weight gradient),
-a split-K fix-up, two column-sum launches and the element-wise pass (profiles/r2_timeline_rollout_step_and_minibatch.txt: the head of the
-critic's chain, which is the critical path of a mini-batch).
+The weight gradients dW = gz^T x (a [C, K] output reduced over the 24576 rows of a mini-batch) on the vendor path are an explicit S-way split over the
+rows — one batched GEMM + a sum over S — instead of one mm: for these shapes hipBLASLt's own split-K launches ~60 workgroups on 256 CUs
+(tools/wgrad_bench.py: 166 -> 70 us at 512x263, 325 -> 58 us at 256x512).  All sums have a fixed order: deterministic, replicas stay bit-identical.
 
 Per process through set_library(lib) — the algorithms call it when they run on the GPU with the HIP library."""
 import ctypes as C
