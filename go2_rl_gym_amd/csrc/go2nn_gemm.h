@@ -55,10 +55,11 @@ __device__ __forceinline__ float4 gm_masked(const float4 v, unsigned m) {
 //     the 2 rows x 8 quads that 16 consecutive threads write (no padding: the 64 x 128 tile's two stages are 48 KB, three workgroups per CU)
 //   k-strided operand:   32 k-rows x R columns; thread = (column quad tid % (R/4), k-rows tid / (R/4) + (1024/R) p).  LDS tile [32][R + 8].
 // Loads are branch-free: clamped (valid) addresses, zeroed by a select on the way to LDS — and only in workgroups that touch an edge.
-template <int R, bool KC, bool VEC, int BK>
+template <int R, bool KC, bool VEC, int BK, int NTHR>
 struct GmStage {
   // k-contiguous: QK k-quads per row, RPP rows per pass of the 256 threads; k-strided: QR column quads per k-row, KP k-rows per pass
-  static constexpr int QK = BK / 4, RPP = GM_THREADS / QK, QR = R / 4, KP = GM_THREADS / QR, P = KC ? R / RPP : BK / KP, LDS_FLOATS = KC ? R * BK : BK * (R + 8);
+  static constexpr int QK = BK / 4, RPP = NTHR / QK, QR = R / 4, KP = NTHR / QR, P = KC ? (R + RPP - 1) / RPP : (BK + KP - 1) / KP, LDS_FLOATS = KC ? R * BK : BK * (R + 8);
+  static constexpr bool RAGGED = KC ? (R % RPP != 0) : (BK % KP != 0);      // the last pass of the threads covers fewer rows than there are threads (768-thread workgroups)
   static constexpr int SWS = BK == 32 ? 1 : 2;      // swizzle: quad ^= (row >> SWS) & (QK - 1)
   const float* base; int ld, kend; bool edge;
   const float* rowp[P];      // KC: the thread's (clamped) rows
@@ -69,7 +70,8 @@ struct GmStage {
     base = src; ld = ld_; kend = kend_; rowok = 0;
     if (KC) {
 #pragma unroll
-      for (int p = 0; p < P; ++p) { const int row = r0 + tid / QK + RPP * p; rowp[p] = src + (size_t)gm_opaque(min(row, n - 1)) * ld_; rowok |= (unsigned)(row < n) << p; }
+      for (int p = 0; p < P; ++p) { const int lrow = tid / QK + RPP * p, row = r0 + (RAGGED ? min(lrow, R - 1) : lrow);      // (a ragged pass: the spare threads re-read the tile's last row — same lines, no traffic — and do not store)
+        rowp[p] = src + (size_t)gm_opaque(min(row, n - 1)) * ld_; rowok |= (unsigned)(row < n) << p; }
       edge = r0 + R > n;
     } else {
       const int col = r0 + 4 * (tid % QR);
@@ -97,7 +99,7 @@ struct GmStage {
         buf[p] = make_float4(rowp[p][k1], rowp[p][k2], rowp[p][k3], rowp[p][k4]); okm |= ((rowok >> p & 1) ? km : 0u) << (4 * p);
       }
     } else {
-      const int k = k0 + tid / QR + KP * p;
+      const int k = k0 + (RAGGED ? min(tid / QR + KP * p, BK - 1) : tid / QR + KP * p);
       const float* q = base + (size_t)gm_opaque(min(k, kend - 1)) * ld + c0;
       if (VEC) buf[p] = *reinterpret_cast<const float4*>(q);
       else if (!edge) buf[p] = gm_ldu(q);        // (workgroup-uniform) an interior column tile of unaligned rows
@@ -116,12 +118,12 @@ struct GmStage {
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const int row = r + RPP * p;
-        *reinterpret_cast<float4*>(lds + row * BK + 4 * (kq ^ ((row >> SWS) & (QK - 1)))) = masked ? gm_masked(buf[p], okm >> (4 * p)) : buf[p];
+        if (!RAGGED || row < R) *reinterpret_cast<float4*>(lds + row * BK + 4 * (kq ^ ((row >> SWS) & (QK - 1)))) = masked ? gm_masked(buf[p], okm >> (4 * p)) : buf[p];
       }
     } else {
       const int rq = tid % QR, kk = tid / QR;
 #pragma unroll
-      for (int p = 0; p < P; ++p) *reinterpret_cast<float4*>(lds + (kk + KP * p) * (R + 8) + 4 * rq) = masked ? gm_masked(buf[p], okm >> (4 * p)) : buf[p];
+      for (int p = 0; p < P; ++p) if (!RAGGED || kk + KP * p < BK) *reinterpret_cast<float4*>(lds + (kk + KP * p) * (R + 8) + 4 * rq) = masked ? gm_masked(buf[p], okm >> (4 * p)) : buf[p];
     }
   }
   // the MFMA fragment of tile row `r` for k-block kb (8 inputs), lane half g: element e stands for input 8 kb + 4 g + e
@@ -154,14 +156,16 @@ __device__ __forceinline__ void gm_issue(SA& sa, SB& sb, int k0, int tid) {
   }
 }
 
-template <int TM, int TN, bool AKC, bool BKC, int EPI, bool VEC, int BK>
-__global__ void __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu(3))) go2nn_gemm_kernel(const GemmArgs g) {      // (>= 3 waves per SIMD: the 128 x 128 tile's
+template <int TM, int TN, bool AKC, bool BKC, int EPI, bool VEC, int BK, int WM = 2>
+__global__ void __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(3))) go2nn_gemm_kernel(const GemmArgs g) {      // (>= 3 waves per SIMD: the 128 x 128 tile's
                                                                                                                                         // 64 accumulators + staging would otherwise take 184 registers = 2 waves)
-  constexpr int BM = 64 * TM, BN = 64 * TN;
-  using SA = GmStage<BM, AKC, VEC, BK>; using SB = GmStage<BN, BKC, VEC, BK>;
-  constexpr int ASZ = SA::LDS_FLOATS, BSZ = SB::LDS_FLOATS;
-  __shared__ __attribute__((aligned(16))) float lds[2 * (ASZ + BSZ)];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, gk = lane >> 5, wm = wave & 1, wn = wave >> 1;
+  // WM x 2 waves; a wave owns TM x TN 32x32 tiles: workgroup tile 32 WM TM x 64 TN.  WM = 2: the 256-thread shapes; WM = 6, TM = 1: 192 x 128 with twelve waves —
+  // the rows of three 64 x 128 workgroups behind ONE staged B tile (the L1 gives co-resident workgroups nothing: r3_gemm_mem_counters_L2_forward.json)
+  constexpr int NTHR = 128 * WM, NW = 2 * WM, BM = 32 * WM * TM, BN = 64 * TN;
+  using SA = GmStage<BM, AKC, VEC, BK, NTHR>; using SB = GmStage<BN, BKC, VEC, BK, NTHR>;
+  constexpr int ASZ = SA::LDS_FLOATS, BSZ = SB::LDS_FLOATS, LOOP_LDS = 2 * (ASZ + BSZ), EPI_LDS = NW * 32 * 32 * TN;
+  __shared__ __attribute__((aligned(16))) float lds[LOOP_LDS > EPI_LDS ? LOOP_LDS : EPI_LDS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, gk = lane >> 5, wm = wave % WM, wn = wave / WM;
   // workgroup -> tile: consecutive workgroup ids go round the 8 XCDs; a XCD gets a contiguous run of tiles (n fastest: the tiles of one row block
   // share their A rows in that XCD's L2)
   const int nb = g.nbm * g.nbn;
@@ -282,10 +286,15 @@ __global__ void __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
       for (int d = LPR; d < 64; d <<= 1) { cs.x += __shfl_xor(cs.x, d); cs.y += __shfl_xor(cs.y, d); cs.z += __shfl_xor(cs.z, d); cs.w += __shfl_xor(cs.w, d); }
       __syncthreads();                      // every wave is done with its LDS quarter
-      float* shs = lds;                     // [2][BN]
+      float* shs = lds;                     // [WM][BN]
       if (lane < LPR) *reinterpret_cast<float4*>(shs + wm * BN + wn * CT + lc) = cs;
       __syncthreads();
-      if (tid < BN && col0 + tid < g.N) g.part[(size_t)bm * g.N + col0 + tid] = shs[tid] + shs[BN + tid];
+      if (tid < BN && col0 + tid < g.N) {
+        float t = shs[tid];
+#pragma unroll
+        for (int w = 1; w < WM; ++w) t += shs[w * BN + tid];
+        g.part[(size_t)bm * g.N + col0 + tid] = t;
+      }
     }
   }
   GM_OUT();
@@ -296,10 +305,11 @@ __global__ void __launch_bounds__(GM_THREADS) __attribute__((amdgpu_waves_per_eu
 // tile shape (TM, TN in 32x32 tiles per wave; workgroup tile 64 TM x 64 TN) for an M x N output with M large: 128 x 128 (16-deep k-tiles, 32 KB of LDS)
 // for outputs of >= 512 columns — at M = 24576 that is 768 workgroups = 3 per CU, all resident, at 8 B / clk / CU from the L2; 64 x 128 (48 KB: three
 // workgroups per CU, 768 of them for 256 columns) below that; 64 x 64 for narrow outputs or when 128 columns would mostly be padding
+static inline int gm_tile_rows(int tm) { return tm == 6 ? 192 : 64 * tm; }      // tm = 6 stands for the twelve-wave shape (6 x 2 waves of one row tile each)
 static inline int gm_pick(int n) { return (n + 127) / 128 * 128 <= (n + 63) / 64 * 64 ? 2 : 1; }
 static inline void gemm_tile(int M, int N, int* tm, int* tn) {
   static const char* const env = getenv("GO2NN_TILE");        // tools/gemm_bench.py: tile sweep (read once)
-  if (env && env[0] >= '1' && env[0] <= '3' && env[1] >= '1' && env[1] <= '2') { *tm = env[0] - '0'; *tn = env[1] - '0'; return; }
+  if (env && ((env[0] >= '1' && env[0] <= '3') || env[0] == '6') && env[1] >= '1' && env[1] <= '2') { *tm = env[0] - '0'; *tn = env[1] - '0'; return; }      // (6x: twelve waves, 192 rows)
   *tn = N > 128 ? gm_pick(N) : 1;
   *tm = (*tn == 2 && N >= 512 && M >= 512) ? 2 : 1;
 }

@@ -277,6 +277,9 @@ template <bool AKC, bool BKC, int EPI, bool VEC>
 static void gemm_dispatch2(int tm, int tn, const GemmArgs& g, int splits, hipStream_t st) {
   const dim3 grid(g.nbm * g.nbn, 1, splits), blk(GM_THREADS);
   const int bk = gemm_bk(tm, tn);
+  if constexpr (AKC) {        // twelve waves (768 threads): a k-contiguous A operand only, like the 192-row shape below
+    if (tm == 6 && tn == 2) { hipLaunchKernelGGL((go2nn_gemm_kernel<1, 2, AKC, BKC, EPI, VEC, 32, 6>), grid, dim3(768), 0, st, g); return; }
+  }
   if constexpr (AKC) {        // 192-row tiles: only with a k-contiguous A operand (a k-strided one is staged R / 4 column quads per k-row: 192 / 4 does not divide 256 threads)
     if (tm == 3 && tn == 2 && bk == 16) { hipLaunchKernelGGL((go2nn_gemm_kernel<3, 2, AKC, BKC, EPI, VEC, 16>), grid, blk, 0, st, g); return; }
     if (tm == 3 && tn == 2)             { hipLaunchKernelGGL((go2nn_gemm_kernel<3, 2, AKC, BKC, EPI, VEC, 32>), grid, blk, 0, st, g); return; }
@@ -440,7 +443,7 @@ int32_t go2nn_linear_backward_input_rows(int32_t M, int32_t C, int32_t Kin) {
 #ifdef GO2_EMU
   return 1;
 #else
-  int tm, tn; gemm_tile(M, Kin, &tm, &tn); return cdiv(M, 64 * tm);
+  int tm, tn; gemm_tile(M, Kin, &tm, &tn); return cdiv(M, gm_tile_rows(tm));
 #endif
 }
 
@@ -497,7 +500,7 @@ int go2nn_linear_elu_forward(const float* x, const float* w, const float* b, flo
   int tm, tn; gemm_tile(M, N, &tm, &tn);
   g.A = x; g.B = w; g.C = y; g.bias = b; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N;
   const bool vec = (K % 4 == 0) && aligned16(x) && aligned16(w);
-  g.kchunk = cdiv(K, GM_BK) * GM_BK; g.nbm = cdiv(M, 64 * tm); g.nbn = cdiv(N, 64 * tn);
+  g.kchunk = cdiv(K, GM_BK) * GM_BK; g.nbm = cdiv(M, gm_tile_rows(tm)); g.nbn = cdiv(N, 64 * tn);
   g.c_vec = (N % 4 == 0) && aligned16(y);
   gemm_dispatch<true, true, EPI_BIAS_ELU>(tm, tn, g, 1, vec, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
@@ -510,7 +513,7 @@ int64_t go2nn_linear_backward_workspace(int32_t M, int32_t C, int32_t Kin) {
   int tm, tn, s, kc; wgrad_shape(M, C, Kin, &tm, &tn, &s, &kc);
   const int64_t wg = (int64_t)s * C * Kin;
   gemm_tile(M, Kin, &tm, &tn);
-  const int64_t ig = (int64_t)cdiv(M, 64 * tm) * Kin;
+  const int64_t ig = (int64_t)cdiv(M, 64) * Kin;          // (an upper bound over the tile shapes: 64 rows per partial row at least)
   return wg > ig ? wg : ig;
 }
 
@@ -532,7 +535,7 @@ int go2nn_linear_backward_input(const float* gz, const float* w, const float* y_
   int tm, tn; gemm_tile(M, Kin, &tm, &tn);
   g.A = gz; g.B = w; g.C = gz_prev; g.Y = y_prev; g.part = workspace; g.M = M; g.N = Kin; g.K = C; g.lda = C; g.ldb = Kin; g.ldc = Kin;
   const bool vec = (C % 4 == 0) && (Kin % 4 == 0) && aligned16(gz) && aligned16(w);
-  g.kchunk = cdiv(C, GM_BK) * GM_BK; g.nbm = cdiv(M, 64 * tm); g.nbn = cdiv(Kin, 64 * tn);
+  g.kchunk = cdiv(C, GM_BK) * GM_BK; g.nbm = cdiv(M, gm_tile_rows(tm)); g.nbn = cdiv(Kin, 64 * tn);
   g.c_vec = (Kin % 4 == 0) && aligned16(gz_prev) && aligned16(y_prev);
   gemm_dispatch<true, false, EPI_DELU_COLSUM>(tm, tn, g, 1, vec, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
