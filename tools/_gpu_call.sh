@@ -1,5 +1,8 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r3m27; mkdir -p $O
-GO2NN_TILE=62 timeout 300 python -m pytest tests/test_gpu_mlp_tail.py -x -q --timeout 120 -k "linear" > $O/pytest62.log 2>&1; echo "pytest62 rc=$?"; tail -3 $O/pytest62.log
-for cfg in "default" "62"; do echo "== GO2NN_TILE=$cfg"; GO2NN_TILE=$cfg timeout 100 python tools/gemm_bench.py 2>&1 | grep -v "amdgpu.ids\|weight grad"; done > $O/tile_sweep.txt 2>&1
-cat $O/tile_sweep.txt
+O=gpurun_out/r3fe; mkdir -p $O
+timeout 400 python -m pytest tests/test_gpu_mlp_tail.py tests/test_gpu_update_golden.py tests/test_gpu_policy_kernel.py -q --timeout 150 > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
+timeout 200 python bench.py --steps 40 --warmup 20 --no-cpu-baseline | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print(round(d['value']/1e6,3), round(d['ms_per_step'],2), d['roofline']['traffic'])"
