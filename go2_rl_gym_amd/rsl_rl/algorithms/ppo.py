@@ -22,6 +22,7 @@ import torch.distributed as dist
 import torch.nn as nn
 import torch.optim as optim
 
+from ..modules.actor_critic import ActorCritic as _AC
 from ..storage import RolloutStorage
 from ._graph import CapturedStep, FusedClipAdam, GradBucket, OverlappedStep, ReducedStep, all_captured, collectives_in_graph
 
@@ -59,6 +60,9 @@ def allreduce_mean_bucket(grads, world, extra=None):
         n = g.numel(); views.append(flat[off:off + n].view_as(g)); off += n
     torch._foreach_copy_(grads, views)           # one multi-tensor launch instead of one copy per parameter
     return flat[off] if extra is not None else None
+
+
+_PLAIN_NOISE = _AC._noise          # (the tests replace ActorCritic._noise to inject the reference's draws: then the rollout asks per step)
 
 
 class _RolloutHeads:
@@ -237,6 +241,18 @@ class PPO(_RolloutHeads):
         self.actor_critic.train()
 
     # ------------------------------------------------------------------ rollout half (ppo.py:90-118)
+    _eps_all = None
+
+    def _rollout_noise(self, ac, st, s):
+        """The standard-normal draws of step s ([N, A], the shape of the action rows).  One launch for the whole rollout at its first step instead of
+        one per step (24 small launches on the chain of dependent kernels); the same law as Normal.sample() per step (actor_critic.py:123-125).
+        A module whose _noise is overridden — the tests inject the reference's draws step by step — is asked per step as before."""
+        if getattr(type(ac), "_noise", None) is not _PLAIN_NOISE:
+            return ac._noise(st.actions[s])
+        if s == 0 or self._eps_all is None or self._eps_all.shape != st.actions.shape or self._eps_all.device != st.actions.device:
+            self._eps_all = torch.randn_like(st.actions)
+        return self._eps_all[s]
+
     def act(self, obs, critic_obs):
         st, t, ac = self.storage, self.transition, self.actor_critic
         s = st.step
@@ -252,12 +268,12 @@ class PPO(_RolloutHeads):
             if pk is not None and obs.is_contiguous() and critic_obs.is_contiguous() and obs.dtype == torch.float32 and critic_obs.dtype == torch.float32:
                 if s == 0:
                     pk.pack()                  # the parameters only change in update(): once per rollout (inside the captured rollout graph too)
-                actions = pk.act(obs, critic_obs, ac._noise(st.actions[s]), st.actions[s], st.mu[s], st.sigma[s], st.actions_log_prob[s].view(-1), st.values[s].view(-1))
+                actions = pk.act(obs, critic_obs, self._rollout_noise(ac, st, s), st.actions[s], st.mu[s], st.sigma[s], st.actions_log_prob[s].view(-1), st.values[s].view(-1))
                 t.actions, t.values, t.actions_log_prob = actions, st.values[s], st.actions_log_prob[s].view(-1)
                 t.action_mean, t.action_sigma = st.mu[s], st.sigma[s]
                 return actions
             mu, value = self._pair(lambda: ac.actor(obs), lambda: ac.evaluate(critic_obs), enabled=self._capture)
-            return self._act_head(mu, ac.std, ac._noise(mu), value, s)      # (drawing the noise before the fork was measured: 1 % slower)
+            return self._act_head(mu, ac.std, self._rollout_noise(ac, st, s), value, s)
         t.actions = ac.act(obs).detach()
         t.values = ac.evaluate(critic_obs).detach()
         t.actions_log_prob = ac.get_actions_log_prob(t.actions).detach()
