@@ -10,12 +10,25 @@ import torch.nn as nn
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 NN_LIB = os.path.join(_HERE, "libgo2nn_hip.so")
-GO2NN_MAX_LAYERS, GO2NN_MAX_WIDTH, GO2NN_ABI_VERSION = 6, 512, 2
+GO2NN_MAX_LAYERS, GO2NN_MAX_WIDTH, GO2NN_ABI_VERSION, GO2NN_MAX_GROUP = 6, 512, 3, 2
 _cached = None
 
 
 class Go2nnSumJob(C.Structure):
     _fields_ = [("part", C.c_void_p), ("out", C.c_void_p), ("nrows", C.c_int32), ("ncols", C.c_int32)]
+
+
+class Go2nnFwdJob(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("b", C.c_void_p), ("y", C.c_void_p), ("M", C.c_int32), ("K", C.c_int32), ("N", C.c_int32)]
+
+
+class Go2nnBwdInJob(C.Structure):
+    _fields_ = [("gz", C.c_void_p), ("w", C.c_void_p), ("y_prev", C.c_void_p), ("gz_prev", C.c_void_p), ("workspace", C.c_void_p),
+                ("M", C.c_int32), ("C", C.c_int32), ("Kin", C.c_int32)]
+
+
+class Go2nnBwdWJob(C.Structure):
+    _fields_ = [("gz", C.c_void_p), ("x", C.c_void_p), ("workspace", C.c_void_p), ("M", C.c_int32), ("C", C.c_int32), ("Kin", C.c_int32)]
 
 
 class Go2nnMlp(C.Structure):
@@ -42,6 +55,11 @@ def bind(path):
     lib.go2nn_sum_rows.argtypes = [C.POINTER(Go2nnSumJob), C.c_int32, C.c_void_p]
     lib.go2nn_head_backward_rows.argtypes = [C.c_int32] * 3
     lib.go2nn_linear_backward_input_rows.argtypes = [C.c_int32] * 3
+    lib.go2nn_linear_elu_forward_group.argtypes = [C.POINTER(Go2nnFwdJob), C.c_int32, C.c_void_p]
+    lib.go2nn_linear_backward_input_group_rows.argtypes = [C.c_int32] * 3
+    lib.go2nn_linear_backward_input_group.argtypes = [C.POINTER(Go2nnBwdInJob), C.c_int32, C.c_void_p]
+    lib.go2nn_linear_backward_weight_group_rows.argtypes = [C.POINTER(Go2nnBwdWJob), C.c_int32]
+    lib.go2nn_linear_backward_weight_group.argtypes = [C.POINTER(Go2nnBwdWJob), C.c_int32, C.c_void_p]
     if lib.go2nn_abi_version() != GO2NN_ABI_VERSION:
         raise RuntimeError("%s: ABI version %d, expected %d" % (path, lib.go2nn_abi_version(), GO2NN_ABI_VERSION))
     return lib

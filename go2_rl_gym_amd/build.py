@@ -77,7 +77,8 @@ def build_nn(force=False):
     """The policy-side MFMA kernels (include/go2nn.h) -> go2_rl_gym_amd/libgo2nn_hip.so.  A library of its own, so that the sha256 that keys the
     step kernel's counter profiles to libgo2sim_hip.so does not move when this one changes.  No -ffast-math (the head's log-probability and
     ELU follow the eager formulation's arithmetic)."""
-    deps = [NN_SRC, os.path.join(HERE, "csrc", "go2nn_train.h"), os.path.join(HERE, "csrc", "go2nn_gemm.h"), os.path.join(ROOT, "include", "go2nn.h")]
+    deps = [NN_SRC, os.path.join(HERE, "csrc", "go2nn_train.h"), os.path.join(HERE, "csrc", "go2nn_gemm.h"), os.path.join(HERE, "csrc", "go2nn_gemm3.h"),
+            os.path.join(ROOT, "include", "go2nn.h")]
     if not force and os.path.exists(NN_OUT) and os.path.getmtime(NN_OUT) >= max(os.path.getmtime(p) for p in deps):
         return NN_OUT
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-cuid=go2nn", "-o", NN_OUT, NN_SRC]

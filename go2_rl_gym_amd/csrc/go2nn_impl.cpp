@@ -237,6 +237,7 @@ __global__ void __launch_bounds__(NN_THREADS) go2nn_mlp_kernel(const NNArgs a) {
 
 #include "go2nn_train.h"
 #include "go2nn_gemm.h"
+#include "go2nn_gemm3.h"
 
 #ifdef GO2_EMU
 // host restatement: the SAME packed buffer, read in the operand order the kernel uses
@@ -575,5 +576,145 @@ int go2nn_policy_act_stamped(const Go2nnMlp* actor, const float* actor_packed, c
   return run(a, 2, stream);
 }
 #endif
+
+}  // extern "C"
+
+// ---- ABI 3: grouped layer calls (go2nn_gemm3.h) ---------------------------------------------------------------------------------------------
+#ifndef GO2_EMU
+#ifdef GM3_STAMPS
+static long long* g_gemm3_stamps = nullptr;
+extern "C" void go2nn_debug_gemm3_stamps(long long* p) { g_gemm3_stamps = p; }      // TOOL-ONLY: device buffer [workgroups][4 waves][8] of the next launches
+#define GM3_SET_STAMPS(a) (a).stamps = g_gemm3_stamps
+#else
+#define GM3_SET_STAMPS(a) do { } while (0)
+#endif
+template <bool BKC, int EPI>
+static int gemm3_launch(int tm, int tn, int bk, const Gemm3Args& a, hipStream_t st) {
+  const dim3 grid(a.ntiles), blk(256);
+  if (tm == 2 && tn == 2 && bk == 16)      hipLaunchKernelGGL((go2nn_gemm3_kernel<2, 2, BKC, EPI, 16>), grid, blk, 0, st, a);
+  else if (tm == 2 && tn == 2)             hipLaunchKernelGGL((go2nn_gemm3_kernel<2, 2, BKC, EPI, 32>), grid, blk, 0, st, a);
+  else if (tm == 1 && tn == 2 && bk == 16) hipLaunchKernelGGL((go2nn_gemm3_kernel<1, 2, BKC, EPI, 16>), grid, blk, 0, st, a);
+  else if (tm == 1 && tn == 2)             hipLaunchKernelGGL((go2nn_gemm3_kernel<1, 2, BKC, EPI, 32>), grid, blk, 0, st, a);
+  else if (tm == 1 && tn == 1)             hipLaunchKernelGGL((go2nn_gemm3_kernel<1, 1, BKC, EPI, 32>), grid, blk, 0, st, a);
+  else FAIL(GO2NN_EINVAL, "gemm3: no kernel for tile %d x %d x %d", tm, tn, bk);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+template <bool VEC>
+static int wgrad3_launch2(int tn, const WgArgs& a, hipStream_t st) {
+  const dim3 grid(a.tiles * a.nsplit), blk(256);
+  if (tn == 4) hipLaunchKernelGGL((go2nn_wgrad_kernel<4, VEC, 6>), grid, blk, 0, st, a);
+  else         hipLaunchKernelGGL((go2nn_wgrad_kernel<2, VEC, 8>), grid, blk, 0, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+#endif
+static int wgrad3_group_shape(const Go2nnBwdWJob* jobs, int njobs, int* tn, int* tiles_of, int* nsplit, int* rows) {
+  if (!jobs || njobs < 1 || njobs > GO2NN_MAX_GROUP) return 0;
+  *tn = 4;
+  for (int j = 0; j < njobs; ++j) {
+    if (!lin_check(jobs[j].M, jobs[j].C, jobs[j].Kin) || jobs[j].M != jobs[0].M || jobs[j].C < 2 || jobs[j].Kin < 4) return 0;
+    if (jobs[j].Kin % 128) *tn = 2;            // 64-column tiles waste less on ragged widths (263 -> 320 instead of 384 columns)
+  }
+  int tiles = 0;
+  for (int j = 0; j < njobs; ++j) { tiles_of[j] = cdiv(jobs[j].C, 64) * cdiv(jobs[j].Kin, 32 * *tn); tiles += tiles_of[j]; }
+  wgrad3_shape(jobs[0].M, tiles, nsplit, rows);
+  return tiles;
+}
+
+extern "C" {
+
+int go2nn_linear_elu_forward_group(const Go2nnFwdJob* jobs, int32_t njobs, void* stream) {
+  if (!jobs || njobs < 1 || njobs > GO2NN_MAX_GROUP) FAIL(GO2NN_EINVAL, "forward group: 1..%d jobs", GO2NN_MAX_GROUP);
+  for (int j = 0; j < njobs; ++j) if (!jobs[j].x || !jobs[j].w || !jobs[j].b || !jobs[j].y || !lin_check(jobs[j].M, jobs[j].N, jobs[j].K)) FAIL(GO2NN_EINVAL, "forward group: bad job %d", j);
+#ifdef GO2_EMU
+  for (int j = 0; j < njobs; ++j) { const int rc = go2nn_linear_elu_forward(jobs[j].x, jobs[j].w, jobs[j].b, jobs[j].y, jobs[j].M, jobs[j].K, jobs[j].N, stream); if (rc) return rc; }
+  return 0;
+#else
+  int tm, tn, bk; gemm3_tile(jobs[0].N, &tm, &tn, &bk);
+  if (njobs == 2) { int tm1, tn1, bk1; gemm3_tile(jobs[1].N, &tm1, &tn1, &bk1);
+    if (tm1 != tm || tn1 != tn || bk1 != bk) { const int rc = go2nn_linear_elu_forward_group(jobs, 1, stream); return rc ? rc : go2nn_linear_elu_forward_group(jobs + 1, 1, stream); } }
+  for (int j = 0; j < njobs; ++j) if (jobs[j].K < 4) {          // (the staging's clamped 16-byte loads need 4 floats per row) -> the single-network kernels
+    for (int i = 0; i < njobs; ++i) { const int rc = go2nn_linear_elu_forward(jobs[i].x, jobs[i].w, jobs[i].b, jobs[i].y, jobs[i].M, jobs[i].K, jobs[i].N, stream); if (rc) return rc; }
+    return 0; }
+  Gemm3Args a; memset(&a, 0, sizeof(a));
+  for (int j = 0; j < njobs; ++j) {
+    Gemm3Prob& g = a.p[j]; const Go2nnFwdJob& q = jobs[j];
+    g.A = q.x; g.B = q.w; g.C = q.y; g.bias = q.b; g.M = q.M; g.N = q.N; g.K = q.K; g.lda = q.K; g.ldb = q.K; g.ldc = q.N;
+    g.nbm = cdiv(q.M, 64 * tm); g.nbn = cdiv(q.N, 64 * tn); g.c_vec = (q.N % 4 == 0) && aligned16(q.y);
+    (j ? a.ntiles : a.ntiles0) = g.nbm * g.nbn;
+  }
+  a.ntiles = njobs == 2 ? a.ntiles0 + a.ntiles : a.ntiles0;
+  GM3_SET_STAMPS(a);
+  return gemm3_launch<true, EPI_BIAS_ELU>(tm, tn, bk, a, (hipStream_t)stream);
+#endif
+}
+
+int32_t go2nn_linear_backward_input_group_rows(int32_t M, int32_t C, int32_t Kin) {
+  if (!lin_check(M, C, Kin)) FAIL(GO2NN_EINVAL, "linear backward: bad shape");
+#ifdef GO2_EMU
+  return 1;
+#else
+  int tm, tn, bk; gemm3_tile(Kin, &tm, &tn, &bk); return cdiv(M, 64 * tm);
+#endif
+}
+
+int go2nn_linear_backward_input_group(const Go2nnBwdInJob* jobs, int32_t njobs, void* stream) {
+  if (!jobs || njobs < 1 || njobs > GO2NN_MAX_GROUP) FAIL(GO2NN_EINVAL, "input-gradient group: 1..%d jobs", GO2NN_MAX_GROUP);
+  for (int j = 0; j < njobs; ++j) if (!jobs[j].gz || !jobs[j].w || !jobs[j].y_prev || !jobs[j].gz_prev || !jobs[j].workspace || !lin_check(jobs[j].M, jobs[j].C, jobs[j].Kin)) FAIL(GO2NN_EINVAL, "input-gradient group: bad job %d", j);
+#ifdef GO2_EMU
+  for (int j = 0; j < njobs; ++j) { const int rc = go2nn_linear_backward_input(jobs[j].gz, jobs[j].w, jobs[j].y_prev, jobs[j].gz_prev, nullptr, jobs[j].workspace, jobs[j].M, jobs[j].C, jobs[j].Kin, stream); if (rc) return rc; }
+  return 0;
+#else
+  int tm, tn, bk; gemm3_tile(jobs[0].Kin, &tm, &tn, &bk);
+  if (njobs == 2) { int tm1, tn1, bk1; gemm3_tile(jobs[1].Kin, &tm1, &tn1, &bk1);
+    if (tm1 != tm || tn1 != tn || bk1 != bk) { const int rc = go2nn_linear_backward_input_group(jobs, 1, stream); return rc ? rc : go2nn_linear_backward_input_group(jobs + 1, 1, stream); } }
+  for (int j = 0; j < njobs; ++j) if (jobs[j].C < 4 || jobs[j].Kin < 4 || jobs[j].Kin % 4) {          // (column quads of W must not straddle Kin) -> the single-network kernels
+    for (int i = 0; i < njobs; ++i) { const int rc = go2nn_linear_backward_input(jobs[i].gz, jobs[i].w, jobs[i].y_prev, jobs[i].gz_prev, nullptr, jobs[i].workspace, jobs[i].M, jobs[i].C, jobs[i].Kin, stream); if (rc) return rc; }
+    return 0; }
+  Gemm3Args a; memset(&a, 0, sizeof(a));
+  for (int j = 0; j < njobs; ++j) {
+    Gemm3Prob& g = a.p[j]; const Go2nnBwdInJob& q = jobs[j];
+    g.A = q.gz; g.B = q.w; g.C = q.gz_prev; g.Y = q.y_prev; g.part = q.workspace; g.M = q.M; g.N = q.Kin; g.K = q.C; g.lda = q.C; g.ldb = q.Kin; g.ldc = q.Kin;
+    g.nbm = cdiv(q.M, 64 * tm); g.nbn = cdiv(q.Kin, 64 * tn); g.c_vec = (q.Kin % 4 == 0) && aligned16(q.gz_prev) && aligned16(q.y_prev);
+    (j ? a.ntiles : a.ntiles0) = g.nbm * g.nbn;
+  }
+  a.ntiles = njobs == 2 ? a.ntiles0 + a.ntiles : a.ntiles0;
+  GM3_SET_STAMPS(a);
+  return gemm3_launch<false, EPI_DELU_COLSUM>(tm, tn, bk, a, (hipStream_t)stream);
+#endif
+}
+
+int32_t go2nn_linear_backward_weight_group_rows(const Go2nnBwdWJob* jobs, int32_t njobs) {
+#ifdef GO2_EMU
+  if (!jobs || njobs < 1 || njobs > GO2NN_MAX_GROUP) FAIL(GO2NN_EINVAL, "weight-gradient group: 1..%d jobs", GO2NN_MAX_GROUP);
+  return 1;
+#else
+  int tn, tiles_of[GO2NN_MAX_GROUP], nsplit, rows;
+  if (!wgrad3_group_shape(jobs, njobs, &tn, tiles_of, &nsplit, &rows)) FAIL(GO2NN_EINVAL, "weight-gradient group: 1..%d jobs with one M, C >= 2, Kin >= 4", GO2NN_MAX_GROUP);
+  return nsplit;
+#endif
+}
+
+int go2nn_linear_backward_weight_group(const Go2nnBwdWJob* jobs, int32_t njobs, void* stream) {
+  int tn, tiles_of[GO2NN_MAX_GROUP], nsplit, rows;
+  const int tiles = wgrad3_group_shape(jobs, njobs, &tn, tiles_of, &nsplit, &rows);
+  if (!tiles) FAIL(GO2NN_EINVAL, "weight-gradient group: 1..%d jobs with one M, C >= 2, Kin >= 4", GO2NN_MAX_GROUP);
+  for (int j = 0; j < njobs; ++j) if (!jobs[j].gz || !jobs[j].x || !jobs[j].workspace) FAIL(GO2NN_EINVAL, "weight-gradient group: bad job %d", j);
+#ifdef GO2_EMU
+  for (int j = 0; j < njobs; ++j) { const int rc = go2nn_linear_backward_weight(jobs[j].gz, jobs[j].x, jobs[j].workspace, jobs[j].workspace, jobs[j].M, jobs[j].C, jobs[j].Kin, stream); if (rc) return rc; }
+  return 0;
+#else
+  WgArgs a; memset(&a, 0, sizeof(a));
+  bool vec = true;
+  for (int j = 0; j < njobs; ++j) {
+    WgProb& g = a.p[j]; const Go2nnBwdWJob& q = jobs[j];
+    g.G = q.gz; g.X = q.x; g.part = q.workspace; g.C = q.C; g.Kin = q.Kin; g.ntc = cdiv(q.C, 64); g.ntk = cdiv(q.Kin, 32 * tn);
+    vec = vec && (q.C % 2 == 0) && (q.Kin % tn == 0) && (((uintptr_t)q.gz & 7) == 0) && (((uintptr_t)q.x & (4 * tn - 1)) == 0);
+  }
+  a.M = jobs[0].M; a.rows_per_slice = rows; a.nsplit = nsplit; a.tiles0 = tiles_of[0]; a.tiles = tiles;
+  return vec ? wgrad3_launch2<true>(tn, a, (hipStream_t)stream) : wgrad3_launch2<false>(tn, a, (hipStream_t)stream);
+#endif
+}
 
 }  // extern "C"

@@ -27,14 +27,14 @@ from ..storage import RolloutStorage
 from ._graph import CapturedStep, FusedClipAdam, GradBucket, OverlappedStep, ReducedStep, all_captured, collectives_in_graph
 
 
-# Adam as ONE multi-tensor kernel per param group (fused) instead of ~6 foreach launches; GO2_ADAM=foreach restores the latter
-_TWO_STREAMS = os.environ.get("GO2_TWO_STREAMS", "1") in ("1", "force")      # actor / critic chains on two HIP streams (+3 % whole-job, measured)
-# ... up to this many envs per GPU only.  Measured on an MI355X (round 3, profiles/r3_large_batch.txt): at 8192 envs and above the first
-# iteration never finishes with the two chains in flight at once, while one stream trains at 4.85 M env-steps/s at 32768 envs.  Consistent
-# with hipBLASLt picking cooperative (stream-K) GEMM kernels for the larger mini-batches, whose workgroups wait for each other and are no
-# longer all resident when a kernel of the other stream holds part of the chip.  Every BASELINE configuration has <= 4096 envs per GPU; above
-# that a GEMM fills the chip alone and the overlap buys nothing.  GO2_TWO_STREAMS=force overrides.
-_TWO_STREAM_MAX_ENVS = 4096
+# Two independent sub-networks of one model on two HIP streams (the CTS family's encoders / heads; PPO's actor | critic pair only when the grouped kernels of
+# modules/fused.py:pair_forward do not apply).  Round 3 found that with two chains of hipBLASLt GEMMs in flight the first iteration never finishes once the GEMMs
+# see more than 24576 rows (profiles/r3_kernel_scaling.txt section 3: 8192 envs x 24 steps / 4 mini-batches; 4096 envs = 24576 rows is what every BASELINE
+# configuration has per GPU and runs) — the cause was never established (no reproducer outside the whole job), so the mode is gated on the ROWS the concurrent
+# GEMMs see (mini-batch rows in update(), envs in act()), not on the env count: 4096 envs with 1 or 2 mini-batches is 98304 / 49152 rows.
+# PPO itself no longer forks a stream: actor and critic layers are grouped launches (round 4).  GO2_TWO_STREAMS=0 switches the fork off everywhere.
+_TWO_STREAMS = os.environ.get("GO2_TWO_STREAMS", "1") == "1"
+_TWO_STREAM_MAX_ROWS = 24576
 _ADAM_IMPL = {"foreach": True} if os.environ.get("GO2_ADAM", "fused") == "foreach" else {"fused": True}
 
 
@@ -73,9 +73,7 @@ class _RolloutHeads:
         """-> (main_fn(), side_fn()) with side_fn on a second HIP stream when on a GPU: the actor and the critic are independent
         networks, so their GEMMs and the many small element-wise kernels between them overlap (also inside a captured graph, where
         the fork / join become graph dependencies; autograd runs each backward on its forward's stream)."""
-        st = getattr(self, "storage", None)
-        small = st is None or getattr(st, "num_envs", 0) <= _TWO_STREAM_MAX_ENVS or os.environ.get("GO2_TWO_STREAMS") == "force"
-        if not (enabled and _TWO_STREAMS and small and str(self.device).startswith("cuda")):
+        if not (enabled and _TWO_STREAMS and self._two_stream_rows_ok() and str(self.device).startswith("cuda")):
             return main_fn(), side_fn()
         cur = torch.cuda.current_stream()
         if self._side is None:
@@ -90,6 +88,24 @@ class _RolloutHeads:
         a = main_fn()
         cur.wait_stream(self._side)
         return a, b
+
+    def _two_stream_rows_ok(self):
+        st = getattr(self, "storage", None)
+        if st is None:
+            return True
+        mb = st.num_envs * st.num_transitions_per_env // max(1, int(getattr(self, "num_mini_batches", 1)))
+        return max(st.num_envs, mb) <= _TWO_STREAM_MAX_ROWS
+
+    def _actor_critic(self, ac, obs, cobs):
+        """-> (ac.actor(obs), ac.evaluate(cobs)).  A plain ActorCritic of two Linear / ELU MLPs with the same hidden widths: ONE autograd node whose layers are
+        grouped launches over both networks (modules/fused.py:_FusedPair, include/go2nn.h ABI 3) — no second stream.  Anything else: the two modules one by
+        one, on two streams where that is safe."""
+        if type(ac) is _AC and torch.is_grad_enabled():
+            from ..modules import fused
+            out = fused.pair_forward(ac.actor, ac.critic, obs, cobs)
+            if out is not None:
+                return out
+        return self._pair(lambda: ac.actor(obs), lambda: ac.evaluate(cobs), enabled=self._capture)
 
     # The two per-step element-wise heads of the rollout as library kernels (go2sim_act_head, go2sim_store_transition): sampling +
     # log-prob + the storage rows in one launch, reward bootstrap + done copy in another, instead of ~23 small launches.
@@ -332,7 +348,7 @@ class PPO(_RolloutHeads):
     def _losses(self, obs_b, cobs_b, act_b, tv_b, adv_b, ret_b, old_lp_b, old_mu_b, old_sig_b):
         ac = self.actor_critic
         if self.fused_loss:
-            mu_b, val_b = self._pair(lambda: ac.actor(obs_b), lambda: ac.evaluate(cobs_b), enabled=self._capture)
+            mu_b, val_b = self._actor_critic(ac, obs_b, cobs_b)
             loss, stats = _FusedPPOLoss.apply(mu_b, ac.std, val_b, self, act_b, tv_b, adv_b, ret_b, old_lp_b, old_mu_b, old_sig_b)
             return loss, stats[1], stats[0], stats[2]
         ac.update_distribution(obs_b)     # the reference calls act() here and discards the sample (ppo.py:131)
@@ -401,7 +417,7 @@ class PPO(_RolloutHeads):
             # the loss kernel already holds d loss / d (mu, std, value): seed the backward pass of the two networks with them directly
             # (loss.backward() through the autograd.Function costs a clone and three multiplications by the unit upstream gradient)
             ac = self.actor_critic
-            mu_b, val_b = self._pair(lambda: ac.actor(batch[0]), lambda: ac.evaluate(batch[1]), enabled=self._capture)
+            mu_b, val_b = self._actor_critic(ac, batch[0], batch[1])
             stats, gmu, gstd, gval = _FusedPPOLoss.kernel(self, mu_b, ac.std, val_b, *batch[2:])
             self.optimizer.zero_grad(set_to_none=True)
             self._acc.add_(stats[:2])             # [surrogate, value loss]; read back swapped in _update_graphs (issued before the backward pass: off its tail)

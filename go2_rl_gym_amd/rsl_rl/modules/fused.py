@@ -289,3 +289,111 @@ class FusedSequential(nn.Sequential):
                 x = m(x)
                 i += 1
         return x
+
+
+# ---- both networks as ONE autograd node (round 4) --------------------------------------------------------------------------------------------------
+# PPO.update evaluates the actor and the critic on the same mini-batch rows (ppo.py:131-133).  As two nodes their layers are separate launches — on two HIP
+# streams the pair takes twice one network's time (profiles/r3_gemm_bench.txt) and needs the second stream.  _FusedPair issues every layer of BOTH networks as
+# one grouped launch (include/go2nn.h ABI 3: go2nn_linear_elu_forward_group / _backward_input_group / _backward_weight_group; the weight gradients read their
+# operands straight from global memory into MFMA registers), and finishes every fixed-order reduction of both backward passes with ONE go2nn_sum_rows launch.
+_PAIR = os.environ.get("GO2_MLP_PAIR", "1") == "1"       # 0: one node per network (round 3)
+
+
+class _FusedPair(torch.autograd.Function):
+    """(x_a, x_c) -> (actor(x_a), critic(x_c)) for two MLPs [Linear -> ELU] x H -> Linear(narrow) with the same hidden widths.
+    args: x_a, x_c, H, then the actor's w1, b1, ..., w_out, b_out and the critic's."""
+
+    @staticmethod
+    def forward(ctx, xa, xc, H, *params):
+        from ..._nn import Go2nnFwdJob
+        n = 2 * (H + 1)
+        P = (params[:n], params[n:])
+        ws = [q[0::2] for q in P]
+        bs = [q[1::2] for q in P]
+        p = lambda t: t.data_ptr()
+        stream = C.c_void_p(torch.cuda.current_stream(xa.device).cuda_stream) if xa.is_cuda else None
+        acts = [[xa], [xc]]
+        for l in range(H):
+            ys = [torch.empty(acts[j][-1].shape[0], ws[j][l].shape[0], device=xa.device, dtype=xa.dtype) for j in range(2)]
+            jobs = (Go2nnFwdJob * 2)(*[Go2nnFwdJob(p(acts[j][-1]), p(ws[j][l]), p(bs[j][l]), p(ys[j]), acts[j][-1].shape[0], ws[j][l].shape[1], ws[j][l].shape[0]) for j in range(2)])
+            _check(_NN.go2nn_linear_elu_forward_group(jobs, 2, stream), "go2nn_linear_elu_forward_group", _NN)
+            for j in range(2):
+                acts[j].append(ys[j])
+        ctx.save_for_backward(*acts[0], *acts[1], *ws[0], *ws[1])
+        ctx.H = H
+        return torch.addmm(bs[0][H], acts[0][-1], ws[0][H].t()), torch.addmm(bs[1][H], acts[1][-1], ws[1][H].t())
+
+    @staticmethod
+    def backward(ctx, ga, gc):
+        from ..._nn import Go2nnBwdInJob, Go2nnBwdWJob, Go2nnSumJob
+        H = ctx.H
+        sv = ctx.saved_tensors
+        acts = (sv[:H + 1], sv[H + 1:2 * (H + 1)])
+        ws = (sv[2 * (H + 1):3 * (H + 1)], sv[3 * (H + 1):])
+        gouts = (ga.contiguous(), gc.contiguous())
+        dev, dt = ga.device, ga.dtype
+        p = lambda t: t.data_ptr()
+        vp = lambda t: C.c_void_p(t.data_ptr())
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if ga.is_cuda else None
+        new = lambda *shape: torch.empty(*shape, device=dev, dtype=dt)
+        B = gouts[0].shape[0]
+        sums = []          # (partial rows, result, nrows, ncols) of both networks: ONE go2nn_sum_rows launch at the end
+        grads = [[None] * (2 * (H + 1)) for _ in range(2)]
+        gz, gb = [None, None], [None, None]
+        for j in range(2):      # the narrow heads: input gradient, ELU', weight / bias gradients, the last hidden layer's bias gradient in one pass each
+            y, w_out = acts[j][H], ws[j][H]
+            Cn, K = w_out.shape
+            n = _NN.go2nn_head_backward_workspace(B, Cn, K)
+            if n < 0:
+                raise RuntimeError("go2nn_head_backward_workspace: %s" % _NN.go2nn_last_error().decode())
+            gz[j], tot, wk = torch.empty_like(y), new((Cn + 1) * K + Cn), new(int(n))
+            _check(_NN.go2nn_head_backward(vp(gouts[j]), vp(y), vp(w_out), vp(gz[j]), None, vp(wk), B, Cn, K, stream), "go2nn_head_backward", _NN)
+            sums.append((wk, tot, _NN.go2nn_head_backward_rows(B, Cn, K), (Cn + 1) * K + Cn))
+            grads[j][2 * H], grads[j][2 * H + 1] = tot[:Cn * K].view(Cn, K), tot[(Cn + 1) * K:]
+            gb[j] = tot[Cn * K:(Cn + 1) * K]
+        for l in range(H - 1, -1, -1):          # gz[j]: gradient at layer l's pre-activation; gb[j]: its column sums
+            shp = [ws[j][l].shape for j in range(2)]
+            wj = (Go2nnBwdWJob * 2)(*[Go2nnBwdWJob(p(gz[j]), p(acts[j][l]), None, B, shp[j][0], shp[j][1]) for j in range(2)])
+            rows = _NN.go2nn_linear_backward_weight_group_rows(wj, 2)
+            if rows <= 0:
+                raise RuntimeError("go2nn_linear_backward_weight_group_rows: %s" % _NN.go2nn_last_error().decode())
+            for j in range(2):
+                wk, dw = new(rows * shp[j][0] * shp[j][1]), torch.empty_like(ws[j][l])
+                wj[j].workspace = p(wk)
+                sums.append((wk, dw, rows, shp[j][0] * shp[j][1]))
+                grads[j][2 * l], grads[j][2 * l + 1] = dw, gb[j]
+            _check(_NN.go2nn_linear_backward_weight_group(wj, 2, stream), "go2nn_linear_backward_weight_group", _NN)
+            if l > 0:
+                gzp = [torch.empty_like(acts[j][l]) for j in range(2)]
+                ij = (Go2nnBwdInJob * 2)()
+                for j in range(2):
+                    r = _NN.go2nn_linear_backward_input_group_rows(B, shp[j][0], shp[j][1])
+                    wk, gbp = new(r * shp[j][1]), new(shp[j][1])
+                    ij[j] = Go2nnBwdInJob(p(gz[j]), p(ws[j][l]), p(acts[j][l]), p(gzp[j]), p(wk), B, shp[j][0], shp[j][1])
+                    sums.append((wk, gbp, r, shp[j][1]))
+                    gb[j] = gbp
+                _check(_NN.go2nn_linear_backward_input_group(ij, 2, stream), "go2nn_linear_backward_input_group", _NN)
+                gz = gzp
+        gx = [gz[j].mm(ws[j][0]) if ctx.needs_input_grad[j] else None for j in range(2)]
+        for k in range(0, len(sums), 16):
+            chunk = sums[k:k + 16]
+            arr = (Go2nnSumJob * len(chunk))(*[Go2nnSumJob(t[0].data_ptr(), t[1].data_ptr(), t[2], t[3]) for t in chunk])
+            _check(_NN.go2nn_sum_rows(arr, len(chunk), stream), "go2nn_sum_rows", _NN)
+        return (gx[0], gx[1], None, *grads[0], *grads[1])
+
+
+def pair_forward(seq_a, seq_c, xa, xc):
+    """-> (seq_a(xa), seq_c(xc)) through _FusedPair, or None when the two modules are not two fusable MLPs with the same hidden widths (the caller then
+    evaluates them one by one)."""
+    if not (_PAIR and _MLP_NODE and _LIB is not None and _NN is not None and torch.is_grad_enabled() and isinstance(seq_a, FusedSequential) and isinstance(seq_c, FusedSequential)):
+        return None
+    if not (xa.dim() == 2 and xc.dim() == 2 and xa.dtype == torch.float32 and xc.dtype == torch.float32 and xa.shape[0] == xc.shape[0] and xa.device == xc.device
+            and (xa.is_cuda or (_LIB.go2sim_is_device_library() == 0 and _NN.go2nn_is_device_library() == 0))):
+        return None
+    la, lc = _whole_mlp(list(seq_a)), _whole_mlp(list(seq_c))
+    if la is None or lc is None or len(la) != len(lc) or any(a.out_features != c.out_features for a, c in zip(la[:-1], lc[:-1])):
+        return None
+    if any(m.in_features < 4 for m in la + lc) or any(m.out_features < 2 for m in la[:-1] + lc[:-1]):
+        return None
+    cont = lambda t: t if t.is_contiguous() else t.contiguous()
+    return _FusedPair.apply(cont(xa), cont(xc), len(la) - 1, *[t for m in la for t in (m.weight, m.bias)], *[t for m in lc for t in (m.weight, m.bias)])

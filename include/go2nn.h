@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define GO2NN_ABI_VERSION 2      /* 2: + the learner-side kernels (go2nn_head_backward, go2nn_linear_*) */
+#define GO2NN_ABI_VERSION 3      /* 2: + the learner-side kernels (go2nn_head_backward, go2nn_linear_*); 3: + the grouped (actor + critic) layer calls */
 #define GO2NN_MAX_LAYERS 6
 #define GO2NN_MAX_WIDTH 512      /* widest layer input / output (LDS holds two 32-row activation tiles of this width) */
 #define GO2NN_EINVAL (-22)
@@ -88,6 +88,27 @@ int64_t go2nn_linear_backward_workspace(int32_t M, int32_t C, int32_t Kin);
 int go2nn_linear_backward_input(const float* gz, const float* w, const float* y_prev, float* gz_prev, float* gb_prev, float* workspace,
                                 int32_t M, int32_t C, int32_t Kin, void* stream);
 int go2nn_linear_backward_weight(const float* gz, const float* x, float* dw, float* workspace, int32_t M, int32_t C, int32_t Kin, void* stream);
+
+
+/* ---- ABI 3: one layer of SEVERAL independent MLPs per launch (PPO.update evaluates the same layer of the actor and of the critic back to back:
+ * ppo.py:131-133 -> actor_critic.py:119-136; as two launches on two HIP streams the pair takes twice one network's time and needs the second stream).
+ * A group is 1..GO2NN_MAX_GROUP jobs; the jobs' tiles form one grid.  Same arithmetic and the same fixed summation orders as the single calls.
+ *   forward:       y = elu(x W^T + b) per job (M, K may differ between the jobs; the 45- and 263-wide input layers are one group)
+ *   input grad:    gz_prev = (gz W) * elu'(y_prev); column partial sums of gz_prev are left in the job's `workspace` as
+ *                  go2nn_linear_backward_input_group_rows(M, C, Kin) rows of Kin columns (the caller finishes them with go2nn_sum_rows)
+ *   weight grad:   row-slice partials of dW = gz^T x are left in the job's `workspace` as go2nn_linear_backward_weight_group_rows(jobs, njobs) rows of
+ *                  C * Kin columns (every job of a group has the same M); operands go from global memory straight into MFMA registers (both are
+ *                  contiguous along the output index), the four waves of a workgroup split the rows of one output tile
+ * workspace floats per job: rows * Kin resp. rows * C * Kin. */
+#define GO2NN_MAX_GROUP 2
+typedef struct Go2nnFwdJob { const float *x, *w, *b; float* y; int32_t M, K, N; } Go2nnFwdJob;
+typedef struct Go2nnBwdInJob { const float *gz, *w, *y_prev; float *gz_prev, *workspace; int32_t M, C, Kin; } Go2nnBwdInJob;
+typedef struct Go2nnBwdWJob { const float *gz, *x; float* workspace; int32_t M, C, Kin; } Go2nnBwdWJob;
+int go2nn_linear_elu_forward_group(const Go2nnFwdJob* jobs, int32_t njobs, void* stream);
+int32_t go2nn_linear_backward_input_group_rows(int32_t M, int32_t C, int32_t Kin);
+int go2nn_linear_backward_input_group(const Go2nnBwdInJob* jobs, int32_t njobs, void* stream);
+int32_t go2nn_linear_backward_weight_group_rows(const Go2nnBwdWJob* jobs, int32_t njobs);
+int go2nn_linear_backward_weight_group(const Go2nnBwdWJob* jobs, int32_t njobs, void* stream);
 
 #ifdef __cplusplus
 }

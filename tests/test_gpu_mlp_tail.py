@@ -52,3 +52,25 @@ def test_sum_rows_on_gpu():
     torch.cuda.synchronize()
     for u, v in zip(a, b):
         assert torch.equal(u, v)
+
+
+from test_mlp_tail import check_linear_group, pair_vs_autograd  # noqa: E402
+
+
+@pytest.mark.parametrize("M,s0,s1", [(70, (45, 96), (263, 96)), (777, (37, 70), (64, 70)), (1000, (130, 33), (8, 33)), (3000, (45, 512), (263, 512)),
+                                     (24576, (45, 512), (263, 512)), (24576, (512, 256), (512, 256)), (24576, (256, 128), (256, 128)), (6144, (512, 256), (512, 256)),
+                                     (4099, (260, 132), (64, 132)), (300, (100, 300), (100, 300))])
+def test_linear_group_on_gpu(M, s0, s1):
+    """the grouped layer calls (go2nn_gemm3.h): every tile shape, K tails (45 / 263 / 37 / 130), ragged M and N, jobs whose tile shapes differ (separate
+    launches), input gradients that fall back to the single-network kernels (Kin not a multiple of 4); bit-reproducible from launch to launch"""
+    lib = _nn.load_nn()
+    a = check_linear_group(lib, M, s0, s1, device="cuda:0")
+    b = check_linear_group(lib, M, s0, s1, device="cuda:0")
+    torch.cuda.synchronize()
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("B", [24576, 1000])
+def test_pair_node_on_gpu(B):
+    pair_vs_autograd(_nn.load_nn(), load_hip(), "cuda:0", B=B, dims_a=(45, 512, 256, 128, 12), dims_c=(263, 512, 256, 128, 1), atol=2e-6)

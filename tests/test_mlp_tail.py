@@ -207,3 +207,120 @@ def test_whole_mlp_node_edge_cases():
         fused.set_library(None); fused.set_nn_library(None)
     for a, b in zip(want, [p.grad for p in net.parameters()]):
         np.testing.assert_allclose(b.numpy(), a.numpy(), atol=2e-5, rtol=1e-4)
+
+
+# ---- ABI 3: the grouped layer calls (one launch for the actor's and the critic's layer; go2_rl_gym_amd/csrc/go2nn_gemm3.h on the GPU) -----------
+GROUP_SHAPES = [(70, (45, 96), (263, 96)), (130, (37, 70), (64, 70)), (65, (130, 33), (8, 33)), (96, (64, 40), (64, 72))]      # M, (K, N) of job 0, of job 1
+
+
+def check_linear_group(lib, M, s0, s1, device="cpu"):
+    """forward, input gradient and weight gradient of two layers as ONE grouped call each, against float64 torch (same bounds as check_linear)"""
+    from go2_rl_gym_amd._nn import Go2nnBwdInJob, Go2nnBwdWJob, Go2nnFwdJob, Go2nnSumJob
+    g = torch.Generator().manual_seed(M * 7 + s0[0] * 3 + s1[0])
+    nan = lambda *shape: torch.full(shape, float("nan"), device=device)
+    jobs = []
+    for K, N in (s0, s1):
+        x, w, b = torch.randn(M, K, generator=g).to(device), (torch.randn(N, K, generator=g) / np.sqrt(K)).to(device), torch.randn(N, generator=g).to(device)
+        gz, yp = torch.randn(M, N, generator=g).to(device), torch.nn.functional.elu(torch.randn(M, K, generator=g)).to(device)
+        jobs.append(dict(K=K, N=N, x=x, w=w, b=b, gz=gz, yp=yp, y=nan(M, N), gzp=nan(M, K), gbp=nan(K), dw=nan(N, K)))
+    st = _stream(jobs[0]["x"])
+    p = lambda t: t.data_ptr()
+    fj = (Go2nnFwdJob * 2)(*[Go2nnFwdJob(p(j["x"]), p(j["w"]), p(j["b"]), p(j["y"]), M, j["K"], j["N"]) for j in jobs])
+    assert lib.go2nn_linear_elu_forward_group(fj, 2, st) == 0, lib.go2nn_last_error().decode()
+    sums, keep = [], []
+    ij = (Go2nnBwdInJob * 2)()
+    for k, j in enumerate(jobs):
+        r = lib.go2nn_linear_backward_input_group_rows(M, j["N"], j["K"])
+        assert r > 0
+        ws = nan(r * j["K"]); keep.append(ws)
+        ij[k] = Go2nnBwdInJob(p(j["gz"]), p(j["w"]), p(j["yp"]), p(j["gzp"]), p(ws), M, j["N"], j["K"])
+        sums.append((ws, j["gbp"], r, j["K"]))
+    assert lib.go2nn_linear_backward_input_group(ij, 2, st) == 0, lib.go2nn_last_error().decode()
+    wj = (Go2nnBwdWJob * 2)(*[Go2nnBwdWJob(p(j["gz"]), p(j["yp"]), None, M, j["N"], j["K"]) for j in jobs])
+    rows = lib.go2nn_linear_backward_weight_group_rows(wj, 2)
+    assert rows > 0, lib.go2nn_last_error().decode()
+    for k, j in enumerate(jobs):
+        ws = nan(rows * j["N"] * j["K"]); keep.append(ws)
+        wj[k].workspace = p(ws)
+        sums.append((ws, j["dw"], rows, j["N"] * j["K"]))
+    assert lib.go2nn_linear_backward_weight_group(wj, 2, st) == 0, lib.go2nn_last_error().decode()
+    arr = (Go2nnSumJob * len(sums))(*[Go2nnSumJob(t[0].data_ptr(), t[1].data_ptr(), t[2], t[3]) for t in sums])
+    assert lib.go2nn_sum_rows(arr, len(sums), st) == 0
+    out = []
+    for j in jobs:
+        K, N, x, w, b, gz, yp = (j[k] for k in ("K", "N", "x", "w", "b", "gz", "yp"))
+        ref = torch.nn.functional.elu(x.double().mm(w.double().t()) + b.double())
+        np.testing.assert_allclose(j["y"].cpu().double().numpy(), ref.cpu().numpy(), atol=3e-6 * np.sqrt(K) + 2e-6, rtol=2e-6)
+        r_gzp = gz.double().mm(w.double()) * torch.where(yp > 0, torch.ones_like(yp), yp + 1.0).double()
+        np.testing.assert_allclose(j["gzp"].cpu().double().numpy(), r_gzp.cpu().numpy(), atol=3e-6 * np.sqrt(N) + 2e-6, rtol=2e-6)
+        np.testing.assert_allclose(j["gbp"].cpu().double().numpy(), r_gzp.sum(0).cpu().numpy(), atol=4e-6 * np.sqrt(M * N) + 1e-5, rtol=2e-5)
+        np.testing.assert_allclose(j["dw"].cpu().double().numpy(), gz.double().t().mm(yp.double()).cpu().numpy(), atol=4e-6 * np.sqrt(M) + 1e-5, rtol=2e-5)
+        out += [j["y"], j["gzp"], j["gbp"], j["dw"]]
+    return out
+
+
+@pytest.mark.parametrize("M,s0,s1", GROUP_SHAPES)
+def test_linear_group_matches_torch(M, s0, s1):
+    check_linear_group(load_nn_emu(), M, s0, s1)
+
+
+def test_group_calls_refuse_bad_arguments():
+    from go2_rl_gym_amd._nn import Go2nnBwdWJob, Go2nnFwdJob
+    lib = load_nn_emu()
+    t = torch.zeros(64)
+    j = (Go2nnFwdJob * 3)(*[Go2nnFwdJob(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 2, 2, 2)] * 3)
+    assert lib.go2nn_linear_elu_forward_group(j, 3, None) < 0 and lib.go2nn_linear_elu_forward_group(None, 1, None) < 0 and lib.go2nn_linear_elu_forward_group(j, 0, None) < 0
+    j[0].x = None
+    assert lib.go2nn_linear_elu_forward_group(j, 1, None) < 0 and b"job 0" in lib.go2nn_last_error()
+    w = (Go2nnBwdWJob * 2)(Go2nnBwdWJob(t.data_ptr(), t.data_ptr(), None, 4, 4, 4), Go2nnBwdWJob(t.data_ptr(), t.data_ptr(), None, 4, 4, 4))
+    assert lib.go2nn_linear_backward_weight_group(w, 2, None) < 0          # no workspace
+
+
+def pair_vs_autograd(nn_lib, sim_lib, device, B=200, dims_a=(45, 64, 32, 12), dims_c=(263, 64, 32, 1), atol=2e-6):
+    """modules/fused.py:pair_forward (one autograd node over both MLPs, grouped layer launches) against the same parameters under plain autograd:
+    both outputs, every parameter gradient, both input gradients"""
+    from go2_rl_gym_amd.rsl_rl.modules import fused
+    from go2_rl_gym_amd.rsl_rl.modules.actor_critic import _mlp
+    torch.manual_seed(5)
+    na, nc = _mlp(dims_a[0], list(dims_a[1:-1]), dims_a[-1], "elu").to(device), _mlp(dims_c[0], list(dims_c[1:-1]), dims_c[-1], "elu").to(device)
+    xa, xc = torch.randn(B, dims_a[0], device=device, requires_grad=True), torch.randn(B, dims_c[0], device=device, requires_grad=True)
+    ta, tc = torch.randn(B, dims_a[-1], device=device), torch.randn(B, dims_c[-1], device=device)
+    res = []
+    for on in (False, True):
+        fused.set_library(sim_lib if on else None); fused.set_nn_library(nn_lib if on else None)
+        try:
+            for t in (xa, xc):
+                t.grad = None
+            na.zero_grad(); nc.zero_grad()
+            out = fused.pair_forward(na, nc, xa, xc) if on else None
+            assert (out is not None) == on
+            ya, yc = out if on else (na(xa), nc(xc))
+            if on:
+                assert type(ya.grad_fn).__name__ == "_FusedPairBackward" and ya.grad_fn is yc.grad_fn
+            (((ya - ta) ** 2).mean() + 0.7 * ((yc - tc) ** 2).mean()).backward()
+            res.append(([ya.detach().clone(), yc.detach().clone()], [p.grad.clone() for p in list(na.parameters()) + list(nc.parameters())] + [xa.grad.clone(), xc.grad.clone()]))
+        finally:
+            fused.set_library(None); fused.set_nn_library(None)
+    for a, b in zip(res[0][0], res[1][0]):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), atol=1e-5)
+    for a, b in zip(res[0][1], res[1][1]):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), atol=atol, rtol=2e-3)
+
+
+@pytest.mark.parametrize("dims_a,dims_c", [((45, 64, 32, 12), (263, 64, 32, 1)), ((20, 16, 3), (9, 16, 1))])
+def test_pair_node_matches_autograd(dims_a, dims_c):
+    pair_vs_autograd(load_nn_emu(), load_oracle(), "cpu", dims_a=dims_a, dims_c=dims_c)
+
+
+def test_pair_node_is_not_taken_for_different_hidden_widths():
+    from go2_rl_gym_amd.rsl_rl.modules import fused
+    from go2_rl_gym_amd.rsl_rl.modules.actor_critic import _mlp
+    fused.set_library(load_oracle()); fused.set_nn_library(load_nn_emu())
+    try:
+        a, c, c2 = _mlp(8, [16, 8], 4, "elu"), _mlp(6, [16, 12], 1, "elu"), _mlp(6, [16], 1, "elu")
+        x, y = torch.randn(5, 8), torch.randn(5, 6)
+        assert fused.pair_forward(a, c, x, y) is None and fused.pair_forward(a, c2, x, y) is None and fused.pair_forward(a, a, x, x[:4]) is None
+        with torch.no_grad():
+            assert fused.pair_forward(a, a, x, x) is None
+    finally:
+        fused.set_library(None); fused.set_nn_library(None)

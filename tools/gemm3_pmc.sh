@@ -1,0 +1,38 @@
+#!/bin/bash
+# TOOL: SQ counters of one grouped learner GEMM (build/gemm3_bench ... one).  On the GPU box: bash tools/gemm3_pmc.sh <tag> f|i|w <layer 1|2|3>  -> gpurun_out/pmc/gemm3_<tag>.json
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+TAG=$1; shift
+mkdir -p $R/gpurun_out/pmc
+cd /tmp && export TMPDIR=/tmp
+P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU"
+P2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA"
+P3="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"
+i=0
+for P in "$P1" "$P2" "$P3"; do
+  i=$((i+1)); rm -rf /tmp/gp_$i
+  timeout 200 rocprofv3 --kernel-trace --pmc $P --output-format csv -d /tmp/gp_$i -o gp -- $R/build/gemm3_bench $R/go2_rl_gym_amd/libgo2nn_hip.so 24576 one "$@" > /tmp/gp_$i.log 2>&1 || tail -5 /tmp/gp_$i.log
+done
+python3 - "$R/gpurun_out/pmc/gemm3_$TAG.json" "$@" <<'PY'
+import csv, glob, json, sys, collections
+out = {"args": sys.argv[2:]}
+for i in (1, 2, 3):
+    fs = glob.glob("/tmp/gp_%d/*counter_collection.csv" % i)
+    if not fs:
+        continue
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(fs[0])):
+        if "go2nn_gemm3_kernel" in r["Kernel_Name"] or "go2nn_wgrad_kernel" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            out["kernel"], out["vgpr"], out["agpr"], out["lds"] = r["Kernel_Name"][:80], int(r["VGPR_Count"]), int(r["Accum_VGPR_Count"]), int(r["LDS_Block_Size"])
+    for k, v in acc.items():
+        out[k] = sum(v) / len(v)
+    fs = glob.glob("/tmp/gp_%d/*kernel_trace.csv" % i)
+    if fs:
+        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(fs[0])) if "go2nn_gemm3_kernel" in r["Kernel_Name"] or "go2nn_wgrad_kernel" in r["Kernel_Name"]]
+        out["us_pass%d" % i] = sum(d) / len(d) / 1e3
+if "GRBM_GUI_ACTIVE" in out and "us_pass3" in out:
+    out["clock_GHz"] = out["GRBM_GUI_ACTIVE"] / out["us_pass3"] / 1e3
+    out["mfma_busy_frac_of_active_cycles"] = out.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024 / out["GRBM_GUI_ACTIVE"]       # 1024 SIMDs
+json.dump(out, open(sys.argv[1], "w"), indent=1)
+print(json.dumps(out))
+PY
