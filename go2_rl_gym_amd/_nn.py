@@ -127,6 +127,8 @@ class PackedMlp:
         return all(self.desc.weight[l] == w.data_ptr() and self.desc.bias[l] == b.data_ptr() for l, (w, b) in enumerate(self.layers))
 
     def pack(self):
+        if not self.still_valid():
+            raise RuntimeError("the MLP's parameter tensors were re-allocated after the policy kernel was built (rebuild PolicyKernel)")
         rc = self.lib.go2nn_pack(C.byref(self.desc), C.c_void_p(self.packed.data_ptr()), self._stream())
         if rc != 0:
             raise RuntimeError("go2nn_pack failed: %s" % self.lib.go2nn_last_error().decode())
@@ -151,8 +153,11 @@ class PolicyKernel:
 
     @staticmethod
     def supports(actor_critic):
-        return (hasattr(actor_critic, "actor") and hasattr(actor_critic, "critic") and hasattr(actor_critic, "std") and mlp_layers(actor_critic.actor) is not None
-                and mlp_layers(actor_critic.critic) is not None and actor_critic.std.dim() == 1)
+        if not (hasattr(actor_critic, "actor") and hasattr(actor_critic, "critic") and hasattr(actor_critic, "std") and actor_critic.std.dim() == 1):
+            return False
+        la, lc = mlp_layers(actor_critic.actor), mlp_layers(actor_critic.critic)
+        # the head of go2nn_policy_act: up to 32 actions, a scalar value (the loss head go2sim_ppo_loss takes up to 16 actions; every go2 task has 12)
+        return la is not None and lc is not None and la[-1][0].shape[0] <= 32 and lc[-1][0].shape[0] == 1 and actor_critic.std.shape[0] == la[-1][0].shape[0]
 
     def pack(self):
         self.actor.pack(); self.critic.pack()

@@ -80,9 +80,8 @@ struct GmStage {
       edge = r0 + R > n;
     }
   }
-  // one 16-byte piece (p < P) of the k-tile starting at k0; the pieces of a tile are issued one by one BETWEEN the MFMA groups of the previous tile
-  // (see the kernel): issued together, the loads of all the workgroups of the chip — which run in step — form a burst that saturates the L2 -> CU path,
-  // every wave sits in its load-issue stall while the MFMA pipes idle, and then every wave multiplies while the memory path idles
+  // one 16-byte piece (p < P) of the k-tile starting at k0 (the kernel issues all pieces of the next tile together, in front of the current tile's MFMAs;
+  // issuing them one by one between the MFMA groups was measured slower: DESIGN 10.0)
   template <int p>
   __device__ __forceinline__ void load_piece(int k0, int tid) {
     if (p == 0) okm = 0;
@@ -156,12 +155,11 @@ __device__ __forceinline__ void gm_issue(SA& sa, SB& sb, int k0, int tid) {
   }
 }
 
-template <int TM, int TN, bool AKC, bool BKC, int EPI, bool VEC, int BK, int WM = 2>
-__global__ void __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(3))) go2nn_gemm_kernel(const GemmArgs g) {      // (>= 3 waves per SIMD: the 128 x 128 tile's
-                                                                                                                                        // 64 accumulators + staging would otherwise take 184 registers = 2 waves)
-  // WM x 2 waves; a wave owns TM x TN 32x32 tiles: workgroup tile 32 WM TM x 64 TN.  WM = 2: the 256-thread shapes; WM = 6, TM = 1: 192 x 128 with twelve waves —
-  // the rows of three 64 x 128 workgroups behind ONE staged B tile (the L1 gives co-resident workgroups nothing: r3_gemm_mem_counters_L2_forward.json)
-  constexpr int NTHR = 128 * WM, NW = 2 * WM, BM = 32 * WM * TM, BN = 64 * TN;
+template <int TM, int TN, bool AKC, bool BKC, int EPI, bool VEC, int BK>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) go2nn_gemm_kernel(const GemmArgs g) {      // (>= 3 waves per SIMD: the 128 x 128 tile's
+                                                                                                                                  // 64 accumulators + staging would otherwise take 184 registers = 2 waves)
+  // 2 x 2 waves; a wave owns TM x TN 32x32 tiles: workgroup tile 64 TM x 64 TN.  (192-row tiles and a twelve-wave 192 x 128 shape were measured and dropped: DESIGN 10.0)
+  constexpr int WM = 2, NTHR = 256, NW = 4, BM = 64 * TM, BN = 64 * TN;
   using SA = GmStage<BM, AKC, VEC, BK, NTHR>; using SB = GmStage<BN, BKC, VEC, BK, NTHR>;
   constexpr int ASZ = SA::LDS_FLOATS, BSZ = SB::LDS_FLOATS, LOOP_LDS = 2 * (ASZ + BSZ), EPI_LDS = NW * 32 * 32 * TN;
   __shared__ __attribute__((aligned(16))) float lds[LOOP_LDS > EPI_LDS ? LOOP_LDS : EPI_LDS];
@@ -305,11 +303,11 @@ __global__ void __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(3
 // tile shape (TM, TN in 32x32 tiles per wave; workgroup tile 64 TM x 64 TN) for an M x N output with M large: 128 x 128 (16-deep k-tiles, 32 KB of LDS)
 // for outputs of >= 512 columns — at M = 24576 that is 768 workgroups = 3 per CU, all resident, at 8 B / clk / CU from the L2; 64 x 128 (48 KB: three
 // workgroups per CU, 768 of them for 256 columns) below that; 64 x 64 for narrow outputs or when 128 columns would mostly be padding
-static inline int gm_tile_rows(int tm) { return tm == 6 ? 192 : 64 * tm; }      // tm = 6 stands for the twelve-wave shape (6 x 2 waves of one row tile each)
+static inline int gm_tile_rows(int tm) { return 64 * tm; }
 static inline int gm_pick(int n) { return (n + 127) / 128 * 128 <= (n + 63) / 64 * 64 ? 2 : 1; }
 static inline void gemm_tile(int M, int N, int* tm, int* tn) {
   static const char* const env = getenv("GO2NN_TILE");        // tools/gemm_bench.py: tile sweep (read once)
-  if (env && ((env[0] >= '1' && env[0] <= '3') || env[0] == '6') && env[1] >= '1' && env[1] <= '2') { *tm = env[0] - '0'; *tn = env[1] - '0'; return; }      // (6x: twelve waves, 192 rows)
+  if (env && env[0] >= '1' && env[0] <= '2' && env[1] >= '1' && env[1] <= '2') { *tm = env[0] - '0'; *tn = env[1] - '0'; return; }
   *tn = N > 128 ? gm_pick(N) : 1;
   *tm = (*tn == 2 && N >= 512 && M >= 512) ? 2 : 1;
 }

@@ -278,13 +278,6 @@ template <bool AKC, bool BKC, int EPI, bool VEC>
 static void gemm_dispatch2(int tm, int tn, const GemmArgs& g, int splits, hipStream_t st) {
   const dim3 grid(g.nbm * g.nbn, 1, splits), blk(GM_THREADS);
   const int bk = gemm_bk(tm, tn);
-  if constexpr (AKC) {        // twelve waves (768 threads): a k-contiguous A operand only, like the 192-row shape below
-    if (tm == 6 && tn == 2) { hipLaunchKernelGGL((go2nn_gemm_kernel<1, 2, AKC, BKC, EPI, VEC, 32, 6>), grid, dim3(768), 0, st, g); return; }
-  }
-  if constexpr (AKC) {        // 192-row tiles: only with a k-contiguous A operand (a k-strided one is staged R / 4 column quads per k-row: 192 / 4 does not divide 256 threads)
-    if (tm == 3 && tn == 2 && bk == 16) { hipLaunchKernelGGL((go2nn_gemm_kernel<3, 2, AKC, BKC, EPI, VEC, 16>), grid, blk, 0, st, g); return; }
-    if (tm == 3 && tn == 2)             { hipLaunchKernelGGL((go2nn_gemm_kernel<3, 2, AKC, BKC, EPI, VEC, 32>), grid, blk, 0, st, g); return; }
-  }
   if (tm == 2 && tn == 2 && bk == 16)      hipLaunchKernelGGL((go2nn_gemm_kernel<2, 2, AKC, BKC, EPI, VEC, 16>), grid, blk, 0, st, g);
   else if (tm == 2 && tn == 2)             hipLaunchKernelGGL((go2nn_gemm_kernel<2, 2, AKC, BKC, EPI, VEC, 32>), grid, blk, 0, st, g);
   else if (tm == 1 && tn == 2 && bk == 16) hipLaunchKernelGGL((go2nn_gemm_kernel<1, 2, AKC, BKC, EPI, VEC, 16>), grid, blk, 0, st, g);

@@ -545,7 +545,7 @@ __global__ void __launch_bounds__(256) go2_adam_norm_kernel(const Go2AdamLaunch 
   const int i = adam_locate(a, blockIdx.x), off = (blockIdx.x - a.first[i]) * GO2_ADAM_CHUNK, n = min(GO2_ADAM_CHUNK, a.t.numel[i] - off);
   const float* __restrict__ g = a.t.grad[i] + off;
   float s = 0.f;
-  if (adam_vec(a, i)) {
+  if (adam_vec(a, i) && n >= 4) {          // (a chunk of fewer than 4 elements — the critic's 1-element output bias — has no quad to load: element by element)
     const int nq = n >> 2;
     float4 x[4];
 #pragma unroll
@@ -579,7 +579,7 @@ __global__ void __launch_bounds__(256) go2_adam_step_kernel(const Go2AdamLaunch 
   const int nb = a.first[a.t.count];
   const int i = adam_locate(a, blockIdx.x), off = (blockIdx.x - a.first[i]) * GO2_ADAM_CHUNK, n = min(GO2_ADAM_CHUNK, a.t.numel[i] - off);
   float* __restrict__ p = a.t.param[i] + off; float* __restrict__ m = a.t.exp_avg[i] + off; float* __restrict__ v = a.t.exp_avg_sq[i] + off; const float* __restrict__ g = a.t.grad[i] + off;
-  const bool vec = adam_vec(a, i);
+  const bool vec = adam_vec(a, i) && n >= 4;
   const int nq = n >> 2;
   float4 g4[4], m4[4], v4[4], p4[4];
   if (vec) {        // the chunk's loads go out before the norm is re-reduced: they do not depend on it

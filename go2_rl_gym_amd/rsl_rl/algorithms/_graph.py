@@ -4,15 +4,11 @@ then replayed.  If the capture fails the step keeps running eagerly — slower, 
 With more than one rank a mini-batch step is TWO captured halves with the gradient all-reduce issued eagerly between their replays
 (ReducedStep + GradBucket): forward/backward/pack | RCCL all-reduce | unpack/LR decision/clip/Adam.  No collective is ever recorded
 into a HIP graph (no graph-captured communicator state, no mixing of captured and eager collectives on one communicator), at the
-price of one extra graph launch per mini-batch.  GO2_GRAPH_COLLECTIVES=1 records the all-reduce inside a single graph instead."""
+price of one extra graph launch per mini-batch (recording it inside the graph measured 0.6 % slower still with one rank, round 2, and is gone)."""
 import os
 
 import torch
 import torch.distributed as dist
-
-
-def collectives_in_graph():
-    return os.environ.get("GO2_GRAPH_COLLECTIVES", "0") == "1"
 
 
 class GradBucket:

@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.optim as optim
 
 from ..storage import RolloutStorageCTS
-from ._graph import CapturedStep, FusedClipAdam, GradBucket, ReducedStep, all_captured, collectives_in_graph
+from ._graph import CapturedStep, FusedClipAdam, GradBucket, ReducedStep, all_captured
 from .ppo import _ADAM_IMPL, _collectives_on, _FusedPPOLoss, _RolloutHeads, _world, allreduce_mean_bucket
 
 
@@ -290,8 +290,6 @@ class CTS(_RolloutHeads):
             kl_mean = self._bucket1.unpack(_world())
         else:
             kl_mean = self._kl
-            if _collectives_on():          # GO2_GRAPH_COLLECTIVES=1: the all-reduce recorded inside the graph
-                kl_mean = _allreduce_mean_grads(self._params1, _world(), kl_mean if self._adaptive() else None)
         if self._fused_adam1 is None:
             self._fused_adam1 = FusedClipAdam(self.lib, self.optimizer1, self._params1, self.max_grad_norm)
         if self._fused_adam1.usable and self._fused_adam1.step(kl_mean if self._adaptive() else None, self.desired_kl if self._adaptive() else 0.0):
@@ -322,8 +320,6 @@ class CTS(_RolloutHeads):
     def _student_back(self, split=False):
         if split:
             self._bucket2.unpack(_world())
-        elif _collectives_on():
-            _allreduce_mean_grads(self._params2, _world())
         if self._fused_adam2 is None:
             self._fused_adam2 = FusedClipAdam(self.lib, self.optimizer2, self._params2, self.max_grad_norm)
         if self._fused_adam2.usable and self._fused_adam2.step():
@@ -343,7 +339,7 @@ class CTS(_RolloutHeads):
             self._perm = {k: torch.empty((nmb * self._mb,) + tuple(self._flat[k].shape[1:]), device=self.device, dtype=self._flat[k].dtype) for k in self._KEYS}
             self._acc = torch.zeros(3 + self._NUM_POLICY_LOGS + self._NUM_STUDENT_LOGS, device=self.device)
             self._bucket1 = self._bucket2 = None
-            if _collectives_on() and not collectives_in_graph():     # two captured halves per slot, the gradient all-reduce eager between them
+            if _collectives_on():     # two captured halves per slot, the gradient all-reduce eager between them
                 mk = lambda front, back, bucket, name: [ReducedStep((lambda i=i: front(i, True)), (lambda: back(True)), bucket, enabled=self._capture, warmup=3 if i == 0 else 1,
                                                                     name="CTS %s step %d" % (name, i)) for i in range(nmb)]
                 self._steps = (mk(self._policy_front, self._policy_back, (lambda: self._bucket1), "policy"),

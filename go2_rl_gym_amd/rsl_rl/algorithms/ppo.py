@@ -24,7 +24,7 @@ import torch.optim as optim
 
 from ..modules.actor_critic import ActorCritic as _AC
 from ..storage import RolloutStorage
-from ._graph import CapturedStep, FusedClipAdam, GradBucket, OverlappedStep, ReducedStep, all_captured, collectives_in_graph
+from ._graph import CapturedStep, FusedClipAdam, GradBucket, OverlappedStep, ReducedStep, all_captured
 
 
 # Two independent sub-networks of one model on two HIP streams (the CTS family's encoders / heads; PPO's actor | critic pair only when the grouped kernels of
@@ -258,6 +258,7 @@ class PPO(_RolloutHeads):
 
     # ------------------------------------------------------------------ rollout half (ppo.py:90-118)
     _eps_all = None
+    _pk_packed = False
 
     def _rollout_noise(self, ac, st, s):
         """The standard-normal draws of step s ([N, A], the shape of the action rows).  One launch for the whole rollout at its first step instead of
@@ -282,8 +283,9 @@ class PPO(_RolloutHeads):
             t.observations, t.critic_observations = obs, critic_obs
             pk = self._policy_kernel()
             if pk is not None and obs.is_contiguous() and critic_obs.is_contiguous() and obs.dtype == torch.float32 and critic_obs.dtype == torch.float32:
-                if s == 0:
-                    pk.pack()                  # the parameters only change in update(): once per rollout (inside the captured rollout graph too)
+                if s == 0 or not self._pk_packed:
+                    pk.pack()                  # the parameters only change in update(): once per rollout (inside the captured rollout graph too); a rollout whose
+                    self._pk_packed = True     # first steps took the eager branch packs at its first kernel step
                 actions = pk.act(obs, critic_obs, self._rollout_noise(ac, st, s), st.actions[s], st.mu[s], st.sigma[s], st.actions_log_prob[s].view(-1), st.values[s].view(-1))
                 t.actions, t.values, t.actions_log_prob = actions, st.values[s], st.actions_log_prob[s].view(-1)
                 t.action_mean, t.action_sigma = st.mu[s], st.sigma[s]
@@ -479,13 +481,11 @@ class PPO(_RolloutHeads):
 
     def _graph_back(self, split=False):
         """LR decision, gradient clipping, Adam.  split: on the all-reduced bucket (shard-mean gradients and KL: every rank takes the
-        same LR branch); otherwise on this rank's gradients, after an all-reduce recorded in the same graph if collectives are on."""
+        same LR branch); otherwise on this rank's gradients."""
         if split:
             kl_mean = self._bucket.unpack(_world())
         else:
             kl_mean = self._kl
-            if _collectives_on():          # GO2_GRAPH_COLLECTIVES=1: ONE RCCL all-reduce (gradients + KL) recorded inside the graph
-                kl_mean = self._allreduce_grads(_world(), kl_mean if self._adaptive() else None)
         if self._fused_adam is None:
             self._fused_adam = FusedClipAdam(self.lib, self.optimizer, self.actor_critic.parameters(), self.max_grad_norm)
         if self._fused_adam.usable and self._fused_adam.step(kl_mean if self._adaptive() else None, self.desired_kl if self._adaptive() else 0.0):
@@ -520,10 +520,10 @@ class PPO(_RolloutHeads):
             # one; then each is captured once and replayed.  A failed capture degrades that slot to eager execution.
             # More than one rank: two captured halves per slot with the gradient all-reduce eager between them (_graph.py).
             self._bucket, self._bucket_c, self._held = None, None, None
-            if _collectives_on() and not collectives_in_graph() and self._overlap_on():
+            if _collectives_on() and self._overlap_on():
                 self._graph = [OverlappedStep((lambda i=i: self._graph_front_a(i)), self._graph_front_b, self._graph_back_overlapped, (lambda: self._bucket_c), (lambda: self._bucket),
                                               enabled=self._capture, warmup=3 if i == 0 else 1, name="PPO mini-batch step %d" % i) for i in range(nmb)]
-            elif _collectives_on() and not collectives_in_graph():
+            elif _collectives_on():
                 self._graph = [ReducedStep((lambda i=i: self._graph_front(i, True)), (lambda: self._graph_back(True)), (lambda: self._bucket),
                                            enabled=self._capture, warmup=3 if i == 0 else 1, name="PPO mini-batch step %d" % i) for i in range(nmb)]
             else:
@@ -551,6 +551,7 @@ class PPO(_RolloutHeads):
         return bool(self.use_graphs and self._capture and all_captured(self._graph))
 
     def update(self):
+        self._pk_packed = False          # the optimizer steps below change the parameters: the next rollout re-packs
         if self.use_graphs:
             out = self._update_graphs()
         else:

@@ -1,6 +1,7 @@
 """MLP actor-critic with a state-independent Gaussian (rsl_rl/rsl_rl/modules/actor_critic.py:38-136).
 Parameter names (`actor.N.weight`, `critic.N.bias`, `std`) match the reference so checkpoints interchange
-(on_policy_runner.py:243-250).  The dense layers are left to PyTorch-ROCm (hipBLASLt); SURVEY 2.1 #10."""
+(on_policy_runner.py:243-250).  The MLPs are FusedSequential modules: under autograd their layers run on the fp32-MFMA kernels of include/go2nn.h
+(modules/fused.py; in PPO.update both networks as one node with grouped launches), in the rollout as one launch (go2nn_policy_act)."""
 import torch
 import torch.nn as nn
 from torch.distributions import Normal

@@ -28,7 +28,6 @@ _LIB = None
 _NN = None
 _WGRAD_SPLIT = int(os.environ.get("GO2_WGRAD_SPLIT", "8"))       # 1 = plain mm
 _MLP_NODE = os.environ.get("GO2_MLP_NODE", "1") == "1"       # 0: per-layer autograd nodes (_LinearELU / _LinearELUHead) instead of the whole-MLP node
-_DEFER_SUMS = os.environ.get("GO2_MLP_DEFER", "1") == "1"
 _WGRAD_MIN_ROWS = 256       # rows per split below which the plain mm is used (tests lower it to drive the split path with small goldens)
 
 
@@ -229,9 +228,10 @@ class _FusedMLP(torch.autograd.Function):
             if l > 0:
                 gzp, gbp = torch.empty_like(h), new(Ki)
                 if _own("i", Ki, Co):
-                    wk = new(int(_NN.go2nn_linear_backward_workspace(B, Co, Ki)))
+                    rows_i = _NN.go2nn_linear_backward_input_rows(B, Co, Ki)
+                    wk = new(rows_i * Ki)          # (the column partials only: go2nn_linear_backward_workspace is sized for the weight gradient's row splits, ~40 x this)
                     _check(_NN.go2nn_linear_backward_input(p(gz), p(w), p(h), p(gzp), None, p(wk), B, Co, Ki, stream), "go2nn_linear_backward_input", _NN)
-                    jobs.append((wk, gbp, _NN.go2nn_linear_backward_input_rows(B, Co, Ki), Ki))
+                    jobs.append((wk, gbp, rows_i, Ki))
                 else:
                     gx = gz.mm(w)
                     wk2 = new(Ki * ((B + 63) // 64))
@@ -240,9 +240,8 @@ class _FusedMLP(torch.autograd.Function):
                         raise RuntimeError("go2sim_elu_backward_bias failed: %s" % _LIB.go2sim_last_error().decode())
                 gz, gb = gzp, gbp
         gx = gz.mm(ws[0]) if ctx.needs_input_grad[0] else None
-        step = 16 if _DEFER_SUMS else 1          # (GO2_MLP_DEFER=0: one launch per reduction, for the A/B)
-        for k in range(0, len(jobs), step):
-            chunk = jobs[k:k + step]
+        for k in range(0, len(jobs), 16):
+            chunk = jobs[k:k + 16]
             arr = (Go2nnSumJob * len(chunk))(*[Go2nnSumJob(t[0].data_ptr(), t[1].data_ptr(), t[2], t[3]) for t in chunk])
             _check(_NN.go2nn_sum_rows(arr, len(chunk), stream), "go2nn_sum_rows", _NN)
         return (gx, *grads)
@@ -297,6 +296,8 @@ class FusedSequential(nn.Sequential):
 # one grouped launch (include/go2nn.h ABI 3: go2nn_linear_elu_forward_group / _backward_input_group / _backward_weight_group; the weight gradients read their
 # operands straight from global memory into MFMA registers), and finishes every fixed-order reduction of both backward passes with ONE go2nn_sum_rows launch.
 _PAIR = os.environ.get("GO2_MLP_PAIR", "1") == "1"       # 0: one node per network (round 3)
+# (Measured and rejected, round 4: the weight gradients on a second HIP stream beside the chain of input gradients — nothing depends on them until the optimizer
+# step — cost 8 % of the whole job: a 2-workgroup-per-CU weight-gradient kernel and a 3-per-CU input-gradient kernel take each other's occupancy.)
 
 
 class _FusedPair(torch.autograd.Function):

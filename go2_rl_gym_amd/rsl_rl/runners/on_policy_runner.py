@@ -120,7 +120,12 @@ class OnPolicyRunner:
         # the step kernel (go2sim_step_rollout); GO2_FUSE_STEP=0 restores copy + store launches
         # (only when the storage rows are tensors the env kernel can write: same device as the env; LeggedRobot.step falls back to the plain
         # step for any destination it cannot write in place)
-        same_dev = torch.device(device) == torch.device(getattr(env, "device", device))
+        def _norm(d):          # 'cuda' and 'cuda:0' name the same device
+            d = torch.device(d)
+            return torch.device(d.type, torch.cuda.current_device()) if d.type == "cuda" and d.index is None else d
+        same_dev = _norm(device) == _norm(getattr(env, "device", device))
+        if on_gpu and not same_dev:
+            print("[OnPolicyRunner] rl_device %s differs from the env's device %s: the fused env step (observations written into the rollout storage in place) is off" % (device, getattr(env, "device", None)))
         self._fuse_step = (bool(on_gpu or os.environ.get("GO2_FUSE_STEP") == "1") and os.environ.get("GO2_FUSE_STEP", "1") != "0" and hasattr(self.env, "_info_ring")
                            and same_dev)
         N, T = self.env.num_envs, self.num_steps_per_env
