@@ -31,6 +31,12 @@ class Go2nnBwdWJob(C.Structure):
     _fields_ = [("gz", C.c_void_p), ("x", C.c_void_p), ("workspace", C.c_void_p), ("M", C.c_int32), ("C", C.c_int32), ("Kin", C.c_int32)]
 
 
+class Go2nnPpoHeads(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("y_a", "y_c", "w_mu", "b_mu", "w_v", "b_v", "std", "actions", "old_mu", "old_sigma", "old_logp", "adv", "old_values", "returns",
+                                          "gz_a", "gz_c", "partials")] + [(k, C.c_int32) for k in ("B", "A", "K", "use_clipped_value_loss")] + \
+               [(k, C.c_float) for k in ("clip", "value_loss_coef", "entropy_coef")]
+
+
 class Go2nnMlp(C.Structure):
     _fields_ = [("num_layers", C.c_int32), ("dims", C.c_int32 * (GO2NN_MAX_LAYERS + 1)),
                 ("weight", C.c_void_p * GO2NN_MAX_LAYERS), ("bias", C.c_void_p * GO2NN_MAX_LAYERS)]
@@ -60,6 +66,9 @@ def bind(path):
     lib.go2nn_linear_backward_input_group.argtypes = [C.POINTER(Go2nnBwdInJob), C.c_int32, C.c_void_p]
     lib.go2nn_linear_backward_weight_group_rows.argtypes = [C.POINTER(Go2nnBwdWJob), C.c_int32]
     lib.go2nn_linear_backward_weight_group.argtypes = [C.POINTER(Go2nnBwdWJob), C.c_int32, C.c_void_p]
+    lib.go2nn_ppo_heads_rows.argtypes = [C.c_int32] * 3
+    lib.go2nn_ppo_heads_cols.argtypes = [C.c_int32] * 2
+    lib.go2nn_ppo_heads.argtypes = [C.POINTER(Go2nnPpoHeads), C.c_void_p]
     if lib.go2nn_abi_version() != GO2NN_ABI_VERSION:
         raise RuntimeError("%s: ABI version %d, expected %d" % (path, lib.go2nn_abi_version(), GO2NN_ABI_VERSION))
     return lib

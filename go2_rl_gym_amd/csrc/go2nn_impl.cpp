@@ -711,3 +711,79 @@ int go2nn_linear_backward_weight_group(const Go2nnBwdWJob* jobs, int32_t njobs, 
 }
 
 }  // extern "C"
+
+extern "C" {
+
+static int ppo_heads_ok(int B, int A, int K) { return B > 0 && A >= 1 && A <= HB_MAX_C && K >= 4 && K <= 256 && (K & 3) == 0; }
+int32_t go2nn_ppo_heads_cols(int32_t A, int32_t K) {
+  if (!ppo_heads_ok(1, A, K)) FAIL(GO2NN_EINVAL, "ppo heads: 1 <= A <= %d, K a multiple of 4 up to 256", HB_MAX_C);
+  return ppo_heads_cols(A, K);
+}
+int32_t go2nn_ppo_heads_rows(int32_t B, int32_t A, int32_t K) {
+  if (!ppo_heads_ok(B, A, K)) FAIL(GO2NN_EINVAL, "ppo heads: bad shape");
+#ifdef GO2_EMU
+  return 1;
+#else
+  int q, rows, nwg; ppo_heads_shape(B, K, &q, &rows, &nwg); return nwg;
+#endif
+}
+int go2nn_ppo_heads(const Go2nnPpoHeads* h, void* stream) {
+  if (!h || !ppo_heads_ok(h->B, h->A, h->K)) FAIL(GO2NN_EINVAL, "ppo heads: bad shape");
+  const void* ptrs[] = {h->y_a, h->y_c, h->w_mu, h->b_mu, h->w_v, h->b_v, h->std, h->actions, h->old_mu, h->old_sigma, h->old_logp, h->adv, h->old_values, h->returns, h->gz_a, h->gz_c, h->partials};
+  for (const void* q : ptrs) if (!q) FAIL(GO2NN_EINVAL, "ppo heads: null pointer");
+  const int B = h->B, A = h->A, K = h->K;
+#ifdef GO2_EMU
+  (void)stream;
+  const float LOG2PI = 1.8378770664093453f, invB = 1.f / (float)B, lo = 1.f - h->clip, hi = 1.f + h->clip;
+  float* S = h->partials; const int nc = ppo_heads_cols(A, K);
+  for (int i = 0; i < nc; ++i) S[i] = 0.f;
+  float* pa = S + PH_NSTAT + A; float* pc = pa + (size_t)(A + 1) * K + A;
+  for (int c = 0; c < A; ++c) { S[3] += 0.5f + 0.5f * LOG2PI + logf(h->std[c]); S[PH_NSTAT + c] = -h->entropy_coef / h->std[c]; }
+  for (int r = 0; r < B; ++r) {
+    const float* ya = h->y_a + (size_t)r * K; const float* yc = h->y_c + (size_t)r * K;
+    float mu[HB_MAX_C], v = h->b_v[0], lp = 0.f, kl = 0.f;
+    for (int k = 0; k < K; ++k) v = fmaf(yc[k], h->w_v[k], v);
+    for (int c = 0; c < A; ++c) {
+      float m = h->b_mu[c]; for (int k = 0; k < K; ++k) m = fmaf(ya[k], h->w_mu[(size_t)c * K + k], m);
+      mu[c] = m;
+      const float sg = h->std[c], d = h->actions[(size_t)r * A + c] - m, so = h->old_sigma[(size_t)r * A + c], dm = h->old_mu[(size_t)r * A + c] - m, isg2 = 1.f / (sg * sg);
+      lp += -d * d * (0.5f * isg2) - logf(sg) - 0.5f * LOG2PI; kl += logf(sg / so + 1e-5f) + (so * so + dm * dm) * (0.5f * isg2) - 0.5f;
+    }
+    const float ad = h->adv[r], ratio = expf(lp - h->old_logp[r]), rc = fminf(fmaxf(ratio, lo), hi), in = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
+    const float s1 = -ad * ratio, s2 = -ad * rc, sur = fmaxf(s1, s2), w = s1 > s2 ? 1.f : (s1 < s2 ? in : 0.5f + 0.5f * in), g_lp = -ad * w * ratio * invB;
+    const float tv = h->old_values[r], rt = h->returns[r], dv = v - tv;
+    float vl, gv;
+    if (h->use_clipped_value_loss) {
+      const float dc = fminf(fmaxf(dv, -h->clip), h->clip), vin = (dv >= -h->clip && dv <= h->clip) ? 1.f : 0.f, vc = tv + dc;
+      const float l1 = (v - rt) * (v - rt), l2 = (vc - rt) * (vc - rt); vl = fmaxf(l1, l2);
+      const float g1 = 2.f * (v - rt), g2 = 2.f * (vc - rt) * vin; gv = l1 > l2 ? g1 : (l1 < l2 ? g2 : 0.5f * g1 + 0.5f * g2);
+    } else { vl = (rt - v) * (rt - v); gv = 2.f * (v - rt); }
+    const float gval = h->value_loss_coef * gv * invB;
+    S[0] += sur * invB; S[1] += vl * invB; S[2] += kl * invB;
+    float gm[HB_MAX_C];
+    for (int c = 0; c < A; ++c) { const float sg = h->std[c], d = h->actions[(size_t)r * A + c] - mu[c], isg2 = 1.f / (sg * sg);
+      gm[c] = g_lp * d * isg2; S[PH_NSTAT + c] += g_lp * (d * d * isg2 / sg - 1.f / sg); pa[(size_t)(A + 1) * K + c] += gm[c]; }
+    for (int k = 0; k < K; ++k) {
+      float gx = 0.f; for (int c = 0; c < A; ++c) { gx = fmaf(gm[c], h->w_mu[(size_t)c * K + k], gx); pa[(size_t)c * K + k] = fmaf(gm[c], ya[k], pa[(size_t)c * K + k]); }
+      const float oa = gx * (ya[k] > 0.f ? 1.f : ya[k] + 1.f), oc = gval * h->w_v[k] * (yc[k] > 0.f ? 1.f : yc[k] + 1.f);
+      h->gz_a[(size_t)r * K + k] = oa; h->gz_c[(size_t)r * K + k] = oc; pa[(size_t)A * K + k] += oa; pc[K + k] += oc; pc[k] = fmaf(gval, yc[k], pc[k]);
+    }
+    pc[2 * K] += gval;
+  }
+#else
+  PpoHeadsArgs a;
+  a.y_a = h->y_a; a.y_c = h->y_c; a.w_mu = h->w_mu; a.b_mu = h->b_mu; a.w_v = h->w_v; a.b_v = h->b_v; a.std_ = h->std; a.actions = h->actions; a.old_mu = h->old_mu;
+  a.old_sigma = h->old_sigma; a.old_logp = h->old_logp; a.adv = h->adv; a.old_values = h->old_values; a.returns = h->returns; a.gz_a = h->gz_a; a.gz_c = h->gz_c; a.part = h->partials;
+  a.B = B; a.A = A; a.K = K; a.use_clip_v = h->use_clipped_value_loss; a.clip = h->clip; a.vcoef = h->value_loss_coef; a.ecoef = h->entropy_coef;
+  int q, rows, nwg; ppo_heads_shape(B, K, &q, &rows, &nwg);
+  hipStream_t st = (hipStream_t)stream;
+  if (A <= 4)       hipLaunchKernelGGL(go2nn_ppo_heads_kernel<4>,  dim3(nwg), dim3(256), 0, st, a, q, rows);
+  else if (A <= 8)  hipLaunchKernelGGL(go2nn_ppo_heads_kernel<8>,  dim3(nwg), dim3(256), 0, st, a, q, rows);
+  else if (A <= 12) hipLaunchKernelGGL(go2nn_ppo_heads_kernel<12>, dim3(nwg), dim3(256), 0, st, a, q, rows);
+  else              hipLaunchKernelGGL(go2nn_ppo_heads_kernel<16>, dim3(nwg), dim3(256), 0, st, a, q, rows);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+}  // extern "C"

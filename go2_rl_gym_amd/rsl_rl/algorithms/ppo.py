@@ -415,7 +415,17 @@ class PPO(_RolloutHeads):
         KL are packed into the all-reduce bucket (more than one rank)."""
         mb = self._mb
         batch = [self._perm[k][i * mb:(i + 1) * mb] for k in self._KEYS]
-        if self.fused_loss:
+        if self.fused_loss and type(self.actor_critic) is _AC and self._heads_path(batch):
+            # a plain ActorCritic: forward, loss and backward of the mini-batch as explicit launches, no autograd graph (modules/fused.py:ppo_pair_grads):
+            # grouped hidden layers, go2nn_ppo_heads (heads forward + loss + heads backward in one pass), ONE go2nn_sum_rows; .grad of every parameter is set
+            from ..modules import fused
+            ac = self.actor_critic
+            self.optimizer.zero_grad(set_to_none=True)
+            stats = fused.ppo_pair_grads(ac, batch[0], batch[1], batch[2], batch[3], batch[4], batch[5], batch[6], batch[7], batch[8], self.clip_param, self.value_loss_coef,
+                                         self.entropy_coef, self.use_clipped_value_loss)
+            self._acc.add_(stats[:2])
+            kl_mean = stats[2]
+        elif self.fused_loss:
             # the loss kernel already holds d loss / d (mu, std, value): seed the backward pass of the two networks with them directly
             # (loss.backward() through the autograd.Function costs a clone and three multiplications by the unit upstream gradient)
             ac = self.actor_critic
@@ -443,6 +453,12 @@ class PPO(_RolloutHeads):
 
     def _adaptive(self):
         return self.desired_kl is not None and self.schedule == "adaptive"
+
+    def _heads_path(self, batch):
+        if getattr(self, "surrogate_split", 0):
+            return False
+        from ..modules import fused
+        return fused.ppo_pair_applicable(self.actor_critic, batch[0], batch[1])
 
     # ---- more than one rank, overlapped schedule (OverlappedStep): the critic's gradients are on the wire while the actor's backward runs ----
     # OFF by default (GO2_OVERLAP_ALLREDUCE=1 switches it on).  Measured on one MI355X with a 1-rank RCCL group (profiles/r3_collectives.txt):

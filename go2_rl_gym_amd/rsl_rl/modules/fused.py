@@ -398,3 +398,99 @@ def pair_forward(seq_a, seq_c, xa, xc):
         return None
     cont = lambda t: t if t.is_contiguous() else t.contiguous()
     return _FusedPair.apply(cont(xa), cont(xc), len(la) - 1, *[t for m in la for t in (m.weight, m.bias)], *[t for m in lc for t in (m.weight, m.bias)])
+
+
+# ---- PPO's whole mini-batch gradient without autograd (round 4) -----------------------------------------------------------------------------------------
+# With both networks in one node, what is left around the hidden layers' grouped GEMMs is the chain  heads forward (two degenerate GEMMs) -> loss head
+# (go2sim_ppo_loss) -> heads backward (two go2nn_head_backward launches): all per row of the mini-batch, all reading / writing the last hidden activations.
+# go2nn_ppo_heads does it in one streaming pass, and since the loss kernel hands out the analytic gradients anyway, the update needs no autograd graph:
+# ppo_pair_grads runs forward, loss and backward as explicit launches (12 per mini-batch instead of 20) and installs the gradients as the parameters' .grad.
+_HEADS = os.environ.get("GO2_PPO_HEADS", "1") == "1"       # 0: the autograd node + go2sim_ppo_loss (A/B)
+
+
+def ppo_pair_applicable(ac, xa, xc):
+    if not (_HEADS and _PAIR and _MLP_NODE and _LIB is not None and _NN is not None and hasattr(ac, "actor") and hasattr(ac, "critic") and hasattr(ac, "std")):
+        return False
+    if not (isinstance(ac.actor, FusedSequential) and isinstance(ac.critic, FusedSequential) and xa.dim() == 2 and xc.dim() == 2 and xa.dtype == torch.float32
+            and xc.dtype == torch.float32 and xa.shape[0] == xc.shape[0] and (xa.is_cuda or (_LIB.go2sim_is_device_library() == 0 and _NN.go2nn_is_device_library() == 0))):
+        return False
+    la, lc = _whole_mlp(list(ac.actor)), _whole_mlp(list(ac.critic))
+    if la is None or lc is None or len(la) != len(lc) or any(a.out_features != c.out_features for a, c in zip(la[:-1], lc[:-1])):
+        return False
+    if any(m.in_features < 4 for m in la + lc) or any(m.out_features < 2 for m in la[:-1] + lc[:-1]):
+        return False
+    K = la[-1].in_features
+    return (lc[-1].out_features == 1 and la[-1].out_features <= 16 and K % 4 == 0 and K <= 256 and ac.std.dim() == 1 and ac.std.shape[0] == la[-1].out_features
+            and all(p.requires_grad for m in la + lc for p in (m.weight, m.bias)) and ac.std.requires_grad)
+
+
+def ppo_pair_grads(ac, xa, xc, actions, old_values, adv, returns, old_logp, old_mu, old_sigma, clip, vcoef, ecoef, use_clipped_value_loss):
+    """One PPO mini-batch gradient (ppo.py:131-170 + loss.backward()) of a plain ActorCritic as explicit launches: grouped hidden layers forward, go2nn_ppo_heads,
+    grouped hidden layers backward, ONE go2nn_sum_rows; every parameter's .grad is set (replaced, as after zero_grad(set_to_none=True)).
+    -> stats [surrogate, value loss, KL, entropy] (means, device tensor)"""
+    from ..._nn import Go2nnBwdInJob, Go2nnBwdWJob, Go2nnFwdJob, Go2nnPpoHeads, Go2nnSumJob
+    la, lc = _whole_mlp(list(ac.actor)), _whole_mlp(list(ac.critic))
+    H = len(la) - 1
+    lins = (la, lc)
+    ws = [[m.weight for m in l] for l in lins]
+    bs = [[m.bias for m in l] for l in lins]
+    dev, dt = xa.device, xa.dtype
+    p = lambda t: t.data_ptr()
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if xa.is_cuda else None
+    new = lambda *shape: torch.empty(*shape, device=dev, dtype=dt)
+    cont = lambda t: t.detach() if t.is_contiguous() else t.detach().contiguous()
+    flat = lambda t: cont(t).reshape(-1)
+    with torch.no_grad():
+        B = xa.shape[0]
+        acts = [[cont(xa)], [cont(xc)]]
+        for l in range(H):
+            ys = [new(B, ws[j][l].shape[0]) for j in range(2)]
+            jobs = (Go2nnFwdJob * 2)(*[Go2nnFwdJob(p(acts[j][-1]), p(ws[j][l]), p(bs[j][l]), p(ys[j]), B, ws[j][l].shape[1], ws[j][l].shape[0]) for j in range(2)])
+            _check(_NN.go2nn_linear_elu_forward_group(jobs, 2, stream), "go2nn_linear_elu_forward_group", _NN)
+            for j in range(2):
+                acts[j].append(ys[j])
+        A, K = ws[0][H].shape
+        rows, cols = _NN.go2nn_ppo_heads_rows(B, A, K), _NN.go2nn_ppo_heads_cols(A, K)
+        if rows <= 0 or cols <= 0:
+            raise RuntimeError("go2nn_ppo_heads: %s" % _NN.go2nn_last_error().decode())
+        gz = [new(B, K), new(B, K)]
+        part, tot = new(rows * cols), new(cols)
+        keep = [cont(actions), cont(old_mu), cont(old_sigma), flat(old_logp), flat(adv), flat(old_values), flat(returns), cont(ac.std)]
+        h = Go2nnPpoHeads(p(acts[0][H]), p(acts[1][H]), p(ws[0][H]), p(bs[0][H]), p(ws[1][H]), p(bs[1][H]), p(keep[7]), p(keep[0]), p(keep[1]), p(keep[2]), p(keep[3]), p(keep[4]),
+                          p(keep[5]), p(keep[6]), p(gz[0]), p(gz[1]), p(part), B, A, K, int(bool(use_clipped_value_loss)), float(clip), float(vcoef), float(ecoef))
+        _check(_NN.go2nn_ppo_heads(C.byref(h), stream), "go2nn_ppo_heads", _NN)
+        sums = [(part, tot, rows, cols)]
+        o = 4 + A
+        ac.std.grad = tot[4:o].view_as(ac.std)
+        ws[0][H].grad, gb_a, bs[0][H].grad = tot[o:o + A * K].view(A, K), tot[o + A * K:o + (A + 1) * K], tot[o + (A + 1) * K:o + (A + 1) * K + A]
+        o += (A + 1) * K + A
+        ws[1][H].grad, gb_c, bs[1][H].grad = tot[o:o + K].view(1, K), tot[o + K:o + 2 * K], tot[o + 2 * K:o + 2 * K + 1]
+        gb = [gb_a, gb_c]
+        for l in range(H - 1, -1, -1):
+            shp = [ws[j][l].shape for j in range(2)]
+            wj = (Go2nnBwdWJob * 2)(*[Go2nnBwdWJob(p(gz[j]), p(acts[j][l]), None, B, shp[j][0], shp[j][1]) for j in range(2)])
+            r = _NN.go2nn_linear_backward_weight_group_rows(wj, 2)
+            if r <= 0:
+                raise RuntimeError("go2nn_linear_backward_weight_group_rows: %s" % _NN.go2nn_last_error().decode())
+            for j in range(2):
+                wk, dw = new(r * shp[j][0] * shp[j][1]), torch.empty_like(ws[j][l])
+                wj[j].workspace = p(wk)
+                sums.append((wk, dw, r, shp[j][0] * shp[j][1]))
+                ws[j][l].grad, bs[j][l].grad = dw, gb[j]
+            _check(_NN.go2nn_linear_backward_weight_group(wj, 2, stream), "go2nn_linear_backward_weight_group", _NN)
+            if l > 0:
+                gzp = [torch.empty_like(acts[j][l]) for j in range(2)]
+                ij = (Go2nnBwdInJob * 2)()
+                for j in range(2):
+                    ri = _NN.go2nn_linear_backward_input_group_rows(B, shp[j][0], shp[j][1])
+                    wk, gbp = new(ri * shp[j][1]), new(shp[j][1])
+                    ij[j] = Go2nnBwdInJob(p(gz[j]), p(ws[j][l]), p(acts[j][l]), p(gzp[j]), p(wk), B, shp[j][0], shp[j][1])
+                    sums.append((wk, gbp, ri, shp[j][1]))
+                    gb[j] = gbp
+                _check(_NN.go2nn_linear_backward_input_group(ij, 2, stream), "go2nn_linear_backward_input_group", _NN)
+                gz = gzp
+        for k in range(0, len(sums), 16):
+            chunk = sums[k:k + 16]
+            arr = (Go2nnSumJob * len(chunk))(*[Go2nnSumJob(t[0].data_ptr(), t[1].data_ptr(), t[2], t[3]) for t in chunk])
+            _check(_NN.go2nn_sum_rows(arr, len(chunk), stream), "go2nn_sum_rows", _NN)
+    return tot[:4]

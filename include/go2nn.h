@@ -110,6 +110,25 @@ int go2nn_linear_backward_input_group(const Go2nnBwdInJob* jobs, int32_t njobs, 
 int32_t go2nn_linear_backward_weight_group_rows(const Go2nnBwdWJob* jobs, int32_t njobs);
 int go2nn_linear_backward_weight_group(const Go2nnBwdWJob* jobs, int32_t njobs, void* stream);
 
+
+/* The narrow heads of BOTH networks forward, the PPO loss head (rsl_rl/rsl_rl/algorithms/ppo.py:131-170: Gaussian log-prob, ratio, clipped surrogate, clipped
+ * value loss, entropy, KL) with its analytic gradients, and the heads backward, as ONE streaming pass over the last hidden activations y_a, y_c [B,K] of the
+ * actor (head W_mu [A,K], b_mu [A]) and the critic (head w_v [1,K], b_v [1]) — in place of two degenerate GEMMs, go2sim_ppo_loss and two go2nn_head_backward
+ * launches.  Same arithmetic as go2sim_ppo_loss (torch.max tie splitting, clamp gradient semantics) with every row weighted 1 / B.
+ * Out: gz_a, gz_c [B,K] = the gradients at the last hidden layers' pre-activations; `partials` = go2nn_ppo_heads_rows(B, A, K) rows of
+ * go2nn_ppo_heads_cols(A, K) columns whose column sums (go2nn_sum_rows) are
+ *   [ surrogate, value loss, KL, entropy (means) | d loss/d std [A] | dW_mu [A,K] | gb_a [K] | db_mu [A] | dW_v [K] | gb_c [K] | db_v ]
+ * (gb_*: bias gradient of the last hidden layer = column sums of gz_*).  A <= 16, K a multiple of 4 up to 256.  Fixed summation order. */
+typedef struct Go2nnPpoHeads {
+  const float *y_a, *y_c, *w_mu, *b_mu, *w_v, *b_v, *std, *actions, *old_mu, *old_sigma, *old_logp, *adv, *old_values, *returns;
+  float *gz_a, *gz_c, *partials;
+  int32_t B, A, K, use_clipped_value_loss;
+  float clip, value_loss_coef, entropy_coef;
+} Go2nnPpoHeads;
+int32_t go2nn_ppo_heads_rows(int32_t B, int32_t A, int32_t K);
+int32_t go2nn_ppo_heads_cols(int32_t A, int32_t K);
+int go2nn_ppo_heads(const Go2nnPpoHeads* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

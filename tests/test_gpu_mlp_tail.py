@@ -74,3 +74,18 @@ def test_linear_group_on_gpu(M, s0, s1):
 @pytest.mark.parametrize("B", [24576, 1000])
 def test_pair_node_on_gpu(B):
     pair_vs_autograd(_nn.load_nn(), load_hip(), "cuda:0", B=B, dims_a=(45, 512, 256, 128, 12), dims_c=(263, 512, 256, 128, 1), atol=2e-6)
+
+
+from test_mlp_tail import ppo_grads_vs_autograd  # noqa: E402
+
+
+@pytest.mark.parametrize("B,dims_a,dims_c,clipv", [(24576, (45, 512, 256, 128, 12), (263, 512, 256, 128, 1), True), (1000, (45, 512, 256, 128, 12), (263, 512, 256, 128, 1), False),
+                                                   (4099, (45, 64, 36, 16), (30, 64, 36, 1), True), (777, (20, 32, 3), (9, 32, 1), True)])
+def test_ppo_heads_path_on_gpu(B, dims_a, dims_c, clipv):
+    """go2nn_ppo_heads + the grouped hidden layers (the no-autograd PPO mini-batch gradient) on the GPU against the eager loss under autograd, at the update's
+    shape and at ragged ones (rows that do not fill the last workgroup, every head width template, K = 36 / 32); bit-reproducible from launch to launch"""
+    a = ppo_grads_vs_autograd(_nn.load_nn(), load_hip(), "cuda:0", B=B, dims_a=dims_a, dims_c=dims_c, clipv=clipv, atol=3e-6)
+    b = ppo_grads_vs_autograd(_nn.load_nn(), load_hip(), "cuda:0", B=B, dims_a=dims_a, dims_c=dims_c, clipv=clipv, atol=3e-6)
+    torch.cuda.synchronize()
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)

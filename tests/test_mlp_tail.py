@@ -324,3 +324,54 @@ def test_pair_node_is_not_taken_for_different_hidden_widths():
             assert fused.pair_forward(a, a, x, x) is None
     finally:
         fused.set_library(None); fused.set_nn_library(None)
+
+
+def ppo_grads_vs_autograd(nn_lib, sim_lib, device, B=300, dims_a=(45, 64, 32, 12), dims_c=(263, 64, 32, 1), clipv=True, atol=3e-6):
+    """modules/fused.py:ppo_pair_grads (no autograd: grouped hidden layers + go2nn_ppo_heads + one go2nn_sum_rows) against the reference's eager loss
+    (rsl_rl/algorithms/ppo.py:131-170 as PPO._losses states it) differentiated by autograd: statistics and every parameter gradient, including std's"""
+    from go2_rl_gym_amd.rsl_rl.algorithms.ppo import PPO
+    from go2_rl_gym_amd.rsl_rl.modules import fused
+    from go2_rl_gym_amd.rsl_rl.modules.actor_critic import ActorCritic
+    torch.manual_seed(11)
+    A = dims_a[-1]
+    ac = ActorCritic(dims_a[0], dims_c[0], A, actor_hidden_dims=list(dims_a[1:-1]), critic_hidden_dims=list(dims_c[1:-1]), init_noise_std=0.8).to(device)
+    with torch.no_grad():
+        ac.std.mul_(torch.linspace(0.7, 1.3, A, device=device))
+    alg = PPO(ac, device=device, lib=None, use_graphs=False, fused_loss=False, entropy_coef=0.01, use_clipped_value_loss=clipv, clip_param=0.2, value_loss_coef=1.0)
+    obs, cobs = torch.randn(B, dims_a[0], device=device), torch.randn(B, dims_c[0], device=device)
+    with torch.no_grad():
+        mu0, v0 = ac.actor(obs), ac.critic(cobs)
+    old_mu, old_sig = mu0 + 0.05 * torch.randn_like(mu0), (ac.std.detach() * (1 + 0.05 * torch.randn(A, device=device))).expand(B, A).contiguous()
+    act = old_mu + old_sig * torch.randn_like(old_mu)
+    old_lp = torch.distributions.Normal(old_mu, old_sig).log_prob(act).sum(-1, keepdim=True)
+    adv, tv = torch.randn(B, 1, device=device), v0 + 0.3 * torch.randn(B, 1, device=device)      # value errors on both sides of the clip range
+    ret = tv + 0.5 * torch.randn(B, 1, device=device)
+    adv[::7] *= 8.0                                                                               # ratios outside the clip range on both sides
+    ac.zero_grad()
+    loss, vl, sur, kl = alg._losses(obs, cobs, act, tv, adv, ret, old_lp, old_mu, old_sig)
+    loss.backward()
+    want = [p.grad.clone() for p in ac.parameters()]
+    ent = ac.entropy.mean()
+    ac.zero_grad(set_to_none=True)
+    fused.set_library(sim_lib); fused.set_nn_library(nn_lib)
+    try:
+        assert fused.ppo_pair_applicable(ac, obs, cobs)
+        stats = fused.ppo_pair_grads(ac, obs, cobs, act, tv, adv, ret, old_lp, old_mu, old_sig, 0.2, 1.0, 0.01, clipv)
+    finally:
+        fused.set_library(None); fused.set_nn_library(None)
+    np.testing.assert_allclose(stats.cpu().numpy(), [float(sur), float(vl), float(kl), float(ent)], rtol=2e-5, atol=2e-6)
+    for (n, p_), w in zip(ac.named_parameters(), want):
+        assert p_.grad is not None and p_.grad.shape == p_.shape, n
+        np.testing.assert_allclose(p_.grad.cpu().numpy(), w.cpu().numpy(), atol=atol, rtol=2e-3, err_msg=n)
+    return [stats] + [p_.grad for p_ in ac.parameters()]
+
+
+@pytest.mark.parametrize("dims_a,dims_c,clipv", [((45, 64, 32, 12), (263, 64, 32, 1), True), ((20, 16, 3), (9, 16, 1), False), ((45, 40, 36, 16), (30, 40, 36, 1), True)])
+def test_ppo_heads_path_matches_the_eager_loss_under_autograd(dims_a, dims_c, clipv):
+    ppo_grads_vs_autograd(load_nn_emu(), load_oracle(), "cpu", dims_a=dims_a, dims_c=dims_c, clipv=clipv)
+
+
+def test_ppo_heads_refuses_unsupported_shapes():
+    lib = load_nn_emu()
+    assert lib.go2nn_ppo_heads_cols(17, 128) < 0 and lib.go2nn_ppo_heads_cols(12, 130) < 0 and lib.go2nn_ppo_heads_rows(0, 12, 128) < 0 and lib.go2nn_ppo_heads(None, None) < 0
+    assert lib.go2nn_ppo_heads_cols(12, 128) == 4 + 12 + 13 * 128 + 12 + 2 * 128 + 1

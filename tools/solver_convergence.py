@@ -10,6 +10,13 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from test_physics_kat import solver_convergence_table
 
+if "--both" in sys.argv:          # the shipped model, then the EXPERIMENT of VERDICT r3 item 3 (GO2_ORACLE_WARM_GROUPS=1: the calf / thigh / hip / base-share slots
+    import subprocess           # warm-started from the previous substep's impulses, matched by body group, like the feet)
+    for w in ("0", "1"):
+        print("==== GO2_ORACLE_WARM_GROUPS=%s %s" % (w, "(shipped model)" if w == "0" else "(experiment: every slot warm-started across the substeps of a policy step)"))
+        sys.stdout.flush()
+        subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, GO2_ORACLE_WARM_GROUPS=w), check=True)
+    sys.exit(0)
 t = solver_convergence_table(steps=100, N=128)
 n = len(next(iter(t.values()))["base_twist"])
 print("contact solve: k sweeps vs 1024 sweeps of the same model (fp64 oracle, %d env-steps = 100 policy steps x 128 envs, N(0,1) actions, re-synced every step)" % n)
