@@ -17,6 +17,13 @@
 #include <vector>
 
 #include "../../include/go2sim.h"
+#ifdef GO2_EMU
+#define GO2_SHUFFLE_FN static inline
+#else
+#include <hip/hip_runtime.h>
+#define GO2_SHUFFLE_FN static __host__ __device__ inline
+#endif
+#include "../../include/go2sim_shuffle.h"
 #include "../../include/go2sim_defaults.h"
 #include "../../include/go2sim_rng.h"
 #define GO2_XLANE_IMPLEMENTATION
@@ -833,6 +840,49 @@ __global__ void __launch_bounds__(256) go2_store_transition_kernel(const float* 
 }
 
 // ---- CTS observation-history ring (on_policy_runner_cts.py:155-156): one thread per (env, feature), H values in flight ------
+// ---- the update's permutation + gathers (go2sim_shuffle_gather) --------------------------------------------------------------------------
+// One wave per output row at a time, its lanes run along the row of every job (263-, 45-, 12- and 1-float rows
+// of the PPO storage: 13 load / store pairs per row); two rows' loads are in flight per wave.  The source row pi(r) is computed by the wave itself (no sort,
+// no index tensor) unless the caller hands in a permutation.  HBM-bound: 2 x 348 floats per row.
+#define GO2_GATHER_ROWS_PER_WG 32
+struct Go2GatherArgs {
+  const float* src[GO2_GATHER_MAX_JOBS]; float* dst[GO2_GATHER_MAX_JOBS]; int32_t w[GO2_GATHER_MAX_JOBS];
+  int32_t njobs, rows, h, nclear; const int64_t* indices; uint32_t* key; float* clear;
+};
+__global__ void __launch_bounds__(256) go2_shuffle_gather_kernel(const Go2GatherArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t seed = 0, counter = 0;
+  if (!a.indices) { seed = a.key[0]; counter = a.key[1]; }          // (read before this workgroup's ticket below: the counter only moves once EVERY workgroup holds a ticket)
+  const int r0 = blockIdx.x * GO2_GATHER_ROWS_PER_WG;
+  for (int rr = wave; rr < GO2_GATHER_ROWS_PER_WG; rr += 8) {       // two rows per trip
+    int r[2], sidx[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      r[u] = r0 + rr + 4 * u;
+      const int rc = min(r[u], a.rows - 1);
+      sidx[u] = a.indices ? (int)a.indices[rc] : (int)go2_shuffle_index((uint32_t)rc, (uint32_t)a.rows, a.h, seed, counter);
+    }
+    for (int j = 0; j < a.njobs; ++j) {
+      const int w = a.w[j];
+      const float* __restrict__ s0 = a.src[j] + (size_t)sidx[0] * w; const float* __restrict__ s1 = a.src[j] + (size_t)sidx[1] * w;
+      float* __restrict__ d0 = a.dst[j] + (size_t)r[0] * w; float* __restrict__ d1 = a.dst[j] + (size_t)r[1] * w;
+      for (int e = lane; e < w; e += 64) {
+        const float v0 = s0[e], v1 = s1[e];
+        if (r[0] < a.rows) d0[e] = v0;
+        if (r[1] < a.rows) d1[e] = v1;
+      }
+    }
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < a.nclear) a.clear[threadIdx.x] = 0.f;
+  if (!a.indices) {          // the last workgroup to finish advances the counter for the next launch (a replayed HIP graph): every workgroup has read it by then
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned t = atomicAdd(&a.key[2], 1u);
+      if (t == gridDim.x - 1) { a.key[2] = 0u; __threadfence(); atomicAdd(&a.key[1], 1u); }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) go2_history_push_kernel(float* __restrict__ hist, const float* __restrict__ obs, const uint8_t* __restrict__ dones, int N, int H, int D) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= N * D) return;
@@ -1574,6 +1624,31 @@ int go2sim_store_transition(const float* rew, const uint8_t* dones, const uint8_
   for (int e = 0; e < N; ++e) { float r = rew[e]; if (touts) r += gamma * (v_st[e] * (touts[e] ? 1.f : 0.f)); rew_st[e] = r; dones_st[e] = dones[e]; }
 #else
   hipLaunchKernelGGL(go2_store_transition_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, rew, dones, touts, v_st, rew_st, dones_st, gamma, N);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+uint32_t go2sim_shuffle_index(uint32_t i, uint32_t n, uint32_t seed, uint32_t counter) { return n ? go2_shuffle_index(i, n, go2_shuffle_half_bits(n), seed, counter) : 0; }
+
+int go2sim_shuffle_gather(const Go2GatherJob* jobs, int32_t njobs, int32_t rows, const int64_t* indices, uint32_t* key_state, float* clear, int32_t nclear, void* stream) {
+  if (!jobs || njobs <= 0 || njobs > GO2_GATHER_MAX_JOBS || rows <= 0 || (!indices && !key_state) || (nclear > 0 && !clear)) FAIL(GO2SIM_EINVAL, "shuffle gather: bad argument");
+  for (int j = 0; j < njobs; ++j) if (!jobs[j].src || !jobs[j].dst || jobs[j].row_floats <= 0) FAIL(GO2SIM_EINVAL, "shuffle gather: bad job %d", j);
+  const int h = go2_shuffle_half_bits((uint32_t)rows);
+#ifdef GO2_EMU
+  (void)stream;
+  for (int32_t r = 0; r < rows; ++r) {
+    const int64_t sidx = indices ? indices[r] : (int64_t)go2_shuffle_index((uint32_t)r, (uint32_t)rows, h, key_state[0], key_state[1]);
+    for (int j = 0; j < njobs; ++j) memcpy(jobs[j].dst + (size_t)r * jobs[j].row_floats, jobs[j].src + (size_t)sidx * jobs[j].row_floats, sizeof(float) * (size_t)jobs[j].row_floats);
+  }
+  if (!indices) key_state[1] += 1u;
+  for (int i = 0; i < nclear; ++i) clear[i] = 0.f;
+#else
+  Go2GatherArgs a; memset(&a, 0, sizeof(a));
+  for (int j = 0; j < njobs; ++j) { a.src[j] = jobs[j].src; a.dst[j] = jobs[j].dst; a.w[j] = jobs[j].row_floats; }
+  a.njobs = njobs; a.rows = rows; a.h = h; a.indices = indices; a.key = key_state; a.clear = clear; a.nclear = nclear;
+  const int nwg = (rows + GO2_GATHER_ROWS_PER_WG - 1) / GO2_GATHER_ROWS_PER_WG;
+  hipLaunchKernelGGL(go2_shuffle_gather_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, a);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

@@ -62,6 +62,7 @@ def allreduce_mean_bucket(grads, world, extra=None):
     return flat[off] if extra is not None else None
 
 
+_RANDPERM = torch.randperm          # (the golden tests replace torch.randperm to replay the reference's permutation: then the update takes that one)
 _PLAIN_NOISE = _AC._noise          # (the tests replace ActorCritic._noise to inject the reference's draws: then the rollout asks per step)
 
 
@@ -342,8 +343,16 @@ class PPO(_RolloutHeads):
         t.clear()
         self.actor_critic.reset(dones)
 
+    def rollout_replayed(self):
+        """The runner replayed the captured rollout (act() did not run in Python): the graph re-packed the policy kernel's weights at its first step."""
+        self._pk_packed = self._pk not in (None, False)
+
     def compute_returns(self, last_critic_obs):
-        last_values = self.actor_critic.evaluate(last_critic_obs).detach()
+        pk = self._pk if self._pk not in (None, False) else None
+        if pk is not None and self._pk_packed and last_critic_obs.is_contiguous() and last_critic_obs.dtype == torch.float32:
+            last_values = pk.critic.forward(last_critic_obs)          # the bootstrap value as ONE launch on the weights packed for this rollout (they have not changed since)
+        else:
+            last_values = self.actor_critic.evaluate(last_critic_obs).detach()
         self.storage.compute_returns(last_values, self.gamma, self.lam)
 
     # ------------------------------------------------------------------ update half (ppo.py:120-187)
@@ -544,13 +553,35 @@ class PPO(_RolloutHeads):
                                            enabled=self._capture, warmup=3 if i == 0 else 1, name="PPO mini-batch step %d" % i) for i in range(nmb)]
             else:
                 self._graph = [CapturedStep((lambda i=i: self._graph_step(i)), enabled=self._capture, warmup=3 if i == 0 else 1, name="PPO mini-batch step %d" % i) for i in range(nmb)]
-            # ONE permutation for the whole update, reused by every epoch, as in the reference (rollout_storage.py:150); randperm + the 9 gathers
-            # replayed from a graph (eager, randperm's sort passes leave the device idle for ~0.15 ms between launches)
+            # ONE permutation for the whole update, reused by every epoch, as in the reference (rollout_storage.py:150), and the nine storage tensors gathered
+            # into mini-batch order: ONE launch (go2sim_shuffle_gather: a keyed sort-free shuffle computed per output row + all gathers + the loss accumulators'
+            # reset) instead of torch.randperm's 12-kernel radix sort, 9 index_select launches and the fills between them (~0.36 ms of launch chain per update)
+            import ctypes as C
+            from ..._abi import Go2GatherJob
+            keys = [k for k in self._KEYS]
+            use_lib = self.lib is not None and hasattr(self.lib, "go2sim_shuffle_gather") and all(self._flat[k].dtype == torch.float32 and self._flat[k].is_contiguous() for k in keys)
+            if use_lib:
+                row = lambda t: int(t[0].numel()) if t.dim() > 1 else 1
+                self._gather_jobs = (Go2GatherJob * len(keys))(*[Go2GatherJob(self._flat[k].data_ptr(), self._perm[k].data_ptr(), row(self._flat[k]), 0) for k in keys])
+                seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())          # (torch's host generator: follows torch.manual_seed)
+                self._shuffle_key = torch.tensor([seed, 0, 0, 0], dtype=torch.int32, device=self.device)
+            rows = nmb * mb
+
             def permute():
-                self._acc.zero_()
-                indices = torch.randperm(nmb * mb, requires_grad=False, device=self.device)
-                for k in self._KEYS:
-                    torch.index_select(self._flat[k], 0, indices, out=self._perm[k])
+                if not use_lib:
+                    self._acc.zero_()
+                    indices = torch.randperm(rows, requires_grad=False, device=self.device)
+                    for k in self._KEYS:
+                        torch.index_select(self._flat[k], 0, indices, out=self._perm[k])
+                    return
+                stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream) if str(self.device).startswith("cuda") else None
+                idx = None
+                if torch.randperm is not _RANDPERM:
+                    idx = torch.randperm(rows, requires_grad=False, device=self.device).to(torch.int64).contiguous()
+                rc = self.lib.go2sim_shuffle_gather(self._gather_jobs, len(keys), rows, C.c_void_p(idx.data_ptr()) if idx is not None else None,
+                                                    C.c_void_p(self._shuffle_key.data_ptr()), C.c_void_p(self._acc.data_ptr()), int(self._acc.numel()), stream)
+                if rc != 0:
+                    raise RuntimeError("go2sim_shuffle_gather failed: %s" % self.lib.go2sim_last_error().decode())
             self._permute = CapturedStep(permute, enabled=self._capture, warmup=2, name="PPO rollout permutation", optional=True)
         self._permute()
         for _ in range(self.num_learning_epochs):

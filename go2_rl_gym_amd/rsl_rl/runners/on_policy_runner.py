@@ -113,6 +113,12 @@ class OnPolicyRunner:
         on_gpu = str(device).startswith("cuda") and getattr(getattr(env, "lib", None), "go2sim_is_device_library", lambda: 0)() == 1
         if on_gpu:
             _enable_tuned_gemms()
+            # ROCm trap (round 4): since plain PPO no longer issues a single vendor GEMM, nothing initialises hipBLASLt before the first HIP-graph capture, and
+            # this PyTorch build then dies inside the capture with "operation not permitted when stream is capturing" (hipblaslt.cpp:171: the library's lazy
+            # handle creation).  One 8 x 8 product, eagerly, before anything is captured, restores the order of events every earlier round had.
+            _w = torch.zeros(8, 8, device=self.device)
+            torch.addmm(_w[0], _w, _w)
+            torch.cuda.synchronize(self.device)
         self.use_graphs = bool(on_gpu and self.alg.use_graphs) if use_graphs is None else bool(use_graphs and on_gpu)
         self._rollout_graph, self._graph_ep_infos, self._eager_rollouts = None, None, 0
         self._returns_graph = None
@@ -230,6 +236,7 @@ class OnPolicyRunner:
                     self._rollout_graph.replay()                       # 24 x (policy, env step kernel, storage) in ONE launch
                     self.env.lib.go2sim_notify_replayed(self.env.handle, T)
                     self.alg.storage.step = T
+                    getattr(self.alg, "rollout_replayed", lambda: None)()
                     ep_infos = self._graph_ep_infos
                 elif self.use_graphs and self._eager_rollouts >= 2:
                     torch.cuda.synchronize()
@@ -251,6 +258,7 @@ class OnPolicyRunner:
                         g.replay()                                     # ... so run this iteration's rollout from the graph
                         self.env.lib.go2sim_notify_replayed(self.env.handle, T)
                         self.alg.storage.step = T
+                        getattr(self.alg, "rollout_replayed", lambda: None)()
                         ep_infos = self._graph_ep_infos
                 else:
                     ep_infos = self._rollout(bk)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GO2SIM_ABI_VERSION 6   /* 6: go2sim_ppo_loss: workspace 24*ceil(B/64) floats (was B/256), A <= 16;  5: Go2SimCfg gained control_type / cmd_tracking_curriculum / cmd_max_curriculum, go2sim_reset_idx, episode_info is GO2_EPISODE_INFO_LEN long;  4: Go2SimCfg gained hf_cells / hf_walls (trimesh wall geometry); test hooks go2sim_debug_*;  3: 3: Go2SimCfg gained max_linear_velocity / max_angular_velocity; go2sim_elu_backward_bias workspace is C*ceil(B/64) */
+#define GO2SIM_ABI_VERSION 7   /* 7: + go2sim_shuffle_gather / go2sim_shuffle_index;  6: go2sim_ppo_loss: workspace 24*ceil(B/64) floats (was B/256), A <= 16;  5: Go2SimCfg gained control_type / cmd_tracking_curriculum / cmd_max_curriculum, go2sim_reset_idx, episode_info is GO2_EPISODE_INFO_LEN long;  4: Go2SimCfg gained hf_cells / hf_walls (trimesh wall geometry); test hooks go2sim_debug_*;  3: 3: Go2SimCfg gained max_linear_velocity / max_angular_velocity; go2sim_elu_backward_bias workspace is C*ceil(B/64) */
 
 #define GO2SIM_EINVAL   (-1)  /* bad argument / config */
 #define GO2SIM_ENOMEM   (-2)
@@ -478,6 +478,20 @@ int  go2sim_adam_clip_step(const Go2AdamTensors* t, float* lr, const float* kl_m
  *   history[dones > 0] = 0;  history = cat(history[:, 1:], obs[:, None])      history: float [N,H,D], obs: float [N,D],
  * dones: uint8 [N] or NULL (no zeroing: the push before the first step, :129). */
 int  go2sim_history_push(float* history, const float* obs, const uint8_t* dones, int32_t N, int32_t H, int32_t D, void* stream);
+
+/* The head of PPO.update: ONE permutation of the rollout for all epochs and the gathers of the storage tensors into mini-batch order
+ * (rsl_rl/rsl_rl/storage/rollout_storage.py:147-183: torch.randperm, then obs[b], critic_obs[b], actions[b], ... per mini-batch), as ONE launch instead of
+ * a 12-kernel radix sort and one gather per tensor:   dst_j[r, :] = src_j[pi(r), :]   for every job j (rows of row_floats floats, dense) and r < rows.
+ *   indices != NULL: pi = the given permutation (int64 [rows]; how the tests replay the reference's torch.randperm draw).
+ *   indices == NULL: pi = go2sim_shuffle_index(., rows, key_state[0], key_state[1]) — a keyed pseudo-random BIJECTION of [0, rows): 6 Feistel rounds over the
+ *     next even power of two with cycle walking (no sort, no scratch: every output row computes its own source row) — and key_state[1] is advanced by one when
+ *     the launch is over, so a replayed HIP graph draws a new permutation every time.  key_state: device uint32 [4] = {seed, counter, internal ticket, 0}.
+ * clear / nclear: floats set to zero by the launch (the update's loss accumulators), or NULL.  Up to GO2_GATHER_MAX_JOBS jobs. */
+#define GO2_GATHER_MAX_JOBS 12
+typedef struct Go2GatherJob { const float* src; float* dst; int32_t row_floats; int32_t pad_; } Go2GatherJob;
+int  go2sim_shuffle_gather(const Go2GatherJob* jobs, int32_t njobs, int32_t rows, const int64_t* indices, uint32_t* key_state, float* clear, int32_t nclear, void* stream);
+/* host-callable statement of the permutation (both libraries; no device work): pi(i) for i < n under (seed, counter) */
+uint32_t go2sim_shuffle_index(uint32_t i, uint32_t n, uint32_t seed, uint32_t counter);
 
 #ifdef __cplusplus
 }

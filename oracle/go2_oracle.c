@@ -1453,6 +1453,23 @@ int go2sim_store_transition(const float* rew, const uint8_t* dones, const uint8_
 }
 
 /* on_policy_runner_cts.py:155-156 restated: zero the rows of finished envs, drop the oldest frame, append obs. */
+#include "../include/go2sim_shuffle.h"
+uint32_t go2sim_shuffle_index(uint32_t i, uint32_t n, uint32_t seed, uint32_t counter) { return n ? go2_shuffle_index(i, n, go2_shuffle_half_bits(n), seed, counter) : 0; }
+/* rollout_storage.py:147-183: one permutation, the storage tensors gathered into mini-batch order (see include/go2sim.h) */
+int go2sim_shuffle_gather(const Go2GatherJob* jobs, int32_t njobs, int32_t rows, const int64_t* indices, uint32_t* key_state, float* clear, int32_t nclear, void* stream) {
+  (void)stream;
+  if (!jobs || njobs<=0 || njobs>GO2_GATHER_MAX_JOBS || rows<=0 || (!indices && !key_state) || (nclear>0 && !clear)) return GO2SIM_EINVAL;
+  for (int j=0;j<njobs;++j) if (!jobs[j].src || !jobs[j].dst || jobs[j].row_floats<=0) return GO2SIM_EINVAL;
+  const int h = go2_shuffle_half_bits((uint32_t)rows);
+  for (int32_t r=0;r<rows;++r) {
+    const int64_t sidx = indices ? indices[r] : (int64_t)go2_shuffle_index((uint32_t)r, (uint32_t)rows, h, key_state[0], key_state[1]);
+    for (int j=0;j<njobs;++j) memcpy(jobs[j].dst+(size_t)r*jobs[j].row_floats, jobs[j].src+(size_t)sidx*jobs[j].row_floats, sizeof(float)*(size_t)jobs[j].row_floats);
+  }
+  if (!indices) key_state[1] += 1u;
+  for (int i=0;i<nclear;++i) clear[i]=0.f;
+  return 0;
+}
+
 int go2sim_history_push(float* history, const float* obs, const uint8_t* dones, int32_t N, int32_t H, int32_t D, void* stream) {
   (void)stream;
   if (!history || !obs || N<=0 || H<=0 || D<=0) return GO2SIM_EINVAL;
