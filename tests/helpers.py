@@ -348,14 +348,20 @@ def heightfield_overrides(num_envs_global, seed=11, mesh_type="heightfield", **t
 #   * rough terrain (facet edges, stair faces: a sphere that changes facet changes its normal): the error distribution is heavy-tailed for
 #     the oracle itself, so the gate is relative to it: the kernel's error quantiles stay within a factor of the fp32 oracle's own error
 #     against the fp64 oracle, measured in the same run on the same inputs.
-PLANE_BOUND = {"root_states": 1e-3, "dof_state": 2e-2, "torques": 1e-2, "obs_buf": 1e-3, "privileged_obs_buf": 1e-3, "rew_buf": 2e-5}
+# Round 4: one decade tighter where the measured distribution (profiles/r2_parity_probe.txt, re-run as r4_parity_probe.txt) supports it —
+# root 1e-3 -> 3e-4, joint state 2e-2 -> 5e-3, torques 1e-2 -> 3e-3, observations 1e-3 -> 3e-4 — with the same three exclusion classes, whose COUNTS the checks now print.
+PLANE_BOUND = {"root_states": 3e-4, "dof_state": 5e-3, "torques": 3e-3, "obs_buf": 3e-4, "privileged_obs_buf": 3e-4, "rew_buf": 2e-5}
+# Rough terrain keeps round 3's absolute bound for its well-conditioned env-steps: the tighter plane values are not what its data supports (MI355X, 8000
+# env-steps on the trimesh: 99th percentile of root_states 1.5e-4 against a third of 3e-4 — facet and wall switches inside a step)
+ROUGH_BOUND = {"root_states": 1e-3, "dof_state": 2e-2, "torques": 1e-2, "obs_buf": 1e-3, "privileged_obs_buf": 1e-3, "rew_buf": 2e-5}
 
 
 class StepErrors:
     """Accumulates per-env max-abs differences of the named buffers between two simulators over many steps."""
 
-    def __init__(self, keys):
+    def __init__(self, keys, bounds=None):
         self.d = {k: [] for k in keys}
+        self.bounds = PLANE_BOUND if bounds is None else bounds          # what "ill-conditioned" is measured against (half a bound)
 
     PENALISED = [4, 5, 8, 9, 12, 13, 16, 17]      # thigh / calf bodies of _reward_collision (legged_robot.py:1277-1279)
 
@@ -377,7 +383,7 @@ class StepErrors:
                 # the bound is an ill-conditioned step (e.g. a robot lying on foot + hip of one leg: two strongly coupled contacts, 4 iterations)
                 # and cannot bound a third evaluation; such env-steps are excluded from the fixed bound and counted (check_plane_errors: rare).
                 c = np.abs(np.asarray(getattr(a, k), np.float64) - np.asarray(getattr(ref64, k), np.float64)).reshape(N, -1).max(1)
-                bound = PLANE_BOUND.get(k)
+                bound = self.bounds.get(k)
                 if bound is not None:
                     ill = c > bound / 2
                     self.ill = getattr(self, "ill", 0) + int(ill.sum())
@@ -401,6 +407,9 @@ def ill_conditioned_envs(so, s64):
 
 
 def check_plane_errors(err):
+    print("[parity, plane] %d env-steps; excluded: %d tensor-rows of ill-conditioned env-steps (fp32 oracle further than half a bound from the fp64 oracle), %d env-steps with a "
+          "_reward_collision force within 0.05 N of its 0.1 N threshold; maxima of the rest: %s" % (getattr(err, "steps_seen", 0), getattr(err, "ill", 0), getattr(err, "edge", 0),
+          ", ".join("%s %.1e / %.0e" % (k, float(err.all(k).max()), b) for k, b in PLANE_BOUND.items())))
     for k, bound in PLANE_BOUND.items():
         v = err.all(k)
         assert v.max() < bound, (k, float(v.max()), bound)                                   # every env of every step
@@ -412,11 +421,13 @@ def check_plane_errors(err):
 
 
 def check_rough_errors(err, ill_cap=0.005):
-    """Rough terrain (err accumulated with ref64): every env-step whose fp32-vs-fp64 ORACLE gap is below half of PLANE_BOUND — a
+    """Rough terrain (err accumulated with ref64): every env-step whose fp32-vs-fp64 ORACLE gap is below half of ROUGH_BOUND — a
     well-conditioned step — is within the plane's absolute bound (99.75 % of them; 99 % within a third of it); the others (a sphere at a facet edge or a
     stair face: the fp64 and fp32 oracles themselves take different facets) stay under the conditioning-relative gate only
     (check_relative_to_conditioning) and their share is capped."""
-    for k, bound in PLANE_BOUND.items():
+    print("[parity, rough] %d env-steps; excluded: %d tensor-rows of ill-conditioned env-steps, %d env-steps at the _reward_collision threshold; outside the plane bound: %s"
+          % (getattr(err, "steps_seen", 0), getattr(err, "ill", 0), getattr(err, "edge", 0), ", ".join("%s %d" % (k, int((err.all(k) > b).sum())) for k, b in ROUGH_BOUND.items())))
+    for k, bound in ROUGH_BOUND.items():
         v = err.all(k)
         # A facet / wall switch is a discontinuity of the model that the fp32-vs-fp64 oracle pair only SAMPLES: a sphere a few ulp from a cell
         # boundary can fall on the other side in a third evaluation although the two oracles agree (measured with the host build of the
@@ -425,7 +436,7 @@ def check_rough_errors(err, ill_cap=0.005):
         # the conditioning-relative far-tail gate still covers), 99 % inside a third of it (measured on the MI355X: 2.3e-4 for root_states).
         assert (v > bound).sum() <= 2 + 0.0025 * len(v), (k, int((v > bound).sum()), len(v), float(v.max()), bound)
         assert np.quantile(v, 0.99) < bound / 3, (k, float(np.quantile(v, 0.99)), bound / 3)
-    assert getattr(err, "ill", 0) <= ill_cap * len(PLANE_BOUND) * err.steps_seen, ("ill-conditioned env-steps", err.ill, err.steps_seen)
+    assert getattr(err, "ill", 0) <= ill_cap * len(ROUGH_BOUND) * err.steps_seen, ("ill-conditioned env-steps", err.ill, err.steps_seen)
     assert getattr(err, "edge", 0) <= 0.01 * max(getattr(err, "rows", 1), 1)
 
 

@@ -242,15 +242,15 @@ def test_fallen_robot_reports_base_thigh_and_calf_at_once():
 @pytest.mark.parametrize("mesh_type", ["heightfield", "trimesh"])
 def test_rough_terrain_one_step_parity(mesh_type):
     """CPU twin of tests/test_gpu_parity.py::test_heightfield_one_step_parity_vs_oracle on the curriculum map: every well-conditioned env-step
-    (fp32-vs-fp64 oracle gap below half of PLANE_BOUND) within the plane's absolute bound, the ill-conditioned rest capped."""
-    from helpers import PLANE_BOUND, StepErrors, check_rough_errors, heightfield_overrides
+    (fp32-vs-fp64 oracle gap below half of ROUGH_BOUND) within that absolute bound, the ill-conditioned rest capped."""
+    from helpers import ROUGH_BOUND, StepErrors, check_rough_errors, heightfield_overrides
     M = 48
     _, ov = heightfield_overrides(M, mesh_type=mesh_type)
     so, s64, se = HostSim(load_oracle(), num_envs=M, **ov), HostSim(load_oracle(f64=True), num_envs=M, **ov), HostSim(load_emu(), num_envs=M, **ov)
     for s_ in (so, s64, se):
         s_.reset_all()
     rng = np.random.default_rng(2)
-    err = StepErrors(PLANE_BOUND)
+    err = StepErrors(ROUGH_BOUND, bounds=ROUGH_BOUND)
     for it in range(50):
         a = rng.normal(0, 0.6, (M, 12)).astype(np.float32)
         for k in STEP_STATE:
