@@ -405,8 +405,8 @@ struct LegPhys {
       s_act = fminf(fmaxf((L.contact_offset - gap) / (0.25f * L.contact_offset), 0.f), 1.f);
     }
     GO2_MARK(30);
-    // The other body groups.  Each sub-lane tests its quarter of the leg's 16 non-foot spheres and one of the leg's share of the base / head
-    // points (table slots with a fixed link type per slot, go2_tables.h SubCand: thigh, thigh, calf, calf | hip, base), keeps the deepest PER
+    // The other body groups.  Each sub-lane tests its share of the leg's 22 non-foot points and one of the leg's share of the base / head
+    // points (table slots with a fixed link type per slot, go2_tables.h SubCand: thigh x 3, calf x 2, hip, base), keeps the deepest PER
     // GROUP, and a 2-round quad tournament per group carries the group's deepest — with the base-frame position, radius, body and facet
     // normal its rows need — to all four sub-lanes.  Ties go to the lower candidate index (the scan order of the sequential formulation).
     {
@@ -445,25 +445,27 @@ struct LegPhys {
       bool act[GO2_NTYPE];
       {
         Cand thigh; thigh.clear();
-        if (do_thigh) { thigh.take(sc.idx[0] >= 0, eval(0, R2, q2)); thigh.take(sc.idx[1] >= 0, eval(1, R2, q2)); }
+        if (do_thigh) { thigh.take(sc.idx[0] >= 0, eval(0, R2, q2)); thigh.take(sc.idx[1] >= 0, eval(1, R2, q2)); thigh.take(sc.idx[2] >= 0, eval(2, R2, q2)); }
         act[GO2_T_THIGH] = group_winner<GO2_T_THIGH>(L, thigh);
       }
+      GO2_LOAD_FENCE();
       {
-        Cand calf, hip; calf.clear(); hip.clear();
-        if (do_calf) calf.take(sc.idx[2] >= 0, eval(2, R3, q3));
-        if (do_calf || do_hip) {   // slot 3: a calf point for sub-lanes 0 and 1, a hip point for sub-lanes 2 and 3
-          const bool hipk = sub >= 2;
-          const M3 Rx = {sel(hipk, R1.x, R3.x), sel(hipk, R1.y, R3.y), sel(hipk, R1.z, R3.z)}; const V3 px = sel(hipk, p1, p3);
-          const Cand c3 = eval(3, Rx, px);
-          calf.take(!hipk && sc.idx[3] >= 0, c3); hip.take(hipk && sc.idx[3] >= 0, c3);
-        }
-        act[GO2_T_CALF] = group_winner<GO2_T_CALF>(L, calf); act[GO2_T_HIP] = group_winner<GO2_T_HIP>(L, hip);
+        Cand calf; calf.clear();
+        if (do_calf) { calf.take(sc.idx[3] >= 0, eval(3, R3, q3)); calf.take(sc.idx[4] >= 0, eval(4, R3, q3)); }
+        act[GO2_T_CALF] = group_winner<GO2_T_CALF>(L, calf);
       }
+      GO2_LOAD_FENCE();
+      {
+        Cand hip; hip.clear();
+        if (do_hip) hip.take(sc.idx[GO2_SC_HIP] >= 0, eval(GO2_SC_HIP, R1, p1));      // (the two hip spheres: sub-lanes 2 and 3)
+        act[GO2_T_HIP] = group_winner<GO2_T_HIP>(L, hip);
+      }
+      GO2_LOAD_FENCE();
       {
         Cand base; base.clear();
-        if (do_base) {   // slot 4: one of the leg's base / head points (sub-lane < number of points of this leg)
+        if (do_base) {   // one of the leg's base / head points (sub-lane < number of points of this leg)
           const M3 Id = {v3(1, 0, 0), v3(0, 1, 0), v3(0, 0, 1)};
-          base.take(sc.idx[4] >= 0, eval(4, Id, v3(0, 0, 0)));
+          base.take(sc.idx[GO2_SC_BASE] >= 0, eval(GO2_SC_BASE, Id, v3(0, 0, 0)));
         }
         act[GO2_T_BASE] = group_winner<GO2_T_BASE>(L, base);
       }

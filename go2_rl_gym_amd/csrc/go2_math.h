@@ -24,6 +24,14 @@
 #define GO2_MARK(n) do { } while (0)
 #endif
 
+// a point the compiler does not move LDS / global loads across (device build; nothing at run time): keeps a table value from being loaded long before its use —
+// the step kernel sits at the register file's limit
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GO2_LOAD_FENCE() asm volatile("" ::: "memory")
+#else
+#define GO2_LOAD_FENCE() do { } while (0)
+#endif
+
 // ---- individually rounded fp32 operations -------------------------------------------------------------------------------
 // INDEX arithmetic that the reference does in eager torch (one correctly rounded IEEE operation per tensor op) must come out
 // bit-identical here: a sample that lands an ulp on the other side of a cell boundary reads a different height.  The device build

@@ -8,17 +8,17 @@
 #define GO2_NLEG_OTHER GO2_LEG_OTHER_PTS
 #define GO2_LANE_BASE_PTS 4   // the base / head points are dealt to the 4 legs (i & 3 == leg) and there to the 4 sub-lanes
 static_assert(GO2_BASE_PTS <= 4 * GO2_LANE_BASE_PTS, "one base point per (leg, sub-lane)");
-// the per-leg candidates are tabulated link by link (gen_go2_model.py emits hip, thigh, calf in this order; checked at create)
-#define GO2_N_HIP_PTS 2
-#define GO2_N_THIGH_PTS 8
-#define GO2_N_CALF_PTS 6
+// the per-leg candidates are tabulated link by link (gen_go2_model.py emits hip, thigh, calf in this order, the counts GO2_N_*_PTS with them; checked at create)
+static_assert(GO2_N_HIP_PTS == 2 && GO2_N_THIGH_PTS == 12 && GO2_N_CALF_PTS == 8, "the dealing below: 3 thigh + 2 calf points per sub-lane, the 2 hip points on sub-lanes 2, 3");
 static_assert(GO2_N_HIP_PTS + GO2_N_THIGH_PTS + GO2_N_CALF_PTS == GO2_NLEG_OTHER, "candidate layout");
 
-// the collision candidates ONE sub-lane of a leg tests (go2_lane.h phaseC).  Five table slots with a fixed link type each, so that the
-// link's pose is known at compile time: slots 0, 1 thigh points, slot 2 a calf point, slot 3 a calf point (sub-lanes 0, 1) or a hip point
-// (sub-lanes 2, 3), slot 4 one of the leg's share of the base / head points (sub-lane k < n_base).  idx = position in the sequential
-// scan order (0..15 leg points, 16.. base points; tie-break), -1 = empty slot.
-#define GO2_SUB_CANDS 5
+// the collision candidates ONE sub-lane of a leg tests (go2_lane.h phaseC).  Seven table slots with a fixed link type each, so that the
+// link's pose is known at compile time: slots 0..2 thigh points (8 box corners + round 4's 4 long-edge midpoints), slots 3, 4 calf points (6 capsule
+// end spheres + round 4's 2 mid-segment spheres), slot 5 a hip point (sub-lanes 2, 3), slot 6 one of the leg's share of the base / head points
+// (sub-lane k < n_base).  idx = position in the sequential scan order (0..21 leg points, 22.. base points; tie-break), -1 = empty slot.
+#define GO2_SUB_CANDS 7
+#define GO2_SC_HIP 5
+#define GO2_SC_BASE 6
 struct SubCand { float pt[GO2_SUB_CANDS][4]; int32_t idx[GO2_SUB_CANDS]; int32_t body[GO2_SUB_CANDS]; };
 
 // per-leg constant table (one per leg index 0..3); plain floats/ints so it can be memcpy'd into LDS

@@ -971,20 +971,21 @@ static void fill_tables(Go2Tables* T) {
     for (int g = 0; g < 4; ++g) for (int a = 0; a < 4; ++a) t.cull_ext[g][a] = 0.f;
     for (int i = 0; i < GO2_LEG_OTHER_PTS; ++i) { const int g = t.other_link[i] - 1; for (int a = 0; a < 3; ++a) t.cull_ext[g][a] = fmaxf(t.cull_ext[g][a], fabsf(t.other_pt[i][a]) + t.other_pt[i][3]); }
     for (int k = 0; k < t.n_base; ++k) for (int a = 0; a < 3; ++a) t.cull_ext[3][a] = fmaxf(t.cull_ext[3][a], fabsf(t.base_pt[k][a]) + t.base_pt[k][3]);
-    // deal the candidates to the 4 sub-lanes: slots {thigh, thigh, calf, calf|hip, base} (go2_tables.h SubCand)
+    // deal the candidates to the 4 sub-lanes: slots {thigh x 3, calf x 2, hip (sub-lanes 2, 3), base} (go2_tables.h SubCand)
     for (int sb = 0; sb < 4; ++sb) {
       SubCand& sc = t.cand[sb];
-      const int leg_idx[4] = {GO2_N_HIP_PTS + sb, GO2_N_HIP_PTS + 4 + sb, GO2_N_HIP_PTS + GO2_N_THIGH_PTS + sb,
-                              sb < 2 ? GO2_N_HIP_PTS + GO2_N_THIGH_PTS + 4 + sb : sb - 2};
-      for (int k = 0; k < 4; ++k) {
+      const int T0 = GO2_N_HIP_PTS, C0 = GO2_N_HIP_PTS + GO2_N_THIGH_PTS;
+      const int leg_idx[6] = {T0 + sb, T0 + 4 + sb, T0 + 8 + sb, C0 + sb, C0 + 4 + sb, sb >= 2 ? sb - 2 : -1};
+      for (int k = 0; k < 6; ++k) {
         const int i = leg_idx[k];
+        if (i < 0) { for (int a = 0; a < 4; ++a) sc.pt[k][a] = 0.f; sc.idx[k] = -1; sc.body[k] = 0; continue; }
         for (int a = 0; a < 4; ++a) sc.pt[k][a] = t.other_pt[i][a];
         sc.idx[k] = i; sc.body[k] = t.other_body[i];
-        const int want = k < 2 ? 2 : (k == 2 ? 3 : (sb < 2 ? 3 : 1));
+        const int want = k < 3 ? 2 : (k < 5 ? 3 : 1);
         if (t.other_link[i] != want) T->layout_ok = 0;
       }
-      if (sb < t.n_base) { for (int a = 0; a < 4; ++a) sc.pt[4][a] = t.base_pt[sb][a]; sc.idx[4] = GO2_NLEG_OTHER + sb; sc.body[4] = t.base_body[sb]; }
-      else { for (int a = 0; a < 4; ++a) sc.pt[4][a] = 0.f; sc.idx[4] = -1; sc.body[4] = 0; }
+      if (sb < t.n_base) { for (int a = 0; a < 4; ++a) sc.pt[GO2_SC_BASE][a] = t.base_pt[sb][a]; sc.idx[GO2_SC_BASE] = GO2_NLEG_OTHER + sb; sc.body[GO2_SC_BASE] = t.base_body[sb]; }
+      else { for (int a = 0; a < 4; ++a) sc.pt[GO2_SC_BASE][a] = 0.f; sc.idx[GO2_SC_BASE] = -1; sc.body[GO2_SC_BASE] = 0; }
     }
   }
   T->base.m0 = (float)kMass[0];

@@ -563,7 +563,7 @@ class PPO(_RolloutHeads):
             if use_lib:
                 row = lambda t: int(t[0].numel()) if t.dim() > 1 else 1
                 self._gather_jobs = (Go2GatherJob * len(keys))(*[Go2GatherJob(self._flat[k].data_ptr(), self._perm[k].data_ptr(), row(self._flat[k]), 0) for k in keys])
-                seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())          # (torch's host generator: follows torch.manual_seed)
+                seed = int((torch.initial_seed() * 0x9E3779B1 + 0x7F4A7C15) & 0x7FFFFFFF)          # (follows torch.manual_seed without drawing from the generator)
                 self._shuffle_key = torch.tensor([seed, 0, 0, 0], dtype=torch.int32, device=self.device)
             rows = nmb * mb
 

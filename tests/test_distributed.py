@@ -163,6 +163,10 @@ def _graph_mode_worker(rank, world, port, out):
     lib = load_oracle()
     n = N // world
     res = {}
+    # the graph-mode update draws its own keyed permutation (go2sim_shuffle_gather) unless torch.randperm has been replaced — which is how the golden tests
+    # replay the reference's draw, and how this test gives both update paths the SAME permutation: a pass-through wrapper, seeded by torch.manual_seed below
+    _randperm = torch.randperm
+    torch.randperm = lambda n_, **kw: _randperm(n_, **kw)
     for mode, overlap in ((None, "1"), ("uncaptured", "1"), ("uncaptured", "0")):
         os.environ["GO2_OVERLAP_ALLREDUCE"] = overlap
         torch.manual_seed(11)

@@ -700,6 +700,24 @@ def test_trimesh_walls_on_gpu(hip):
     assert np.all(tw.settle_against_riser(hip, DeviceSim, "heightfield")[:, 0] < 5.93)
 
 
+def test_calf_across_a_nosing_reports_a_calf_force_on_gpu(hip):
+    """The known-answer case of the capsule flank samples (tests/test_trimesh_walls.py::calf_across_nosing) on the HIP kernel: only the middle of the
+    FL calf touches the riser's edge; the calf body reports the force, equal to the oracle's."""
+    import test_trimesh_walls as tw
+    gaps_o, f_o, _ = tw.calf_across_nosing(load_oracle(), HostSim)
+    import torch
+
+    def device_query(lib, s, pts):
+        dp, do = torch.as_tensor(np.ascontiguousarray(pts, np.float32), device="cuda:0"), torch.zeros(len(pts), 4, device="cuda:0")
+        assert lib.go2sim_debug_contact_query(s.h, C.c_void_p(dp.data_ptr()), C.c_void_p(do.data_ptr()), len(pts), s._st()) == 0
+        torch.cuda.synchronize()
+        return do.cpu().numpy()
+    gaps, f, others = tw.calf_across_nosing(hip, DeviceSim, query=device_query)
+    assert gaps[0] > 0.0105 and gaps[1] > 0.03 and abs(gaps[2] + 0.004) < 2e-4, gaps
+    assert f[1] > 1.0 and others == 0.0, (f, others)
+    assert abs(f[1] - f_o[1]) < 2e-3 * f_o[1], (f, f_o)
+
+
 def test_step_rollout_on_gpu(hip):
     """go2sim_step_rollout on the device: redirected observation rows, fused transition store, extras copy == go2sim_step + those operations."""
     from test_lane_emulation import check_step_rollout

@@ -181,3 +181,62 @@ def test_feet_pressed_into_a_riser_are_stopped_by_its_face(which):
     assert np.all(np.abs(tri[:, 2] - r) < 0.006), tri                   # on the lower tread, not lifted onto a ramp
     hfm = settle_against_riser(lib, HostSim, "heightfield")
     assert np.all(hfm[:, 0] < 5.93), hfm                                # pushed down the ramp, ~8 cm further back than the face
+
+
+# --- flank samples of the leg capsules -----------------------------------------------------------------------------------------------------------
+# FL leg kinematics of go2.urdf as include/go2_model_data.h states it (joint origins; the main calf capsule's end spheres and its mid-segment sample)
+_HIP_O, _THIGH_O, _KNEE_O = np.array([0.1934, 0.0465, 0.0]), np.array([0.0, 0.0955, 0.0]), np.array([0.0, 0.0, -0.213])
+_CALF_END_A, _CALF_END_B, _CALF_MID, _CALF_R = np.array([-0.0045076, 0.0, -0.0013181]), np.array([0.0205076, 0.0, -0.1186819]), np.array([0.008, 0.0, -0.06]), 0.012
+FL_THIGH_B, FL_CALF_B, FL_FOOT_B = 4, 5, 6
+
+
+def _roty(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+
+
+def calf_across_nosing(lib, sim, query=query):
+    """Known-answer case of the mid-segment samples (tools/gen_go2_model.py, kind 4 points of a capsule): the FL calf lies ACROSS the nosing of the
+    15-cm riser at x = 6 m — its upper end sphere hangs 14 mm above the upper tread (outside the contact offset), its lower end sphere is 4.5 cm in
+    front of the face, and only the middle of the capsule touches the edge (4 mm deep).  A leg collided by end spheres alone reports no calf force
+    here (and the robot's calf sinks through the nosing until an end arrives); with the mid sample the calf body reports the contact, which is what
+    PhysX's capsule does and what _reward_collision reads (legged_robot.py:1277-1279).
+    -> (gaps of [end A, end B, mid] from the contact query before the step, |F| of FL thigh / calf / foot after one env step)."""
+    _, ov = riser_world("trimesh")
+    kw = dict(turn_over=1, turn_over_proportions=np.array([0.0, 0.0, 1.0], np.float32), push_robots=0, seed=3, kp=[0.0] * 12, kd=[0.5] * 12,
+              randomize_action_delay=0, add_noise=0)
+    s = sim(lib, num_envs=1, **ov, **kw)
+    s.reset_all()
+    q2, alpha = 0.6, 0.3                                              # thigh leaning back; the capsule's axis 0.3 rad below the horizontal
+    u = (_CALF_END_B - _CALF_END_A) / np.linalg.norm(_CALF_END_B - _CALF_END_A)
+    q3 = -(np.pi / 2 - alpha) + np.arctan2(u[0], -u[2]) - q2         # R_y(q2 + q3) u = (cos alpha, 0, -sin alpha)
+    assert np.allclose(_roty(q2 + q3) @ u, [np.cos(alpha), 0, -np.sin(alpha)], atol=1e-9) and -2.7227 < q3 < -0.83776
+    # the robot stands on the UPPER level facing -x (yaw pi), so its FL calf points over the edge towards the lower level
+    yaw = np.diag([-1.0, -1.0, 1.0])
+    knee = _HIP_O + _THIGH_O + _roty(q2) @ _KNEE_O                   # base frame (hip joint at 0)
+    Rc = _roty(q2 + q3)
+    mid_b = knee + Rc @ _CALF_MID
+    base = np.array([6.0, 1.0, STEP_H + _CALF_R - 0.004]) - yaw @ mid_b        # the mid sample's sphere: centre over the edge, 4 mm deep
+    world = lambda p: base + yaw @ (knee + Rc @ p)
+    root = np.asarray(s.root_states).copy(); root[0, :3] = base; root[0, 3:7] = [0, 0, 1, 0]; root[0, 7:] = 0
+    s.root_states[:] = root
+    d = np.asarray(s.dof_state).copy(); d[0, :, 1] = 0
+    d[0, :, 0] = [0.0, q2, q3] + [0.0, 1.5, -2.6] * 3                  # the other three legs tucked up, clear of the tread
+    s.dof_state[:] = d
+    pts = np.array([list(world(p)) + [_CALF_R] for p in (_CALF_END_A, _CALF_END_B, _CALF_MID)], np.float32)
+    gaps = query(lib, s, pts)[:, 0].copy()
+    s.step(np.zeros((1, 12), np.float32))
+    f = np.linalg.norm(np.asarray(s.contact_forces, np.float64)[0, [FL_THIGH_B, FL_CALF_B, FL_FOOT_B]], axis=-1)
+    others = np.linalg.norm(np.delete(np.asarray(s.contact_forces, np.float64)[0], FL_CALF_B, axis=0), axis=-1).max()
+    s.close()
+    return gaps, f, others
+
+
+@pytest.mark.parametrize("which", ["oracle", "lane_emulation"])
+def test_calf_lying_across_a_nosing_between_its_end_spheres_reports_a_calf_force(which):
+    lib = {"oracle": load_oracle, "lane_emulation": load_emu}[which]()
+    gaps, f, others = calf_across_nosing(lib, HostSim)
+    assert gaps[0] > 0.0105 and gaps[1] > 0.03, gaps                 # both end spheres outside the contact offset (1 cm): alone they see nothing
+    assert abs(gaps[2] + 0.004) < 2e-4, gaps                           # the mid sample is 4 mm into the edge
+    assert f[1] > 1.0, f                                               # ... and the calf body reports it
+    assert others == 0.0, others                                       # nothing else of the robot touches anything

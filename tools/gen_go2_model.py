@@ -125,12 +125,25 @@ for ln in link_order:
             ax = Rw @ np.array([0, 0, 1.0])
             spheres.append((body, mi, tw + 0.5 * L * ax, r, 1))
             spheres.append((body, mi, tw - 0.5 * L * ax, r, 1))
+            if mi != 0 and L >= 0.06:
+                # replace_cylinder_with_capsule (legged_robot.py:965-980): a capsule is its two end spheres EXACTLY on a plane (the lowest point of a
+                # segment is an end); on the trimesh a stair nosing can enter BETWEEN the ends of a long one.  Round 4: the two long calf capsules
+                # (0.12 m, 0.065 m) carry a mid-segment sphere (kind 4: sorted behind the link's end spheres below, so ties on a plane go to an end)
+                spheres.append((body, mi, tw, r, 4))
         elif g.tag == "box":
             sx, sy, sz = vec(g.get("size"))
             for a in (-1, 1):
                 for b_ in (-1, 1):
                     for c_ in (-1, 1):
                         spheres.append((body, mi, tw + Rw @ np.array([a * sx / 2, b_ * sy / 2, c_ * sz / 2]), 0.0, 2))
+            if mi != 0:
+                # the thigh box (0.11 m long, go2.urdf:206-209): midpoints of its four long edges (kind 4), for the same reason
+                ext = [sx, sy, sz]; la = int(np.argmax(ext))
+                for b_ in (-1, 1):
+                    for c_ in (-1, 1):
+                        v = [0.0, 0.0, 0.0]; oth = [k for k in range(3) if k != la]
+                        v[oth[0]] = b_ * ext[oth[0]] / 2; v[oth[1]] = c_ * ext[oth[1]] / 2
+                        spheres.append((body, mi, tw + Rw @ np.array(v), 0.0, 4))
             if mi == 0 and BODY_NAMES[body] == "base":
                 # The trunk box is the one primitive long enough (0.376 m) for the ground to reach it BETWEEN its corners — a stair nosing or
                 # an obstacle edge under the belly (mesh_type 'trimesh').  Extra surface samples, appended after all other base points below
@@ -143,7 +156,9 @@ for ln in link_order:
 # group: feet first (one per leg), then per-leg non-foot, then base-attached
 feet = [s for s in spheres if BODY_NAMES[s[0]].endswith("foot")]
 assert len(feet) == 4
-leg_other = [[s for s in spheres if (1 + 3 * l) <= s[1] <= (3 + 3 * l) and not BODY_NAMES[s[0]].endswith("foot")] for l in range(4)]
+# per leg: link by link (hip, thigh, calf), inside a link the primitive's own points first and the round-4 flank samples (kind 4) behind them
+leg_other = [[s for lk in (1, 2, 3) for kinds in ((0, 1, 2), (4,)) for s in spheres
+              if s[1] == lk + 3 * l and s[4] in kinds and not BODY_NAMES[s[0]].endswith("foot")] for l in range(4)]
 base_pts = [s for s in spheres if s[1] == 0 and s[4] != 3] + [s for s in spheres if s[1] == 0 and s[4] == 3]
 assert len(base_pts) <= 16, "the lane programs deal the base points to 4 legs x 4 sub-lanes (go2_tables.h)"
 n_leg_other = len(leg_other[0]); assert all(len(x) == n_leg_other for x in leg_other)
@@ -157,6 +172,8 @@ o.append(" * loaded at legged_gym/envs/base/legged_robot.py:961-980). Numbers on
 o.append("#ifndef GO2_MODEL_DATA_H\n#define GO2_MODEL_DATA_H\n")
 o.append(f"#define GO2_NUM_BODIES {len(bodies)}\n#define GO2_NUM_DOF 12\n#define GO2_NUM_LEGS 4\n#define GO2_NUM_LINKS 13")
 o.append(f"#define GO2_LEG_OTHER_PTS {n_leg_other}   /* non-foot collision candidates per leg */")
+for nm, lk in (("HIP", 1), ("THIGH", 2), ("CALF", 3)):
+    o.append(f"#define GO2_N_{nm}_PTS {sum(1 for s in leg_other[0] if s[1] == lk)}")
 o.append(f"#define GO2_BASE_PTS {len(base_pts)}       /* candidates rigidly attached to the base (base box, heads) */")
 o.append(f"#define GO2_TOTAL_MASS {f(total_mass)}\n")
 o.append("/* body order used for contact_forces[N,19,3] / rigid_body_states[N,19,13] */")
