@@ -10,7 +10,7 @@ import torch.nn as nn
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 NN_LIB = os.path.join(_HERE, "libgo2nn_hip.so")
-GO2NN_MAX_LAYERS, GO2NN_MAX_WIDTH, GO2NN_ABI_VERSION, GO2NN_MAX_GROUP = 6, 512, 3, 2
+GO2NN_MAX_LAYERS, GO2NN_MAX_WIDTH, GO2NN_ABI_VERSION, GO2NN_MAX_GROUP = 6, 512, 4, 2
 _cached = None
 
 
@@ -19,16 +19,21 @@ class Go2nnSumJob(C.Structure):
 
 
 class Go2nnFwdJob(C.Structure):
-    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("b", C.c_void_p), ("y", C.c_void_p), ("M", C.c_int32), ("K", C.c_int32), ("N", C.c_int32)]
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("b", C.c_void_p), ("y", C.c_void_p), ("M", C.c_int32), ("K", C.c_int32), ("N", C.c_int32), ("pad_", C.c_int32),
+                ("w_split", C.c_void_p)]          # ABI 4: the weight's split image (go2nn_split_weights) selects the 3 x bf16 kernel; None = fp32 MFMA
 
 
 class Go2nnBwdInJob(C.Structure):
     _fields_ = [("gz", C.c_void_p), ("w", C.c_void_p), ("y_prev", C.c_void_p), ("gz_prev", C.c_void_p), ("workspace", C.c_void_p),
-                ("M", C.c_int32), ("C", C.c_int32), ("Kin", C.c_int32)]
+                ("M", C.c_int32), ("C", C.c_int32), ("Kin", C.c_int32), ("pad_", C.c_int32), ("w_split", C.c_void_p)]
 
 
 class Go2nnBwdWJob(C.Structure):
-    _fields_ = [("gz", C.c_void_p), ("x", C.c_void_p), ("workspace", C.c_void_p), ("M", C.c_int32), ("C", C.c_int32), ("Kin", C.c_int32)]
+    _fields_ = [("gz", C.c_void_p), ("x", C.c_void_p), ("workspace", C.c_void_p), ("M", C.c_int32), ("C", C.c_int32), ("Kin", C.c_int32), ("split", C.c_int32)]
+
+
+class Go2nnSplitJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("image", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32)]
 
 
 class Go2nnPpoHeads(C.Structure):
@@ -66,6 +71,9 @@ def bind(path):
     lib.go2nn_linear_backward_input_group.argtypes = [C.POINTER(Go2nnBwdInJob), C.c_int32, C.c_void_p]
     lib.go2nn_linear_backward_weight_group_rows.argtypes = [C.POINTER(Go2nnBwdWJob), C.c_int32]
     lib.go2nn_linear_backward_weight_group.argtypes = [C.POINTER(Go2nnBwdWJob), C.c_int32, C.c_void_p]
+    lib.go2nn_split_weights_bytes.restype = C.c_int64
+    lib.go2nn_split_weights_bytes.argtypes = [C.c_int32] * 2
+    lib.go2nn_split_weights.argtypes = [C.POINTER(Go2nnSplitJob), C.c_int32, C.c_void_p]
     lib.go2nn_ppo_heads_rows.argtypes = [C.c_int32] * 3
     lib.go2nn_ppo_heads_cols.argtypes = [C.c_int32] * 2
     lib.go2nn_ppo_heads.argtypes = [C.POINTER(Go2nnPpoHeads), C.c_void_p]

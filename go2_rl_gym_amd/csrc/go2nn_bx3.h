@@ -1,0 +1,350 @@
+// go2nn_bx3.h — the learner's GEMMs on the bf16 matrix pipe with fp32 operands: every fp32 value is split EXACTLY into three bf16 planes
+// (hi + mid + lo = 8 + 8 + 8 significand bits, round-to-nearest at each level) and a product a . b is formed from six bf16 MFMA terms with fp32 accumulation:
+//     a b  ~=  hi hi + hi mid + mid hi + mid mid + hi lo + lo hi          (dropped: mid lo, lo mid, lo lo  <  2^-23 |a b|)
+// The dropped terms are below the fp32 rounding of the product itself, and a 512-deep contraction takes 192 accumulator roundings here against 256 with
+// v_mfma_f32_32x32x2_f32 — measured against float64 the result is as close as the fp32-MFMA kernels' (tools/gemm3_bench.cpp prints both; tests/test_gpu_mlp_tail.py
+// holds the same tolerances for both).  What it buys: v_mfma_f32_32x32x16_bf16 issues every 32 cycles for 16 k, the fp32 form every 64 cycles for 2 k — six terms
+// cost 192 cycles per 16 k against 512 (MI355X guide, per-instruction constants).  This is NOT bf16 arithmetic: no operand bit is dropped.
+// (included by go2nn_impl.cpp after go2nn_gemm3.h, whose staging class G3Stage and epilogue conventions it shares.)
+//
+//   go2nn_bx3_split_kernel      weights [N][K] fp32 -> the plane images both GEMM orientations read (once per optimizer step; the matrices are small)
+//   go2nn_bx3_kernel<TM, EPI>   forward  Y = elu(X W^T + b)  and input gradient  Gp = (G W) * elu'(Yp) + column sums, grouped (actor + critic tiles in one grid)
+//        A operand (activations / gradients, [M][K] fp32 in HBM): staged through registers as in go2nn_gemm3_kernel, split on the way to LDS (22 VALU
+//        instructions per 4 values, beside the other workgroup's MFMAs: two workgroups per CU)
+//        B operand (weights): read as ready-made plane tiles, a linear 24 KB copy per 128 x 32 tile
+//        LDS image of a plane: [row][32 k] bf16 = 64 B per row, the four 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3 — a fragment read
+//        (ds_read_b128: lane i reads chunk 2 kb + g of row i) is conflict-free in each of the instruction's 16-lane groups, and so are the 8-byte stores
+//   go2nn_wgrad_bx3_kernel      weight gradient dW = G^T X: both operands k-strided; a lane gathers its 8 contraction rows with 8 coalesced loads, splits them in
+//        registers and feeds the MFMAs directly (no LDS in the loop), as go2nn_wgrad_kernel does for fp32
+#pragma once
+
+#ifndef GO2_EMU
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#endif
+
+#define BX3_BK 16
+#ifndef BX3_SGB_VALU
+#define BX3_SGB_VALU 5
+#endif
+#define BX3_TILE_BYTES 12288          /* one 128-row x 16-k weight tile: 3 planes x 128 rows x 32 B */
+
+#ifdef GO2_EMU
+#define BX3_HD
+#else
+#define BX3_HD __host__ __device__
+#endif
+BX3_HD static inline long long bx3_image_bytes(int rows, int con) { return (long long)((rows + 127) / 128) * ((con + BX3_BK - 1) / BX3_BK) * BX3_TILE_BYTES; }
+
+struct Bx3Prob {
+  const float* A; const unsigned char* B; float* C; const float* bias; const float* Y; float* part;
+  int M, N, K, lda, ldc, nbm, nbn, c_vec, nkt;
+};
+struct Bx3Args { Bx3Prob p[2]; int ntiles0, ntiles; long long* stamps; };
+struct Bx3SplitJob { const float* w; unsigned char* img; int N, K; };          // img: forward image, then the transposed one
+struct Bx3SplitArgs { Bx3SplitJob j[8]; int njobs; };
+
+#ifndef GO2_EMU
+__device__ __forceinline__ unsigned bx3_pk(float a, float b) { f32x2 v = {a, b}; return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
+__device__ __forceinline__ float bx3_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bx3_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+// four fp32 -> three planes of four bf16 (8 bytes each); the residuals are exact (Sterbenz: hi is within a factor 2 of x, so x - hi needs no rounding)
+__device__ __forceinline__ void bx3_split4(const f32x4& x, u32x2& h, u32x2& m, u32x2& l) {
+  h[0] = bx3_pk(x[0], x[1]); h[1] = bx3_pk(x[2], x[3]);
+  const float r0 = x[0] - bx3_lo(h[0]), r1 = x[1] - bx3_hi(h[0]), r2 = x[2] - bx3_lo(h[1]), r3 = x[3] - bx3_hi(h[1]);
+  m[0] = bx3_pk(r0, r1); m[1] = bx3_pk(r2, r3);
+  const float s0 = r0 - bx3_lo(m[0]), s1 = r1 - bx3_hi(m[0]), s2 = r2 - bx3_lo(m[1]), s3 = r3 - bx3_hi(m[1]);
+  l[0] = bx3_pk(s0, s1); l[1] = bx3_pk(s2, s3);
+}
+
+// ---- weights -> plane images -----------------------------------------------------------------------------------------------------------------------------
+// image of an operand with `rows` rows and a contraction of `con`: [row tile of 128][k tile of 16][plane][row][chunk ^ ((row >> 3) & 1)][8 bf16], zero beyond the
+// matrix.  One thread per (tile, row, chunk): 8 values, 3 x 16 bytes out.  blockIdx.y = 2 job + orientation (0: rows = n, con = k; 1: rows = k, con = n).
+__global__ void __launch_bounds__(256) go2nn_bx3_split_kernel(const Bx3SplitArgs sa) {
+  const int job = blockIdx.y >> 1, tr = blockIdx.y & 1;
+  const Bx3SplitJob& j = sa.j[job];
+  const int rows = tr ? j.K : j.N, con = tr ? j.N : j.K;
+  const int nrt = (rows + 127) / 128, nkt = (con + BX3_BK - 1) / BX3_BK;
+  const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (long long)nrt * nkt * 256) return;
+  const int chunk = (int)(id & 1), r = (int)(id >> 1) & 127, tile = (int)(id >> 8), kt = tile % nkt, rt = tile / nkt;
+  const int row = rt * 128 + r, c0 = kt * BX3_BK + chunk * 8;
+  f32x4 v[2];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = c0 + e;
+    const bool in = row < rows && c < con;
+    const int rr = min(row, rows - 1), cc = min(c, con - 1);
+    const float x = tr ? j.w[(size_t)cc * j.K + rr] : j.w[(size_t)rr * j.K + cc];
+    v[e >> 2][e & 3] = in ? x : 0.f;
+  }
+  u32x2 h0, m0, l0, h1, m1, l1;
+  bx3_split4(v[0], h0, m0, l0); bx3_split4(v[1], h1, m1, l1);
+  unsigned char* img = j.img + (tr ? bx3_image_bytes(j.N, j.K) : 0) + (size_t)tile * BX3_TILE_BYTES + r * 32 + ((chunk ^ ((r >> 3) & 1)) << 4);
+  *reinterpret_cast<u32x4*>(img) = u32x4{h0[0], h0[1], h1[0], h1[1]};
+  *reinterpret_cast<u32x4*>(img + 4096) = u32x4{m0[0], m0[1], m1[0], m1[1]};
+  *reinterpret_cast<u32x4*>(img + 8192) = u32x4{l0[0], l0[1], l1[0], l1[1]};
+}
+
+// ---- forward / input gradient ---------------------------------------------------------------------------------------------------------------------------
+// k-tiles of 16 (one MFMA k-block), two LDS stages, two staging register sets (the loads of tile kt + 2 are issued at the top of tile kt).  One k-tile, per wave:
+//     top      global loads of tile kt + 2
+//     phase 1  the first three terms' MFMAs on the fragments of tile kt; the staged tile kt + 1 is split and written to the other stage
+//     barrier  (tile kt + 1 is in LDS; every wave is past its reads of that stage, they were waited for in front of the MFMAs of tile kt - 1)
+//     phase 2  the fragments of tile kt + 1 are requested (inline-asm ds_read_b128, one counted wait at the top of the next tile), the other three terms' MFMAs
+template <int OFF> __device__ __forceinline__ void bx3_dsr128(u32x4& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF) : "memory"); }
+// fragments of one k-tile: hi and mid planes (two sets alternate between the tiles); the lo planes are used by the first two terms only, so ONE set serves every
+// tile — it is re-read in phase 2, behind the MFMAs that consumed it
+template <int TM> struct Bx3Frags {
+  u32x4 a[TM][2], b[2][2];
+  __device__ __forceinline__ void opaque() {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int t = 0; t < TM; ++t) g3_opaque(a[t][p]);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) g3_opaque(b[t][p]);
+    }
+  }
+};
+template <int TM, int EPI>
+__global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
+  constexpr int BM = 64 * TM, BN = 128, BK = BX3_BK, TN = 2;
+  constexpr int AP = BM * 32, BP = 4096, BOFF = 3 * AP, STAGE = 3 * AP + 3 * BP, LOOP_LDS = 2 * STAGE, EPI_LDS = 4 * 32 * 32 * TN * 4;
+  using SA = G3Stage<BM, true, BK>;
+  using FR = Bx3Frags<TM>;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LOOP_LDS > EPI_LDS ? LOOP_LDS : EPI_LDS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, gk = lane >> 5, wm = wave & 1, wn = wave >> 1;
+  // workgroup -> tile: each problem's tiles dealt to the 8 XCDs in contiguous runs (go2nn_gemm3_kernel)
+  int t = blockIdx.x, pi;
+  const int n0 = ga.ntiles0, n1 = ga.ntiles - ga.ntiles0;
+  if (((n0 | n1) & 7) == 0) { const int x = t & 7, j = t >> 3, c0 = n0 >> 3, c1 = n1 >> 3; pi = j >= c0 ? 1 : 0; t = pi ? x * c1 + (j - c0) : x * c0 + j; }
+  else { pi = t >= n0 ? 1 : 0; t -= pi ? n0 : 0; }
+  const Bx3Prob& g = ga.p[pi];
+  const int bm = t / g.nbn, bn = t - bm * g.nbn;
+  const int row0 = bm * BM, col0 = bn * BN;
+  const int nk = g.nkt;
+
+#ifdef GM3_STAMPS
+  long long st_[6] = {0, 0, 0, 0, 0, 0};
+  const long long wall0_ = wall_clock64();
+#endif
+  G3_T(0);
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  SA sa; sa.init(g.A, g.lda, row0, g.M, g.K, tid);
+  f32x4 ba0[SA::P], ba1[SA::P]; u32x4 bb[3];          // A: two staging sets (HBM latency: two tiles ahead); B: one (L2 hits: re-issued as soon as it is committed)
+  const unsigned char* bimg = g.B + (size_t)bn * nk * BX3_TILE_BYTES + tid * 16;
+  auto issue_b = [&](int kt) __attribute__((always_inline)) {
+    const unsigned char* s = bimg + (size_t)kt * BX3_TILE_BYTES;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) bb[p] = *reinterpret_cast<const u32x4*>(s + p * 4096);
+  };
+  // staging thread -> LDS: row = tid / 4 + 64 p, k-quad kq = tid % 4 (half a 16-byte chunk)
+  const int kq = tid & 3, srow = tid >> 2;
+  const unsigned st_off = (unsigned)(srow * 32 + (((kq >> 1) ^ ((srow >> 3) & 1)) << 4) + ((kq & 1) << 3));          // (+ 64 p rows: the same swizzle bit)
+  auto commit = [&](auto fix_c, int stage, int kt, const f32x4 (&ba)[SA::P]) __attribute__((always_inline)) {
+    constexpr bool FIX = decltype(fix_c)::value;
+    unsigned char* st = lds + stage * STAGE;
+#pragma unroll
+    for (int p = 0; p < SA::P; ++p) {
+      f32x4 v = ba[p];
+      if (FIX) {        // the k-tile that crosses K: quads the clamp moved left are shifted back, k >= K is zero (go2nn_gemm3.h: G3Stage::commit_piece<true>)
+        const int k = kt * BK + sa.lead, sh = k - min(k, g.K - 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { float tv = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) tv = (q == e + sh) ? ba[p][q] : tv;
+          v[e] = k + e < g.K ? tv : 0.f; }
+      }
+      u32x2 h, m, l; bx3_split4(v, h, m, l);
+      unsigned char* d = st + st_off + p * (64 * 32);
+      *reinterpret_cast<u32x2*>(d) = h; *reinterpret_cast<u32x2*>(d + AP) = m; *reinterpret_cast<u32x2*>(d + 2 * AP) = l;
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(st + BOFF + p * 4096 + tid * 16) = bb[p];
+  };
+  // fragment reads: lane i of a 32-row tile reads chunk gk of row i (stage, plane and tile offsets are instruction immediates)
+  const unsigned lbase = (unsigned)(uintptr_t)lds;
+  const unsigned fch = (unsigned)((gk ^ ((i >> 3) & 1)) << 4);
+  const unsigned fa = lbase + (unsigned)((wm * 32 * TM + i) * 32) + fch, fb = lbase + (unsigned)(BOFF + (wn * 64 + i) * 32) + fch;
+  FR f0, f1; u32x4 la[TM], lb[2];
+  auto read_frags = [&](auto stage_c, FR& f) __attribute__((always_inline)) {
+    constexpr int SOFF = decltype(stage_c)::value * STAGE;
+    g3_for<0, TM>([&](auto a_c) __attribute__((always_inline)) { constexpr int A = decltype(a_c)::value; bx3_dsr128<SOFF + 2 * AP + A * 32 * 32>(la[A], fa); });
+    g3_for<0, 2>([&](auto b_c) __attribute__((always_inline)) { constexpr int B = decltype(b_c)::value; bx3_dsr128<SOFF + 2 * BP + B * 32 * 32>(lb[B], fb); });
+    g3_for<0, 2>([&](auto p_c) __attribute__((always_inline)) {
+      constexpr int P = decltype(p_c)::value;
+      g3_for<0, TM>([&](auto a_c) __attribute__((always_inline)) { constexpr int A = decltype(a_c)::value; bx3_dsr128<SOFF + P * AP + A * 32 * 32>(f.a[A][P], fa); });
+      g3_for<0, 2>([&](auto b_c) __attribute__((always_inline)) { constexpr int B = decltype(b_c)::value; bx3_dsr128<SOFF + P * BP + B * 32 * 32>(f.b[B][P], fb); });
+    });
+  };
+  // six terms, small ones first (plane 0 hi, 1 mid, 2 lo); consecutive MFMAs go to different accumulators
+  auto mfmas = [&](auto q0_c, auto q1_c, const FR& f) __attribute__((always_inline)) {
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    g3_for<decltype(q0_c)::value, decltype(q1_c)::value>([&](auto q_c) __attribute__((always_inline)) {
+      constexpr int Q = decltype(q_c)::value;
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          const u32x4 av = PA[Q] == 2 ? la[a] : f.a[a][PA[Q] & 1], bv = PB[Q] == 2 ? lb[b] : f.b[b][PB[Q] & 1];
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[a][b], 0, 0, 0);
+        }
+    });
+  };
+  auto lo_opaque = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < TM; ++t) g3_opaque(la[t]);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) g3_opaque(lb[t]);
+  };
+
+  // One k-tile, held in stage CUR (= kt & 1).  MORE: tile kt + 1 follows.
+  // A contraction that is not a multiple of 16 leaves a ragged last tile: the pipelined loop runs the nkp whole tiles, the ragged one is a pass of its own behind it
+  // (its displaced quads are put right on the way to LDS: a branch in the loop's commit would keep the scheduler from placing the split between the MFMAs)
+  const bool ragged = (g.K & (BK - 1)) != 0;
+  const int nkp = ragged ? nk - 1 : nk;
+  auto tile = [&](auto cur_c, auto more_c, int kt) __attribute__((always_inline)) {
+    constexpr int CUR = decltype(cur_c)::value; constexpr bool MORE = decltype(more_c)::value;
+    auto& a_ld = CUR ? ba1 : ba0; auto& a_st = CUR ? ba0 : ba1;
+    FR& fc = CUR ? f1 : f0; FR& fn = CUR ? f0 : f1;
+#ifndef BX3_DBG_NOA
+    if constexpr (MORE) { const int k2 = min(kt + 2, nkp - 1); sa.issue(k2 * BK, a_ld); }          // (past the last tile: a re-read that is never used — straight-line code)
+#endif
+    g3_wait_lgkm<0>();
+    fc.opaque(); lo_opaque();
+    mfmas(G3Int<0>{}, G3Int<3>{}, fc);
+    if constexpr (MORE) {
+#ifndef BX3_DBG_NOCOMMIT
+      commit(G3Int<0>{}, CUR ^ 1, kt + 1, a_st);
+#endif
+#ifndef BX3_DBG_NOB
+      issue_b(min(kt + 2, nkp - 1));
+#endif
+#ifndef BX3_NO_SGB
+      // the split's VALU work and the LDS stores between the MFMAs (a bf16 MFMA occupies the matrix pipe for 32 cycles: room for ~6 other issues)
+#pragma unroll
+      for (int q = 0; q < 6 * TM; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, BX3_SGB_VALU, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        if (q < 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+#ifndef BX3_DBG_NOBAR
+      __syncthreads();
+#endif
+#ifndef BX3_DBG_NOREAD
+      read_frags(G3Int<CUR ^ 1>{}, fn);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mfmas(G3Int<3>{}, G3Int<6>{}, fc);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  constexpr G3Int<0> I0{}; constexpr G3Int<1> I1{};
+  if (nkp > 0) {
+    sa.issue(0, ba0); issue_b(0);
+    if (nkp > 1) sa.issue(BK, ba1);
+    commit(I0, 0, 0, ba0);
+    if (nkp > 1) issue_b(1);
+    __syncthreads();
+    read_frags(I0, f0);
+    G3_T(1);
+    int kt = 0;
+    for (; kt + 2 < nkp; kt += 2) { tile(I0, I1, kt); tile(I1, I1, kt + 1); }
+    if (nkp - kt == 2) { tile(I0, I1, kt); tile(I1, I0, kt + 1); }
+    else tile(I0, I0, kt);
+  }
+  if (ragged) {
+    __syncthreads();
+    sa.issue((nk - 1) * BK, ba0); issue_b(nk - 1);
+    commit(I1, 0, nk - 1, ba0);
+    __syncthreads();
+    read_frags(I0, f0);
+    g3_wait_lgkm<0>();
+    f0.opaque(); lo_opaque();
+    mfmas(G3Int<0>{}, G3Int<6>{}, f0);
+  }
+  G3_T(2);
+  __syncthreads();          // every wave is done with the stages: the epilogue turns tiles through the same LDS
+  G3_T(3);
+
+  // epilogue: go2nn_gemm3_kernel's (every wave turns its tile, 32 rows at a time, through its LDS quarter; 16-byte row accesses)
+  constexpr int CT = 32 * TN, LPR = CT / 4, RPI = 64 / LPR, NI = 32 / RPI;
+  const int lc = (lane % LPR) * 4, lr = lane / LPR;
+  const int col = col0 + wn * CT + lc;
+  const bool cv = g.c_vec != 0 && col + 3 < g.N;
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (EPI == EPI_BIAS_ELU) {
+    const int c1 = min(col, g.N - 1), c2 = min(col + 1, g.N - 1), c3 = min(col + 2, g.N - 1), c4 = min(col + 3, g.N - 1);
+    bias4 = make_float4(g.bias[c1], g.bias[c2], g.bias[c3], g.bias[c4]);
+  }
+  {
+    float* wl = reinterpret_cast<float*>(lds) + wave * (32 * CT);
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const int rbase = row0 + wm * 32 * TM + a * 32 + lr;
+      float4 y4[EPI == EPI_DELU_COLSUM ? NI : 1];
+      if (EPI == EPI_DELU_COLSUM) {
+#pragma unroll
+        for (int n = 0; n < NI; ++n) {
+          const float* q = g.Y + (size_t)min(rbase + n * RPI, g.M - 1) * g.ldc;
+          if (cv) y4[n] = *reinterpret_cast<const float4*>(q + col);
+          else y4[n] = make_float4(q[min(col, g.N - 1)], q[min(col + 1, g.N - 1)], q[min(col + 2, g.N - 1)], q[min(col + 3, g.N - 1)]);
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * gk;
+          const int cc = b * 32 + i;
+          wl[row * CT + (cc ^ (gk << 5 & (CT - 1)))] = acc[a][b][r];
+        }
+#pragma unroll
+      for (int n = 0; n < NI; ++n) {
+        const int lrow = lr + n * RPI, row = rbase + n * RPI;
+        float4 v = *reinterpret_cast<const float4*>(wl + lrow * CT + (lc ^ ((lrow >> 2 & 1) << 5 & (CT - 1))));
+        if (EPI == EPI_BIAS_ELU) v = make_float4(elu1(v.x + bias4.x), elu1(v.y + bias4.y), elu1(v.z + bias4.z), elu1(v.w + bias4.w));
+        if (EPI == EPI_DELU_COLSUM) {
+          const float4 y = y4[EPI == EPI_DELU_COLSUM ? n : 0];
+          v.x *= y.x > 0.f ? 1.f : y.x + 1.f; v.y *= y.y > 0.f ? 1.f : y.y + 1.f; v.z *= y.z > 0.f ? 1.f : y.z + 1.f; v.w *= y.w > 0.f ? 1.f : y.w + 1.f;
+          if (row < g.M) { cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w; }
+        }
+        if (row < g.M) {
+          float* o = g.C + (size_t)row * g.ldc + col;
+          if (cv) *reinterpret_cast<float4*>(o) = v;
+          else { if (col < g.N) o[0] = v.x; if (col + 1 < g.N) o[1] = v.y; if (col + 2 < g.N) o[2] = v.z; if (col + 3 < g.N) o[3] = v.w; }
+        }
+      }
+    }
+    if (EPI == EPI_DELU_COLSUM) {
+#pragma unroll
+      for (int d = LPR; d < 64; d <<= 1) { cs.x += __shfl_xor(cs.x, d); cs.y += __shfl_xor(cs.y, d); cs.z += __shfl_xor(cs.z, d); cs.w += __shfl_xor(cs.w, d); }
+      __syncthreads();
+      float* shs = reinterpret_cast<float*>(lds);                     // [2][BN]
+      if (lane < LPR) *reinterpret_cast<float4*>(shs + wm * BN + wn * CT + lc) = cs;
+      __syncthreads();
+      // one partial row per 64 data rows whatever the tile height (the caller's row count, go2nn_linear_backward_input_group_rows, does not depend on the kernel)
+      if (TM == 1) { if (tid < BN && col0 + tid < g.N) g.part[(size_t)bm * g.N + col0 + tid] = shs[tid] + shs[BN + tid]; }
+      else { const int h = tid / BN, c = tid % BN; if (col0 + c < g.N && (bm * 2 + h) * 64 < g.M) g.part[(size_t)(bm * 2 + h) * g.N + col0 + c] = shs[h * BN + c]; }
+    }
+  }
+#ifdef GM3_STAMPS
+  G3_T(4);
+  if (ga.stamps && (tid & 63) == 0) { long long* o = ga.stamps + ((size_t)blockIdx.x * 4 + wave) * 8; o[0] = st_[0]; o[1] = st_[1]; o[2] = st_[2]; o[3] = st_[3]; o[4] = st_[4]; o[5] = wall_clock64(); o[6] = wall0_; }
+#endif
+}
+#endif  // !GO2_EMU

@@ -22,6 +22,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <algorithm>
 
 #include "../../include/go2nn.h"
 
@@ -238,6 +239,7 @@ __global__ void __launch_bounds__(NN_THREADS) go2nn_mlp_kernel(const NNArgs a) {
 #include "go2nn_train.h"
 #include "go2nn_gemm.h"
 #include "go2nn_gemm3.h"
+#include "go2nn_bx3.h"
 
 #ifdef GO2_EMU
 // host restatement: the SAME packed buffer, read in the operand order the kernel uses
@@ -593,6 +595,21 @@ static int gemm3_launch(int tm, int tn, int bk, const Gemm3Args& a, hipStream_t 
   HIPCHK(hipGetLastError());
   return 0;
 }
+template <int EPI>
+static int bx3_launch(int tm, const Bx3Args& a, hipStream_t st) {
+  const dim3 grid(a.ntiles), blk(256);
+  if (tm == 2) hipLaunchKernelGGL((go2nn_bx3_kernel<2, EPI>), grid, blk, 0, st, a);
+  else         hipLaunchKernelGGL((go2nn_bx3_kernel<1, EPI>), grid, blk, 0, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// rows per workgroup tile of the split-operand kernels: 128 while that still gives every CU its two workgroups, else 64
+static inline int bx3_tm(int M, int N0, int N1) {
+  static const char* const env = getenv("GO2NN_BX3_TM");        // tools only
+  if (env && (env[0] == '1' || env[0] == '2')) return env[0] - '0';
+  const int tiles = cdiv(M, 128) * (cdiv(N0, 128) + (N1 ? cdiv(N1, 128) : 0));
+  return tiles >= 512 ? 2 : 1;
+}
 template <bool VEC>
 static int wgrad3_launch2(int tn, const WgArgs& a, hipStream_t st) {
   const dim3 grid(a.tiles * a.nsplit), blk(256);
@@ -617,6 +634,27 @@ static int wgrad3_group_shape(const Go2nnBwdWJob* jobs, int njobs, int* tn, int*
 
 extern "C" {
 
+int64_t go2nn_split_weights_bytes(int32_t N, int32_t K) {
+  if (N <= 0 || K <= 0 || N > 4096 || K > 4096) FAIL(GO2NN_EINVAL, "split image: bad shape");
+  return bx3_image_bytes(N, K) + bx3_image_bytes(K, N);
+}
+
+int go2nn_split_weights(const Go2nnSplitJob* jobs, int32_t njobs, void* stream) {
+  if (!jobs || njobs < 1 || njobs > 8) FAIL(GO2NN_EINVAL, "split weights: 1..8 jobs");
+  for (int j = 0; j < njobs; ++j) if (!jobs[j].w || !jobs[j].image || jobs[j].N <= 0 || jobs[j].K <= 0 || jobs[j].N > 4096 || jobs[j].K > 4096 || ((uintptr_t)jobs[j].image & 15)) FAIL(GO2NN_EINVAL, "split weights: bad job %d", j);
+#ifdef GO2_EMU
+  return 0;          // (the host build's products read the fp32 weights)
+#else
+  Bx3SplitArgs a; memset(&a, 0, sizeof(a)); a.njobs = njobs;
+  long long most = 0;
+  for (int j = 0; j < njobs; ++j) { a.j[j].w = jobs[j].w; a.j[j].img = (unsigned char*)jobs[j].image; a.j[j].N = jobs[j].N; a.j[j].K = jobs[j].K;
+    most = std::max(most, std::max(bx3_image_bytes(jobs[j].N, jobs[j].K), bx3_image_bytes(jobs[j].K, jobs[j].N)) / 48); }          // threads: one per 3 x 16 bytes
+  hipLaunchKernelGGL(go2nn_bx3_split_kernel, dim3((unsigned)cdiv((int)most, 256), 2 * njobs), dim3(256), 0, (hipStream_t)stream, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+#endif
+}
+
 int go2nn_linear_elu_forward_group(const Go2nnFwdJob* jobs, int32_t njobs, void* stream) {
   if (!jobs || njobs < 1 || njobs > GO2NN_MAX_GROUP) FAIL(GO2NN_EINVAL, "forward group: 1..%d jobs", GO2NN_MAX_GROUP);
   for (int j = 0; j < njobs; ++j) if (!jobs[j].x || !jobs[j].w || !jobs[j].b || !jobs[j].y || !lin_check(jobs[j].M, jobs[j].N, jobs[j].K)) FAIL(GO2NN_EINVAL, "forward group: bad job %d", j);
@@ -624,6 +662,19 @@ int go2nn_linear_elu_forward_group(const Go2nnFwdJob* jobs, int32_t njobs, void*
   for (int j = 0; j < njobs; ++j) { const int rc = go2nn_linear_elu_forward(jobs[j].x, jobs[j].w, jobs[j].b, jobs[j].y, jobs[j].M, jobs[j].K, jobs[j].N, stream); if (rc) return rc; }
   return 0;
 #else
+  if (jobs[0].w_split && jobs[njobs - 1].w_split && jobs[0].K >= 4 && jobs[njobs - 1].K >= 4) {          // split-operand kernel (go2nn_bx3.h)
+    Bx3Args a; memset(&a, 0, sizeof(a));
+    const int tm = bx3_tm(jobs[0].M, jobs[0].N, njobs == 2 ? jobs[1].N : 0);
+    for (int j = 0; j < njobs; ++j) {
+      Bx3Prob& g = a.p[j]; const Go2nnFwdJob& q = jobs[j];
+      g.A = q.x; g.B = (const unsigned char*)q.w_split; g.C = q.y; g.bias = q.b; g.M = q.M; g.N = q.N; g.K = q.K; g.lda = q.K; g.ldc = q.N;
+      g.nbm = cdiv(q.M, 64 * tm); g.nbn = cdiv(q.N, 128); g.nkt = cdiv(q.K, BX3_BK); g.c_vec = (q.N % 4 == 0) && aligned16(q.y);
+      (j ? a.ntiles : a.ntiles0) = g.nbm * g.nbn;
+    }
+    a.ntiles = njobs == 2 ? a.ntiles0 + a.ntiles : a.ntiles0;
+    GM3_SET_STAMPS(a);
+    return bx3_launch<EPI_BIAS_ELU>(tm, a, (hipStream_t)stream);
+  }
   int tm, tn, bk; gemm3_tile(jobs[0].N, &tm, &tn, &bk);
   if (njobs == 2) { int tm1, tn1, bk1; gemm3_tile(jobs[1].N, &tm1, &tn1, &bk1);
     if (tm1 != tm || tn1 != tn || bk1 != bk) { const int rc = go2nn_linear_elu_forward_group(jobs, 1, stream); return rc ? rc : go2nn_linear_elu_forward_group(jobs + 1, 1, stream); } }
@@ -659,6 +710,20 @@ int go2nn_linear_backward_input_group(const Go2nnBwdInJob* jobs, int32_t njobs, 
   for (int j = 0; j < njobs; ++j) { const int rc = go2nn_linear_backward_input(jobs[j].gz, jobs[j].w, jobs[j].y_prev, jobs[j].gz_prev, nullptr, jobs[j].workspace, jobs[j].M, jobs[j].C, jobs[j].Kin, stream); if (rc) return rc; }
   return 0;
 #else
+  if (jobs[0].w_split && jobs[njobs - 1].w_split && jobs[0].C >= 4 && jobs[njobs - 1].C >= 4) {          // split-operand kernel: A = gz [M,C], B = the transposed image (rows k, contraction c)
+    Bx3Args a; memset(&a, 0, sizeof(a));
+    const int tm = bx3_tm(jobs[0].M, jobs[0].Kin, njobs == 2 ? jobs[1].Kin : 0);
+    for (int j = 0; j < njobs; ++j) {
+      Bx3Prob& g = a.p[j]; const Go2nnBwdInJob& q = jobs[j];
+      g.A = q.gz; g.B = (const unsigned char*)q.w_split + bx3_image_bytes(q.C, q.Kin); g.C = q.gz_prev; g.Y = q.y_prev; g.part = q.workspace;
+      g.M = q.M; g.N = q.Kin; g.K = q.C; g.lda = q.C; g.ldc = q.Kin;
+      g.nbm = cdiv(q.M, 64 * tm); g.nbn = cdiv(q.Kin, 128); g.nkt = cdiv(q.C, BX3_BK); g.c_vec = (q.Kin % 4 == 0) && aligned16(q.gz_prev) && aligned16(q.y_prev);
+      (j ? a.ntiles : a.ntiles0) = g.nbm * g.nbn;
+    }
+    a.ntiles = njobs == 2 ? a.ntiles0 + a.ntiles : a.ntiles0;
+    GM3_SET_STAMPS(a);
+    return bx3_launch<EPI_DELU_COLSUM>(tm, a, (hipStream_t)stream);
+  }
   int tm, tn, bk; gemm3_tile(jobs[0].Kin, &tm, &tn, &bk);
   if (njobs == 2) { int tm1, tn1, bk1; gemm3_tile(jobs[1].Kin, &tm1, &tn1, &bk1);
     if (tm1 != tm || tn1 != tn || bk1 != bk) { const int rc = go2nn_linear_backward_input_group(jobs, 1, stream); return rc ? rc : go2nn_linear_backward_input_group(jobs + 1, 1, stream); } }

@@ -300,6 +300,30 @@ _PAIR = os.environ.get("GO2_MLP_PAIR", "1") == "1"       # 0: one node per netwo
 # step — cost 8 % of the whole job: a 2-workgroup-per-CU weight-gradient kernel and a 3-per-CU input-gradient kernel take each other's occupancy.)
 
 
+# The hidden layers' products on the bf16 matrix pipe with fp32 operands (include/go2nn.h ABI 4: every fp32 value split exactly into three bf16 planes, six MFMA terms,
+# fp32 accumulation — as close to float64 as the fp32-MFMA kernels, tests/test_gpu_mlp_tail.py).  0: the fp32-MFMA kernels.
+_SPLIT = os.environ.get("GO2_GEMM_SPLIT", "1") == "1"
+
+
+def _split_images(ws, H, dev, stream):
+    """-> images[j][l]: the split image of hidden layer l's weight of network j (one go2nn_split_weights launch for all of them), or None when switched off.
+    The weights change with every optimizer step, so this runs at the head of every mini-batch's forward pass (a few microseconds: the matrices are small)."""
+    from ..._nn import Go2nnSplitJob
+    if not _SPLIT or H == 0 or 2 * H > 8:
+        return None
+    imgs, jobs = [[None] * H for _ in range(2)], []
+    for j in range(2):
+        for l in range(H):
+            N, K = ws[j][l].shape
+            n = _NN.go2nn_split_weights_bytes(N, K)
+            if n <= 0:
+                raise RuntimeError("go2nn_split_weights_bytes: %s" % _NN.go2nn_last_error().decode())
+            imgs[j][l] = torch.empty(int(n), device=dev, dtype=torch.uint8)
+            jobs.append(Go2nnSplitJob(ws[j][l].data_ptr(), imgs[j][l].data_ptr(), N, K))
+    _check(_NN.go2nn_split_weights((Go2nnSplitJob * len(jobs))(*jobs), len(jobs), stream), "go2nn_split_weights", _NN)
+    return imgs
+
+
 class _FusedPair(torch.autograd.Function):
     """(x_a, x_c) -> (actor(x_a), critic(x_c)) for two MLPs [Linear -> ELU] x H -> Linear(narrow) with the same hidden widths.
     args: x_a, x_c, H, then the actor's w1, b1, ..., w_out, b_out and the critic's."""
@@ -314,14 +338,16 @@ class _FusedPair(torch.autograd.Function):
         p = lambda t: t.data_ptr()
         stream = C.c_void_p(torch.cuda.current_stream(xa.device).cuda_stream) if xa.is_cuda else None
         acts = [[xa], [xc]]
+        imgs = _split_images(ws, H, xa.device, stream)
+        sp = lambda j, l: imgs[j][l].data_ptr() if imgs is not None else None
         for l in range(H):
             ys = [torch.empty(acts[j][-1].shape[0], ws[j][l].shape[0], device=xa.device, dtype=xa.dtype) for j in range(2)]
-            jobs = (Go2nnFwdJob * 2)(*[Go2nnFwdJob(p(acts[j][-1]), p(ws[j][l]), p(bs[j][l]), p(ys[j]), acts[j][-1].shape[0], ws[j][l].shape[1], ws[j][l].shape[0]) for j in range(2)])
+            jobs = (Go2nnFwdJob * 2)(*[Go2nnFwdJob(p(acts[j][-1]), p(ws[j][l]), p(bs[j][l]), p(ys[j]), acts[j][-1].shape[0], ws[j][l].shape[1], ws[j][l].shape[0], 0, sp(j, l)) for j in range(2)])
             _check(_NN.go2nn_linear_elu_forward_group(jobs, 2, stream), "go2nn_linear_elu_forward_group", _NN)
             for j in range(2):
                 acts[j].append(ys[j])
         ctx.save_for_backward(*acts[0], *acts[1], *ws[0], *ws[1])
-        ctx.H = H
+        ctx.H, ctx.imgs = H, imgs
         return torch.addmm(bs[0][H], acts[0][-1], ws[0][H].t()), torch.addmm(bs[1][H], acts[1][-1], ws[1][H].t())
 
     @staticmethod
@@ -370,7 +396,7 @@ class _FusedPair(torch.autograd.Function):
                 for j in range(2):
                     r = _NN.go2nn_linear_backward_input_group_rows(B, shp[j][0], shp[j][1])
                     wk, gbp = new(r * shp[j][1]), new(shp[j][1])
-                    ij[j] = Go2nnBwdInJob(p(gz[j]), p(ws[j][l]), p(acts[j][l]), p(gzp[j]), p(wk), B, shp[j][0], shp[j][1])
+                    ij[j] = Go2nnBwdInJob(p(gz[j]), p(ws[j][l]), p(acts[j][l]), p(gzp[j]), p(wk), B, shp[j][0], shp[j][1], 0, ctx.imgs[j][l].data_ptr() if ctx.imgs is not None else None)
                     sums.append((wk, gbp, r, shp[j][1]))
                     gb[j] = gbp
                 _check(_NN.go2nn_linear_backward_input_group(ij, 2, stream), "go2nn_linear_backward_input_group", _NN)
@@ -443,9 +469,11 @@ def ppo_pair_grads(ac, xa, xc, actions, old_values, adv, returns, old_logp, old_
     with torch.no_grad():
         B = xa.shape[0]
         acts = [[cont(xa)], [cont(xc)]]
+        imgs = _split_images(ws, H, dev, stream)
+        sp = lambda j, l: imgs[j][l].data_ptr() if imgs is not None else None
         for l in range(H):
             ys = [new(B, ws[j][l].shape[0]) for j in range(2)]
-            jobs = (Go2nnFwdJob * 2)(*[Go2nnFwdJob(p(acts[j][-1]), p(ws[j][l]), p(bs[j][l]), p(ys[j]), B, ws[j][l].shape[1], ws[j][l].shape[0]) for j in range(2)])
+            jobs = (Go2nnFwdJob * 2)(*[Go2nnFwdJob(p(acts[j][-1]), p(ws[j][l]), p(bs[j][l]), p(ys[j]), B, ws[j][l].shape[1], ws[j][l].shape[0], 0, sp(j, l)) for j in range(2)])
             _check(_NN.go2nn_linear_elu_forward_group(jobs, 2, stream), "go2nn_linear_elu_forward_group", _NN)
             for j in range(2):
                 acts[j].append(ys[j])
@@ -484,7 +512,7 @@ def ppo_pair_grads(ac, xa, xc, actions, old_values, adv, returns, old_logp, old_
                 for j in range(2):
                     ri = _NN.go2nn_linear_backward_input_group_rows(B, shp[j][0], shp[j][1])
                     wk, gbp = new(ri * shp[j][1]), new(shp[j][1])
-                    ij[j] = Go2nnBwdInJob(p(gz[j]), p(ws[j][l]), p(acts[j][l]), p(gzp[j]), p(wk), B, shp[j][0], shp[j][1])
+                    ij[j] = Go2nnBwdInJob(p(gz[j]), p(ws[j][l]), p(acts[j][l]), p(gzp[j]), p(wk), B, shp[j][0], shp[j][1], 0, sp(j, l))
                     sums.append((wk, gbp, ri, shp[j][1]))
                     gb[j] = gbp
                 _check(_NN.go2nn_linear_backward_input_group(ij, 2, stream), "go2nn_linear_backward_input_group", _NN)

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define GO2NN_ABI_VERSION 3      /* 2: + the learner-side kernels (go2nn_head_backward, go2nn_linear_*); 3: + the grouped (actor + critic) layer calls */
+#define GO2NN_ABI_VERSION 4      /* 2: + the learner-side kernels (go2nn_head_backward, go2nn_linear_*); 3: + the grouped (actor + critic) layer calls; 4: + split-operand (3 x bf16) products */
 #define GO2NN_MAX_LAYERS 6
 #define GO2NN_MAX_WIDTH 512      /* widest layer input / output (LDS holds two 32-row activation tiles of this width) */
 #define GO2NN_EINVAL (-22)
@@ -101,14 +101,27 @@ int go2nn_linear_backward_weight(const float* gz, const float* x, float* dw, flo
  *                  contiguous along the output index), the four waves of a workgroup split the rows of one output tile
  * workspace floats per job: rows * Kin resp. rows * C * Kin. */
 #define GO2NN_MAX_GROUP 2
-typedef struct Go2nnFwdJob { const float *x, *w, *b; float* y; int32_t M, K, N; } Go2nnFwdJob;
-typedef struct Go2nnBwdInJob { const float *gz, *w, *y_prev; float *gz_prev, *workspace; int32_t M, C, Kin; } Go2nnBwdInJob;
-typedef struct Go2nnBwdWJob { const float *gz, *x; float* workspace; int32_t M, C, Kin; } Go2nnBwdWJob;
+typedef struct Go2nnFwdJob { const float *x, *w, *b; float* y; int32_t M, K, N; int32_t pad_; const void* w_split; } Go2nnFwdJob;
+typedef struct Go2nnBwdInJob { const float *gz, *w, *y_prev; float *gz_prev, *workspace; int32_t M, C, Kin; int32_t pad_; const void* w_split; } Go2nnBwdInJob;
+typedef struct Go2nnBwdWJob { const float *gz, *x; float* workspace; int32_t M, C, Kin; int32_t split; } Go2nnBwdWJob;
 int go2nn_linear_elu_forward_group(const Go2nnFwdJob* jobs, int32_t njobs, void* stream);
 int32_t go2nn_linear_backward_input_group_rows(int32_t M, int32_t C, int32_t Kin);
 int go2nn_linear_backward_input_group(const Go2nnBwdInJob* jobs, int32_t njobs, void* stream);
 int32_t go2nn_linear_backward_weight_group_rows(const Go2nnBwdWJob* jobs, int32_t njobs);
 int go2nn_linear_backward_weight_group(const Go2nnBwdWJob* jobs, int32_t njobs, void* stream);
+
+/* ---- ABI 4: the same three products on the bf16 matrix pipe WITHOUT giving up fp32 operands.  Every fp32 value is split exactly into three bf16 planes
+ * (8 + 8 + 8 significand bits) and a product is six bf16 MFMA terms accumulated in fp32 — the three terms left out are below 2^-23 of the product, i.e. below
+ * the rounding of an fp32 multiply; against float64 the results are as close as the fp32-MFMA kernels' (tools/gemm3_bench.cpp, tests/test_gpu_mlp_tail.py hold both
+ * to the same tolerances).  v_mfma_f32_32x32x16_bf16 moves 16 k per 32 cycles, v_mfma_f32_32x32x2_f32 2 k per 64: six terms cost 3/8 of the fp32 form.
+ *   go2nn_split_weights   a layer's weight [N,K] -> its split image for both orientations (forward: rows n; input gradient: rows k), `go2nn_split_weights_bytes`
+ *                         bytes in a caller-owned buffer; run once after every optimizer step (one launch for up to 8 layers)
+ *   Go2nnFwdJob.w_split / Go2nnBwdInJob.w_split   that image: non-NULL selects the split-operand kernel for the group (every job of a group alike)
+ *   Go2nnBwdWJob.split    1 selects it for the weight gradient (both operands are activations: split in registers, no image)
+ * NULL / 0 keep the fp32-MFMA kernels (bit-for-bit the ABI 3 results). */
+typedef struct Go2nnSplitJob { const float* w; void* image; int32_t N, K; } Go2nnSplitJob;
+int64_t go2nn_split_weights_bytes(int32_t N, int32_t K);
+int go2nn_split_weights(const Go2nnSplitJob* jobs, int32_t njobs, void* stream);
 
 
 /* The narrow heads of BOTH networks forward, the PPO loss head (rsl_rl/rsl_rl/algorithms/ppo.py:131-170: Gaussian log-prob, ratio, clipped surrogate, clipped

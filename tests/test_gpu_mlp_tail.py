@@ -71,6 +71,21 @@ def test_linear_group_on_gpu(M, s0, s1):
         assert torch.equal(u, v)
 
 
+@pytest.mark.parametrize("M,s0,s1", [(70, (45, 96), (263, 96)), (777, (37, 70), (64, 70)), (1000, (130, 33), (8, 33)), (3000, (45, 512), (263, 512)),
+                                     (24576, (45, 512), (48, 512)), (24576, (512, 256), (512, 256)), (24576, (256, 128), (256, 128)), (6144, (512, 256), (512, 256)),
+                                     (4099, (260, 132), (64, 132)), (300, (100, 300), (100, 300)), (513, (7, 40), (16, 40))])
+def test_linear_group_split_operands_on_gpu(M, s0, s1):
+    """the ABI 4 kernels (go2nn_bx3.h: fp32 operands as three bf16 planes, six bf16-MFMA terms, fp32 accumulation) against float64 torch within the SAME
+    bounds the fp32-MFMA kernels are held to: whole and ragged contractions (45 / 37 / 7: the peeled last k-tile), both tile heights, ragged M and N;
+    bit-reproducible from launch to launch"""
+    lib = _nn.load_nn()
+    a = check_linear_group(lib, M, s0, s1, device="cuda:0", split=True)
+    b = check_linear_group(lib, M, s0, s1, device="cuda:0", split=True)
+    torch.cuda.synchronize()
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
 @pytest.mark.parametrize("B", [24576, 1000])
 def test_pair_node_on_gpu(B):
     pair_vs_autograd(_nn.load_nn(), load_hip(), "cuda:0", B=B, dims_a=(45, 512, 256, 128, 12), dims_c=(263, 512, 256, 128, 1), atol=2e-6)

@@ -213,9 +213,10 @@ def test_whole_mlp_node_edge_cases():
 GROUP_SHAPES = [(70, (45, 96), (263, 96)), (130, (37, 70), (64, 70)), (65, (130, 33), (8, 33)), (96, (64, 40), (64, 72))]      # M, (K, N) of job 0, of job 1
 
 
-def check_linear_group(lib, M, s0, s1, device="cpu"):
-    """forward, input gradient and weight gradient of two layers as ONE grouped call each, against float64 torch (same bounds as check_linear)"""
-    from go2_rl_gym_amd._nn import Go2nnBwdInJob, Go2nnBwdWJob, Go2nnFwdJob, Go2nnSumJob
+def check_linear_group(lib, M, s0, s1, device="cpu", split=False):
+    """forward, input gradient and weight gradient of two layers as ONE grouped call each, against float64 torch (same bounds as check_linear).
+    split: the ABI 4 split-operand kernels (3 x bf16 planes per fp32 value, six MFMA terms) — held to the SAME bounds as the fp32-MFMA kernels."""
+    from go2_rl_gym_amd._nn import Go2nnBwdInJob, Go2nnBwdWJob, Go2nnFwdJob, Go2nnSplitJob, Go2nnSumJob
     g = torch.Generator().manual_seed(M * 7 + s0[0] * 3 + s1[0])
     nan = lambda *shape: torch.full(shape, float("nan"), device=device)
     jobs = []
@@ -225,7 +226,17 @@ def check_linear_group(lib, M, s0, s1, device="cpu"):
         jobs.append(dict(K=K, N=N, x=x, w=w, b=b, gz=gz, yp=yp, y=nan(M, N), gzp=nan(M, K), gbp=nan(K), dw=nan(N, K)))
     st = _stream(jobs[0]["x"])
     p = lambda t: t.data_ptr()
-    fj = (Go2nnFwdJob * 2)(*[Go2nnFwdJob(p(j["x"]), p(j["w"]), p(j["b"]), p(j["y"]), M, j["K"], j["N"]) for j in jobs])
+    for j in jobs:
+        j["img"] = None
+        if split:
+            n = lib.go2nn_split_weights_bytes(j["N"], j["K"])
+            assert n > 0, lib.go2nn_last_error().decode()
+            j["img_t"] = torch.full((int(n),), 0xff, dtype=torch.uint8, device=device)
+            j["img"] = j["img_t"].data_ptr()
+    if split:
+        sj = (Go2nnSplitJob * 2)(*[Go2nnSplitJob(p(j["w"]), j["img"], j["N"], j["K"]) for j in jobs])
+        assert lib.go2nn_split_weights(sj, 2, st) == 0, lib.go2nn_last_error().decode()
+    fj = (Go2nnFwdJob * 2)(*[Go2nnFwdJob(p(j["x"]), p(j["w"]), p(j["b"]), p(j["y"]), M, j["K"], j["N"], 0, j["img"]) for j in jobs])
     assert lib.go2nn_linear_elu_forward_group(fj, 2, st) == 0, lib.go2nn_last_error().decode()
     sums, keep = [], []
     ij = (Go2nnBwdInJob * 2)()
@@ -233,10 +244,10 @@ def check_linear_group(lib, M, s0, s1, device="cpu"):
         r = lib.go2nn_linear_backward_input_group_rows(M, j["N"], j["K"])
         assert r > 0
         ws = nan(r * j["K"]); keep.append(ws)
-        ij[k] = Go2nnBwdInJob(p(j["gz"]), p(j["w"]), p(j["yp"]), p(j["gzp"]), p(ws), M, j["N"], j["K"])
+        ij[k] = Go2nnBwdInJob(p(j["gz"]), p(j["w"]), p(j["yp"]), p(j["gzp"]), p(ws), M, j["N"], j["K"], 0, j["img"])
         sums.append((ws, j["gbp"], r, j["K"]))
     assert lib.go2nn_linear_backward_input_group(ij, 2, st) == 0, lib.go2nn_last_error().decode()
-    wj = (Go2nnBwdWJob * 2)(*[Go2nnBwdWJob(p(j["gz"]), p(j["yp"]), None, M, j["N"], j["K"]) for j in jobs])
+    wj = (Go2nnBwdWJob * 2)(*[Go2nnBwdWJob(p(j["gz"]), p(j["yp"]), None, M, j["N"], j["K"], 1 if split else 0) for j in jobs])
     rows = lib.go2nn_linear_backward_weight_group_rows(wj, 2)
     assert rows > 0, lib.go2nn_last_error().decode()
     for k, j in enumerate(jobs):
@@ -262,6 +273,7 @@ def check_linear_group(lib, M, s0, s1, device="cpu"):
 @pytest.mark.parametrize("M,s0,s1", GROUP_SHAPES)
 def test_linear_group_matches_torch(M, s0, s1):
     check_linear_group(load_nn_emu(), M, s0, s1)
+    check_linear_group(load_nn_emu(), M, s0, s1, split=True)          # (the host build reads the fp32 weights: the call path and the struct layout)
 
 
 def test_group_calls_refuse_bad_arguments():

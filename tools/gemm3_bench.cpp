@@ -24,7 +24,9 @@ struct Lib {
   decltype(&go2nn_linear_backward_workspace) bws; decltype(&go2nn_linear_backward_input_rows) bin_rows; decltype(&go2nn_sum_rows) sum_rows;
   decltype(&go2nn_linear_elu_forward_group) fwd_g; decltype(&go2nn_linear_backward_input_group) bin_g; decltype(&go2nn_linear_backward_input_group_rows) bin_g_rows;
   decltype(&go2nn_linear_backward_weight_group) bw_g; decltype(&go2nn_linear_backward_weight_group_rows) bw_g_rows; decltype(&go2nn_last_error) err;
+  decltype(&go2nn_split_weights) split; decltype(&go2nn_split_weights_bytes) split_bytes;
 };
+static bool g_bx3 = false;          // BX3=1: the split-operand (3 x bf16) kernels instead of the fp32-MFMA ones
 template <class T> static void sym(void* h, const char* n, T& f) { f = (T)dlsym(h, n); if (!f) { fprintf(stderr, "missing symbol %s\n", n); exit(2); } }
 static Lib load(const char* path) {
   Lib l; l.h = dlopen(path, RTLD_NOW); if (!l.h) { fprintf(stderr, "dlopen %s: %s\n", path, dlerror()); exit(2); }
@@ -32,6 +34,8 @@ static Lib load(const char* path) {
   sym(l.h, "go2nn_linear_backward_workspace", l.bws); sym(l.h, "go2nn_linear_backward_input_rows", l.bin_rows); sym(l.h, "go2nn_sum_rows", l.sum_rows);
   sym(l.h, "go2nn_linear_elu_forward_group", l.fwd_g); sym(l.h, "go2nn_linear_backward_input_group", l.bin_g); sym(l.h, "go2nn_linear_backward_input_group_rows", l.bin_g_rows);
   sym(l.h, "go2nn_linear_backward_weight_group", l.bw_g); sym(l.h, "go2nn_linear_backward_weight_group_rows", l.bw_g_rows); sym(l.h, "go2nn_last_error", l.err);
+  sym(l.h, "go2nn_split_weights", l.split); sym(l.h, "go2nn_split_weights_bytes", l.split_bytes);
+  g_bx3 = getenv("BX3") && atoi(getenv("BX3"));
   return l;
 }
 
@@ -54,7 +58,14 @@ static void acc_err(Err& e, double got, double want, double scale, double tol) {
 }
 
 // one network's layer problem at M rows
-struct Layer { int K, N; Buf x, w, b, y, gz, y_prev, gzp, ws_in, ws_w, dw, gbp; };
+struct Layer { int K, N; Buf x, w, b, y, gz, y_prev, gzp, ws_in, ws_w, dw, gbp; void* img = nullptr;
+  const void* split(const Lib& L) {          // the weight's split image (BX3=1), else NULL = the fp32-MFMA kernels
+    if (!g_bx3) return nullptr;
+    if (!img) CK(hipMalloc(&img, (size_t)L.split_bytes(N, K)));
+    Go2nnSplitJob sj = {w.d, img, N, K}; if (L.split(&sj, 1, nullptr)) { fprintf(stderr, "split failed: %s\n", L.err()); exit(2); }
+    return img;
+  }
+};
 
 static int check_all(const Lib& L, int M, const std::vector<std::pair<int, int>>& shapes_a, const std::vector<std::pair<int, int>>& shapes_b, int nsample) {
   int fails = 0;
@@ -70,7 +81,7 @@ static int check_all(const Lib& L, int M, const std::vector<std::pair<int, int>>
     }
     // ---- forward, grouped
     Go2nnFwdJob fj[2];
-    for (int j = 0; j < 2; ++j) fj[j] = {ly[j].x.d, ly[j].w.d, ly[j].b.d, ly[j].y.d, M, ly[j].K, ly[j].N};
+    for (int j = 0; j < 2; ++j) fj[j] = {ly[j].x.d, ly[j].w.d, ly[j].b.d, ly[j].y.d, M, ly[j].K, ly[j].N, 0, ly[j].split(L)};
     if (L.fwd_g(fj, 2, nullptr)) { printf("fwd group failed: %s\n", L.err()); return 1; }
     CK(hipDeviceSynchronize());
     for (int j = 0; j < 2; ++j) {
@@ -88,7 +99,7 @@ static int check_all(const Lib& L, int M, const std::vector<std::pair<int, int>>
     Go2nnBwdInJob ij[2]; int rows_in[2];
     for (int j = 0; j < 2; ++j) {
       Layer& l = ly[j]; rows_in[j] = L.bin_g_rows(M, l.N, l.K); l.ws_in.alloc((size_t)rows_in[j] * l.K, false);
-      ij[j] = {l.gz.d, l.w.d, l.x.d, l.gzp.d, l.ws_in.d, M, l.N, l.K};
+      ij[j] = {l.gz.d, l.w.d, l.x.d, l.gzp.d, l.ws_in.d, M, l.N, l.K, 0, l.split(L)};
     }
     if (L.bin_g(ij, 2, nullptr)) { printf("input-grad group failed: %s\n", L.err()); return 1; }
     for (int j = 0; j < 2; ++j) { Go2nnSumJob sj = {ly[j].ws_in.d, ly[j].gbp.d, rows_in[j], ly[j].K}; if (L.sum_rows(&sj, 1, nullptr)) { printf("sum_rows failed\n"); return 1; } }
@@ -108,7 +119,7 @@ static int check_all(const Lib& L, int M, const std::vector<std::pair<int, int>>
     }
     // ---- weight gradient, grouped: dw [N,K] = gz^T x
     Go2nnBwdWJob wj[2];
-    for (int j = 0; j < 2; ++j) wj[j] = {ly[j].gz.d, ly[j].x.d, nullptr, M, ly[j].N, ly[j].K};
+    for (int j = 0; j < 2; ++j) wj[j] = {ly[j].gz.d, ly[j].x.d, nullptr, M, ly[j].N, ly[j].K, g_bx3 ? 1 : 0};
     const int wrows = L.bw_g_rows(wj, 2);
     if (wrows <= 0) { printf("weight-grad rows failed: %s\n", L.err()); return 1; }
     for (int j = 0; j < 2; ++j) { ly[j].ws_w.alloc((size_t)wrows * ly[j].N * ly[j].K, false); wj[j].workspace = ly[j].ws_w.d; }
@@ -176,7 +187,8 @@ int main(int argc, char** argv) {
       Layer& l = ly[j]; l.K = Ks[j]; l.N = N;
       l.x.alloc((size_t)M * l.K); l.w.alloc((size_t)l.N * l.K, true, 1.f / sqrtf((float)l.K)); l.b.alloc(l.N); l.y.alloc((size_t)M * l.N, false);
       l.gz.alloc((size_t)M * l.N, true, 0.01f); l.gzp.alloc((size_t)M * l.K, false); l.ws_in.alloc((size_t)L.bin_g_rows(M, l.N, l.K) * l.K, false);
-      fj[j] = {l.x.d, l.w.d, l.b.d, l.y.d, M, l.K, l.N}; ij[j] = {l.gz.d, l.w.d, l.x.d, l.gzp.d, l.ws_in.d, M, l.N, l.K}; wj[j] = {l.gz.d, l.x.d, nullptr, M, l.N, l.K};
+      const void* sp = l.split(L);
+      fj[j] = {l.x.d, l.w.d, l.b.d, l.y.d, M, l.K, l.N, 0, sp}; ij[j] = {l.gz.d, l.w.d, l.x.d, l.gzp.d, l.ws_in.d, M, l.N, l.K, 0, sp}; wj[j] = {l.gz.d, l.x.d, nullptr, M, l.N, l.K, g_bx3 ? 1 : 0};
     }
     const int wrows = L.bw_g_rows(wj, 2);
     for (int j = 0; j < 2; ++j) { ly[j].ws_w.alloc((size_t)wrows * ly[j].N * ly[j].K, false); wj[j].workspace = ly[j].ws_w.d; }
@@ -198,6 +210,8 @@ int main(int argc, char** argv) {
       for (size_t w = 0; w < nwg * 4; ++w) { const long long* o = &h[w * 8]; if (!o[4]) continue; ++n; s_pro += o[1] - o[0]; s_loop += o[2] - o[1]; s_bar += o[3] - o[2]; s_epi += o[4] - o[3]; s_tot += o[4] - o[0];
         starts.push_back(o[0] - t0); ends.push_back(o[4] - t0); }
       std::sort(starts.begin(), starts.end()); std::sort(ends.begin(), ends.end());
+      { double fsum = 0; size_t fn = 0; for (size_t w = 0; w < nwg * 4; ++w) { const long long* o = &h[w * 8]; if (!o[4] || !o[6] || o[5] <= o[6]) continue; fsum += (double)(o[4] - o[0]) / ((o[5] - o[6]) / 100.0); ++fn; }
+        if (fn) printf("   shader clock over the waves' lifetimes: %.0f MHz (mean of %zu waves)\n", fsum / fn, fn); }
       printf("stamps %c layer %d, %d job(s): %zu waves; per wave mean ticks: prologue %.0f, k-loop %.0f, barrier %.0f, epilogue %.0f, total %.0f\n", kind, layer, njobs, n, s_pro / n, s_loop / n, s_bar / n, s_epi / n, s_tot / n);
       printf("   wave starts p0/p50/p90/p100 = %lld / %lld / %lld / %lld ticks after the first; ends p0/p10/p50/p100 = %lld / %lld / %lld / %lld;  wall span of the end stamps %.2f us (100 MHz clock)\n",
              starts[0], starts[n / 2], starts[n * 9 / 10], starts[n - 1], ends[0], ends[n / 10], ends[n / 2], ends[n - 1], (wall1 - wall0) / 100.0);
@@ -224,7 +238,7 @@ int main(int argc, char** argv) {
         l.ws_in.alloc((size_t)std::max<int64_t>(L.bws(M, l.N, l.K), (int64_t)L.bin_g_rows(M, l.N, l.K) * l.K), false);
       }
       Go2nnFwdJob fj[2]; Go2nnBwdInJob ij[2]; Go2nnBwdWJob wj[2];
-      for (int j = 0; j < 2; ++j) { fj[j] = {ly[j].x.d, ly[j].w.d, ly[j].b.d, ly[j].y.d, M, ly[j].K, ly[j].N}; ij[j] = {ly[j].gz.d, ly[j].w.d, ly[j].x.d, ly[j].gzp.d, ly[j].ws_in.d, M, ly[j].N, ly[j].K}; wj[j] = {ly[j].gz.d, ly[j].x.d, nullptr, M, ly[j].N, ly[j].K}; }
+      for (int j = 0; j < 2; ++j) { const void* sp = ly[j].split(L); fj[j] = {ly[j].x.d, ly[j].w.d, ly[j].b.d, ly[j].y.d, M, ly[j].K, ly[j].N, 0, sp}; ij[j] = {ly[j].gz.d, ly[j].w.d, ly[j].x.d, ly[j].gzp.d, ly[j].ws_in.d, M, ly[j].N, ly[j].K, 0, sp}; wj[j] = {ly[j].gz.d, ly[j].x.d, nullptr, M, ly[j].N, ly[j].K, g_bx3 ? 1 : 0}; }
       const int wrows = L.bw_g_rows(wj, 2);
       for (int j = 0; j < 2; ++j) { ly[j].ws_w.alloc((size_t)std::max<int64_t>((int64_t)wrows * ly[j].N * ly[j].K, L.bws(M, ly[j].N, ly[j].K)), false); wj[j].workspace = ly[j].ws_w.d; }
       const double fl = 2.0 * M * sh.N * (sh.Ka + sh.Kc);
