@@ -20,7 +20,7 @@
 //     the SAME k of two DIFFERENT 32-column tiles (tile b = columns n0 + 2 i + b) — no transpose, half the LDS instructions of four ds_read_b32;
 //     the epilogue's LDS turn undoes the column interleave.
 //
-//   go2nn_wgrad_kernel<TN, VEC>    weight gradient dW [C, Kin] = G^T X, contraction over the M rows of the mini-batch
+//   go2nn_wgrad_kernel<TA, TN, VECA, VECB>    weight gradient dW [C, Kin] = G^T X, contraction over the M rows of the mini-batch
 //     Both operands have the contraction index as their ROW: a lane's MFMA operand for k-step (rows m, m + 1) is G[m + g][c0 + 2 i .. + 1] /
 //     X[m + g][k0 + 4 i .. + 3] — 8 / 16 contiguous bytes, a half-wave reads 256 / 512 contiguous bytes.  So the operands go from global memory
 //     STRAIGHT into MFMA registers (a register ring a few k-steps deep), no LDS, no barrier in the loop; the values of one load feed 2 resp. 4
@@ -364,9 +364,14 @@ __global__ void __launch_bounds__(256, GM3_WAVES(TM, TN, BK)) go2nn_gemm3_kernel
 }
 
 // ---- weight gradient: operands straight from global memory into MFMA registers ------------------------------------------------------------
-template <int TN, bool VEC, int D>
+// TA / TN: 32-column tiles of G / of X one load of a lane feeds (tile b = columns c0 + T i + b): 2 x 4 for the square layers, 4 x 2 for the tall-skinny
+// input layer (dW [512, 45]: four times the MFMAs per loaded byte of G, whose 50 MB per network are what that layer's gradient streams).
+// VECA / VECB: the operand's rows are aligned to the lane's piece (one load instruction per piece); else 4-byte loads (a 45-float row pitch).
+template <int TA, int TN, bool VECA, bool VECB, int D>
 __global__ void __launch_bounds__(256, 2) go2nn_wgrad_kernel(const WgArgs wa) {
-  static_assert(TN == 2 || TN == 4, "8- or 16-byte X operand");
+  static_assert((TA == 2 || TA == 4) && (TN == 2 || TN == 4) && TA * TN <= 8, "8- or 16-byte operand pieces, at most 8 accumulator tiles");
+  typedef float AV __attribute__((ext_vector_type(TA)));
+  typedef float AVu __attribute__((ext_vector_type(TA), aligned(4)));
   typedef float BV __attribute__((ext_vector_type(TN)));
   typedef float BVu __attribute__((ext_vector_type(TN), aligned(4)));
   __shared__ __attribute__((aligned(16))) BV red[4][16][64];          // one row tile (a) of the four waves' accumulators at a time
@@ -379,48 +384,56 @@ __global__ void __launch_bounds__(256, 2) go2nn_wgrad_kernel(const WgArgs wa) {
   t -= pi ? wa.tiles0 : 0;
   const WgProb& g = wa.p[pi];
   const int tc = t / g.ntk, tk = t - tc * g.ntk;
-  const int c0 = tc * 64, k0 = tk * 32 * TN;
+  const int c0 = tc * 32 * TA, k0 = tk * 32 * TN;
   const int rpw = wa.rows_per_slice >> 2;                      // rows per wave (a multiple of 2)
   const int m0 = slice * wa.rows_per_slice + wave * rpw, mend = min(wa.M, m0 + rpw);
   const int nsteps = (rpw / 2 + D - 1) / D * D;                // k-steps (2 rows each), padded to the ring depth with masked steps
 
   // the lane's column pieces, clamped into the row (out-of-range pieces are zeroed at use)
-  const int ca = c0 + 2 * i, cb = k0 + TN * i;
-  const bool a_ok0 = ca < g.C, a_ok1 = ca + 1 < g.C;
-  bool b_ok[TN];
+  const int ca = c0 + TA * i, cb = k0 + TN * i;
+  bool a_ok[TA], b_ok[TN];
+#pragma unroll
+  for (int e = 0; e < TA; ++e) a_ok[e] = ca + e < g.C;
 #pragma unroll
   for (int e = 0; e < TN; ++e) b_ok[e] = cb + e < g.Kin;
-  const int cac = gm_opaque(min(ca, g.C - 2 < 0 ? 0 : g.C - 2)), cbc = gm_opaque(min(cb, g.Kin - TN < 0 ? 0 : g.Kin - TN));
+  const int cac = gm_opaque(min(ca, g.C - TA < 0 ? 0 : g.C - TA)), cbc = gm_opaque(min(cb, g.Kin - TN < 0 ? 0 : g.Kin - TN));
   // (a clamped piece starts further left: its elements are re-aligned by the shifts below; only edge tiles take that path)
-  const bool a_edge = c0 + 64 > g.C, b_edge = k0 + 32 * TN > g.Kin;
+  const bool a_edge = c0 + 32 * TA > g.C, b_edge = k0 + 32 * TN > g.Kin;
   const int a_sh = ca - cac, b_sh = cb - cbc;                  // 0 inside the matrix
 
-  f32x16 acc[2][TN];
+  f32x16 acc[TA][TN];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TA; ++a)
 #pragma unroll
     for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  f32x2 ra[D]; BV rb[D];
+  AV ra[D]; BV rb[D];
   auto issue = [&](int s, int step) __attribute__((always_inline)) {
     const int m = gm_opaque(min(m0 + 2 * step + gk, wa.M - 1));
     const float* pa = g.G + (size_t)m * g.C + cac; const float* pb = g.X + (size_t)m * g.Kin + cbc;
-    if (VEC) { ra[s] = *reinterpret_cast<const f32x2*>(pa); rb[s] = *reinterpret_cast<const BV*>(pb); }
-    else { ra[s] = *reinterpret_cast<const GmF2u*>(pa); rb[s] = *reinterpret_cast<const BVu*>(pb); }
+    if (VECA) ra[s] = *reinterpret_cast<const AV*>(pa); else ra[s] = *reinterpret_cast<const AVu*>(pa);
+    if (VECB) rb[s] = *reinterpret_cast<const BV*>(pb); else rb[s] = *reinterpret_cast<const BVu*>(pb);
   };
 #pragma unroll
   for (int s = 0; s < D; ++s) issue(s, s);
   for (int j = 0; j < nsteps; j += D) {
 #pragma unroll
     for (int s = 0; s < D; ++s) {
-      f32x2 av = ra[s]; BV bv = rb[s];
+      AV av = ra[s]; BV bv = rb[s];
       const bool live = m0 + 2 * (j + s) + gk < mend;
       issue(s, j + s + D);
       if (a_edge) {                // (workgroup-uniform) shifted + masked pieces of an edge tile
-        const float x0 = a_sh == 0 ? av[0] : av[1], x1 = av[1];
-        av[0] = (a_ok0 && a_sh <= 1) ? x0 : 0.f; av[1] = (a_ok1 && a_sh == 0) ? x1 : 0.f;
+        AV w;
+#pragma unroll
+        for (int e = 0; e < TA; ++e) {
+          float v = 0.f;
+#pragma unroll
+          for (int q = 0; q < TA; ++q) v = (q == e + a_sh) ? av[q] : v;
+          w[e] = a_ok[e] ? v : 0.f;
+        }
+        av = w;
       }
       if (b_edge) {
         BV w;
@@ -433,19 +446,20 @@ __global__ void __launch_bounds__(256, 2) go2nn_wgrad_kernel(const WgArgs wa) {
         }
         bv = w;
       }
-      av[0] = live ? av[0] : 0.f; av[1] = live ? av[1] : 0.f;
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int e = 0; e < TA; ++e) av[e] = live ? av[e] : 0.f;
+#pragma unroll
+      for (int a = 0; a < TA; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
     }
   }
   // the four waves' partial tiles, summed in wave order, one row tile at a time; accumulator (a, b, r) of lane (j = lane & 31, g) is
-  // dW[c0 + 2 ((r & 3) + 8 (r >> 2) + 4 g) + a][k0 + TN j + b]: the TN values of one (a, r) are TN consecutive floats of one output row
+  // dW[c0 + TA ((r & 3) + 8 (r >> 2) + 4 g) + a][k0 + TN j + b]: the TN values of one (a, r) are TN consecutive floats of one output row
   float* __restrict__ out = g.part + (size_t)slice * g.C * g.Kin;
   const bool k_vec = (g.Kin % TN == 0) && ((reinterpret_cast<uintptr_t>(g.part) & (4 * TN - 1)) == 0) && (((size_t)g.C * g.Kin) % TN == 0);
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
+  for (int a = 0; a < TA; ++a) {
     if (a) __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -463,7 +477,7 @@ __global__ void __launch_bounds__(256, 2) go2nn_wgrad_kernel(const WgArgs wa) {
       for (int w = 1; w < 4; ++w) { const BV u = red[w][r][lane];
 #pragma unroll
         for (int b = 0; b < TN; ++b) v[b] += u[b]; }
-      const int c = c0 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * gk) + a, k = k0 + TN * i;
+      const int c = c0 + TA * ((r & 3) + 8 * (r >> 2) + 4 * gk) + a, k = k0 + TN * i;
       if (c < g.C) {
         float* o = out + (size_t)c * g.Kin + k;
         if (k_vec && k + TN <= g.Kin) *reinterpret_cast<BV*>(o) = v;

@@ -610,24 +610,31 @@ static inline int bx3_tm(int M, int N0, int N1) {
   const int tiles = cdiv(M, 128) * (cdiv(N0, 128) + (N1 ? cdiv(N1, 128) : 0));
   return tiles >= 512 ? 2 : 1;
 }
-template <bool VEC>
-static int wgrad3_launch2(int tn, const WgArgs& a, hipStream_t st) {
+template <bool VECA, bool VECB>
+static int wgrad3_launch2(int ta, int tn, const WgArgs& a, hipStream_t st) {
   const dim3 grid(a.tiles * a.nsplit), blk(256);
-  if (tn == 4) hipLaunchKernelGGL((go2nn_wgrad_kernel<4, VEC, 6>), grid, blk, 0, st, a);
-  else         hipLaunchKernelGGL((go2nn_wgrad_kernel<2, VEC, 8>), grid, blk, 0, st, a);
+  if (ta == 4)      hipLaunchKernelGGL((go2nn_wgrad_kernel<4, 2, VECA, VECB, 8>), grid, blk, 0, st, a);
+  else if (tn == 4) hipLaunchKernelGGL((go2nn_wgrad_kernel<2, 4, VECA, VECB, 6>), grid, blk, 0, st, a);
+  else              hipLaunchKernelGGL((go2nn_wgrad_kernel<2, 2, VECA, VECB, 8>), grid, blk, 0, st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
 #endif
-static int wgrad3_group_shape(const Go2nnBwdWJob* jobs, int njobs, int* tn, int* tiles_of, int* nsplit, int* rows) {
+// tile of the grouped weight gradient: 64 x 128 (2 x 4 column tiles per lane load) for the square layers; 128 x 64 for a tall-skinny gradient (every job's Kin <= 64 and
+// C >= 128: the input layer's dW [512, 45 | 48] — G's bytes per MFMA halve); 64 x 64 otherwise (ragged widths waste less: 263 -> 320 instead of 384 columns)
+static int wgrad3_group_shape(const Go2nnBwdWJob* jobs, int njobs, int* ta, int* tn, int* tiles_of, int* nsplit, int* rows) {
   if (!jobs || njobs < 1 || njobs > GO2NN_MAX_GROUP) return 0;
-  *tn = 4;
+  *tn = 4; *ta = 2;
+  bool skinny = true;
   for (int j = 0; j < njobs; ++j) {
     if (!lin_check(jobs[j].M, jobs[j].C, jobs[j].Kin) || jobs[j].M != jobs[0].M || jobs[j].C < 2 || jobs[j].Kin < 4) return 0;
-    if (jobs[j].Kin % 128) *tn = 2;            // 64-column tiles waste less on ragged widths (263 -> 320 instead of 384 columns)
+    if (jobs[j].Kin % 128) *tn = 2;
+    if (jobs[j].Kin > 64 || jobs[j].C < 128) skinny = false;
   }
+  static const bool no_skinny = getenv("GO2NN_WG3_SKINNY") && atoi(getenv("GO2NN_WG3_SKINNY")) == 0;          // tools only (A/B)
+  if (skinny && !no_skinny) { *ta = 4; *tn = 2; }
   int tiles = 0;
-  for (int j = 0; j < njobs; ++j) { tiles_of[j] = cdiv(jobs[j].C, 64) * cdiv(jobs[j].Kin, 32 * *tn); tiles += tiles_of[j]; }
+  for (int j = 0; j < njobs; ++j) { tiles_of[j] = cdiv(jobs[j].C, 32 * *ta) * cdiv(jobs[j].Kin, 32 * *tn); tiles += tiles_of[j]; }
   wgrad3_shape(jobs[0].M, tiles, nsplit, rows);
   return tiles;
 }
@@ -748,15 +755,15 @@ int32_t go2nn_linear_backward_weight_group_rows(const Go2nnBwdWJob* jobs, int32_
   if (!jobs || njobs < 1 || njobs > GO2NN_MAX_GROUP) FAIL(GO2NN_EINVAL, "weight-gradient group: 1..%d jobs", GO2NN_MAX_GROUP);
   return 1;
 #else
-  int tn, tiles_of[GO2NN_MAX_GROUP], nsplit, rows;
-  if (!wgrad3_group_shape(jobs, njobs, &tn, tiles_of, &nsplit, &rows)) FAIL(GO2NN_EINVAL, "weight-gradient group: 1..%d jobs with one M, C >= 2, Kin >= 4", GO2NN_MAX_GROUP);
+  int ta, tn, tiles_of[GO2NN_MAX_GROUP], nsplit, rows;
+  if (!wgrad3_group_shape(jobs, njobs, &ta, &tn, tiles_of, &nsplit, &rows)) FAIL(GO2NN_EINVAL, "weight-gradient group: 1..%d jobs with one M, C >= 2, Kin >= 4", GO2NN_MAX_GROUP);
   return nsplit;
 #endif
 }
 
 int go2nn_linear_backward_weight_group(const Go2nnBwdWJob* jobs, int32_t njobs, void* stream) {
-  int tn, tiles_of[GO2NN_MAX_GROUP], nsplit, rows;
-  const int tiles = wgrad3_group_shape(jobs, njobs, &tn, tiles_of, &nsplit, &rows);
+  int ta, tn, tiles_of[GO2NN_MAX_GROUP], nsplit, rows;
+  const int tiles = wgrad3_group_shape(jobs, njobs, &ta, &tn, tiles_of, &nsplit, &rows);
   if (!tiles) FAIL(GO2NN_EINVAL, "weight-gradient group: 1..%d jobs with one M, C >= 2, Kin >= 4", GO2NN_MAX_GROUP);
   for (int j = 0; j < njobs; ++j) if (!jobs[j].gz || !jobs[j].x || !jobs[j].workspace) FAIL(GO2NN_EINVAL, "weight-gradient group: bad job %d", j);
 #ifdef GO2_EMU
@@ -764,14 +771,17 @@ int go2nn_linear_backward_weight_group(const Go2nnBwdWJob* jobs, int32_t njobs, 
   return 0;
 #else
   WgArgs a; memset(&a, 0, sizeof(a));
-  bool vec = true;
+  bool veca = true, vecb = true;
   for (int j = 0; j < njobs; ++j) {
     WgProb& g = a.p[j]; const Go2nnBwdWJob& q = jobs[j];
-    g.G = q.gz; g.X = q.x; g.part = q.workspace; g.C = q.C; g.Kin = q.Kin; g.ntc = cdiv(q.C, 64); g.ntk = cdiv(q.Kin, 32 * tn);
-    vec = vec && (q.C % 2 == 0) && (q.Kin % tn == 0) && (((uintptr_t)q.gz & 7) == 0) && (((uintptr_t)q.x & (4 * tn - 1)) == 0);
+    g.G = q.gz; g.X = q.x; g.part = q.workspace; g.C = q.C; g.Kin = q.Kin; g.ntc = cdiv(q.C, 32 * ta); g.ntk = cdiv(q.Kin, 32 * tn);
+    veca = veca && (q.C % ta == 0) && (((uintptr_t)q.gz & (4 * ta - 1)) == 0);
+    vecb = vecb && (q.Kin % tn == 0) && (((uintptr_t)q.x & (4 * tn - 1)) == 0);
   }
   a.M = jobs[0].M; a.rows_per_slice = rows; a.nsplit = nsplit; a.tiles0 = tiles_of[0]; a.tiles = tiles;
-  return vec ? wgrad3_launch2<true>(tn, a, (hipStream_t)stream) : wgrad3_launch2<false>(tn, a, (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  return veca ? (vecb ? wgrad3_launch2<true, true>(ta, tn, a, st) : wgrad3_launch2<true, false>(ta, tn, a, st))
+              : (vecb ? wgrad3_launch2<false, true>(ta, tn, a, st) : wgrad3_launch2<false, false>(ta, tn, a, st));
 #endif
 }
 

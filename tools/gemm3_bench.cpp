@@ -222,11 +222,12 @@ int main(int argc, char** argv) {
     // ragged and small problems (every edge path), then the update's shapes at a reduced row count
     fails += check_all(L, 777, {{45, 96}, {37, 70}, {130, 33}}, {{263, 96}, {64, 70}, {7, 33}}, 1500);
     fails += check_all(L, 3000, {{45, 512}, {512, 256}, {256, 128}}, {{263, 512}, {512, 256}, {256, 128}}, 1500);
+    fails += check_all(L, 3000, {{45, 512}, {48, 512}, {45, 130}}, {{48, 512}, {48, 512}, {64, 200}}, 1500);          // tall-skinny weight gradients (128 x 64 tiles), aligned and not
     printf("CHECK %s (%d bad values)\n", fails ? "FAILED" : "ok", fails);
   }
   if (mode != "check") {
     struct Sh { const char* name; int Ka, Kc, N; };
-    const Sh shapes[] = {{"L1 (45|263)->512", 45, 263, 512}, {"L2 512->256", 512, 512, 256}, {"L3 256->128", 256, 256, 128}};
+    const Sh shapes[] = {{"L1 (45|263)->512", 45, 263, 512}, {"L1 flat (45|48)->512", 45, 48, 512}, {"L2 512->256", 512, 512, 256}, {"L3 256->128", 256, 256, 128}};
     printf("M = %d rows per network; us per launch (TF/s over the useful flops)\n", M);
     double tot_old = 0, tot_new = 0;
     for (const Sh& sh : shapes) {

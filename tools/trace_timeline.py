@@ -18,9 +18,11 @@ for a, b in zip(idx, idx[1:]):
 for a, b in zip(idx, idx[1:]):
     if (k[b][1] - k[a][1]) > 5e6:
         seg = k[a:b]
-        L = [i for i, r in enumerate(seg) if r[0].startswith("go2_ppo_loss_kernel")]
+        L = [i for i, r in enumerate(seg) if r[0].startswith("go2_ppo_loss_kernel") or "go2nn_ppo_heads_kernel" in r[0]]
+        if len(L) < 5:
+            continue          # (a pause that is not an update: warm-up, graph capture)
         print("update: %.2f ms, %d kernels, %d mini-batches" % ((seg[-1][2] - seg[0][1]) / 1e6, len(seg), len(L)))
-        show(seg[L[3]:L[4] + 1], "one mini-batch (loss kernel .. next loss kernel)")
+        show(seg[L[3]:L[4] + 1], "one mini-batch (loss / heads kernel .. the next one)")
         pre = seg[:L[0]]
         show(pre[-60:], "before the first mini-batch (GAE, permutation gathers, first forward)")
         break
