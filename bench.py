@@ -106,7 +106,7 @@ def cpu_baseline(task="go2_flat", sizes=(64, NUM_ENVS), iters=3):
         runner, _ = task_registry.make_alg_runner(env, task, args, log_root=None)
         threads = min(nproc, CPU_THREADS)
         if n >= 1024:
-            # ascending thread counts; the sweep stops at the first count that is slower than the best so far or whose iteration takes more
+            # ascending thread counts; the sweep stops at a count whose iteration takes more
             # than 12 s (a container may report more hardware threads than its CPU quota gives it: oversubscribed OpenMP pools crawl), and
             # in any case after 60 s — bench.py has to finish within minutes
             t_sweep = time.perf_counter()
@@ -118,7 +118,8 @@ def cpu_baseline(task="go2_flat", sizes=(64, NUM_ENVS), iters=3):
                 dt = time.perf_counter() - t0
                 sweep[str(th)] = {"env_steps_per_s": n * 24 / dt, "collection_only_env_steps_per_s": n * 24 / runner.last_collection_time}
                 best = max(v["env_steps_per_s"] for v in sweep.values())
-                if sweep[str(th)]["env_steps_per_s"] < 0.9 * best or dt > 12.0 or time.perf_counter() - t_sweep > 60.0:
+                # (a count that is slower than the best so far ends the sweep only beyond 64 threads: 8 .. 64 are always timed)
+                if (th >= 64 and sweep[str(th)]["env_steps_per_s"] < 0.9 * best) or dt > 12.0 or time.perf_counter() - t_sweep > 60.0:
                     break
             threads = best_threads = int(max(sweep, key=lambda k: sweep[k]["env_steps_per_s"]))
             _set_cpu_threads(threads)

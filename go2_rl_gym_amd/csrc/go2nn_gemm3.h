@@ -364,8 +364,8 @@ __global__ void __launch_bounds__(256, GM3_WAVES(TM, TN, BK)) go2nn_gemm3_kernel
 }
 
 // ---- weight gradient: operands straight from global memory into MFMA registers ------------------------------------------------------------
-// TA / TN: 32-column tiles of G / of X one load of a lane feeds (tile b = columns c0 + T i + b): 2 x 4 for the square layers, 4 x 2 for the tall-skinny
-// input layer (dW [512, 45]: four times the MFMAs per loaded byte of G, whose 50 MB per network are what that layer's gradient streams).
+// TA / TN: 32-column tiles of G / of X one load of a lane feeds (tile b = columns c0 + T i + b): 2 x 4 for the square layers, 2 x 2 for ragged widths
+// (4 x 2 was measured for the input layer and rejected: go2nn_impl.cpp, wgrad3_group_shape).
 // VECA / VECB: the operand's rows are aligned to the lane's piece (one load instruction per piece); else 4-byte loads (a 45-float row pitch).
 template <int TA, int TN, bool VECA, bool VECB, int D>
 __global__ void __launch_bounds__(256, 2) go2nn_wgrad_kernel(const WgArgs wa) {

@@ -613,26 +613,22 @@ static inline int bx3_tm(int M, int N0, int N1) {
 template <bool VECA, bool VECB>
 static int wgrad3_launch2(int ta, int tn, const WgArgs& a, hipStream_t st) {
   const dim3 grid(a.tiles * a.nsplit), blk(256);
-  if (ta == 4)      hipLaunchKernelGGL((go2nn_wgrad_kernel<4, 2, VECA, VECB, 8>), grid, blk, 0, st, a);
-  else if (tn == 4) hipLaunchKernelGGL((go2nn_wgrad_kernel<2, 4, VECA, VECB, 6>), grid, blk, 0, st, a);
+  if (tn == 4) hipLaunchKernelGGL((go2nn_wgrad_kernel<2, 4, VECA, VECB, 6>), grid, blk, 0, st, a);
   else              hipLaunchKernelGGL((go2nn_wgrad_kernel<2, 2, VECA, VECB, 8>), grid, blk, 0, st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
 #endif
-// tile of the grouped weight gradient: 64 x 128 (2 x 4 column tiles per lane load) for the square layers; 128 x 64 for a tall-skinny gradient (every job's Kin <= 64 and
-// C >= 128: the input layer's dW [512, 45 | 48] — G's bytes per MFMA halve); 64 x 64 otherwise (ragged widths waste less: 263 -> 320 instead of 384 columns)
+// tile of the grouped weight gradient: 64 x 128 (2 x 4 column tiles per lane load) when every Kin is a multiple of 128, else 64 x 64 (ragged widths waste less:
+// 263 -> 320 instead of 384 columns).  Measured and rejected: 128 x 64 tiles for the input layer's dW [512, 45 | 263] — a quarter fewer bytes through the lanes'
+// loads (604 -> 452 MB), but 200 registers = 2 waves per SIMD instead of 4: 95 -> 117 us (profiles/r4_gemm_split_bench.txt)
 static int wgrad3_group_shape(const Go2nnBwdWJob* jobs, int njobs, int* ta, int* tn, int* tiles_of, int* nsplit, int* rows) {
   if (!jobs || njobs < 1 || njobs > GO2NN_MAX_GROUP) return 0;
   *tn = 4; *ta = 2;
-  bool skinny = true;
   for (int j = 0; j < njobs; ++j) {
     if (!lin_check(jobs[j].M, jobs[j].C, jobs[j].Kin) || jobs[j].M != jobs[0].M || jobs[j].C < 2 || jobs[j].Kin < 4) return 0;
     if (jobs[j].Kin % 128) *tn = 2;
-    if (jobs[j].Kin > 64 || jobs[j].C < 128) skinny = false;
   }
-  static const bool no_skinny = getenv("GO2NN_WG3_SKINNY") && atoi(getenv("GO2NN_WG3_SKINNY")) == 0;          // tools only (A/B)
-  if (skinny && !no_skinny) { *ta = 4; *tn = 2; }
   int tiles = 0;
   for (int j = 0; j < njobs; ++j) { tiles_of[j] = cdiv(jobs[j].C, 32 * *ta) * cdiv(jobs[j].Kin, 32 * *tn); tiles += tiles_of[j]; }
   wgrad3_shape(jobs[0].M, tiles, nsplit, rows);

@@ -222,7 +222,7 @@ int main(int argc, char** argv) {
     // ragged and small problems (every edge path), then the update's shapes at a reduced row count
     fails += check_all(L, 777, {{45, 96}, {37, 70}, {130, 33}}, {{263, 96}, {64, 70}, {7, 33}}, 1500);
     fails += check_all(L, 3000, {{45, 512}, {512, 256}, {256, 128}}, {{263, 512}, {512, 256}, {256, 128}}, 1500);
-    fails += check_all(L, 3000, {{45, 512}, {48, 512}, {45, 130}}, {{48, 512}, {48, 512}, {64, 200}}, 1500);          // tall-skinny weight gradients (128 x 64 tiles), aligned and not
+    fails += check_all(L, 3000, {{45, 512}, {48, 512}, {45, 130}}, {{48, 512}, {48, 512}, {64, 200}}, 1500);          // narrow input layers, aligned rows and not
     printf("CHECK %s (%d bad values)\n", fails ? "FAILED" : "ok", fails);
   }
   if (mode != "check") {
