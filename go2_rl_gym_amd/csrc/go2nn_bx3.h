@@ -26,6 +26,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #endif
 
 #define BX3_BK 16
+#ifndef BX3_DA
+#define BX3_DA(TM) ((TM) == 1 ? 4 : 2)          /* staging sets of the A operand (tiles of lookahead) */
+#endif
 #ifndef BX3_SGB_VALU
 #define BX3_SGB_VALU 5
 #endif
@@ -111,6 +114,7 @@ template <int TM> struct Bx3Frags {
 };
 template <int TM, int EPI>
 __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
+  static_assert(TM <= 2 || EPI != EPI_DELU_COLSUM, "the column sums are kept per 64 data rows");
   constexpr int BM = 64 * TM, BN = 128, BK = BX3_BK, TN = 2;
   constexpr int AP = BM * 32, BP = 4096, BOFF = 3 * AP, STAGE = 3 * AP + 3 * BP, LOOP_LDS = 2 * STAGE, EPI_LDS = 4 * 32 * 32 * TN * 4;
   using SA = G3Stage<BM, true, BK>;
@@ -140,8 +144,35 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+  // the epilogue's geometry and its operands that do not depend on the product: the bias (forward) and the first 32-row slab of the ELU outputs Y whose derivative
+  // multiplies the input gradient are requested HERE, in front of the k-loop — at the head of the epilogue their latency was exposed once per workgroup
+  constexpr int CT = 32 * TN, LPR = CT / 4, RPI = 64 / LPR, NI = 32 / RPI;
+  const int lc = (lane % LPR) * 4, lr = lane / LPR;
+  const int col = col0 + wn * CT + lc;
+  const bool cv = g.c_vec != 0 && col + 3 < g.N;
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (EPI == EPI_BIAS_ELU) {
+    const int c1 = min(col, g.N - 1), c2 = min(col + 1, g.N - 1), c3 = min(col + 2, g.N - 1), c4 = min(col + 3, g.N - 1);
+    bias4 = make_float4(g.bias[c1], g.bias[c2], g.bias[c3], g.bias[c4]);
+  }
+  float4 y4[EPI == EPI_DELU_COLSUM ? TM : 1][EPI == EPI_DELU_COLSUM ? NI : 1];
+  auto load_y = [&](auto a_c) __attribute__((always_inline)) {
+    constexpr int A_ = decltype(a_c)::value;
+    if constexpr (EPI == EPI_DELU_COLSUM) {
+#pragma unroll
+      for (int n = 0; n < NI; ++n) {
+        const float* q = g.Y + (size_t)min(row0 + wm * 32 * TM + A_ * 32 + lr + n * RPI, g.M - 1) * g.ldc;
+        if (cv) y4[A_][n] = *reinterpret_cast<const float4*>(q + col);
+        else y4[A_][n] = make_float4(q[min(col, g.N - 1)], q[min(col + 1, g.N - 1)], q[min(col + 2, g.N - 1)], q[min(col + 3, g.N - 1)]);
+      }
+    }
+  };
+  if constexpr (TM >= 2) load_y(G3Int<0>{});          // (64-row tiles: 32 more registers would cost the third workgroup per CU)
+
   SA sa; sa.init(g.A, g.lda, row0, g.M, g.K, tid);
-  f32x4 ba0[SA::P], ba1[SA::P]; u32x4 bb[3];          // A: two staging sets (HBM latency: two tiles ahead); B: one (L2 hits: re-issued as soon as it is committed)
+  // A: DA staging sets — the loads of tile kt + DA are issued at the top of tile kt (HBM latency); B: one set (L2 hits: re-issued as soon as it is committed)
+  constexpr int DA = BX3_DA(TM);
+  f32x4 ba[DA][SA::P]; u32x4 bb[3];
   const unsigned char* bimg = g.B + (size_t)bn * nk * BX3_TILE_BYTES + tid * 16;
   auto issue_b = [&](int kt) __attribute__((always_inline)) {
     const unsigned char* s = bimg + (size_t)kt * BX3_TILE_BYTES;
@@ -213,17 +244,18 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
   // (its displaced quads are put right on the way to LDS: a branch in the loop's commit would keep the scheduler from placing the split between the MFMAs)
   const bool ragged = (g.K & (BK - 1)) != 0;
   const int nkp = ragged ? nk - 1 : nk;
-  auto tile = [&](auto cur_c, auto more_c, int kt) __attribute__((always_inline)) {
-    constexpr int CUR = decltype(cur_c)::value; constexpr bool MORE = decltype(more_c)::value;
-    auto& a_ld = CUR ? ba1 : ba0; auto& a_st = CUR ? ba0 : ba1;
+  // (set indices are compile-time constants: a runtime index would put the staging arrays into scratch) tile kt's data sits in set kt % DA
+  auto tile = [&](auto cur_c, auto set_c, const bool MORE, int kt) __attribute__((always_inline)) {
+    constexpr int CUR = decltype(cur_c)::value, SET = decltype(set_c)::value;
+    auto& a_ld = ba[SET]; auto& a_st = ba[(SET + 1) % DA];          // tile kt was committed during tile kt - 1: its set takes tile kt + DA; tile kt + 1 is committed now
     FR& fc = CUR ? f1 : f0; FR& fn = CUR ? f0 : f1;
 #ifndef BX3_DBG_NOA
-    if constexpr (MORE) { const int k2 = min(kt + 2, nkp - 1); sa.issue(k2 * BK, a_ld); }          // (past the last tile: a re-read that is never used — straight-line code)
+    { const int k2 = min(kt + DA, nkp - 1); sa.issue(k2 * BK, a_ld); }          // (past the last tile: a re-read that is never used — straight-line code)
 #endif
     g3_wait_lgkm<0>();
     fc.opaque(); lo_opaque();
     mfmas(G3Int<0>{}, G3Int<3>{}, fc);
-    if constexpr (MORE) {
+    if (MORE) {          // (workgroup-uniform)
 #ifndef BX3_DBG_NOCOMMIT
       commit(G3Int<0>{}, CUR ^ 1, kt + 1, a_st);
 #endif
@@ -254,22 +286,22 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
   };
   constexpr G3Int<0> I0{}; constexpr G3Int<1> I1{};
   if (nkp > 0) {
-    sa.issue(0, ba0); issue_b(0);
-    if (nkp > 1) sa.issue(BK, ba1);
-    commit(I0, 0, 0, ba0);
+    issue_b(0);
+    g3_for<0, DA>([&](auto d_c) __attribute__((always_inline)) { constexpr int D_ = decltype(d_c)::value; sa.issue(min(D_, nkp - 1) * BK, ba[D_]); });
+    commit(I0, 0, 0, ba[0]);
     if (nkp > 1) issue_b(1);
     __syncthreads();
     read_frags(I0, f0);
     G3_T(1);
-    int kt = 0;
-    for (; kt + 2 < nkp; kt += 2) { tile(I0, I1, kt); tile(I1, I1, kt + 1); }
-    if (nkp - kt == 2) { tile(I0, I1, kt); tile(I1, I0, kt + 1); }
-    else tile(I0, I0, kt);
+    // tiles in groups of lcm(2, DA): stage parity and staging set are compile-time constants of a tile's code; MORE (tile kt + 1 follows) is a uniform branch
+    constexpr int G = (DA % 2) ? 2 * DA : DA;
+    for (int kt = 0; kt < nkp; kt += G)
+      g3_for<0, G>([&](auto j_c) __attribute__((always_inline)) { constexpr int J = decltype(j_c)::value; if (kt + J < nkp) tile(G3Int<J & 1>{}, G3Int<J % DA>{}, kt + J + 1 < nkp, kt + J); });
   }
   if (ragged) {
     __syncthreads();
-    sa.issue((nk - 1) * BK, ba0); issue_b(nk - 1);
-    commit(I1, 0, nk - 1, ba0);
+    sa.issue((nk - 1) * BK, ba[0]); issue_b(nk - 1);
+    commit(I1, 0, nk - 1, ba[0]);
     __syncthreads();
     read_frags(I0, f0);
     g3_wait_lgkm<0>();
@@ -281,30 +313,13 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
   G3_T(3);
 
   // epilogue: go2nn_gemm3_kernel's (every wave turns its tile, 32 rows at a time, through its LDS quarter; 16-byte row accesses)
-  constexpr int CT = 32 * TN, LPR = CT / 4, RPI = 64 / LPR, NI = 32 / RPI;
-  const int lc = (lane % LPR) * 4, lr = lane / LPR;
-  const int col = col0 + wn * CT + lc;
-  const bool cv = g.c_vec != 0 && col + 3 < g.N;
-  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (EPI == EPI_BIAS_ELU) {
-    const int c1 = min(col, g.N - 1), c2 = min(col + 1, g.N - 1), c3 = min(col + 2, g.N - 1), c4 = min(col + 3, g.N - 1);
-    bias4 = make_float4(g.bias[c1], g.bias[c2], g.bias[c3], g.bias[c4]);
-  }
+  g3_for<(TM >= 2 ? 1 : 0), TM>([&](auto a_c) __attribute__((always_inline)) { load_y(a_c); });
   {
     float* wl = reinterpret_cast<float*>(lds) + wave * (32 * CT);
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
       const int rbase = row0 + wm * 32 * TM + a * 32 + lr;
-      float4 y4[EPI == EPI_DELU_COLSUM ? NI : 1];
-      if (EPI == EPI_DELU_COLSUM) {
-#pragma unroll
-        for (int n = 0; n < NI; ++n) {
-          const float* q = g.Y + (size_t)min(rbase + n * RPI, g.M - 1) * g.ldc;
-          if (cv) y4[n] = *reinterpret_cast<const float4*>(q + col);
-          else y4[n] = make_float4(q[min(col, g.N - 1)], q[min(col + 1, g.N - 1)], q[min(col + 2, g.N - 1)], q[min(col + 3, g.N - 1)]);
-        }
-      }
 #pragma unroll
       for (int b = 0; b < TN; ++b)
 #pragma unroll
@@ -319,7 +334,7 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
         float4 v = *reinterpret_cast<const float4*>(wl + lrow * CT + (lc ^ ((lrow >> 2 & 1) << 5 & (CT - 1))));
         if (EPI == EPI_BIAS_ELU) v = make_float4(elu1(v.x + bias4.x), elu1(v.y + bias4.y), elu1(v.z + bias4.z), elu1(v.w + bias4.w));
         if (EPI == EPI_DELU_COLSUM) {
-          const float4 y = y4[EPI == EPI_DELU_COLSUM ? n : 0];
+          const float4 y = y4[EPI == EPI_DELU_COLSUM ? a : 0][EPI == EPI_DELU_COLSUM ? n : 0];
           v.x *= y.x > 0.f ? 1.f : y.x + 1.f; v.y *= y.y > 0.f ? 1.f : y.y + 1.f; v.z *= y.z > 0.f ? 1.f : y.z + 1.f; v.w *= y.w > 0.f ? 1.f : y.w + 1.f;
           if (row < g.M) { cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w; }
         }

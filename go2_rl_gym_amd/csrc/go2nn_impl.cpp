@@ -598,17 +598,25 @@ static int gemm3_launch(int tm, int tn, int bk, const Gemm3Args& a, hipStream_t 
 template <int EPI>
 static int bx3_launch(int tm, const Bx3Args& a, hipStream_t st) {
   const dim3 grid(a.ntiles), blk(256);
-  if (tm == 2) hipLaunchKernelGGL((go2nn_bx3_kernel<2, EPI>), grid, blk, 0, st, a);
-  else         hipLaunchKernelGGL((go2nn_bx3_kernel<1, EPI>), grid, blk, 0, st, a);
+  if (tm == 3) { if constexpr (EPI == EPI_BIAS_ELU) hipLaunchKernelGGL((go2nn_bx3_kernel<3, EPI>), grid, blk, 0, st, a); else FAIL(GO2NN_EINVAL, "bx3: no 192-row tile for this epilogue"); }
+  else if (tm == 2) hipLaunchKernelGGL((go2nn_bx3_kernel<2, EPI>), grid, blk, 0, st, a);
+  else              hipLaunchKernelGGL((go2nn_bx3_kernel<1, EPI>), grid, blk, 0, st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
-// rows per workgroup tile of the split-operand kernels: 128 while that still gives every CU its two workgroups, else 64
-static inline int bx3_tm(int M, int N0, int N1) {
+// rows per workgroup tile of the split-operand kernels (64 tm).  All workgroups of a launch are resident at once only if they fit the chip's slots (2 per CU for
+// the 128- and 192-row tiles, 3 for 64 rows); a launch of 768 workgroups on 512 slots runs a second, half-empty round (measured: MFMA busy 37 %).  So: the tile
+// height whose workgroup count fills whole rounds best, the larger one on a tie (less weight traffic per MFMA).  192 rows exist for the forward epilogue only.
+static inline int bx3_tm(int M, int N0, int N1, int tm_max) {
   static const char* const env = getenv("GO2NN_BX3_TM");        // tools only
-  if (env && (env[0] == '1' || env[0] == '2')) return env[0] - '0';
-  const int tiles = cdiv(M, 128) * (cdiv(N0, 128) + (N1 ? cdiv(N1, 128) : 0));
-  return tiles >= 512 ? 2 : 1;
+  if (env && env[0] >= '1' && env[0] <= '0' + tm_max) return env[0] - '0';
+  int best = 1; double best_eff = -1.0;
+  for (int tm = 1; tm <= tm_max; ++tm) {
+    const long long tiles = (long long)cdiv(M, 64 * tm) * (cdiv(N0, 128) + (N1 ? cdiv(N1, 128) : 0)), slots = tm == 1 ? 768 : 512;
+    const double eff = (double)tiles / (double)((tiles + slots - 1) / slots * slots);
+    if (eff >= best_eff - 1e-9) { best_eff = eff > best_eff ? eff : best_eff; best = tm; }
+  }
+  return best;
 }
 template <bool VECA, bool VECB>
 static int wgrad3_launch2(int ta, int tn, const WgArgs& a, hipStream_t st) {
@@ -667,7 +675,7 @@ int go2nn_linear_elu_forward_group(const Go2nnFwdJob* jobs, int32_t njobs, void*
 #else
   if (jobs[0].w_split && jobs[njobs - 1].w_split && jobs[0].K >= 4 && jobs[njobs - 1].K >= 4) {          // split-operand kernel (go2nn_bx3.h)
     Bx3Args a; memset(&a, 0, sizeof(a));
-    const int tm = bx3_tm(jobs[0].M, jobs[0].N, njobs == 2 ? jobs[1].N : 0);
+    const int tm = bx3_tm(jobs[0].M, jobs[0].N, njobs == 2 ? jobs[1].N : 0, 3);
     for (int j = 0; j < njobs; ++j) {
       Bx3Prob& g = a.p[j]; const Go2nnFwdJob& q = jobs[j];
       g.A = q.x; g.B = (const unsigned char*)q.w_split; g.C = q.y; g.bias = q.b; g.M = q.M; g.N = q.N; g.K = q.K; g.lda = q.K; g.ldc = q.N;
@@ -715,7 +723,7 @@ int go2nn_linear_backward_input_group(const Go2nnBwdInJob* jobs, int32_t njobs, 
 #else
   if (jobs[0].w_split && jobs[njobs - 1].w_split && jobs[0].C >= 4 && jobs[njobs - 1].C >= 4) {          // split-operand kernel: A = gz [M,C], B = the transposed image (rows k, contraction c)
     Bx3Args a; memset(&a, 0, sizeof(a));
-    const int tm = bx3_tm(jobs[0].M, jobs[0].Kin, njobs == 2 ? jobs[1].Kin : 0);
+    const int tm = bx3_tm(jobs[0].M, jobs[0].Kin, njobs == 2 ? jobs[1].Kin : 0, 2);
     for (int j = 0; j < njobs; ++j) {
       Bx3Prob& g = a.p[j]; const Go2nnBwdInJob& q = jobs[j];
       g.A = q.gz; g.B = (const unsigned char*)q.w_split + bx3_image_bytes(q.C, q.Kin); g.C = q.gz_prev; g.Y = q.y_prev; g.part = q.workspace;

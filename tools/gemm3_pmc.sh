@@ -10,7 +10,7 @@ P3="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIV
 i=0
 for P in "$P1" "$P2" "$P3"; do
   i=$((i+1)); rm -rf /tmp/gp_$i
-  timeout 200 rocprofv3 --kernel-trace --pmc $P --output-format csv -d /tmp/gp_$i -o gp -- $R/build/gemm3_bench $R/go2_rl_gym_amd/libgo2nn_hip.so 24576 one "$@" > /tmp/gp_$i.log 2>&1 || tail -5 /tmp/gp_$i.log
+  timeout 200 rocprofv3 --kernel-trace --pmc $P --output-format csv -d /tmp/gp_$i -o gp -- ${GEMM3_BENCH:-$R/build/gemm3_bench} $R/go2_rl_gym_amd/libgo2nn_hip.so 24576 one "$@" > /tmp/gp_$i.log 2>&1 || tail -5 /tmp/gp_$i.log
 done
 python3 - "$R/gpurun_out/pmc/gemm3_$TAG.json" "$@" <<'PY'
 import csv, glob, json, sys, collections
@@ -21,14 +21,14 @@ for i in (1, 2, 3):
         continue
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
-        if "go2nn_gemm3_kernel" in r["Kernel_Name"] or "go2nn_wgrad_kernel" in r["Kernel_Name"]:
+        if any(n in r["Kernel_Name"] for n in ("go2nn_gemm3_kernel", "go2nn_wgrad_kernel", "go2nn_bx3_kernel")):
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
             out["kernel"], out["vgpr"], out["agpr"], out["lds"] = r["Kernel_Name"][:80], int(r["VGPR_Count"]), int(r["Accum_VGPR_Count"]), int(r["LDS_Block_Size"])
     for k, v in acc.items():
         out[k] = sum(v) / len(v)
     fs = glob.glob("/tmp/gp_%d/*kernel_trace.csv" % i)
     if fs:
-        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(fs[0])) if "go2nn_gemm3_kernel" in r["Kernel_Name"] or "go2nn_wgrad_kernel" in r["Kernel_Name"]]
+        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(fs[0])) if any(n in r["Kernel_Name"] for n in ("go2nn_gemm3_kernel", "go2nn_wgrad_kernel", "go2nn_bx3_kernel"))]
         out["us_pass%d" % i] = sum(d) / len(d) / 1e3
 if "GRBM_GUI_ACTIVE" in out and "us_pass3" in out:
     out["clock_GHz"] = out["GRBM_GUI_ACTIVE"] / out["us_pass3"] / 1e3
