@@ -335,16 +335,34 @@ GO2_HD void go2_step_body(Go2Shared& sh, const Go2DevBlock* __restrict__ blk, co
     STAMP(2);
     GO2_MARK(20);
     float fb[9];
-    lane_finish_phys(ph_, po_, ax, tab, p, L, e, lane, sub, fb);
+    {
+      int tid1 = tid;          // (indices recomputed behind the loop instead of kept across it: see the note at post-physics below)
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" : "+v"(tid1));
+#endif
+      const int e = bid * GO2_WG_ENVS + (tid1 >> 4), lane = (tid1 >> 2) & 3, sub = tid1 & 3;
+      lane_finish_phys(ph_, po_, ax, tab, p, L, e, lane, sub, fb);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) fb[i] = xl::leg_sum(fb[i]);
-    lane_store_base_forces(ph_, po_, ax, p, L, e, lane, sub, fb);
+      for (int i = 0; i < 9; ++i) fb[i] = xl::leg_sum(fb[i]);
+      lane_store_base_forces(ph_, po_, ax, p, L, e, lane, sub, fb);
+    }
   } else {
     lane_load_physout(ph_, po_, ax, tab, p, L, e, lane);
   }
   STAMP(3);
   if (MODE & MODE_POST) {
     GO2_MARK(21);
+    // the lane's indices and LDS rows again, from a copy of the thread id the compiler cannot trace back: what post-physics reads of them was live across the
+    // substep loop, whose register file is full — the compiler kept them in 48 B of scratch per lane (3 MB written and read back per launch: 1.42 x the
+    // algorithmic HBM bytes in the PMC profile); recomputing them costs six integer instructions
+    int tid2 = tid;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(tid2));
+#endif
+    const int e = bid * GO2_WG_ENVS + (tid2 >> 4), lane = (tid2 >> 2) & 3, sub = tid2 & 3;
+    const LegTab& t = tab.leg[lane];
+    GO2_AS3 float (*uc)[4] = (GO2_AS3 float (*)[4])sh.ucache[tid2 >> 4];
+    GO2_AS3 float* hc = (GO2_AS3 float*)sh.hcache[tid2 >> 4];
     lane_init_post(ph_, po_, ax, (const GO2_AS3 uint8_t*)tab.slot_code, uc, hc, &p, &L, &S, e, lane, sub);
     po_.yaw_seen = yaw_seen; po_.out = outs;
 #if defined(__HIP_DEVICE_COMPILE__) && defined(GO2_KBENCH_STAMPS)

@@ -4,18 +4,27 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/${1:-final}; mkdir -p $O
 cd $R
-timeout 600 python -m pytest tests -q -m gpu -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log
+timeout 900 python -m pytest tests -q -m gpu -s -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log
 timeout 400 python bench.py > $O/bench.json 2> $O/bench.err
+GO2_GEMM_SPLIT=0 timeout 200 python bench.py --no-cpu-baseline > $O/bench_fp32_mfma_gemms.json 2> /dev/null
 timeout 200 python bench.py --task go2 --no-cpu-baseline > $O/bench_go2.json 2> /dev/null
 timeout 200 python bench.py --task go2_cts --steps 50 --no-cpu-baseline > $O/bench_go2_cts.json 2> /dev/null
 timeout 200 python bench.py --task go2 --num-envs 32768 --steps 20 --warmup 8 --no-cpu-baseline > $O/bench_go2_32768.json 2> /dev/null
+timeout 200 python bench.py --num-envs 8192 --steps 40 --warmup 10 --no-cpu-baseline > $O/bench_go2_flat_8192.json 2> /dev/null
 timeout 200 python bench.py --task go2_moe_cts --num-envs 8192 --steps 20 --warmup 8 --no-cpu-baseline > $O/bench_go2_moe_cts_8192.json 2> /dev/null
-timeout 200 python bench.py --task go2_moe_cts --num-envs 1024 --steps 50 --warmup 10 --no-cpu-baseline > $O/bench_go2_moe_cts_1024.json 2> /dev/null
 timeout 150 python tools/kbench.py 4096 > $O/kbench.txt 2>&1
 timeout 150 python tools/kbench.py 4096 rough > $O/kbench_rough.txt 2>&1
 timeout 120 python tools/kscale.py 1024 4096 8192 32768 > $O/kscale.txt 2>&1
-timeout 120 python tools/termination_check.py "round-3 model (one contact per body group)" > $O/termination_check.txt 2>&1
 timeout 100 python tools/policy_bench.py 4096 > $O/policy_bench.txt 2>&1
+hipcc -O2 -std=c++17 tools/gemm3_bench.cpp -o /tmp/gemm3_bench -ldl 2>/dev/null
+{ echo "# tools/gemm3_bench.cpp on one MI355X, 24576 rows per network: the grouped learner products checked against a float64 host reference and timed (HIP events, warm)";
+  echo "## split operands (3 x bf16 planes, six MFMA terms; ABI 4) — forward / input gradient; the weight gradients are the fp32-MFMA kernel in both runs";
+  BX3=1 timeout 300 /tmp/gemm3_bench go2_rl_gym_amd/libgo2nn_hip.so 24576 all;
+  echo "## fp32 MFMA (ABI 3)"; timeout 300 /tmp/gemm3_bench go2_rl_gym_amd/libgo2nn_hip.so 24576 all; } > $O/gemm_split_bench.txt 2>&1
+export GEMM3_BENCH=/tmp/gemm3_bench
+BX3=1 bash tools/gemm3_pmc.sh bx3_fwd_L2 f 2 10 > /dev/null 2>&1
+BX3=1 bash tools/gemm3_pmc.sh bx3_igrad_L2 i 2 10 > /dev/null 2>&1
+bash tools/gemm3_pmc.sh f32_wgrad_L2 w 2 10 > /dev/null 2>&1
 bash tools/pmc_pass.sh 4096 100 go2_flat > $O/pmc_flat.log 2>&1
 bash tools/pmc_pass.sh 4096 100 go2 > $O/pmc_go2.log 2>&1
 bash tools/sq_pass.sh 4096 60 go2_flat > $O/sq_flat.log 2>&1
@@ -25,5 +34,6 @@ cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_bench
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o bench -- python $R/bench.py --steps 30 --warmup 20 --no-cpu-baseline > $O/bench_under_rocprof.json 2> /dev/null
 find /tmp/prof_bench -name "*kernel_stats.csv" -exec cp {} $O/bench_kernel_stats.csv \;
 cd $R
+python tools/trace_timeline.py $(find /tmp/prof_bench -name "*kernel_trace.csv" | head -1) > $O/timeline.txt 2>&1
 tail -3 $O/pytest_gpu.log; for f in $O/bench*.json; do echo $f; grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"kernel_ms": [0-9.]*\|"collection_only": [0-9.]*' $f | tr '\n' ' '; echo; done
-tail -3 $O/termination_check.txt; cat $O/kscale.txt | grep -v amdgpu
+cat $O/kscale.txt | grep -v amdgpu | tail -8
