@@ -10,12 +10,11 @@
 //   go2nn_bx3_split_kernel      weights [N][K] fp32 -> the plane images both GEMM orientations read (once per optimizer step; the matrices are small)
 //   go2nn_bx3_kernel<TM, EPI>   forward  Y = elu(X W^T + b)  and input gradient  Gp = (G W) * elu'(Yp) + column sums, grouped (actor + critic tiles in one grid)
 //        A operand (activations / gradients, [M][K] fp32 in HBM): staged through registers as in go2nn_gemm3_kernel, split on the way to LDS (22 VALU
-//        instructions per 4 values, beside the other workgroup's MFMAs: two workgroups per CU)
-//        B operand (weights): read as ready-made plane tiles, a linear 24 KB copy per 128 x 32 tile
-//        LDS image of a plane: [row][32 k] bf16 = 64 B per row, the four 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3 — a fragment read
-//        (ds_read_b128: lane i reads chunk 2 kb + g of row i) is conflict-free in each of the instruction's 16-lane groups, and so are the 8-byte stores
-//   go2nn_wgrad_bx3_kernel      weight gradient dW = G^T X: both operands k-strided; a lane gathers its 8 contraction rows with 8 coalesced loads, splits them in
-//        registers and feeds the MFMAs directly (no LDS in the loop), as go2nn_wgrad_kernel does for fp32
+//        instructions per 4 values)
+//        B operand (weights): read as ready-made plane tiles, a linear 12 KB copy per 128 x 16 tile
+//        LDS image of a plane: [row][16 k] bf16 = 32 B per row, the two 16-byte chunks of a row swapped by bit 3 of the row — a fragment read
+//        (ds_read_b128: lane i reads chunk g of row i) is conflict-free in each of the instruction's 16-lane groups, and so are the 8-byte stores
+// The weight gradient (both operands k-strided, both would need the split) stays on go2nn_wgrad_kernel: DESIGN.md section 5.
 #pragma once
 
 #ifndef GO2_EMU
@@ -249,19 +248,13 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
     constexpr int CUR = decltype(cur_c)::value, SET = decltype(set_c)::value;
     auto& a_ld = ba[SET]; auto& a_st = ba[(SET + 1) % DA];          // tile kt was committed during tile kt - 1: its set takes tile kt + DA; tile kt + 1 is committed now
     FR& fc = CUR ? f1 : f0; FR& fn = CUR ? f0 : f1;
-#ifndef BX3_DBG_NOA
     { const int k2 = min(kt + DA, nkp - 1); sa.issue(k2 * BK, a_ld); }          // (past the last tile: a re-read that is never used — straight-line code)
-#endif
     g3_wait_lgkm<0>();
     fc.opaque(); lo_opaque();
     mfmas(G3Int<0>{}, G3Int<3>{}, fc);
     if (MORE) {          // (workgroup-uniform)
-#ifndef BX3_DBG_NOCOMMIT
       commit(G3Int<0>{}, CUR ^ 1, kt + 1, a_st);
-#endif
-#ifndef BX3_DBG_NOB
       issue_b(min(kt + 2, nkp - 1));
-#endif
 #ifndef BX3_NO_SGB
       // the split's VALU work and the LDS stores between the MFMAs (a bf16 MFMA occupies the matrix pipe for 32 cycles: room for ~6 other issues)
 #pragma unroll
@@ -273,12 +266,8 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);
-#ifndef BX3_DBG_NOBAR
       __syncthreads();
-#endif
-#ifndef BX3_DBG_NOREAD
       read_frags(G3Int<CUR ^ 1>{}, fn);
-#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     mfmas(G3Int<3>{}, G3Int<6>{}, fc);
