@@ -628,8 +628,9 @@ static int wgrad3_launch2(int ta, int tn, const WgArgs& a, hipStream_t st) {
 }
 #endif
 // tile of the grouped weight gradient: 64 x 128 (2 x 4 column tiles per lane load) when every Kin is a multiple of 128, else 64 x 64 (ragged widths waste less:
-// 263 -> 320 instead of 384 columns).  Measured and rejected: 128 x 64 tiles for the input layer's dW [512, 45 | 263] — a quarter fewer bytes through the lanes'
-// loads (604 -> 452 MB), but 200 registers = 2 waves per SIMD instead of 4: 95 -> 117 us (profiles/r4_gemm_split_bench.txt)
+// 263 -> 320 instead of 384 columns).  Measured and rejected for the input layer's dW [512, 45 | 263] (93-95 us; the padded tiles' MFMAs alone are 70 us at 2.1 GHz):
+// 128 x 64 tiles (a quarter fewer bytes through the lanes' loads, but 200 registers = 2 waves per SIMD instead of 4: 117 us) and 256 x 64 workgroup tiles with the X
+// columns shared through LDS (16-row chunks, four waves on four column blocks, no cross-wave reduction: 121 us — two barriers per chunk cost more than the loads saved)
 static int wgrad3_group_shape(const Go2nnBwdWJob* jobs, int njobs, int* ta, int* tn, int* tiles_of, int* nsplit, int* rows) {
   if (!jobs || njobs < 1 || njobs > GO2NN_MAX_GROUP) return 0;
   *tn = 4; *ta = 2;
