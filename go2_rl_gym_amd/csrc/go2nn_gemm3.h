@@ -492,10 +492,9 @@ __global__ void __launch_bounds__(256, 2) go2nn_wgrad_kernel(const WgArgs wa) {
 #endif  // !GO2_EMU
 
 // tile shape of the grouped forward / input-gradient GEMMs for an output of N columns (rows: the mini-batch): 64 x 128 workgroup tiles with 32-deep k-tiles
-// (48 KB of LDS, 3 workgroups per CU, no spills: measured best at every shape of the update, profiles/r4_gemm3.txt), 64 x 64 for narrow outputs
+// (48 KB of LDS, 3 workgroups per CU, no spills: measured best at every shape of the update against 128 x 128 and 16-deep tiles, profiles/r4_gemm3_bench.txt — those
+// instantiations are not shipped), 64 x 64 for narrow outputs
 static inline void gemm3_tile(int N, int* tm, int* tn, int* bk) {
-  static const char* const env = getenv("GO2NN_TILE3");        // tools only: "<tm><tn><bk/16>", e.g. 221 (read once)
-  if (env && env[0] >= '1' && env[0] <= '2' && env[1] >= '1' && env[1] <= '2' && env[2] >= '1' && env[2] <= '2') { *tm = env[0] - '0'; *tn = env[1] - '0'; *bk = 16 * (env[2] - '0'); return; }
   *tn = N > 64 ? 2 : 1;
   *tm = 1;
   *bk = 32;

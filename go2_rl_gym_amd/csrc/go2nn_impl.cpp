@@ -586,11 +586,8 @@ extern "C" void go2nn_debug_gemm3_stamps(long long* p) { g_gemm3_stamps = p; }  
 template <bool BKC, int EPI>
 static int gemm3_launch(int tm, int tn, int bk, const Gemm3Args& a, hipStream_t st) {
   const dim3 grid(a.ntiles), blk(256);
-  if (tm == 2 && tn == 2 && bk == 16)      hipLaunchKernelGGL((go2nn_gemm3_kernel<2, 2, BKC, EPI, 16>), grid, blk, 0, st, a);
-  else if (tm == 2 && tn == 2)             hipLaunchKernelGGL((go2nn_gemm3_kernel<2, 2, BKC, EPI, 32>), grid, blk, 0, st, a);
-  else if (tm == 1 && tn == 2 && bk == 16) hipLaunchKernelGGL((go2nn_gemm3_kernel<1, 2, BKC, EPI, 16>), grid, blk, 0, st, a);
-  else if (tm == 1 && tn == 2)             hipLaunchKernelGGL((go2nn_gemm3_kernel<1, 2, BKC, EPI, 32>), grid, blk, 0, st, a);
-  else if (tm == 1 && tn == 1)             hipLaunchKernelGGL((go2nn_gemm3_kernel<1, 1, BKC, EPI, 32>), grid, blk, 0, st, a);
+  if (tm == 1 && tn == 2 && bk == 32)      hipLaunchKernelGGL((go2nn_gemm3_kernel<1, 2, BKC, EPI, 32>), grid, blk, 0, st, a);
+  else if (tm == 1 && tn == 1 && bk == 32) hipLaunchKernelGGL((go2nn_gemm3_kernel<1, 1, BKC, EPI, 32>), grid, blk, 0, st, a);
   else FAIL(GO2NN_EINVAL, "gemm3: no kernel for tile %d x %d x %d", tm, tn, bk);
   HIPCHK(hipGetLastError());
   return 0;
