@@ -43,8 +43,9 @@ BX3_HD static inline long long bx3_image_bytes(int rows, int con) { return (long
 struct Bx3Prob {
   const float* A; const unsigned char* B; float* C; const float* bias; const float* Y; float* part;
   int M, N, K, lda, ldc, nbm, nbn, c_vec, nkt;
+  const float* Bf; int ldb;          // weight-gradient mode: the second operand is an activation matrix too (fp32, [rows][N])
 };
-struct Bx3Args { Bx3Prob p[2]; int ntiles0, ntiles; long long* stamps; };
+struct Bx3Args { Bx3Prob p[2]; int ntiles0, ntiles; long long* stamps; int wg_M, wg_rows; };          // wg_*: the mini-batch's rows and the rows of one slice (weight-gradient mode)
 struct Bx3SplitJob { const float* w; unsigned char* img; int N, K; };          // img: forward image, then the transposed one
 struct Bx3SplitArgs { Bx3SplitJob j[8]; int njobs; };
 
@@ -111,9 +112,13 @@ template <int TM> struct Bx3Frags {
     }
   }
 };
-template <int TM, int EPI>
+// WG (weight gradient dW [C, Kin] = G^T X over one row slice of the mini-batch): both operands are [rows][columns] fp32 with the CONTRACTION index as their row, so a
+// staging thread owns one column and gathers its 8 contraction rows with 8 loads (coalesced across the lanes: 256 B per wave and load), splits them and stores the
+// 16 bytes per plane as one fragment chunk; the k-loop, the fragments and the MFMAs are the same.  Output tile = 128 rows of C x 128 columns of Kin of slice `slice`.
+template <int TM, int EPI, bool WG = false>
 __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
   static_assert(TM <= 2 || EPI != EPI_DELU_COLSUM, "the column sums are kept per 64 data rows");
+  static_assert(!WG || (TM == 2 && EPI == EPI_STORE), "weight-gradient mode: 128 x 128 tiles, plain store");
   constexpr int BM = 64 * TM, BN = 128, BK = BX3_BK, TN = 2;
   constexpr int AP = BM * 32, BP = 4096, BOFF = 3 * AP, STAGE = 3 * AP + 3 * BP, LOOP_LDS = 2 * STAGE, EPI_LDS = 4 * 32 * 32 * TN * 4;
   using SA = G3Stage<BM, true, BK>;
@@ -121,14 +126,20 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[LOOP_LDS > EPI_LDS ? LOOP_LDS : EPI_LDS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, gk = lane >> 5, wm = wave & 1, wn = wave >> 1;
   // workgroup -> tile: each problem's tiles dealt to the 8 XCDs in contiguous runs (go2nn_gemm3_kernel)
-  int t = blockIdx.x, pi;
+  int t = blockIdx.x, pi, slice = 0;
   const int n0 = ga.ntiles0, n1 = ga.ntiles - ga.ntiles0;
-  if (((n0 | n1) & 7) == 0) { const int x = t & 7, j = t >> 3, c0 = n0 >> 3, c1 = n1 >> 3; pi = j >= c0 ? 1 : 0; t = pi ? x * c1 + (j - c0) : x * c0 + j; }
+  if constexpr (WG) {          // workgroup -> (row slice, tile): the slices with index = x mod 8 live on XCD x, all tiles of a slice next to each other (go2nn_wgrad_kernel)
+    const int xcd = t & 7, idx = t >> 3;
+    slice = (idx / ga.ntiles) * 8 + xcd; t = idx % ga.ntiles;
+    pi = t >= n0 ? 1 : 0; t -= pi ? n0 : 0;
+  } else if (((n0 | n1) & 7) == 0) { const int x = t & 7, j = t >> 3, c0 = n0 >> 3, c1 = n1 >> 3; pi = j >= c0 ? 1 : 0; t = pi ? x * c1 + (j - c0) : x * c0 + j; }
   else { pi = t >= n0 ? 1 : 0; t -= pi ? n0 : 0; }
   const Bx3Prob& g = ga.p[pi];
   const int bm = t / g.nbn, bn = t - bm * g.nbn;
   const int row0 = bm * BM, col0 = bn * BN;
-  const int nk = g.nkt;
+  const int nk = WG ? (ga.wg_rows + BK - 1) / BK : g.nkt;
+  const int m0 = slice * ga.wg_rows, mend = min(ga.wg_M, m0 + ga.wg_rows);          // (weight-gradient mode)
+  float* const Cout = g.C + (WG ? (size_t)slice * g.M * g.N : 0);
 
 #ifdef GM3_STAMPS
   long long st_[6] = {0, 0, 0, 0, 0, 0};
@@ -168,12 +179,45 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
   };
   if constexpr (TM >= 2) load_y(G3Int<0>{});          // (64-row tiles: 32 more registers would cost the third workgroup per CU)
 
-  SA sa; sa.init(g.A, g.lda, row0, g.M, g.K, tid);
+  SA sa; sa.init(g.A, g.lda, row0, g.M, WG ? 4 : g.K, tid);
   // A: DA staging sets — the loads of tile kt + DA are issued at the top of tile kt (HBM latency); B: one set (L2 hits: re-issued as soon as it is committed)
   constexpr int DA = BX3_DA(TM);
-  f32x4 ba[DA][SA::P]; u32x4 bb[3];
-  const unsigned char* bimg = g.B + (size_t)bn * nk * BX3_TILE_BYTES + tid * 16;
+  f32x4 ba[DA][WG ? 4 : SA::P]; u32x4 bb[3];          // (weight-gradient mode: a set is 8 values of G's column and 8 of X's)
+  // weight-gradient staging: thread -> (column tid % 128 of the tile, contraction half tid / 128)
+  const int scol = tid & 127, skg = tid >> 7;
+  const float* const wg_a = g.A + min(row0 + scol, g.M - 1);                              // G [rows][C]: output row = column of G
+  const float* const wg_b = WG ? g.Bf + min(col0 + scol, g.N - 1) : nullptr;              // X [rows][Kin]
+  auto issue_wg = [&](int kt, f32x4 (&w)[WG ? 4 : SA::P]) __attribute__((always_inline)) {
+    if constexpr (WG) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const size_t m = (size_t)gm_opaque(min(m0 + kt * BK + skg * 8 + j, ga.wg_M - 1));
+        w[j >> 2][j & 3] = wg_a[m * g.lda]; w[2 + (j >> 2)][j & 3] = wg_b[m * g.ldb];
+      }
+    }
+  };
+  auto commit_wg = [&](int stage, int kt, const f32x4 (&w)[WG ? 4 : SA::P]) __attribute__((always_inline)) {
+    if constexpr (WG) {
+      unsigned char* st = lds + stage * STAGE + scol * 32 + ((skg ^ ((scol >> 3) & 1)) << 4);
+      f32x4 a0 = w[0], a1 = w[1];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {          // rows beyond the slice contribute nothing: zero on G's side
+        a0[j] = m0 + kt * BK + skg * 8 + j < mend ? a0[j] : 0.f; a1[j] = m0 + kt * BK + skg * 8 + 4 + j < mend ? a1[j] : 0.f;
+      }
+      u32x2 h0, m0_, l0, h1, m1, l1;
+      bx3_split4(a0, h0, m0_, l0); bx3_split4(a1, h1, m1, l1);
+      *reinterpret_cast<u32x4*>(st) = u32x4{h0[0], h0[1], h1[0], h1[1]};
+      *reinterpret_cast<u32x4*>(st + AP) = u32x4{m0_[0], m0_[1], m1[0], m1[1]};
+      *reinterpret_cast<u32x4*>(st + 2 * AP) = u32x4{l0[0], l0[1], l1[0], l1[1]};
+      bx3_split4(w[2], h0, m0_, l0); bx3_split4(w[3], h1, m1, l1);
+      *reinterpret_cast<u32x4*>(st + BOFF) = u32x4{h0[0], h0[1], h1[0], h1[1]};
+      *reinterpret_cast<u32x4*>(st + BOFF + BP) = u32x4{m0_[0], m0_[1], m1[0], m1[1]};
+      *reinterpret_cast<u32x4*>(st + BOFF + 2 * BP) = u32x4{l0[0], l0[1], l1[0], l1[1]};
+    }
+  };
+  const unsigned char* bimg = WG ? nullptr : g.B + (size_t)bn * nk * BX3_TILE_BYTES + tid * 16;
   auto issue_b = [&](int kt) __attribute__((always_inline)) {
+    if constexpr (WG) return;
     const unsigned char* s = bimg + (size_t)kt * BX3_TILE_BYTES;
 #pragma unroll
     for (int p = 0; p < 3; ++p) bb[p] = *reinterpret_cast<const u32x4*>(s + p * 4096);
@@ -241,19 +285,19 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
   // One k-tile, held in stage CUR (= kt & 1).  MORE: tile kt + 1 follows.
   // A contraction that is not a multiple of 16 leaves a ragged last tile: the pipelined loop runs the nkp whole tiles, the ragged one is a pass of its own behind it
   // (its displaced quads are put right on the way to LDS: a branch in the loop's commit would keep the scheduler from placing the split between the MFMAs)
-  const bool ragged = (g.K & (BK - 1)) != 0;
+  const bool ragged = !WG && (g.K & (BK - 1)) != 0;
   const int nkp = ragged ? nk - 1 : nk;
   // (set indices are compile-time constants: a runtime index would put the staging arrays into scratch) tile kt's data sits in set kt % DA
   auto tile = [&](auto cur_c, auto set_c, const bool MORE, int kt) __attribute__((always_inline)) {
     constexpr int CUR = decltype(cur_c)::value, SET = decltype(set_c)::value;
     auto& a_ld = ba[SET]; auto& a_st = ba[(SET + 1) % DA];          // tile kt was committed during tile kt - 1: its set takes tile kt + DA; tile kt + 1 is committed now
     FR& fc = CUR ? f1 : f0; FR& fn = CUR ? f0 : f1;
-    { const int k2 = min(kt + DA, nkp - 1); sa.issue(k2 * BK, a_ld); }          // (past the last tile: a re-read that is never used — straight-line code)
+    { const int k2 = min(kt + DA, nkp - 1); if constexpr (WG) issue_wg(k2, a_ld); else sa.issue(k2 * BK, a_ld); }          // (past the last tile: a re-read that is never used — straight-line code)
     g3_wait_lgkm<0>();
     fc.opaque(); lo_opaque();
     mfmas(G3Int<0>{}, G3Int<3>{}, fc);
     if (MORE) {          // (workgroup-uniform)
-      commit(G3Int<0>{}, CUR ^ 1, kt + 1, a_st);
+      if constexpr (WG) commit_wg(CUR ^ 1, kt + 1, a_st); else commit(G3Int<0>{}, CUR ^ 1, kt + 1, a_st);
       issue_b(min(kt + 2, nkp - 1));
 #ifndef BX3_NO_SGB
       // the split's VALU work and the LDS stores between the MFMAs (a bf16 MFMA occupies the matrix pipe for 32 cycles: room for ~6 other issues)
@@ -276,8 +320,9 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
   constexpr G3Int<0> I0{}; constexpr G3Int<1> I1{};
   if (nkp > 0) {
     issue_b(0);
-    g3_for<0, DA>([&](auto d_c) __attribute__((always_inline)) { constexpr int D_ = decltype(d_c)::value; sa.issue(min(D_, nkp - 1) * BK, ba[D_]); });
-    commit(I0, 0, 0, ba[0]);
+    g3_for<0, DA>([&](auto d_c) __attribute__((always_inline)) { constexpr int D_ = decltype(d_c)::value;
+      if constexpr (WG) issue_wg(min(D_, nkp - 1), ba[D_]); else sa.issue(min(D_, nkp - 1) * BK, ba[D_]); });
+    if constexpr (WG) commit_wg(0, 0, ba[0]); else commit(I0, 0, 0, ba[0]);
     if (nkp > 1) issue_b(1);
     __syncthreads();
     read_frags(I0, f0);
@@ -287,7 +332,7 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
     for (int kt = 0; kt < nkp; kt += G)
       g3_for<0, G>([&](auto j_c) __attribute__((always_inline)) { constexpr int J = decltype(j_c)::value; if (kt + J < nkp) tile(G3Int<J & 1>{}, G3Int<J % DA>{}, kt + J + 1 < nkp, kt + J); });
   }
-  if (ragged) {
+  if constexpr (!WG) if (ragged) {
     __syncthreads();
     sa.issue((nk - 1) * BK, ba[0]); issue_b(nk - 1);
     commit(I1, 0, nk - 1, ba[0]);
@@ -328,7 +373,7 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
           if (row < g.M) { cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w; }
         }
         if (row < g.M) {
-          float* o = g.C + (size_t)row * g.ldc + col;
+          float* o = Cout + (size_t)row * g.ldc + col;
           if (cv) *reinterpret_cast<float4*>(o) = v;
           else { if (col < g.N) o[0] = v.x; if (col + 1 < g.N) o[1] = v.y; if (col + 2 < g.N) o[2] = v.z; if (col + 3 < g.N) o[3] = v.w; }
         }

@@ -380,7 +380,7 @@ class _FusedPair(torch.autograd.Function):
             gb[j] = tot[Cn * K:(Cn + 1) * K]
         for l in range(H - 1, -1, -1):          # gz[j]: gradient at layer l's pre-activation; gb[j]: its column sums
             shp = [ws[j][l].shape for j in range(2)]
-            wj = (Go2nnBwdWJob * 2)(*[Go2nnBwdWJob(p(gz[j]), p(acts[j][l]), None, B, shp[j][0], shp[j][1]) for j in range(2)])
+            wj = (Go2nnBwdWJob * 2)(*[Go2nnBwdWJob(p(gz[j]), p(acts[j][l]), None, B, shp[j][0], shp[j][1], 1 if ctx.imgs is not None else 0) for j in range(2)])
             rows = _NN.go2nn_linear_backward_weight_group_rows(wj, 2)
             if rows <= 0:
                 raise RuntimeError("go2nn_linear_backward_weight_group_rows: %s" % _NN.go2nn_last_error().decode())
@@ -496,7 +496,7 @@ def ppo_pair_grads(ac, xa, xc, actions, old_values, adv, returns, old_logp, old_
         gb = [gb_a, gb_c]
         for l in range(H - 1, -1, -1):
             shp = [ws[j][l].shape for j in range(2)]
-            wj = (Go2nnBwdWJob * 2)(*[Go2nnBwdWJob(p(gz[j]), p(acts[j][l]), None, B, shp[j][0], shp[j][1]) for j in range(2)])
+            wj = (Go2nnBwdWJob * 2)(*[Go2nnBwdWJob(p(gz[j]), p(acts[j][l]), None, B, shp[j][0], shp[j][1], 1 if imgs is not None else 0) for j in range(2)])
             r = _NN.go2nn_linear_backward_weight_group_rows(wj, 2)
             if r <= 0:
                 raise RuntimeError("go2nn_linear_backward_weight_group_rows: %s" % _NN.go2nn_last_error().decode())
