@@ -632,19 +632,22 @@ static int wgrad3_group_shape(const Go2nnBwdWJob* jobs, int njobs, int* ta, int*
   if (!jobs || njobs < 1 || njobs > GO2NN_MAX_GROUP) return 0;
   *tn = 4; *ta = 2;
   bool split = true; int t128 = 0;
+  int kin_sum = 0, kin_pad = 0;
   for (int j = 0; j < njobs; ++j) {
     if (!lin_check(jobs[j].M, jobs[j].C, jobs[j].Kin) || jobs[j].M != jobs[0].M || jobs[j].C < 2 || jobs[j].Kin < 4) return 0;
     if (jobs[j].Kin % 128) *tn = 2;
-    if (!jobs[j].split || jobs[j].C % 128 || jobs[j].Kin % 128) split = false;
-    t128 += (jobs[j].C / 128) * (jobs[j].Kin / 128);
+    if (!jobs[j].split || jobs[j].C % 128) split = false;
+    t128 += (jobs[j].C / 128) * cdiv(jobs[j].Kin, 128); kin_sum += jobs[j].Kin; kin_pad += cdiv(jobs[j].Kin, 128) * 128;
   }
 #ifndef GO2_EMU
-  // split-operand weight gradient (go2nn_bx3_kernel<2, EPI_STORE, true>; *ta = 9 stands for it): asked for by every job, whole 128 x 128 tiles, and enough of them
-  // that a slice is long (the 256 -> 128 layer's 4 tiles would be 128 slices of 12 k-tiles each, and as many partial tiles to sum)
+  // split-operand weight gradient (go2nn_bx3_kernel<2, EPI_STORE, true>; *ta = 9 stands for it): asked for by every job, C in whole 128-row tiles, Kin padded to 128-column
+  // tiles by at most a factor 2 (measured: dW [512, 45 | 263] 97 -> 87 us although 40 % of its MFMAs are padding; [512, 45 | 48] 40 -> 49 us), and enough tiles that a
+  // slice is long (the 256 -> 128 layer's 4 tiles would be 128 slices of 12 k-tiles each, and as many partial tiles to sum: no gain measured)
+  if (kin_pad > 2 * kin_sum) split = false;
   static const bool no_wg_split = getenv("GO2NN_WG_SPLIT") && atoi(getenv("GO2NN_WG_SPLIT")) == 0;          // tools only (A/B)
   if (split && t128 >= 8 && !no_wg_split) {
     *ta = 9;
-    for (int j = 0; j < njobs; ++j) tiles_of[j] = (jobs[j].C / 128) * (jobs[j].Kin / 128);
+    for (int j = 0; j < njobs; ++j) tiles_of[j] = (jobs[j].C / 128) * cdiv(jobs[j].Kin, 128);
     wgrad3_shape(jobs[0].M, t128, nsplit, rows);
     *rows = (*rows + BX3_BK - 1) / BX3_BK * BX3_BK;
     return t128;
@@ -793,7 +796,7 @@ int go2nn_linear_backward_weight_group(const Go2nnBwdWJob* jobs, int32_t njobs, 
     for (int j = 0; j < njobs; ++j) {
       Bx3Prob& g = b.p[j]; const Go2nnBwdWJob& q = jobs[j];
       g.A = q.gz; g.lda = q.C; g.Bf = q.x; g.ldb = q.Kin; g.C = q.workspace; g.ldc = q.Kin; g.M = q.C; g.N = q.Kin; g.K = rows;
-      g.nbm = q.C / 128; g.nbn = q.Kin / 128; g.c_vec = aligned16(q.workspace);
+      g.nbm = q.C / 128; g.nbn = cdiv(q.Kin, 128); g.c_vec = aligned16(q.workspace) && (q.Kin % 4 == 0);
     }
     b.ntiles0 = tiles_of[0]; b.ntiles = tiles; b.wg_M = jobs[0].M; b.wg_rows = rows;
     hipLaunchKernelGGL((go2nn_bx3_kernel<2, EPI_STORE, true>), dim3(tiles * nsplit), dim3(256), 0, (hipStream_t)stream, b);
