@@ -18,7 +18,7 @@ timeout 120 python tools/kscale.py 1024 4096 8192 32768 > $O/kscale.txt 2>&1
 timeout 100 python tools/policy_bench.py 4096 > $O/policy_bench.txt 2>&1
 hipcc -O2 -std=c++17 tools/gemm3_bench.cpp -o /tmp/gemm3_bench -ldl 2>/dev/null
 { echo "# tools/gemm3_bench.cpp on one MI355X, 24576 rows per network: the grouped learner products checked against a float64 host reference and timed (HIP events, warm)";
-  echo "## split operands (3 x bf16 planes, six MFMA terms; ABI 4) — forward / input gradient; the weight gradients are the fp32-MFMA kernel in both runs";
+  echo "## split operands (3 x bf16 planes, six MFMA terms; ABI 4) — forward, input gradient and the weight gradients of the wide layers (the 256 -> 128 layer and narrow input layers stay on the fp32-MFMA kernel)";
   BX3=1 timeout 300 /tmp/gemm3_bench go2_rl_gym_amd/libgo2nn_hip.so 24576 all;
   echo "## fp32 MFMA (ABI 3)"; timeout 300 /tmp/gemm3_bench go2_rl_gym_amd/libgo2nn_hip.so 24576 all; } > $O/gemm_split_bench.txt 2>&1
 export GEMM3_BENCH=/tmp/gemm3_bench
