@@ -28,9 +28,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef BX3_DA
 #define BX3_DA(TM) ((TM) == 1 ? 4 : 2)          /* staging sets of the A operand (tiles of lookahead) */
 #endif
-#ifndef BX3_SGB_VALU
-#define BX3_SGB_VALU 5
-#endif
+#define BX3_SGB_VALU 5          /* VALU issues the scheduler is asked to place behind each MFMA of a tile's first phase */
 #define BX3_TILE_BYTES 12288          /* one 128-row x 16-k weight tile: 3 planes x 128 rows x 32 B */
 
 #ifdef GO2_EMU
@@ -299,7 +297,6 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
     if (MORE) {          // (workgroup-uniform)
       if constexpr (WG) commit_wg(CUR ^ 1, kt + 1, a_st); else commit(G3Int<0>{}, CUR ^ 1, kt + 1, a_st);
       issue_b(min(kt + 2, nkp - 1));
-#ifndef BX3_NO_SGB
       // the split's VALU work and the LDS stores between the MFMAs (a bf16 MFMA occupies the matrix pipe for 32 cycles: room for ~6 other issues)
 #pragma unroll
       for (int q = 0; q < 6 * TM; ++q) {
@@ -308,7 +305,6 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
         __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         if (q < 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
-#endif
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
       read_frags(G3Int<CUR ^ 1>{}, fn);
