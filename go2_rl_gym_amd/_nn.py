@@ -15,7 +15,7 @@ _cached = None
 
 
 class Go2nnSumJob(C.Structure):
-    _fields_ = [("part", C.c_void_p), ("out", C.c_void_p), ("nrows", C.c_int32), ("ncols", C.c_int32)]
+    _fields_ = [("part", C.c_void_p), ("out", C.c_void_p), ("nrows", C.c_int32), ("ncols", C.c_int32), ("acc", C.c_void_p), ("nacc", C.c_int32), ("pad_", C.c_int32)]
 
 
 class Go2nnFwdJob(C.Structure):

@@ -412,12 +412,13 @@ int go2nn_sum_rows(const Go2nnSumJob* jobs, int32_t njobs, void* stream) {
     float s = 0.f;
     for (int r = 0; r < jobs[j].nrows; ++r) s += jobs[j].part[(int64_t)r * jobs[j].ncols + c];
     jobs[j].out[c] = s;
+    if (jobs[j].acc && c < jobs[j].nacc) jobs[j].acc[c] += s;
   }
 #else
   SumRowsArgs a; memset(&a, 0, sizeof(a));
   a.njobs = njobs; a.first_block[0] = 0;
   for (int j = 0; j < njobs; ++j) {
-    a.part[j] = jobs[j].part; a.out[j] = jobs[j].out; a.nrows[j] = jobs[j].nrows; a.ncols[j] = jobs[j].ncols;
+    a.part[j] = jobs[j].part; a.out[j] = jobs[j].out; a.nrows[j] = jobs[j].nrows; a.ncols[j] = jobs[j].ncols; a.acc[j] = jobs[j].acc; a.nacc[j] = jobs[j].acc ? jobs[j].nacc : 0;
     a.first_block[j + 1] = a.first_block[j] + (jobs[j].nrows <= 32 ? (jobs[j].ncols + 255) / 256 : (jobs[j].ncols + 15) / 16);
   }
   hipLaunchKernelGGL(go2nn_sum_rows_kernel, dim3(a.first_block[njobs]), dim3(256), 0, (hipStream_t)stream, a);

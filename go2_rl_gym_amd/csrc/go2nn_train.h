@@ -99,8 +99,8 @@ __global__ void __launch_bounds__(HB_THREADS) go2nn_head_bwd_kernel(const float*
 // column, 256 columns per block).
 #define SR_MAX_JOBS 16
 struct SumRowsArgs {
-  const float* part[SR_MAX_JOBS]; float* out[SR_MAX_JOBS];
-  int nrows[SR_MAX_JOBS], ncols[SR_MAX_JOBS], first_block[SR_MAX_JOBS + 1];      // blocks [first_block[j], first_block[j+1]) belong to job j
+  const float* part[SR_MAX_JOBS]; float* out[SR_MAX_JOBS]; float* acc[SR_MAX_JOBS];
+  int nrows[SR_MAX_JOBS], ncols[SR_MAX_JOBS], nacc[SR_MAX_JOBS], first_block[SR_MAX_JOBS + 1];      // blocks [first_block[j], first_block[j+1]) belong to job j
   int njobs;
 };
 __global__ void __launch_bounds__(256) go2nn_sum_rows_kernel(const SumRowsArgs a) {
@@ -121,6 +121,7 @@ __global__ void __launch_bounds__(256) go2nn_sum_rows_kernel(const SumRowsArgs a
         for (int u = 0; u < 8; ++u) if (r0 + u < nrows) s += v[u];
       }
       out[c] = s;
+      if (a.acc[j] && c < a.nacc[j]) a.acc[j][c] += s;          // (one thread per column: no race)
     }
     return;
   }
@@ -144,6 +145,7 @@ __global__ void __launch_bounds__(256) go2nn_sum_rows_kernel(const SumRowsArgs a
 #pragma unroll
       for (int i = 0; i < wd; ++i) t[i] += t[i + wd];
     out[c] = t[0];
+    if (a.acc[j] && c < a.nacc[j]) a.acc[j][c] += t[0];
   }
 }
 #endif  // !GO2_EMU

@@ -431,8 +431,7 @@ class PPO(_RolloutHeads):
             ac = self.actor_critic
             self.optimizer.zero_grad(set_to_none=True)
             stats = fused.ppo_pair_grads(ac, batch[0], batch[1], batch[2], batch[3], batch[4], batch[5], batch[6], batch[7], batch[8], self.clip_param, self.value_loss_coef,
-                                         self.entropy_coef, self.use_clipped_value_loss)
-            self._acc.add_(stats[:2])
+                                         self.entropy_coef, self.use_clipped_value_loss, acc=self._acc)          # (the running loss sums: added by the pass's go2nn_sum_rows launch)
             kl_mean = stats[2]
         elif self.fused_loss:
             # the loss kernel already holds d loss / d (mu, std, value): seed the backward pass of the two networks with them directly

@@ -450,9 +450,10 @@ def ppo_pair_applicable(ac, xa, xc):
             and all(p.requires_grad for m in la + lc for p in (m.weight, m.bias)) and ac.std.requires_grad)
 
 
-def ppo_pair_grads(ac, xa, xc, actions, old_values, adv, returns, old_logp, old_mu, old_sigma, clip, vcoef, ecoef, use_clipped_value_loss):
+def ppo_pair_grads(ac, xa, xc, actions, old_values, adv, returns, old_logp, old_mu, old_sigma, clip, vcoef, ecoef, use_clipped_value_loss, acc=None):
     """One PPO mini-batch gradient (ppo.py:131-170 + loss.backward()) of a plain ActorCritic as explicit launches: grouped hidden layers forward, go2nn_ppo_heads,
     grouped hidden layers backward, ONE go2nn_sum_rows; every parameter's .grad is set (replaced, as after zero_grad(set_to_none=True)).
+    acc: optional float32[>= 2] device tensor — the mini-batch's surrogate and value loss are ADDED to acc[0:2] by the same go2nn_sum_rows launch (the update's running sums).
     -> stats [surrogate, value loss, KL, entropy] (means, device tensor)"""
     from ..._nn import Go2nnBwdInJob, Go2nnBwdWJob, Go2nnFwdJob, Go2nnPpoHeads, Go2nnSumJob
     la, lc = _whole_mlp(list(ac.actor)), _whole_mlp(list(ac.critic))
@@ -487,7 +488,7 @@ def ppo_pair_grads(ac, xa, xc, actions, old_values, adv, returns, old_logp, old_
         h = Go2nnPpoHeads(p(acts[0][H]), p(acts[1][H]), p(ws[0][H]), p(bs[0][H]), p(ws[1][H]), p(bs[1][H]), p(keep[7]), p(keep[0]), p(keep[1]), p(keep[2]), p(keep[3]), p(keep[4]),
                           p(keep[5]), p(keep[6]), p(gz[0]), p(gz[1]), p(part), B, A, K, int(bool(use_clipped_value_loss)), float(clip), float(vcoef), float(ecoef))
         _check(_NN.go2nn_ppo_heads(C.byref(h), stream), "go2nn_ppo_heads", _NN)
-        sums = [(part, tot, rows, cols)]
+        sums = [(part, tot, rows, cols, acc)]
         o = 4 + A
         ac.std.grad = tot[4:o].view_as(ac.std)
         ws[0][H].grad, gb_a, bs[0][H].grad = tot[o:o + A * K].view(A, K), tot[o + A * K:o + (A + 1) * K], tot[o + (A + 1) * K:o + (A + 1) * K + A]
@@ -519,6 +520,7 @@ def ppo_pair_grads(ac, xa, xc, actions, old_values, adv, returns, old_logp, old_
                 gz = gzp
         for k in range(0, len(sums), 16):
             chunk = sums[k:k + 16]
-            arr = (Go2nnSumJob * len(chunk))(*[Go2nnSumJob(t[0].data_ptr(), t[1].data_ptr(), t[2], t[3]) for t in chunk])
+            arr = (Go2nnSumJob * len(chunk))(*[Go2nnSumJob(t[0].data_ptr(), t[1].data_ptr(), t[2], t[3], t[4].data_ptr() if len(t) > 4 and t[4] is not None else None,
+                                                             2 if len(t) > 4 and t[4] is not None else 0, 0) for t in chunk])
             _check(_NN.go2nn_sum_rows(arr, len(chunk), stream), "go2nn_sum_rows", _NN)
     return tot[:4]

@@ -67,7 +67,7 @@ int go2nn_policy_act(const Go2nnMlp* actor, const float* actor_packed, const Go2
  * go2nn_head_backward (sums == NULL) and go2nn_linear_backward_input (gb_prev == NULL) then leave their per-workgroup partial rows in `workspace` —
  * go2nn_*_rows rows of (C + 1) K + C resp. Kin columns — and the caller finishes all of a backward pass's reductions (and the row splits of its
  * weight gradients) with one go2nn_sum_rows call, off the chain of dependent GEMMs. */
-typedef struct Go2nnSumJob { const float* part; float* out; int32_t nrows, ncols; } Go2nnSumJob;
+typedef struct Go2nnSumJob { const float* part; float* out; int32_t nrows, ncols; float* acc; int32_t nacc, pad_; } Go2nnSumJob;      /* ABI 4: acc != NULL: acc[c] += out[c] for c < nacc (a running sum over launches, e.g. the update's mean losses) */
 int go2nn_sum_rows(const Go2nnSumJob* jobs, int32_t njobs, void* stream);
 int32_t go2nn_head_backward_rows(int32_t B, int32_t C, int32_t K);
 int32_t go2nn_linear_backward_input_rows(int32_t M, int32_t C, int32_t Kin);

@@ -175,6 +175,15 @@ def check_sum_rows(lib, device="cpu"):
     for p, o, (r, c) in zip(parts, outs, shapes):
         np.testing.assert_allclose(o.cpu().double().numpy(), p.double().sum(0).cpu().numpy(), atol=3e-6 * np.sqrt(r) * 4, rtol=1e-6)
     assert lib.go2nn_sum_rows(arr, 17, None) < 0 and lib.go2nn_sum_rows(None, 1, None) < 0
+    # ABI 4: a job may ADD its first nacc column sums to a running vector (PPO.update's loss sums over the mini-batches): two launches add twice
+    accs = [torch.full((5,), 10.0, device=device), torch.full((3,), -1.0, device=device)]
+    arr2 = (Go2nnSumJob * 2)(Go2nnSumJob(parts[1].data_ptr(), outs[1].data_ptr(), shapes[1][0], shapes[1][1], accs[0].data_ptr(), 5, 0),
+                             Go2nnSumJob(parts[5].data_ptr(), outs[5].data_ptr(), shapes[5][0], shapes[5][1], accs[1].data_ptr(), 2, 0))
+    for _ in range(2):
+        assert lib.go2nn_sum_rows(arr2, 2, _stream(parts[0])) == 0, lib.go2nn_last_error().decode()
+    np.testing.assert_allclose(accs[0].cpu().double().numpy(), 10.0 + 2 * parts[1].double().sum(0)[:5].cpu().numpy(), atol=2e-4)
+    np.testing.assert_allclose(accs[1].cpu().double().numpy()[:2], -1.0 + 2 * parts[5].double().sum(0)[:2].cpu().numpy(), atol=2e-4)
+    assert float(accs[1][2]) == -1.0          # beyond nacc: untouched
     return outs
 
 
