@@ -81,7 +81,7 @@ def test_ppo_update_golden_on_gpu(monkeypatch, mode):
         alg.compute_returns(cobs[T])
 
     if mode == "graphs":
-        for _ in range(2):          # slot 0 is captured at its 4th call, slot 1 at its 2nd: two warm-up updates, then everything replays
+        for _ in range(2):          # the first epoch of the first update runs eagerly, the second is captured: after two updates everything replays
             rollout(False)
             alg.update()
         torch.cuda.synchronize()
