@@ -115,7 +115,6 @@ template <int TM> struct Bx3Frags {
 // 16 bytes per plane as one fragment chunk; the k-loop, the fragments and the MFMAs are the same.  Output tile = 128 rows of C x 128 columns of Kin of slice `slice`.
 template <int TM, int EPI, bool WG = false>
 __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
-  static_assert(TM <= 2 || EPI != EPI_DELU_COLSUM, "the column sums are kept per 64 data rows");
   static_assert(!WG || (TM == 2 && EPI == EPI_STORE), "weight-gradient mode: 128 x 128 tiles, plain store");
   constexpr int BM = 64 * TM, BN = 128, BK = BX3_BK, TN = 2;
   constexpr int AP = BM * 32, BP = 4096, BOFF = 3 * AP, STAGE = 3 * AP + 3 * BP, LOOP_LDS = 2 * STAGE, EPI_LDS = 4 * 32 * 32 * TN * 4;
@@ -318,7 +317,7 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
     g3_for<0, DA>([&](auto d_c) __attribute__((always_inline)) { constexpr int D_ = decltype(d_c)::value;
       if constexpr (WG) issue_wg(min(D_, nkp - 1), ba[D_]); else sa.issue(min(D_, nkp - 1) * BK, ba[D_]); });
     // (BEHIND the first tiles' loads: vmcnt counts in order, in front of them the Y loads stood between the first tile and its commit — prologue 9.6 k instead of 4.9 k ticks)
-    if constexpr (TM >= 2) load_y(G3Int<0>{});          // (64-row tiles: 32 more registers would cost the third workgroup per CU)
+    if constexpr (TM == 2) load_y(G3Int<0>{});          // (64-row tiles: 32 more registers would cost the third workgroup per CU; 192-row tiles have none to spare)
     if constexpr (WG) commit_wg(0, 0, ba[0]); else commit(I0, 0, 0, ba[0]);
     if (nkp > 1) issue_b(1);
     __syncthreads();
@@ -344,10 +343,12 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
   G3_T(3);
 
   // epilogue: go2nn_gemm3_kernel's (every wave turns its tile, 32 rows at a time, through its LDS quarter; 16-byte row accesses)
-  g3_for<(TM >= 2 ? 1 : 0), TM>([&](auto a_c) __attribute__((always_inline)) { load_y(a_c); });
+  g3_for<(TM == 2 ? 1 : 0), TM>([&](auto a_c) __attribute__((always_inline)) { load_y(a_c); });
   {
     float* wl = reinterpret_cast<float*>(lds) + wave * (32 * CT);
-    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 cs[EPI == EPI_DELU_COLSUM ? TM : 1];          // column sums of the wave's 32-row tiles, one each
+#pragma unroll
+    for (int a = 0; a < (EPI == EPI_DELU_COLSUM ? TM : 1); ++a) cs[a] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
       const int rbase = row0 + wm * 32 * TM + a * 32 + lr;
@@ -367,7 +368,7 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
         if (EPI == EPI_DELU_COLSUM) {
           const float4 y = y4[EPI == EPI_DELU_COLSUM ? a : 0][EPI == EPI_DELU_COLSUM ? n : 0];
           v.x *= y.x > 0.f ? 1.f : y.x + 1.f; v.y *= y.y > 0.f ? 1.f : y.y + 1.f; v.z *= y.z > 0.f ? 1.f : y.z + 1.f; v.w *= y.w > 0.f ? 1.f : y.w + 1.f;
-          if (row < g.M) { cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w; }
+          if (row < g.M) { float4& c4 = cs[EPI == EPI_DELU_COLSUM ? a : 0]; c4.x += v.x; c4.y += v.y; c4.z += v.z; c4.w += v.w; }
         }
         if (row < g.M) {
           float* o = Cout + (size_t)row * g.ldc + col;
@@ -377,15 +378,23 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
       }
     }
     if (EPI == EPI_DELU_COLSUM) {
+      // one partial row per 64 data rows whatever the tile height (the caller's row count, go2nn_linear_backward_input_group_rows, does not depend on the kernel): the
+      // workgroup's 2 TM row tiles of 32 (wave wm, tile a -> wm TM + a) are summed in pairs
+      __syncthreads();
+      float* shs = reinterpret_cast<float*>(lds);                     // [2 TM][BN]
 #pragma unroll
-      for (int d = LPR; d < 64; d <<= 1) { cs.x += __shfl_xor(cs.x, d); cs.y += __shfl_xor(cs.y, d); cs.z += __shfl_xor(cs.z, d); cs.w += __shfl_xor(cs.w, d); }
+      for (int a = 0; a < TM; ++a) {
+        float4 c4 = cs[EPI == EPI_DELU_COLSUM ? a : 0];
+#pragma unroll
+        for (int d = LPR; d < 64; d <<= 1) { c4.x += __shfl_xor(c4.x, d); c4.y += __shfl_xor(c4.y, d); c4.z += __shfl_xor(c4.z, d); c4.w += __shfl_xor(c4.w, d); }
+        if (lane < LPR) *reinterpret_cast<float4*>(shs + (wm * TM + a) * BN + wn * CT + lc) = c4;
+      }
       __syncthreads();
-      float* shs = reinterpret_cast<float*>(lds);                     // [2][BN]
-      if (lane < LPR) *reinterpret_cast<float4*>(shs + wm * BN + wn * CT + lc) = cs;
-      __syncthreads();
-      // one partial row per 64 data rows whatever the tile height (the caller's row count, go2nn_linear_backward_input_group_rows, does not depend on the kernel)
-      if (TM == 1) { if (tid < BN && col0 + tid < g.N) g.part[(size_t)bm * g.N + col0 + tid] = shs[tid] + shs[BN + tid]; }
-      else { const int h = tid / BN, c = tid % BN; if (col0 + c < g.N && (bm * 2 + h) * 64 < g.M) g.part[(size_t)(bm * 2 + h) * g.N + col0 + c] = shs[h * BN + c]; }
+      if (tid < BN && col0 + tid < g.N) {
+#pragma unroll
+        for (int q = 0; q < TM; ++q)
+          if ((bm * TM + q) * 64 < g.M) g.part[(size_t)(bm * TM + q) * g.N + col0 + tid] = shs[(2 * q) * BN + tid] + shs[(2 * q + 1) * BN + tid];
+      }
     }
   }
 #ifdef GM3_STAMPS
