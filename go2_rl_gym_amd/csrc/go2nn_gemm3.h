@@ -499,10 +499,12 @@ static inline void gemm3_tile(int N, int* tm, int* tn, int* bk) {
   *tm = 1;
   *bk = 32;
 }
-// row slices of the grouped weight gradient: ~512 workgroups over all tiles of the group, a multiple of 8 slices (one XCD per slice class),
-// at least 64 rows per slice
+// row slices of the grouped weight gradient: ~512 workgroups over all tiles of the group (~256 when the group has 8 tiles or fewer: the 256 -> 128 layer's kernel takes
+// the same 33 us with 32 slices as with 64, and the slices' partial tiles are what go2nn_sum_rows has to read — 41 -> 38 us with the sum), a multiple of 8 slices
+// (one XCD per slice class), at least 64 rows per slice
 static inline void wgrad3_shape(int M, int tiles, int* nsplit, int* rows_per_slice) {
-  static const int target = getenv("GO2NN_WG3_WGS") ? atoi(getenv("GO2NN_WG3_WGS")) : 512;      // tools only (read once)
+  static const int env_target = getenv("GO2NN_WG3_WGS") ? atoi(getenv("GO2NN_WG3_WGS")) : 0;      // tools only (read once)
+  const int target = env_target ? env_target : (tiles <= 8 ? 256 : 512);
   int s = (target / (tiles > 0 ? tiles : 1) + 7) / 8 * 8;
   if (s < 8) s = 8;
   while (s > 8 && (M + s - 1) / s < 64) s -= 8;
