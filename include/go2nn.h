@@ -113,7 +113,8 @@ int go2nn_linear_backward_weight_group(const Go2nnBwdWJob* jobs, int32_t njobs, 
 /* ---- ABI 4: the same three products on the bf16 matrix pipe WITHOUT giving up fp32 operands.  Every fp32 value is split exactly into three bf16 planes
  * (8 + 8 + 8 significand bits) and a product is six bf16 MFMA terms accumulated in fp32 — the three terms left out are below 2^-23 of the product, i.e. below
  * the rounding of an fp32 multiply; against float64 the results are as close as the fp32-MFMA kernels' (tools/gemm3_bench.cpp, tests/test_gpu_mlp_tail.py hold both
- * to the same tolerances).  v_mfma_f32_32x32x16_bf16 moves 16 k per 32 cycles, v_mfma_f32_32x32x2_f32 2 k per 64: six terms cost 3/8 of the fp32 form.
+ * to the same tolerances; rms error 0.8 - 1.2 x).  One measurable difference: the bf16 pipe's accumulation is not round-to-nearest-even, every output carries a bias of
+ * about a third of an fp32 ulp towards -inf, which a column sum over 24576 rows turns into ~1.5e-6 of the sum (fp32 kernels: ~4e-7).  v_mfma_f32_32x32x16_bf16 moves 16 k per 32 cycles, v_mfma_f32_32x32x2_f32 2 k per 64: six terms cost 3/8 of the fp32 form.
  *   go2nn_split_weights   a layer's weight [N,K] -> its split image for both orientations (forward: rows n; input gradient: rows k), `go2nn_split_weights_bytes`
  *                         bytes in a caller-owned buffer; run once after every optimizer step (one launch for up to 8 layers)
  *   Go2nnFwdJob.w_split / Go2nnBwdInJob.w_split   that image: non-NULL selects the split-operand kernel for the group (every job of a group alike)

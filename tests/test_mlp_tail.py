@@ -222,7 +222,7 @@ def test_whole_mlp_node_edge_cases():
 GROUP_SHAPES = [(70, (45, 96), (263, 96)), (130, (37, 70), (64, 70)), (65, (130, 33), (8, 33)), (96, (64, 40), (64, 72))]      # M, (K, N) of job 0, of job 1
 
 
-def check_linear_group(lib, M, s0, s1, device="cpu", split=False):
+def check_linear_group(lib, M, s0, s1, device="cpu", split=False, with_refs=False):
     """forward, input gradient and weight gradient of two layers as ONE grouped call each, against float64 torch (same bounds as check_linear).
     split: the ABI 4 split-operand kernels (3 x bf16 planes per fp32 value, six MFMA terms) — held to the SAME bounds as the fp32-MFMA kernels."""
     from go2_rl_gym_amd._nn import Go2nnBwdInJob, Go2nnBwdWJob, Go2nnFwdJob, Go2nnSplitJob, Go2nnSumJob
@@ -266,7 +266,7 @@ def check_linear_group(lib, M, s0, s1, device="cpu", split=False):
     assert lib.go2nn_linear_backward_weight_group(wj, 2, st) == 0, lib.go2nn_last_error().decode()
     arr = (Go2nnSumJob * len(sums))(*[Go2nnSumJob(t[0].data_ptr(), t[1].data_ptr(), t[2], t[3]) for t in sums])
     assert lib.go2nn_sum_rows(arr, len(sums), st) == 0
-    out = []
+    out, refs = [], []
     for j in jobs:
         K, N, x, w, b, gz, yp = (j[k] for k in ("K", "N", "x", "w", "b", "gz", "yp"))
         ref = torch.nn.functional.elu(x.double().mm(w.double().t()) + b.double())
@@ -276,7 +276,8 @@ def check_linear_group(lib, M, s0, s1, device="cpu", split=False):
         np.testing.assert_allclose(j["gbp"].cpu().double().numpy(), r_gzp.sum(0).cpu().numpy(), atol=4e-6 * np.sqrt(M * N) + 1e-5, rtol=2e-5)
         np.testing.assert_allclose(j["dw"].cpu().double().numpy(), gz.double().t().mm(yp.double()).cpu().numpy(), atol=4e-6 * np.sqrt(M) + 1e-5, rtol=2e-5)
         out += [j["y"], j["gzp"], j["gbp"], j["dw"]]
-    return out
+        refs += [ref, r_gzp, r_gzp.sum(0), gz.double().t().mm(yp.double())]
+    return (out, refs) if with_refs else out
 
 
 @pytest.mark.parametrize("M,s0,s1", GROUP_SHAPES)
