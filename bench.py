@@ -17,7 +17,6 @@ import ctypes as C
 import json
 import os
 import sys
-import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
