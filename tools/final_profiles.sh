@@ -25,6 +25,7 @@ export GEMM3_BENCH=/tmp/gemm3_bench
 BX3=1 bash tools/gemm3_pmc.sh bx3_fwd_L2 f 2 10 > /dev/null 2>&1
 BX3=1 bash tools/gemm3_pmc.sh bx3_igrad_L2 i 2 10 > /dev/null 2>&1
 bash tools/gemm3_pmc.sh f32_wgrad_L2 w 2 10 > /dev/null 2>&1
+BX3=1 bash tools/gemm3_pmc.sh bx3_wgrad_L2 w 2 10 > /dev/null 2>&1
 bash tools/pmc_pass.sh 4096 100 go2_flat > $O/pmc_flat.log 2>&1
 bash tools/pmc_pass.sh 4096 100 go2 > $O/pmc_go2.log 2>&1
 bash tools/sq_pass.sh 4096 60 go2_flat > $O/sq_flat.log 2>&1
