@@ -53,10 +53,17 @@ def build_hip_kbench(force=False):
     return build_hip(force=force, out=KBENCH_OUT, flags=EXTRA_FLAGS + ["-DGO2_KBENCH_STAMPS"])
 
 
+def stale(out, deps=None):
+    """True when `out` is missing or older than any source it is built from — every file of csrc/ and include/ for both libraries: a header added to
+    one of them can never be forgotten in a hand-kept list (round 4's go2nn_bx3.h was)."""
+    deps = _deps() if deps is None else deps
+    return not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(p) for p in deps)
+
+
 def build_hip(force=False, verbose=False, out=OUT, flags=None):
     OUT, EXTRA_FLAGS = out, (globals()["EXTRA_FLAGS"] if flags is None else flags)
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= max(os.path.getmtime(p) for p in _deps()):
+    if not force and not stale(OUT):
         return OUT
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + EXTRA_FLAGS + ["-o", OUT, SRC]
     if verbose:
@@ -77,9 +84,7 @@ def build_nn(force=False):
     """The policy-side MFMA kernels (include/go2nn.h) -> go2_rl_gym_amd/libgo2nn_hip.so.  A library of its own, so that the sha256 that keys the
     step kernel's counter profiles to libgo2sim_hip.so does not move when this one changes.  No -ffast-math (the head's log-probability and
     ELU follow the eager formulation's arithmetic)."""
-    deps = [NN_SRC, os.path.join(HERE, "csrc", "go2nn_train.h"), os.path.join(HERE, "csrc", "go2nn_gemm.h"), os.path.join(HERE, "csrc", "go2nn_gemm3.h"),
-            os.path.join(ROOT, "include", "go2nn.h")]
-    if not force and os.path.exists(NN_OUT) and os.path.getmtime(NN_OUT) >= max(os.path.getmtime(p) for p in deps):
+    if not force and not stale(NN_OUT):
         return NN_OUT
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-cuid=go2nn", "-o", NN_OUT, NN_SRC]
     r = subprocess.run(cmd, capture_output=True, text=True)

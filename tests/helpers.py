@@ -487,8 +487,8 @@ def load_nn_emu():
     from go2_rl_gym_amd import _nn
     out = os.path.join(ROOT, "tests", "emu", "libgo2nn_emu.so")
     src = os.path.join(ROOT, "go2_rl_gym_amd", "csrc", "go2nn_impl.cpp")
-    deps = [src, os.path.join(ROOT, "go2_rl_gym_amd", "csrc", "go2nn_train.h"), os.path.join(ROOT, "go2_rl_gym_amd", "csrc", "go2nn_gemm.h"), os.path.join(ROOT, "include", "go2nn.h")]
-    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
+    from go2_rl_gym_amd import build as _b
+    if _b.stale(out):          # (every file of csrc/ and include/)
         os.makedirs(os.path.dirname(out), exist_ok=True)
         subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-DGO2_EMU", "-w", "-o", out, src], check=True)
     lib = _nn.bind(out)
