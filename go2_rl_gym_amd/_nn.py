@@ -10,7 +10,7 @@ import torch.nn as nn
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 NN_LIB = os.path.join(_HERE, "libgo2nn_hip.so")
-GO2NN_MAX_LAYERS, GO2NN_MAX_WIDTH, GO2NN_ABI_VERSION, GO2NN_MAX_GROUP = 6, 512, 4, 2
+GO2NN_MAX_LAYERS, GO2NN_MAX_WIDTH, GO2NN_ABI_VERSION, GO2NN_MAX_GROUP = 6, 512, 5, 2
 _cached = None
 
 
@@ -19,13 +19,13 @@ class Go2nnSumJob(C.Structure):
 
 
 class Go2nnFwdJob(C.Structure):
-    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("b", C.c_void_p), ("y", C.c_void_p), ("M", C.c_int32), ("K", C.c_int32), ("N", C.c_int32), ("pad_", C.c_int32),
-                ("w_split", C.c_void_p)]          # ABI 4: the weight's split image (go2nn_split_weights) selects the 3 x bf16 kernel; None = fp32 MFMA
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("b", C.c_void_p), ("y", C.c_void_p), ("M", C.c_int32), ("K", C.c_int32), ("N", C.c_int32), ("act", C.c_int32),
+                ("w_split", C.c_void_p)]          # ABI 4: the weight's split image (go2nn_split_weights) selects the 3 x bf16 kernel; None = fp32 MFMA.  ABI 5: act 1 = no activation
 
 
 class Go2nnBwdInJob(C.Structure):
     _fields_ = [("gz", C.c_void_p), ("w", C.c_void_p), ("y_prev", C.c_void_p), ("gz_prev", C.c_void_p), ("workspace", C.c_void_p),
-                ("M", C.c_int32), ("C", C.c_int32), ("Kin", C.c_int32), ("pad_", C.c_int32), ("w_split", C.c_void_p)]
+                ("M", C.c_int32), ("C", C.c_int32), ("Kin", C.c_int32), ("plain", C.c_int32), ("w_split", C.c_void_p)]          # ABI 5: plain 1 = gz W only
 
 
 class Go2nnBwdWJob(C.Structure):
@@ -39,7 +39,7 @@ class Go2nnSplitJob(C.Structure):
 class Go2nnPpoHeads(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("y_a", "y_c", "w_mu", "b_mu", "w_v", "b_v", "std", "actions", "old_mu", "old_sigma", "old_logp", "adv", "old_values", "returns",
                                           "gz_a", "gz_c", "partials")] + [(k, C.c_int32) for k in ("B", "A", "K", "use_clipped_value_loss")] + \
-               [(k, C.c_float) for k in ("clip", "value_loss_coef", "entropy_coef")]
+               [(k, C.c_float) for k in ("clip", "value_loss_coef", "entropy_coef")] + [("surrogate_split", C.c_int32)]          # ABI 5: CTS' teacher rows (0: plain PPO)
 
 
 class Go2nnMlp(C.Structure):
@@ -77,6 +77,10 @@ def bind(path):
     lib.go2nn_ppo_heads_rows.argtypes = [C.c_int32] * 3
     lib.go2nn_ppo_heads_cols.argtypes = [C.c_int32] * 2
     lib.go2nn_ppo_heads.argtypes = [C.POINTER(Go2nnPpoHeads), C.c_void_p]
+    lib.go2nn_l2norm_backward_rows.argtypes = [C.c_int32]
+    lib.go2nn_latent_concat.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.go2nn_l2norm_backward.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    lib.go2nn_latent_mse.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]
     if lib.go2nn_abi_version() != GO2NN_ABI_VERSION:
         raise RuntimeError("%s: ABI version %d, expected %d" % (path, lib.go2nn_abi_version(), GO2NN_ABI_VERSION))
     return lib

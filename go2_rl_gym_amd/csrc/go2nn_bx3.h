@@ -45,7 +45,7 @@ struct Bx3Prob {
 };
 struct Bx3Args { Bx3Prob p[2]; int ntiles0, ntiles; long long* stamps; int wg_M, wg_rows; };          // wg_*: the mini-batch's rows and the rows of one slice (weight-gradient mode)
 struct Bx3SplitJob { const float* w; unsigned char* img; int N, K; };          // img: forward image, then the transposed one
-struct Bx3SplitArgs { Bx3SplitJob j[8]; int njobs; };
+struct Bx3SplitArgs { Bx3SplitJob j[GO2NN_MAX_SPLIT_JOBS]; int njobs; };
 
 #ifndef GO2_EMU
 __device__ __forceinline__ unsigned bx3_pk(float a, float b) { f32x2 v = {a, b}; return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
   const int col = col0 + wn * CT + lc;
   const bool cv = g.c_vec != 0 && col + 3 < g.N;
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (EPI == EPI_BIAS_ELU) {
+  if (EPI == EPI_BIAS_ELU || EPI == EPI_BIAS) {
     const int c1 = min(col, g.N - 1), c2 = min(col + 1, g.N - 1), c3 = min(col + 2, g.N - 1), c4 = min(col + 3, g.N - 1);
     bias4 = make_float4(g.bias[c1], g.bias[c2], g.bias[c3], g.bias[c4]);
   }
@@ -365,6 +365,7 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
         const int lrow = lr + n * RPI, row = rbase + n * RPI;
         float4 v = *reinterpret_cast<const float4*>(wl + lrow * CT + (lc ^ ((lrow >> 2 & 1) << 5 & (CT - 1))));
         if (EPI == EPI_BIAS_ELU) v = make_float4(elu1(v.x + bias4.x), elu1(v.y + bias4.y), elu1(v.z + bias4.z), elu1(v.w + bias4.w));
+        if (EPI == EPI_BIAS) v = make_float4(v.x + bias4.x, v.y + bias4.y, v.z + bias4.z, v.w + bias4.w);
         if (EPI == EPI_DELU_COLSUM) {
           const float4 y = y4[EPI == EPI_DELU_COLSUM ? a : 0][EPI == EPI_DELU_COLSUM ? n : 0];
           v.x *= y.x > 0.f ? 1.f : y.x + 1.f; v.y *= y.y > 0.f ? 1.f : y.y + 1.f; v.z *= y.z > 0.f ? 1.f : y.z + 1.f; v.w *= y.w > 0.f ? 1.f : y.w + 1.f;

@@ -1,0 +1,94 @@
+// go2nn_cts.h — the row-wise pieces of the Concurrent Teacher-Student networks around the grouped GEMMs (included by go2nn_impl.cpp; include/go2nn.h ABI 5).
+//
+// CTS (rsl_rl/rsl_rl/modules/actor_critic_cts.py:49-80,146-176; rsl_rl/rsl_rl/algorithms/cts.py:167-285) puts a 32-wide L2-normalised latent in front of the actor and
+// the critic: latent = F.normalize(encoder(x)) (modules/utils.py:24-30), actor input = cat([latent, obs]), critic input = cat([latent.detach(), privileged obs]).  In
+// autograd that is a norm reduction, a clamp, a division, two cats and their backward nodes per mini-batch — 15-20 small launches on [B, 32] tensors.  Here:
+//   go2nn_latent_concat_kernel   z -> zhat written straight into the first L columns of the two input matrices (+ 1 / |z| kept for the backward pass)
+//   go2nn_l2norm_bwd_kernel      dz = (g - zhat (zhat . g)) / |z| from the first L columns of the actor's plain input gradient, + column partial sums (bias gradient)
+//   go2nn_latent_mse_kernel      the student step's loss head: both normalisations, the MSE, its gradient through the student's normalisation, column partial sums
+// A row is LP = L / 4 lanes (a float4 each; LP a power of two up to 32: L = 4 .. 128), row sums by an xor butterfly inside the LP-lane group; per-workgroup partial rows
+// are formed in a fixed order (row lanes through LDS) and finished by go2nn_sum_rows: bit-reproducible.
+#pragma once
+
+#define CTS_EPS 1e-12f           /* F.normalize's eps */
+#define CTS_ROWS_PER_WG 512      /* rows of one workgroup of the two backward kernels (one partial row each) */
+static inline int cts_ok(int n, int L) { return n > 0 && L >= 4 && L <= 128 && (L & 3) == 0 && ((L >> 2) & ((L >> 2) - 1)) == 0; }
+static inline int cts_rows(int n) { return (n + CTS_ROWS_PER_WG - 1) / CTS_ROWS_PER_WG; }
+
+#ifndef GO2_EMU
+__device__ __forceinline__ float cts_group_sum(float v, int LP) {
+  for (int d = 1; d < LP; d <<= 1) v += __shfl_xor(v, d);
+  return v;
+}
+__device__ __forceinline__ float4 cts_ld4(const float* p, bool vec) {
+  if (vec) return *reinterpret_cast<const float4*>(p);
+  const GmF4u v = *reinterpret_cast<const GmF4u*>(p); return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void cts_st4(float* p, const float4& v, bool vec) {
+  if (vec) *reinterpret_cast<float4*>(p) = v;
+  else { GmF4u u = {v.x, v.y, v.z, v.w}; *reinterpret_cast<GmF4u*>(p) = u; }
+}
+
+__global__ void __launch_bounds__(256) go2nn_latent_concat_kernel(const float* __restrict__ z, int n, int L, float* __restrict__ da, int lda, float* __restrict__ db, int ldb,
+                                                                  float* __restrict__ inv_norm) {
+  const int LP = L >> 2, rpw = 256 / LP, c = (threadIdx.x % LP) * 4;
+  const int r = blockIdx.x * rpw + threadIdx.x / LP;
+  const int rc = min(r, n - 1);
+  const float4 v = *reinterpret_cast<const float4*>(z + (size_t)rc * L + c);
+  const float ss = cts_group_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w, LP);
+  const float inv = 1.f / fmaxf(sqrtf(ss), CTS_EPS);
+  if (r >= n) return;
+  const float4 o = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+  // (a destination row starts at a multiple of its pitch: 16-byte stores only when the pitch keeps rows aligned)
+  if (da) cts_st4(da + (size_t)r * lda + c, o, (lda & 3) == 0 && ((uintptr_t)da & 15) == 0);
+  if (db) cts_st4(db + (size_t)r * ldb + c, o, (ldb & 3) == 0 && ((uintptr_t)db & 15) == 0);
+  if (inv_norm && c == 0) inv_norm[r] = inv;
+}
+
+// One workgroup = CTS_ROWS_PER_WG rows; thread = (column quad, row lane); the row lanes' column sums are combined through LDS in row-lane order.
+template <bool MSE>
+__global__ void __launch_bounds__(256) go2nn_cts_bwd_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ zh, int ldz, const float* __restrict__ inv_norm,
+                                                            const float* __restrict__ zs, const float* __restrict__ zt, float* __restrict__ dz, float* __restrict__ part,
+                                                            int n, int L, float scale) {
+  __shared__ float4 sh[256];
+  __shared__ float shl[256];
+  const int LP = L >> 2, RL = 256 / LP, cq = threadIdx.x % LP, rl = threadIdx.x / LP, c = cq * 4;
+  const int r0 = blockIdx.x * CTS_ROWS_PER_WG, r1 = min(n, r0 + CTS_ROWS_PER_WG);
+  const bool gvec = MSE || ((ldg & 3) == 0 && ((uintptr_t)g & 15) == 0), zvec = MSE || ((ldz & 3) == 0 && ((uintptr_t)zh & 15) == 0);
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+  float loss = 0.f;
+  for (int rb = r0; rb < r1; rb += RL) {          // (uniform trip count: the butterflies need every lane of a row group)
+    const int r = rb + rl, rc = min(r, r1 - 1);
+    const bool live = r < r1;
+    float4 gv, zv; float inv;
+    if (MSE) {
+      const float4 s = *reinterpret_cast<const float4*>(zs + (size_t)rc * L + c), t = *reinterpret_cast<const float4*>(zt + (size_t)rc * L + c);
+      const float is = 1.f / fmaxf(sqrtf(cts_group_sum(s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w, LP)), CTS_EPS);
+      const float it = 1.f / fmaxf(sqrtf(cts_group_sum(t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w, LP)), CTS_EPS);
+      zv = make_float4(s.x * is, s.y * is, s.z * is, s.w * is);
+      const float4 d = make_float4(t.x * it - zv.x, t.y * it - zv.y, t.z * it - zv.z, t.w * it - zv.w);          // that - shat
+      if (live) loss += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+      gv = make_float4(-scale * d.x, -scale * d.y, -scale * d.z, -scale * d.w);                                   // d loss / d shat = 2 (shat - that) / (n L) (scale = 2 / (n L) x the caller's factor)
+      inv = is;
+    } else {
+      gv = cts_ld4(g + (size_t)rc * ldg + c, gvec); zv = cts_ld4(zh + (size_t)rc * ldz + c, zvec); inv = inv_norm[rc];
+    }
+    const float dot = cts_group_sum(gv.x * zv.x + gv.y * zv.y + gv.z * zv.z + gv.w * zv.w, LP);
+    const float4 o = make_float4((gv.x - zv.x * dot) * inv, (gv.y - zv.y * dot) * inv, (gv.z - zv.z * dot) * inv, (gv.w - zv.w * dot) * inv);
+    if (live) { *reinterpret_cast<float4*>(dz + (size_t)r * L + c) = o; cs.x += o.x; cs.y += o.y; cs.z += o.z; cs.w += o.w; }
+  }
+  sh[threadIdx.x] = cs; if (MSE) shl[threadIdx.x] = loss;
+  __syncthreads();
+  float* prow = part + (size_t)blockIdx.x * (L + (MSE ? 4 : 0));          // MSE: [loss, 0, 0, 0 | column sums] (the sums stay 16-byte aligned behind the scalar)
+  if (rl == 0) {
+    float4 s = sh[cq];
+    for (int j = 1; j < RL; ++j) { const float4 t = sh[j * LP + cq]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+    float* o = prow + (MSE ? 4 : 0) + c; o[0] = s.x; o[1] = s.y; o[2] = s.z; o[3] = s.w;
+  }
+  if (MSE && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int j = 0; j < 256; ++j) s += shl[j];
+    prow[0] = s / ((float)n * (float)L); prow[1] = prow[2] = prow[3] = 0.f;
+  }
+}
+#endif  // !GO2_EMU

@@ -23,7 +23,7 @@
 
 #define GM_BK 32
 #define GM_THREADS 256
-enum { EPI_STORE = 0, EPI_BIAS_ELU = 1, EPI_DELU_COLSUM = 2 };
+enum { EPI_STORE = 0, EPI_BIAS_ELU = 1, EPI_DELU_COLSUM = 2, EPI_BIAS = 3 };          // EPI_BIAS: a Linear without activation (the encoders' last layer; grouped kernels only)
 
 struct GemmArgs {
   const float *A, *B; float* C;

@@ -145,11 +145,12 @@ struct G3Frags {
 
 // waves per SIMD the register allocation is held to (= workgroups per CU): 2 for the 128 x 128 tile (at 3 = 168 registers the compiler spills, and a spill of a
 // fragment register between its inline-asm ds_read and the wait stores a value that has not landed: measured wrong results), 3 for the 64 x 128 tile, 4 for 64 x 64
+// (round 5: the k-strided B operand's 64 x 128 tile — the fp32 input gradient, GO2_GEMM_SPLIT=0 — spilled 8 - 28 B per lane at 168 registers: held to 2 waves instead)
 #ifndef GM3_WAVES
-#define GM3_WAVES(TM, TN, BK) ((TM) * (TN) == 4 ? 2 : (TM) * (TN) == 2 ? 3 : 4)
+#define GM3_WAVES(TM, TN, BK, BKC) ((TM) * (TN) == 4 ? 2 : (TM) * (TN) == 2 ? ((BKC) ? 3 : 2) : 4)
 #endif
 template <int TM, int TN, bool BKC, int EPI, int BK>
-__global__ void __launch_bounds__(256, GM3_WAVES(TM, TN, BK)) go2nn_gemm3_kernel(const Gemm3Args ga) {
+__global__ void __launch_bounds__(256, GM3_WAVES(TM, TN, BK, BKC)) go2nn_gemm3_kernel(const Gemm3Args ga) {
   static_assert(BKC || TN <= 2, "the natural-orientation B fragments are 4- or 8-byte reads");
   constexpr int NTHR = 256, BM = 64 * TM, BN = 64 * TN, NKB = BK / 8;
   static_assert(NKB % 2 == 0, "the two fragment sets alternate per k-block");
@@ -287,7 +288,7 @@ __global__ void __launch_bounds__(256, GM3_WAVES(TM, TN, BK)) go2nn_gemm3_kernel
   constexpr int NI_EARLY = GM3_EARLY_DIV ? NI / GM3_EARLY_DIV : 0;          // (all NI rows early costs 32 more registers beside two staging sets: spills at 3 waves per SIMD)
   auto epi_prefetch = [&](auto n0_c, auto n1_c) __attribute__((always_inline)) {
     constexpr int N0 = decltype(n0_c)::value, N1 = decltype(n1_c)::value;
-    if (EPI == EPI_BIAS_ELU && N0 == 0) {
+    if ((EPI == EPI_BIAS_ELU || EPI == EPI_BIAS) && N0 == 0) {
       const int c1 = min(col, g.N - 1), c2 = min(col + 1, g.N - 1), c3 = min(col + 2, g.N - 1), c4 = min(col + 3, g.N - 1);
       bias4 = make_float4(g.bias[c1], g.bias[c2], g.bias[c3], g.bias[c4]);
     }
@@ -335,6 +336,7 @@ __global__ void __launch_bounds__(256, GM3_WAVES(TM, TN, BK)) go2nn_gemm3_kernel
         const int lrow = lr + n * RPI, row = rbase + n * RPI;
         float4 v = *reinterpret_cast<const float4*>(wl + lrow * CT + (lc ^ ((lrow >> 2 & 1) << 5 & (CT - 1))));
         if (EPI == EPI_BIAS_ELU) v = make_float4(elu1(v.x + bias4.x), elu1(v.y + bias4.y), elu1(v.z + bias4.z), elu1(v.w + bias4.w));
+        if (EPI == EPI_BIAS) v = make_float4(v.x + bias4.x, v.y + bias4.y, v.z + bias4.z, v.w + bias4.w);
         if (EPI == EPI_DELU_COLSUM) {
           const float4 y = y4[EPI == EPI_DELU_COLSUM ? a : 0][EPI == EPI_DELU_COLSUM ? n : 0];
           v.x *= y.x > 0.f ? 1.f : y.x + 1.f; v.y *= y.y > 0.f ? 1.f : y.y + 1.f; v.z *= y.z > 0.f ? 1.f : y.z + 1.f; v.w *= y.w > 0.f ? 1.f : y.w + 1.f;

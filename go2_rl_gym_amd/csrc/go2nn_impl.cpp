@@ -240,6 +240,7 @@ __global__ void __launch_bounds__(NN_THREADS) go2nn_mlp_kernel(const NNArgs a) {
 #include "go2nn_gemm.h"
 #include "go2nn_gemm3.h"
 #include "go2nn_bx3.h"
+#include "go2nn_cts.h"
 
 #ifdef GO2_EMU
 // host restatement: the SAME packed buffer, read in the operand order the kernel uses
@@ -404,7 +405,7 @@ int go2nn_policy_act(const Go2nnMlp* actor, const float* actor_packed, const Go2
 }
 
 int go2nn_sum_rows(const Go2nnSumJob* jobs, int32_t njobs, void* stream) {
-  if (!jobs || njobs <= 0 || njobs > 16) FAIL(GO2NN_EINVAL, "sum rows: 1..16 jobs");
+  if (!jobs || njobs <= 0 || njobs > GO2NN_MAX_SUM_JOBS) FAIL(GO2NN_EINVAL, "sum rows: 1..%d jobs", GO2NN_MAX_SUM_JOBS);
   for (int j = 0; j < njobs; ++j) if (!jobs[j].part || !jobs[j].out || jobs[j].nrows <= 0 || jobs[j].ncols <= 0) FAIL(GO2NN_EINVAL, "sum rows: bad job %d", j);
 #ifdef GO2_EMU
   (void)stream;
@@ -596,7 +597,7 @@ static int gemm3_launch(int tm, int tn, int bk, const Gemm3Args& a, hipStream_t 
 template <int EPI>
 static int bx3_launch(int tm, const Bx3Args& a, hipStream_t st) {
   const dim3 grid(a.ntiles), blk(256);
-  if (tm == 3) { if constexpr (EPI == EPI_BIAS_ELU) hipLaunchKernelGGL((go2nn_bx3_kernel<3, EPI>), grid, blk, 0, st, a); else FAIL(GO2NN_EINVAL, "bx3: no 192-row tile for this epilogue"); }
+  if (tm == 3) { if constexpr (EPI == EPI_BIAS_ELU || EPI == EPI_BIAS) hipLaunchKernelGGL((go2nn_bx3_kernel<3, EPI>), grid, blk, 0, st, a); else FAIL(GO2NN_EINVAL, "bx3: no 192-row tile for this epilogue"); }
   else if (tm == 2) hipLaunchKernelGGL((go2nn_bx3_kernel<2, EPI>), grid, blk, 0, st, a);
   else              hipLaunchKernelGGL((go2nn_bx3_kernel<1, EPI>), grid, blk, 0, st, a);
   HIPCHK(hipGetLastError());
@@ -668,7 +669,7 @@ int64_t go2nn_split_weights_bytes(int32_t N, int32_t K) {
 }
 
 int go2nn_split_weights(const Go2nnSplitJob* jobs, int32_t njobs, void* stream) {
-  if (!jobs || njobs < 1 || njobs > 8) FAIL(GO2NN_EINVAL, "split weights: 1..8 jobs");
+  if (!jobs || njobs < 1 || njobs > GO2NN_MAX_SPLIT_JOBS) FAIL(GO2NN_EINVAL, "split weights: 1..%d jobs", GO2NN_MAX_SPLIT_JOBS);
   for (int j = 0; j < njobs; ++j) if (!jobs[j].w || !jobs[j].image || jobs[j].N <= 0 || jobs[j].K <= 0 || jobs[j].N > 4096 || jobs[j].K > 4096 || ((uintptr_t)jobs[j].image & 15)) FAIL(GO2NN_EINVAL, "split weights: bad job %d", j);
 #ifdef GO2_EMU
   return 0;          // (the host build's products read the fp32 weights)
@@ -686,8 +687,19 @@ int go2nn_split_weights(const Go2nnSplitJob* jobs, int32_t njobs, void* stream) 
 int go2nn_linear_elu_forward_group(const Go2nnFwdJob* jobs, int32_t njobs, void* stream) {
   if (!jobs || njobs < 1 || njobs > GO2NN_MAX_GROUP) FAIL(GO2NN_EINVAL, "forward group: 1..%d jobs", GO2NN_MAX_GROUP);
   for (int j = 0; j < njobs; ++j) if (!jobs[j].x || !jobs[j].w || !jobs[j].b || !jobs[j].y || !lin_check(jobs[j].M, jobs[j].N, jobs[j].K)) FAIL(GO2NN_EINVAL, "forward group: bad job %d", j);
+  const int act = jobs[0].act;
+  if (act != 0 && act != 1) FAIL(GO2NN_EINVAL, "forward group: act 0 (ELU) or 1 (none)");
+  for (int j = 1; j < njobs; ++j) if (jobs[j].act != act) FAIL(GO2NN_EINVAL, "forward group: every job of a group carries the same activation flag");
 #ifdef GO2_EMU
-  for (int j = 0; j < njobs; ++j) { const int rc = go2nn_linear_elu_forward(jobs[j].x, jobs[j].w, jobs[j].b, jobs[j].y, jobs[j].M, jobs[j].K, jobs[j].N, stream); if (rc) return rc; }
+  for (int j = 0; j < njobs; ++j) {
+    if (!act) { const int rc = go2nn_linear_elu_forward(jobs[j].x, jobs[j].w, jobs[j].b, jobs[j].y, jobs[j].M, jobs[j].K, jobs[j].N, stream); if (rc) return rc; continue; }
+    const Go2nnFwdJob& q = jobs[j];
+    for (int m = 0; m < q.M; ++m) for (int n = 0; n < q.N; ++n) {
+      float acc = 0.f;
+      for (int k = 0; k < q.K; ++k) acc = fmaf(q.x[(int64_t)m * q.K + k], q.w[(int64_t)n * q.K + k], acc);
+      q.y[(int64_t)m * q.N + n] = acc + q.b[n];
+    }
+  }
   return 0;
 #else
   if (jobs[0].w_split && jobs[njobs - 1].w_split && jobs[0].K >= 4 && jobs[njobs - 1].K >= 4) {          // split-operand kernel (go2nn_bx3.h)
@@ -701,12 +713,13 @@ int go2nn_linear_elu_forward_group(const Go2nnFwdJob* jobs, int32_t njobs, void*
     }
     a.ntiles = njobs == 2 ? a.ntiles0 + a.ntiles : a.ntiles0;
     GM3_SET_STAMPS(a);
-    return bx3_launch<EPI_BIAS_ELU>(tm, a, (hipStream_t)stream);
+    return act ? bx3_launch<EPI_BIAS>(tm, a, (hipStream_t)stream) : bx3_launch<EPI_BIAS_ELU>(tm, a, (hipStream_t)stream);
   }
   int tm, tn, bk; gemm3_tile(jobs[0].N, &tm, &tn, &bk);
   if (njobs == 2) { int tm1, tn1, bk1; gemm3_tile(jobs[1].N, &tm1, &tn1, &bk1);
     if (tm1 != tm || tn1 != tn || bk1 != bk) { const int rc = go2nn_linear_elu_forward_group(jobs, 1, stream); return rc ? rc : go2nn_linear_elu_forward_group(jobs + 1, 1, stream); } }
   for (int j = 0; j < njobs; ++j) if (jobs[j].K < 4) {          // (the staging's clamped 16-byte loads need 4 floats per row) -> the single-network kernels
+    if (act) FAIL(GO2NN_EINVAL, "forward group: a layer without activation needs K >= 4");
     for (int i = 0; i < njobs; ++i) { const int rc = go2nn_linear_elu_forward(jobs[i].x, jobs[i].w, jobs[i].b, jobs[i].y, jobs[i].M, jobs[i].K, jobs[i].N, stream); if (rc) return rc; }
     return 0; }
   Gemm3Args a; memset(&a, 0, sizeof(a));
@@ -718,7 +731,7 @@ int go2nn_linear_elu_forward_group(const Go2nnFwdJob* jobs, int32_t njobs, void*
   }
   a.ntiles = njobs == 2 ? a.ntiles0 + a.ntiles : a.ntiles0;
   GM3_SET_STAMPS(a);
-  return gemm3_launch<true, EPI_BIAS_ELU>(tm, tn, bk, a, (hipStream_t)stream);
+  return act ? gemm3_launch<true, EPI_BIAS>(tm, tn, bk, a, (hipStream_t)stream) : gemm3_launch<true, EPI_BIAS_ELU>(tm, tn, bk, a, (hipStream_t)stream);
 #endif
 }
 
@@ -733,9 +746,19 @@ int32_t go2nn_linear_backward_input_group_rows(int32_t M, int32_t C, int32_t Kin
 
 int go2nn_linear_backward_input_group(const Go2nnBwdInJob* jobs, int32_t njobs, void* stream) {
   if (!jobs || njobs < 1 || njobs > GO2NN_MAX_GROUP) FAIL(GO2NN_EINVAL, "input-gradient group: 1..%d jobs", GO2NN_MAX_GROUP);
-  for (int j = 0; j < njobs; ++j) if (!jobs[j].gz || !jobs[j].w || !jobs[j].y_prev || !jobs[j].gz_prev || !jobs[j].workspace || !lin_check(jobs[j].M, jobs[j].C, jobs[j].Kin)) FAIL(GO2NN_EINVAL, "input-gradient group: bad job %d", j);
+  const int plain = jobs[0].plain;
+  if (plain != 0 && plain != 1) FAIL(GO2NN_EINVAL, "input-gradient group: plain 0 or 1");
+  for (int j = 0; j < njobs; ++j) if (jobs[j].plain != plain || !jobs[j].gz || !jobs[j].w || !jobs[j].gz_prev || (!plain && (!jobs[j].y_prev || !jobs[j].workspace)) || !lin_check(jobs[j].M, jobs[j].C, jobs[j].Kin)) FAIL(GO2NN_EINVAL, "input-gradient group: bad job %d", j);
 #ifdef GO2_EMU
-  for (int j = 0; j < njobs; ++j) { const int rc = go2nn_linear_backward_input(jobs[j].gz, jobs[j].w, jobs[j].y_prev, jobs[j].gz_prev, nullptr, jobs[j].workspace, jobs[j].M, jobs[j].C, jobs[j].Kin, stream); if (rc) return rc; }
+  for (int j = 0; j < njobs; ++j) {
+    if (!plain) { const int rc = go2nn_linear_backward_input(jobs[j].gz, jobs[j].w, jobs[j].y_prev, jobs[j].gz_prev, nullptr, jobs[j].workspace, jobs[j].M, jobs[j].C, jobs[j].Kin, stream); if (rc) return rc; continue; }
+    const Go2nnBwdInJob& q = jobs[j];
+    for (int m = 0; m < q.M; ++m) for (int k = 0; k < q.Kin; ++k) {
+      float acc = 0.f;
+      for (int c = 0; c < q.C; ++c) acc = fmaf(q.gz[(int64_t)m * q.C + c], q.w[(int64_t)c * q.Kin + k], acc);
+      q.gz_prev[(int64_t)m * q.Kin + k] = acc;
+    }
+  }
   return 0;
 #else
   if (jobs[0].w_split && jobs[njobs - 1].w_split && jobs[0].C >= 4 && jobs[njobs - 1].C >= 4) {          // split-operand kernel: A = gz [M,C], B = the transposed image (rows k, contraction c)
@@ -745,29 +768,30 @@ int go2nn_linear_backward_input_group(const Go2nnBwdInJob* jobs, int32_t njobs, 
       Bx3Prob& g = a.p[j]; const Go2nnBwdInJob& q = jobs[j];
       g.A = q.gz; g.B = (const unsigned char*)q.w_split + bx3_image_bytes(q.C, q.Kin); g.C = q.gz_prev; g.Y = q.y_prev; g.part = q.workspace;
       g.M = q.M; g.N = q.Kin; g.K = q.C; g.lda = q.C; g.ldc = q.Kin;
-      g.nbm = cdiv(q.M, 64 * tm); g.nbn = cdiv(q.Kin, 128); g.nkt = cdiv(q.C, BX3_BK); g.c_vec = (q.Kin % 4 == 0) && aligned16(q.gz_prev) && aligned16(q.y_prev);
+      g.nbm = cdiv(q.M, 64 * tm); g.nbn = cdiv(q.Kin, 128); g.nkt = cdiv(q.C, BX3_BK); g.c_vec = (q.Kin % 4 == 0) && aligned16(q.gz_prev) && (plain || aligned16(q.y_prev));
       (j ? a.ntiles : a.ntiles0) = g.nbm * g.nbn;
     }
     a.ntiles = njobs == 2 ? a.ntiles0 + a.ntiles : a.ntiles0;
     GM3_SET_STAMPS(a);
-    return bx3_launch<EPI_DELU_COLSUM>(tm, a, (hipStream_t)stream);
+    return plain ? bx3_launch<EPI_STORE>(tm, a, (hipStream_t)stream) : bx3_launch<EPI_DELU_COLSUM>(tm, a, (hipStream_t)stream);
   }
   int tm, tn, bk; gemm3_tile(jobs[0].Kin, &tm, &tn, &bk);
   if (njobs == 2) { int tm1, tn1, bk1; gemm3_tile(jobs[1].Kin, &tm1, &tn1, &bk1);
     if (tm1 != tm || tn1 != tn || bk1 != bk) { const int rc = go2nn_linear_backward_input_group(jobs, 1, stream); return rc ? rc : go2nn_linear_backward_input_group(jobs + 1, 1, stream); } }
   for (int j = 0; j < njobs; ++j) if (jobs[j].C < 4 || jobs[j].Kin < 4 || jobs[j].Kin % 4) {          // (column quads of W must not straddle Kin) -> the single-network kernels
+    if (plain) FAIL(GO2NN_EINVAL, "plain input gradient on the fp32-MFMA kernels: C >= 4 and Kin a multiple of 4 (the split-operand kernel takes any Kin)");
     for (int i = 0; i < njobs; ++i) { const int rc = go2nn_linear_backward_input(jobs[i].gz, jobs[i].w, jobs[i].y_prev, jobs[i].gz_prev, nullptr, jobs[i].workspace, jobs[i].M, jobs[i].C, jobs[i].Kin, stream); if (rc) return rc; }
     return 0; }
   Gemm3Args a; memset(&a, 0, sizeof(a));
   for (int j = 0; j < njobs; ++j) {
     Gemm3Prob& g = a.p[j]; const Go2nnBwdInJob& q = jobs[j];
     g.A = q.gz; g.B = q.w; g.C = q.gz_prev; g.Y = q.y_prev; g.part = q.workspace; g.M = q.M; g.N = q.Kin; g.K = q.C; g.lda = q.C; g.ldb = q.Kin; g.ldc = q.Kin;
-    g.nbm = cdiv(q.M, 64 * tm); g.nbn = cdiv(q.Kin, 64 * tn); g.c_vec = (q.Kin % 4 == 0) && aligned16(q.gz_prev) && aligned16(q.y_prev);
+    g.nbm = cdiv(q.M, 64 * tm); g.nbn = cdiv(q.Kin, 64 * tn); g.c_vec = (q.Kin % 4 == 0) && aligned16(q.gz_prev) && (plain || aligned16(q.y_prev));
     (j ? a.ntiles : a.ntiles0) = g.nbm * g.nbn;
   }
   a.ntiles = njobs == 2 ? a.ntiles0 + a.ntiles : a.ntiles0;
   GM3_SET_STAMPS(a);
-  return gemm3_launch<false, EPI_DELU_COLSUM>(tm, tn, bk, a, (hipStream_t)stream);
+  return plain ? gemm3_launch<false, EPI_STORE>(tm, tn, bk, a, (hipStream_t)stream) : gemm3_launch<false, EPI_DELU_COLSUM>(tm, tn, bk, a, (hipStream_t)stream);
 #endif
 }
 
@@ -843,6 +867,8 @@ int go2nn_ppo_heads(const Go2nnPpoHeads* h, void* stream) {
 #ifdef GO2_EMU
   (void)stream;
   const float LOG2PI = 1.8378770664093453f, invB = 1.f / (float)B, lo = 1.f - h->clip, hi = 1.f + h->clip;
+  const int split = (h->surrogate_split > 0 && h->surrogate_split < B) ? h->surrogate_split : 0;
+  const float w_head = split ? 1.f / (float)split : invB, w_tail = split ? 1.f / (float)(B - split) : invB;
   float* S = h->partials; const int nc = ppo_heads_cols(A, K);
   for (int i = 0; i < nc; ++i) S[i] = 0.f;
   float* pa = S + PH_NSTAT + A; float* pc = pa + (size_t)(A + 1) * K + A;
@@ -858,7 +884,7 @@ int go2nn_ppo_heads(const Go2nnPpoHeads* h, void* stream) {
       lp += -d * d * (0.5f * isg2) - logf(sg) - 0.5f * LOG2PI; kl += logf(sg / so + 1e-5f) + (so * so + dm * dm) * (0.5f * isg2) - 0.5f;
     }
     const float ad = h->adv[r], ratio = expf(lp - h->old_logp[r]), rc = fminf(fmaxf(ratio, lo), hi), in = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
-    const float s1 = -ad * ratio, s2 = -ad * rc, sur = fmaxf(s1, s2), w = s1 > s2 ? 1.f : (s1 < s2 ? in : 0.5f + 0.5f * in), g_lp = -ad * w * ratio * invB;
+    const float s1 = -ad * ratio, s2 = -ad * rc, sur = fmaxf(s1, s2), w = s1 > s2 ? 1.f : (s1 < s2 ? in : 0.5f + 0.5f * in), wr = (!split || r < split) ? w_head : w_tail, g_lp = -ad * w * ratio * wr;
     const float tv = h->old_values[r], rt = h->returns[r], dv = v - tv;
     float vl, gv;
     if (h->use_clipped_value_loss) {
@@ -867,7 +893,7 @@ int go2nn_ppo_heads(const Go2nnPpoHeads* h, void* stream) {
       const float g1 = 2.f * (v - rt), g2 = 2.f * (vc - rt) * vin; gv = l1 > l2 ? g1 : (l1 < l2 ? g2 : 0.5f * g1 + 0.5f * g2);
     } else { vl = (rt - v) * (rt - v); gv = 2.f * (v - rt); }
     const float gval = h->value_loss_coef * gv * invB;
-    S[0] += sur * invB; S[1] += vl * invB; S[2] += kl * invB;
+    S[0] += sur * wr; S[1] += vl * invB; S[2] += kl * invB;
     float gm[HB_MAX_C];
     for (int c = 0; c < A; ++c) { const float sg = h->std[c], d = h->actions[(size_t)r * A + c] - mu[c], isg2 = 1.f / (sg * sg);
       gm[c] = g_lp * d * isg2; S[PH_NSTAT + c] += g_lp * (d * d * isg2 / sg - 1.f / sg); pa[(size_t)(A + 1) * K + c] += gm[c]; }
@@ -883,12 +909,86 @@ int go2nn_ppo_heads(const Go2nnPpoHeads* h, void* stream) {
   a.y_a = h->y_a; a.y_c = h->y_c; a.w_mu = h->w_mu; a.b_mu = h->b_mu; a.w_v = h->w_v; a.b_v = h->b_v; a.std_ = h->std; a.actions = h->actions; a.old_mu = h->old_mu;
   a.old_sigma = h->old_sigma; a.old_logp = h->old_logp; a.adv = h->adv; a.old_values = h->old_values; a.returns = h->returns; a.gz_a = h->gz_a; a.gz_c = h->gz_c; a.part = h->partials;
   a.B = B; a.A = A; a.K = K; a.use_clip_v = h->use_clipped_value_loss; a.clip = h->clip; a.vcoef = h->value_loss_coef; a.ecoef = h->entropy_coef;
+  a.split = (h->surrogate_split > 0 && h->surrogate_split < B) ? h->surrogate_split : B;
+  a.w_head = a.split < B ? 1.f / (float)a.split : 1.f / (float)B; a.w_tail = a.split < B ? 1.f / (float)(B - a.split) : 1.f / (float)B;
   int q, rows, nwg; ppo_heads_shape(B, K, &q, &rows, &nwg);
   hipStream_t st = (hipStream_t)stream;
   if (A <= 4)       hipLaunchKernelGGL(go2nn_ppo_heads_kernel<4>,  dim3(nwg), dim3(256), 0, st, a, q, rows);
   else if (A <= 8)  hipLaunchKernelGGL(go2nn_ppo_heads_kernel<8>,  dim3(nwg), dim3(256), 0, st, a, q, rows);
   else if (A <= 12) hipLaunchKernelGGL(go2nn_ppo_heads_kernel<12>, dim3(nwg), dim3(256), 0, st, a, q, rows);
   else              hipLaunchKernelGGL(go2nn_ppo_heads_kernel<16>, dim3(nwg), dim3(256), 0, st, a, q, rows);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+}  // extern "C"
+
+// ---- ABI 5: the latent normaliser of the CTS networks (go2nn_cts.h) ---------------------------------------------------------------------------------------
+extern "C" {
+
+int32_t go2nn_l2norm_backward_rows(int32_t n) {
+  if (n <= 0) FAIL(GO2NN_EINVAL, "l2norm backward: n > 0");
+#ifdef GO2_EMU
+  return 1;
+#else
+  return cts_rows(n);
+#endif
+}
+
+int go2nn_latent_concat(const float* z, int32_t n, int32_t L, float* dst_a, int32_t lda, float* dst_b, int32_t ldb, float* inv_norm, void* stream) {
+  if (!z || !cts_ok(n, L) || (!dst_a && !dst_b) || (dst_a && lda < L) || (dst_b && ldb < L)) FAIL(GO2NN_EINVAL, "latent concat: L a multiple of 4 with L / 4 a power of two up to 32, pitches >= L");
+#ifdef GO2_EMU
+  (void)stream;
+  for (int r = 0; r < n; ++r) {
+    float ss = 0.f;
+    for (int c = 0; c < L; ++c) ss += z[(size_t)r * L + c] * z[(size_t)r * L + c];
+    const float inv = 1.f / fmaxf(sqrtf(ss), CTS_EPS);
+    for (int c = 0; c < L; ++c) { const float o = z[(size_t)r * L + c] * inv; if (dst_a) dst_a[(size_t)r * lda + c] = o; if (dst_b) dst_b[(size_t)r * ldb + c] = o; }
+    if (inv_norm) inv_norm[r] = inv;
+  }
+#else
+  const int rpw = 256 / (L >> 2);
+  hipLaunchKernelGGL(go2nn_latent_concat_kernel, dim3(cdiv(n, rpw)), dim3(256), 0, (hipStream_t)stream, z, n, L, dst_a, lda, dst_b, ldb, inv_norm);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+int go2nn_l2norm_backward(const float* g, int32_t ldg, const float* zhat, int32_t ldz, const float* inv_norm, float* dz, float* partials, int32_t n, int32_t L, void* stream) {
+  if (!g || !zhat || !inv_norm || !dz || !partials || !cts_ok(n, L) || ldg < L || ldz < L) FAIL(GO2NN_EINVAL, "l2norm backward: bad argument");
+#ifdef GO2_EMU
+  (void)stream;
+  for (int c = 0; c < L; ++c) partials[c] = 0.f;
+  for (int r = 0; r < n; ++r) {
+    float dot = 0.f;
+    for (int c = 0; c < L; ++c) dot += g[(size_t)r * ldg + c] * zhat[(size_t)r * ldz + c];
+    for (int c = 0; c < L; ++c) { const float o = (g[(size_t)r * ldg + c] - zhat[(size_t)r * ldz + c] * dot) * inv_norm[r]; dz[(size_t)r * L + c] = o; partials[c] += o; }
+  }
+#else
+  hipLaunchKernelGGL(go2nn_cts_bwd_kernel<false>, dim3(cts_rows(n)), dim3(256), 0, (hipStream_t)stream, g, ldg, zhat, ldz, inv_norm, (const float*)nullptr, (const float*)nullptr, dz, partials, n, L, 0.f);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+int go2nn_latent_mse(const float* z_s, const float* z_t, float* dz_s, float* partials, int32_t n, int32_t L, float grad_scale, void* stream) {
+  if (!z_s || !z_t || !dz_s || !partials || !cts_ok(n, L)) FAIL(GO2NN_EINVAL, "latent mse: bad argument");
+  const float scale = grad_scale * 2.f / ((float)n * (float)L);
+#ifdef GO2_EMU
+  (void)stream;
+  for (int c = 0; c < L + 4; ++c) partials[c] = 0.f;
+  float loss = 0.f;
+  for (int r = 0; r < n; ++r) {
+    float ss = 0.f, st = 0.f, dot = 0.f, gv[128], zv[128];
+    for (int c = 0; c < L; ++c) { ss += z_s[(size_t)r * L + c] * z_s[(size_t)r * L + c]; st += z_t[(size_t)r * L + c] * z_t[(size_t)r * L + c]; }
+    const float is = 1.f / fmaxf(sqrtf(ss), CTS_EPS), it = 1.f / fmaxf(sqrtf(st), CTS_EPS);
+    for (int c = 0; c < L; ++c) { zv[c] = z_s[(size_t)r * L + c] * is; const float d = z_t[(size_t)r * L + c] * it - zv[c]; loss += d * d; gv[c] = -scale * d; dot += gv[c] * zv[c]; }
+    for (int c = 0; c < L; ++c) { const float o = (gv[c] - zv[c] * dot) * is; dz_s[(size_t)r * L + c] = o; partials[4 + c] += o; }
+  }
+  partials[0] = loss / ((float)n * (float)L);
+#else
+  hipLaunchKernelGGL(go2nn_cts_bwd_kernel<true>, dim3(cts_rows(n)), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, 0, (const float*)nullptr, 0, (const float*)nullptr, z_s, z_t, dz_s, partials, n, L, scale);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(HB_THREADS) go2nn_head_bwd_kernel(const float*
 // deterministic reduction of a backward pass — per-workgroup column partials of the head and of the input gradients, the row splits of the weight
 // gradients.  Two block shapes: "tall" (many rows, few columns: 16 columns x 16 row groups, LDS tree) and "wide" (<= 32 rows: one thread per
 // column, 256 columns per block).
-#define SR_MAX_JOBS 16
+#define SR_MAX_JOBS GO2NN_MAX_SUM_JOBS
 struct SumRowsArgs {
   const float* part[SR_MAX_JOBS]; float* out[SR_MAX_JOBS]; float* acc[SR_MAX_JOBS];
   int nrows[SR_MAX_JOBS], ncols[SR_MAX_JOBS], nacc[SR_MAX_JOBS], first_block[SR_MAX_JOBS + 1];      // blocks [first_block[j], first_block[j+1]) belong to job j
@@ -164,6 +164,7 @@ struct PpoHeadsArgs {
   const float *y_a, *y_c, *w_mu, *b_mu, *w_v, *b_v, *std_, *actions, *old_mu, *old_sigma, *old_logp, *adv, *old_values, *returns;
   float *gz_a, *gz_c, *part;
   int B, A, K, use_clip_v; float clip, vcoef, ecoef;
+  int split; float w_head, w_tail;          // the surrogate's row weights: rows [0, split) w_head, the rest w_tail (plain PPO: split = B, both 1 / B; CTS: 1 / teacher rows, 1 / student rows)
 };
 #ifdef GO2_EMU
 #define PH_HD
@@ -175,7 +176,7 @@ PH_HD static inline int ppo_heads_cols(int A, int K) { return PH_NSTAT + A + (A 
 // what a lane loads for one row: its four columns of both activations, the row's scalars, and the action-dimension values of the lane's ROLE (see below)
 struct PhRow { float4 ya, yc; float act, omu, osg, olp, ad, tv, rt; };
 template <int CP>
-__global__ void __launch_bounds__(256, 2) go2nn_ppo_heads_kernel(const PpoHeadsArgs a, int qp_log2, int rows_per_wg) {
+__global__ void __launch_bounds__(256, CP > 12 ? 1 : 2) go2nn_ppo_heads_kernel(const PpoHeadsArgs a, int qp_log2, int rows_per_wg) {          // (13 - 16 actions: 256 registers spilled 36 B per lane)
   static_assert(CP <= 16, "16 value slots in the reduce-scatter");
   __shared__ float4 sh[256];
   __shared__ float shs[256 / 16][PH_NSTAT + 2 * HB_MAX_C + 1];
@@ -245,7 +246,8 @@ __global__ void __launch_bounds__(256, 2) go2nn_ppo_heads_kernel(const PpoHeadsA
     const float ratio = expf(lp - x.olp), rcl = fminf(fmaxf(ratio, lo), hi), in = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
     const float s1 = -x.ad * ratio, s2 = -x.ad * rcl, sur = fmaxf(s1, s2);
     const float w = s1 > s2 ? 1.f : (s1 < s2 ? in : 0.5f + 0.5f * in);          // torch.max splits ties evenly; clamp passes gradient inside [lo, hi]
-    const float g_lp = live ? -x.ad * w * ratio * invB : 0.f;
+    const float wr = rb + rl < a.split ? a.w_head : a.w_tail;
+    const float g_lp = live ? -x.ad * w * ratio * wr : 0.f;
     const float dv = v - x.tv;
     float vl, gv;
     if (a.use_clip_v) {
@@ -254,7 +256,7 @@ __global__ void __launch_bounds__(256, 2) go2nn_ppo_heads_kernel(const PpoHeadsA
       const float g1 = 2.f * (v - x.rt), g2 = 2.f * (vc - x.rt) * vin; gv = l1 > l2 ? g1 : (l1 < l2 ? g2 : 0.5f * g1 + 0.5f * g2);
     } else { vl = (x.rt - v) * (x.rt - v); gv = 2.f * (v - x.rt); }
     const float gval = live ? a.vcoef * gv * invB : 0.f;
-    if (live) { s_sur += sur * invB; s_vl += vl * invB; s_kl += kl * invB; }
+    if (live) { s_sur += sur * wr; s_vl += vl * invB; s_kl += kl * invB; }
     const float gm_r = role_on ? g_lp * dd * isg2 : 0.f;          // d loss / d mu[row][role]
     gs += role_on ? g_lp * (dd * dd * isg2 / sg - 1.f / sg) : 0.f;
     dbm += gm_r;

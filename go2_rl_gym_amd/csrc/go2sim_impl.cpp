@@ -864,7 +864,7 @@ __global__ void __launch_bounds__(256) go2_store_transition_kernel(const float* 
 // no index tensor) unless the caller hands in a permutation.  HBM-bound: 2 x 348 floats per row.
 #define GO2_GATHER_ROWS_PER_WG 32
 struct Go2GatherArgs {
-  const float* src[GO2_GATHER_MAX_JOBS]; float* dst[GO2_GATHER_MAX_JOBS]; int32_t w[GO2_GATHER_MAX_JOBS];
+  const float* src[GO2_GATHER_MAX_JOBS]; float* dst[GO2_GATHER_MAX_JOBS]; int32_t w[GO2_GATHER_MAX_JOBS], dp[GO2_GATHER_MAX_JOBS];          // dp: destination row pitch
   int32_t njobs, rows, h, nclear; const int64_t* indices; uint32_t* key; float* clear;
 };
 __global__ void __launch_bounds__(256) go2_shuffle_gather_kernel(const Go2GatherArgs a) {
@@ -883,7 +883,7 @@ __global__ void __launch_bounds__(256) go2_shuffle_gather_kernel(const Go2Gather
     for (int j = 0; j < a.njobs; ++j) {
       const int w = a.w[j];
       const float* __restrict__ s0 = a.src[j] + (size_t)sidx[0] * w; const float* __restrict__ s1 = a.src[j] + (size_t)sidx[1] * w;
-      float* __restrict__ d0 = a.dst[j] + (size_t)r[0] * w; float* __restrict__ d1 = a.dst[j] + (size_t)r[1] * w;
+      float* __restrict__ d0 = a.dst[j] + (size_t)r[0] * a.dp[j]; float* __restrict__ d1 = a.dst[j] + (size_t)r[1] * a.dp[j];
       for (int e = lane; e < w; e += 64) {
         const float v0 = s0[e], v1 = s1[e];
         if (r[0] < a.rows) d0[e] = v0;
@@ -891,7 +891,7 @@ __global__ void __launch_bounds__(256) go2_shuffle_gather_kernel(const Go2Gather
       }
     }
   }
-  if (blockIdx.x == 0 && (int)threadIdx.x < a.nclear) a.clear[threadIdx.x] = 0.f;
+  if (blockIdx.x == 0) for (int i = threadIdx.x; i < a.nclear; i += 256) a.clear[i] = 0.f;
   if (!a.indices) {          // the last workgroup to finish advances the counter for the next launch (a replayed HIP graph): every workgroup has read it by then
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1652,19 +1652,19 @@ uint32_t go2sim_shuffle_index(uint32_t i, uint32_t n, uint32_t seed, uint32_t co
 
 int go2sim_shuffle_gather(const Go2GatherJob* jobs, int32_t njobs, int32_t rows, const int64_t* indices, uint32_t* key_state, float* clear, int32_t nclear, void* stream) {
   if (!jobs || njobs <= 0 || njobs > GO2_GATHER_MAX_JOBS || rows <= 0 || (!indices && !key_state) || (nclear > 0 && !clear)) FAIL(GO2SIM_EINVAL, "shuffle gather: bad argument");
-  for (int j = 0; j < njobs; ++j) if (!jobs[j].src || !jobs[j].dst || jobs[j].row_floats <= 0) FAIL(GO2SIM_EINVAL, "shuffle gather: bad job %d", j);
+  for (int j = 0; j < njobs; ++j) if (!jobs[j].src || !jobs[j].dst || jobs[j].row_floats <= 0 || (jobs[j].dst_pitch != 0 && jobs[j].dst_pitch < jobs[j].row_floats)) FAIL(GO2SIM_EINVAL, "shuffle gather: bad job %d", j);
   const int h = go2_shuffle_half_bits((uint32_t)rows);
 #ifdef GO2_EMU
   (void)stream;
   for (int32_t r = 0; r < rows; ++r) {
     const int64_t sidx = indices ? indices[r] : (int64_t)go2_shuffle_index((uint32_t)r, (uint32_t)rows, h, key_state[0], key_state[1]);
-    for (int j = 0; j < njobs; ++j) memcpy(jobs[j].dst + (size_t)r * jobs[j].row_floats, jobs[j].src + (size_t)sidx * jobs[j].row_floats, sizeof(float) * (size_t)jobs[j].row_floats);
+    for (int j = 0; j < njobs; ++j) memcpy(jobs[j].dst + (size_t)r * (jobs[j].dst_pitch ? jobs[j].dst_pitch : jobs[j].row_floats), jobs[j].src + (size_t)sidx * jobs[j].row_floats, sizeof(float) * (size_t)jobs[j].row_floats);
   }
   if (!indices) key_state[1] += 1u;
   for (int i = 0; i < nclear; ++i) clear[i] = 0.f;
 #else
   Go2GatherArgs a; memset(&a, 0, sizeof(a));
-  for (int j = 0; j < njobs; ++j) { a.src[j] = jobs[j].src; a.dst[j] = jobs[j].dst; a.w[j] = jobs[j].row_floats; }
+  for (int j = 0; j < njobs; ++j) { a.src[j] = jobs[j].src; a.dst[j] = jobs[j].dst; a.w[j] = jobs[j].row_floats; a.dp[j] = jobs[j].dst_pitch ? jobs[j].dst_pitch : jobs[j].row_floats; }
   a.njobs = njobs; a.rows = rows; a.h = h; a.indices = indices; a.key = key_state; a.clear = clear; a.nclear = nclear;
   const int nwg = (rows + GO2_GATHER_ROWS_PER_WG - 1) / GO2_GATHER_ROWS_PER_WG;
   hipLaunchKernelGGL(go2_shuffle_gather_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, a);

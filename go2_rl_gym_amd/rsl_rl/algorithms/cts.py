@@ -76,6 +76,7 @@ class CTS(_RolloutHeads):
         assert len(self.student_env_idxs) == self.student_num_envs, f"{len(self.student_env_idxs)=} != {self.student_num_envs=}"
         self.surrogate_split = 0            # set per update: teacher rows of a mini-batch (read by _FusedPPOLoss)
         self._steps = None
+        self._plan = False                  # the no-autograd mini-batch (modules/fused_cts.py): decided at the first graph-mode update (None: not applicable)
         self._fused_adam1 = self._fused_adam2 = None
         if _world() > 1:
             for p in self.model.parameters():
@@ -272,12 +273,35 @@ class CTS(_RolloutHeads):
     def _adaptive(self):
         return self.desired_kl is not None and self.schedule == "adaptive"
 
+    def _own_plan(self):
+        """The CTS mini-batch as explicit launches without autograd (modules/fused_cts.py), when it covers this model and algorithm — the plain CTS heads and loss
+        (MoE-CTS included: only its student step differs) on the library pair; None keeps the autograd formulation (GO2_CTS_OWN=0 forces that, for A/B runs)."""
+        if self._plan is False:
+            self._plan = None
+            if self.fused_loss and self.lib is not None and type(self)._policy_extra is CTS._policy_extra and os.environ.get("GO2_CTS_OWN", "1") == "1":
+                from ..modules import fused_cts
+                self._plan = fused_cts.cts_plan(self.model)
+        return self._plan
+
+    def _own_student(self):
+        plan = self._own_plan()
+        return plan is not None and plan.student is not None and type(self)._student_losses is CTS._student_losses
+
     def _policy_front(self, i, split=False):
         mb = self._mb
-        loss, value_loss, surrogate_loss, ent, kl_mean = self._policy_losses(*(self._perm[k][i * mb:(i + 1) * mb] for k in self._KEYS), self._teacher_rows())
-        self.optimizer1.zero_grad(set_to_none=True)
-        loss.backward()
-        self._acc[:3 + self._NUM_POLICY_LOGS].add_(torch.stack([value_loss.detach(), surrogate_loss.detach(), ent.detach()] + [v.detach() for v in self._policy_logs]))
+        if self._own_plan() is not None:
+            from ..modules import fused_cts
+            P, n_t, s = self._perm, self._teacher_rows(), slice(i * mb, (i + 1) * mb)
+            self.optimizer1.zero_grad(set_to_none=True)
+            stats = fused_cts.cts_policy_grads(self._plan, self.model, P["ain"][s], P["cin"][s], P["cobs"][i * mb:i * mb + n_t],
+                                               tuple(P[k][s] for k in ("act", "val", "adv", "ret", "logp", "mu", "sig")), n_t, self.clip_param, self.value_loss_coef,
+                                               self.entropy_coef, self.use_clipped_value_loss, acc=self._acc_own)          # (the running sums: added by the pass's go2nn_sum_rows launch)
+            kl_mean = stats[2]
+        else:
+            loss, value_loss, surrogate_loss, ent, kl_mean = self._policy_losses(*(self._perm[k][i * mb:(i + 1) * mb] for k in self._KEYS), self._teacher_rows())
+            self.optimizer1.zero_grad(set_to_none=True)
+            loss.backward()
+            self._acc[:3 + self._NUM_POLICY_LOGS].add_(torch.stack([value_loss.detach(), surrogate_loss.detach(), ent.detach()] + [v.detach() for v in self._policy_logs]))
         if split:      # more than one rank: gradients + mean KL into the all-reduce bucket (_graph.py)
             if self._bucket1 is None:
                 self._bucket1 = GradBucket(self._params1, 1 if self._adaptive() else 0)
@@ -308,10 +332,15 @@ class CTS(_RolloutHeads):
 
     def _student_front(self, i, split=False):
         mb, n_t = self._mb, self._teacher_rows()
-        loss, logs = self._student_losses(self._perm["hist"][i * mb + n_t:(i + 1) * mb], self._perm["cobs"][i * mb + n_t:(i + 1) * mb])
+        hist_s, priv_s = self._perm["hist"][i * mb + n_t:(i + 1) * mb], self._perm["cobs"][i * mb + n_t:(i + 1) * mb]
         self.optimizer2.zero_grad(set_to_none=True)
-        loss.backward()
-        self._acc[3 + self._NUM_POLICY_LOGS:].add_(torch.stack([v.detach() for v in logs]))
+        if self._own_student():
+            from ..modules import fused_cts
+            fused_cts.cts_student_grads(self._plan, self.model, hist_s, priv_s, acc=self._acc_own[4:])
+        else:
+            loss, logs = self._student_losses(hist_s, priv_s)
+            loss.backward()
+            self._acc[3 + self._NUM_POLICY_LOGS:].add_(torch.stack([v.detach() for v in logs]))
         if split:
             if self._bucket2 is None:
                 self._bucket2 = GradBucket(self._params2)
@@ -331,34 +360,91 @@ class CTS(_RolloutHeads):
         self._student_front(i)
         self._student_back()
 
+    def _gather_update(self, order):
+        """The rollout into mini-batch order, once per update.  Own path: ONE go2sim_shuffle_gather launch over the given index list — obs / privileged obs land
+        straight in the column blocks behind the latent of the actor's / critic's input matrices (dst_pitch) — which also clears the loss accumulators."""
+        if self._gather_jobs is None:
+            self._accbuf.zero_()
+            for k in self._KEYS:
+                torch.index_select(self._flat[k], 0, order, out=self._perm[k])
+            return
+        import ctypes as C
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream) if str(self.device).startswith("cuda") else None
+        self._order = order.to(torch.int64).contiguous()          # (alive until the launch has run)
+        rc = self.lib.go2sim_shuffle_gather(self._gather_jobs, len(self._gather_jobs), int(order.numel()), C.c_void_p(self._order.data_ptr()), None,
+                                            C.c_void_p(self._accbuf.data_ptr()), int(self._accbuf.numel()), stream)
+        if rc != 0:
+            raise RuntimeError("go2sim_shuffle_gather failed: %s" % self.lib.go2sim_last_error().decode())
+
+    def _student_latents(self):
+        """The student rows' latents of the whole update into the first L columns of both input matrices: optimizer1 never touches the student encoder (cts.py:72-77), so
+        they are constants of the policy epochs — computed once per update instead of in each of the 20 policy steps."""
+        from ..modules import fused_cts
+        nmb, mb, n_t, plan = self.num_mini_batches, self._mb, self._teacher_rows(), self._plan
+        L, P = plan.L, self._perm
+        hist = P["hist"].view(nmb, mb, -1)[:, n_t:].reshape(nmb * (mb - n_t), -1)
+        with torch.no_grad():
+            lat = None if plan.student is not None else self.model.student_latent(hist)[0].view(nmb, mb - n_t, L)
+            for i in range(nmb):
+                da, dc = P["ain"][i * mb + n_t:(i + 1) * mb], P["cin"][i * mb + n_t:(i + 1) * mb]
+                if plan.student is not None:          # a plain MLP: forward on the own kernels, the normaliser writes into both matrices
+                    fused_cts.encoder_latents(plan, plan.student, hist[i * (mb - n_t):(i + 1) * (mb - n_t)], da, dc)
+                else:                                 # (the MoE encoders: torch modules, no gradient)
+                    da[:, :L] = lat[i]; dc[:, :L] = lat[i]
+
     def _update_graphs(self):
         st, nmb = self.storage, self.num_mini_batches
         if self._steps is None:
+            plan = self._own_plan()
             self._flat = st.flat()
             self._mb = (st.teacher_num_envs * st.num_transitions_per_env) // nmb + (st.student_num_envs * st.num_transitions_per_env) // nmb
-            self._perm = {k: torch.empty((nmb * self._mb,) + tuple(self._flat[k].shape[1:]), device=self.device, dtype=self._flat[k].dtype) for k in self._KEYS}
-            self._acc = torch.zeros(3 + self._NUM_POLICY_LOGS + self._NUM_STUDENT_LOGS, device=self.device)
+            rows = nmb * self._mb
+            new = lambda *shape: torch.empty(*shape, device=self.device, dtype=torch.float32)
+            self._perm = {k: new(rows, *self._flat[k].shape[1:]) for k in self._KEYS if not (plan is not None and k == "obs")}
+            # accumulators: [own policy step: surrogate, value, KL, entropy | own student step: latent loss, 0, 0, 0 | the autograd formulation's: value, surrogate, entropy, logs]
+            self._accbuf = torch.zeros(8 + 3 + self._NUM_POLICY_LOGS + self._NUM_STUDENT_LOGS, device=self.device)
+            self._acc_own, self._acc = self._accbuf[:8], self._accbuf[8:]
             self._bucket1 = self._bucket2 = None
+            self._gather_jobs = None
+            if plan is not None:
+                import ctypes as C
+                from ..._abi import Go2GatherJob
+                L, no, npriv = plan.L, self._flat["obs"].shape[1], self._flat["cobs"].shape[1]
+                self._perm["ain"], self._perm["cin"] = new(rows, L + no), new(rows, L + npriv)
+                F, Pm = self._flat, self._perm
+                jobs = [Go2GatherJob(F["obs"].data_ptr(), Pm["ain"].data_ptr() + 4 * L, no, L + no), Go2GatherJob(F["cobs"].data_ptr(), Pm["cin"].data_ptr() + 4 * L, npriv, L + npriv)]
+                jobs += [Go2GatherJob(F[k].data_ptr(), Pm[k].data_ptr(), int(F[k][0].numel()), 0) for k in self._KEYS if k != "obs"]
+                assert all(F[k].dtype == torch.float32 and F[k].is_contiguous() for k in self._KEYS)
+                self._gather_jobs = (Go2GatherJob * len(jobs))(*jobs)
+                self._latents_step = CapturedStep(self._student_latents, enabled=self._capture, warmup=2, name="CTS student latents", optional=True)
             if _collectives_on():     # two captured halves per slot, the gradient all-reduce eager between them
                 mk = lambda front, back, bucket, name: [ReducedStep((lambda i=i: front(i, True)), (lambda: back(True)), bucket, enabled=self._capture, warmup=3 if i == 0 else 1,
                                                                     name="CTS %s step %d" % (name, i)) for i in range(nmb)]
                 self._steps = (mk(self._policy_front, self._policy_back, (lambda: self._bucket1), "policy"),
                                mk(self._student_front, self._student_back, (lambda: self._bucket2), "student"))
+            elif plan is not None:
+                # one rank, own path: a whole EPOCH (its nmb steps, each on its own chunk of the permuted rollout) is one graph, as in PPO (5 + 5 graph launches per update instead of 20 + 20)
+                mk = lambda fn, name: [CapturedStep((lambda: [fn(i) for i in range(nmb)] and None), enabled=self._capture, warmup=1, name="CTS %s epoch (%d steps)" % (name, nmb))]
+                self._steps = (mk(self._policy_step, "policy"), mk(self._student_step, "student"))
             else:
                 mk = lambda fn, name: [CapturedStep((lambda i=i: fn(i)), enabled=self._capture, warmup=3 if i == 0 else 1, name="CTS %s step %d" % (name, i)) for i in range(nmb)]
                 self._steps = (mk(self._policy_step, "policy"), mk(self._student_step, "student"))
-        self._acc.zero_()
         # the rollout is gathered ONCE per update into mini-batch order ([teacher rows | student rows] per mini-batch; every epoch
         # reuses the same permutation, rollout_storage_cts.py:152-160), so each captured step reads a contiguous chunk
-        order = torch.cat(st.mini_batch_indices(nmb))
-        for k in self._KEYS:
-            torch.index_select(self._flat[k], 0, order, out=self._perm[k])
+        self._gather_update(torch.cat(st.mini_batch_indices(nmb)))
+        if self._plan is not None:
+            self._latents_step()
         for steps in self._steps:
             for _ in range(self.num_learning_epochs):
-                for i in range(nmb):
-                    steps[i]()
+                for step in steps:
+                    step()
         n = self.num_learning_epochs * nmb
-        out = torch.cat([self._acc / n, self._lr_t.reshape(1)]).tolist()          # ONE device -> host read per update
+        acc = self._acc
+        if self._plan is not None:      # the own steps' running sums, in the autograd formulation's slots
+            own, P = self._acc_own, self._NUM_POLICY_LOGS
+            parts = [own[1:2], own[0:1], own[3:4], acc[3:3 + P], own[4:5] if self._own_student() else acc[3 + P:3 + P + 1], acc[3 + P + 1:]]
+            acc = torch.cat(parts)
+        out = torch.cat([acc / n, self._lr_t.reshape(1)]).tolist()          # ONE device -> host read per update
         self.learning_rate = float(out.pop())
         return self._ordered(tuple(out))
 

@@ -1,0 +1,299 @@
+"""A CTS mini-batch (rsl_rl/rsl_rl/algorithms/cts.py:167-285) as explicit launches of include/go2nn.h — no autograd graph, no vendor GEMM.
+
+The policy step differentiates   teacher_encoder -> L2Norm -> [latent | obs] -> actor,   [latent.detach() | privileged obs] -> critic   through the PPO loss with the
+split surrogate (cts.py:228-231); the student step differentiates the student encoder through the latent MSE (cts.py:259-275).  Both are chains of Linear / ELU layers
+around three row-wise pieces (the normaliser forward, its backward, the MSE head), so they are the grouped split-operand GEMMs of PPO's mini-batch
+(modules/fused.py:ppo_pair_grads) plus go2nn_latent_concat / go2nn_l2norm_backward / go2nn_latent_mse (include/go2nn.h ABI 5):
+
+  policy step  (26 launches):  split weights | teacher encoder forward x3 | latent_concat (zhat straight into the first L columns of both input matrices) |
+               actor + critic forward x3 (grouped) | go2nn_ppo_heads (surrogate_split = teacher rows) | weight gradients x3 + input gradients x2 (grouped) |
+               the actor's plain input gradient on the teacher rows | l2norm_backward | teacher encoder weight gradients x3 + input gradients x2 | ONE go2nn_sum_rows
+  student step (13 launches):  split weights | student + teacher encoder forward x3 (grouped) | latent_mse | student weight gradients x3 + input gradients x2 | sum_rows
+
+What makes the policy step cheap beyond the kernels: optimizer1 never touches the student encoder, so the student rows' latents are constants of an update — they are
+written into the input matrices ONCE per update (algorithms/cts.py), not recomputed in each of the 20 policy steps; and obs / privileged obs are gathered straight into
+the column blocks behind the latent (go2sim_shuffle_gather's dst_pitch), so no torch.cat ever runs.
+
+Every parameter's .grad is set (replaced, as after zero_grad(set_to_none=True)); all sums have a fixed order."""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import fused
+
+
+def _leaves(m):
+    """the leaf modules of nested nn.Sequential / MLP (modules/utils.py: .network) containers, in order"""
+    if isinstance(m, nn.Sequential):
+        return [x for c in m for x in _leaves(c)]
+    if isinstance(getattr(m, "network", None), nn.Sequential):
+        return _leaves(m.network)
+    return [m]
+
+
+def mlp_linears(m, norm=False):
+    """[Linear, ELU(1)] x H + Linear (+ an L2Norm when `norm`) with H >= 1 -> the Linear modules, else None"""
+    from .utils import L2Norm
+    mods = _leaves(m)
+    if norm:
+        if not mods or not isinstance(mods[-1], L2Norm):
+            return None
+        mods = mods[:-1]
+    if len(mods) < 3 or len(mods) % 2 == 0:
+        return None
+    lins = []
+    for k, x in enumerate(mods):
+        if k % 2 == 0:
+            if not (isinstance(x, nn.Linear) and x.bias is not None and x.weight.dtype == torch.float32 and x.weight.requires_grad and x.bias.requires_grad
+                    and x.in_features >= 4 and x.weight.is_contiguous()):
+                return None
+            lins.append(x)
+        elif not (isinstance(x, nn.ELU) and x.alpha == 1.0):
+            return None
+    if any(l.out_features % 4 or l.out_features < 4 for l in lins[:-1]):
+        return None
+    return lins
+
+
+class CtsPlan:
+    """Which Linear modules make up the teacher encoder, the actor, the critic (and the student encoder, when it is a plain MLP) of an ActorCriticCTS-family model."""
+
+    def __init__(self, teacher, actor, critic, student, L):
+        self.teacher, self.actor, self.critic, self.student, self.L = teacher, actor, critic, student, L
+
+
+def _latent_ok(L):
+    return L >= 4 and L % 4 == 0 and L <= 128 and ((L // 4) & (L // 4 - 1)) == 0
+
+
+def cts_plan(model):
+    """-> CtsPlan when the no-autograd mini-batch applies to `model`, else None (the algorithm then keeps the autograd formulation): the library pair is loaded, the
+    heads are the base class's ([latent | obs] -> actor MLP, [latent | privileged obs] -> critic MLP, one std per action), every network is Linear / ELU with an
+    L2-normalised latent, actor and critic share their hidden widths, and the split-operand kernels are on (the plain input gradient of a 77-wide layer exists only there)."""
+    from .actor_critic_cts import ActorCriticCTS
+    if not (fused._HEADS and fused._PAIR and fused._LIB is not None and fused._NN is not None and isinstance(model, ActorCriticCTS)):
+        return None
+    if not (fused._SPLIT or fused._NN.go2nn_is_device_library() == 0):
+        return None
+    t = type(model)
+    if any(getattr(t, n) is not getattr(ActorCriticCTS, n) for n in ("policy_mean", "value", "policy_dist", "latents", "evaluate_joint")) or model.state_dependent_std:
+        return None
+    te, la, lc = mlp_linears(model.teacher_encoder, norm=True), mlp_linears(model.actor), mlp_linears(model.critic)
+    if te is None or la is None or lc is None or len(la) != len(lc) or any(a.out_features != c.out_features for a, c in zip(la[:-1], lc[:-1])):
+        return None
+    L, K = te[-1].out_features, la[-1].in_features
+    if not (_latent_ok(L) and lc[-1].out_features == 1 and la[-1].out_features <= 16 and K % 4 == 0 and K <= 256 and model.std.dim() == 1
+            and model.std.shape[0] == la[-1].out_features and model.std.requires_grad and la[0].in_features > L and lc[0].in_features > L):
+        return None
+    st = None
+    if t.student_latent is ActorCriticCTS.student_latent and hasattr(model, "student_encoder"):
+        st = mlp_linears(model.student_encoder, norm=True)
+        if st is not None and (st[-1].out_features != L or len(st) != len(te)):
+            st = None
+    return CtsPlan(te, la, lc, st, L)
+
+
+class _Launch:
+    """The go2nn calls of one mini-batch on one device / stream; collects the fixed-order reductions of the pass for ONE go2nn_sum_rows launch."""
+
+    def __init__(self, dev):
+        self.dev, self.nn = dev, fused._NN
+        self.stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else None
+        self.sums = []          # (partial rows, result, nrows, ncols[, acc, nacc])
+
+    def new(self, *shape):
+        return torch.empty(*shape, device=self.dev, dtype=torch.float32)
+
+    def check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed: %s" % (what, self.nn.go2nn_last_error().decode()))
+
+    def images(self, lins):
+        """split images of the layers' weights (both orientations), ONE launch; [None] * n when the split-operand kernels are off"""
+        from ..._nn import Go2nnSplitJob
+        if not fused._SPLIT:
+            return [None] * len(lins)
+        imgs, jobs = [], []
+        for m in lins:
+            N, K = m.weight.shape
+            n = self.nn.go2nn_split_weights_bytes(N, K)
+            if n <= 0:
+                raise RuntimeError("go2nn_split_weights_bytes: %s" % self.nn.go2nn_last_error().decode())
+            imgs.append(torch.empty(int(n), device=self.dev, dtype=torch.uint8))
+            jobs.append(Go2nnSplitJob(m.weight.data_ptr(), imgs[-1].data_ptr(), N, K))
+        for k in range(0, len(jobs), 16):
+            chunk = jobs[k:k + 16]
+            self.check(self.nn.go2nn_split_weights((Go2nnSplitJob * len(chunk))(*chunk), len(chunk), self.stream), "go2nn_split_weights")
+        return imgs
+
+    def forward(self, jobs, act=0):
+        """jobs: [(x [M, K], Linear, image)] (1 or 2, one launch) -> [y [M, N]];  act 0: ELU, 1: none"""
+        from ..._nn import Go2nnFwdJob
+        ys = [self.new(x.shape[0], m.out_features) for x, m, _ in jobs]
+        arr = (Go2nnFwdJob * len(jobs))(*[Go2nnFwdJob(x.data_ptr(), m.weight.data_ptr(), m.bias.data_ptr(), y.data_ptr(), x.shape[0], m.in_features, m.out_features, act,
+                                                      img.data_ptr() if img is not None else None) for (x, m, img), y in zip(jobs, ys)])
+        self.check(self.nn.go2nn_linear_elu_forward_group(arr, len(jobs), self.stream), "go2nn_linear_elu_forward_group")
+        return ys
+
+    def wgrad(self, jobs):
+        """jobs: [(gz [M, C], x [M, Kin], Linear)] with one M: the layers' weight gradients (row-slice partials now, .grad = their sum after finish())"""
+        from ..._nn import Go2nnBwdWJob
+        arr = (Go2nnBwdWJob * len(jobs))(*[Go2nnBwdWJob(gz.data_ptr(), x.data_ptr(), None, gz.shape[0], m.out_features, m.in_features, 1 if fused._SPLIT else 0) for gz, x, m in jobs])
+        rows = self.nn.go2nn_linear_backward_weight_group_rows(arr, len(jobs))
+        if rows <= 0:
+            raise RuntimeError("go2nn_linear_backward_weight_group_rows: %s" % self.nn.go2nn_last_error().decode())
+        for j, (gz, x, m) in enumerate(jobs):
+            n = m.out_features * m.in_features
+            wk, dw = self.new(rows * n), torch.empty_like(m.weight)
+            arr[j].workspace = wk.data_ptr()
+            self.sums.append((wk, dw, rows, n))
+            m.weight.grad = dw
+        self.check(self.nn.go2nn_linear_backward_weight_group(arr, len(jobs), self.stream), "go2nn_linear_backward_weight_group")
+
+    def bwd_in(self, jobs, plain=False):
+        """jobs: [(gz [M, C], Linear, y_prev [M, Kin] or None, image)] -> ([gz_prev [M, Kin]], [gb_prev [Kin]] (valid after finish(); None when plain))"""
+        from ..._nn import Go2nnBwdInJob
+        arr, outs, gbs = (Go2nnBwdInJob * len(jobs))(), [], []
+        for j, (gz, m, yp, img) in enumerate(jobs):
+            M, Co, Ki = gz.shape[0], m.out_features, m.in_features
+            o = self.new(M, Ki)
+            wk = gb = None
+            if not plain:
+                r = self.nn.go2nn_linear_backward_input_group_rows(M, Co, Ki)
+                wk, gb = self.new(r * Ki), self.new(Ki)
+                self.sums.append((wk, gb, r, Ki))
+            arr[j] = Go2nnBwdInJob(gz.data_ptr(), m.weight.data_ptr(), yp.data_ptr() if yp is not None else None, o.data_ptr(), wk.data_ptr() if wk is not None else None,
+                                   M, Co, Ki, 1 if plain else 0, img.data_ptr() if img is not None else None)
+            outs.append(o); gbs.append(gb)
+        self.check(self.nn.go2nn_linear_backward_input_group(arr, len(jobs), self.stream), "go2nn_linear_backward_input_group")
+        return outs, gbs
+
+    def chain_backward(self, chains):
+        """chains: 1 or 2 dicts {lins, acts, gz, gb, imgs} of equally many layers and one M: gz / gb = the gradient at lins[-1]'s output and its column sums;
+        acts[l] = the input of lins[l] (acts[l > 0] an ELU output).  Sets .grad of every weight and bias; -> the gradients at lins[0]'s pre-activation."""
+        n = len(chains[0]["lins"])
+        gz, gb = [c["gz"] for c in chains], [c["gb"] for c in chains]
+        for l in range(n - 1, -1, -1):
+            self.wgrad([(gz[j], c["acts"][l], c["lins"][l]) for j, c in enumerate(chains)])
+            for j, c in enumerate(chains):
+                c["lins"][l].bias.grad = gb[j]
+            if l > 0:
+                gz, gb = self.bwd_in([(gz[j], c["lins"][l], c["acts"][l], c["imgs"][l]) for j, c in enumerate(chains)])
+        return gz
+
+    def finish(self):
+        from ..._nn import Go2nnSumJob
+        for k in range(0, len(self.sums), 32):
+            chunk = self.sums[k:k + 32]
+            arr = (Go2nnSumJob * len(chunk))(*[Go2nnSumJob(t[0].data_ptr(), t[1].data_ptr(), t[2], t[3], t[4].data_ptr() if len(t) > 4 and t[4] is not None else None,
+                                                           t[5] if len(t) > 4 and t[4] is not None else 0, 0) for t in chunk])
+            self.check(self.nn.go2nn_sum_rows(arr, len(chunk), self.stream), "go2nn_sum_rows")
+        self.sums = []
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def latent_concat(k, z, dst_a, dst_b, inv=None):
+    """zhat = z / max(|z|, 1e-12) into the first L columns of dst_a / dst_b (row-major, any pitch >= L; either may be None); inv [n] <- 1 / max(|z|, 1e-12)"""
+    n, L = z.shape
+    k.check(k.nn.go2nn_latent_concat(_p(z), n, L, _p(dst_a), dst_a.stride(0) if dst_a is not None else 0, _p(dst_b), dst_b.stride(0) if dst_b is not None else 0, _p(inv), k.stream),
+            "go2nn_latent_concat")
+
+
+def cts_policy_grads(plan, model, ain, cin, priv_t, batch, n_t, clip, vcoef, ecoef, use_clipped_value_loss, acc=None):
+    """One CTS policy mini-batch gradient (cts.py:180-250 + loss.backward()).
+    ain [B, L + obs], cin [B, L + priv]: the actor's / critic's input matrices, rows [0, n_t) teacher samples, the rest student samples; columns [L, ...) hold obs /
+    privileged obs, the STUDENT rows' first L columns the (constant) student latents; the teacher rows' first L columns are written here.  priv_t [n_t, priv]: the
+    teacher rows' privileged observations (the teacher encoder's input).  batch: actions, old values, advantages, returns, old log-probs, old mu, old sigma.
+    acc: optional float32[>= 4] — [surrogate, value loss, KL, entropy] of the mini-batch are ADDED to it by the pass's go2nn_sum_rows launch.
+    -> stats [surrogate, value loss, KL, entropy] (device tensor; valid after the launches)"""
+    from ..._nn import Go2nnPpoHeads
+    actions, old_values, adv, returns, old_logp, old_mu, old_sigma = batch
+    k = _Launch(ain.device)
+    nn_ = k.nn
+    te, la, lc, L = plan.teacher, plan.actor, plan.critic, plan.L
+    H, B = len(la) - 1, ain.shape[0]
+    cont = lambda t: t.detach() if t.is_contiguous() else t.detach().contiguous()
+    flat = lambda t: cont(t).reshape(-1)
+    with torch.no_grad():
+        imgs = k.images(te + la[:H] + lc[:H])
+        ie, ia, ic = imgs[:len(te)], imgs[len(te):len(te) + H], imgs[len(te) + H:]
+        # teacher encoder on the teacher rows -> zhat into both input matrices
+        eacts = [cont(priv_t)]
+        for l, m in enumerate(te):
+            eacts.append(k.forward([(eacts[-1], m, ie[l])], act=1 if l == len(te) - 1 else 0)[0])
+        inv = k.new(n_t)
+        latent_concat(k, eacts[-1], ain, cin, inv)
+        # actor + critic hidden layers, grouped
+        acts = [[ain], [cin]]
+        for l in range(H):
+            ys = k.forward([(acts[0][-1], la[l], ia[l]), (acts[1][-1], lc[l], ic[l])])
+            acts[0].append(ys[0]); acts[1].append(ys[1])
+        # heads forward + PPO loss (split surrogate) + heads backward
+        A, K = la[H].weight.shape
+        rows, cols = nn_.go2nn_ppo_heads_rows(B, A, K), nn_.go2nn_ppo_heads_cols(A, K)
+        if rows <= 0 or cols <= 0:
+            raise RuntimeError("go2nn_ppo_heads: %s" % nn_.go2nn_last_error().decode())
+        gz = [k.new(B, K), k.new(B, K)]
+        part, tot = k.new(rows * cols), k.new(cols)
+        keep = [cont(actions), cont(old_mu), cont(old_sigma), flat(old_logp), flat(adv), flat(old_values), flat(returns), cont(model.std)]
+        p = lambda t: t.data_ptr()
+        h = Go2nnPpoHeads(p(acts[0][H]), p(acts[1][H]), p(la[H].weight), p(la[H].bias), p(lc[H].weight), p(lc[H].bias), p(keep[7]), p(keep[0]), p(keep[1]), p(keep[2]), p(keep[3]),
+                          p(keep[4]), p(keep[5]), p(keep[6]), p(gz[0]), p(gz[1]), p(part), B, A, K, int(bool(use_clipped_value_loss)), float(clip), float(vcoef), float(ecoef), int(n_t))
+        k.check(nn_.go2nn_ppo_heads(C.byref(h), k.stream), "go2nn_ppo_heads")
+        k.sums.append((part, tot, rows, cols, acc, 4))
+        o = 4 + A
+        model.std.grad = tot[4:o].view_as(model.std)
+        la[H].weight.grad, gb_a, la[H].bias.grad = tot[o:o + A * K].view(A, K), tot[o + A * K:o + (A + 1) * K], tot[o + (A + 1) * K:o + (A + 1) * K + A]
+        o += (A + 1) * K + A
+        lc[H].weight.grad, gb_c, lc[H].bias.grad = tot[o:o + K].view(1, K), tot[o + K:o + 2 * K], tot[o + 2 * K:o + 2 * K + 1]
+        gz1 = k.chain_backward([{"lins": la[:H], "acts": acts[0], "gz": gz[0], "gb": gb_a, "imgs": ia}, {"lins": lc[:H], "acts": acts[1], "gz": gz[1], "gb": gb_c, "imgs": ic}])
+        # into the teacher encoder: d loss / d [latent | obs] of the actor on the teacher rows (the critic sees latent.detach()), through the normaliser
+        g_in = k.bwd_in([(gz1[0][:n_t], la[0], None, ia[0])], plain=True)[0][0]
+        r = nn_.go2nn_l2norm_backward_rows(n_t)
+        dz, zpart, gb_z = k.new(n_t, L), k.new(r * L), k.new(L)
+        k.check(nn_.go2nn_l2norm_backward(_p(g_in), g_in.stride(0), _p(ain), ain.stride(0), _p(inv), _p(dz), _p(zpart), n_t, L, k.stream), "go2nn_l2norm_backward")
+        k.sums.append((zpart, gb_z, r, L))
+        k.chain_backward([{"lins": te, "acts": eacts, "gz": dz, "gb": gb_z, "imgs": ie}])
+        k.finish()
+    return tot[:4]
+
+
+def cts_student_grads(plan, model, hist_s, priv_s, acc=None):
+    """One CTS student mini-batch gradient (cts.py:259-275 + latent_loss.backward()): hist_s [n_s, H * obs], priv_s [n_s, priv] = the student rows of the mini-batch.
+    acc: optional float32[>= 1] — the latent loss is ADDED to acc[0].  -> the latent loss (1-element device tensor; valid after the launches)"""
+    k = _Launch(hist_s.device)
+    nn_ = k.nn
+    st, te, L = plan.student, plan.teacher, plan.L
+    n = hist_s.shape[0]
+    cont = lambda t: t.detach() if t.is_contiguous() else t.detach().contiguous()
+    with torch.no_grad():
+        imgs = k.images(st + te)
+        is_, it = imgs[:len(st)], imgs[len(st):]
+        sacts, tx = [cont(hist_s)], cont(priv_s)
+        for l in range(len(st)):
+            last = 1 if l == len(st) - 1 else 0
+            ys = k.forward([(sacts[-1], st[l], is_[l]), (tx, te[l], it[l])], act=last)
+            sacts.append(ys[0]); tx = ys[1]
+        r = nn_.go2nn_l2norm_backward_rows(n)
+        dz, part, tot = k.new(n, L), k.new(r * (L + 4)), k.new(L + 4)          # [loss, 0, 0, 0 | the last bias gradient]
+        k.check(nn_.go2nn_latent_mse(_p(sacts[-1]), _p(tx), _p(dz), _p(part), n, L, 1.0, k.stream), "go2nn_latent_mse")
+        k.sums.append((part, tot, r, L + 4, acc, 1))
+        k.chain_backward([{"lins": st, "acts": sacts, "gz": dz, "gb": tot[4:], "imgs": is_}])
+        k.finish()
+    return tot[:1]
+
+
+def encoder_latents(plan, lins, x, dst_a, dst_b):
+    """zhat = L2Norm(MLP(x)) of a plain encoder (the student's, once per update) straight into the first L columns of dst_a / dst_b — forward only, own kernels"""
+    k = _Launch(x.device)
+    with torch.no_grad():
+        imgs = k.images(lins)
+        h = x if x.is_contiguous() else x.contiguous()
+        for l, m in enumerate(lins):
+            h = k.forward([(h, m, imgs[l])], act=1 if l == len(lins) - 1 else 0)[0]
+        latent_concat(k, h, dst_a, dst_b)
+    return h

@@ -18,7 +18,8 @@
 extern "C" {
 #endif
 
-#define GO2NN_ABI_VERSION 4      /* 2: + the learner-side kernels (go2nn_head_backward, go2nn_linear_*); 3: + the grouped (actor + critic) layer calls; 4: + split-operand (3 x bf16) products */
+#define GO2NN_ABI_VERSION 5      /* 2: + the learner-side kernels (go2nn_head_backward, go2nn_linear_*); 3: + the grouped (actor + critic) layer calls; 4: + split-operand (3 x bf16) products;
+                                    5: + the CTS pieces: layers without activation, plain input gradients, the latent normaliser forward / backward, the split surrogate, two-segment policy inputs */
 #define GO2NN_MAX_LAYERS 6
 #define GO2NN_MAX_WIDTH 512      /* widest layer input / output (LDS holds two 32-row activation tiles of this width) */
 #define GO2NN_EINVAL (-22)
@@ -68,6 +69,7 @@ int go2nn_policy_act(const Go2nnMlp* actor, const float* actor_packed, const Go2
  * go2nn_*_rows rows of (C + 1) K + C resp. Kin columns — and the caller finishes all of a backward pass's reductions (and the row splits of its
  * weight gradients) with one go2nn_sum_rows call, off the chain of dependent GEMMs. */
 typedef struct Go2nnSumJob { const float* part; float* out; int32_t nrows, ncols; float* acc; int32_t nacc, pad_; } Go2nnSumJob;      /* ABI 4: acc != NULL: acc[c] += out[c] for c < nacc (a running sum over launches, e.g. the update's mean losses) */
+#define GO2NN_MAX_SUM_JOBS 32      /* (ABI 5: was 16 — a CTS policy step finishes 19 reductions in one launch) */
 int go2nn_sum_rows(const Go2nnSumJob* jobs, int32_t njobs, void* stream);
 int32_t go2nn_head_backward_rows(int32_t B, int32_t C, int32_t K);
 int32_t go2nn_linear_backward_input_rows(int32_t M, int32_t C, int32_t Kin);
@@ -101,8 +103,13 @@ int go2nn_linear_backward_weight(const float* gz, const float* x, float* dw, flo
  *                  contiguous along the output index), the four waves of a workgroup split the rows of one output tile
  * workspace floats per job: rows * Kin resp. rows * C * Kin. */
 #define GO2NN_MAX_GROUP 2
-typedef struct Go2nnFwdJob { const float *x, *w, *b; float* y; int32_t M, K, N; int32_t pad_; const void* w_split; } Go2nnFwdJob;
-typedef struct Go2nnBwdInJob { const float *gz, *w, *y_prev; float *gz_prev, *workspace; int32_t M, C, Kin; int32_t pad_; const void* w_split; } Go2nnBwdInJob;
+/* ABI 5 (what was padding; 0 keeps the ABI 3 / 4 meaning).  Every job of a group carries the same flag.
+ *   Go2nnFwdJob.act     0: y = elu(x W^T + b);  1: y = x W^T + b — the LAST Linear of an encoder, whose output goes to a normaliser instead of an ELU
+ *                       (rsl_rl/rsl_rl/modules/actor_critic_cts.py:49-80: teacher_encoder / student_encoder = MLP -> L2Norm)
+ *   Go2nnBwdInJob.plain 0: gz_prev = (gz W) * elu'(y_prev) + column partials;  1: gz_prev = gz W — the gradient at the INPUT of a network's first layer
+ *                       (CTS: d loss / d [latent | obs], actor_critic_cts.py:146-151 -> autograd); y_prev and workspace are not read */
+typedef struct Go2nnFwdJob { const float *x, *w, *b; float* y; int32_t M, K, N; int32_t act; const void* w_split; } Go2nnFwdJob;
+typedef struct Go2nnBwdInJob { const float *gz, *w, *y_prev; float *gz_prev, *workspace; int32_t M, C, Kin; int32_t plain; const void* w_split; } Go2nnBwdInJob;
 typedef struct Go2nnBwdWJob { const float *gz, *x; float* workspace; int32_t M, C, Kin; int32_t split; } Go2nnBwdWJob;
 int go2nn_linear_elu_forward_group(const Go2nnFwdJob* jobs, int32_t njobs, void* stream);
 int32_t go2nn_linear_backward_input_group_rows(int32_t M, int32_t C, int32_t Kin);
@@ -121,6 +128,7 @@ int go2nn_linear_backward_weight_group(const Go2nnBwdWJob* jobs, int32_t njobs, 
  *   Go2nnBwdWJob.split    1 selects it for the weight gradient (both operands are activations: split in registers, no image)
  * NULL / 0 keep the fp32-MFMA kernels (bit-for-bit the ABI 3 results). */
 typedef struct Go2nnSplitJob { const float* w; void* image; int32_t N, K; } Go2nnSplitJob;
+#define GO2NN_MAX_SPLIT_JOBS 16      /* (ABI 5: was 8 — teacher encoder + actor + critic of a CTS policy step are 9 hidden layers) */
 int64_t go2nn_split_weights_bytes(int32_t N, int32_t K);
 int go2nn_split_weights(const Go2nnSplitJob* jobs, int32_t njobs, void* stream);
 
@@ -132,16 +140,38 @@ int go2nn_split_weights(const Go2nnSplitJob* jobs, int32_t njobs, void* stream);
  * Out: gz_a, gz_c [B,K] = the gradients at the last hidden layers' pre-activations; `partials` = go2nn_ppo_heads_rows(B, A, K) rows of
  * go2nn_ppo_heads_cols(A, K) columns whose column sums (go2nn_sum_rows) are
  *   [ surrogate, value loss, KL, entropy (means) | d loss/d std [A] | dW_mu [A,K] | gb_a [K] | db_mu [A] | dW_v [K] | gb_c [K] | db_v ]
- * (gb_*: bias gradient of the last hidden layer = column sums of gz_*).  A <= 16, K a multiple of 4 up to 256.  Fixed summation order. */
+ * (gb_*: bias gradient of the last hidden layer = column sums of gz_*).  A <= 16, K a multiple of 4 up to 256.  Fixed summation order.
+ * ABI 5: surrogate_split = n > 0 gives the CTS surrogate (rsl_rl/rsl_rl/algorithms/cts.py:228-231): mean over rows [0, n) + mean over rows [n, B) — a row's surrogate
+ * and its gradient are weighted 1 / n resp. 1 / (B - n) instead of 1 / B (go2sim_ppo_loss's surrogate_split); value loss, KL and entropy keep 1 / B. */
 typedef struct Go2nnPpoHeads {
   const float *y_a, *y_c, *w_mu, *b_mu, *w_v, *b_v, *std, *actions, *old_mu, *old_sigma, *old_logp, *adv, *old_values, *returns;
   float *gz_a, *gz_c, *partials;
   int32_t B, A, K, use_clipped_value_loss;
   float clip, value_loss_coef, entropy_coef;
+  int32_t surrogate_split;
 } Go2nnPpoHeads;
 int32_t go2nn_ppo_heads_rows(int32_t B, int32_t A, int32_t K);
 int32_t go2nn_ppo_heads_cols(int32_t A, int32_t K);
 int go2nn_ppo_heads(const Go2nnPpoHeads* a, void* stream);
+
+
+/* ---- ABI 5: the latent normaliser of the Concurrent Teacher-Student networks (rsl_rl/rsl_rl/modules/utils.py:24-30 L2Norm = F.normalize(x, p=2, dim=-1): x / max(|x|, 1e-12);
+ * rsl_rl/rsl_rl/modules/actor_critic_cts.py:49-80,146-176: latent = L2Norm(encoder MLP), actor input = [latent | obs], critic input = [latent.detach() | privileged obs]).
+ * Row-wise streaming kernels over [n, L] (L a multiple of 4, <= 128); fixed summation orders.
+ *
+ * go2nn_latent_concat: zhat = z / max(|z|, 1e-12) written into columns [0, L) of up to two row-major destinations with their own row pitch (the [latent | obs] and
+ *   [latent | privileged obs] input matrices of the actor and the critic: torch.cat + two copies in the reference), inv_norm [n] = 1 / max(|z|, 1e-12) kept for the backward pass
+ *   (dst_b, inv_norm may be NULL).
+ * go2nn_l2norm_backward: g = d loss / d zhat read from columns [0, L) of a matrix with row pitch ldg (the plain input gradient of the actor's first layer), zhat likewise
+ *   (pitch ldz):  dz = (g - zhat (zhat . g)) * inv_norm  -> dz [n, L] dense; column partial sums of dz (the encoder's last bias gradient) as
+ *   go2nn_l2norm_backward_rows(n) rows of L columns in `partials` (finished by go2nn_sum_rows).
+ * go2nn_latent_mse: the student step of CTS (rsl_rl/rsl_rl/algorithms/cts.py:259-275): shat = normalise(z_s), that = normalise(z_t),
+ *   loss = mean((that - shat)^2) over n L elements; dz_s = gradient of the loss at the student encoder's un-normalised output z_s.  `partials` = go2nn_l2norm_backward_rows(n)
+ *   rows of 4 + L columns: [ loss, 0, 0, 0 | column sums of dz_s ].  grad_scale multiplies dz_s (1: the plain MSE). */
+int32_t go2nn_l2norm_backward_rows(int32_t n);
+int go2nn_latent_concat(const float* z, int32_t n, int32_t L, float* dst_a, int32_t lda, float* dst_b, int32_t ldb, float* inv_norm, void* stream);
+int go2nn_l2norm_backward(const float* g, int32_t ldg, const float* zhat, int32_t ldz, const float* inv_norm, float* dz, float* partials, int32_t n, int32_t L, void* stream);
+int go2nn_latent_mse(const float* z_s, const float* z_t, float* dz_s, float* partials, int32_t n, int32_t L, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

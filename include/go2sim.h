@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GO2SIM_ABI_VERSION 7   /* 7: + go2sim_shuffle_gather / go2sim_shuffle_index;  6: go2sim_ppo_loss: workspace 24*ceil(B/64) floats (was B/256), A <= 16;  5: Go2SimCfg gained control_type / cmd_tracking_curriculum / cmd_max_curriculum, go2sim_reset_idx, episode_info is GO2_EPISODE_INFO_LEN long;  4: Go2SimCfg gained hf_cells / hf_walls (trimesh wall geometry); test hooks go2sim_debug_*;  3: 3: Go2SimCfg gained max_linear_velocity / max_angular_velocity; go2sim_elu_backward_bias workspace is C*ceil(B/64) */
+#define GO2SIM_ABI_VERSION 8   /* 8: Go2GatherJob.dst_pitch (a gathered row may land inside a wider destination row: the [latent | obs] input matrices of CTS), any nclear;  7: + go2sim_shuffle_gather / go2sim_shuffle_index;  6: go2sim_ppo_loss: workspace 24*ceil(B/64) floats (was B/256), A <= 16;  5: Go2SimCfg gained control_type / cmd_tracking_curriculum / cmd_max_curriculum, go2sim_reset_idx, episode_info is GO2_EPISODE_INFO_LEN long;  4: Go2SimCfg gained hf_cells / hf_walls (trimesh wall geometry); test hooks go2sim_debug_*;  3: 3: Go2SimCfg gained max_linear_velocity / max_angular_velocity; go2sim_elu_backward_bias workspace is C*ceil(B/64) */
 
 #define GO2SIM_EINVAL   (-1)  /* bad argument / config */
 #define GO2SIM_ENOMEM   (-2)
@@ -486,9 +486,12 @@ int  go2sim_history_push(float* history, const float* obs, const uint8_t* dones,
  *   indices == NULL: pi = go2sim_shuffle_index(., rows, key_state[0], key_state[1]) — a keyed pseudo-random BIJECTION of [0, rows): 6 Feistel rounds over the
  *     next even power of two with cycle walking (no sort, no scratch: every output row computes its own source row) — and key_state[1] is advanced by one when
  *     the launch is over, so a replayed HIP graph draws a new permutation every time.  key_state: device uint32 [4] = {seed, counter, internal ticket, 0}.
- * clear / nclear: floats set to zero by the launch (the update's loss accumulators), or NULL.  Up to GO2_GATHER_MAX_JOBS jobs. */
+ * clear / nclear: floats set to zero by the launch (the update's loss accumulators), or NULL.  Up to GO2_GATHER_MAX_JOBS jobs.
+ * ABI 8: dst_pitch = floats between two destination rows (0: dense = row_floats).  A wider pitch lets the gathered rows land in a column block of a wider matrix:
+ * the CTS update gathers obs / privileged obs straight into columns [32, 32 + 45) / [32, 32 + 263) of the actor's / critic's [latent | obs] input matrices
+ * (rsl_rl/rsl_rl/modules/actor_critic_cts.py:146-151,168-176 builds them with torch.cat per mini-batch); `dst` then points at the block's first column. */
 #define GO2_GATHER_MAX_JOBS 12
-typedef struct Go2GatherJob { const float* src; float* dst; int32_t row_floats; int32_t pad_; } Go2GatherJob;
+typedef struct Go2GatherJob { const float* src; float* dst; int32_t row_floats; int32_t dst_pitch; } Go2GatherJob;
 int  go2sim_shuffle_gather(const Go2GatherJob* jobs, int32_t njobs, int32_t rows, const int64_t* indices, uint32_t* key_state, float* clear, int32_t nclear, void* stream);
 /* host-callable statement of the permutation (both libraries; no device work): pi(i) for i < n under (seed, counter) */
 uint32_t go2sim_shuffle_index(uint32_t i, uint32_t n, uint32_t seed, uint32_t counter);

@@ -1459,11 +1459,11 @@ uint32_t go2sim_shuffle_index(uint32_t i, uint32_t n, uint32_t seed, uint32_t co
 int go2sim_shuffle_gather(const Go2GatherJob* jobs, int32_t njobs, int32_t rows, const int64_t* indices, uint32_t* key_state, float* clear, int32_t nclear, void* stream) {
   (void)stream;
   if (!jobs || njobs<=0 || njobs>GO2_GATHER_MAX_JOBS || rows<=0 || (!indices && !key_state) || (nclear>0 && !clear)) return GO2SIM_EINVAL;
-  for (int j=0;j<njobs;++j) if (!jobs[j].src || !jobs[j].dst || jobs[j].row_floats<=0) return GO2SIM_EINVAL;
+  for (int j=0;j<njobs;++j) if (!jobs[j].src || !jobs[j].dst || jobs[j].row_floats<=0 || (jobs[j].dst_pitch!=0 && jobs[j].dst_pitch<jobs[j].row_floats)) return GO2SIM_EINVAL;
   const int h = go2_shuffle_half_bits((uint32_t)rows);
   for (int32_t r=0;r<rows;++r) {
     const int64_t sidx = indices ? indices[r] : (int64_t)go2_shuffle_index((uint32_t)r, (uint32_t)rows, h, key_state[0], key_state[1]);
-    for (int j=0;j<njobs;++j) memcpy(jobs[j].dst+(size_t)r*jobs[j].row_floats, jobs[j].src+(size_t)sidx*jobs[j].row_floats, sizeof(float)*(size_t)jobs[j].row_floats);
+    for (int j=0;j<njobs;++j) memcpy(jobs[j].dst+(size_t)r*(jobs[j].dst_pitch?jobs[j].dst_pitch:jobs[j].row_floats), jobs[j].src+(size_t)sidx*jobs[j].row_floats, sizeof(float)*(size_t)jobs[j].row_floats);
   }
   if (!indices) key_state[1] += 1u;
   for (int i=0;i<nclear;++i) clear[i]=0.f;

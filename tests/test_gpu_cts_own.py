@@ -1,0 +1,39 @@
+"""The CTS mini-batch without autograd (modules/fused_cts.py over include/go2nn.h ABI 5) on a real MI355X: the HIP kernels against float64 torch / the reference's
+formulation under autograd, at the update's shapes (24576-row mini-batches: 18432 teacher + 6144 student rows; 45 / 263 / 225-wide inputs, 32-wide latent) and at ragged
+ones; bit-reproducible from launch to launch.  Run with -m gpu.  CPU twin on the host build: tests/test_cts_own.py."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import load_hip  # noqa: E402
+from go2_rl_gym_amd import _nn  # noqa: E402
+from test_cts_own import cts_policy_grads_vs_autograd, cts_student_grads_vs_autograd, latent_pieces_vs_torch  # noqa: E402
+
+FULL = dict(actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128], teacher_encoder_hidden_dims=[512, 256], student_encoder_hidden_dims=[512, 256], latent_dim=32)
+SMALL = dict(actor_hidden_dims=[64, 32, 16], critic_hidden_dims=[64, 32, 16], teacher_encoder_hidden_dims=[48, 24], student_encoder_hidden_dims=[40, 24], latent_dim=8)
+
+
+@pytest.mark.parametrize("n,L,pa,pb", [(1, 4, 4, 9), (37, 8, 53, 271), (18432, 32, 77, 295), (6144, 32, 32, 32), (1500, 128, 128, 130), (513, 16, 61, 279)])
+def test_latent_pieces_on_gpu(n, L, pa, pb):
+    latent_pieces_vs_torch(_nn.load_nn(), "cuda:0", n, L, pa, pb)
+
+
+@pytest.mark.parametrize("kind,B,n_t,dims", [("CTS", 24576, 18432, FULL), ("MoECTS", 24576, 18432, FULL), ("CTS", 1000, 750, FULL), ("CTS", 4099, 3001, SMALL), ("CTS", 300, 220, None)])
+def test_cts_policy_step_on_gpu(kind, B, n_t, dims):
+    priv = 263 if dims is FULL else 60
+    a = cts_policy_grads_vs_autograd(_nn.load_nn(), load_hip(), "cuda:0", kind, B, n_t, dims, atol=3e-6, priv=priv)
+    b = cts_policy_grads_vs_autograd(_nn.load_nn(), load_hip(), "cuda:0", kind, B, n_t, dims, atol=3e-6, priv=priv)
+    torch.cuda.synchronize()
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("n,dims", [(6144, FULL), (1000, FULL), (67, SMALL), (150, None)])
+def test_cts_student_step_on_gpu(n, dims):
+    priv = 263 if dims is FULL else 60
+    a = cts_student_grads_vs_autograd(_nn.load_nn(), load_hip(), "cuda:0", n, dims, priv=priv)
+    b = cts_student_grads_vs_autograd(_nn.load_nn(), load_hip(), "cuda:0", n, dims, priv=priv)
+    torch.cuda.synchronize()
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
