@@ -42,6 +42,10 @@ class Go2nnPpoHeads(C.Structure):
                [(k, C.c_float) for k in ("clip", "value_loss_coef", "entropy_coef")] + [("surrogate_split", C.c_int32)]          # ABI 5: CTS' teacher rows (0: plain PPO)
 
 
+class Go2nnMlpIO(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("x2", C.c_void_p), ("rows", C.c_void_p), ("y", C.c_void_p)] + [(k, C.c_int32) for k in ("ldx", "ldx2", "kx", "nrows", "ldy", "normalize")]
+
+
 class Go2nnMlp(C.Structure):
     _fields_ = [("num_layers", C.c_int32), ("dims", C.c_int32 * (GO2NN_MAX_LAYERS + 1)),
                 ("weight", C.c_void_p * GO2NN_MAX_LAYERS), ("bias", C.c_void_p * GO2NN_MAX_LAYERS)]
@@ -55,6 +59,8 @@ def bind(path):
     lib.go2nn_pack.argtypes = [C.POINTER(Go2nnMlp), C.c_void_p, C.c_void_p]
     lib.go2nn_mlp_forward.argtypes = [C.POINTER(Go2nnMlp), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.go2nn_policy_act.argtypes = [C.POINTER(Go2nnMlp), C.c_void_p, C.POINTER(Go2nnMlp), C.c_void_p] + [C.c_void_p] * 10 + [C.c_int32, C.c_void_p]
+    lib.go2nn_mlp_forward_rows.argtypes = [C.POINTER(C.POINTER(Go2nnMlp)), C.POINTER(C.c_void_p), C.POINTER(Go2nnMlpIO), C.c_int32, C.c_void_p]
+    lib.go2nn_policy_act_latent.argtypes = [C.POINTER(Go2nnMlp), C.c_void_p, C.POINTER(Go2nnMlp), C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 10 + [C.c_int32, C.c_void_p]
     lib.go2nn_head_backward_workspace.restype = C.c_int64
     lib.go2nn_head_backward_workspace.argtypes = [C.c_int32] * 3
     lib.go2nn_head_backward.argtypes = [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_void_p]
@@ -122,8 +128,11 @@ class PackedMlp:
     """One MLP's parameters as the kernels read them: the Go2nnMlp descriptor (pointers to the LIVE parameter tensors) and the packed operand
     buffer, refreshed by pack() — one small launch — whenever the parameters have changed (once per rollout: they only change in update())."""
 
-    def __init__(self, lib, seq):
-        layers = mlp_layers(seq)
+    def __init__(self, lib, seq, linears=None):
+        """seq: an nn.Sequential of Linear / ELU; or linears: the Linear modules of such a stack (wherever they live: nested containers, a normaliser behind them)"""
+        layers = mlp_layers(seq) if linears is None else [(m.weight, m.bias) for m in linears]
+        if layers is not None and (len(layers) > GO2NN_MAX_LAYERS or max([layers[0][0].shape[1]] + [w.shape[0] for w, _ in layers]) > GO2NN_MAX_WIDTH):
+            layers = None
         if layers is None:
             raise ValueError("not a Linear/ELU MLP the kernel supports")
         self.lib, self.layers = lib, layers
@@ -194,4 +203,63 @@ class PolicyKernel:
                                        p(self.ac.std.detach()), p(eps), p(actions), p(a_st), p(mu_st), p(sig_st), p(lp_st), p(v_st), N, self.actor._stream())
         if rc != 0:
             raise RuntimeError("go2nn_policy_act failed: %s" % self.lib.go2nn_last_error().decode())
+        return actions
+
+
+class PolicyKernelCTS:
+    """CTS.act of one rollout step (rsl_rl/rsl_rl/algorithms/cts.py:112-149 over modules/actor_critic_cts.py:146-176) as TWO launches:
+    both encoders on their env subsets -> the env-ordered normalised latent (go2nn_mlp_forward_rows), then actor([latent | obs]) + critic([latent | privileged obs]) +
+    the sampling head (go2nn_policy_act_latent).  plan: modules/fused_cts.py:CtsPlan (which Linear modules make up the four networks); a model whose student encoder
+    is not a plain MLP (the MoE variants) leaves the student rows of the latent to the caller."""
+
+    def __init__(self, lib, model, plan, teacher_idx, student_idx):
+        self.lib, self.model, self.L = lib, model, plan.L
+        self.enc_t = PackedMlp(lib, None, linears=plan.teacher)
+        self.enc_s = PackedMlp(lib, None, linears=plan.student) if plan.student is not None else None
+        self.actor, self.critic = PackedMlp(lib, None, linears=plan.actor), PackedMlp(lib, None, linears=plan.critic)
+        if self.actor.out_dim > 32 or self.critic.out_dim != 1:
+            raise ValueError("head: up to 32 actions and a scalar value")
+        self.ti, self.si = teacher_idx.to(torch.int32).contiguous(), student_idx.to(torch.int32).contiguous()
+        self._nets = [self.enc_t] + ([self.enc_s] if self.enc_s is not None else [])
+
+    def pack(self):
+        for m in self._nets + [self.actor, self.critic]:
+            m.pack()
+
+    def _rows(self, nets, ios):
+        n = len(nets)
+        descs = (C.POINTER(Go2nnMlp) * n)(*[C.pointer(m.desc) for m in nets])
+        packed = (C.c_void_p * n)(*[m.packed.data_ptr() for m in nets])
+        rc = self.lib.go2nn_mlp_forward_rows(descs, packed, (Go2nnMlpIO * n)(*ios), n, nets[0]._stream())
+        if rc != 0:
+            raise RuntimeError("go2nn_mlp_forward_rows failed: %s" % self.lib.go2nn_last_error().decode())
+
+    def latents(self, privileged_obs, history, latent):
+        """latent [N, L] (env order) <- L2Norm(teacher_encoder(privileged_obs[teacher envs])), L2Norm(student_encoder(history[student envs])) — one launch
+        (the student rows only when the student encoder is a plain MLP)"""
+        for t in (privileged_obs, history, latent):
+            assert t.is_contiguous() and t.dtype == torch.float32
+        L = self.L
+        ios = [Go2nnMlpIO(privileged_obs.data_ptr(), None, self.ti.data_ptr(), latent.data_ptr(), privileged_obs.shape[1], 0, privileged_obs.shape[1], self.ti.numel(), L, 1)]
+        if self.enc_s is not None:
+            ios.append(Go2nnMlpIO(history.data_ptr(), None, self.si.data_ptr(), latent.data_ptr(), history.shape[1], 0, history.shape[1], self.si.numel(), L, 1))
+        self._rows(self._nets, ios)
+
+    def value(self, latent, privileged_obs):
+        """critic([latent | privileged obs]) -> [N, 1] (the bootstrap value of compute_returns), one launch on the packed weights"""
+        N = latent.shape[0]
+        v = torch.empty(N, 1, dtype=torch.float32, device=latent.device)
+        self._rows([self.critic], [Go2nnMlpIO(latent.data_ptr(), privileged_obs.data_ptr(), None, v.data_ptr(), self.L, privileged_obs.shape[1], self.L, N, 1, 0)])
+        return v
+
+    def act(self, latent, obs, privileged_obs, eps, a_st=None, mu_st=None, sig_st=None, lp_st=None, v_st=None):
+        N, A = obs.shape[0], self.actor.out_dim
+        actions = torch.empty(N, A, dtype=torch.float32, device=obs.device)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        for t in (latent, obs, privileged_obs, eps, a_st, mu_st, sig_st, lp_st, v_st):
+            assert t is None or (t.is_contiguous() and t.dtype == torch.float32), "contiguous float32 tensors"
+        rc = self.lib.go2nn_policy_act_latent(C.byref(self.actor.desc), p(self.actor.packed), C.byref(self.critic.desc), p(self.critic.packed), p(latent), self.L, p(obs), p(privileged_obs),
+                                              p(self.model.std.detach()), p(eps), p(actions), p(a_st), p(mu_st), p(sig_st), p(lp_st), p(v_st), N, self.actor._stream())
+        if rc != 0:
+            raise RuntimeError("go2nn_policy_act_latent failed: %s" % self.lib.go2nn_last_error().decode())
         return actions

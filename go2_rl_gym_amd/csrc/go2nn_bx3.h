@@ -327,7 +327,9 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
     constexpr int G = (DA % 2) ? 2 * DA : DA;
     for (int kt = 0; kt < nkp; kt += G)
       g3_for<0, G>([&](auto j_c) __attribute__((always_inline)) { constexpr int J = decltype(j_c)::value; if (kt + J < nkp) tile(G3Int<J & 1>{}, G3Int<J % DA>{}, kt + J + 1 < nkp, kt + J); });
-  }
+  } else if constexpr (TM == 2) {
+    load_y(G3Int<0>{});          // (a contraction shorter than one k-tile — the 8-wide latent of the toy CTS networks — has no pipelined loop: the first slab's ELU outputs are requested here.
+  }                              //  Round 5: found by the CTS student step at K = 8, where the slab was read uninitialised)
   if constexpr (!WG) if (ragged) {
     __syncthreads();
     sa.issue((nk - 1) * BK, ba[0]); issue_b(nk - 1);

@@ -47,12 +47,20 @@ struct NetDesc {
   int32_t KB[GO2NN_MAX_LAYERS], NT[GO2NN_MAX_LAYERS];    // k-blocks of 8, output tiles of 32
   int64_t woff[GO2NN_MAX_LAYERS], boff[GO2NN_MAX_LAYERS];
   const float* packed; const float* x;
+  // ABI 5 (the CTS rollout): the input row is two segments — columns [0, kx) from x (row pitch ldx), [kx, in_dim) from x2 (pitch ldx2) —, the network runs on
+  // the rows `rows[0 .. nrows)` of its inputs (NULL: rows 0 .. nrows - 1), and mode 0 stores y[row * ldy + n], L2-normalised when `normalize`
+  const float* x2; const int32_t* rows; float* y;
+  int32_t ldx, ldx2, kx, nrows, ldy, normalize;
 };
 struct NNArgs {
   NetDesc net[2];
   const float *std_, *eps; float *a_out, *a_st, *mu_st, *sig_st, *lp_st, *v_st; float* y;
-  int32_t N, A, mode;           // mode 0: forward of net[0] into y; mode 1: policy act (net[0] actor, net[1] critic)
+  int32_t N, A, mode;           // mode 0: forward of every net (grid.y) into its own y; mode 1: policy act (net[0] actor, net[1] critic); N = the largest nrows
 };
+// the plain case: one dense input matrix, rows 0 .. N - 1, dense output
+static inline void net_io(NetDesc& d, const float* x, int N, float* y) {
+  d.x = x; d.x2 = nullptr; d.rows = nullptr; d.y = y; d.ldx = d.in_dim; d.ldx2 = 0; d.kx = d.in_dim; d.nrows = N; d.ldy = d.out_dim; d.normalize = 0;
+}
 
 static int describe(const Go2nnMlp* m, NetDesc* d, int64_t* total) {
   if (!m || m->num_layers <= 0 || m->num_layers > GO2NN_MAX_LAYERS) return 0;
@@ -178,14 +186,18 @@ __global__ void __launch_bounds__(NN_THREADS) go2nn_mlp_kernel(const NNArgs a) {
 #define NN_STAMP(k) do { } while (0)
 #endif
   NN_STAMP(0);
+  if (row0 >= nd.nrows) return;          // (the two networks of a launch may run on different numbers of rows: whole workgroups past a network's rows leave)
   {   // stage the workgroup's input rows, zero-padded to the first layer's k-blocks
     // (a wave takes its share of the rows, its lanes run along the row: coalesced, no division; all of a thread's loads are in flight together)
-    const int Kp = nd.KB[0] * 8, K0 = nd.in_dim, w = tid >> 6;
+    const int Kp = nd.KB[0] * 8, K0 = nd.in_dim, kx = nd.kx, w = tid >> 6;
 #pragma unroll
     for (int r = 0; r < NN_ROWS / NN_WAVES; ++r) {
-      const int i = w * (NN_ROWS / NN_WAVES) + r; const bool live = row0 + i < a.N;
-      const float* __restrict__ src = nd.x + (int64_t)(live ? row0 + i : 0) * K0;
-      for (int k = lane; k < Kp; k += 64) A[i * NN_LD + k] = (live && k < K0) ? src[k] : 0.f;
+      const int i = w * (NN_ROWS / NN_WAVES) + r; const bool live = row0 + i < nd.nrows;
+      const int e = live ? row0 + i : nd.nrows - 1;
+      const int64_t sr = nd.rows ? nd.rows[e] : e;
+      const float* __restrict__ src = nd.x + sr * nd.ldx;
+      const float* __restrict__ src2 = nd.x2 ? nd.x2 + sr * nd.ldx2 - kx : src;          // (indexed with k >= kx only)
+      for (int k = lane; k < Kp; k += 64) A[i * NN_LD + k] = (live && k < K0) ? (k < kx ? src[k] : src2[k]) : 0.f;
     }
   }
   __syncthreads();
@@ -207,9 +219,16 @@ __global__ void __launch_bounds__(NN_THREADS) go2nn_mlp_kernel(const NNArgs a) {
   // A now holds the network's output tile [32][32 NT_last]
   if (a.mode == 0) {
     const int No = nd.out_dim;
+    if (nd.normalize) {          // F.normalize(x, p=2, dim=-1): x / max(|x|, 1e-12), the scale of row r parked behind its last column (No <= 512 < NN_LD)
+      if (tid < NN_ROWS) { float ss = 0.f; for (int n = 0; n < No; ++n) ss += A[tid * NN_LD + n] * A[tid * NN_LD + n]; A[tid * NN_LD + No] = 1.f / fmaxf(sqrtf(ss), 1e-12f); }
+      __syncthreads();
+    }
     for (int idx = tid; idx < NN_ROWS * No; idx += NN_THREADS) {
       const int r = idx / No, n = idx - r * No;
-      if (row0 + r < a.N) a.y[(int64_t)(row0 + r) * No + n] = A[r * NN_LD + n];
+      if (row0 + r < nd.nrows) {
+        const int64_t dr = nd.rows ? nd.rows[row0 + r] : row0 + r;
+        nd.y[dr * nd.ldy + n] = nd.normalize ? A[r * NN_LD + n] * A[r * NN_LD + No] : A[r * NN_LD + n];
+      }
     }
     return;
   }
@@ -247,7 +266,11 @@ __global__ void __launch_bounds__(NN_THREADS) go2nn_mlp_kernel(const NNArgs a) {
 static void emu_forward(const NetDesc& nd, int N, int row0, float out[NN_ROWS][GO2NN_MAX_WIDTH]) {
   static thread_local float A[NN_ROWS][NN_LD], B[NN_ROWS][NN_LD];
   memset(A, 0, sizeof(A));
-  for (int i = 0; i < NN_ROWS; ++i) for (int k = 0; k < nd.in_dim; ++k) A[i][k] = row0 + i < N ? nd.x[(int64_t)(row0 + i) * nd.in_dim + k] : 0.f;
+  (void)N;
+  for (int i = 0; i < NN_ROWS && row0 + i < nd.nrows; ++i) {
+    const int64_t sr = nd.rows ? nd.rows[row0 + i] : row0 + i;
+    for (int k = 0; k < nd.in_dim; ++k) A[i][k] = k < nd.kx ? nd.x[sr * nd.ldx + k] : nd.x2[sr * nd.ldx2 + (k - nd.kx)];
+  }
   for (int l = 0; l < nd.nl; ++l) {
     const float* Wp = nd.packed + nd.woff[l]; const float* bp = nd.packed + nd.boff[l];
     memset(B, 0, sizeof(B));
@@ -362,10 +385,19 @@ static int run(NNArgs& a, int nets, void* stream) {
   (void)stream;
   static thread_local float out[2][NN_ROWS][GO2NN_MAX_WIDTH];
   for (int row0 = 0; row0 < a.N; row0 += NN_ROWS) {
-    for (int y = 0; y < nets; ++y) emu_forward(a.net[y], a.N, row0, out[y]);
+    for (int y = 0; y < nets; ++y) if (row0 < a.net[y].nrows) emu_forward(a.net[y], a.N, row0, out[y]);
+    if (a.mode == 0) {
+      for (int y = 0; y < nets; ++y) { const NetDesc& nd = a.net[y];
+        for (int r = 0; r < NN_ROWS && row0 + r < nd.nrows; ++r) {
+          float inv = 1.f;
+          if (nd.normalize) { float ss = 0.f; for (int n = 0; n < nd.out_dim; ++n) ss += out[y][r][n] * out[y][r][n]; inv = 1.f / fmaxf(sqrtf(ss), 1e-12f); }
+          const int64_t dr = nd.rows ? nd.rows[row0 + r] : row0 + r;
+          for (int n = 0; n < nd.out_dim; ++n) nd.y[dr * nd.ldy + n] = nd.normalize ? out[y][r][n] * inv : out[y][r][n];
+        } }
+      continue;
+    }
     for (int r = 0; r < NN_ROWS && row0 + r < a.N; ++r) {
       const int e = row0 + r;
-      if (a.mode == 0) { for (int n = 0; n < a.net[0].out_dim; ++n) a.y[(int64_t)e * a.net[0].out_dim + n] = out[0][r][n]; continue; }
       float lp = 0.f;
       for (int j = 0; j < a.A; ++j) {
         const int64_t k = (int64_t)e * a.A + j;
@@ -387,8 +419,24 @@ static int run(NNArgs& a, int nets, void* stream) {
 int go2nn_mlp_forward(const Go2nnMlp* m, const float* packed, const float* x, float* y, int32_t N, void* stream) {
   NNArgs a; memset(&a, 0, sizeof(a));
   if (!packed || !x || !y || N <= 0 || !describe(m, &a.net[0], nullptr)) FAIL(GO2NN_EINVAL, "bad argument");
-  a.net[0].packed = packed; a.net[0].x = x; a.y = y; a.N = N; a.mode = 0;
+  a.net[0].packed = packed; net_io(a.net[0], x, N, y); a.N = N; a.mode = 0;
   return run(a, 1, stream);
+}
+
+int go2nn_mlp_forward_rows(const Go2nnMlp* const* nets, const float* const* packed, const Go2nnMlpIO* io, int32_t nnets, void* stream) {
+  NNArgs a; memset(&a, 0, sizeof(a));
+  if (!nets || !packed || !io || nnets < 1 || nnets > 2) FAIL(GO2NN_EINVAL, "forward rows: 1 or 2 networks");
+  for (int j = 0; j < nnets; ++j) {
+    NetDesc& d = a.net[j]; const Go2nnMlpIO& q = io[j];
+    if (!packed[j] || !describe(nets[j], &d, nullptr)) FAIL(GO2NN_EINVAL, "forward rows: bad network %d", j);
+    const int k2 = d.in_dim - q.kx;
+    if (!q.x || !q.y || q.nrows <= 0 || q.kx < 1 || q.kx > d.in_dim || q.ldx < q.kx || (k2 > 0 && (!q.x2 || q.ldx2 < k2)) || q.ldy < d.out_dim)
+      FAIL(GO2NN_EINVAL, "forward rows: bad input / output description of network %d (segments %d + %d of %d inputs)", j, q.kx, k2, d.in_dim);
+    d.packed = packed[j]; d.x = q.x; d.x2 = k2 > 0 ? q.x2 : nullptr; d.rows = q.rows; d.y = q.y; d.ldx = q.ldx; d.ldx2 = q.ldx2; d.kx = q.kx; d.nrows = q.nrows; d.ldy = q.ldy; d.normalize = q.normalize ? 1 : 0;
+    a.N = std::max(a.N, q.nrows);
+  }
+  a.mode = 0;
+  return run(a, nnets, stream);
 }
 
 int go2nn_policy_act(const Go2nnMlp* actor, const float* actor_packed, const Go2nnMlp* critic, const float* critic_packed,
@@ -398,7 +446,24 @@ int go2nn_policy_act(const Go2nnMlp* actor, const float* actor_packed, const Go2
   if (!actor_packed || !critic_packed || !obs || !critic_obs || !std_ || !eps || !a_out || N <= 0 || !describe(actor, &a.net[0], nullptr) || !describe(critic, &a.net[1], nullptr))
     FAIL(GO2NN_EINVAL, "bad argument");
   if (a.net[0].out_dim > 32 || a.net[1].out_dim != 1) FAIL(GO2NN_EINVAL, "the head handles up to 32 actions and a scalar value (got %d, %d)", a.net[0].out_dim, a.net[1].out_dim);
-  a.net[0].packed = actor_packed; a.net[0].x = obs; a.net[1].packed = critic_packed; a.net[1].x = critic_obs;
+  a.net[0].packed = actor_packed; net_io(a.net[0], obs, N, nullptr); a.net[1].packed = critic_packed; net_io(a.net[1], critic_obs, N, nullptr);
+  a.std_ = std_; a.eps = eps; a.a_out = a_out; a.a_st = a_st; a.mu_st = mu_st; a.sig_st = sig_st; a.lp_st = lp_st; a.v_st = v_st;
+  a.N = N; a.A = a.net[0].out_dim; a.mode = 1;
+  return run(a, 2, stream);
+}
+
+int go2nn_policy_act_latent(const Go2nnMlp* actor, const float* actor_packed, const Go2nnMlp* critic, const float* critic_packed,
+                            const float* latent, int32_t L, const float* obs, const float* critic_obs, const float* std_, const float* eps,
+                            float* a_out, float* a_st, float* mu_st, float* sig_st, float* lp_st, float* v_st, int32_t N, void* stream) {
+  NNArgs a; memset(&a, 0, sizeof(a));
+  if (!actor_packed || !critic_packed || !latent || !obs || !critic_obs || !std_ || !eps || !a_out || N <= 0 || !describe(actor, &a.net[0], nullptr) || !describe(critic, &a.net[1], nullptr))
+    FAIL(GO2NN_EINVAL, "bad argument");
+  if (a.net[0].out_dim > 32 || a.net[1].out_dim != 1) FAIL(GO2NN_EINVAL, "the head handles up to 32 actions and a scalar value (got %d, %d)", a.net[0].out_dim, a.net[1].out_dim);
+  if (L < 1 || L >= a.net[0].in_dim || L >= a.net[1].in_dim) FAIL(GO2NN_EINVAL, "latent width %d against input widths %d / %d", L, a.net[0].in_dim, a.net[1].in_dim);
+  for (int j = 0; j < 2; ++j) {
+    NetDesc& d = a.net[j];
+    d.packed = j ? critic_packed : actor_packed; d.x = latent; d.ldx = L; d.kx = L; d.x2 = j ? critic_obs : obs; d.ldx2 = d.in_dim - L; d.rows = nullptr; d.y = nullptr; d.nrows = N; d.ldy = d.out_dim; d.normalize = 0;
+  }
   a.std_ = std_; a.eps = eps; a.a_out = a_out; a.a_st = a_st; a.mu_st = mu_st; a.sig_st = sig_st; a.lp_st = lp_st; a.v_st = v_st;
   a.N = N; a.A = a.net[0].out_dim; a.mode = 1;
   return run(a, 2, stream);
@@ -568,7 +633,7 @@ int go2nn_policy_act_stamped(const Go2nnMlp* actor, const float* actor_packed, c
                              const float* obs, const float* critic_obs, const float* std_, const float* eps, float* a_out, void* stamps, int32_t N, void* stream) {
   NNArgs a; memset(&a, 0, sizeof(a));
   if (!describe(actor, &a.net[0], nullptr) || !describe(critic, &a.net[1], nullptr)) return GO2NN_EINVAL;
-  a.net[0].packed = actor_packed; a.net[0].x = obs; a.net[1].packed = critic_packed; a.net[1].x = critic_obs;
+  a.net[0].packed = actor_packed; net_io(a.net[0], obs, N, nullptr); a.net[1].packed = critic_packed; net_io(a.net[1], critic_obs, N, nullptr);
   a.std_ = std_; a.eps = eps; a.a_out = a_out; a.y = (float*)stamps; a.N = N; a.A = a.net[0].out_dim; a.mode = 1;
   return run(a, 2, stream);
 }
@@ -780,7 +845,19 @@ int go2nn_linear_backward_input_group(const Go2nnBwdInJob* jobs, int32_t njobs, 
     if (tm1 != tm || tn1 != tn || bk1 != bk) { const int rc = go2nn_linear_backward_input_group(jobs, 1, stream); return rc ? rc : go2nn_linear_backward_input_group(jobs + 1, 1, stream); } }
   for (int j = 0; j < njobs; ++j) if (jobs[j].C < 4 || jobs[j].Kin < 4 || jobs[j].Kin % 4) {          // (column quads of W must not straddle Kin) -> the single-network kernels
     if (plain) FAIL(GO2NN_EINVAL, "plain input gradient on the fp32-MFMA kernels: C >= 4 and Kin a multiple of 4 (the split-operand kernel takes any Kin)");
-    for (int i = 0; i < njobs; ++i) { const int rc = go2nn_linear_backward_input(jobs[i].gz, jobs[i].w, jobs[i].y_prev, jobs[i].gz_prev, nullptr, jobs[i].workspace, jobs[i].M, jobs[i].C, jobs[i].Kin, stream); if (rc) return rc; }
+    // (go2nn_linear_backward_input picks its own tile height — 128 rows for Kin >= 512 — and then leaves HALF the partial rows the group's callers were told
+    //  to sum, go2nn_linear_backward_input_group_rows = one per 64 rows: the single-network kernel is launched here with 64-row tiles whatever the shape)
+    for (int i = 0; i < njobs; ++i) {
+      const Go2nnBwdInJob& q = jobs[i];
+      GemmArgs g; memset(&g, 0, sizeof(g));
+      int tm1, tn1; gemm_tile(q.M, q.Kin, &tm1, &tn1); tm1 = 1;
+      g.A = q.gz; g.B = q.w; g.C = q.gz_prev; g.Y = q.y_prev; g.part = q.workspace; g.M = q.M; g.N = q.Kin; g.K = q.C; g.lda = q.C; g.ldb = q.Kin; g.ldc = q.Kin;
+      const bool vec = (q.C % 4 == 0) && (q.Kin % 4 == 0) && aligned16(q.gz) && aligned16(q.w);
+      g.kchunk = cdiv(q.C, GM_BK) * GM_BK; g.nbm = cdiv(q.M, gm_tile_rows(tm1)); g.nbn = cdiv(q.Kin, 64 * tn1);
+      g.c_vec = (q.Kin % 4 == 0) && aligned16(q.gz_prev) && aligned16(q.y_prev);
+      gemm_dispatch<true, false, EPI_DELU_COLSUM>(tm1, tn1, g, 1, vec, (hipStream_t)stream);
+      HIPCHK(hipGetLastError());
+    }
     return 0; }
   Gemm3Args a; memset(&a, 0, sizeof(a));
   for (int j = 0; j < njobs; ++j) {

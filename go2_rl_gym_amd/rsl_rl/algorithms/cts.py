@@ -129,6 +129,20 @@ class CTS(_RolloutHeads):
         if privileged_obs.data_ptr() != st.privileged_observations[s].data_ptr():
             st.privileged_observations[s].copy_(privileged_obs)
         st.history[s].copy_(history)
+        pk = self._policy_kernel() if self.fused_rollout else None
+        if pk is not None and all(x.is_contiguous() and x.dtype == torch.float32 for x in (obs, privileged_obs, history)):
+            # two launches (include/go2nn.h ABI 5): both encoders on their env subsets -> the env-ordered latent; actor + critic + sampling head on [latent | obs] / [latent | priv]
+            if s == 0 or not self._pk_packed:
+                pk.pack()                  # the parameters only change in update(): once per rollout (inside the captured rollout graph too)
+                self._pk_packed = True
+                self._pk_recorded = self._pk_recorded or s == 0
+            latent = self._rollout_latent(pk, privileged_obs, history)
+            actions = pk.act(latent, obs, privileged_obs, self._rollout_noise(m, st, s), st.actions[s], st.mu[s], st.sigma[s], st.actions_log_prob[s].view(-1), st.values[s].view(-1))
+            t.actions, t.values, t.actions_log_prob = actions, st.values[s], st.actions_log_prob[s].view(-1)
+            t.action_mean, t.action_sigma = st.mu[s], st.sigma[s]
+            return actions
+        if s == 0:
+            self._pk_recorded = False
         latent = self._latent_env_order(privileged_obs, history)
         if self.fused_rollout:
             mu, value = self._pair(lambda: m.policy_mean(latent, obs), lambda: m.evaluate_joint(privileged_obs, latent, obs), enabled=self._capture and not m.heads_share_parameters)
@@ -160,9 +174,49 @@ class CTS(_RolloutHeads):
         self.model.history.masked_fill_(dones.view(-1, 1, 1) > 0, 0.0)          # model.reset(dones) (:163) without a boolean-index sync
 
     def compute_returns(self, last_privileged_obs, last_history, last_obs=None):
-        latent = self._latent_env_order(last_privileged_obs, last_history)
-        last_values = self.model.evaluate_joint(last_privileged_obs, latent, last_obs).detach()
+        pk = self._pk if self._pk not in (None, False) else None
+        if pk is not None and self._pk_packed and all(x.is_contiguous() and x.dtype == torch.float32 for x in (last_privileged_obs, last_history)):
+            last_values = pk.value(self._rollout_latent(pk, last_privileged_obs, last_history), last_privileged_obs)      # on the weights packed for this rollout (unchanged since)
+        else:
+            latent = self._latent_env_order(last_privileged_obs, last_history)
+            last_values = self.model.evaluate_joint(last_privileged_obs, latent, last_obs).detach()
         self.storage.compute_returns(last_values, self.gamma, self.lam)
+
+    _pk = None
+
+    def _policy_kernel(self):
+        """-> _nn.PolicyKernelCTS for this model, or None (GO2_FUSED_POLICY=0, or heads / encoders the kernel does not cover: modules/fused_cts.py:cts_plan).  On a
+        GPU the library must be there (fused.set_library raises otherwise); nn_lib: tests hand in the host build."""
+        if self._pk is None:
+            self._pk = False
+            nn_lib = getattr(self, "nn_lib", None)
+            on = nn_lib is not None or (str(self.device).startswith("cuda") and self.lib is not None and os.environ.get("GO2_FUSED_POLICY", "1") == "1")
+            if on and self.storage is not None and self.storage.privileged_observations is not None:
+                from ..modules import fused, fused_cts
+                from ... import _nn
+                lib = nn_lib if nn_lib is not None else (fused._NN if fused._NN is not None else _nn.load_nn())
+                saved = fused._NN
+                fused._NN = lib
+                try:
+                    plan = fused_cts.cts_plan(self.model)
+                finally:
+                    fused._NN = saved
+                try:
+                    if plan is not None:
+                        self._pk = _nn.PolicyKernelCTS(lib, self.model, plan, self.teacher_env_idxs, self.student_env_idxs)
+                        self._latent_buf = torch.zeros(self.storage.num_envs, plan.L, device=self.device)
+                except ValueError:          # (a width the kernel's LDS tiles do not hold)
+                    self._pk = False
+        return self._pk if self._pk is not False else None
+
+    def _rollout_latent(self, pk, privileged_obs, history):
+        """-> the env-ordered latent [N, L]: one launch for both encoders; a student encoder that is not a plain MLP (MoE) runs as torch modules, without gradient, on the same stream"""
+        latent = self._latent_buf
+        if pk.enc_s is None:
+            with torch.no_grad():
+                latent.index_copy_(0, self.student_env_idxs, self.model.student_latent(history[self.student_env_idxs])[0])
+        pk.latents(privileged_obs, history, latent)
+        return latent
 
     # ------------------------------------------------------------------ update half (:167-286)
     def _policy_losses(self, obs_b, priv_b, hist_b, act_b, tv_b, adv_b, ret_b, old_lp_b, old_mu_b, old_sig_b, n_t):
@@ -453,6 +507,7 @@ class CTS(_RolloutHeads):
         return bool(self.use_graphs and self._capture and all_captured(self._steps))
 
     def update(self):
+        self._pk_packed = False          # the optimizer steps below change the parameters: the next rollout re-packs
         out = self._update_graphs() if self.use_graphs else self._update_eager()
         self.storage.clear()
         return out

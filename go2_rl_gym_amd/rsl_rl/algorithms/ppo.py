@@ -63,12 +63,33 @@ def allreduce_mean_bucket(grads, world, extra=None):
 
 
 _RANDPERM = torch.randperm          # (the golden tests replace torch.randperm to replay the reference's permutation: then the update takes that one)
-_PLAIN_NOISE = _AC._noise          # (the tests replace ActorCritic._noise to inject the reference's draws: then the rollout asks per step)
+
+
+from ..modules.actor_critic_cts import ActorCriticCTS as _ACC          # noqa: E402
+_PLAIN = (_AC._noise, _ACC._noise)          # the modules' own _noise functions as they are at import (the tests replace them to inject the reference's draws: then the rollout asks per step)
 
 
 class _RolloutHeads:
     """Shared pieces of the PPO-family algorithms: two-stream actor/critic evaluation and the per-step rollout heads."""
     _side = None
+    _eps_all = None
+    _pk_packed = False          # the policy kernel's packed weights are those of the current parameters (they change in update() only)
+    _pk_recorded = False        # the rollout last RUN THROUGH PYTHON (eager, or while being captured) packed at its first step: what a replay of that capture does too
+
+    def _rollout_noise(self, ac, st, s):
+        """The standard-normal draws of step s ([N, A], the shape of the action rows).  One launch for the whole rollout at its first step instead of
+        one per step (24 small launches on the chain of dependent kernels); the same law as Normal.sample() per step (actor_critic.py:123-125).
+        A module whose _noise is overridden — the tests inject the reference's draws step by step — is asked per step as before."""
+        if getattr(type(ac), "_noise", None) not in _PLAIN:
+            return ac._noise(st.actions[s])
+        if s == 0 or self._eps_all is None or self._eps_all.shape != st.actions.shape or self._eps_all.device != st.actions.device:
+            self._eps_all = torch.randn_like(st.actions)
+        return self._eps_all[s]
+
+    def rollout_replayed(self):
+        """The runner replayed the captured rollout (act() did not run in Python): the weights are packed iff the captured rollout recorded the pack launch at its
+        first step — known from the flag act() left when it ran under capture (a rollout that took the non-kernel branch must not claim packed weights)."""
+        self._pk_packed = bool(self._pk_recorded)
 
     def _pair(self, main_fn, side_fn, enabled=True):
         """-> (main_fn(), side_fn()) with side_fn on a second HIP stream when on a GPU: the actor and the critic are independent
@@ -258,19 +279,6 @@ class PPO(_RolloutHeads):
         self.actor_critic.train()
 
     # ------------------------------------------------------------------ rollout half (ppo.py:90-118)
-    _eps_all = None
-    _pk_packed = False
-
-    def _rollout_noise(self, ac, st, s):
-        """The standard-normal draws of step s ([N, A], the shape of the action rows).  One launch for the whole rollout at its first step instead of
-        one per step (24 small launches on the chain of dependent kernels); the same law as Normal.sample() per step (actor_critic.py:123-125).
-        A module whose _noise is overridden — the tests inject the reference's draws step by step — is asked per step as before."""
-        if getattr(type(ac), "_noise", None) is not _PLAIN_NOISE:
-            return ac._noise(st.actions[s])
-        if s == 0 or self._eps_all is None or self._eps_all.shape != st.actions.shape or self._eps_all.device != st.actions.device:
-            self._eps_all = torch.randn_like(st.actions)
-        return self._eps_all[s]
-
     def act(self, obs, critic_obs):
         st, t, ac = self.storage, self.transition, self.actor_critic
         s = st.step
@@ -287,10 +295,13 @@ class PPO(_RolloutHeads):
                 if s == 0 or not self._pk_packed:
                     pk.pack()                  # the parameters only change in update(): once per rollout (inside the captured rollout graph too); a rollout whose
                     self._pk_packed = True     # first steps took the eager branch packs at its first kernel step
+                    self._pk_recorded = self._pk_recorded or s == 0
                 actions = pk.act(obs, critic_obs, self._rollout_noise(ac, st, s), st.actions[s], st.mu[s], st.sigma[s], st.actions_log_prob[s].view(-1), st.values[s].view(-1))
                 t.actions, t.values, t.actions_log_prob = actions, st.values[s], st.actions_log_prob[s].view(-1)
                 t.action_mean, t.action_sigma = st.mu[s], st.sigma[s]
                 return actions
+            if s == 0:
+                self._pk_recorded = False      # (this rollout does not start on the kernel: a replay of it must not claim packed weights)
             mu, value = self._pair(lambda: ac.actor(obs), lambda: ac.evaluate(critic_obs), enabled=self._capture)
             return self._act_head(mu, ac.std, self._rollout_noise(ac, st, s), value, s)
         t.actions = ac.act(obs).detach()
@@ -342,10 +353,6 @@ class PPO(_RolloutHeads):
         st.step += 1
         t.clear()
         self.actor_critic.reset(dones)
-
-    def rollout_replayed(self):
-        """The runner replayed the captured rollout (act() did not run in Python): the graph re-packed the policy kernel's weights at its first step."""
-        self._pk_packed = self._pk not in (None, False)
 
     def compute_returns(self, last_critic_obs):
         pk = self._pk if self._pk not in (None, False) else None

@@ -55,6 +55,25 @@ int go2nn_policy_act(const Go2nnMlp* actor, const float* actor_packed, const Go2
                      const float* obs, const float* critic_obs, const float* std, const float* eps,
                      float* a_out, float* a_st, float* mu_st, float* sig_st, float* lp_st, float* v_st, int32_t N, void* stream);
 
+/* ---- ABI 5: the same kernel in the rollout of the Concurrent Teacher-Student runner (rsl_rl/rsl_rl/runners/on_policy_runner_cts.py:135-160 -> algorithms/cts.py:112-149 ->
+ * modules/actor_critic_cts.py:146-176): per step the reference gathers teacher / student env rows, runs teacher_encoder(privileged obs) resp. student_encoder(history),
+ * normalises, cats [latent | obs] and [latent | privileged obs], runs actor and critic, samples — ~45 launches.  Here: TWO launches.
+ *   go2nn_mlp_forward_rows   up to two MLPs in one launch, each on its own row subset `rows[0 .. nrows)` of its inputs (the teacher / student envs; NULL: rows 0 .. nrows - 1),
+ *                            its input row made of two column segments (x: columns [0, kx), x2: the rest), its output stored at the SAME row index of y (pitch ldy),
+ *                            L2-normalised (F.normalize: x / max(|x|, 1e-12)) when `normalize` — both encoders write the env-ordered latent [N, L] directly
+ *   go2nn_policy_act_latent  go2nn_policy_act with the actor's input = [latent | obs] and the critic's = [latent | critic_obs] read as two segments (no cat);
+ *                            actor->dims[0] = L + obs width, critic->dims[0] = L + critic_obs width */
+typedef struct Go2nnMlpIO {
+  const float* x; const float* x2;      /* input segments (x2 may be NULL when kx = the network's input width) */
+  const int32_t* rows;                  /* device int32 [nrows] or NULL */
+  float* y;
+  int32_t ldx, ldx2, kx, nrows, ldy, normalize;
+} Go2nnMlpIO;
+int go2nn_mlp_forward_rows(const Go2nnMlp* const* nets, const float* const* packed, const Go2nnMlpIO* io, int32_t nnets, void* stream);
+int go2nn_policy_act_latent(const Go2nnMlp* actor, const float* actor_packed, const Go2nnMlp* critic, const float* critic_packed,
+                            const float* latent, int32_t L, const float* obs, const float* critic_obs, const float* std, const float* eps,
+                            float* a_out, float* a_st, float* mu_st, float* sig_st, float* lp_st, float* v_st, int32_t N, void* stream);
+
 /* ---- learner side: PPO.update's backward pass (rsl_rl/rsl_rl/algorithms/ppo.py:120-187; autograd over modules/actor_critic.py:50-75) ----
  *
  * Backward of an MLP's tail  h -> Linear -> ELU(alpha=1) -> y [B,K] -> Linear(W [C,K], b [C]) -> out [B,C]  for a NARROW output (C <= 16: the

@@ -101,6 +101,8 @@ def test_one_iteration_matches_reference(kind, fixture, fused, monkeypatch, tmp_
     alg.fused_loss = alg.fused_rollout = bool(fused)
     if own:
         assert alg.use_graphs and (alg._own_plan() is not None) == (kind in ("CTS", "MoECTS", "MoENGCTS")) and alg._own_student() == (kind == "CTS")
+        alg.nn_lib = load_nn_emu()          # the rollout through the host build of the two-launch policy step (go2nn_mlp_forward_rows + go2nn_policy_act_latent)
+        assert (alg._policy_kernel() is not None) == (kind in ("CTS", "MoECTS", "MoENGCTS"))
     np.testing.assert_array_equal(alg.teacher_env_idxs.numpy(), g["teacher_env_idxs"])
     np.testing.assert_array_equal(alg.student_env_idxs.numpy(), g["student_env_idxs"])
     sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w0_")}

@@ -41,3 +41,13 @@ def test_asymmetric_weights_catch_a_transposed_tile_on_gpu():
     x = torch.eye(64, device="cuda:0")[:50].contiguous()
     with torch.no_grad():
         np.testing.assert_allclose(m.forward(x).cpu().numpy(), seq(x).cpu().numpy(), atol=2e-5, rtol=1e-5)
+
+
+from test_policy_kernel import cts_policy_kernel_vs_modules  # noqa: E402
+
+
+@pytest.mark.parametrize("kind,N,full", [("CTS", 4096, True), ("MoECTS", 8192, True), ("CTS", 1000, True), ("CTS", 203, False), ("CTS", 5, False)])
+def test_cts_policy_kernel_on_gpu(kind, N, full):
+    """the two-launch CTS policy step (go2nn_mlp_forward_rows + go2nn_policy_act_latent) on the MI355X against the torch modules: row subsets whose sizes differ between
+    the two encoders (3 : 1), ragged last workgroups, the 295- and 77-wide two-segment inputs"""
+    cts_policy_kernel_vs_modules(_nn.load_nn(), "cuda:0", kind, N, full, atol=6e-6)          # (hipBLASLt sums in another order: a few ulp of the activations' scale, as above)

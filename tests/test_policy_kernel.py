@@ -114,3 +114,69 @@ def test_ppo_act_through_the_policy_kernel(tmp_path, monkeypatch):
         np.testing.assert_allclose(a[k][0].numpy(), b[k][0].numpy(), atol=2e-6, rtol=2e-6, err_msg=k)
     np.testing.assert_allclose(a["actions_log_prob"][0].numpy(), b["actions_log_prob"][0].numpy(), atol=2e-5)
     assert torch.isfinite(b["rewards"]).all() and abs(float(a["rewards"].mean() - b["rewards"].mean())) < 0.05
+
+
+def cts_policy_kernel_vs_modules(lib, device, kind="CTS", N=203, full=False, atol=3e-6):
+    """_nn.PolicyKernelCTS (go2nn_mlp_forward_rows + go2nn_policy_act_latent: CTS.act of one rollout step, rsl_rl/algorithms/cts.py:112-149) against the modules:
+    the env-ordered latent of both encoders on their env subsets, actor / critic on [latent | obs] / [latent | priv], the sampling head, the bootstrap value"""
+    from go2_rl_gym_amd.rsl_rl.modules import ActorCriticCTS, ActorCriticMoECTS, fused, fused_cts
+    torch.manual_seed(7)
+    dims = (dict(actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128], teacher_encoder_hidden_dims=[512, 256], student_encoder_hidden_dims=[512, 256], latent_dim=32) if full else
+            dict(actor_hidden_dims=[40, 24], critic_hidden_dims=[40, 24], teacher_encoder_hidden_dims=[48, 20], student_encoder_hidden_dims=[36, 28], latent_dim=8))
+    if kind == "MoECTS":
+        dims.update(student_encoder_hidden_dims=dims["student_encoder_hidden_dims"] + [16], expert_num=4)
+    n_priv = 263 if full else 61
+    model = (ActorCriticCTS if kind == "CTS" else ActorCriticMoECTS)(45, n_priv, 12, N, 5, init_noise_std=1.0, **dims).to(device)
+    with torch.no_grad():
+        model.std.copy_(torch.rand(12) * 0.8 + 0.3)
+    saved = (fused._LIB, fused._NN)
+    fused._LIB, fused._NN = object(), lib          # (cts_plan only asks whether the pair is there)
+    try:
+        plan = fused_cts.cts_plan(model)
+    finally:
+        fused._LIB, fused._NN = saved
+    assert plan is not None and (plan.student is not None) == (kind == "CTS")
+    ids = torch.arange(N, device=device)
+    ti, si = ids[ids % 4 != 0], ids[ids % 4 == 0]
+    pk = _nn.PolicyKernelCTS(lib, model, plan, ti, si); pk.pack()
+    g = torch.Generator().manual_seed(2)
+    r = lambda *s: torch.randn(*s, generator=g).to(device)
+    obs, priv, hist, eps = r(N, 45), r(N, n_priv) * 2, r(N, 225), r(N, 12)
+    with torch.no_grad():
+        lat_ref = torch.empty(N, plan.L, device=device)
+        lat_ref[ti] = model.teacher_encoder(priv[ti]); lat_ref[si] = model.student_latent(hist[si])[0]
+        mu_ref, v_ref = model.policy_mean(lat_ref, obs), model.evaluate_joint(priv, lat_ref, obs).view(-1)
+        a_ref = mu_ref + model.std * eps
+        lp_ref = torch.distributions.Normal(mu_ref, mu_ref * 0.0 + model.std).log_prob(a_ref).sum(-1)
+    latent = torch.full((N, plan.L), 9.0, device=device)
+    if pk.enc_s is None:
+        latent[si] = lat_ref[si]          # (the MoE student encoder is the caller's)
+    pk.latents(priv, hist, latent)
+    np.testing.assert_allclose(latent.cpu().numpy(), lat_ref.cpu().numpy(), atol=atol)
+    st = {k: torch.zeros(N, 12, device=device) for k in ("a", "mu", "sig")}; lp, v = torch.zeros(N, device=device), torch.zeros(N, device=device)
+    actions = pk.act(latent, obs, priv, eps, st["a"], st["mu"], st["sig"], lp, v)
+    np.testing.assert_allclose(st["mu"].cpu().numpy(), mu_ref.cpu().numpy(), atol=atol, rtol=2e-6)
+    np.testing.assert_allclose(v.cpu().numpy(), v_ref.cpu().numpy(), atol=atol, rtol=2e-6)
+    np.testing.assert_allclose(actions.cpu().numpy(), a_ref.cpu().numpy(), atol=atol, rtol=2e-6)
+    np.testing.assert_allclose(lp.cpu().numpy(), lp_ref.cpu().numpy(), atol=10 * atol, rtol=2e-6)
+    assert torch.equal(actions, st["a"]) and torch.equal(actions, st["mu"] + model.std.detach() * eps)
+    np.testing.assert_allclose(pk.value(latent, priv).view(-1).cpu().numpy(), v_ref.cpu().numpy(), atol=atol, rtol=2e-6)
+
+
+@pytest.mark.parametrize("kind,N,full", [("CTS", 203, False), ("MoECTS", 64, False), ("CTS", 5, False), ("CTS", 130, True)])
+def test_cts_policy_kernel_matches_modules(kind, N, full):
+    cts_policy_kernel_vs_modules(load_nn_emu(), "cpu", kind, N, full)
+
+
+def test_forward_rows_refuses_bad_descriptions():
+    import ctypes as C
+    lib = load_nn_emu()
+    ac = _ac(dims=(40, 24))
+    m = _nn.PackedMlp(lib, ac.critic); m.pack()
+    x, y = torch.zeros(4, 263), torch.zeros(4, 1)
+    descs, packed = (C.POINTER(_nn.Go2nnMlp) * 1)(C.pointer(m.desc)), (C.c_void_p * 1)(m.packed.data_ptr())
+    io = lambda **kw: (_nn.Go2nnMlpIO * 1)(_nn.Go2nnMlpIO(**dict(dict(x=x.data_ptr(), x2=None, rows=None, y=y.data_ptr(), ldx=263, ldx2=0, kx=263, nrows=4, ldy=1, normalize=0), **kw)))
+    assert lib.go2nn_mlp_forward_rows(descs, packed, io(), 1, None) == 0
+    assert lib.go2nn_mlp_forward_rows(descs, packed, io(kx=200), 1, None) < 0 and b"segments" in lib.go2nn_last_error()          # a second segment without x2
+    assert lib.go2nn_mlp_forward_rows(descs, packed, io(ldx=100), 1, None) < 0 and lib.go2nn_mlp_forward_rows(descs, packed, io(nrows=0), 1, None) < 0
+    assert lib.go2nn_mlp_forward_rows(descs, packed, io(), 3, None) < 0
