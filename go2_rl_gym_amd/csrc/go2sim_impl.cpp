@@ -901,6 +901,22 @@ __global__ void __launch_bounds__(256) go2_shuffle_gather_kernel(const Go2Gather
   }
 }
 
+__global__ void __launch_bounds__(256) go2_cts_indices_kernel(int64_t* __restrict__ out, int nmb, int nt, int ns, int tb, int sb, int ht, int hs, const int64_t* __restrict__ map, uint32_t* key) {
+  const uint32_t seed = key[0], counter = key[1];          // (read before this workgroup's ticket below)
+  const int r = blockIdx.x * 256 + threadIdx.x, mb = tb + sb;
+  if (r < nmb * mb) {
+    const int i = r / mb, j = r - i * mb;
+    const int64_t k = j < tb ? (int64_t)go2_shuffle_index((uint32_t)(i * tb + j), (uint32_t)nt, ht, seed, counter)
+                             : (int64_t)nt + (int64_t)go2_shuffle_index((uint32_t)(i * sb + j - tb), (uint32_t)ns, hs, seed ^ GO2_SHUFFLE_TAIL_SEED, counter);
+    out[r] = map ? map[k] : k;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {          // the last workgroup to finish advances the counter (go2_shuffle_gather_kernel's ticket)
+    const unsigned t = atomicAdd(&key[2], 1u);
+    if (t == gridDim.x - 1) { key[2] = 0u; __threadfence(); atomicAdd(&key[1], 1u); }
+  }
+}
+
 __global__ void __launch_bounds__(256) go2_history_push_kernel(float* __restrict__ hist, const float* __restrict__ obs, const uint8_t* __restrict__ dones, int N, int H, int D) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= N * D) return;
@@ -1668,6 +1684,24 @@ int go2sim_shuffle_gather(const Go2GatherJob* jobs, int32_t njobs, int32_t rows,
   a.njobs = njobs; a.rows = rows; a.h = h; a.indices = indices; a.key = key_state; a.clear = clear; a.nclear = nclear;
   const int nwg = (rows + GO2_GATHER_ROWS_PER_WG - 1) / GO2_GATHER_ROWS_PER_WG;
   hipLaunchKernelGGL(go2_shuffle_gather_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, a);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
+int go2sim_cts_minibatch_indices(int64_t* out, int32_t nmb, int32_t nt, int32_t ns, const int64_t* map, uint32_t* key_state, void* stream) {
+  if (!out || !key_state || nmb <= 0 || nt < nmb || ns < nmb) FAIL(GO2SIM_EINVAL, "cts indices: nmb >= 1 mini-batches of at least one teacher and one student sample each");
+  const int tb = nt / nmb, sb = ns / nmb, ht = go2_shuffle_half_bits((uint32_t)nt), hs = go2_shuffle_half_bits((uint32_t)ns);
+#ifdef GO2_EMU
+  (void)stream;
+  for (int i = 0; i < nmb; ++i) for (int j = 0; j < tb + sb; ++j) {
+    const int64_t k = j < tb ? (int64_t)go2_shuffle_index((uint32_t)(i * tb + j), (uint32_t)nt, ht, key_state[0], key_state[1])
+                             : (int64_t)nt + (int64_t)go2_shuffle_index((uint32_t)(i * sb + j - tb), (uint32_t)ns, hs, key_state[0] ^ GO2_SHUFFLE_TAIL_SEED, key_state[1]);
+    out[(size_t)i * (tb + sb) + j] = map ? map[k] : k;
+  }
+  key_state[1] += 1u;
+#else
+  hipLaunchKernelGGL(go2_cts_indices_kernel, dim3((nmb * (tb + sb) + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, nmb, nt, ns, tb, sb, ht, hs, map, key_state);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

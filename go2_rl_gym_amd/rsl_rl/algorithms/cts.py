@@ -20,7 +20,7 @@ import torch.optim as optim
 
 from ..storage import RolloutStorageCTS
 from ._graph import CapturedStep, FusedClipAdam, GradBucket, ReducedStep, all_captured
-from .ppo import _ADAM_IMPL, _collectives_on, _FusedPPOLoss, _RolloutHeads, _world, allreduce_mean_bucket
+from .ppo import _ADAM_IMPL, _RANDPERM, _collectives_on, _FusedPPOLoss, _RolloutHeads, _world, allreduce_mean_bucket
 
 
 def _allreduce_mean_grads(params, world, extra=None):
@@ -171,7 +171,10 @@ class CTS(_RolloutHeads):
             st.dones[s].copy_(dones.view(-1, 1))
         st.step += 1
         self.transition.clear()
-        self.model.history.masked_fill_(dones.view(-1, 1, 1) > 0, 0.0)          # model.reset(dones) (:163) without a boolean-index sync
+        # model.reset(dones) (:163): the deployment-side history inside the module (written by act_inference only) — all zeros throughout training, where zeroing
+        # rows of it is a no-op: two launches per env step saved
+        if getattr(self.model, "_history_dirty", True):
+            self.model.history.masked_fill_(dones.view(-1, 1, 1) > 0, 0.0)          # without a boolean-index sync
 
     def compute_returns(self, last_privileged_obs, last_history, last_obs=None):
         pk = self._pk if self._pk not in (None, False) else None
@@ -424,11 +427,24 @@ class CTS(_RolloutHeads):
             return
         import ctypes as C
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream) if str(self.device).startswith("cuda") else None
-        self._order = order.to(torch.int64).contiguous()          # (alive until the launch has run)
-        rc = self.lib.go2sim_shuffle_gather(self._gather_jobs, len(self._gather_jobs), int(order.numel()), C.c_void_p(self._order.data_ptr()), None,
+        self._order_live = order.to(torch.int64).contiguous()          # (alive until the launch has run)
+        rc = self.lib.go2sim_shuffle_gather(self._gather_jobs, len(self._gather_jobs), int(order.numel()), C.c_void_p(self._order_live.data_ptr()), None,
                                             C.c_void_p(self._accbuf.data_ptr()), int(self._accbuf.numel()), stream)
         if rc != 0:
             raise RuntimeError("go2sim_shuffle_gather failed: %s" % self.lib.go2sim_last_error().decode())
+
+    def _update_head(self):
+        """rollout_storage_cts.py:152-160 on the device: the two keyed permutations -> the update's index list (go2sim_cts_minibatch_indices), the gather, the student latents"""
+        import ctypes as C
+        st, nmb = self.storage, self.num_mini_batches
+        T = st.num_transitions_per_env
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream) if str(self.device).startswith("cuda") else None
+        rc = self.lib.go2sim_cts_minibatch_indices(C.c_void_p(self._order.data_ptr()), nmb, st.teacher_num_envs * T, st.student_num_envs * T, C.c_void_p(st.ref2mine.data_ptr()),
+                                                   C.c_void_p(self._shuffle_key.data_ptr()), stream)
+        if rc != 0:
+            raise RuntimeError("go2sim_cts_minibatch_indices failed: %s" % self.lib.go2sim_last_error().decode())
+        self._gather_update(self._order)
+        self._student_latents()
 
     def _student_latents(self):
         """The student rows' latents of the whole update into the first L columns of both input matrices: optimizer1 never touches the student encoder (cts.py:72-77), so
@@ -470,7 +486,9 @@ class CTS(_RolloutHeads):
                 jobs += [Go2GatherJob(F[k].data_ptr(), Pm[k].data_ptr(), int(F[k][0].numel()), 0) for k in self._KEYS if k != "obs"]
                 assert all(F[k].dtype == torch.float32 and F[k].is_contiguous() for k in self._KEYS)
                 self._gather_jobs = (Go2GatherJob * len(jobs))(*jobs)
-                self._latents_step = CapturedStep(self._student_latents, enabled=self._capture, warmup=2, name="CTS student latents", optional=True)
+                self._make_shuffle_key()
+                self._order = torch.empty(rows, dtype=torch.int64, device=self.device)
+                self._head_step = CapturedStep(self._update_head, enabled=self._capture, warmup=2, name="CTS update head (permutation, gather, student latents)", optional=True)
             if _collectives_on():     # two captured halves per slot, the gradient all-reduce eager between them
                 mk = lambda front, back, bucket, name: [ReducedStep((lambda i=i: front(i, True)), (lambda: back(True)), bucket, enabled=self._capture, warmup=3 if i == 0 else 1,
                                                                     name="CTS %s step %d" % (name, i)) for i in range(nmb)]
@@ -485,9 +503,12 @@ class CTS(_RolloutHeads):
                 self._steps = (mk(self._policy_step, "policy"), mk(self._student_step, "student"))
         # the rollout is gathered ONCE per update into mini-batch order ([teacher rows | student rows] per mini-batch; every epoch
         # reuses the same permutation, rollout_storage_cts.py:152-160), so each captured step reads a contiguous chunk
-        self._gather_update(torch.cat(st.mini_batch_indices(nmb)))
-        if self._plan is not None:
-            self._latents_step()
+        if self._plan is not None and torch.randperm is _RANDPERM and hasattr(self.lib, "go2sim_cts_minibatch_indices"):
+            self._head_step()          # keyed permutations on the device + gather + student latents: three launches (+ the MoE student encoder), one graph
+        else:                          # (the goldens replace torch.randperm to replay the reference's draws; the autograd formulation)
+            self._gather_update(torch.cat(st.mini_batch_indices(nmb)))
+            if self._plan is not None:
+                self._student_latents()
         for steps in self._steps:
             for _ in range(self.num_learning_epochs):
                 for step in steps:

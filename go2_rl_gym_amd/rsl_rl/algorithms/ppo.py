@@ -86,6 +86,23 @@ class _RolloutHeads:
             self._eps_all = torch.randn_like(st.actions)
         return self._eps_all[s]
 
+    # The update's permutation in graph mode: a keyed bijection computed on the device (include/go2sim_shuffle.h) under (seed, counter).  The seed follows
+    # torch.manual_seed at the time the key is made (the first graph-mode update), NOT torch's generator state afterwards; the counter advances by one per update on the
+    # device and is set to the iteration number when a checkpoint is loaded (runner.load -> set_shuffle_counter), so a resumed run does not replay the permutations of
+    # iterations 0, 1, ....  DESIGN.md section 8 lists this among the deliberate deviations.
+    _shuffle_key = None
+    _shuffle_counter0 = 0
+
+    def _make_shuffle_key(self):
+        seed = int((torch.initial_seed() * 0x9E3779B1 + 0x7F4A7C15) & 0x7FFFFFFF)          # (follows torch.manual_seed without drawing from the generator)
+        self._shuffle_key = torch.tensor([seed, int(self._shuffle_counter0) & 0x7FFFFFFF, 0, 0], dtype=torch.int32, device=self.device)
+        return self._shuffle_key
+
+    def set_shuffle_counter(self, it):
+        self._shuffle_counter0 = int(it)
+        if self._shuffle_key is not None:
+            self._shuffle_key[1] = int(it) & 0x7FFFFFFF
+
     def rollout_replayed(self):
         """The runner replayed the captured rollout (act() did not run in Python): the weights are packed iff the captured rollout recorded the pack launch at its
         first step — known from the flag act() left when it ran under capture (a rollout that took the non-kernel branch must not claim packed weights)."""
@@ -571,8 +588,7 @@ class PPO(_RolloutHeads):
             if use_lib:
                 row = lambda t: int(t[0].numel()) if t.dim() > 1 else 1
                 self._gather_jobs = (Go2GatherJob * len(keys))(*[Go2GatherJob(self._flat[k].data_ptr(), self._perm[k].data_ptr(), row(self._flat[k]), 0) for k in keys])
-                seed = int((torch.initial_seed() * 0x9E3779B1 + 0x7F4A7C15) & 0x7FFFFFFF)          # (follows torch.manual_seed without drawing from the generator)
-                self._shuffle_key = torch.tensor([seed, 0, 0, 0], dtype=torch.int32, device=self.device)
+                self._make_shuffle_key()
             rows = nmb * mb
 
             def permute():

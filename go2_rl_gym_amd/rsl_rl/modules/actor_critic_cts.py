@@ -81,6 +81,10 @@ class ActorCriticCTS(nn.Module):
     def reset(self, dones=None):
         self.history[dones > 0] = 0.0
 
+    def load_state_dict(self, *a, **k):
+        self._history_dirty = True          # (whatever comes with a checkpoint: no assumption about the buffer)
+        return super().load_state_dict(*a, **k)
+
     def forward(self):
         raise NotImplementedError
 
@@ -116,7 +120,10 @@ class ActorCriticCTS(nn.Module):
     def get_actions_log_prob(self, actions):
         return self.distribution.log_prob(actions).sum(dim=-1)
 
+    _history_dirty = False      # the deployment-side history holds something other than zeros (then CTS.process_env_step zeroes finished envs' rows, cts.py:163)
+
     def act_inference(self, obs):
+        self._history_dirty = True
         self.history = torch.cat([self.history[:, 1:], obs.unsqueeze(1)], dim=1)
         latent = self.student_latent(self.history.flatten(1))[0]
         return self.policy_mean(latent, obs)

@@ -365,6 +365,7 @@ class OnPolicyRunner:
             load_optimizer_state(self.alg.optimizer, d["optimizer_state_dict"])
             self.alg.rebind_lr()
         self.current_learning_iteration = d["iter"]
+        getattr(self.alg, "set_shuffle_counter", lambda it: None)(d["iter"])          # graph mode's keyed permutation continues at the checkpoint's iteration
         return d["infos"]
 
     def get_inference_policy(self, device=None):

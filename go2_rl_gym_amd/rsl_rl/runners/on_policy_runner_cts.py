@@ -115,6 +115,7 @@ class OnPolicyRunnerCTS(OnPolicyRunner):
             load_optimizer_state(self.alg.optimizer2, d["optimizer2_state_dict"])
             self.alg.rebind_lr()
         self.current_learning_iteration = d["iter"]
+        self.alg.set_shuffle_counter(d["iter"])          # graph mode's keyed permutations continue at the checkpoint's iteration
         return d["infos"]
 
     def get_inference_policy(self, device=None):

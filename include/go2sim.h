@@ -495,6 +495,14 @@ typedef struct Go2GatherJob { const float* src; float* dst; int32_t row_floats; 
 int  go2sim_shuffle_gather(const Go2GatherJob* jobs, int32_t njobs, int32_t rows, const int64_t* indices, uint32_t* key_state, float* clear, int32_t nclear, void* stream);
 /* host-callable statement of the permutation (both libraries; no device work): pi(i) for i < n under (seed, counter) */
 uint32_t go2sim_shuffle_index(uint32_t i, uint32_t n, uint32_t seed, uint32_t counter);
+/* ABI 8: the index list of a CTS update (rsl_rl/rsl_rl/storage/rollout_storage_cts.py:152-160: teacher and student samples are shuffled SEPARATELY — two torch.randperm —
+ * and mini-batch i is [teacher chunk i | student chunk i]), as one launch instead of two radix sorts and ~10 slicing / cat / index launches:
+ *   out[i (tb + sb) + j] = map[ j < tb ? pi_t(i tb + j) : nt + pi_s(i sb + j - tb) ]      i < nmb, tb = nt / nmb, sb = ns / nmb
+ * pi_t = go2sim_shuffle_index(., nt, key_state[0], key_state[1]), pi_s = go2sim_shuffle_index(., ns, key_state[0] ^ GO2_SHUFFLE_TAIL_SEED, key_state[1]); key_state[1]
+ * advances by one when the launch is over (a replayed HIP graph draws new permutations every time).  map: int64 [nt + ns] (the storage position of sample k of the
+ * reference's teacher-first layout) or NULL (identity).  out: int64 [nmb (tb + sb)], what go2sim_shuffle_gather takes as `indices`. */
+#define GO2_SHUFFLE_TAIL_SEED 0x9E3779B9u
+int  go2sim_cts_minibatch_indices(int64_t* out, int32_t nmb, int32_t nt, int32_t ns, const int64_t* map, uint32_t* key_state, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1470,6 +1470,20 @@ int go2sim_shuffle_gather(const Go2GatherJob* jobs, int32_t njobs, int32_t rows,
   return 0;
 }
 
+int go2sim_cts_minibatch_indices(int64_t* out, int32_t nmb, int32_t nt, int32_t ns, const int64_t* map, uint32_t* key_state, void* stream) {
+  /* rollout_storage_cts.py:152-160 with the keyed permutations of include/go2sim_shuffle.h in place of the two torch.randperm draws */
+  (void)stream;
+  if (!out || !key_state || nmb<=0 || nt<nmb || ns<nmb) return GO2SIM_EINVAL;
+  const int tb = nt/nmb, sb = ns/nmb, ht = go2_shuffle_half_bits((uint32_t)nt), hs = go2_shuffle_half_bits((uint32_t)ns);
+  for (int i=0;i<nmb;++i) for (int j=0;j<tb+sb;++j) {
+    const int64_t k = j<tb ? (int64_t)go2_shuffle_index((uint32_t)(i*tb+j), (uint32_t)nt, ht, key_state[0], key_state[1])
+                           : (int64_t)nt + (int64_t)go2_shuffle_index((uint32_t)(i*sb+j-tb), (uint32_t)ns, hs, key_state[0]^GO2_SHUFFLE_TAIL_SEED, key_state[1]);
+    out[(size_t)i*(tb+sb)+j] = map ? map[k] : k;
+  }
+  key_state[1] += 1u;
+  return 0;
+}
+
 int go2sim_history_push(float* history, const float* obs, const uint8_t* dones, int32_t N, int32_t H, int32_t D, void* stream) {
   (void)stream;
   if (!history || !obs || N<=0 || H<=0 || D<=0) return GO2SIM_EINVAL;

@@ -3,6 +3,8 @@ its host statement go2sim_shuffle_index for every row, the device-side counter a
 update's size.  Run with -m gpu."""
 import ctypes as C
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -42,3 +44,32 @@ def test_shuffle_gather_replayed_from_a_graph_at_the_update_size():
         assert torch.equal(torch.sort(dst[3].view(-1)).values, torch.sort(src[3].view(-1)).values)
         assert prev is None or not torch.equal(prev, dst[3])
         prev = dst[3].clone()
+
+
+def test_cts_minibatch_indices_on_gpu():
+    """go2sim_cts_minibatch_indices (two keyed permutations -> the CTS update's index list) on the MI355X against its host-side definition, at a toy size and at the
+    update's size (3072 teacher + 1024 student envs x 24 steps, 4 mini-batches)"""
+    from test_shuffle import check_cts_indices, cts_indices
+    lib = load_hip()
+    check_cts_indices(lib, "cuda:0")
+    key = torch.tensor([31337, 2, 0, 0], dtype=torch.int32, device="cuda:0")
+    nt, ns, nmb = 3072 * 24, 1024 * 24, 4
+    out, m = cts_indices(lib, nmb, nt, ns, key, "cuda:0")
+    torch.cuda.synchronize()
+    o = out.cpu().numpy().reshape(nmb, -1)
+    inv = torch.empty(int(m.max()) + 1, dtype=torch.int64); inv[m.cpu()] = torch.arange(nt + ns)
+    ks = inv[torch.from_numpy(o)].numpy()
+    assert (ks[:, :nt // nmb] < nt).all() and (ks[:, nt // nmb:] >= nt).all() and len(np.unique(ks)) == nt + ns and key.tolist() == [31337, 3, 0, 0]
+
+
+def test_gather_into_a_column_block_on_gpu():
+    lib = load_hip()
+    rows, w, L = 24576, 263, 32
+    g = torch.Generator().manual_seed(3)
+    src, wide, clear = torch.randn(rows, w, generator=g).to("cuda:0"), torch.full((rows, L + w), 5.0, device="cuda:0"), torch.ones(700, device="cuda:0")
+    idx = torch.randperm(rows, generator=g).to("cuda:0")
+    from go2_rl_gym_amd._abi import Go2GatherJob
+    job = (Go2GatherJob * 1)(Go2GatherJob(src.data_ptr(), wide.data_ptr() + 4 * L, w, L + w))
+    assert lib.go2sim_shuffle_gather(job, 1, rows, C.c_void_p(idx.data_ptr()), None, C.c_void_p(clear.data_ptr()), 650, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(wide[:, L:], src[idx]) and (wide[:, :L] == 5.0).all() and (clear[:650] == 0).all() and (clear[650:] == 1).all()
