@@ -91,4 +91,94 @@ __global__ void __launch_bounds__(256) go2nn_cts_bwd_kernel(const float* __restr
     prow[0] = s / ((float)n * (float)L); prow[1] = prow[2] = prow[3] = 0.f;
   }
 }
+
+// ---- the loss head of the MoE student step (rsl_rl/rsl_rl/modules/utils.py:96-152 MoE / StudentMoEEncoder; rsl_rl/rsl_rl/algorithms/moe_cts.py:203-214) -------------
+//   w = softmax(logits [n, E]);  y = sum_e w_e outs[:, e, :];  shat = y / max(|y|, 1e-12);  latent loss = mean((that - shat)^2);
+//   usage = mean_rows(w);  load-balance loss = mean_e((usage_e - 1 / E)^2);  total = latent + coef * load balance
+// In autograd: softmax, a broadcast product, two reductions, the normaliser, two losses and all their backward nodes — ~55 launches on [n, 8] / [n, 32] / [n, 8, 32]
+// tensors (250 us of a 1.2 ms student step, profiles/r5b_go2_moe_cts_timeline.txt).  Two passes, because the load-balance gradient needs the batch mean of the gate:
+//   go2nn_moe_usage_kernel   column partial sums of softmax(logits)                                  (finished by go2nn_sum_rows -> usage_sum [E])
+//   go2nn_moe_mix_kernel     everything else for a row in registers; d loss / d outs [n, E, L] and d loss / d logits [n, E] out, loss partials
+#define MOE_MAX_E 16
+__global__ void __launch_bounds__(CTS_ROWS_PER_WG) go2nn_moe_usage_kernel(const float* __restrict__ logits, float* __restrict__ part, int n, int E) {
+  __shared__ float sh[CTS_ROWS_PER_WG][MOE_MAX_E + 1];
+  const int r = blockIdx.x * CTS_ROWS_PER_WG + threadIdx.x;
+  float w[MOE_MAX_E];
+  if (r < n) {
+    float mx = -3.4e38f, sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < MOE_MAX_E; ++e) { w[e] = e < E ? logits[(size_t)r * E + e] : -3.4e38f; mx = fmaxf(mx, w[e]); }
+#pragma unroll
+    for (int e = 0; e < MOE_MAX_E; ++e) { w[e] = e < E ? expf(w[e] - mx) : 0.f; sum += w[e]; }
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int e = 0; e < MOE_MAX_E; ++e) sh[threadIdx.x][e] = w[e] * inv;
+  } else {
+#pragma unroll
+    for (int e = 0; e < MOE_MAX_E; ++e) sh[threadIdx.x][e] = 0.f;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < E) { float s = 0.f; for (int j = 0; j < CTS_ROWS_PER_WG; ++j) s += sh[j][threadIdx.x]; part[(size_t)blockIdx.x * E + threadIdx.x] = s; }
+}
+
+__global__ void __launch_bounds__(256) go2nn_moe_mix_kernel(const float* __restrict__ logits, const float* __restrict__ outs, const float* __restrict__ that,
+                                                            const float* __restrict__ usage_sum, float* __restrict__ dlogits, float* __restrict__ douts, float* __restrict__ part,
+                                                            int n, int E, int L, float coef) {
+  __shared__ float shl[256];
+  const int LP = L >> 2, RL = 256 / LP, cq = threadIdx.x % LP, rl = threadIdx.x / LP, c = cq * 4;
+  const int r0 = blockIdx.x * CTS_ROWS_PER_WG, r1 = min(n, r0 + CTS_ROWS_PER_WG);
+  const float invE = 1.f / (float)E, invn = 1.f / (float)n, scale = 2.f / ((float)n * (float)L);
+  float lbg[MOE_MAX_E];          // d (coef * load balance) / d w[row][e] = coef * 2 (usage_e - 1 / E) / (E n), the same for every row
+#pragma unroll
+  for (int e = 0; e < MOE_MAX_E; ++e) lbg[e] = e < E ? coef * 2.f * (usage_sum[e] * invn - invE) * invE * invn : 0.f;
+  float loss = 0.f;
+  for (int rb = r0; rb < r1; rb += RL) {
+    const int r = rb + rl, rc = min(r, r1 - 1);
+    const bool live = r < r1;
+    float w[MOE_MAX_E]; float4 o[MOE_MAX_E];
+    float mx = -3.4e38f, sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < MOE_MAX_E; ++e) {
+      w[e] = e < E ? logits[(size_t)rc * E + e] : -3.4e38f; mx = fmaxf(mx, w[e]);
+      o[e] = e < E ? *reinterpret_cast<const float4*>(outs + ((size_t)rc * E + e) * L + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int e = 0; e < MOE_MAX_E; ++e) { w[e] = e < E ? expf(w[e] - mx) : 0.f; sum += w[e]; }
+    const float isum = 1.f / sum;
+    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int e = 0; e < MOE_MAX_E; ++e) { w[e] *= isum; y.x = fmaf(w[e], o[e].x, y.x); y.y = fmaf(w[e], o[e].y, y.y); y.z = fmaf(w[e], o[e].z, y.z); y.w = fmaf(w[e], o[e].w, y.w); }
+    const float inv = 1.f / fmaxf(sqrtf(cts_group_sum(y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w, LP)), CTS_EPS);
+    const float4 sh_ = make_float4(y.x * inv, y.y * inv, y.z * inv, y.w * inv);
+    const float4 t = *reinterpret_cast<const float4*>(that + (size_t)rc * L + c);
+    const float4 d = make_float4(t.x - sh_.x, t.y - sh_.y, t.z - sh_.z, t.w - sh_.w);
+    if (live) loss += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+    const float4 gs = make_float4(-scale * d.x, -scale * d.y, -scale * d.z, -scale * d.w);          // d latent loss / d shat
+    const float dot = cts_group_sum(gs.x * sh_.x + gs.y * sh_.y + gs.z * sh_.z + gs.w * sh_.w, LP);
+    const float4 dy = make_float4((gs.x - sh_.x * dot) * inv, (gs.y - sh_.y * dot) * inv, (gs.z - sh_.z * dot) * inv, (gs.w - sh_.w * dot) * inv);
+    float dw[MOE_MAX_E], wd = 0.f;
+#pragma unroll
+    for (int e = 0; e < MOE_MAX_E; ++e) {
+      if (e < E) {
+        if (live) *reinterpret_cast<float4*>(douts + ((size_t)r * E + e) * L + c) = make_float4(w[e] * dy.x, w[e] * dy.y, w[e] * dy.z, w[e] * dy.w);
+        dw[e] = cts_group_sum(dy.x * o[e].x + dy.y * o[e].y + dy.z * o[e].z + dy.w * o[e].w, LP) + lbg[e];
+        wd = fmaf(w[e], dw[e], wd);
+      } else dw[e] = 0.f;
+    }
+    if (live && cq == 0) {
+#pragma unroll
+      for (int e = 0; e < MOE_MAX_E; ++e) if (e < E) dlogits[(size_t)r * E + e] = w[e] * (dw[e] - wd);          // softmax backward
+    }
+  }
+  shl[threadIdx.x] = loss;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int j = 0; j < 256; ++j) s += shl[j];
+    float lb = 0.f;
+    if (blockIdx.x == 0) { for (int e = 0; e < E; ++e) { const float u = usage_sum[e] * invn - invE; lb += u * u; } lb *= invE; }
+    float* prow = part + (size_t)blockIdx.x * 4;
+    prow[0] = s / ((float)n * (float)L); prow[1] = lb; prow[2] = prow[3] = 0.f;
+  }
+}
 #endif  // !GO2_EMU

@@ -259,13 +259,19 @@ class CTS(_RolloutHeads):
         """Hook: extra terms of the policy loss from the value head's auxiliary output (the actor gate weights of the AC-MoE variants)."""
         return loss
 
-    def _student_losses(self, hist_s, priv_s):
-        """-> total loss, (latent_loss, ...) for the log    (student rows only)"""
+    def _student_losses(self, hist_s, priv_s, teacher_latent=None):
+        """-> total loss, (latent_loss, ...) for the log    (student rows only).  teacher_latent: the teacher encoder's latent of these rows when the caller holds it
+        (graph mode computes it once per update: optimizer2 never touches the teacher encoder, so it is a constant of the student epochs)"""
         student_latent, _ = self.model.student_latent(hist_s)
-        with torch.no_grad():
-            teacher_latent = self.model.teacher_encoder(priv_s)
+        teacher_latent = self._teacher_latent(priv_s, teacher_latent)
         latent_loss = (teacher_latent - student_latent).pow(2).mean()
         return latent_loss, (latent_loss,)
+
+    def _teacher_latent(self, priv_s, given=None):
+        if given is not None:
+            return given
+        with torch.no_grad():
+            return self.model.teacher_encoder(priv_s)
 
     _NUM_STUDENT_LOGS = 1
 
@@ -395,9 +401,7 @@ class CTS(_RolloutHeads):
             from ..modules import fused_cts
             fused_cts.cts_student_grads(self._plan, self.model, hist_s, priv_s, acc=self._acc_own[4:])
         else:
-            loss, logs = self._student_losses(hist_s, priv_s)
-            loss.backward()
-            self._acc[3 + self._NUM_POLICY_LOGS:].add_(torch.stack([v.detach() for v in logs]))
+            self._student_backward(hist_s, priv_s, self._tlat[i] if self._tlat is not None else None)
         if split:
             if self._bucket2 is None:
                 self._bucket2 = GradBucket(self._params2)
@@ -412,6 +416,12 @@ class CTS(_RolloutHeads):
             return
         nn.utils.clip_grad_norm_(self._params2, self.max_grad_norm, foreach=True)
         self.optimizer2.step()
+
+    def _student_backward(self, hist_s, priv_s, teacher_latent):
+        """forward + backward of the student loss on one mini-batch's student rows (graph mode); the logs are added to the accumulators"""
+        loss, logs = self._student_losses(hist_s, priv_s, teacher_latent) if teacher_latent is not None else self._student_losses(hist_s, priv_s)
+        loss.backward()
+        self._acc[3 + self._NUM_POLICY_LOGS:].add_(torch.stack([v.detach() for v in logs]))
 
     def _student_step(self, i):
         self._student_front(i)
@@ -446,6 +456,16 @@ class CTS(_RolloutHeads):
         self._gather_update(self._order)
         self._student_latents()
 
+    def _student_takes_teacher_latent(self):
+        import inspect
+        return "teacher_latent" in inspect.signature(self._student_losses).parameters
+
+    def _teacher_latents(self):
+        from ..modules import fused_cts
+        nmb, mb, n_t = self.num_mini_batches, self._mb, self._teacher_rows()
+        for i in range(nmb):
+            fused_cts.encoder_latents(self._plan, self._plan.teacher, self._perm["cobs"][i * mb + n_t:(i + 1) * mb], self._tlat[i], None)
+
     def _student_latents(self):
         """The student rows' latents of the whole update into the first L columns of both input matrices: optimizer1 never touches the student encoder (cts.py:72-77), so
         they are constants of the policy epochs — computed once per update instead of in each of the 20 policy steps."""
@@ -476,6 +496,7 @@ class CTS(_RolloutHeads):
             self._acc_own, self._acc = self._accbuf[:8], self._accbuf[8:]
             self._bucket1 = self._bucket2 = None
             self._gather_jobs = None
+            self._tlat, self._tlat_step = None, None
             if plan is not None:
                 import ctypes as C
                 from ..._abi import Go2GatherJob
@@ -488,6 +509,9 @@ class CTS(_RolloutHeads):
                 self._gather_jobs = (Go2GatherJob * len(jobs))(*jobs)
                 self._make_shuffle_key()
                 self._order = torch.empty(rows, dtype=torch.int64, device=self.device)
+                if not self._own_student() and self._student_takes_teacher_latent():
+                    self._tlat = new(nmb, self._mb - self._teacher_rows(), L)
+                    self._tlat_step = CapturedStep(self._teacher_latents, enabled=self._capture, warmup=2, name="CTS teacher latents of the student rows", optional=True)
                 self._head_step = CapturedStep(self._update_head, enabled=self._capture, warmup=2, name="CTS update head (permutation, gather, student latents)", optional=True)
             if _collectives_on():     # two captured halves per slot, the gradient all-reduce eager between them
                 mk = lambda front, back, bucket, name: [ReducedStep((lambda i=i: front(i, True)), (lambda: back(True)), bucket, enabled=self._capture, warmup=3 if i == 0 else 1,
@@ -509,7 +533,9 @@ class CTS(_RolloutHeads):
             self._gather_update(torch.cat(st.mini_batch_indices(nmb)))
             if self._plan is not None:
                 self._student_latents()
-        for steps in self._steps:
+        for phase, steps in enumerate(self._steps):
+            if phase == 1 and self._tlat_step is not None:
+                self._tlat_step()          # the teacher latents of the student rows: constants of the student epochs, computed once (own kernels) instead of in each of the 20 steps
             for _ in range(self.num_learning_epochs):
                 for step in steps:
                     step()

@@ -12,14 +12,25 @@ class MoECTS(CTS):
         super().__init__(model, num_envs, history_length, **kwargs)
         self.load_balance_coef = load_balance_coef
 
-    def _student_losses(self, hist_s, priv_s):
+    def _student_losses(self, hist_s, priv_s, teacher_latent=None):
         student_latent, gate = self.model.student_latent(hist_s)
-        with torch.no_grad():
-            teacher_latent = self.model.teacher_encoder(priv_s)
+        teacher_latent = self._teacher_latent(priv_s, teacher_latent)
         latent_loss = (teacher_latent - student_latent).pow(2).mean()
         usage = gate.mean(dim=0)
         load_balance_loss = (usage - 1.0 / gate.shape[1]).pow(2).mean()
         return latent_loss + self.load_balance_coef * load_balance_loss, (latent_loss, load_balance_loss)
+
+
+    def _student_backward(self, hist_s, priv_s, teacher_latent):
+        """Graph mode on the library pair: the mixture, the normaliser, both losses and their backward as two launches (modules/fused_cts.py:moe_head_grads) — autograd
+        only runs through the gate MLP, the experts' backbone and the expert heads, seeded with the head's analytic gradients."""
+        from ..modules import fused_cts
+        t_hat = self._teacher_latent(priv_s, teacher_latent)
+        if not (self.fused_loss and fused_cts.moe_head_applicable(self.model, t_hat.shape[1])):
+            return super()._student_backward(hist_s, priv_s, teacher_latent)
+        logits, outs = self.model.student_moe_parts(hist_s)
+        _, dl, do = fused_cts.moe_head_grads(logits, outs, t_hat, self.load_balance_coef, acc=self._acc[3 + self._NUM_POLICY_LOGS:])
+        torch.autograd.backward([logits, outs], [dl, do])
 
 
 class MoENGCTS(MoECTS):
@@ -54,10 +65,9 @@ class DualMoECTS(ACMoECTS):
     """AC-MoE heads + the MoE student encoder (dual_moe_cts.py:40-262): returns (..., latent, student load balance, actor load balance)."""
     _NUM_STUDENT_LOGS = 2
 
-    def _student_losses(self, hist_s, priv_s):
+    def _student_losses(self, hist_s, priv_s, teacher_latent=None):
         student_latent, gate = self.model.student_latent(hist_s)
-        with torch.no_grad():
-            teacher_latent = self.model.teacher_encoder(priv_s)
+        teacher_latent = self._teacher_latent(priv_s, teacher_latent)
         latent_loss = (teacher_latent - student_latent).pow(2).mean()
         lb = _balance(gate)
         return latent_loss + self.load_balance_coef * lb, (latent_loss, lb)

@@ -29,3 +29,6 @@ class ActorCriticMoECTS(ActorCriticCTS):
 
     def student_latent(self, history):
         return self.student_moe_encoder(history)
+
+    def student_moe_parts(self, history):
+        return self.student_moe_encoder.moe.parts(history)

@@ -260,6 +260,180 @@ def _whole_mlp(mods):
     return lins + [mods[-1]]
 
 
+class _Launch:
+    """The go2nn calls of one mini-batch on one device / stream; collects the fixed-order reductions of the pass for ONE go2nn_sum_rows launch."""
+
+    def __init__(self, dev):
+        self.dev, self.nn = dev, _NN
+        self.stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else None
+        self.sums = []          # (partial rows, result, nrows, ncols[, acc, nacc])
+
+    def new(self, *shape):
+        return torch.empty(*shape, device=self.dev, dtype=torch.float32)
+
+    def check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed: %s" % (what, self.nn.go2nn_last_error().decode()))
+
+    def images(self, lins):
+        """split images of the layers' weights (both orientations), ONE launch; [None] * n when the split-operand kernels are off"""
+        from ..._nn import Go2nnSplitJob
+        if not _SPLIT:
+            return [None] * len(lins)
+        imgs, jobs = [], []
+        for m in lins:
+            N, K = m.weight.shape
+            n = self.nn.go2nn_split_weights_bytes(N, K)
+            if n <= 0:
+                raise RuntimeError("go2nn_split_weights_bytes: %s" % self.nn.go2nn_last_error().decode())
+            imgs.append(torch.empty(int(n), device=self.dev, dtype=torch.uint8))
+            jobs.append(Go2nnSplitJob(m.weight.data_ptr(), imgs[-1].data_ptr(), N, K))
+        for k in range(0, len(jobs), 16):
+            chunk = jobs[k:k + 16]
+            self.check(self.nn.go2nn_split_weights((Go2nnSplitJob * len(chunk))(*chunk), len(chunk), self.stream), "go2nn_split_weights")
+        return imgs
+
+    def forward(self, jobs, act=0):
+        """jobs: [(x [M, K], Linear, image)] (1 or 2, one launch) -> [y [M, N]];  act 0: ELU, 1: none"""
+        from ..._nn import Go2nnFwdJob
+        ys = [self.new(x.shape[0], m.out_features) for x, m, _ in jobs]
+        arr = (Go2nnFwdJob * len(jobs))(*[Go2nnFwdJob(x.data_ptr(), m.weight.data_ptr(), m.bias.data_ptr(), y.data_ptr(), x.shape[0], m.in_features, m.out_features, act,
+                                                      img.data_ptr() if img is not None else None) for (x, m, img), y in zip(jobs, ys)])
+        self.check(self.nn.go2nn_linear_elu_forward_group(arr, len(jobs), self.stream), "go2nn_linear_elu_forward_group")
+        return ys
+
+    def wgrad(self, jobs, sink=None, tag=None):
+        """jobs: [(gz [M, C], x [M, Kin], Linear)] with one M: the layers' weight gradients (row-slice partials now, .grad = their sum after finish()).
+        sink: a dict that receives the gradient tensors under (tag, "w") instead of the parameters' .grad (inside an autograd node)"""
+        from ..._nn import Go2nnBwdWJob
+        arr = (Go2nnBwdWJob * len(jobs))(*[Go2nnBwdWJob(gz.data_ptr(), x.data_ptr(), None, gz.shape[0], m.out_features, m.in_features, 1 if _SPLIT else 0) for gz, x, m in jobs])
+        rows = self.nn.go2nn_linear_backward_weight_group_rows(arr, len(jobs))
+        if rows <= 0:
+            raise RuntimeError("go2nn_linear_backward_weight_group_rows: %s" % self.nn.go2nn_last_error().decode())
+        for j, (gz, x, m) in enumerate(jobs):
+            n = m.out_features * m.in_features
+            wk, dw = self.new(rows * n), torch.empty_like(m.weight)
+            arr[j].workspace = wk.data_ptr()
+            self.sums.append((wk, dw, rows, n))
+            if sink is None:
+                m.weight.grad = dw
+            else:
+                sink[(tag, "w")] = dw
+        self.check(self.nn.go2nn_linear_backward_weight_group(arr, len(jobs), self.stream), "go2nn_linear_backward_weight_group")
+
+    def bwd_in(self, jobs, plain=False):
+        """jobs: [(gz [M, C], Linear, y_prev [M, Kin] or None, image)] -> ([gz_prev [M, Kin]], [gb_prev [Kin]] (valid after finish(); None when plain))"""
+        from ..._nn import Go2nnBwdInJob
+        arr, outs, gbs = (Go2nnBwdInJob * len(jobs))(), [], []
+        for j, (gz, m, yp, img) in enumerate(jobs):
+            M, Co, Ki = gz.shape[0], m.out_features, m.in_features
+            o = self.new(M, Ki)
+            wk = gb = None
+            if not plain:
+                r = self.nn.go2nn_linear_backward_input_group_rows(M, Co, Ki)
+                wk, gb = self.new(r * Ki), self.new(Ki)
+                self.sums.append((wk, gb, r, Ki))
+            arr[j] = Go2nnBwdInJob(gz.data_ptr(), m.weight.data_ptr(), yp.data_ptr() if yp is not None else None, o.data_ptr(), wk.data_ptr() if wk is not None else None,
+                                   M, Co, Ki, 1 if plain else 0, img.data_ptr() if img is not None else None)
+            outs.append(o); gbs.append(gb)
+        self.check(self.nn.go2nn_linear_backward_input_group(arr, len(jobs), self.stream), "go2nn_linear_backward_input_group")
+        return outs, gbs
+
+    def chain_backward(self, chains, sink=None):
+        """chains: 1 or 2 dicts {lins, acts, gz, gb, imgs} of equally many layers and one M: gz / gb = the gradient at lins[-1]'s output and its column sums;
+        acts[l] = the input of lins[l] (acts[l > 0] an ELU output).  Sets .grad of every weight and bias; -> the gradients at lins[0]'s pre-activation."""
+        n = len(chains[0]["lins"])
+        gz, gb = [c["gz"] for c in chains], [c["gb"] for c in chains]
+        for l in range(n - 1, -1, -1):
+            self.wgrad([(gz[j], c["acts"][l], c["lins"][l]) for j, c in enumerate(chains)], sink, l)
+            for j, c in enumerate(chains):
+                if sink is None:
+                    c["lins"][l].bias.grad = gb[j]
+                else:
+                    sink[(l, "b")] = gb[j]
+            if l > 0:
+                gz, gb = self.bwd_in([(gz[j], c["lins"][l], c["acts"][l], c["imgs"][l]) for j, c in enumerate(chains)])
+        return gz
+
+    def finish(self):
+        from ..._nn import Go2nnSumJob
+        for k in range(0, len(self.sums), 32):
+            chunk = self.sums[k:k + 32]
+            arr = (Go2nnSumJob * len(chunk))(*[Go2nnSumJob(t[0].data_ptr(), t[1].data_ptr(), t[2], t[3], t[4].data_ptr() if len(t) > 4 and t[4] is not None else None,
+                                                           t[5] if len(t) > 4 and t[4] is not None else 0, 0) for t in chunk])
+            self.check(self.nn.go2nn_sum_rows(arr, len(chunk), self.stream), "go2nn_sum_rows")
+        self.sums = []
+
+
+
+class _FusedChain(torch.autograd.Function):
+    """x -> [Linear -> ELU] x n (an activation behind EVERY layer: the experts' backbone of the MoE encoders, rsl_rl/rsl_rl/modules/utils.py:47-62 with last_activation=True)
+    as ONE autograd node on the split-operand kernels: forward = n single-job launches with the ELU in the epilogue; backward = one pass for the top layer's ELU' + bias
+    gradient (go2sim_elu_backward_bias), then weight gradients and input gradients with the ELU' of the layer below in the epilogue, one go2nn_sum_rows.
+    args: x, w1, b1, ..., wn, bn."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        ws, bs = params[0::2], params[1::2]
+        k = _Launch(x.device)
+        lins = [_LinearView(w, b) for w, b in zip(ws, bs)]
+        imgs = k.images(lins)
+        acts = [x]
+        for l, m in enumerate(lins):
+            acts.append(k.forward([(acts[-1], m, imgs[l])])[0])
+        ctx.save_for_backward(*acts, *ws)
+        ctx.n, ctx.imgs = len(ws), imgs
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, gy):
+        n = ctx.n
+        acts, ws = ctx.saved_tensors[:n + 1], ctx.saved_tensors[n + 1:]
+        k = _Launch(gy.device)
+        gy = gy.contiguous()
+        y = acts[n]
+        B, Cn = y.shape
+        gz, gb = torch.empty_like(y), k.new(Cn)
+        wk = k.new(Cn * ((B + 63) // 64))
+        p = lambda t: C.c_void_p(t.data_ptr())
+        rc = _LIB.go2sim_elu_backward_bias(p(gy), p(y), p(gz), p(gb), p(wk), B, Cn, k.stream)
+        if rc != 0:
+            raise RuntimeError("go2sim_elu_backward_bias failed: %s" % _LIB.go2sim_last_error().decode())
+        lins = [_LinearView(w, None) for w in ws]
+        grads = {}
+        gz0 = k.chain_backward([{"lins": lins, "acts": acts, "gz": gz, "gb": gb, "imgs": ctx.imgs}], sink=grads)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = k.bwd_in([(gz0[0], lins[0], None, ctx.imgs[0])], plain=True)[0][0]
+        k.finish()
+        out = []
+        for l in range(n):
+            out += [grads[(l, "w")], grads[(l, "b")]]
+        return (gx, *out)
+
+
+class _LinearView:
+    """what _Launch needs of a Linear layer, around bare tensors (inside an autograd node there are no modules)"""
+
+    def __init__(self, weight, bias):
+        self.weight, self.bias = weight, bias
+        self.out_features, self.in_features = weight.shape
+
+
+def _all_elu_chain(mods):
+    """[Linear, ELU(1)] x n with n >= 1 and nothing else -> the Linear modules, else None"""
+    if len(mods) < 2 or len(mods) % 2:
+        return None
+    lins = []
+    for k in range(0, len(mods), 2):
+        m, a = mods[k], mods[k + 1]
+        if not (isinstance(m, nn.Linear) and isinstance(a, nn.ELU) and a.alpha == 1.0 and m.bias is not None and m.weight.requires_grad and m.out_features % 4 == 0
+                and m.in_features >= 4 and m.weight.dtype == torch.float32):
+            return None
+        lins.append(m)
+    return lins
+
+
 class FusedSequential(nn.Sequential):
     """nn.Sequential whose (Linear, ELU(alpha=1)) pairs take the fused path when gradients are being recorded."""
 
@@ -271,6 +445,9 @@ class FusedSequential(nn.Sequential):
             lins = _whole_mlp(mods)
             if lins is not None:
                 return _FusedMLP.apply(x if x.is_contiguous() else x.contiguous(), *[t for m in lins for t in (m.weight, m.bias)])
+            lins = _all_elu_chain(mods) if (_SPLIT or _NN.go2nn_is_device_library() == 0) and _CHAIN else None
+            if lins is not None:          # (the sink's single-chain keys: one chain per node)
+                return _FusedChain.apply(x if x.is_contiguous() else x.contiguous(), *[t for m in lins for t in (m.weight, m.bias)])
         i = 0
         while i < len(mods):
             m = mods[i]
@@ -303,6 +480,7 @@ _PAIR = os.environ.get("GO2_MLP_PAIR", "1") == "1"       # 0: one node per netwo
 # The hidden layers' products on the bf16 matrix pipe with fp32 operands (include/go2nn.h ABI 4: every fp32 value split exactly into three bf16 planes, six MFMA terms,
 # fp32 accumulation — as close to float64 as the fp32-MFMA kernels, tests/test_gpu_mlp_tail.py).  0: the fp32-MFMA kernels.
 _SPLIT = os.environ.get("GO2_GEMM_SPLIT", "1") == "1"
+_CHAIN = os.environ.get("GO2_MLP_CHAIN", "1") == "1"       # 0: per-layer autograd nodes (hipBLASLt) for the all-ELU chains (the MoE encoders' backbones) instead of _FusedChain (A/B)
 
 
 def _split_images(ws, H, dev, stream):

@@ -94,102 +94,7 @@ def cts_plan(model):
     return CtsPlan(te, la, lc, st, L)
 
 
-class _Launch:
-    """The go2nn calls of one mini-batch on one device / stream; collects the fixed-order reductions of the pass for ONE go2nn_sum_rows launch."""
-
-    def __init__(self, dev):
-        self.dev, self.nn = dev, fused._NN
-        self.stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else None
-        self.sums = []          # (partial rows, result, nrows, ncols[, acc, nacc])
-
-    def new(self, *shape):
-        return torch.empty(*shape, device=self.dev, dtype=torch.float32)
-
-    def check(self, rc, what):
-        if rc != 0:
-            raise RuntimeError("%s failed: %s" % (what, self.nn.go2nn_last_error().decode()))
-
-    def images(self, lins):
-        """split images of the layers' weights (both orientations), ONE launch; [None] * n when the split-operand kernels are off"""
-        from ..._nn import Go2nnSplitJob
-        if not fused._SPLIT:
-            return [None] * len(lins)
-        imgs, jobs = [], []
-        for m in lins:
-            N, K = m.weight.shape
-            n = self.nn.go2nn_split_weights_bytes(N, K)
-            if n <= 0:
-                raise RuntimeError("go2nn_split_weights_bytes: %s" % self.nn.go2nn_last_error().decode())
-            imgs.append(torch.empty(int(n), device=self.dev, dtype=torch.uint8))
-            jobs.append(Go2nnSplitJob(m.weight.data_ptr(), imgs[-1].data_ptr(), N, K))
-        for k in range(0, len(jobs), 16):
-            chunk = jobs[k:k + 16]
-            self.check(self.nn.go2nn_split_weights((Go2nnSplitJob * len(chunk))(*chunk), len(chunk), self.stream), "go2nn_split_weights")
-        return imgs
-
-    def forward(self, jobs, act=0):
-        """jobs: [(x [M, K], Linear, image)] (1 or 2, one launch) -> [y [M, N]];  act 0: ELU, 1: none"""
-        from ..._nn import Go2nnFwdJob
-        ys = [self.new(x.shape[0], m.out_features) for x, m, _ in jobs]
-        arr = (Go2nnFwdJob * len(jobs))(*[Go2nnFwdJob(x.data_ptr(), m.weight.data_ptr(), m.bias.data_ptr(), y.data_ptr(), x.shape[0], m.in_features, m.out_features, act,
-                                                      img.data_ptr() if img is not None else None) for (x, m, img), y in zip(jobs, ys)])
-        self.check(self.nn.go2nn_linear_elu_forward_group(arr, len(jobs), self.stream), "go2nn_linear_elu_forward_group")
-        return ys
-
-    def wgrad(self, jobs):
-        """jobs: [(gz [M, C], x [M, Kin], Linear)] with one M: the layers' weight gradients (row-slice partials now, .grad = their sum after finish())"""
-        from ..._nn import Go2nnBwdWJob
-        arr = (Go2nnBwdWJob * len(jobs))(*[Go2nnBwdWJob(gz.data_ptr(), x.data_ptr(), None, gz.shape[0], m.out_features, m.in_features, 1 if fused._SPLIT else 0) for gz, x, m in jobs])
-        rows = self.nn.go2nn_linear_backward_weight_group_rows(arr, len(jobs))
-        if rows <= 0:
-            raise RuntimeError("go2nn_linear_backward_weight_group_rows: %s" % self.nn.go2nn_last_error().decode())
-        for j, (gz, x, m) in enumerate(jobs):
-            n = m.out_features * m.in_features
-            wk, dw = self.new(rows * n), torch.empty_like(m.weight)
-            arr[j].workspace = wk.data_ptr()
-            self.sums.append((wk, dw, rows, n))
-            m.weight.grad = dw
-        self.check(self.nn.go2nn_linear_backward_weight_group(arr, len(jobs), self.stream), "go2nn_linear_backward_weight_group")
-
-    def bwd_in(self, jobs, plain=False):
-        """jobs: [(gz [M, C], Linear, y_prev [M, Kin] or None, image)] -> ([gz_prev [M, Kin]], [gb_prev [Kin]] (valid after finish(); None when plain))"""
-        from ..._nn import Go2nnBwdInJob
-        arr, outs, gbs = (Go2nnBwdInJob * len(jobs))(), [], []
-        for j, (gz, m, yp, img) in enumerate(jobs):
-            M, Co, Ki = gz.shape[0], m.out_features, m.in_features
-            o = self.new(M, Ki)
-            wk = gb = None
-            if not plain:
-                r = self.nn.go2nn_linear_backward_input_group_rows(M, Co, Ki)
-                wk, gb = self.new(r * Ki), self.new(Ki)
-                self.sums.append((wk, gb, r, Ki))
-            arr[j] = Go2nnBwdInJob(gz.data_ptr(), m.weight.data_ptr(), yp.data_ptr() if yp is not None else None, o.data_ptr(), wk.data_ptr() if wk is not None else None,
-                                   M, Co, Ki, 1 if plain else 0, img.data_ptr() if img is not None else None)
-            outs.append(o); gbs.append(gb)
-        self.check(self.nn.go2nn_linear_backward_input_group(arr, len(jobs), self.stream), "go2nn_linear_backward_input_group")
-        return outs, gbs
-
-    def chain_backward(self, chains):
-        """chains: 1 or 2 dicts {lins, acts, gz, gb, imgs} of equally many layers and one M: gz / gb = the gradient at lins[-1]'s output and its column sums;
-        acts[l] = the input of lins[l] (acts[l > 0] an ELU output).  Sets .grad of every weight and bias; -> the gradients at lins[0]'s pre-activation."""
-        n = len(chains[0]["lins"])
-        gz, gb = [c["gz"] for c in chains], [c["gb"] for c in chains]
-        for l in range(n - 1, -1, -1):
-            self.wgrad([(gz[j], c["acts"][l], c["lins"][l]) for j, c in enumerate(chains)])
-            for j, c in enumerate(chains):
-                c["lins"][l].bias.grad = gb[j]
-            if l > 0:
-                gz, gb = self.bwd_in([(gz[j], c["lins"][l], c["acts"][l], c["imgs"][l]) for j, c in enumerate(chains)])
-        return gz
-
-    def finish(self):
-        from ..._nn import Go2nnSumJob
-        for k in range(0, len(self.sums), 32):
-            chunk = self.sums[k:k + 32]
-            arr = (Go2nnSumJob * len(chunk))(*[Go2nnSumJob(t[0].data_ptr(), t[1].data_ptr(), t[2], t[3], t[4].data_ptr() if len(t) > 4 and t[4] is not None else None,
-                                                           t[5] if len(t) > 4 and t[4] is not None else 0, 0) for t in chunk])
-            self.check(self.nn.go2nn_sum_rows(arr, len(chunk), self.stream), "go2nn_sum_rows")
-        self.sums = []
+_Launch = fused._Launch
 
 
 def _p(t):
@@ -297,3 +202,35 @@ def encoder_latents(plan, lins, x, dst_a, dst_b):
             h = k.forward([(h, m, imgs[l])], act=1 if l == len(lins) - 1 else 0)[0]
         latent_concat(k, h, dst_a, dst_b)
     return h
+
+
+def moe_head_grads(logits, outs, t_hat, lb_coef, acc=None):
+    """The loss head of the MoE student step (moe_cts.py:203-214 over modules/utils.py:96-152) with its analytic gradients, as two launches + the reductions:
+    logits [n, E] (the gate before its softmax), outs [n, E, L] (the experts' outputs), t_hat [n, L] (the teacher's normalised latent).
+    acc: optional float32[>= 2] — latent loss and load-balance loss are ADDED to acc[0:2].  -> stats [latent loss, load balance], d loss / d logits, d loss / d outs"""
+    k = _Launch(logits.device)
+    nn_ = k.nn
+    n, E = logits.shape
+    L = outs.shape[2]
+    cont = lambda t: t.detach() if t.is_contiguous() else t.detach().contiguous()
+    logits, outs, t_hat = cont(logits), cont(outs), cont(t_hat)
+    with torch.no_grad():
+        r = nn_.go2nn_l2norm_backward_rows(n)
+        upart, usage = k.new(r * E), k.new(E)
+        k.check(nn_.go2nn_moe_usage(_p(logits), _p(upart), n, E, k.stream), "go2nn_moe_usage")
+        k.sums.append((upart, usage, r, E))
+        k.finish()
+        dl, do, part, tot = k.new(n, E), k.new(n, E, L), k.new(r * 4), k.new(4)
+        k.check(nn_.go2nn_moe_mix_loss(_p(logits), _p(outs), _p(t_hat), _p(usage), _p(dl), _p(do), _p(part), n, E, L, float(lb_coef), k.stream), "go2nn_moe_mix_loss")
+        k.sums.append((part, tot, r, 4, acc, 2))
+        k.finish()
+    return tot[:2], dl, do
+
+
+def moe_head_applicable(model, L):
+    """the fused MoE loss head needs the library pair, an L2-normalised mixture and the model's `student_moe_parts` hook (gate logits and expert outputs before the mix)"""
+    from .utils import L2Norm
+    enc = getattr(model, "student_moe_encoder", None)
+    return (fused._LIB is not None and fused._NN is not None and hasattr(model, "student_moe_parts") and enc is not None and isinstance(getattr(enc, "norm_layer", None), L2Norm)
+            and _latent_ok(L) and getattr(enc, "expert_num", getattr(getattr(enc, "moe", None), "expert_num", 99)) <= 16)
+

@@ -109,11 +109,16 @@ class MoE(nn.Module):
         outs = self.experts(x)                                         # [B, E, out]
         return torch.sum(weights.unsqueeze(-1) * outs, dim=1), weights                   # [B, out]
 
+    def parts(self, x):
+        """-> (gate logits [B, E] — the gating MLP before its softmax —, expert outputs [B, E, out]): what the fused loss head of the student step mixes itself"""
+        return self.gating_network[0](x), self.experts(x)
+
 
 class StudentMoEEncoder(nn.Module):
     def __init__(self, expert_num, input_dim, hidden_dims, output_dim, activation="elu", norm_type="l2norm"):
         super().__init__()
         self.norm_layer = make_norm(norm_type)
+        self.expert_num = expert_num
         self.moe = MoE(expert_num, input_dim, hidden_dims, output_dim, activation)
 
     def forward(self, obs):

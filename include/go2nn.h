@@ -192,6 +192,17 @@ int go2nn_latent_concat(const float* z, int32_t n, int32_t L, float* dst_a, int3
 int go2nn_l2norm_backward(const float* g, int32_t ldg, const float* zhat, int32_t ldz, const float* inv_norm, float* dz, float* partials, int32_t n, int32_t L, void* stream);
 int go2nn_latent_mse(const float* z_s, const float* z_t, float* dz_s, float* partials, int32_t n, int32_t L, float grad_scale, void* stream);
 
+/* The loss head of the MoE student step (rsl_rl/rsl_rl/modules/utils.py:96-152: MoE.forward + StudentMoEEncoder's normaliser; rsl_rl/rsl_rl/algorithms/moe_cts.py:203-214):
+ *   w = softmax(logits [n, E]);  y = sum_e w_e outs[:, e, :] (outs [n, E, L]);  shat = y / max(|y|, 1e-12);  latent loss = mean((t_hat - shat)^2)   (t_hat [n, L]: the teacher's
+ *   NORMALISED latent);  usage = mean over rows of w;  load balance = mean_e((usage_e - 1 / E)^2);  loss = latent + lb_coef * load balance
+ * with its analytic gradients — two launches (the load-balance gradient needs the batch mean of the gate first) in place of ~55 element-wise / reduction launches of autograd:
+ *   go2nn_moe_usage      partials = go2nn_l2norm_backward_rows(n) rows of E: column partial sums of w (go2nn_sum_rows -> usage_sum [E], sums not means)
+ *   go2nn_moe_mix_loss   d_logits [n, E], d_outs [n, E, L] = d loss / d logits, / d outs;  partials = go2nn_l2norm_backward_rows(n) rows of 4: [ latent loss | load balance (row 0) | 0 | 0 ]
+ * E <= 16; L as above.  Fixed summation order. */
+int go2nn_moe_usage(const float* logits, float* partials, int32_t n, int32_t E, void* stream);
+int go2nn_moe_mix_loss(const float* logits, const float* outs, const float* t_hat, const float* usage_sum, float* d_logits, float* d_outs, float* partials,
+                       int32_t n, int32_t E, int32_t L, float lb_coef, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -189,3 +189,64 @@ def test_plan_refuses_what_the_kernels_do_not_cover():
         assert fused_cts.cts_plan(ActorCriticCTS(45, 60, 12, 8, 5, latent_dim=8, **base)) is None
     finally:
         fused.set_library(None); fused.set_nn_library(None)
+
+
+def chain_vs_autograd(nn_lib, sim_lib, device, B=200, dims=(45, 64, 32, 96), atol=2e-6):
+    """modules/fused.py:_FusedChain (an MLP with an ELU behind EVERY layer — the experts' backbone of the MoE encoders — as one autograd node on the split-operand
+    kernels) against plain autograd: output, every parameter gradient, the input gradient"""
+    from go2_rl_gym_amd.rsl_rl.modules import fused
+    from go2_rl_gym_amd.rsl_rl.modules.utils import MLP
+    torch.manual_seed(9)
+    net = MLP(list(dims), "elu", last_activation=True).to(device)
+    x, tgt = torch.randn(B, dims[0], device=device, requires_grad=True), torch.randn(B, dims[-1], device=device)
+    res = []
+    for on in (False, True):
+        fused.set_library(sim_lib if on else None); fused.set_nn_library(nn_lib if on else None)
+        try:
+            net.zero_grad(); x.grad = None
+            out = net(x)
+            assert (type(out.grad_fn).__name__ == "_FusedChainBackward") == on
+            ((out - tgt) ** 2).mean().backward()
+            res.append((out.detach().clone(), [q.grad.clone() for q in net.parameters()] + [x.grad.clone()]))
+        finally:
+            fused.set_library(None); fused.set_nn_library(None)
+    np.testing.assert_allclose(res[1][0].cpu().numpy(), res[0][0].cpu().numpy(), atol=atol * 4, rtol=2e-5)
+    for a, b in zip(res[1][1], res[0][1]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=atol + 2e-5 * float(b.abs().max()), rtol=2e-3)
+    return res[1][1]
+
+
+@pytest.mark.parametrize("B,dims", [(200, (45, 64, 32, 96)), (77, (225, 40)), (130, (60, 48, 24, 8, 64))])
+def test_all_elu_chain_node_matches_autograd(B, dims):
+    chain_vs_autograd(load_nn_emu(), load_oracle(), "cpu", B, dims)
+
+
+def moe_head_vs_autograd(nn_lib, sim_lib, device, n=150, E=8, L=32, coef=0.01):
+    """fused_cts.moe_head_grads (go2nn_moe_usage + go2nn_moe_mix_loss) against the reference's formulation under autograd (modules/utils.py:96-152 MoE.forward +
+    the normaliser; moe_cts.py:203-214): both losses, d loss / d gate logits, d loss / d expert outputs"""
+    from go2_rl_gym_amd.rsl_rl.modules import fused, fused_cts
+    g = torch.Generator().manual_seed(n * 31 + E)
+    logits = (torch.randn(n, E, generator=g) * 2).to(device).requires_grad_(True)
+    outs = torch.randn(n, E, L, generator=g).to(device).requires_grad_(True)
+    t_hat = torch.nn.functional.normalize(torch.randn(n, L, generator=g), dim=-1).to(device)
+    w = torch.softmax(logits, dim=-1)
+    lat = torch.nn.functional.normalize(torch.sum(w.unsqueeze(-1) * outs, dim=1), p=2.0, dim=-1)
+    latent_loss = (t_hat - lat).pow(2).mean()
+    lb = (w.mean(dim=0) - 1.0 / E).pow(2).mean()
+    (latent_loss + coef * lb).backward()
+    fused.set_library(sim_lib); fused.set_nn_library(nn_lib)
+    try:
+        acc = torch.full((2,), 5.0, device=device)
+        stats, dl, do = fused_cts.moe_head_grads(logits.detach(), outs.detach(), t_hat, coef, acc=acc)
+    finally:
+        fused.set_library(None); fused.set_nn_library(None)
+    np.testing.assert_allclose(stats.cpu().numpy(), [float(latent_loss), float(lb)], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(acc.cpu().numpy() - 5.0, stats.cpu().numpy(), atol=2e-6)
+    np.testing.assert_allclose(dl.cpu().numpy(), logits.grad.cpu().numpy(), atol=2e-6 * float(logits.grad.abs().max()) + 1e-10, rtol=2e-4)
+    np.testing.assert_allclose(do.cpu().numpy(), outs.grad.cpu().numpy(), atol=2e-6 * float(outs.grad.abs().max()) + 1e-10, rtol=2e-4)
+    return [stats, dl, do]
+
+
+@pytest.mark.parametrize("n,E,L,coef", [(150, 8, 32, 0.01), (1, 4, 8, 1.0), (67, 16, 4, 0.5), (300, 3, 128, 0.0)])
+def test_moe_loss_head_matches_autograd(n, E, L, coef):
+    moe_head_vs_autograd(load_nn_emu(), load_oracle(), "cpu", n, E, L, coef)

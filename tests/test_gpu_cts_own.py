@@ -37,3 +37,24 @@ def test_cts_student_step_on_gpu(n, dims):
     torch.cuda.synchronize()
     for u, v in zip(a, b):
         assert torch.equal(u, v)
+
+
+from test_cts_own import chain_vs_autograd  # noqa: E402
+
+
+@pytest.mark.parametrize("B,dims", [(12288, (225, 512, 256, 2048)), (6144, (225, 512, 256, 2048)), (1000, (225, 512, 256, 2048)), (200, (45, 64, 32, 96)), (77, (225, 40))])
+def test_all_elu_chain_node_on_gpu(B, dims):
+    """the MoE student encoder's backbone (225 -> 512 -> 256 -> 8 x 256, an ELU behind every layer) as one autograd node on the split-operand kernels"""
+    chain_vs_autograd(_nn.load_nn(), load_hip(), "cuda:0", B, dims, atol=3e-6)
+
+
+from test_cts_own import moe_head_vs_autograd  # noqa: E402
+
+
+@pytest.mark.parametrize("n,E,L,coef", [(12288, 8, 32, 0.01), (6144, 8, 32, 0.01), (1, 4, 8, 1.0), (67, 16, 4, 0.5), (300, 3, 128, 0.0), (1000, 8, 32, 1.0)])
+def test_moe_loss_head_on_gpu(n, E, L, coef):
+    a = moe_head_vs_autograd(_nn.load_nn(), load_hip(), "cuda:0", n, E, L, coef)
+    b = moe_head_vs_autograd(_nn.load_nn(), load_hip(), "cuda:0", n, E, L, coef)
+    torch.cuda.synchronize()
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)

@@ -25,4 +25,11 @@ for a, b in zip(idx, idx[1:]):
         show(seg[L[3]:L[4] + 1], "one mini-batch (loss / heads kernel .. the next one)")
         pre = seg[:L[0]]
         show(pre[-60:], "before the first mini-batch (GAE, permutation gathers, first forward)")
+        # the CTS family's student phase: optimizer steps that follow no loss-head kernel; one step = Adam step .. the next Adam step
+        A = [i for i, r in enumerate(seg) if r[0].startswith("go2_adam_step_kernel")]
+        stu = [(a, b) for a, b in zip(A, A[1:]) if a > L[-1]]
+        if len(stu) > 4:
+            a, b = stu[len(stu) // 2]
+            print("student phase: %d steps, %.2f ms" % (len(stu) + 1, (seg[A[-1]][2] - seg[stu[0][0]][2]) / 1e6))
+            show(seg[a + 1:b + 1], "one student step (behind an Adam step .. the next Adam step)")
         break
