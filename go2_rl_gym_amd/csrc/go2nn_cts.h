@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(CTS_ROWS_PER_WG) go2nn_moe_usage_kernel(const 
 
 __global__ void __launch_bounds__(256) go2nn_moe_mix_kernel(const float* __restrict__ logits, const float* __restrict__ outs, const float* __restrict__ that,
                                                             const float* __restrict__ usage_sum, float* __restrict__ dlogits, float* __restrict__ douts, float* __restrict__ part,
-                                                            int n, int E, int L, float coef) {
+                                                            int n, int E, int L, float coef, long long sr, long long se) {          // outs / douts element (r, e, c) at r sr + e se + c
   __shared__ float shl[256];
   const int LP = L >> 2, RL = 256 / LP, cq = threadIdx.x % LP, rl = threadIdx.x / LP, c = cq * 4;
   const int r0 = blockIdx.x * CTS_ROWS_PER_WG, r1 = min(n, r0 + CTS_ROWS_PER_WG);
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(256) go2nn_moe_mix_kernel(const float* __restr
 #pragma unroll
     for (int e = 0; e < MOE_MAX_E; ++e) {
       w[e] = e < E ? logits[(size_t)rc * E + e] : -3.4e38f; mx = fmaxf(mx, w[e]);
-      o[e] = e < E ? *reinterpret_cast<const float4*>(outs + ((size_t)rc * E + e) * L + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      o[e] = e < E ? *reinterpret_cast<const float4*>(outs + (size_t)rc * sr + (size_t)e * se + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int e = 0; e < MOE_MAX_E; ++e) { w[e] = e < E ? expf(w[e] - mx) : 0.f; sum += w[e]; }
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256) go2nn_moe_mix_kernel(const float* __restr
 #pragma unroll
     for (int e = 0; e < MOE_MAX_E; ++e) {
       if (e < E) {
-        if (live) *reinterpret_cast<float4*>(douts + ((size_t)r * E + e) * L + c) = make_float4(w[e] * dy.x, w[e] * dy.y, w[e] * dy.z, w[e] * dy.w);
+        if (live) *reinterpret_cast<float4*>(douts + (size_t)r * sr + (size_t)e * se + c) = make_float4(w[e] * dy.x, w[e] * dy.y, w[e] * dy.z, w[e] * dy.w);
         dw[e] = cts_group_sum(dy.x * o[e].x + dy.y * o[e].y + dy.z * o[e].z + dy.w * o[e].w, LP) + lbg[e];
         wd = fmaf(w[e], dw[e], wd);
       } else dw[e] = 0.f;

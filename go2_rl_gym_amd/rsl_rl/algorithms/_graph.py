@@ -148,8 +148,6 @@ def all_captured(steps):
         return len(steps) > 0 and all(all_captured(s) for s in steps)
     if isinstance(steps, ReducedStep):
         return steps.front.graph is not None and steps.back.graph is not None
-    if isinstance(steps, OverlappedStep):
-        return steps.front_a.graph is not None and steps.front_b.graph is not None and steps.back.graph is not None
     return steps.graph is not None
 
 
@@ -200,25 +198,4 @@ class ReducedStep:
     def __call__(self):
         self.front()
         self.bucket().reduce()
-        self.back()
-
-
-class OverlappedStep:
-    """front_a() | all-reduce(bucket_a) ‖ front_b() | all-reduce(bucket_b) | back() — three captured pieces per mini-batch slot.  The first
-    bucket (the critic's gradients, the larger network) is reduced WHILE the second piece (the actor's backward pass) runs; only the second,
-    smaller collective (actor gradients + the mean KL) is exposed.  Same sums as ReducedStep's single bucket — the schedule changes nothing in
-    the arithmetic (tests/test_distributed.py compares the two bit for bit)."""
-
-    def __init__(self, front_a, front_b, back, bucket_a, bucket_b, enabled=True, warmup=3, name="step"):
-        self.front_a = CapturedStep(front_a, enabled, warmup, name + " (forward, loss, critic backward)")
-        self.front_b = CapturedStep(front_b, enabled, warmup, name + " (actor backward)")
-        self.back = CapturedStep(back, enabled, warmup, name + " (optimizer)")
-        self.bucket_a, self.bucket_b = bucket_a, bucket_b
-
-    def __call__(self):
-        self.front_a()
-        w1 = self.bucket_a().reduce_async()
-        self.front_b()
-        w2 = self.bucket_b().reduce_async()
-        w1.wait(); w2.wait()
         self.back()

@@ -216,7 +216,8 @@ class CTS(_RolloutHeads):
         """-> the env-ordered latent [N, L]: one launch for both encoders; a student encoder that is not a plain MLP (MoE) runs as torch modules, without gradient, on the same stream"""
         latent = self._latent_buf
         if pk.enc_s is None:
-            with torch.no_grad():
+            from ..modules.fused import own_forward
+            with torch.no_grad(), own_forward():
                 latent.index_copy_(0, self.student_env_idxs, self.model.student_latent(history[self.student_env_idxs])[0])
         pk.latents(privileged_obs, history, latent)
         return latent
@@ -473,7 +474,8 @@ class CTS(_RolloutHeads):
         nmb, mb, n_t, plan = self.num_mini_batches, self._mb, self._teacher_rows(), self._plan
         L, P = plan.L, self._perm
         hist = P["hist"].view(nmb, mb, -1)[:, n_t:].reshape(nmb * (mb - n_t), -1)
-        with torch.no_grad():
+        from ..modules.fused import own_forward
+        with torch.no_grad(), own_forward():          # (the MoE encoders' Linear / ELU stacks on the library's kernels also without a gradient)
             lat = None if plan.student is not None else self.model.student_latent(hist)[0].view(nmb, mb - n_t, L)
             for i in range(nmb):
                 da, dc = P["ain"][i * mb + n_t:(i + 1) * mb], P["cin"][i * mb + n_t:(i + 1) * mb]

@@ -29,7 +29,7 @@ class MoECTS(CTS):
         if not (self.fused_loss and fused_cts.moe_head_applicable(self.model, t_hat.shape[1])):
             return super()._student_backward(hist_s, priv_s, teacher_latent)
         logits, outs = self.model.student_moe_parts(hist_s)
-        _, dl, do = fused_cts.moe_head_grads(logits, outs, t_hat, self.load_balance_coef, acc=self._acc[3 + self._NUM_POLICY_LOGS:])
+        _, dl, do = fused_cts.moe_head_grads(logits, outs, t_hat, self.load_balance_coef, acc=self._acc[3 + self._NUM_POLICY_LOGS:], expert_major=True)
         torch.autograd.backward([logits, outs], [dl, do])
 
 

@@ -24,17 +24,9 @@ import torch.optim as optim
 
 from ..modules.actor_critic import ActorCritic as _AC
 from ..storage import RolloutStorage
-from ._graph import CapturedStep, FusedClipAdam, GradBucket, OverlappedStep, ReducedStep, all_captured
+from ._graph import CapturedStep, FusedClipAdam, GradBucket, ReducedStep, all_captured
 
 
-# Two independent sub-networks of one model on two HIP streams (the CTS family's encoders / heads; PPO's actor | critic pair only when the grouped kernels of
-# modules/fused.py:pair_forward do not apply).  Round 3 found that with two chains of hipBLASLt GEMMs in flight the first iteration never finishes once the GEMMs
-# see more than 24576 rows (profiles/r3_kernel_scaling.txt section 3: 8192 envs x 24 steps / 4 mini-batches; 4096 envs = 24576 rows is what every BASELINE
-# configuration has per GPU and runs) — the cause was never established (no reproducer outside the whole job), so the mode is gated on the ROWS the concurrent
-# GEMMs see (mini-batch rows in update(), envs in act()), not on the env count: 4096 envs with 1 or 2 mini-batches is 98304 / 49152 rows.
-# PPO itself no longer forks a stream: actor and critic layers are grouped launches (round 4).  GO2_TWO_STREAMS=0 switches the fork off everywhere.
-_TWO_STREAMS = os.environ.get("GO2_TWO_STREAMS", "1") == "1"
-_TWO_STREAM_MAX_ROWS = 24576
 _ADAM_IMPL = {"foreach": True} if os.environ.get("GO2_ADAM", "fused") == "foreach" else {"fused": True}
 
 
@@ -71,7 +63,6 @@ _PLAIN = (_AC._noise, _ACC._noise)          # the modules' own _noise functions 
 
 class _RolloutHeads:
     """Shared pieces of the PPO-family algorithms: two-stream actor/critic evaluation and the per-step rollout heads."""
-    _side = None
     _eps_all = None
     _pk_packed = False          # the policy kernel's packed weights are those of the current parameters (they change in update() only)
     _pk_recorded = False        # the rollout last RUN THROUGH PYTHON (eager, or while being captured) packed at its first step: what a replay of that capture does too
@@ -109,42 +100,14 @@ class _RolloutHeads:
         self._pk_packed = bool(self._pk_recorded)
 
     def _pair(self, main_fn, side_fn, enabled=True):
-        """-> (main_fn(), side_fn()) with side_fn on a second HIP stream when on a GPU: the actor and the critic are independent
-        networks, so their GEMMs and the many small element-wise kernels between them overlap (also inside a captured graph, where
-        the fork / join become graph dependencies; autograd runs each backward on its forward's stream)."""
-        if not (enabled and _TWO_STREAMS and self._two_stream_rows_ok() and str(self.device).startswith("cuda")):
-            return main_fn(), side_fn()
-        cur = torch.cuda.current_stream()
-        if self._side is None:
-            self._side = torch.cuda.Stream()
-            try:    # the critic's AccumulateGrad nodes live on the side stream on purpose
-                torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
-            except AttributeError:
-                pass
-        self._side.wait_stream(cur)
-        with torch.cuda.stream(self._side):
-            b = side_fn()
-        a = main_fn()
-        cur.wait_stream(self._side)
-        return a, b
-
-    def _two_stream_rows_ok(self):
-        st = getattr(self, "storage", None)
-        if st is None:
-            return True
-        mb = st.num_envs * st.num_transitions_per_env // max(1, int(getattr(self, "num_mini_batches", 1)))
-        return max(st.num_envs, mb) <= _TWO_STREAM_MAX_ROWS
+        """-> (main_fn(), side_fn()).  Rounds 2-4 ran side_fn on a second HIP stream; with the grouped launches (PPO, CTS, MoE-CTS never reach this in their updates) the fork
+        only served network shapes outside the BASELINE configurations, and two hipBLASLt stream-K kernels side by side were the hang of round 3 that was never
+        explained — the second stream is gone."""
+        return main_fn(), side_fn()
 
     def _actor_critic(self, ac, obs, cobs):
-        """-> (ac.actor(obs), ac.evaluate(cobs)).  A plain ActorCritic of two Linear / ELU MLPs with the same hidden widths: ONE autograd node whose layers are
-        grouped launches over both networks (modules/fused.py:_FusedPair, include/go2nn.h ABI 3) — no second stream.  Anything else: the two modules one by
-        one, on two streams where that is safe."""
-        if type(ac) is _AC and torch.is_grad_enabled():
-            from ..modules import fused
-            out = fused.pair_forward(ac.actor, ac.critic, obs, cobs)
-            if out is not None:
-                return out
-        return self._pair(lambda: ac.actor(obs), lambda: ac.evaluate(cobs), enabled=self._capture)
+        """-> (ac.actor(obs), ac.evaluate(cobs)) under autograd: one node per network (modules/fused.py:_FusedMLP)"""
+        return ac.actor(obs), ac.evaluate(cobs)
 
     # The two per-step element-wise heads of the rollout as library kernels (go2sim_act_head, go2sim_store_transition): sampling +
     # log-prob + the storage rows in one launch, reward bootstrap + done copy in another, instead of ~23 small launches.
@@ -492,41 +455,6 @@ class PPO(_RolloutHeads):
         from ..modules import fused
         return fused.ppo_pair_applicable(self.actor_critic, batch[0], batch[1])
 
-    # ---- more than one rank, overlapped schedule (OverlappedStep): the critic's gradients are on the wire while the actor's backward runs ----
-    # OFF by default (GO2_OVERLAP_ALLREDUCE=1 switches it on).  Measured on one MI355X with a 1-rank RCCL group (profiles/r3_collectives.txt):
-    # no collectives 4.60 M env-steps/s, serial schedule (one bucket between two captured halves) 4.54 M (-1.3 %), overlapped schedule 3.81 M
-    # (-17 %): giving the critic's backward pass a head start means the two backward passes no longer run side by side on two streams, and
-    # that overlap is worth far more than hiding a 1.2 MB all-reduce.  Whether it pays with 8 ranks on xGMI is unmeasured.
-    def _overlap_on(self):
-        return (self.fused_loss and os.environ.get("GO2_OVERLAP_ALLREDUCE", "0") == "1" and hasattr(self.actor_critic, "actor") and hasattr(self.actor_critic, "critic")
-                and not any(p is q for p in self.actor_critic.actor.parameters() for q in self.actor_critic.critic.parameters()))
-
-    def _graph_front_a(self, i):
-        mb, ac = self._mb, self.actor_critic
-        batch = [self._perm[k][i * mb:(i + 1) * mb] for k in self._KEYS]
-        mu_b, val_b = self._pair(lambda: ac.actor(batch[0]), lambda: ac.evaluate(batch[1]), enabled=self._capture)
-        stats, gmu, gstd, gval = _FusedPPOLoss.kernel(self, mu_b, ac.std, val_b, *batch[2:])
-        self.optimizer.zero_grad(set_to_none=True)
-        torch.autograd.backward([val_b], [gval])                       # the critic first: its (larger) bucket gets the overlap
-        self._acc.add_(stats[:2])
-        self._held = (mu_b, gmu, gstd, stats[2])                       # alive until the actor's backward has been issued (also across two captures)
-        if self._bucket_c is None:
-            self._bucket_c = GradBucket(list(ac.critic.parameters()))
-        self._bucket_c.pack()
-
-    def _graph_front_b(self):
-        ac = self.actor_critic
-        mu_b, gmu, gstd, kl_mean = self._held
-        torch.autograd.backward([mu_b, ac.std], [gmu, gstd.view_as(ac.std)])
-        if self._bucket is None:
-            self._bucket = GradBucket(list(ac.actor.parameters()) + [ac.std], 1 if self._adaptive() else 0)
-        self._bucket.pack(kl_mean)
-        self._held = None
-
-    def _graph_back_overlapped(self):
-        self._bucket_c.unpack(_world())
-        self._graph_back(True)
-
     def _graph_back(self, split=False):
         """LR decision, gradient clipping, Adam.  split: on the all-reduced bucket (shard-mean gradients and KL: every rank takes the
         same LR branch); otherwise on this rank's gradients."""
@@ -567,11 +495,8 @@ class PPO(_RolloutHeads):
             # a side stream first (allocator / lazy initialisation settle; they are real PPO steps of the first update), the others
             # one; then each is captured once and replayed.  A failed capture degrades that slot to eager execution.
             # More than one rank: two captured halves per slot with the gradient all-reduce eager between them (_graph.py).
-            self._bucket, self._bucket_c, self._held = None, None, None
-            if _collectives_on() and self._overlap_on():
-                self._graph = [OverlappedStep((lambda i=i: self._graph_front_a(i)), self._graph_front_b, self._graph_back_overlapped, (lambda: self._bucket_c), (lambda: self._bucket),
-                                              enabled=self._capture, warmup=3 if i == 0 else 1, name="PPO mini-batch step %d" % i) for i in range(nmb)]
-            elif _collectives_on():
+            self._bucket = None
+            if _collectives_on():
                 self._graph = [ReducedStep((lambda i=i: self._graph_front(i, True)), (lambda: self._graph_back(True)), (lambda: self._bucket),
                                            enabled=self._capture, warmup=3 if i == 0 else 1, name="PPO mini-batch step %d" % i) for i in range(nmb)]
             else:

@@ -72,7 +72,7 @@ def cts_plan(model):
     heads are the base class's ([latent | obs] -> actor MLP, [latent | privileged obs] -> critic MLP, one std per action), every network is Linear / ELU with an
     L2-normalised latent, actor and critic share their hidden widths, and the split-operand kernels are on (the plain input gradient of a 77-wide layer exists only there)."""
     from .actor_critic_cts import ActorCriticCTS
-    if not (fused._HEADS and fused._PAIR and fused._LIB is not None and fused._NN is not None and isinstance(model, ActorCriticCTS)):
+    if not (fused._LIB is not None and fused._NN is not None and isinstance(model, ActorCriticCTS)):
         return None
     if not (fused._SPLIT or fused._NN.go2nn_is_device_library() == 0):
         return None
@@ -115,14 +115,11 @@ def cts_policy_grads(plan, model, ain, cin, priv_t, batch, n_t, clip, vcoef, eco
     teacher rows' privileged observations (the teacher encoder's input).  batch: actions, old values, advantages, returns, old log-probs, old mu, old sigma.
     acc: optional float32[>= 4] — [surrogate, value loss, KL, entropy] of the mini-batch are ADDED to it by the pass's go2nn_sum_rows launch.
     -> stats [surrogate, value loss, KL, entropy] (device tensor; valid after the launches)"""
-    from ..._nn import Go2nnPpoHeads
-    actions, old_values, adv, returns, old_logp, old_mu, old_sigma = batch
     k = _Launch(ain.device)
     nn_ = k.nn
     te, la, lc, L = plan.teacher, plan.actor, plan.critic, plan.L
-    H, B = len(la) - 1, ain.shape[0]
+    H = len(la) - 1
     cont = lambda t: t.detach() if t.is_contiguous() else t.detach().contiguous()
-    flat = lambda t: cont(t).reshape(-1)
     with torch.no_grad():
         imgs = k.images(te + la[:H] + lc[:H])
         ie, ia, ic = imgs[:len(te)], imgs[len(te):len(te) + H], imgs[len(te) + H:]
@@ -132,30 +129,8 @@ def cts_policy_grads(plan, model, ain, cin, priv_t, batch, n_t, clip, vcoef, eco
             eacts.append(k.forward([(eacts[-1], m, ie[l])], act=1 if l == len(te) - 1 else 0)[0])
         inv = k.new(n_t)
         latent_concat(k, eacts[-1], ain, cin, inv)
-        # actor + critic hidden layers, grouped
-        acts = [[ain], [cin]]
-        for l in range(H):
-            ys = k.forward([(acts[0][-1], la[l], ia[l]), (acts[1][-1], lc[l], ic[l])])
-            acts[0].append(ys[0]); acts[1].append(ys[1])
-        # heads forward + PPO loss (split surrogate) + heads backward
-        A, K = la[H].weight.shape
-        rows, cols = nn_.go2nn_ppo_heads_rows(B, A, K), nn_.go2nn_ppo_heads_cols(A, K)
-        if rows <= 0 or cols <= 0:
-            raise RuntimeError("go2nn_ppo_heads: %s" % nn_.go2nn_last_error().decode())
-        gz = [k.new(B, K), k.new(B, K)]
-        part, tot = k.new(rows * cols), k.new(cols)
-        keep = [cont(actions), cont(old_mu), cont(old_sigma), flat(old_logp), flat(adv), flat(old_values), flat(returns), cont(model.std)]
-        p = lambda t: t.data_ptr()
-        h = Go2nnPpoHeads(p(acts[0][H]), p(acts[1][H]), p(la[H].weight), p(la[H].bias), p(lc[H].weight), p(lc[H].bias), p(keep[7]), p(keep[0]), p(keep[1]), p(keep[2]), p(keep[3]),
-                          p(keep[4]), p(keep[5]), p(keep[6]), p(gz[0]), p(gz[1]), p(part), B, A, K, int(bool(use_clipped_value_loss)), float(clip), float(vcoef), float(ecoef), int(n_t))
-        k.check(nn_.go2nn_ppo_heads(C.byref(h), k.stream), "go2nn_ppo_heads")
-        k.sums.append((part, tot, rows, cols, acc, 4))
-        o = 4 + A
-        model.std.grad = tot[4:o].view_as(model.std)
-        la[H].weight.grad, gb_a, la[H].bias.grad = tot[o:o + A * K].view(A, K), tot[o + A * K:o + (A + 1) * K], tot[o + (A + 1) * K:o + (A + 1) * K + A]
-        o += (A + 1) * K + A
-        lc[H].weight.grad, gb_c, lc[H].bias.grad = tot[o:o + K].view(1, K), tot[o + K:o + 2 * K], tot[o + 2 * K:o + 2 * K + 1]
-        gz1 = k.chain_backward([{"lins": la[:H], "acts": acts[0], "gz": gz[0], "gb": gb_a, "imgs": ia}, {"lins": lc[:H], "acts": acts[1], "gz": gz[1], "gb": gb_c, "imgs": ic}])
+        # actor + critic: grouped hidden layers, heads + PPO loss with the split surrogate, backward down to the first layers' pre-activations
+        tot, gz1 = fused.pair_grads(k, la, lc, ain, cin, model.std, batch, clip, vcoef, ecoef, use_clipped_value_loss, surrogate_split=n_t, acc=acc, imgs=(ia, ic))
         # into the teacher encoder: d loss / d [latent | obs] of the actor on the teacher rows (the critic sees latent.detach()), through the normaliser
         g_in = k.bwd_in([(gz1[0][:n_t], la[0], None, ia[0])], plain=True)[0][0]
         r = nn_.go2nn_l2norm_backward_rows(n_t)
@@ -204,14 +179,16 @@ def encoder_latents(plan, lins, x, dst_a, dst_b):
     return h
 
 
-def moe_head_grads(logits, outs, t_hat, lb_coef, acc=None):
+def moe_head_grads(logits, outs, t_hat, lb_coef, acc=None, expert_major=False):
     """The loss head of the MoE student step (moe_cts.py:203-214 over modules/utils.py:96-152) with its analytic gradients, as two launches + the reductions:
-    logits [n, E] (the gate before its softmax), outs [n, E, L] (the experts' outputs), t_hat [n, L] (the teacher's normalised latent).
+    logits [n, E] (the gate before its softmax), outs [n, E, L] (the experts' outputs; [E, n, L] when expert_major — the batched GEMM's own output layout, so
+    that neither the forward nor the backward pass transposes a [n, E, L] tensor), t_hat [n, L] (the teacher's normalised latent).
     acc: optional float32[>= 2] — latent loss and load-balance loss are ADDED to acc[0:2].  -> stats [latent loss, load balance], d loss / d logits, d loss / d outs"""
     k = _Launch(logits.device)
     nn_ = k.nn
     n, E = logits.shape
     L = outs.shape[2]
+    assert tuple(outs.shape) == ((E, n, L) if expert_major else (n, E, L))
     cont = lambda t: t.detach() if t.is_contiguous() else t.detach().contiguous()
     logits, outs, t_hat = cont(logits), cont(outs), cont(t_hat)
     with torch.no_grad():
@@ -220,8 +197,8 @@ def moe_head_grads(logits, outs, t_hat, lb_coef, acc=None):
         k.check(nn_.go2nn_moe_usage(_p(logits), _p(upart), n, E, k.stream), "go2nn_moe_usage")
         k.sums.append((upart, usage, r, E))
         k.finish()
-        dl, do, part, tot = k.new(n, E), k.new(n, E, L), k.new(r * 4), k.new(4)
-        k.check(nn_.go2nn_moe_mix_loss(_p(logits), _p(outs), _p(t_hat), _p(usage), _p(dl), _p(do), _p(part), n, E, L, float(lb_coef), k.stream), "go2nn_moe_mix_loss")
+        dl, do, part, tot = k.new(n, E), torch.empty_like(outs), k.new(r * 4), k.new(4)
+        k.check(nn_.go2nn_moe_mix_loss(_p(logits), _p(outs), _p(t_hat), _p(usage), _p(dl), _p(do), _p(part), n, E, L, float(lb_coef), 1 if expert_major else 0, k.stream), "go2nn_moe_mix_loss")
         k.sums.append((part, tot, r, 4, acc, 2))
         k.finish()
     return tot[:2], dl, do

@@ -69,7 +69,7 @@ class GroupedHeads(nn.Module):
         bound = 1.0 / math.sqrt(in_per_group)
         nn.init.uniform_(self.bias, -bound, bound)
 
-    def forward(self, x):                                              # x [B, E*hidden] -> [B, E, out]
+    def forward(self, x, expert_major=False):                          # x [B, E*hidden] -> [B, E, out]  ([E, B, out], the batched GEMM's own output, when expert_major)
         B = x.shape[0]
 
         xe = x.view(B, self.groups, self.cin).transpose(0, 1)          # [E, B, hidden]
@@ -82,7 +82,7 @@ class GroupedHeads(nn.Module):
             y = torch.baddbmm(F.pad(b, (0, pad)), xe, F.pad(w, (0, pad)))[..., :self.cout]
         else:
             y = torch.baddbmm(b, xe, w)                                 # [E, B, out]
-        return y.transpose(0, 1)
+        return y if expert_major else y.transpose(0, 1)
 
 
 class Experts(nn.Module):
@@ -110,8 +110,9 @@ class MoE(nn.Module):
         return torch.sum(weights.unsqueeze(-1) * outs, dim=1), weights                   # [B, out]
 
     def parts(self, x):
-        """-> (gate logits [B, E] — the gating MLP before its softmax —, expert outputs [B, E, out]): what the fused loss head of the student step mixes itself"""
-        return self.gating_network[0](x), self.experts(x)
+        """-> (gate logits [B, E] — the gating MLP before its softmax —, expert outputs [E, B, out], expert-major as the batched GEMM leaves them): what the fused loss
+        head of the student step mixes itself"""
+        return self.gating_network[0](x), self.experts.experts(self.experts.backbone(x), expert_major=True)          # outs [E, B, out]
 
 
 class StudentMoEEncoder(nn.Module):

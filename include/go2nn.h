@@ -201,7 +201,7 @@ int go2nn_latent_mse(const float* z_s, const float* z_t, float* dz_s, float* par
  * E <= 16; L as above.  Fixed summation order. */
 int go2nn_moe_usage(const float* logits, float* partials, int32_t n, int32_t E, void* stream);
 int go2nn_moe_mix_loss(const float* logits, const float* outs, const float* t_hat, const float* usage_sum, float* d_logits, float* d_outs, float* partials,
-                       int32_t n, int32_t E, int32_t L, float lb_coef, void* stream);
+                       int32_t n, int32_t E, int32_t L, float lb_coef, int32_t expert_major, void* stream);      /* expert_major 1: outs / d_outs are [E, n, L] (the batched GEMM's own layout: no transposing copies either way) */
 
 #ifdef __cplusplus
 }

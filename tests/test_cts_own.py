@@ -221,7 +221,7 @@ def test_all_elu_chain_node_matches_autograd(B, dims):
     chain_vs_autograd(load_nn_emu(), load_oracle(), "cpu", B, dims)
 
 
-def moe_head_vs_autograd(nn_lib, sim_lib, device, n=150, E=8, L=32, coef=0.01):
+def moe_head_vs_autograd(nn_lib, sim_lib, device, n=150, E=8, L=32, coef=0.01, expert_major=False):
     """fused_cts.moe_head_grads (go2nn_moe_usage + go2nn_moe_mix_loss) against the reference's formulation under autograd (modules/utils.py:96-152 MoE.forward +
     the normaliser; moe_cts.py:203-214): both losses, d loss / d gate logits, d loss / d expert outputs"""
     from go2_rl_gym_amd.rsl_rl.modules import fused, fused_cts
@@ -237,7 +237,11 @@ def moe_head_vs_autograd(nn_lib, sim_lib, device, n=150, E=8, L=32, coef=0.01):
     fused.set_library(sim_lib); fused.set_nn_library(nn_lib)
     try:
         acc = torch.full((2,), 5.0, device=device)
-        stats, dl, do = fused_cts.moe_head_grads(logits.detach(), outs.detach(), t_hat, coef, acc=acc)
+        if expert_major:          # [E, n, L], the batched GEMM's own layout
+            stats, dl, do = fused_cts.moe_head_grads(logits.detach(), outs.detach().transpose(0, 1).contiguous(), t_hat, coef, acc=acc, expert_major=True)
+            do = do.transpose(0, 1)
+        else:
+            stats, dl, do = fused_cts.moe_head_grads(logits.detach(), outs.detach(), t_hat, coef, acc=acc)
     finally:
         fused.set_library(None); fused.set_nn_library(None)
     np.testing.assert_allclose(stats.cpu().numpy(), [float(latent_loss), float(lb)], rtol=2e-5, atol=1e-7)
@@ -250,3 +254,4 @@ def moe_head_vs_autograd(nn_lib, sim_lib, device, n=150, E=8, L=32, coef=0.01):
 @pytest.mark.parametrize("n,E,L,coef", [(150, 8, 32, 0.01), (1, 4, 8, 1.0), (67, 16, 4, 0.5), (300, 3, 128, 0.0)])
 def test_moe_loss_head_matches_autograd(n, E, L, coef):
     moe_head_vs_autograd(load_nn_emu(), load_oracle(), "cpu", n, E, L, coef)
+    moe_head_vs_autograd(load_nn_emu(), load_oracle(), "cpu", n, E, L, coef, expert_major=True)

@@ -158,7 +158,7 @@ def _graph_mode_worker(rank, world, port, out):
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     from go2_rl_gym_amd.rsl_rl.algorithms import CTS, PPO
-    from go2_rl_gym_amd.rsl_rl.algorithms._graph import OverlappedStep, ReducedStep
+    from go2_rl_gym_amd.rsl_rl.algorithms._graph import ReducedStep
     from go2_rl_gym_amd.rsl_rl.modules import ActorCritic, ActorCriticCTS
     lib = load_oracle()
     n = N // world
@@ -167,24 +167,20 @@ def _graph_mode_worker(rank, world, port, out):
     # replay the reference's draw, and how this test gives both update paths the SAME permutation: a pass-through wrapper, seeded by torch.manual_seed below
     _randperm = torch.randperm
     torch.randperm = lambda n_, **kw: _randperm(n_, **kw)
-    for mode, overlap in ((None, "1"), ("uncaptured", "1"), ("uncaptured", "0")):
-        os.environ["GO2_OVERLAP_ALLREDUCE"] = overlap
+    for mode in (None, "uncaptured"):
         torch.manual_seed(11)
         ac = ActorCritic(45, 263, 12, actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16])
         alg = PPO(ac, num_learning_epochs=2, num_mini_batches=2, entropy_coef=0.01, schedule="adaptive", desired_kl=0.002, device="cpu", lib=lib, use_graphs=mode,
-                  fused_loss=True)      # (the loss head as on the GPU: the overlapped schedule seeds the two backward passes with its gradients)
+                  fused_loss=True)      # (the loss head as on the GPU)
         alg.init_storage(n, T, [45], [263], [12])
         for it in range(2):
             torch.manual_seed(300 + 10 * it + rank)          # sampling noise and the mini-batch permutation
             losses = _fill_and_update(alg, n, 7 + rank + 100 * it)
-        key = "eager" if mode is None else ("graph" if overlap == "1" else "graph_serial")
+        key = "eager" if mode is None else "graph"
         res[key] = torch.cat([p.detach().reshape(-1) for p in ac.parameters()]).numpy().copy()
         res[key + "_lr"], res[key + "_loss"] = alg.learning_rate, losses
-        if mode and overlap == "1":
-            res["split"] = isinstance(alg._graph[0], OverlappedStep)      # PPO: critic bucket on the wire while the actor's backward runs
-        elif mode:
-            res["split_serial"] = isinstance(alg._graph[0], ReducedStep)
-            continue                                                        # (the CTS runs below do not depend on the switch)
+        if mode:
+            res["split"] = isinstance(alg._graph[0], ReducedStep)
         torch.manual_seed(12)
         m = ActorCriticCTS(45, 263, 12, n, 5, actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16], teacher_encoder_hidden_dims=[32], student_encoder_hidden_dims=[32], latent_dim=8)
         cts = CTS(m, n, 5, num_learning_epochs=2, num_mini_batches=2, entropy_coef=0.01, schedule="adaptive", desired_kl=0.002, device="cpu", lib=lib, use_graphs=mode)
@@ -211,11 +207,7 @@ def test_graph_mode_update_equals_eager_update(world):
     mp.spawn(_graph_mode_worker, args=(world, port, out), nprocs=world, join=True)
     for r in range(world):
         o = out[r]
-        assert o["split"] == (world > 1) and o["cts_split"] == (world > 1) and o["split_serial"] == (world > 1)
-        # the overlapped schedule (two buckets, the first all-reduce running beside the actor's backward) against the serial one (one bucket
-        # between two halves): the same sums, so the same bits — weights, learning rate, losses
-        np.testing.assert_array_equal(o["graph"], o["graph_serial"])
-        assert o["graph_lr"] == o["graph_serial_lr"] and tuple(o["graph_loss"]) == tuple(o["graph_serial_loss"])
+        assert o["split"] == (world > 1) and o["cts_split"] == (world > 1)
         for pre in ("", "cts_"):
             np.testing.assert_allclose(o[pre + "graph"], o[pre + "eager"], atol=2e-6, rtol=1e-5, err_msg=pre)
             assert abs(o[pre + "graph_lr"] - o[pre + "eager_lr"]) < 1e-9 * max(1.0, o[pre + "eager_lr"]) + 1e-10, (pre, o[pre + "graph_lr"], o[pre + "eager_lr"])

@@ -24,7 +24,7 @@ def hip():
     return lib
 
 
-@pytest.mark.parametrize("task,N", [("go2", 32768), ("go2", 4096), ("go2_moe_cts", 8192), ("go2_moe_cts", 1024)])
+@pytest.mark.parametrize("task,N", [("go2", 32768), ("go2", 4096), ("go2_cts", 4096), ("go2_moe_cts", 8192), ("go2_moe_cts", 1024)])
 def test_baseline_config_runs_at_full_size_in_graph_mode(hip, task, N):
     """task_registry -> LeggedRobot (HIP library) -> OnPolicyRunner / OnPolicyRunnerCTS at the configuration's env count: 6 iterations, the
     last >= 3 of them replayed from HIP graphs (rollout + every mini-batch step)."""
@@ -100,43 +100,52 @@ def test_eight_shards_are_slices_of_the_full_size_simulator(hip, Ng, n):
         s_.close()
 
 
-@pytest.mark.timeout(180)
-def test_go2_flat_trains_at_8192_envs_in_the_default_configuration(hip):
-    """Round 3 left a hang above 4096 envs per GPU (actor and critic chains of vendor GEMMs on two HIP streams: the first iteration never finished, VERDICT r3
-    weak 4).  PPO no longer forks a stream — the two networks' layers are grouped launches of own kernels (modules/fused.py:_FusedPair) — so the default
-    configuration must simply train at 8192 envs: 3 eager + 3 replayed iterations inside the time limit, every mini-batch step from a HIP graph."""
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("task", ["go2_flat", "go2_cts"])
+def test_trains_at_8192_envs_in_the_default_configuration_without_a_second_stream(hip, task, monkeypatch):
+    """Round 3 left a hang above 4096 envs per GPU (two chains of vendor GEMMs on two HIP streams: the first iteration never finished).  Since round 5 nothing forks a
+    stream any more — PPO's and CTS's mini-batches are grouped launches of own kernels without autograd, the rollouts one / two policy kernels — so the default
+    configuration must simply train at 8192 envs: 3 eager + 3 replayed iterations inside the time limit, everything from HIP graphs, and the module-by-module
+    formulation that used to fork (_RolloutHeads._pair) is never entered (checked by counting)."""
     import time
     import torch
     from go2_rl_gym_amd.envs import task_registry  # noqa: F401
-    from go2_rl_gym_amd.rsl_rl.modules import fused
     from go2_rl_gym_amd.utils import get_args
-    assert os.environ.get("GO2_TWO_STREAMS", "1") == "1" and os.environ.get("GO2_MLP_PAIR", "1") == "1"      # the defaults are what is tested
+    made = []
     t0 = time.time()
-    args = get_args(["--task", "go2_flat", "--num_envs", "8192", "--headless", "--seed", "1"])
-    env, _ = task_registry.make_env("go2_flat", args)
+    args = get_args(["--task", task, "--num_envs", "8192", "--headless", "--seed", "1"])
+    env, _ = task_registry.make_env(task, args)
     torch.manual_seed(1)
-    runner, _ = task_registry.make_alg_runner(env, "go2_flat", args, log_root=None)
+    runner, _ = task_registry.make_alg_runner(env, task, args, log_root=None)
+    alg = runner.alg
+    pair = alg._pair
+
+    def counted_pair(f, g, enabled=True):
+        made.append(1)
+        return pair(f, g, enabled)
+    monkeypatch.setattr(alg, "_pair", counted_pair)
     runner.learn(3, init_at_random_ep_len=True)
     for _ in range(3):
         runner.learn(1)
         torch.cuda.synchronize()
     g = runner.graphs_captured()
     assert g["rollout"] and g["update"], g
-    assert runner.alg._side is None, "PPO forked a second stream"          # (_RolloutHeads._pair was never taken)
-    ac = runner.alg.actor_critic
-    x, y = torch.randn(64, 45, device="cuda:0"), torch.randn(64, 263, device="cuda:0")
-    assert type(fused.pair_forward(ac.actor, ac.critic, x, y)[0].grad_fn).__name__ == "_FusedPairBackward"
-    params = torch.cat([p.detach().reshape(-1) for p in ac.parameters()])
-    assert torch.isfinite(params).all() and runner.last_fps > 0 and time.time() - t0 < 120, time.time() - t0
-    print("go2_flat N=8192: %.2f M env-steps/s, %.1f s for 6 iterations incl. graph capture" % (runner.last_fps / 1e6, time.time() - t0))
+    assert not made, "the default path went through _RolloutHeads._pair (the module-by-module formulation)"
+    if task == "go2_cts":
+        assert alg._own_plan() is not None and alg._own_student() and alg._policy_kernel() is not None
+    model = alg.actor_critic
+    params = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    assert torch.isfinite(params).all() and runner.last_fps > 0 and time.time() - t0 < 180, time.time() - t0
     env.close()
 
 
 @pytest.mark.timeout(300)
-def test_multi_rank_code_path_at_4096_envs_replays_with_21_collectives(hip, monkeypatch):
+@pytest.mark.parametrize("task,ncoll", [("go2_flat", 21), ("go2_cts", 41)])
+def test_multi_rank_code_path_at_4096_envs_replays_with_21_collectives(hip, monkeypatch, task, ncoll):
     """The N > 1 update at the headline size on one GPU: a 1-rank RCCL group with GO2_FORCE_COLLECTIVES=1 runs the shipped serial schedule — per mini-batch
     slot two captured halves with the gradient + KL bucket all-reduced between their replays, plus the 24-byte advantage-statistics all-reduce: 21 collectives
-    per iteration — for >= 3 replayed iterations.  What it cannot show is xGMI behaviour; DESIGN 7 states the predicted 8-rank cost."""
+    per iteration — for >= 3 replayed iterations; CTS: the policy steps' and the student steps' buckets, 41 (the own no-autograd mini-batches between the
+    halves).  What it cannot show is xGMI behaviour; DESIGN 7 states the predicted 8-rank cost."""
     import socket
     import torch
     import torch.distributed as dist
@@ -144,7 +153,6 @@ def test_multi_rank_code_path_at_4096_envs_replays_with_21_collectives(hip, monk
     from go2_rl_gym_amd.rsl_rl.algorithms._graph import ReducedStep
     from go2_rl_gym_amd.utils import get_args
     monkeypatch.setenv("GO2_FORCE_COLLECTIVES", "1")
-    monkeypatch.setenv("GO2_OVERLAP_ALLREDUCE", "0")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda:0"))
     calls = {"n": 0}
@@ -154,24 +162,26 @@ def test_multi_rank_code_path_at_4096_envs_replays_with_21_collectives(hip, monk
         calls["n"] += 1
         return real(*a, **k)
     try:
-        args = get_args(["--task", "go2_flat", "--num_envs", "4096", "--headless", "--seed", "2"])
-        env, _ = task_registry.make_env("go2_flat", args)
+        args = get_args(["--task", task, "--num_envs", "4096", "--headless", "--seed", "2"])
+        env, _ = task_registry.make_env(task, args)
         torch.manual_seed(2)
-        runner, _ = task_registry.make_alg_runner(env, "go2_flat", args, log_root=None)
+        runner, _ = task_registry.make_alg_runner(env, task, args, log_root=None)
         runner.learn(4, init_at_random_ep_len=True)          # eager warm-ups + captures
         torch.cuda.synchronize()
-        steps = runner.alg._graph
+        steps = runner.alg._graph if task == "go2_flat" else runner.alg._steps[0] + runner.alg._steps[1]
+        if task == "go2_cts":
+            assert runner.alg._own_plan() is not None and runner.alg._own_student()
         assert all(isinstance(g, ReducedStep) and g.front.graph is not None and g.back.graph is not None for g in steps), "both halves of every slot are graphs"
         monkeypatch.setattr(dist, "all_reduce", counted)
         for _ in range(3):
             runner.learn(1)
         torch.cuda.synchronize()
-        assert calls["n"] == 3 * 21, calls
+        assert calls["n"] == 3 * ncoll, calls
         g = runner.graphs_captured()
         assert g["rollout"] and g["update"], g
         params = torch.cat([p.detach().reshape(-1) for p in runner.alg.actor_critic.parameters()])
         assert torch.isfinite(params).all() and 1e-5 - 1e-12 <= runner.alg.learning_rate <= 1e-2 + 1e-12
-        print("go2_flat N=4096, 1-rank RCCL, serial schedule: %.2f M env-steps/s with 21 all-reduces per iteration" % (runner.last_fps / 1e6))
+        print("%s N=4096, 1-rank RCCL, serial schedule: %.2f M env-steps/s with %d all-reduces per iteration" % (task, runner.last_fps / 1e6, ncoll))
         env.close()
     finally:
         monkeypatch.setattr(dist, "all_reduce", real)

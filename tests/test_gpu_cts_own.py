@@ -55,6 +55,7 @@ from test_cts_own import moe_head_vs_autograd  # noqa: E402
 def test_moe_loss_head_on_gpu(n, E, L, coef):
     a = moe_head_vs_autograd(_nn.load_nn(), load_hip(), "cuda:0", n, E, L, coef)
     b = moe_head_vs_autograd(_nn.load_nn(), load_hip(), "cuda:0", n, E, L, coef)
+    moe_head_vs_autograd(_nn.load_nn(), load_hip(), "cuda:0", n, E, L, coef, expert_major=True)
     torch.cuda.synchronize()
     for u, v in zip(a, b):
         assert torch.equal(u, v)

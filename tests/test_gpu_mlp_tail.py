@@ -23,10 +23,15 @@ def test_head_backward_on_gpu(B, Cn, K):
         assert torch.equal(u, v)
 
 
-@pytest.mark.parametrize("dims", [(45, 512, 256, 128, 12), (263, 512, 256, 128, 1)])
-@pytest.mark.parametrize("node,own", [(False, "auto"), (True, "auto"), (True, "all"), (True, "none")])
-def test_fused_tail_on_gpu(dims, node, own):
-    tail_vs_autograd(_nn.load_nn(), load_hip(), "cuda:0", B=24576, dims=dims, atol=2e-6, node=node, own=own)
+@pytest.mark.parametrize("dims", [(45, 512, 256, 128, 12), (263, 512, 256, 128, 1), (263, 512, 256, 32), (225, 512, 256, 8)])
+@pytest.mark.parametrize("split", [True, False])
+def test_fused_tail_on_gpu(dims, split):
+    """the whole-MLP autograd node (modules/fused.py:_FusedMLP) at the update's row count: the actor, the critic, a CTS encoder (32-wide output on the GEMM kernels), the MoE
+    gate (8-wide output: go2nn_head_backward); split-operand kernels (the default) and the fp32-MFMA ones (GO2_GEMM_SPLIT=0, the switch that stays for A/B runs)"""
+    if not split and dims[0] % 4:
+        # (the plain input gradient of a layer whose width is not a multiple of 4 is the one product the fp32-MFMA formulation leaves to the vendor GEMM)
+        pass
+    tail_vs_autograd(_nn.load_nn(), load_hip(), "cuda:0", B=24576, dims=dims, atol=2e-6, split=split)
 
 
 from test_mlp_tail import check_linear  # noqa: E402
@@ -54,7 +59,7 @@ def test_sum_rows_on_gpu():
         assert torch.equal(u, v)
 
 
-from test_mlp_tail import check_linear_group, pair_vs_autograd  # noqa: E402
+from test_mlp_tail import check_linear_group  # noqa: E402
 
 
 @pytest.mark.parametrize("M,s0,s1", [(70, (45, 96), (263, 96)), (777, (37, 70), (64, 70)), (1000, (130, 33), (8, 33)), (3000, (45, 512), (263, 512)),
@@ -108,11 +113,6 @@ def test_split_operand_error_is_the_fp32_kernels_error(M, s0, s1):
             assert eb <= 1.5 * ea + 1e-12, (n, ea, eb)
             assert abs(float((b.double() - r).mean())) <= 2e-7 * scale, n          # the per-output bias itself: a fraction of an ulp
     print("[split / fp32 rms error vs float64, M=%d %s %s] " % (M, s0, s1) + ", ".join(line))
-
-
-@pytest.mark.parametrize("B", [24576, 1000])
-def test_pair_node_on_gpu(B):
-    pair_vs_autograd(_nn.load_nn(), load_hip(), "cuda:0", B=B, dims_a=(45, 512, 256, 128, 12), dims_c=(263, 512, 256, 128, 1), atol=2e-6)
 
 
 from test_mlp_tail import ppo_grads_vs_autograd  # noqa: E402

@@ -336,7 +336,10 @@ def test_cts_training_graph_vs_eager_on_gpu(hip, task):
     assert np.isfinite(out[True][1]).all() and out[True][4] > 0
     assert abs(out[True][0] - 1e-3) < 1e-9 and abs(out[False][0] - 1e-3) < 1e-9
     d = np.abs(out[True][1] - out[False][1])
-    assert np.median(d) < 5e-3, np.median(d)          # same data distribution, different noise: the weights stay close after 100 fixed-rate steps
+    # same data distribution, different noise AND different mini-batch permutations (graph mode: the keyed device-side shuffle; eager: torch.randperm): the weights stay
+    # close after 100 fixed-rate Adam steps of 1e-3 each (round 5: 5e-3 -> 7e-3, the MoE run measured 5.0e-3 once both the permutation and the noise differ; the
+    # ARITHMETIC of graph mode is pinned to the reference's by tests/test_gpu_update_golden.py, not here)
+    assert np.median(d) < 7e-3, np.median(d)
     assert abs(out[True][3] - out[False][3]) < 0.05
 
 
@@ -539,14 +542,13 @@ def test_multi_rank_update_shape_on_one_gpu(hip, task, monkeypatch):
     import torch
     import torch.distributed as dist
     from go2_rl_gym_amd.envs import task_registry  # noqa: F401
-    from go2_rl_gym_amd.rsl_rl.algorithms._graph import OverlappedStep, ReducedStep
+    from go2_rl_gym_amd.rsl_rl.algorithms._graph import ReducedStep
     from go2_rl_gym_amd.utils import get_args
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = {}
-    for forced in (False, True, "serial"):
+    for forced in (False, True):
         if forced:
             monkeypatch.setenv("GO2_FORCE_COLLECTIVES", "1")
-            monkeypatch.setenv("GO2_OVERLAP_ALLREDUCE", "0" if forced == "serial" else "1")
             s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
             dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda:0"))
         try:
@@ -559,10 +561,7 @@ def test_multi_rank_update_shape_on_one_gpu(hip, task, monkeypatch):
             torch.cuda.synchronize()
             alg = runner.alg
             steps = alg._graph if task == "go2_flat" else alg._steps[0] + alg._steps[1]
-            if forced is True and task == "go2_flat":
-                # PPO: three captured pieces per slot, the critic's bucket on the wire (RCCL, asynchronous) while the actor's backward replays
-                assert all(isinstance(g, OverlappedStep) and g.front_a.graph is not None and g.front_b.graph is not None and g.back.graph is not None for g in steps)
-            elif forced:
+            if forced:
                 assert all(isinstance(g, ReducedStep) and g.front.graph is not None and g.back.graph is not None for g in steps)
             else:
                 assert all(not isinstance(g, ReducedStep) and g.graph is not None for g in steps)
@@ -575,12 +574,8 @@ def test_multi_rank_update_shape_on_one_gpu(hip, task, monkeypatch):
     # the arithmetic of the split update is pinned on the CPU (tests/test_distributed.py: equal to the eager update, identical replicas);
     # here: it runs captured with RCCL between the halves and trains like the single-graph mode.  The adaptive rate at 512 envs is
     # chaotic (x1.5 per mini-batch), so the two runs are compared by behaviour, not by weights.
-    for k in (True, "serial"):
-        assert np.isfinite(out[k][1]).all() and 1e-5 - 1e-12 <= out[k][0] <= 1e-2 + 1e-12
-        assert abs(out[k][2] - out[False][2]) < 0.05
-    # overlapped and serial schedules form the same sums (bit-identical with 2 gloo ranks: tests/test_distributed.py); on the GPU the two RUNS
-    # differ by the order of the GAE kernel's fp64 atomics only
-    assert np.median(np.abs(out[True][1] - out["serial"][1])) < 5e-3
+    assert np.isfinite(out[True][1]).all() and 1e-5 - 1e-12 <= out[True][0] <= 1e-2 + 1e-12
+    assert abs(out[True][2] - out[False][2]) < 0.05
 
 
 @pytest.mark.parametrize("terrain", ["plane", "heightfield"])
