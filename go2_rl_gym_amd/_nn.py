@@ -88,7 +88,7 @@ def bind(path):
     lib.go2nn_l2norm_backward.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.go2nn_latent_mse.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]
     lib.go2nn_moe_usage.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
-    lib.go2nn_moe_mix_loss.argtypes = [C.c_void_p] * 7 + [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]
+    lib.go2nn_moe_mix_loss.argtypes = [C.c_void_p] * 7 + [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     if lib.go2nn_abi_version() != GO2NN_ABI_VERSION:
         raise RuntimeError("%s: ABI version %d, expected %d" % (path, lib.go2nn_abi_version(), GO2NN_ABI_VERSION))
     return lib

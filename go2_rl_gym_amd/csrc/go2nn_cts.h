@@ -121,33 +121,40 @@ __global__ void __launch_bounds__(CTS_ROWS_PER_WG) go2nn_moe_usage_kernel(const 
   if ((int)threadIdx.x < E) { float s = 0.f; for (int j = 0; j < CTS_ROWS_PER_WG; ++j) s += sh[j][threadIdx.x]; part[(size_t)blockIdx.x * E + threadIdx.x] = s; }
 }
 
+template <int ME>          // ME: 8 or 16 expert slots held in registers (E <= ME)
 __global__ void __launch_bounds__(256) go2nn_moe_mix_kernel(const float* __restrict__ logits, const float* __restrict__ outs, const float* __restrict__ that,
                                                             const float* __restrict__ usage_sum, float* __restrict__ dlogits, float* __restrict__ douts, float* __restrict__ part,
-                                                            int n, int E, int L, float coef, long long sr, long long se) {          // outs / douts element (r, e, c) at r sr + e se + c
-  __shared__ float shl[256];
+                                                            int n, int E, int L, float coef, long long sr, long long se,          // outs / douts element (r, e, c) at r sr + e se + c
+                                                            const float* __restrict__ bias, float* __restrict__ dbias_part) {       // optional: the experts' output bias [E, L] is added here
+  __shared__ float shl[256];                                                                                                        // (and its gradient's partial rows [E L] left), so autograd sees a plain bmm
+  __shared__ float4 shb[256];
   const int LP = L >> 2, RL = 256 / LP, cq = threadIdx.x % LP, rl = threadIdx.x / LP, c = cq * 4;
   const int r0 = blockIdx.x * CTS_ROWS_PER_WG, r1 = min(n, r0 + CTS_ROWS_PER_WG);
   const float invE = 1.f / (float)E, invn = 1.f / (float)n, scale = 2.f / ((float)n * (float)L);
-  float lbg[MOE_MAX_E];          // d (coef * load balance) / d w[row][e] = coef * 2 (usage_e - 1 / E) / (E n), the same for every row
+  float lbg[ME];          // d (coef * load balance) / d w[row][e] = coef * 2 (usage_e - 1 / E) / (E n), the same for every row
 #pragma unroll
-  for (int e = 0; e < MOE_MAX_E; ++e) lbg[e] = e < E ? coef * 2.f * (usage_sum[e] * invn - invE) * invE * invn : 0.f;
+  for (int e = 0; e < ME; ++e) lbg[e] = e < E ? coef * 2.f * (usage_sum[e] * invn - invE) * invE * invn : 0.f;
   float loss = 0.f;
+  float4 bq[ME], db[ME];
+#pragma unroll
+  for (int e = 0; e < ME; ++e) { bq[e] = (bias && e < E) ? *reinterpret_cast<const float4*>(bias + (size_t)e * L + c) : make_float4(0.f, 0.f, 0.f, 0.f); db[e] = make_float4(0.f, 0.f, 0.f, 0.f); }
   for (int rb = r0; rb < r1; rb += RL) {
     const int r = rb + rl, rc = min(r, r1 - 1);
     const bool live = r < r1;
-    float w[MOE_MAX_E]; float4 o[MOE_MAX_E];
+    float w[ME]; float4 o[ME];
     float mx = -3.4e38f, sum = 0.f;
 #pragma unroll
-    for (int e = 0; e < MOE_MAX_E; ++e) {
+    for (int e = 0; e < ME; ++e) {
       w[e] = e < E ? logits[(size_t)rc * E + e] : -3.4e38f; mx = fmaxf(mx, w[e]);
       o[e] = e < E ? *reinterpret_cast<const float4*>(outs + (size_t)rc * sr + (size_t)e * se + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      o[e].x += bq[e].x; o[e].y += bq[e].y; o[e].z += bq[e].z; o[e].w += bq[e].w;
     }
 #pragma unroll
-    for (int e = 0; e < MOE_MAX_E; ++e) { w[e] = e < E ? expf(w[e] - mx) : 0.f; sum += w[e]; }
+    for (int e = 0; e < ME; ++e) { w[e] = e < E ? expf(w[e] - mx) : 0.f; sum += w[e]; }
     const float isum = 1.f / sum;
     float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int e = 0; e < MOE_MAX_E; ++e) { w[e] *= isum; y.x = fmaf(w[e], o[e].x, y.x); y.y = fmaf(w[e], o[e].y, y.y); y.z = fmaf(w[e], o[e].z, y.z); y.w = fmaf(w[e], o[e].w, y.w); }
+    for (int e = 0; e < ME; ++e) { w[e] *= isum; y.x = fmaf(w[e], o[e].x, y.x); y.y = fmaf(w[e], o[e].y, y.y); y.z = fmaf(w[e], o[e].z, y.z); y.w = fmaf(w[e], o[e].w, y.w); }
     const float inv = 1.f / fmaxf(sqrtf(cts_group_sum(y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w, LP)), CTS_EPS);
     const float4 sh_ = make_float4(y.x * inv, y.y * inv, y.z * inv, y.w * inv);
     const float4 t = *reinterpret_cast<const float4*>(that + (size_t)rc * L + c);
@@ -156,18 +163,32 @@ __global__ void __launch_bounds__(256) go2nn_moe_mix_kernel(const float* __restr
     const float4 gs = make_float4(-scale * d.x, -scale * d.y, -scale * d.z, -scale * d.w);          // d latent loss / d shat
     const float dot = cts_group_sum(gs.x * sh_.x + gs.y * sh_.y + gs.z * sh_.z + gs.w * sh_.w, LP);
     const float4 dy = make_float4((gs.x - sh_.x * dot) * inv, (gs.y - sh_.y * dot) * inv, (gs.z - sh_.z * dot) * inv, (gs.w - sh_.w * dot) * inv);
-    float dw[MOE_MAX_E], wd = 0.f;
+    float dw[ME], wd = 0.f;
 #pragma unroll
-    for (int e = 0; e < MOE_MAX_E; ++e) {
+    for (int e = 0; e < ME; ++e) {
       if (e < E) {
-        if (live) *reinterpret_cast<float4*>(douts + (size_t)r * sr + (size_t)e * se + c) = make_float4(w[e] * dy.x, w[e] * dy.y, w[e] * dy.z, w[e] * dy.w);
+        if (live) { const float4 g4 = make_float4(w[e] * dy.x, w[e] * dy.y, w[e] * dy.z, w[e] * dy.w);
+          *reinterpret_cast<float4*>(douts + (size_t)r * sr + (size_t)e * se + c) = g4; db[e].x += g4.x; db[e].y += g4.y; db[e].z += g4.z; db[e].w += g4.w; }
         dw[e] = cts_group_sum(dy.x * o[e].x + dy.y * o[e].y + dy.z * o[e].z + dy.w * o[e].w, LP) + lbg[e];
         wd = fmaf(w[e], dw[e], wd);
       } else dw[e] = 0.f;
     }
     if (live && cq == 0) {
 #pragma unroll
-      for (int e = 0; e < MOE_MAX_E; ++e) if (e < E) dlogits[(size_t)r * E + e] = w[e] * (dw[e] - wd);          // softmax backward
+      for (int e = 0; e < ME; ++e) if (e < E) dlogits[(size_t)r * E + e] = w[e] * (dw[e] - wd);          // softmax backward
+    }
+  }
+  if (dbias_part) {          // the workgroup's partial row of the output bias gradient: row lanes added in a fixed order, expert by expert
+#pragma unroll
+    for (int e = 0; e < ME; ++e) if (e < E) {
+      shb[threadIdx.x] = db[e];
+      __syncthreads();
+      if (rl == 0) {
+        float4 t = shb[cq];
+        for (int j = 1; j < RL; ++j) { const float4 u = shb[j * LP + cq]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        *reinterpret_cast<float4*>(dbias_part + (size_t)blockIdx.x * E * L + (size_t)e * L + c) = t;
+      }
+      __syncthreads();
     }
   }
   shl[threadIdx.x] = loss;

@@ -1090,8 +1090,8 @@ int go2nn_moe_usage(const float* logits, float* partials, int32_t n, int32_t E, 
 }
 
 int go2nn_moe_mix_loss(const float* logits, const float* outs, const float* t_hat, const float* usage_sum, float* d_logits, float* d_outs, float* partials,
-                       int32_t n, int32_t E, int32_t L, float lb_coef, int32_t expert_major, void* stream) {
-  if (!logits || !outs || !t_hat || !usage_sum || !d_logits || !d_outs || !partials || !cts_ok(n, L) || E < 1 || E > 16) FAIL(GO2NN_EINVAL, "moe mix loss: bad argument (1 <= E <= 16)");
+                       int32_t n, int32_t E, int32_t L, float lb_coef, int32_t expert_major, const float* bias, float* dbias_partials, void* stream) {
+  if (!logits || !outs || !t_hat || !usage_sum || !d_logits || !d_outs || !partials || !cts_ok(n, L) || E < 1 || E > 16 || (dbias_partials && !bias)) FAIL(GO2NN_EINVAL, "moe mix loss: bad argument (1 <= E <= 16)");
   const long long sr = expert_major ? L : (long long)E * L, se = expert_major ? (long long)n * L : L;          // [E, n, L] (the batched GEMM's own output) or [n, E, L]
 #ifdef GO2_EMU
   (void)stream;
@@ -1104,20 +1104,22 @@ int go2nn_moe_mix_loss(const float* logits, const float* outs, const float* t_ha
     for (int e = 0; e < E; ++e) mx = fmaxf(mx, logits[(size_t)r * E + e]);
     for (int e = 0; e < E; ++e) { w[e] = expf(logits[(size_t)r * E + e] - mx); sum += w[e]; }
     for (int e = 0; e < E; ++e) w[e] /= sum;
-    for (int c = 0; c < L; ++c) { y[c] = 0.f; for (int e = 0; e < E; ++e) y[c] = fmaf(w[e], outs[(size_t)r * sr + (size_t)e * se + c], y[c]); ss += y[c] * y[c]; }
+    for (int c = 0; c < L; ++c) { y[c] = 0.f; for (int e = 0; e < E; ++e) y[c] = fmaf(w[e], outs[(size_t)r * sr + (size_t)e * se + c] + (bias ? bias[(size_t)e * L + c] : 0.f), y[c]); ss += y[c] * y[c]; }
     const float inv = 1.f / fmaxf(sqrtf(ss), CTS_EPS);
     for (int c = 0; c < L; ++c) { sh[c] = y[c] * inv; const float d = t_hat[(size_t)r * L + c] - sh[c]; loss += d * d; dy[c] = -scale * d; dot += dy[c] * sh[c]; }
     for (int c = 0; c < L; ++c) dy[c] = (dy[c] - sh[c] * dot) * inv;
     for (int e = 0; e < E; ++e) {
       float s = 0.f;
-      for (int c = 0; c < L; ++c) { d_outs[(size_t)r * sr + (size_t)e * se + c] = w[e] * dy[c]; s += dy[c] * outs[(size_t)r * sr + (size_t)e * se + c]; }
+      for (int c = 0; c < L; ++c) { d_outs[(size_t)r * sr + (size_t)e * se + c] = w[e] * dy[c]; s += dy[c] * (outs[(size_t)r * sr + (size_t)e * se + c] + (bias ? bias[(size_t)e * L + c] : 0.f));
+        if (dbias_partials) dbias_partials[(size_t)e * L + c] = (r ? dbias_partials[(size_t)e * L + c] : 0.f) + w[e] * dy[c]; }
       dw[e] = s + lb_coef * 2.f * (usage_sum[e] * invn - invE) * invE * invn; wd = fmaf(w[e], dw[e], wd);
     }
     for (int e = 0; e < E; ++e) d_logits[(size_t)r * E + e] = w[e] * (dw[e] - wd);
   }
   partials[0] = loss / ((float)n * (float)L); partials[1] = lb; partials[2] = partials[3] = 0.f;
 #else
-  hipLaunchKernelGGL(go2nn_moe_mix_kernel, dim3(cts_rows(n)), dim3(256), 0, (hipStream_t)stream, logits, outs, t_hat, usage_sum, d_logits, d_outs, partials, n, E, L, lb_coef, sr, se);
+  if (E <= 8) hipLaunchKernelGGL(go2nn_moe_mix_kernel<8>, dim3(cts_rows(n)), dim3(256), 0, (hipStream_t)stream, logits, outs, t_hat, usage_sum, d_logits, d_outs, partials, n, E, L, lb_coef, sr, se, bias, dbias_partials);
+  else        hipLaunchKernelGGL(go2nn_moe_mix_kernel<16>, dim3(cts_rows(n)), dim3(256), 0, (hipStream_t)stream, logits, outs, t_hat, usage_sum, d_logits, d_outs, partials, n, E, L, lb_coef, sr, se, bias, dbias_partials);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

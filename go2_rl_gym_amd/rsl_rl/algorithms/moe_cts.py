@@ -28,9 +28,10 @@ class MoECTS(CTS):
         t_hat = self._teacher_latent(priv_s, teacher_latent)
         if not (self.fused_loss and fused_cts.moe_head_applicable(self.model, t_hat.shape[1])):
             return super()._student_backward(hist_s, priv_s, teacher_latent)
-        logits, outs = self.model.student_moe_parts(hist_s)
-        _, dl, do = fused_cts.moe_head_grads(logits, outs, t_hat, self.load_balance_coef, acc=self._acc[3 + self._NUM_POLICY_LOGS:], expert_major=True)
+        logits, outs, bias = self.model.student_moe_parts(hist_s)
+        _, dl, do, dbias = fused_cts.moe_head_grads(logits, outs, t_hat, self.load_balance_coef, acc=self._acc[3 + self._NUM_POLICY_LOGS:], expert_major=True, bias=bias)
         torch.autograd.backward([logits, outs], [dl, do])
+        bias.grad = dbias.view_as(bias)          # (the heads' bias is added inside the loss head: its gradient comes from there, not through autograd)
 
 
 class MoENGCTS(MoECTS):

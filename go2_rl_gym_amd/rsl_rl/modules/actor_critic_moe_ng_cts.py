@@ -64,7 +64,7 @@ class ActorCriticMoENGCTS(ActorCriticCTS):
         return self.get_student_latent_and_weights(history)
 
     def student_moe_parts(self, history):
-        """-> (gate logits, expert outputs [E, B, latent], expert-major) before the mixture (the fused loss head of the student step, modules/fused_cts.py:moe_head_grads)"""
+        """-> (gate logits, expert outputs [E, B, latent] before their bias, the heads' bias) ahead of the mixture (the fused loss head of the student step, fused_cts.moe_head_grads)"""
         B, enc = history.shape[0], self.student_moe_encoder
         no_goal = history.reshape(B, self.history_length, -1).index_select(2, self._no_goal_idx).reshape(B, -1)
-        return enc.gating_network[:-1](history), enc.experts_out(enc.experts_hidden(enc.experts_backbone(no_goal)), expert_major=True)
+        return enc.gating_network[:-1](history), enc.experts_out(enc.experts_hidden(enc.experts_backbone(no_goal)), expert_major=True, with_bias=False), enc.experts_out.bias

@@ -179,11 +179,12 @@ def encoder_latents(plan, lins, x, dst_a, dst_b):
     return h
 
 
-def moe_head_grads(logits, outs, t_hat, lb_coef, acc=None, expert_major=False):
+def moe_head_grads(logits, outs, t_hat, lb_coef, acc=None, expert_major=False, bias=None):
     """The loss head of the MoE student step (moe_cts.py:203-214 over modules/utils.py:96-152) with its analytic gradients, as two launches + the reductions:
     logits [n, E] (the gate before its softmax), outs [n, E, L] (the experts' outputs; [E, n, L] when expert_major — the batched GEMM's own output layout, so
     that neither the forward nor the backward pass transposes a [n, E, L] tensor), t_hat [n, L] (the teacher's normalised latent).
-    acc: optional float32[>= 2] — latent loss and load-balance loss are ADDED to acc[0:2].  -> stats [latent loss, load balance], d loss / d logits, d loss / d outs"""
+    bias (optional, [E * L]): the expert heads' output bias when `outs` comes without it (a plain bmm under autograd): added by the kernel, its gradient returned fourth.
+    acc: optional float32[>= 2] — latent loss and load-balance loss are ADDED to acc[0:2].  -> stats [latent loss, load balance], d loss / d logits, d loss / d outs(, d loss / d bias)"""
     k = _Launch(logits.device)
     nn_ = k.nn
     n, E = logits.shape
@@ -198,10 +199,16 @@ def moe_head_grads(logits, outs, t_hat, lb_coef, acc=None, expert_major=False):
         k.sums.append((upart, usage, r, E))
         k.finish()
         dl, do, part, tot = k.new(n, E), torch.empty_like(outs), k.new(r * 4), k.new(4)
-        k.check(nn_.go2nn_moe_mix_loss(_p(logits), _p(outs), _p(t_hat), _p(usage), _p(dl), _p(do), _p(part), n, E, L, float(lb_coef), 1 if expert_major else 0, k.stream), "go2nn_moe_mix_loss")
+        bpart = dbias = None
+        if bias is not None:
+            bias = cont(bias).reshape(-1)
+            bpart, dbias = k.new(r * E * L), k.new(E * L)
+            k.sums.append((bpart, dbias, r, E * L))
+        k.check(nn_.go2nn_moe_mix_loss(_p(logits), _p(outs), _p(t_hat), _p(usage), _p(dl), _p(do), _p(part), n, E, L, float(lb_coef), 1 if expert_major else 0, _p(bias), _p(bpart), k.stream),
+                "go2nn_moe_mix_loss")
         k.sums.append((part, tot, r, 4, acc, 2))
         k.finish()
-    return tot[:2], dl, do
+    return (tot[:2], dl, do) if bias is None else (tot[:2], dl, do, dbias)
 
 
 def moe_head_applicable(model, L):

@@ -69,8 +69,11 @@ class GroupedHeads(nn.Module):
         bound = 1.0 / math.sqrt(in_per_group)
         nn.init.uniform_(self.bias, -bound, bound)
 
-    def forward(self, x, expert_major=False):                          # x [B, E*hidden] -> [B, E, out]  ([E, B, out], the batched GEMM's own output, when expert_major)
+    def forward(self, x, expert_major=False, with_bias=True):          # x [B, E*hidden] -> [B, E, out]  ([E, B, out], the batched GEMM's own output, when expert_major)
         B = x.shape[0]
+        if not with_bias:                                               # (the fused loss head of the student step adds the bias itself: a plain batched product here)
+            assert expert_major
+            return torch.bmm(x.view(B, self.groups, self.cin).transpose(0, 1), self.weight.view(self.groups, self.cout, self.cin).transpose(1, 2))
 
         xe = x.view(B, self.groups, self.cin).transpose(0, 1)          # [E, B, hidden]
         w = self.weight.view(self.groups, self.cout, self.cin).transpose(1, 2)   # [E, hidden, out]
@@ -110,9 +113,10 @@ class MoE(nn.Module):
         return torch.sum(weights.unsqueeze(-1) * outs, dim=1), weights                   # [B, out]
 
     def parts(self, x):
-        """-> (gate logits [B, E] — the gating MLP before its softmax —, expert outputs [E, B, out], expert-major as the batched GEMM leaves them): what the fused loss
-        head of the student step mixes itself"""
-        return self.gating_network[0](x), self.experts.experts(self.experts.backbone(x), expert_major=True)          # outs [E, B, out]
+        """-> (gate logits [B, E] — the gating MLP before its softmax —, expert outputs [E, B, out] before their bias, expert-major as the batched GEMM leaves them,
+        the heads' bias parameter [E * out]): what the fused loss head of the student step mixes itself"""
+        heads = self.experts.experts
+        return self.gating_network[0](x), heads(self.experts.backbone(x), expert_major=True, with_bias=False), heads.bias          # outs [E, B, out] WITHOUT the bias
 
 
 class StudentMoEEncoder(nn.Module):

@@ -201,7 +201,10 @@ int go2nn_latent_mse(const float* z_s, const float* z_t, float* dz_s, float* par
  * E <= 16; L as above.  Fixed summation order. */
 int go2nn_moe_usage(const float* logits, float* partials, int32_t n, int32_t E, void* stream);
 int go2nn_moe_mix_loss(const float* logits, const float* outs, const float* t_hat, const float* usage_sum, float* d_logits, float* d_outs, float* partials,
-                       int32_t n, int32_t E, int32_t L, float lb_coef, int32_t expert_major, void* stream);      /* expert_major 1: outs / d_outs are [E, n, L] (the batched GEMM's own layout: no transposing copies either way) */
+                       int32_t n, int32_t E, int32_t L, float lb_coef, int32_t expert_major, const float* bias, float* dbias_partials, void* stream);
+/* expert_major 1: outs / d_outs are [E, n, L] (the batched GEMM's own layout: no transposing copies either way).  bias (optional, [E, L]): the expert heads' output bias,
+ * added to outs here — autograd then differentiates a plain batched product — with its gradient left as go2nn_l2norm_backward_rows(n) partial rows of E L columns in
+ * dbias_partials (a 77 us torch reduction otherwise). */
 
 #ifdef __cplusplus
 }

@@ -237,9 +237,11 @@ def moe_head_vs_autograd(nn_lib, sim_lib, device, n=150, E=8, L=32, coef=0.01, e
     fused.set_library(sim_lib); fused.set_nn_library(nn_lib)
     try:
         acc = torch.full((2,), 5.0, device=device)
-        if expert_major:          # [E, n, L], the batched GEMM's own layout
-            stats, dl, do = fused_cts.moe_head_grads(logits.detach(), outs.detach().transpose(0, 1).contiguous(), t_hat, coef, acc=acc, expert_major=True)
+        if expert_major:          # [E, n, L], the batched GEMM's own layout; the heads' bias added (and differentiated) inside the head
+            bias = torch.randn(E * L, generator=g).to(device) * 0.3
+            stats, dl, do, dbias = fused_cts.moe_head_grads(logits.detach(), (outs.detach() - bias.view(1, E, L)).transpose(0, 1).contiguous(), t_hat, coef, acc=acc, expert_major=True, bias=bias)
             do = do.transpose(0, 1)
+            np.testing.assert_allclose(dbias.view(E, L).cpu().numpy(), outs.grad.sum(0).cpu().numpy(), atol=4e-6 * float(outs.grad.abs().max()) * np.sqrt(n) + 1e-10, rtol=2e-4)
         else:
             stats, dl, do = fused_cts.moe_head_grads(logits.detach(), outs.detach(), t_hat, coef, acc=acc)
     finally:
