@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Learning-curve check: train a task for N iterations on the GPU and print reward / episode length / tracking terms every K iterations.
-   python tools/train_curve.py [task] [iterations] [every]"""
+   python tools/train_curve.py [task] [iterations] [every] [seed]"""
 import os, sys, tempfile, io, contextlib, re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,7 +9,8 @@ from go2_rl_gym_amd.utils import get_args
 task = sys.argv[1] if len(sys.argv) > 1 else "go2_flat"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 every = int(sys.argv[3]) if len(sys.argv) > 3 else 50
-args = get_args(["--task", task, "--num_envs", "4096", "--headless", "--seed", "1"])
+seed = sys.argv[4] if len(sys.argv) > 4 else "1"
+args = get_args(["--task", task, "--num_envs", "4096", "--headless", "--seed", seed])
 env, _ = task_registry.make_env(task, args)
 runner, _ = task_registry.make_alg_runner(env, task, args, log_root=tempfile.mkdtemp())
 env.common_step_counter = 0
