@@ -339,10 +339,11 @@ class CTS(_RolloutHeads):
 
     def _own_plan(self):
         """The CTS mini-batch as explicit launches without autograd (modules/fused_cts.py), when it covers this model and algorithm — the plain CTS heads and loss
-        (MoE-CTS included: only its student step differs) on the library pair; None keeps the autograd formulation (GO2_CTS_OWN=0 forces that, for A/B runs)."""
+        (MoE-CTS included: only its student step differs) on the library pair; None keeps the autograd formulation (GO2_FUSED_MLP=0 forces that for A/B runs: the
+        library pair is then never handed to modules/fused.py)."""
         if self._plan is False:
             self._plan = None
-            if self.fused_loss and self.lib is not None and type(self)._policy_extra is CTS._policy_extra and os.environ.get("GO2_CTS_OWN", "1") == "1":
+            if self.fused_loss and self.lib is not None and type(self)._policy_extra is CTS._policy_extra:
                 from ..modules import fused_cts
                 self._plan = fused_cts.cts_plan(self.model)
         return self._plan
@@ -464,8 +465,8 @@ class CTS(_RolloutHeads):
     def _teacher_latents(self):
         from ..modules import fused_cts
         nmb, mb, n_t = self.num_mini_batches, self._mb, self._teacher_rows()
-        for i in range(nmb):
-            fused_cts.encoder_latents(self._plan, self._plan.teacher, self._perm["cobs"][i * mb + n_t:(i + 1) * mb], self._tlat[i], None)
+        priv_s = self._perm["cobs"].view(nmb, mb, -1)[:, n_t:].reshape(nmb * (mb - n_t), -1)          # all mini-batches' student rows: one forward
+        fused_cts.encoder_latents(self._plan, self._plan.teacher, priv_s, self._tlat.view(nmb * (mb - n_t), -1), None)
 
     def _student_latents(self):
         """The student rows' latents of the whole update into the first L columns of both input matrices: optimizer1 never touches the student encoder (cts.py:72-77), so
@@ -476,12 +477,17 @@ class CTS(_RolloutHeads):
         hist = P["hist"].view(nmb, mb, -1)[:, n_t:].reshape(nmb * (mb - n_t), -1)
         from ..modules.fused import own_forward
         with torch.no_grad(), own_forward():          # (the MoE encoders' Linear / ELU stacks on the library's kernels also without a gradient)
-            lat = None if plan.student is not None else self.model.student_latent(hist)[0].view(nmb, mb - n_t, L)
+            n_s = mb - n_t
+            if plan.student is not None:              # a plain MLP: ONE forward over all mini-batches' student rows on the own kernels; the normaliser writes into both matrices
+                z = fused_cts.encoder_forward(plan.student, hist).view(nmb, n_s, L)
+                k = fused_cts._Launch(hist.device)
+            else:                                     # (the MoE encoders: torch modules, no gradient)
+                lat = self.model.student_latent(hist)[0].view(nmb, n_s, L)
             for i in range(nmb):
                 da, dc = P["ain"][i * mb + n_t:(i + 1) * mb], P["cin"][i * mb + n_t:(i + 1) * mb]
-                if plan.student is not None:          # a plain MLP: forward on the own kernels, the normaliser writes into both matrices
-                    fused_cts.encoder_latents(plan, plan.student, hist[i * (mb - n_t):(i + 1) * (mb - n_t)], da, dc)
-                else:                                 # (the MoE encoders: torch modules, no gradient)
+                if plan.student is not None:
+                    fused_cts.latent_concat(k, z[i], da, dc)
+                else:
                     da[:, :L] = lat[i]; dc[:, :L] = lat[i]
 
     def _update_graphs(self):

@@ -27,7 +27,7 @@ from ..storage import RolloutStorage
 from ._graph import CapturedStep, FusedClipAdam, GradBucket, ReducedStep, all_captured
 
 
-_ADAM_IMPL = {"foreach": True} if os.environ.get("GO2_ADAM", "fused") == "foreach" else {"fused": True}
+_ADAM_IMPL = {"fused": True}          # torch's capturable Adam where the library's clip + Adam kernel does not serve (GO2_FUSED_ADAM=0, a variant it does not cover)
 
 
 def _world():

@@ -67,4 +67,4 @@ class ActorCriticMoENGCTS(ActorCriticCTS):
         """-> (gate logits, expert outputs [E, B, latent] before their bias, the heads' bias) ahead of the mixture (the fused loss head of the student step, fused_cts.moe_head_grads)"""
         B, enc = history.shape[0], self.student_moe_encoder
         no_goal = history.reshape(B, self.history_length, -1).index_select(2, self._no_goal_idx).reshape(B, -1)
-        return enc.gating_network[:-1](history), enc.experts_out(enc.experts_hidden(enc.experts_backbone(no_goal)), expert_major=True, with_bias=False), enc.experts_out.bias
+        return enc.gating_network[:-1](history), enc.experts_out.expert_major(enc.experts_hidden(enc.experts_backbone(no_goal)), with_bias=False), enc.experts_out.bias

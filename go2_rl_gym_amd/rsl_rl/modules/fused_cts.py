@@ -167,16 +167,22 @@ def cts_student_grads(plan, model, hist_s, priv_s, acc=None):
     return tot[:1]
 
 
-def encoder_latents(plan, lins, x, dst_a, dst_b):
-    """zhat = L2Norm(MLP(x)) of a plain encoder (the student's, once per update) straight into the first L columns of dst_a / dst_b — forward only, own kernels"""
+def encoder_forward(lins, x):
+    """the un-normalised output z = MLP(x) of a plain encoder (forward only, own kernels: one split launch + one launch per layer)"""
     k = _Launch(x.device)
     with torch.no_grad():
         imgs = k.images(lins)
         h = x if x.is_contiguous() else x.contiguous()
         for l, m in enumerate(lins):
             h = k.forward([(h, m, imgs[l])], act=1 if l == len(lins) - 1 else 0)[0]
-        latent_concat(k, h, dst_a, dst_b)
     return h
+
+
+def encoder_latents(plan, lins, x, dst_a, dst_b):
+    """zhat = L2Norm(MLP(x)) of a plain encoder straight into the first L columns of dst_a / dst_b — forward only, own kernels"""
+    z = encoder_forward(lins, x)
+    latent_concat(_Launch(x.device), z, dst_a, dst_b)
+    return z
 
 
 def moe_head_grads(logits, outs, t_hat, lb_coef, acc=None, expert_major=False, bias=None):

@@ -69,23 +69,27 @@ class GroupedHeads(nn.Module):
         bound = 1.0 / math.sqrt(in_per_group)
         nn.init.uniform_(self.bias, -bound, bound)
 
-    def forward(self, x, expert_major=False, with_bias=True):          # x [B, E*hidden] -> [B, E, out]  ([E, B, out], the batched GEMM's own output, when expert_major)
-        B = x.shape[0]
-        if not with_bias:                                               # (the fused loss head of the student step adds the bias itself: a plain batched product here)
-            assert expert_major
-            return torch.bmm(x.view(B, self.groups, self.cin).transpose(0, 1), self.weight.view(self.groups, self.cout, self.cin).transpose(1, 2))
+    def forward(self, x):                                              # x [B, E*hidden] -> [B, E, out]
+        return self._heads(x, True).transpose(0, 1)
 
+    def _heads(self, x, with_bias: bool):                              # -> [E, B, out], the batched GEMM's own output layout
+        B = x.shape[0]
         xe = x.view(B, self.groups, self.cin).transpose(0, 1)          # [E, B, hidden]
         w = self.weight.view(self.groups, self.cout, self.cin).transpose(1, 2)   # [E, hidden, out]
+        if not with_bias:                                               # (the fused loss head of the student step adds the bias itself: a plain batched product here)
+            return torch.bmm(xe, w)
         b = self.bias.view(self.groups, 1, self.cout)
         if self.cout < 32 and x.is_cuda:
             # narrow heads (12 actions, 1 value): the strided-batched GEMM with N < 32 runs ~100x slower on ROCm 7 (58 ms vs 0.5 ms
             # per fwd+bwd at 24576 rows, tools/probe_heads.py) — pad the output to 32 zero columns and slice them off again
             pad = 32 - self.cout
-            y = torch.baddbmm(F.pad(b, (0, pad)), xe, F.pad(w, (0, pad)))[..., :self.cout]
-        else:
-            y = torch.baddbmm(b, xe, w)                                 # [E, B, out]
-        return y if expert_major else y.transpose(0, 1)
+            return torch.baddbmm(F.pad(b, (0, pad)), xe, F.pad(w, (0, pad)))[..., :self.cout]
+        return torch.baddbmm(b, xe, w)
+
+    @torch.jit.ignore
+    def expert_major(self, x, with_bias=True):
+        """[E, B, out] — no transposing view in front of the consumer (the fused loss head of the MoE student step, modules/fused_cts.py:moe_head_grads)"""
+        return self._heads(x, with_bias)
 
 
 class Experts(nn.Module):
@@ -116,7 +120,7 @@ class MoE(nn.Module):
         """-> (gate logits [B, E] — the gating MLP before its softmax —, expert outputs [E, B, out] before their bias, expert-major as the batched GEMM leaves them,
         the heads' bias parameter [E * out]): what the fused loss head of the student step mixes itself"""
         heads = self.experts.experts
-        return self.gating_network[0](x), heads(self.experts.backbone(x), expert_major=True, with_bias=False), heads.bias          # outs [E, B, out] WITHOUT the bias
+        return self.gating_network[0](x), heads.expert_major(self.experts.backbone(x), with_bias=False), heads.bias          # outs [E, B, out] WITHOUT the bias
 
 
 class StudentMoEEncoder(nn.Module):

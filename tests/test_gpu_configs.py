@@ -186,3 +186,37 @@ def test_multi_rank_code_path_at_4096_envs_replays_with_21_collectives(hip, monk
     finally:
         monkeypatch.setattr(dist, "all_reduce", real)
         dist.destroy_process_group()
+
+
+SWITCH_SCRIPT = """
+import sys, torch
+sys.path.insert(0, %r)
+from go2_rl_gym_amd.envs import task_registry
+from go2_rl_gym_amd.utils import get_args
+task = sys.argv[1]
+args = get_args(["--task", task, "--num_envs", "512", "--headless", "--seed", "4"])
+env, _ = task_registry.make_env(task, args)
+torch.manual_seed(4)
+runner, _ = task_registry.make_alg_runner(env, task, args, log_root=None)
+runner.learn(6, init_at_random_ep_len=True)
+torch.cuda.synchronize()
+model = runner.alg.actor_critic
+p = torch.cat([q.detach().reshape(-1) for q in model.parameters()])
+g = runner.graphs_captured()
+assert torch.isfinite(p).all() and torch.isfinite(env.obs_buf).all() and g["rollout"] and g["update"], g
+print("OK %%s %%.3f" %% (task, float(env.rew_buf.mean())))
+"""
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("switch", ["GO2_FUSE_STEP", "GO2_FUSED_ADAM", "GO2_FUSED_MLP", "GO2_GEMM_SPLIT", "GO2_FUSED_POLICY"])
+def test_every_formulation_switch_still_trains(switch):
+    """The five switches that select an older / reference formulation (README: =0 each; the other five are GO2_STRICT_GRAPHS, GO2_TUNE_GEMM, GO2_FORCE_COLLECTIVES,
+    GO2_DIST_BACKEND — covered by bench.py and the multi-rank tests — and GO2_HIPCC_FLAGS, the build's): PPO and CTS train for 6 iterations at 512 envs in HIP-graph
+    mode with the switch off, in a process of its own (the switches are read at import)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for task in ("go2_flat", "go2_flat_cts"):
+        r = subprocess.run([sys.executable, "-c", SWITCH_SCRIPT % root, task], env=dict(os.environ, **{switch: "0"}), capture_output=True, text=True, timeout=180)
+        assert r.returncode == 0 and ("OK " + task) in r.stdout, (switch, task, r.stdout[-500:], r.stderr[-1500:])

@@ -31,8 +31,11 @@ for i in (1, 2, 3):
         d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(fs[0])) if any(n in r["Kernel_Name"] for n in ("go2nn_gemm3_kernel", "go2nn_wgrad_kernel", "go2nn_bx3_kernel"))]
         out["us_pass%d" % i] = sum(d) / len(d) / 1e3
 if "GRBM_GUI_ACTIVE" in out and "us_pass3" in out:
-    out["clock_GHz"] = out["GRBM_GUI_ACTIVE"] / out["us_pass3"] / 1e3
-    out["mfma_busy_frac_of_active_cycles"] = out.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024 / out["GRBM_GUI_ACTIVE"]       # 1024 SIMDs
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs (round 4's files divided by the launch time only and showed "17.4 GHz" / "5 % busy")
+    XCDS, SIMDS = 8, 1024
+    cyc = out["GRBM_GUI_ACTIVE"] / XCDS                                   # active cycles of the launch, per XCD
+    out["clock_GHz"] = cyc / out["us_pass3"] / 1e3
+    out["mfma_busy_frac_of_active_cycles"] = out.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (SIMDS * cyc)          # busy cycles summed over 1024 SIMDs / (SIMDs x active cycles)
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 print(json.dumps(out))
 PY
