@@ -4,37 +4,37 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/${1:-final}; mkdir -p $O
 cd $R
-timeout 900 python -m pytest tests -q -m gpu -s -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log
+python __graft_entry__.py > $O/build.log 2>&1
+timeout 1500 python -m pytest tests -q -m gpu -s -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log
 timeout 400 python bench.py > $O/bench.json 2> $O/bench.err
 GO2_GEMM_SPLIT=0 timeout 200 python bench.py --no-cpu-baseline > $O/bench_fp32_mfma_gemms.json 2> /dev/null
+GO2_FUSED_MLP=0 timeout 200 python bench.py --steps 30 --no-cpu-baseline > $O/bench_reference_formulation.json 2> /dev/null
 timeout 200 python bench.py --task go2 --no-cpu-baseline > $O/bench_go2.json 2> /dev/null
 timeout 200 python bench.py --task go2_cts --steps 50 --no-cpu-baseline > $O/bench_go2_cts.json 2> /dev/null
 timeout 200 python bench.py --task go2 --num-envs 32768 --steps 20 --warmup 8 --no-cpu-baseline > $O/bench_go2_32768.json 2> /dev/null
 timeout 200 python bench.py --num-envs 8192 --steps 40 --warmup 10 --no-cpu-baseline > $O/bench_go2_flat_8192.json 2> /dev/null
 timeout 200 python bench.py --task go2_moe_cts --num-envs 8192 --steps 20 --warmup 8 --no-cpu-baseline > $O/bench_go2_moe_cts_8192.json 2> /dev/null
+timeout 200 python bench.py --task go2_moe_cts --num-envs 1024 --steps 30 --warmup 8 --no-cpu-baseline > $O/bench_go2_moe_cts_1024.json 2> /dev/null
 timeout 150 python tools/kbench.py 4096 > $O/kbench.txt 2>&1
 timeout 150 python tools/kbench.py 4096 rough > $O/kbench_rough.txt 2>&1
-timeout 120 python tools/kscale.py 1024 4096 8192 32768 > $O/kscale.txt 2>&1
 timeout 100 python tools/policy_bench.py 4096 > $O/policy_bench.txt 2>&1
 hipcc -O2 -std=c++17 tools/gemm3_bench.cpp -o /tmp/gemm3_bench -ldl 2>/dev/null
-{ echo "# tools/gemm3_bench.cpp on one MI355X, 24576 rows per network: the grouped learner products checked against a float64 host reference and timed (HIP events, warm)";
-  echo "## split operands (3 x bf16 planes, six MFMA terms; ABI 4) — forward, input gradient and the weight gradients of the wide layers (the 256 -> 128 layer and narrow input layers stay on the fp32-MFMA kernel)";
-  BX3=1 timeout 300 /tmp/gemm3_bench go2_rl_gym_amd/libgo2nn_hip.so 24576 all;
-  echo "## fp32 MFMA (ABI 3)"; timeout 300 /tmp/gemm3_bench go2_rl_gym_amd/libgo2nn_hip.so 24576 all; } > $O/gemm_split_bench.txt 2>&1
 export GEMM3_BENCH=/tmp/gemm3_bench
 BX3=1 bash tools/gemm3_pmc.sh bx3_fwd_L2 f 2 10 > /dev/null 2>&1
 BX3=1 bash tools/gemm3_pmc.sh bx3_igrad_L2 i 2 10 > /dev/null 2>&1
-bash tools/gemm3_pmc.sh f32_wgrad_L2 w 2 10 > /dev/null 2>&1
 BX3=1 bash tools/gemm3_pmc.sh bx3_wgrad_L2 w 2 10 > /dev/null 2>&1
 bash tools/pmc_pass.sh 4096 100 go2_flat > $O/pmc_flat.log 2>&1
 bash tools/pmc_pass.sh 4096 100 go2 > $O/pmc_go2.log 2>&1
 bash tools/sq_pass.sh 4096 60 go2_flat > $O/sq_flat.log 2>&1
 bash tools/sq_pass.sh 4096 60 go2 > $O/sq_go2.log 2>&1
 cp $R/gpurun_out/pmc/*.json $R/gpurun_out/pmc/*.csv $O/ 2>/dev/null
-cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_bench
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o bench -- python $R/bench.py --steps 30 --warmup 20 --no-cpu-baseline > $O/bench_under_rocprof.json 2> /dev/null
-find /tmp/prof_bench -name "*kernel_stats.csv" -exec cp {} $O/bench_kernel_stats.csv \;
+cd /tmp && export TMPDIR=/tmp
+for spec in "go2_flat 4096 30 20" "go2_cts 4096 12 8" "go2_moe_cts 8192 8 8"; do
+  set -- $spec; task=$1; n=$2; steps=$3; warm=$4
+  rm -rf /tmp/prof_$task
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$task -o b -- python $R/bench.py --task $task --num-envs $n --steps $steps --warmup $warm --no-cpu-baseline > $O/bench_${task}_under_rocprof.json 2> /dev/null
+  find /tmp/prof_$task -name "*kernel_stats.csv" -exec cp {} $O/bench_${task}_kernel_stats.csv \;
+  python $R/tools/trace_timeline.py $(find /tmp/prof_$task -name "*kernel_trace.csv" | head -1) > $O/${task}_timeline.txt 2>&1
+done
 cd $R
-python tools/trace_timeline.py $(find /tmp/prof_bench -name "*kernel_trace.csv" | head -1) > $O/timeline.txt 2>&1
 tail -3 $O/pytest_gpu.log; for f in $O/bench*.json; do echo $f; grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"kernel_ms": [0-9.]*\|"collection_only": [0-9.]*' $f | tr '\n' ' '; echo; done
-cat $O/kscale.txt | grep -v amdgpu | tail -8

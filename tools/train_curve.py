@@ -11,8 +11,12 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 every = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 seed = sys.argv[4] if len(sys.argv) > 4 else "1"
 args = get_args(["--task", task, "--num_envs", "4096", "--headless", "--seed", seed])
-env, _ = task_registry.make_env(task, args)
-runner, _ = task_registry.make_alg_runner(env, task, args, log_root=tempfile.mkdtemp())
+# (as in the reference, --seed only reaches the TRAIN config — update_cfg_from_args, legged_gym/utils/helpers.py:99-126 — while make_env seeds every generator and the
+#  simulator from env_cfg.seed, which get_cfgs copied from the registered train config before the CLI was read: a seed study has to set both itself)
+env_cfg, train_cfg = task_registry.get_cfgs(task)
+env_cfg.seed = train_cfg.seed = int(seed)
+env, _ = task_registry.make_env(task, args, env_cfg=env_cfg)
+runner, _ = task_registry.make_alg_runner(env, None, args, train_cfg=train_cfg, log_root=tempfile.mkdtemp())
 env.common_step_counter = 0
 env.update_reward_curriculum(force_update=True)
 done = 0
