@@ -375,7 +375,11 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
         }
         if (row < g.M) {
           float* o = Cout + (size_t)row * g.ldc + col;
+#ifdef BX3_NT_STORE          /* tools only (round 5 prototype: non-temporal epilogue stores, profiles/r5_gemm_store_variants.txt) */
+          if (cv) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(o));
+#else
           if (cv) *reinterpret_cast<float4*>(o) = v;
+#endif
           else { if (col < g.N) o[0] = v.x; if (col + 1 < g.N) o[1] = v.y; if (col + 2 < g.N) o[2] = v.z; if (col + 3 < g.N) o[3] = v.w; }
         }
       }
