@@ -268,9 +268,9 @@ def main():
             "metric": "env-steps/sec at 4096 envs (go2 flat); 1/2/4/8-GPU scaling", "value": total_steps / elapsed, "unit": "env-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            # what "f32" means in the learner's GEMMs (the env step, the rollout's policy kernel and every element-wise kernel are plain fp32): VERDICT r4 item 4
-            "arith": ("learner GEMMs: fp32 operands split exactly into 3 bf16 planes, 6 bf16-MFMA terms (v_mfma_f32_32x32x16_bf16), fp32 accumulate — no operand bit dropped; "
-                      "rollout policy kernel: fp32 MFMA (v_mfma_f32_32x32x2_f32); env step: fp32 VALU" if os.environ.get("GO2_GEMM_SPLIT", "1") == "1" else
+            # what "f32" means in the matrix products (the env step and every element-wise kernel are plain fp32): VERDICT r4 item 4
+            "arith": ("learner GEMMs and rollout policy kernel: fp32 operands split exactly into 3 bf16 planes, 6 bf16-MFMA terms (v_mfma_f32_32x32x16_bf16), fp32 accumulate — "
+                      "no operand bit dropped; env step: fp32 VALU" if os.environ.get("GO2_GEMM_SPLIT", "1") == "1" else
                       "learner GEMMs and rollout policy kernel: fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate; env step: fp32 VALU"),
             "config": {"workload": "task=%s, num_envs=%d per GPU, full PPO iteration = 24 rollout steps + GAE + 5 epochs x 4 mini-batches"
                                    % ("go2 flat terrain (go2_flat)" if a.task == "go2_flat" else a.task + " (NOT the BASELINE workload)", N),

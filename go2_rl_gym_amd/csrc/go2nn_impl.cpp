@@ -39,6 +39,10 @@ static thread_local char g_err[256] = "";
 #define NN_THREADS 512         // 8 waves = two per SIMD: one wave's load / LDS waits are filled with the other's MFMAs (measured: 256 -> 65 us, 512 -> see profiles/r3_policy_kernel.txt)
 #endif
 #define NN_WAVES (NN_THREADS / 64)
+#define NN3_LDS 163840          // the split-operand kernel's LDS: the whole 160 KB of a CU
+// row pitch in bytes of a bf16 plane of `width` (a multiple of 16) columns: 16 bytes off a multiple of 64 — the 16-byte fragment reads of 16 consecutive rows
+// fall into 16 different 16-byte bank groups
+#define nn3_pitch(width) (((width) + 31) / 32 * 64 + 16)
 
 // what the kernel needs of one network: padded shapes and the offsets of its layers in the packed buffer
 struct NetDesc {
@@ -46,6 +50,10 @@ struct NetDesc {
   int32_t K[GO2NN_MAX_LAYERS], N[GO2NN_MAX_LAYERS];      // true input / output width of layer l
   int32_t KB[GO2NN_MAX_LAYERS], NT[GO2NN_MAX_LAYERS];    // k-blocks of 8, output tiles of 32
   int64_t woff[GO2NN_MAX_LAYERS], boff[GO2NN_MAX_LAYERS];
+  // the split-operand image of the same weights (go2nn_mlp3_kernel): 16-input k-blocks, KV3 of them hold inputs, padded with zero blocks to KB3 (a multiple of the
+  // weight ring's depth); lds3 = bytes of the kernel's first LDS region (the even activations), 0 = the network's activations do not fit the 160 KB as planes
+  int32_t KB3[GO2NN_MAX_LAYERS], KV3[GO2NN_MAX_LAYERS], lds3;
+  int64_t woff3[GO2NN_MAX_LAYERS];
   const float* packed; const float* x;
   // ABI 5 (the CTS rollout): the input row is two segments — columns [0, kx) from x (row pitch ldx), [kx, in_dim) from x2 (pitch ldx2) —, the network runs on
   // the rows `rows[0 .. nrows)` of its inputs (NULL: rows 0 .. nrows - 1), and mode 0 stores y[row * ldy + n], L2-normalised when `normalize`
@@ -73,6 +81,19 @@ static int describe(const Go2nnMlp* m, NetDesc* d, int64_t* total) {
     d->woff[l] = off; off += (int64_t)d->NT[l] * d->KB[l] * 64 * 4;
     d->boff[l] = off; off += (int64_t)d->NT[l] * 32;
   }
+  // (behind the fp32 image: GO2_GEMM_SPLIT=0 and the shapes whose planes do not fit the LDS run the fp32-MFMA kernel from the same buffer)
+  int64_t even = 0, odd = 0;
+  for (int l = 0; l < m->num_layers; ++l) {
+    d->KV3[l] = (d->K[l] + 15) / 16;
+    const int ring = d->NT[l] > NN_WAVES ? 4 : 8;          // run_layer3's ring slots
+    d->KB3[l] = (d->KV3[l] + ring - 1) / ring * ring;
+    d->woff3[l] = off; off += (int64_t)d->NT[l] * d->KB3[l] * 768;
+    const int64_t bytes = 3LL * NN_ROWS * nn3_pitch(l == 0 ? 16 * d->KV3[0] : 32 * d->NT[l - 1]);
+    ((l & 1) ? odd : even) = std::max((l & 1) ? odd : even, bytes);
+  }
+  { const int64_t bytes = (int64_t)NN_ROWS * (32 * d->NT[m->num_layers - 1] + 4) * 4;          // the last layer's output tile stays fp32 (the heads read it)
+    ((m->num_layers & 1) ? odd : even) = std::max((m->num_layers & 1) ? odd : even, bytes); }
+  d->lds3 = even + odd <= NN3_LDS ? (int32_t)even : 0;
   if (total) *total = off;
   return 1;
 }
@@ -82,22 +103,6 @@ static int describe(const Go2nnMlp* m, NetDesc* d, int64_t* total) {
 #ifndef GO2_EMU
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__global__ void __launch_bounds__(256) go2nn_pack_kernel(const float* __restrict__ W, const float* __restrict__ b, float* __restrict__ out_w, float* __restrict__ out_b,
-                                                         int K, int N, int KB, int NT) {
-  const int64_t nw = (int64_t)NT * KB * 256;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < nw + NT * 32; idx += (int64_t)gridDim.x * 256) {
-    if (idx < nw) {
-      const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63); const int64_t blk = idx >> 8;
-      const int kb = (int)(blk % KB), t = (int)(blk / KB);
-      const int n = 32 * t + (lane & 31), k = 8 * kb + 4 * (lane >> 5) + e;
-      out_w[idx] = (n < N && k < K) ? W[(int64_t)n * K + k] : 0.f;
-    } else {
-      const int n = (int)(idx - nw);
-      out_b[n] = n < N ? b[n] : 0.f;
-    }
-  }
-}
 
 // ELU(alpha = 1): exp(v) - 1 through the hardware exponential (v_exp_f32, ~1 ulp of exp): absolute error <= 1.2e-7 — fp32 round-off of the
 // activations' own scale; libm's expm1f costs ~40 instructions and the epilogue of a 512-wide layer evaluates it 64 times per lane
@@ -171,6 +176,44 @@ __device__ __forceinline__ void run_layer(const float* __restrict__ A, float* __
   }
 }
 
+// the network's output tile A [32][ld] fp32 -> mode 0: the output rows (L2-normalised on request); mode 1: the sampling head (actor) / the value (critic)
+__device__ __forceinline__ void nn_finish(const NNArgs& a, const NetDesc& nd, float* A, const int ld, const int row0, const int tid) {
+  if (a.mode == 0) {
+    const int No = nd.out_dim;
+    if (nd.normalize) {          // F.normalize(x, p=2, dim=-1): x / max(|x|, 1e-12), the scale of row r parked behind its last column (No <= 512 < ld)
+      if (tid < NN_ROWS) { float ss = 0.f; for (int n = 0; n < No; ++n) ss += A[tid * ld + n] * A[tid * ld + n]; A[tid * ld + No] = 1.f / fmaxf(sqrtf(ss), 1e-12f); }
+      __syncthreads();
+    }
+    for (int idx = tid; idx < NN_ROWS * No; idx += NN_THREADS) {
+      const int r = idx / No, n = idx - r * No;
+      if (row0 + r < nd.nrows) {
+        const int64_t dr = nd.rows ? nd.rows[row0 + r] : row0 + r;
+        nd.y[dr * nd.ldy + n] = nd.normalize ? A[r * ld + n] * A[r * ld + No] : A[r * ld + n];
+      }
+    }
+    return;
+  }
+  if (tid < NN_ROWS) {
+    const int e = row0 + tid;
+    if (e >= a.N) return;
+    if (blockIdx.y == 0) {      // actor: the sampling head (ppo.py:90-102; go2sim_act_head's arithmetic: a = mu + std * eps as two rounded operations)
+      float lp = 0.f;
+      for (int j = 0; j < a.A; ++j) {
+        const int64_t k = (int64_t)e * a.A + j;
+        const float m = A[tid * ld + j], sg = a.std_[j], act = add_rn(m, mul_rn(sg, a.eps[k])), d = act - m;
+        lp += -(d * d) / (2.f * sg * sg) - logf(sg) - HALF_LOG2PI;
+        a.a_out[k] = act;
+        if (a.a_st) a.a_st[k] = act;
+        if (a.mu_st) a.mu_st[k] = m;
+        if (a.sig_st) a.sig_st[k] = sg;
+      }
+      if (a.lp_st) a.lp_st[e] = lp;
+    } else if (a.v_st) {
+      a.v_st[e] = A[tid * ld];
+    }
+  }
+}
+
 __global__ void __launch_bounds__(NN_THREADS) go2nn_mlp_kernel(const NNArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[2 * NN_ROWS * NN_LD];
   const NetDesc& nd = a.net[blockIdx.y];
@@ -216,41 +259,7 @@ __global__ void __launch_bounds__(NN_THREADS) go2nn_mlp_kernel(const NNArgs a) {
     NN_STAMP(2 + l);
     float* t_ = A; A = B; B = t_;
   }
-  // A now holds the network's output tile [32][32 NT_last]
-  if (a.mode == 0) {
-    const int No = nd.out_dim;
-    if (nd.normalize) {          // F.normalize(x, p=2, dim=-1): x / max(|x|, 1e-12), the scale of row r parked behind its last column (No <= 512 < NN_LD)
-      if (tid < NN_ROWS) { float ss = 0.f; for (int n = 0; n < No; ++n) ss += A[tid * NN_LD + n] * A[tid * NN_LD + n]; A[tid * NN_LD + No] = 1.f / fmaxf(sqrtf(ss), 1e-12f); }
-      __syncthreads();
-    }
-    for (int idx = tid; idx < NN_ROWS * No; idx += NN_THREADS) {
-      const int r = idx / No, n = idx - r * No;
-      if (row0 + r < nd.nrows) {
-        const int64_t dr = nd.rows ? nd.rows[row0 + r] : row0 + r;
-        nd.y[dr * nd.ldy + n] = nd.normalize ? A[r * NN_LD + n] * A[r * NN_LD + No] : A[r * NN_LD + n];
-      }
-    }
-    return;
-  }
-  if (tid < NN_ROWS) {
-    const int e = row0 + tid;
-    if (e >= a.N) return;
-    if (blockIdx.y == 0) {      // actor: the sampling head (ppo.py:90-102; go2sim_act_head's arithmetic: a = mu + std * eps as two rounded operations)
-      float lp = 0.f;
-      for (int j = 0; j < a.A; ++j) {
-        const int64_t k = (int64_t)e * a.A + j;
-        const float m = A[tid * NN_LD + j], sg = a.std_[j], act = add_rn(m, mul_rn(sg, a.eps[k])), d = act - m;
-        lp += -(d * d) / (2.f * sg * sg) - logf(sg) - HALF_LOG2PI;
-        a.a_out[k] = act;
-        if (a.a_st) a.a_st[k] = act;
-        if (a.mu_st) a.mu_st[k] = m;
-        if (a.sig_st) a.sig_st[k] = sg;
-      }
-      if (a.lp_st) a.lp_st[e] = lp;
-    } else if (a.v_st) {
-      a.v_st[e] = A[tid * NN_LD];
-    }
-  }
+  nn_finish(a, nd, A, NN_LD, row0, tid);          // A now holds the network's output tile [32][32 NT_last]
 }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) FAIL(GO2NN_EDEVICE, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
 #endif  // !GO2_EMU
@@ -259,6 +268,7 @@ __global__ void __launch_bounds__(NN_THREADS) go2nn_mlp_kernel(const NNArgs a) {
 #include "go2nn_gemm.h"
 #include "go2nn_gemm3.h"
 #include "go2nn_bx3.h"
+#include "go2nn_mlp3.h"
 #include "go2nn_cts.h"
 
 #ifdef GO2_EMU
@@ -371,7 +381,8 @@ int go2nn_pack(const Go2nnMlp* m, float* packed, void* stream) {
 #else
     const int64_t total = (int64_t)d.NT[l] * d.KB[l] * 256 + d.NT[l] * 32;
     int blocks = (int)((total + 255) / 256); blocks = blocks > 1024 ? 1024 : blocks;
-    hipLaunchKernelGGL(go2nn_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, m->weight[l], m->bias[l], packed + d.woff[l], packed + d.boff[l], d.K[l], d.N[l], d.KB[l], d.NT[l]);
+    hipLaunchKernelGGL(go2nn_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, m->weight[l], m->bias[l], packed + d.woff[l], packed + d.boff[l], reinterpret_cast<u32x4*>(packed + d.woff3[l]),
+                       d.K[l], d.N[l], d.KB[l], d.KB3[l], d.NT[l]);
 #endif
   }
 #ifndef GO2_EMU
@@ -410,7 +421,13 @@ static int run(NNArgs& a, int nets, void* stream) {
     }
   }
 #else
-  hipLaunchKernelGGL(go2nn_mlp_kernel, dim3((a.N + NN_ROWS - 1) / NN_ROWS, nets), dim3(NN_THREADS), 0, (hipStream_t)stream, a);
+  // the split-operand kernel (go2nn_mlp3.h) unless GO2_GEMM_SPLIT=0 asks for fp32 MFMA everywhere (the learner's switch: one arithmetic per run) or a network's planes do not fit the LDS
+  static const bool fp32_mfma = getenv("GO2_GEMM_SPLIT") && atoi(getenv("GO2_GEMM_SPLIT")) == 0;
+  bool split = !fp32_mfma;
+  for (int y = 0; y < nets; ++y) split = split && a.net[y].lds3 > 0;
+  const dim3 grid((a.N + NN_ROWS - 1) / NN_ROWS, nets), blk(NN_THREADS);
+  if (split) hipLaunchKernelGGL(go2nn_mlp3_kernel, grid, blk, 0, (hipStream_t)stream, a);
+  else       hipLaunchKernelGGL(go2nn_mlp_kernel, grid, blk, 0, (hipStream_t)stream, a);
   HIPCHK(hipGetLastError());
 #endif
   return 0;

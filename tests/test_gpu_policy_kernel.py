@@ -51,3 +51,26 @@ def test_cts_policy_kernel_on_gpu(kind, N, full):
     """the two-launch CTS policy step (go2nn_mlp_forward_rows + go2nn_policy_act_latent) on the MI355X against the torch modules: row subsets whose sizes differ between
     the two encoders (3 : 1), ragged last workgroups, the 295- and 77-wide two-segment inputs"""
     cts_policy_kernel_vs_modules(_nn.load_nn(), "cuda:0", kind, N, full, atol=6e-6)          # (hipBLASLt sums in another order: a few ulp of the activations' scale, as above)
+
+
+@pytest.mark.parametrize("dims,kernel", [((45, 512, 256, 128, 12), "planes"), ((263, 512, 256, 128, 1), "planes"), ((77, 100, 50, 7), "planes"), ((17, 33), "planes"),
+                                         ((300, 512, 512, 12), "fp32"), ((512, 512), "fp32")])
+def test_split_operand_policy_kernel_is_as_close_to_float64_as_fp32(dims, kernel):
+    """Round 5: the rollout's MLPs run on the bf16 matrix pipe with every weight and activation split exactly into three bf16 planes (go2nn_mlp3.h).  Against the same
+    network in float64 its error is that of an fp32 evaluation (torch fp32 on hipBLASLt beside it), on ragged widths too; two neighbouring 512-wide activations do
+    not fit the LDS as planes — those networks stay on the fp32-MFMA kernel (same entry point, same buffer), checked here to give fp32-grade results as well."""
+    lib = _nn.load_nn()
+    torch.manual_seed(3)
+    layers = []
+    for i in range(len(dims) - 1):
+        layers.append(torch.nn.Linear(dims[i], dims[i + 1]))
+        if i < len(dims) - 2:
+            layers.append(torch.nn.ELU())
+    seq = torch.nn.Sequential(*layers).to("cuda:0")
+    m = _nn.PackedMlp(lib, seq); m.pack()
+    x = torch.randn(997, dims[0], device="cuda:0") * 1.5
+    with torch.no_grad():
+        y = m.forward(x).double(); y32 = seq(x).double(); y64 = seq.double()(x.double())
+    scale = float(y64.abs().max())
+    e_kernel, e_torch = float((y - y64).abs().max()) / scale, float((y32 - y64).abs().max()) / scale
+    assert e_kernel < 2e-6 and e_kernel < 4.0 * e_torch + 2e-7, (kernel, e_kernel, e_torch)

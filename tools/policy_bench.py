@@ -44,7 +44,7 @@ print("N = %d rows: torch chains + elementwise head %.1f us per policy step | fu
       (N, graph_time(torch_path), graph_time(fused), graph_time(pk.pack)))
 if "--stamps" in sys.argv:      # per-workgroup phase timestamps (a -DGO2NN_STAMPS build of the library under build/variants/)
     import ctypes as C
-    lib = _nn.bind(os.path.join(ROOT, "build", "variants", "libgo2nn_stamps.so"))
+    lib = _nn.bind(os.environ.get("GO2NN_STAMPS_LIB") or os.path.join(ROOT, "build", "variants", "libgo2nn_stamps.so"))
     pk2 = _nn.PolicyKernel(lib, ac); pk2.pack()
     nwg = (N + 31) // 32
     buf = torch.zeros(2 * nwg, 8, dtype=torch.int64, device=dev)
@@ -63,3 +63,9 @@ if "--stamps" in sys.argv:      # per-workgroup phase timestamps (a -DGO2NN_STAM
         d = t[y * nwg:(y + 1) * nwg]
         print("%s workgroups: stage %.1f us | layers %s us | total mean %.1f max %.1f us; first start -> last end %.1f us" %
               (name, (d[:, 1] - d[:, 0]).mean(), " ".join("%.1f" % (d[:, 2 + l] - d[:, 1 + l]).mean() for l in range(4)), (d[:, 5] - d[:, 0]).mean(), (d[:, 5] - d[:, 0]).max(), d[:, 5].max() - t[:, 0].min()))
+        if d[:, 6].any():      # (the split-operand kernel: k-loop and epilogue of the wave that holds thread 0, per layer, 10 ns units packed 4 x 16 bits per word)
+            raw = buf.cpu().numpy()[y * nwg:(y + 1) * nwg, 6:8]
+            f = lambda l, part: ((raw[:, l >> 1] >> (32 * (l & 1) + 16 * part)) & 0xffff)
+            print("      thread 0's wave, layers 1-4: k-loop %s us | epilogue %s us (mean over the workgroups where that wave had a tile)" %
+                  (" ".join("%.1f" % (f(l, 0)[f(l, 0) > 0].mean() / 100.0 if (f(l, 0) > 0).any() else 0) for l in range(4)),
+                   " ".join("%.1f" % (f(l, 1)[f(l, 0) > 0].mean() / 100.0 if (f(l, 0) > 0).any() else 0) for l in range(4))))
