@@ -25,7 +25,7 @@ class Go2nnFwdJob(C.Structure):
 
 class Go2nnBwdInJob(C.Structure):
     _fields_ = [("gz", C.c_void_p), ("w", C.c_void_p), ("y_prev", C.c_void_p), ("gz_prev", C.c_void_p), ("workspace", C.c_void_p),
-                ("M", C.c_int32), ("C", C.c_int32), ("Kin", C.c_int32), ("plain", C.c_int32), ("w_split", C.c_void_p)]          # ABI 5: plain 1 = gz W only
+                ("M", C.c_int32), ("C", C.c_int32), ("Kin", C.c_int32), ("plain", C.c_int32), ("w_split", C.c_void_p), ("ld", C.c_int32)]          # ABI 5: plain 1 = gz W only; ld = pitch of y_prev / gz_prev (0: Kin)
 
 
 class Go2nnBwdWJob(C.Structure):

@@ -830,15 +830,19 @@ int go2nn_linear_backward_input_group(const Go2nnBwdInJob* jobs, int32_t njobs, 
   if (!jobs || njobs < 1 || njobs > GO2NN_MAX_GROUP) FAIL(GO2NN_EINVAL, "input-gradient group: 1..%d jobs", GO2NN_MAX_GROUP);
   const int plain = jobs[0].plain;
   if (plain != 0 && plain != 1) FAIL(GO2NN_EINVAL, "input-gradient group: plain 0 or 1");
-  for (int j = 0; j < njobs; ++j) if (jobs[j].plain != plain || !jobs[j].gz || !jobs[j].w || !jobs[j].gz_prev || (!plain && (!jobs[j].y_prev || !jobs[j].workspace)) || !lin_check(jobs[j].M, jobs[j].C, jobs[j].Kin)) FAIL(GO2NN_EINVAL, "input-gradient group: bad job %d", j);
+  for (int j = 0; j < njobs; ++j) if (jobs[j].plain != plain || !jobs[j].gz || !jobs[j].w || !jobs[j].gz_prev || (!plain && (!jobs[j].y_prev || !jobs[j].workspace)) || !lin_check(jobs[j].M, jobs[j].C, jobs[j].Kin) ||
+                                      (jobs[j].ld != 0 && jobs[j].ld < jobs[j].Kin)) FAIL(GO2NN_EINVAL, "input-gradient group: bad job %d", j);
 #ifdef GO2_EMU
   for (int j = 0; j < njobs; ++j) {
-    if (!plain) { const int rc = go2nn_linear_backward_input(jobs[j].gz, jobs[j].w, jobs[j].y_prev, jobs[j].gz_prev, nullptr, jobs[j].workspace, jobs[j].M, jobs[j].C, jobs[j].Kin, stream); if (rc) return rc; continue; }
+    if (!plain && !jobs[j].ld) { const int rc = go2nn_linear_backward_input(jobs[j].gz, jobs[j].w, jobs[j].y_prev, jobs[j].gz_prev, nullptr, jobs[j].workspace, jobs[j].M, jobs[j].C, jobs[j].Kin, stream); if (rc) return rc; continue; }
     const Go2nnBwdInJob& q = jobs[j];
+    const int64_t ld = q.ld ? q.ld : q.Kin;
+    if (!plain) for (int k = 0; k < q.Kin; ++k) q.workspace[k] = 0.f;          // (the host build leaves ONE partial row: go2nn_linear_backward_input_group_rows = 1)
     for (int m = 0; m < q.M; ++m) for (int k = 0; k < q.Kin; ++k) {
       float acc = 0.f;
       for (int c = 0; c < q.C; ++c) acc = fmaf(q.gz[(int64_t)m * q.C + c], q.w[(int64_t)c * q.Kin + k], acc);
-      q.gz_prev[(int64_t)m * q.Kin + k] = acc;
+      if (!plain) { const float y = q.y_prev[m * ld + k]; acc *= y > 0.f ? 1.f : y + 1.f; q.workspace[k] += acc; }
+      q.gz_prev[m * ld + k] = acc;
     }
   }
   return 0;
@@ -849,8 +853,8 @@ int go2nn_linear_backward_input_group(const Go2nnBwdInJob* jobs, int32_t njobs, 
     for (int j = 0; j < njobs; ++j) {
       Bx3Prob& g = a.p[j]; const Go2nnBwdInJob& q = jobs[j];
       g.A = q.gz; g.B = (const unsigned char*)q.w_split + bx3_image_bytes(q.C, q.Kin); g.C = q.gz_prev; g.Y = q.y_prev; g.part = q.workspace;
-      g.M = q.M; g.N = q.Kin; g.K = q.C; g.lda = q.C; g.ldc = q.Kin;
-      g.nbm = cdiv(q.M, 64 * tm); g.nbn = cdiv(q.Kin, 128); g.nkt = cdiv(q.C, BX3_BK); g.c_vec = (q.Kin % 4 == 0) && aligned16(q.gz_prev) && (plain || aligned16(q.y_prev));
+      g.M = q.M; g.N = q.Kin; g.K = q.C; g.lda = q.C; g.ldc = q.ld ? q.ld : q.Kin;
+      g.nbm = cdiv(q.M, 64 * tm); g.nbn = cdiv(q.Kin, 128); g.nkt = cdiv(q.C, BX3_BK); g.c_vec = (q.Kin % 4 == 0) && (g.ldc % 4 == 0) && aligned16(q.gz_prev) && (plain || aligned16(q.y_prev));
       (j ? a.ntiles : a.ntiles0) = g.nbm * g.nbn;
     }
     a.ntiles = njobs == 2 ? a.ntiles0 + a.ntiles : a.ntiles0;
@@ -861,6 +865,7 @@ int go2nn_linear_backward_input_group(const Go2nnBwdInJob* jobs, int32_t njobs, 
   if (njobs == 2) { int tm1, tn1, bk1; gemm3_tile(jobs[1].Kin, &tm1, &tn1, &bk1);
     if (tm1 != tm || tn1 != tn || bk1 != bk) { const int rc = go2nn_linear_backward_input_group(jobs, 1, stream); return rc ? rc : go2nn_linear_backward_input_group(jobs + 1, 1, stream); } }
   for (int j = 0; j < njobs; ++j) if (jobs[j].C < 4 || jobs[j].Kin < 4 || jobs[j].Kin % 4) {          // (column quads of W must not straddle Kin) -> the single-network kernels
+    for (int i = 0; i < njobs; ++i) if (jobs[i].ld) FAIL(GO2NN_EINVAL, "pitched input gradient on the fp32-MFMA kernels: C >= 4 and Kin a multiple of 4");
     if (plain) FAIL(GO2NN_EINVAL, "plain input gradient on the fp32-MFMA kernels: C >= 4 and Kin a multiple of 4 (the split-operand kernel takes any Kin)");
     // (go2nn_linear_backward_input picks its own tile height — 128 rows for Kin >= 512 — and then leaves HALF the partial rows the group's callers were told
     //  to sum, go2nn_linear_backward_input_group_rows = one per 64 rows: the single-network kernel is launched here with 64-row tiles whatever the shape)
@@ -879,8 +884,8 @@ int go2nn_linear_backward_input_group(const Go2nnBwdInJob* jobs, int32_t njobs, 
   Gemm3Args a; memset(&a, 0, sizeof(a));
   for (int j = 0; j < njobs; ++j) {
     Gemm3Prob& g = a.p[j]; const Go2nnBwdInJob& q = jobs[j];
-    g.A = q.gz; g.B = q.w; g.C = q.gz_prev; g.Y = q.y_prev; g.part = q.workspace; g.M = q.M; g.N = q.Kin; g.K = q.C; g.lda = q.C; g.ldb = q.Kin; g.ldc = q.Kin;
-    g.nbm = cdiv(q.M, 64 * tm); g.nbn = cdiv(q.Kin, 64 * tn); g.c_vec = (q.Kin % 4 == 0) && aligned16(q.gz_prev) && (plain || aligned16(q.y_prev));
+    g.A = q.gz; g.B = q.w; g.C = q.gz_prev; g.Y = q.y_prev; g.part = q.workspace; g.M = q.M; g.N = q.Kin; g.K = q.C; g.lda = q.C; g.ldb = q.Kin; g.ldc = q.ld ? q.ld : q.Kin;
+    g.nbm = cdiv(q.M, 64 * tm); g.nbn = cdiv(q.Kin, 64 * tn); g.c_vec = (q.Kin % 4 == 0) && (g.ldc % 4 == 0) && aligned16(q.gz_prev) && (plain || aligned16(q.y_prev));
     (j ? a.ntiles : a.ntiles0) = g.nbm * g.nbn;
   }
   a.ntiles = njobs == 2 ? a.ntiles0 + a.ntiles : a.ntiles0;

@@ -149,6 +149,29 @@ class _Launch:
         self.check(self.nn.go2nn_linear_backward_input_group(arr, len(jobs), self.stream), "go2nn_linear_backward_input_group")
         return outs, gbs
 
+    def bwd_in_blocks(self, do, w, y, imgs):
+        """The E heads of a grouped layer (GroupedHeads: Conv1d(groups = E)) back into the shared matrix they read: do [E, M, C] (expert-major, dense), w [E, C, Kin],
+        y [M, E * Kin] the ELU outputs the heads read -> (gz [M, E * Kin] = (do[e] w[e]) * elu'(y) in block e, gb [E * Kin] its column sums, valid after finish()).
+        Pitched jobs of the grouped input gradient (Go2nnBwdInJob.ld), GO2NN_MAX_GROUP per launch: no [E, M, Kin] intermediate, no transposing copy, no separate ELU' pass."""
+        from ..._nn import Go2nnBwdInJob, GO2NN_MAX_GROUP
+        E, M, Co = do.shape
+        Ki = w.shape[2]
+        gz, gb = torch.empty_like(y), self.new(E * Ki)
+        r = self.nn.go2nn_linear_backward_input_group_rows(M, Co, Ki)
+        if r <= 0:
+            raise RuntimeError("go2nn_linear_backward_input_group_rows: %s" % self.nn.go2nn_last_error().decode())
+        wk = self.new(E, r * Ki)
+        for e0 in range(0, E, GO2NN_MAX_GROUP):
+            n = min(GO2NN_MAX_GROUP, E - e0)
+            arr = (Go2nnBwdInJob * n)()
+            for j in range(n):
+                e = e0 + j
+                arr[j] = Go2nnBwdInJob(do[e].data_ptr(), w[e].data_ptr(), y.data_ptr() + 4 * e * Ki, gz.data_ptr() + 4 * e * Ki, wk[e].data_ptr(), M, Co, Ki, 0,
+                                       imgs[e].data_ptr() if imgs[e] is not None else None, E * Ki)
+                self.sums.append((wk[e], gb[e * Ki:(e + 1) * Ki], r, Ki))
+            self.check(self.nn.go2nn_linear_backward_input_group(arr, n, self.stream), "go2nn_linear_backward_input_group (pitched)")
+        return gz, gb
+
     def chain_backward(self, chains, sink=None):
         """chains: 1 or 2 dicts {lins, acts, gz, gb, imgs} of equally many layers and one M: gz / gb = the gradient at lins[-1]'s output and its column sums;
         acts[l] = the input of lins[l] (acts[l > 0] an ELU output).  Sets .grad of every weight and bias; -> the gradients at lins[0]'s pre-activation."""
@@ -291,6 +314,73 @@ class _FusedChain(torch.autograd.Function):
         for l in range(n):
             out += [grads[(l, "w")], grads[(l, "b")]]
         return (gx, *out)
+
+
+class _FusedChainHeads(torch.autograd.Function):
+    """The experts of a MoE encoder (rsl_rl/rsl_rl/modules/utils.py:64-93): x -> [Linear -> ELU] x n (the shared backbone, E * hidden wide at its top) -> E linear heads
+    hidden -> out WITHOUT their bias (the mixing kernel adds it) as ONE node -> outs [E, B, out], expert-major.  Forward = _FusedChain's + one batched product; backward:
+    the heads' weight gradient as one batched product, their input gradient as pitched jobs of the grouped input-gradient kernel that write (do[e] W[e]) * elu'(y) straight
+    into block e of the backbone's top gradient with its bias partials (round 5: this replaced a batched product, the transposing copy of its [E, B, hidden] result into
+    [B, E * hidden] and a separate ELU' + column-sum pass: 135 -> 45 us of the student step at 8192 envs), then the chain as in _FusedChain.
+    args: x, heads weight [E * out, hidden, 1], E, w1, b1, ..., wn, bn."""
+
+    @staticmethod
+    def forward(ctx, x, hw, E, *params):
+        ws, bs = params[0::2], params[1::2]
+        k = _Launch(x.device)
+        lins = [_LinearView(w, b) for w, b in zip(ws, bs)]
+        imgs = k.images(lins)
+        acts = _stack_forward(k, x, lins, imgs, len(lins), False)
+        y = acts[-1]
+        B, hid = y.shape[0], y.shape[1] // E
+        w3 = hw.view(E, -1, hid)                                                        # [E, out, hidden]
+        outs = torch.bmm(y.view(B, E, hid).transpose(0, 1), w3.transpose(1, 2))         # [E, B, out]
+        ctx.save_for_backward(*acts, *ws, hw)
+        ctx.n, ctx.imgs, ctx.E = len(ws), imgs, E
+        return outs
+
+    @staticmethod
+    def backward(ctx, do):
+        n, E = ctx.n, ctx.E
+        acts, ws, hw = ctx.saved_tensors[:n + 1], ctx.saved_tensors[n + 1:2 * n + 1], ctx.saved_tensors[2 * n + 1]
+        k = _Launch(do.device)
+        do = do.contiguous()
+        y = acts[n]
+        B, hid = y.shape[0], y.shape[1] // E
+        w3 = hw.view(E, -1, hid)
+        ghw = torch.bmm(do.transpose(1, 2), y.view(B, E, hid).transpose(0, 1)).reshape(hw.shape)          # d / d W[e] = do[e]^T y[:, block e]
+        himgs = k.images([_LinearView(w3[e], None) for e in range(E)])
+        gz, gb = k.bwd_in_blocks(do, w3, y, himgs)
+        lins = [_LinearView(w, None) for w in ws]
+        grads = {}
+        gz0 = k.chain_backward([{"lins": lins, "acts": acts, "gz": gz, "gb": gb, "imgs": ctx.imgs}], sink=grads)
+        gx = _input_grad(k, gz0[0], lins[0], ctx.imgs[0]) if ctx.needs_input_grad[0] else None
+        k.finish()
+        out = []
+        for l in range(n):
+            out += [grads[(l, "w")], grads[(l, "b")]]
+        return (gx, ghw, None, *out)
+
+
+def chain_heads(backbone, heads, x):
+    """outs [E, B, out] (no bias) of GroupedHeads `heads` over the [Linear, ELU] x n Sequential `backbone` as one _FusedChainHeads node, or None when the pair is not
+    covered (the library is not bound, no gradient is being recorded, other modules in the backbone, a hidden width that is not a multiple of 4, heads without gradient)."""
+    if not isinstance(backbone, FusedSequential) or _LIB is None or _NN is None or not torch.is_grad_enabled() or x.dim() != 2 or x.dtype != torch.float32:
+        return None
+    if not (x.is_cuda or (_LIB.go2sim_is_device_library() == 0 and _NN.go2nn_is_device_library() == 0)):
+        return None
+    mods = list(backbone)
+    st = _stack(mods)
+    if st is None or st[1] or st[2] != len(mods):
+        return None
+    lins = st[0]
+    E, hid, out = heads.groups, heads.cin, heads.cout
+    if lins[-1].out_features != E * hid or hid % 4 or out < 4 or not heads.weight.requires_grad or heads.weight.dtype != torch.float32 or not heads.weight.is_contiguous():
+        return None
+    if not _SPLIT and _NN.go2nn_is_device_library() != 0 and hid % 4:
+        return None
+    x = x if x.is_contiguous() else x.contiguous()
+    return _FusedChainHeads.apply(x, heads.weight, E, *[t for m in lins for t in (m.weight, m.bias)])
 
 
 def _stack(mods):

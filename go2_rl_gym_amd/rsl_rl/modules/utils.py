@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .actor_critic import get_activation
-from .fused import FusedSequential
+from .fused import FusedSequential, chain_heads as _chain_heads
 
 
 class L2Norm(nn.Module):
@@ -120,7 +120,10 @@ class MoE(nn.Module):
         """-> (gate logits [B, E] — the gating MLP before its softmax —, expert outputs [E, B, out] before their bias, expert-major as the batched GEMM leaves them,
         the heads' bias parameter [E * out]): what the fused loss head of the student step mixes itself"""
         heads = self.experts.experts
-        return self.gating_network[0](x), heads.expert_major(self.experts.backbone(x), with_bias=False), heads.bias          # outs [E, B, out] WITHOUT the bias
+        outs = _chain_heads(self.experts.backbone.network, heads, x)          # the backbone and its heads as ONE autograd node on the library's kernels where they are covered
+        if outs is None:
+            outs = heads.expert_major(self.experts.backbone(x), with_bias=False)
+        return self.gating_network[0](x), outs, heads.bias          # outs [E, B, out] WITHOUT the bias
 
 
 class StudentMoEEncoder(nn.Module):

@@ -126,9 +126,13 @@ int go2nn_linear_backward_weight(const float* gz, const float* x, float* dw, flo
  *   Go2nnFwdJob.act     0: y = elu(x W^T + b);  1: y = x W^T + b — the LAST Linear of an encoder, whose output goes to a normaliser instead of an ELU
  *                       (rsl_rl/rsl_rl/modules/actor_critic_cts.py:49-80: teacher_encoder / student_encoder = MLP -> L2Norm)
  *   Go2nnBwdInJob.plain 0: gz_prev = (gz W) * elu'(y_prev) + column partials;  1: gz_prev = gz W — the gradient at the INPUT of a network's first layer
- *                       (CTS: d loss / d [latent | obs], actor_critic_cts.py:146-151 -> autograd); y_prev and workspace are not read */
+ *                       (CTS: d loss / d [latent | obs], actor_critic_cts.py:146-151 -> autograd); y_prev and workspace are not read
+ *   Go2nnBwdInJob.ld    row pitch in floats of y_prev and gz_prev, 0 = Kin (dense).  A pitch > Kin addresses a column block of a wider matrix: the E expert heads of
+ *                       a MoE encoder (rsl_rl/rsl_rl/modules/utils.py:78-93, Conv1d(groups=E)) read their 128 columns of the shared [M, E * 128] backbone output and
+ *                       write the matching block of its gradient, ELU' and bias partials in the epilogue, with no transposing copy in between; the job's
+ *                       workspace stays dense (rows x Kin) */
 typedef struct Go2nnFwdJob { const float *x, *w, *b; float* y; int32_t M, K, N; int32_t act; const void* w_split; } Go2nnFwdJob;
-typedef struct Go2nnBwdInJob { const float *gz, *w, *y_prev; float *gz_prev, *workspace; int32_t M, C, Kin; int32_t plain; const void* w_split; } Go2nnBwdInJob;
+typedef struct Go2nnBwdInJob { const float *gz, *w, *y_prev; float *gz_prev, *workspace; int32_t M, C, Kin; int32_t plain; const void* w_split; int32_t ld; } Go2nnBwdInJob;
 typedef struct Go2nnBwdWJob { const float *gz, *x; float* workspace; int32_t M, C, Kin; int32_t split; } Go2nnBwdWJob;
 int go2nn_linear_elu_forward_group(const Go2nnFwdJob* jobs, int32_t njobs, void* stream);
 int32_t go2nn_linear_backward_input_group_rows(int32_t M, int32_t C, int32_t Kin);

@@ -221,6 +221,36 @@ def test_all_elu_chain_node_matches_autograd(B, dims):
     chain_vs_autograd(load_nn_emu(), load_oracle(), "cpu", B, dims)
 
 
+def chain_heads_vs_autograd(nn_lib, sim_lib, device, B=200, E=4, dims=(45, 64, 32), hid=16, out=8, atol=2e-6):
+    """modules/fused.py:_FusedChainHeads (the experts of a MoE encoder — the shared backbone and its E heads — as one autograd node; the heads' input gradient as
+    pitched jobs of the grouped input-gradient kernel, Go2nnBwdInJob.ld) against the modules under plain autograd: outputs, every parameter gradient, the input gradient"""
+    from go2_rl_gym_amd.rsl_rl.modules import fused
+    from go2_rl_gym_amd.rsl_rl.modules.utils import MoE
+    torch.manual_seed(11)
+    moe = MoE(E, dims[0], list(dims[1:]) + [hid], out, "elu").to(device)
+    x, tgt = torch.randn(B, dims[0], device=device, requires_grad=True), torch.randn(E, B, out, device=device)
+    res = []
+    for on in (False, True):
+        fused.set_library(sim_lib if on else None); fused.set_nn_library(nn_lib if on else None)
+        try:
+            moe.zero_grad(); x.grad = None
+            logits, outs, bias = moe.parts(x)
+            assert (type(outs.grad_fn).__name__ == "_FusedChainHeadsBackward") == on and outs.shape == (E, B, out)
+            (((outs - tgt) ** 2).mean() + (logits ** 2).mean()).backward()
+            ps = [q for q in moe.experts.parameters() if q is not bias]
+            res.append((outs.detach().clone(), [q.grad.clone() for q in ps] + [x.grad.clone()]))
+        finally:
+            fused.set_library(None); fused.set_nn_library(None)
+    np.testing.assert_allclose(res[1][0].cpu().numpy(), res[0][0].cpu().numpy(), atol=atol * 4, rtol=2e-5)
+    for a, b in zip(res[1][1], res[0][1]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=atol + 2e-5 * float(b.abs().max()), rtol=2e-3)
+
+
+@pytest.mark.parametrize("B,E,dims,hid,out", [(200, 4, (45, 64, 32), 16, 8), (77, 3, (30, 24), 8, 4), (130, 8, (60, 48), 128, 32)])
+def test_experts_node_matches_autograd(B, E, dims, hid, out):
+    chain_heads_vs_autograd(load_nn_emu(), load_oracle(), "cpu", B, E, dims, hid, out)
+
+
 def moe_head_vs_autograd(nn_lib, sim_lib, device, n=150, E=8, L=32, coef=0.01, expert_major=False):
     """fused_cts.moe_head_grads (go2nn_moe_usage + go2nn_moe_mix_loss) against the reference's formulation under autograd (modules/utils.py:96-152 MoE.forward +
     the normaliser; moe_cts.py:203-214): both losses, d loss / d gate logits, d loss / d expert outputs"""

@@ -48,6 +48,16 @@ def test_all_elu_chain_node_on_gpu(B, dims):
     chain_vs_autograd(_nn.load_nn(), load_hip(), "cuda:0", B, dims, atol=3e-6)
 
 
+from test_cts_own import chain_heads_vs_autograd  # noqa: E402
+
+
+@pytest.mark.parametrize("B,E,dims,hid,out", [(12288, 8, (225, 512, 256), 256, 32), (1000, 8, (225, 512, 256), 256, 32), (200, 4, (45, 64, 32), 16, 8), (77, 3, (30, 24), 8, 4)])
+def test_experts_node_on_gpu(B, E, dims, hid, out):
+    """the MoE student encoder's experts (backbone 225 -> 512 -> 256 -> 8 x 256 and the 8 heads 256 -> 32) as one node: the heads' input gradient written by pitched jobs of
+    the grouped split-operand kernel into the [B, 2048] gradient of the backbone's top"""
+    chain_heads_vs_autograd(_nn.load_nn(), load_hip(), "cuda:0", B, E, dims, hid, out, atol=3e-6)
+
+
 from test_cts_own import moe_head_vs_autograd  # noqa: E402
 
 
