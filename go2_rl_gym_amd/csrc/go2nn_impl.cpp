@@ -1,5 +1,6 @@
 // go2nn_impl.cpp — the C ABI of include/go2nn.h: the rollout's policy evaluation (PPO.act, rsl_rl/rsl_rl/algorithms/ppo.py:90-102) as ONE
-// fp32-MFMA kernel.
+// MFMA kernel.  This file holds the fp32-MFMA form (go2nn_mlp_kernel: GO2_GEMM_SPLIT=0, and networks too wide for the other one's LDS layout); the default since round 5 is
+// go2nn_mlp3_kernel (go2nn_mlp3.h: the same job on the bf16 matrix pipe with exactly split fp32 operands), chosen in run() below.
 //
 // Built two ways, like go2sim_impl.cpp:
 //   hipcc --offload-arch=gfx950  -> libgo2nn_hip.so : the product

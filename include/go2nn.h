@@ -5,8 +5,11 @@
  * (rsl_rl/rsl_rl/modules/actor_critic.py:119-136): two 4-layer MLPs (Linear, ELU, ..., Linear; :50-75), a Gaussian sample
  * a = mu + std * eps, its log-probability, and the rows PPO.act keeps for RolloutStorage.add_transitions
  * (rsl_rl/rsl_rl/storage/rollout_storage.py:88-101).  In PyTorch that is ~30 launches per env step (8 GEMMs, 6 ELUs, the sampling head)
- * at M = 4096 rows — launch-latency-bound; here it is ONE launch: a workgroup carries 32 rows through all layers of one network with
- * fp32 MFMA (v_mfma_f32_32x32x2_f32), activations in LDS, weights streamed from L2 in a pre-packed operand order.
+ * at M = 4096 rows — launch-latency-bound; here it is ONE launch: a workgroup carries 32 rows through all layers of one network on the
+ * matrix pipe, activations in LDS, weights streamed from L2 in a pre-packed operand order.  Arithmetic: fp32 operands split EXACTLY into
+ * three bf16 planes, six v_mfma_f32_32x32x16_bf16 terms per product, fp32 accumulate (csrc/go2nn_mlp3.h; no operand bit is dropped, the
+ * results are as close to float64 as an fp32 evaluation's); with GO2_GEMM_SPLIT=0 in the environment, or for networks whose activations
+ * do not fit the LDS as planes (two neighbouring 512-wide layers), v_mfma_f32_32x32x2_f32 on the fp32 values (csrc/go2nn_impl.cpp).
  *
  * Plain pointers and sizes, no torch types; asynchronous on the given HIP stream; 0 = ok, negative = error (go2nn_last_error).
  * All pointers are device pointers unless stated. */
@@ -37,7 +40,8 @@ typedef struct Go2nnMlp {
 int go2nn_abi_version(void);
 const char* go2nn_last_error(void);
 
-/* Number of floats of the packed operand buffer of `m` (weights in MFMA B-operand order, zero-padded to 32 x 8 tiles, + padded biases);
+/* Number of floats of the packed operand buffer of `m` (weights in MFMA B-operand order for both arithmetics — fp32 zero-padded to 32 x 8 tiles, the three bf16 planes
+ * to 32 x 16 —, + padded biases; the layout is the library's own);
  * negative on an unsupported shape (more than GO2NN_MAX_LAYERS layers, a dimension above GO2NN_MAX_WIDTH). */
 int64_t go2nn_packed_floats(const Go2nnMlp* m);
 /* Re-pack the CURRENT weights of `m` into `packed` (call after every optimizer step that the next forward must see; one small launch). */

@@ -1,5 +1,5 @@
 // bf16-MFMA issue-rate probe (v_mfma_f32_32x32x16_bf16): W waves per SIMD, A independent accumulators, optionally three ds_read_b128 per six MFMAs (the policy
-// kernel's k-block).   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_bf16_probe tools/mfma_bf16_probe.hip && /tmp/mfma_bf16_probe
+// kernel's k-block).   hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o /tmp/mfma_bf16_probe tools/mfma_bf16_probe.hip && /tmp/mfma_bf16_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -36,7 +36,7 @@ __global__ void probe(float* out, int iters) {
 }
 template <int A, bool LDS>
 void run(int threads, int iters) {
-  float* out; hipMalloc(&out, 256 * 1024 * 4);
+  float* out; (void)hipMalloc(&out, 256 * 1024 * 4);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   probe<A, LDS><<<256, threads>>>(out, 10); hipDeviceSynchronize();
   hipEventRecord(e0); probe<A, LDS><<<256, threads>>>(out, iters); hipEventRecord(e1); hipEventSynchronize(e1);
