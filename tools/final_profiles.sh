@@ -15,18 +15,27 @@ timeout 200 python bench.py --task go2 --num-envs 32768 --steps 20 --warmup 8 --
 timeout 200 python bench.py --num-envs 8192 --steps 40 --warmup 10 --no-cpu-baseline > $O/bench_go2_flat_8192.json 2> /dev/null
 timeout 200 python bench.py --task go2_moe_cts --num-envs 8192 --steps 20 --warmup 8 --no-cpu-baseline > $O/bench_go2_moe_cts_8192.json 2> /dev/null
 timeout 200 python bench.py --task go2_moe_cts --num-envs 1024 --steps 30 --warmup 8 --no-cpu-baseline > $O/bench_go2_moe_cts_1024.json 2> /dev/null
+if [ -z "$SKIP_STEP_KERNEL" ]; then          # (SKIP_STEP_KERNEL=1: libgo2sim_hip.so is unchanged since the last full set — its kbench / PMC / SQ files stay valid, keyed by the library's hash)
 timeout 150 python tools/kbench.py 4096 > $O/kbench.txt 2>&1
 timeout 150 python tools/kbench.py 4096 rough > $O/kbench_rough.txt 2>&1
-timeout 100 python tools/policy_bench.py 4096 > $O/policy_bench.txt 2>&1
+fi
+{ timeout 100 python tools/policy_bench.py 4096 | tail -1; timeout 100 python tools/policy_bench.py 8192 | tail -1; GO2_GEMM_SPLIT=0 timeout 100 python tools/policy_bench.py 4096 | tail -1; GO2_GEMM_SPLIT=0 timeout 100 python tools/policy_bench.py 8192 | tail -1; } > $O/policy_bench.txt 2>&1
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -cuid=go2nn -DGO2NN_STAMPS -o build/variants/libgo2nn_stamps.so go2_rl_gym_amd/csrc/go2nn_impl.cpp 2>/dev/null
+timeout 100 python tools/policy_bench.py 4096 --stamps 2>&1 | tail -5 >> $O/policy_bench.txt
 hipcc -O2 -std=c++17 tools/gemm3_bench.cpp -o /tmp/gemm3_bench -ldl 2>/dev/null
 export GEMM3_BENCH=/tmp/gemm3_bench
+if [ -z "$SKIP_STEP_KERNEL" ]; then          # (the learner's GEMM kernels likewise)
 BX3=1 bash tools/gemm3_pmc.sh bx3_fwd_L2 f 2 10 > /dev/null 2>&1
 BX3=1 bash tools/gemm3_pmc.sh bx3_igrad_L2 i 2 10 > /dev/null 2>&1
 BX3=1 bash tools/gemm3_pmc.sh bx3_wgrad_L2 w 2 10 > /dev/null 2>&1
+fi
+PASSES="1 3" bash tools/policy_pmc.sh mlp3 4096 > $O/policy_pmc.log 2>&1
+if [ -z "$SKIP_STEP_KERNEL" ]; then
 bash tools/pmc_pass.sh 4096 100 go2_flat > $O/pmc_flat.log 2>&1
 bash tools/pmc_pass.sh 4096 100 go2 > $O/pmc_go2.log 2>&1
 bash tools/sq_pass.sh 4096 60 go2_flat > $O/sq_flat.log 2>&1
 bash tools/sq_pass.sh 4096 60 go2 > $O/sq_go2.log 2>&1
+fi
 cp $R/gpurun_out/pmc/*.json $R/gpurun_out/pmc/*.csv $O/ 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 for spec in "go2_flat 4096 30 20" "go2_cts 4096 12 8" "go2_moe_cts 8192 8 8"; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# TOOL: SQ counters of the rollout's policy kernel (tools/policy_bench.py).  On the GPU box: bash tools/policy_pmc.sh <tag> [N]  -> gpurun_out/pmc/policy_<tag>.json
+# TOOL: SQ counters of the rollout's policy kernel (tools/policy_bench.py).  On the GPU box: [PASSES="1 3"] bash tools/policy_pmc.sh <tag> [N]  -> gpurun_out/pmc/policy_<tag>.json
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=$1; N=${2:-4096}
 mkdir -p $R/gpurun_out/pmc
@@ -11,6 +11,7 @@ P4="TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum T
 i=0
 for P in "$P1" "$P2" "$P3" "$P4"; do
   i=$((i+1)); rm -rf /tmp/pp_$i
+  case " ${PASSES:-1 2 3 4} " in *" $i "*) ;; *) continue;; esac
   timeout 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d /tmp/pp_$i -o pp -- python $R/tools/policy_bench.py $N > /tmp/pp_$i.log 2>&1 || tail -5 /tmp/pp_$i.log
 done
 python3 - "$R/gpurun_out/pmc/policy_$TAG.json" <<'PY'
