@@ -158,3 +158,27 @@ def test_every_source_file_makes_both_libraries_stale(tmp_path):
         os.utime(probe, (now + 20, now + 20))
         assert b.stale(str(out), [p for p in deps if p != d] + [str(probe)]), d
     assert b.stale(str(tmp_path / "missing.so"))
+
+
+def test_go2nn_structs_of_the_bindings_match_the_header(tmp_path):
+    """Every struct of include/go2nn.h that _nn.py restates as a ctypes.Structure: same size and same field offsets as gcc sees them in the header
+    (a field added on one side only — Go2nnBwdInJob.ld in round 5 — shifts what the library reads without any error)."""
+    from go2_rl_gym_amd import _nn
+    structs = ["Go2nnSumJob", "Go2nnFwdJob", "Go2nnBwdInJob", "Go2nnBwdWJob", "Go2nnSplitJob", "Go2nnPpoHeads", "Go2nnMlpIO", "Go2nnMlp"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = []
+    for s in structs:
+        lines.append('printf("%s %%zu", sizeof(%s));' % (s, s))
+        for f, _ in getattr(_nn, s)._fields_:
+            lines.append('printf(" %%zu", offsetof(%s, %s));' % (s, f))
+        lines.append('printf("\\n");')
+    src = tmp_path / "probe.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "include/go2nn.h"\nint main(void) {\n%s\nreturn 0; }\n' % "\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-I", root, "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
+    for s, line in zip(structs, out):
+        got = line.split()
+        cs = getattr(_nn, s)
+        assert got[0] == s and int(got[1]) == C.sizeof(cs), (s, got[1], C.sizeof(cs))
+        assert [int(x) for x in got[2:]] == [getattr(cs, f).offset for f, _ in cs._fields_], s
