@@ -178,7 +178,7 @@ struct PhRow { float4 ya, yc; float act, omu, osg, olp, ad, tv, rt; };
 template <int CP>
 __global__ void __launch_bounds__(256, CP > 12 ? 1 : 2) go2nn_ppo_heads_kernel(const PpoHeadsArgs a, int qp_log2, int rows_per_wg) {          // (13 - 16 actions: 256 registers spilled 36 B per lane)
   static_assert(CP <= 16, "16 value slots in the reduce-scatter");
-  __shared__ float4 sh[256];
+  __shared__ float4 sh[CP + 3][256];          // (60 KB at 12 actions: two workgroups per CU still fit)
   __shared__ float shs[256 / 16][PH_NSTAT + 2 * HB_MAX_C + 1];
   const int B = a.B, A = a.A, K = a.K;
   const int QP = 1 << qp_log2, RL = 256 >> qp_log2, SH = qp_log2 - 4;          // QP >= 16 lanes per row; lane role c = cq >> SH (2^SH lanes share a role)
@@ -280,18 +280,18 @@ __global__ void __launch_bounds__(256, CP > 12 ? 1 : 2) go2nn_ppo_heads_kernel(c
   // the workgroup's partial row: [stats | d loss / d std | dW_mu [A][K] | gb_a [K] | db_mu [A] | dW_v [K] | gb_c [K] | db_v]; row lanes added in a fixed order
   float* prow = a.part + (size_t)blockIdx.x * ppo_heads_cols(A, K);
   float* pa = prow + PH_NSTAT + A; float* pc = pa + (size_t)(A + 1) * K + A;
+  // (all CP + 3 quantities through LDS at once, ONE barrier: one quantity per pass cost two barriers each, 30 in all — 6 of the kernel's 28 us at 24576 rows.  The row
+  //  lanes of a column quad are added in the same fixed order as before: bit-identical partials.)
 #pragma unroll
-  for (int c = 0; c < CP + 3; ++c) {
-    if (c < A || c >= CP) {
-      sh[threadIdx.x] = c < CP ? dw[c < CP ? c : 0] : (c == CP ? gba : (c == CP + 1 ? dwv : gbc));
-      __syncthreads();
-      if (rl == 0 && on) {
-        float4 t4 = sh[cq];
-        for (int j = 1; j < RL; ++j) { const float4 t = sh[j * QP + cq]; t4.x += t.x; t4.y += t.y; t4.z += t.z; t4.w += t.w; }
-        float* o = c < CP ? pa + (size_t)c * K : (c == CP ? pa + (size_t)A * K : (c == CP + 1 ? pc : pc + K));
-        *reinterpret_cast<float4*>(o + k0) = t4;
-      }
-      __syncthreads();
+  for (int c = 0; c < CP + 3; ++c) sh[c][threadIdx.x] = c < CP ? dw[c < CP ? c : 0] : (c == CP ? gba : (c == CP + 1 ? dwv : gbc));
+  __syncthreads();
+  for (int task = threadIdx.x; task < ((CP + 3) << qp_log2); task += 256) {
+    const int c = task >> qp_log2, q = task & (QP - 1);
+    if ((c < A || c >= CP) && 4 * q < K) {
+      float4 t4 = sh[c][q];
+      for (int j = 1; j < RL; ++j) { const float4 t = sh[c][j * QP + q]; t4.x += t.x; t4.y += t.y; t4.z += t.z; t4.w += t.w; }
+      float* o = c < CP ? pa + (size_t)c * K : (c == CP ? pa + (size_t)A * K : (c == CP + 1 ? pc : pc + K));
+      *reinterpret_cast<float4*>(o + 4 * q) = t4;
     }
   }
   if (cq == 0) { shs[rl][0] = s_sur; shs[rl][1] = s_vl; shs[rl][2] = s_kl; shs[rl][3] = 0.f; shs[rl][PH_NSTAT + 2 * HB_MAX_C] = dbv; }
