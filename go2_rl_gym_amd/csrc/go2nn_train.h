@@ -22,7 +22,7 @@
 template <int CP>
 __global__ void __launch_bounds__(HB_THREADS) go2nn_head_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ w,
                                                                     float* __restrict__ gz, float* __restrict__ part, int B, int C, int K, int qp_log2, int rows_per_wg) {
-  __shared__ float4 sh[HB_THREADS];
+  __shared__ float4 sh[CP + 1][HB_THREADS];
   __shared__ float shd[HB_THREADS / 16][HB_MAX_C];
   const int QP = 1 << qp_log2, RL = HB_THREADS >> qp_log2;
   const int cq = threadIdx.x & (QP - 1), rl = threadIdx.x >> qp_log2;
@@ -68,17 +68,16 @@ __global__ void __launch_bounds__(HB_THREADS) go2nn_head_bwd_kernel(const float*
     }
   }
   float* prow = part + (size_t)blockIdx.x * ((size_t)(C + 1) * K + C);
+  // (every set through LDS at once, one barrier — go2nn_ppo_heads_kernel; the row lanes are added in the same fixed order: bit-identical partials)
 #pragma unroll
-  for (int c = 0; c <= CP; ++c) {
-    if (c < C || c == CP) {                            // c == CP: the gb set, stored behind the C rows of dW
-      sh[threadIdx.x] = c == CP ? gb : dw[c < CP ? c : 0];
-      __syncthreads();
-      if (rl == 0 && on) {
-        float4 s = sh[cq];
-        for (int j = 1; j < RL; ++j) { const float4 t = sh[j * QP + cq]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
-        *reinterpret_cast<float4*>(prow + (size_t)(c == CP ? C : c) * K + k0) = s;
-      }
-      __syncthreads();
+  for (int c = 0; c <= CP; ++c) sh[c][threadIdx.x] = c == CP ? gb : dw[c < CP ? c : 0];          // c == CP: the gb set, stored behind the C rows of dW
+  __syncthreads();
+  for (int task = threadIdx.x; task < ((CP + 1) << qp_log2); task += HB_THREADS) {
+    const int c = task >> qp_log2, q = task & (QP - 1);
+    if ((c < C || c == CP) && 4 * q < K) {
+      float4 s = sh[c][q];
+      for (int j = 1; j < RL; ++j) { const float4 t = sh[c][j * QP + q]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+      *reinterpret_cast<float4*>(prow + (size_t)(c == CP ? C : c) * K + 4 * q) = s;
     }
   }
   if (cq == 0) {
