@@ -276,6 +276,8 @@ def main():
                                    % ("go2 flat terrain (go2_flat)" if a.task == "go2_flat" else a.task + " (NOT the BASELINE workload)", N),
                        "num_envs_per_gpu": N, "num_steps_per_env": 24, "parallelism": "env-sharded dp%d" % world},
             "collection_only": world * N * 24 * a.steps / col,
+            # which kernel evaluated the rollout's networks (go2nn_mlp_arith: 3 = split-operand planes, 1 = fp32 MFMA; null = the torch chains ran): a silent fall-back shows here
+            "policy_kernel_arith": (lambda pk: None if pk in (None, False) else {k: getattr(pk, k).arith for k in ("enc_t", "enc_s", "actor", "critic") if getattr(pk, k, None) is not None})(getattr(runner.alg, "_pk", None)),
             "graphs": graphs,      # both halves of every timed iteration were replayed from HIP graphs (bench.py exits non-zero otherwise)
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1, "backend": (dist.get_backend() if dist.is_initialized() else None),
             "collectives_per_iteration": {"all_reduce": ncoll["all_reduce"] / max(a.steps, 1),

@@ -57,6 +57,7 @@ def bind(path):
     lib.go2nn_packed_floats.restype = C.c_int64
     lib.go2nn_packed_floats.argtypes = [C.POINTER(Go2nnMlp)]
     lib.go2nn_pack.argtypes = [C.POINTER(Go2nnMlp), C.c_void_p, C.c_void_p]
+    lib.go2nn_mlp_arith.argtypes = [C.POINTER(Go2nnMlp)]
     lib.go2nn_mlp_forward.argtypes = [C.POINTER(Go2nnMlp), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.go2nn_policy_act.argtypes = [C.POINTER(Go2nnMlp), C.c_void_p, C.POINTER(Go2nnMlp), C.c_void_p] + [C.c_void_p] * 10 + [C.c_int32, C.c_void_p]
     lib.go2nn_mlp_forward_rows.argtypes = [C.POINTER(C.POINTER(Go2nnMlp)), C.POINTER(C.c_void_p), C.POINTER(Go2nnMlpIO), C.c_int32, C.c_void_p]
@@ -150,6 +151,7 @@ class PackedMlp:
             raise ValueError(lib.go2nn_last_error().decode())
         self.packed = torch.zeros(int(n), dtype=torch.float32, device=layers[0][0].device)
         self.in_dim, self.out_dim = int(self.desc.dims[0]), int(self.desc.dims[len(layers)])
+        self.arith = int(lib.go2nn_mlp_arith(C.byref(self.desc)))          # 3: split-operand kernel, 1: fp32-MFMA kernel, 0: the host test build (include/go2nn.h)
 
     def _stream(self):
         d = self.packed.device

@@ -366,6 +366,19 @@ int64_t go2nn_packed_floats(const Go2nnMlp* m) {
   return total;
 }
 
+#ifndef GO2_EMU
+static bool nn_fp32_mfma() { static const bool v = getenv("GO2_GEMM_SPLIT") && atoi(getenv("GO2_GEMM_SPLIT")) == 0; return v; }          // the learner's switch: one arithmetic per run
+#endif
+int32_t go2nn_mlp_arith(const Go2nnMlp* m) {
+  NetDesc d;
+  if (!describe(m, &d, nullptr)) FAIL(GO2NN_EINVAL, "unsupported MLP shape (1..%d layers, widths 1..%d)", GO2NN_MAX_LAYERS, GO2NN_MAX_WIDTH);
+#ifdef GO2_EMU
+  return 0;
+#else
+  return (!nn_fp32_mfma() && d.lds3 > 0) ? 3 : 1;
+#endif
+}
+
 int go2nn_pack(const Go2nnMlp* m, float* packed, void* stream) {
   NetDesc d;
   if (!packed || !describe(m, &d, nullptr)) FAIL(GO2NN_EINVAL, "bad argument");
@@ -423,8 +436,7 @@ static int run(NNArgs& a, int nets, void* stream) {
   }
 #else
   // the split-operand kernel (go2nn_mlp3.h) unless GO2_GEMM_SPLIT=0 asks for fp32 MFMA everywhere (the learner's switch: one arithmetic per run) or a network's planes do not fit the LDS
-  static const bool fp32_mfma = getenv("GO2_GEMM_SPLIT") && atoi(getenv("GO2_GEMM_SPLIT")) == 0;
-  bool split = !fp32_mfma;
+  bool split = !nn_fp32_mfma();
   for (int y = 0; y < nets; ++y) split = split && a.net[y].lds3 > 0;
   const dim3 grid((a.N + NN_ROWS - 1) / NN_ROWS, nets), blk(NN_THREADS);
   if (split) hipLaunchKernelGGL(go2nn_mlp3_kernel, grid, blk, 0, (hipStream_t)stream, a);

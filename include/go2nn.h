@@ -44,6 +44,10 @@ const char* go2nn_last_error(void);
  * to 32 x 16 —, + padded biases; the layout is the library's own);
  * negative on an unsupported shape (more than GO2NN_MAX_LAYERS layers, a dimension above GO2NN_MAX_WIDTH). */
 int64_t go2nn_packed_floats(const Go2nnMlp* m);
+/* Which kernel evaluates `m` in the calls below (a host-side query, no device work): 3 = the split-operand kernel (csrc/go2nn_mlp3.h: three bf16 planes, six bf16-MFMA terms),
+ * 1 = the fp32-MFMA kernel (GO2_GEMM_SPLIT=0 in the environment, or activations that do not fit the LDS as planes), 0 = the host test build's loops; negative on an unsupported
+ * shape.  bench.py and the GPU tests read it so that a fall-back to the slower kernel cannot go unnoticed. */
+int32_t go2nn_mlp_arith(const Go2nnMlp* m);
 /* Re-pack the CURRENT weights of `m` into `packed` (call after every optimizer step that the next forward must see; one small launch). */
 int go2nn_pack(const Go2nnMlp* m, float* packed, void* stream);
 

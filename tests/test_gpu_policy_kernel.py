@@ -74,3 +74,12 @@ def test_split_operand_policy_kernel_is_as_close_to_float64_as_fp32(dims, kernel
     scale = float(y64.abs().max())
     e_kernel, e_torch = float((y - y64).abs().max()) / scale, float((y32 - y64).abs().max()) / scale
     assert e_kernel < 2e-6 and e_kernel < 4.0 * e_torch + 2e-7, (kernel, e_kernel, e_torch)
+
+
+def test_the_baseline_networks_run_on_the_split_operand_kernel():
+    """no silent fall-back: the library reports the kernel that serves each network (go2nn_mlp_arith), and for the tasks' shapes that is the split-operand one"""
+    import os
+    lib = _nn.load_nn()
+    pk = _nn.PolicyKernel(lib, _ac(dims=(512, 256, 128)).to("cuda:0"))
+    want = 3 if os.environ.get("GO2_GEMM_SPLIT", "1") == "1" else 1
+    assert (pk.actor.arith, pk.critic.arith) == (want, want)

@@ -2,6 +2,7 @@
 same source (packing, padding, operand order, the sampling head, the Python side) against plain PyTorch fp32.  GPU twin (the MFMA kernel
 itself): tests/test_gpu_policy_kernel.py."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -180,3 +181,24 @@ def test_forward_rows_refuses_bad_descriptions():
     assert lib.go2nn_mlp_forward_rows(descs, packed, io(kx=200), 1, None) < 0 and b"segments" in lib.go2nn_last_error()          # a second segment without x2
     assert lib.go2nn_mlp_forward_rows(descs, packed, io(ldx=100), 1, None) < 0 and lib.go2nn_mlp_forward_rows(descs, packed, io(nrows=0), 1, None) < 0
     assert lib.go2nn_mlp_forward_rows(descs, packed, io(), 3, None) < 0
+
+
+def test_the_query_names_the_kernel_that_serves_a_network():
+    """go2nn_mlp_arith (include/go2nn.h): the host test build answers 0; the HIP library — loaded here without a GPU, the query is host arithmetic — answers 3 (split-operand planes)
+    for every network of the BASELINE tasks and 1 (fp32 MFMA) where two neighbouring 512-wide activations do not fit the LDS as planes."""
+    import ctypes as C
+    from go2_rl_gym_amd import _nn, build
+    def desc(dims):
+        d = _nn.Go2nnMlp(); d.num_layers = len(dims) - 1
+        for i, v in enumerate(dims):
+            d.dims[i] = v
+        return d
+    emu = load_nn_emu()
+    assert emu.go2nn_mlp_arith(C.byref(desc((45, 512, 256, 128, 12)))) == 0
+    hip = _nn.bind(build.build_nn())
+    nets = [(45, 512, 256, 128, 12), (263, 512, 256, 128, 1),          # go2 / go2_flat: actor, critic
+            (77, 512, 256, 128, 12), (295, 512, 256, 128, 1), (263, 512, 256, 32), (225, 512, 256, 32)]          # go2_cts: [latent | obs] actor, [latent | priv] critic, teacher / student encoder
+    if os.environ.get("GO2_GEMM_SPLIT", "1") == "1":
+        assert [hip.go2nn_mlp_arith(C.byref(desc(n))) for n in nets] == [3] * len(nets)
+        assert hip.go2nn_mlp_arith(C.byref(desc((300, 512, 512, 12)))) == 1
+    assert hip.go2nn_mlp_arith(C.byref(desc((45, 600, 12)))) < 0 and b"unsupported" in hip.go2nn_last_error()
