@@ -34,7 +34,7 @@ for i in (1, 2, 3, 4):
         out["us_pass%d" % i] = sum(d) / len(d) / 1e3
 if "GRBM_GUI_ACTIVE" in out and "us_pass3" in out:
     cyc = out["GRBM_GUI_ACTIVE"] / 8          # summed over the 8 XCDs
-    out["clock_GHz"] = cyc / out["us_pass3"] / 1e3
+    out["gui_active_cycles_per_xcd"] = cyc          # (includes the launch's dispatch and drain: cyc / us_pass3 = 2.8 "GHz" for this 36 us kernel — NOT a clock; the GEMMs' 80-100 us launches give 2.17)
     out["mfma_busy_frac_of_active_cycles"] = out.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024 * cyc)
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 print(json.dumps(out))
