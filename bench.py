@@ -142,8 +142,12 @@ def cpu_baseline(task="go2_flat", sizes=(64, NUM_ENVS), iters=3):
                       "num_envs=64 runs with %d threads" % (" and ".join(str(n) for n in sizes), sizes[-1], iters, min(nproc, CPU_THREADS))}
 
 
+_STDOUT = sys.stdout
+
+
 def main():
     a = parse()
+    sys.stdout = sys.stderr          # stdout carries ONE line, the JSON: what the mirrored helpers print on the way ("Setting seed: 1", as the reference's set_seed does) goes to stderr
     os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, CPU_THREADS)))   # read by libgomp (the oracle) at load
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")                               # dmabuf IPC for RCCL across processes (host driver requirement)
     os.environ.setdefault("GO2_STRICT_GRAPHS", "1")          # a failed HIP-graph capture raises: no number from a silently degraded (eager) run
@@ -306,7 +310,7 @@ def main():
         pass
     if out is not None:
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=_STDOUT, flush=True)
 
 
 if __name__ == "__main__":
