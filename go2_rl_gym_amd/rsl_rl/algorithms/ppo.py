@@ -500,9 +500,13 @@ class PPO(_RolloutHeads):
                 self._graph = [ReducedStep((lambda i=i: self._graph_front(i, True)), (lambda: self._graph_back(True)), (lambda: self._bucket),
                                            enabled=self._capture, warmup=3 if i == 0 else 1, name="PPO mini-batch step %d" % i) for i in range(nmb)]
             else:
-                # one rank: a whole EPOCH (its nmb mini-batch steps, each on its own chunk of the permuted rollout) is one graph — a graph launch costs ≈ 9 µs of idle
-                # chip between two mini-batches (profiles/r4_timeline…: Adam step -> next split), 5 launches per update instead of 20 (measured: 15.85 -> 15.76 ms per iteration).  The first epoch runs eagerly.
-                self._graph = [CapturedStep((lambda: [self._graph_step(i) for i in range(nmb)] and None), enabled=self._capture, warmup=1, name="PPO epoch (%d mini-batch steps)" % nmb)]
+                # one rank: the whole UPDATE (every epoch's nmb mini-batch steps, each on its own chunk of the permuted rollout) is one graph — a graph launch costs ≈ 9 µs of idle
+                # chip between two mini-batches (profiles/r4_timeline…: Adam step -> next split): round 4 went from 20 launches per update to 5 (one per epoch: 15.85 -> 15.76 ms per
+                # iteration), round 5 to one.  The first update runs eagerly.
+                ne = self.num_learning_epochs
+                self._graph = [CapturedStep((lambda: [self._graph_step(i) for _ in range(ne) for i in range(nmb)] and None), enabled=self._capture, warmup=1,
+                                            name="PPO update (%d epochs x %d mini-batch steps)" % (ne, nmb))]
+            self._graph_reps = self.num_learning_epochs if _collectives_on() else 1
             # ONE permutation for the whole update, reused by every epoch, as in the reference (rollout_storage.py:150), and the nine storage tensors gathered
             # into mini-batch order: ONE launch (go2sim_shuffle_gather: a keyed sort-free shuffle computed per output row + all gathers + the loss accumulators'
             # reset) instead of torch.randperm's 12-kernel radix sort, 9 index_select launches and the fills between them (~0.36 ms of launch chain per update)
@@ -533,7 +537,7 @@ class PPO(_RolloutHeads):
                     raise RuntimeError("go2sim_shuffle_gather failed: %s" % self.lib.go2sim_last_error().decode())
             self._permute = CapturedStep(permute, enabled=self._capture, warmup=2, name="PPO rollout permutation", optional=True)
         self._permute()
-        for _ in range(self.num_learning_epochs):
+        for _ in range(self._graph_reps):
             for g in self._graph:
                 g()
         n = self.num_learning_epochs * nmb
