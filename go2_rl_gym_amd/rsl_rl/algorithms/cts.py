@@ -76,6 +76,7 @@ class CTS(_RolloutHeads):
         assert len(self.student_env_idxs) == self.student_num_envs, f"{len(self.student_env_idxs)=} != {self.student_num_envs=}"
         self.surrogate_split = 0            # set per update: teacher rows of a mini-batch (read by _FusedPPOLoss)
         self._steps = None
+        self._step_reps = None
         self._plan = False                  # the no-autograd mini-batch (modules/fused_cts.py): decided at the first graph-mode update (None: not applicable)
         self._fused_adam1 = self._fused_adam2 = None
         if _world() > 1:
@@ -521,15 +522,18 @@ class CTS(_RolloutHeads):
                     self._tlat = new(nmb, self._mb - self._teacher_rows(), L)
                     self._tlat_step = CapturedStep(self._teacher_latents, enabled=self._capture, warmup=2, name="CTS teacher latents of the student rows", optional=True)
                 self._head_step = CapturedStep(self._update_head, enabled=self._capture, warmup=2, name="CTS update head (permutation, gather, student latents)", optional=True)
+            self._step_reps = None          # (set by the branch whose graphs span every epoch)
             if _collectives_on():     # two captured halves per slot, the gradient all-reduce eager between them
                 mk = lambda front, back, bucket, name: [ReducedStep((lambda i=i: front(i, True)), (lambda: back(True)), bucket, enabled=self._capture, warmup=3 if i == 0 else 1,
                                                                     name="CTS %s step %d" % (name, i)) for i in range(nmb)]
                 self._steps = (mk(self._policy_front, self._policy_back, (lambda: self._bucket1), "policy"),
                                mk(self._student_front, self._student_back, (lambda: self._bucket2), "student"))
             elif plan is not None:
-                # one rank, own path: a whole EPOCH (its nmb steps, each on its own chunk of the permuted rollout) is one graph, as in PPO (5 + 5 graph launches per update instead of 20 + 20)
-                mk = lambda fn, name: [CapturedStep((lambda: [fn(i) for i in range(nmb)] and None), enabled=self._capture, warmup=1, name="CTS %s epoch (%d steps)" % (name, nmb))]
+                # one rank, own path: a whole PHASE (every epoch's nmb steps, each on its own chunk of the permuted rollout) is one graph, as in PPO (1 + 1 graph launches per update instead of 20 + 20)
+                ne = self.num_learning_epochs
+                mk = lambda fn, name: [CapturedStep((lambda: [fn(i) for _ in range(ne) for i in range(nmb)] and None), enabled=self._capture, warmup=1, name="CTS %s phase (%d epochs x %d steps)" % (name, ne, nmb))]
                 self._steps = (mk(self._policy_step, "policy"), mk(self._student_step, "student"))
+                self._step_reps = 1
             else:
                 mk = lambda fn, name: [CapturedStep((lambda i=i: fn(i)), enabled=self._capture, warmup=3 if i == 0 else 1, name="CTS %s step %d" % (name, i)) for i in range(nmb)]
                 self._steps = (mk(self._policy_step, "policy"), mk(self._student_step, "student"))
@@ -544,7 +548,7 @@ class CTS(_RolloutHeads):
         for phase, steps in enumerate(self._steps):
             if phase == 1 and self._tlat_step is not None:
                 self._tlat_step()          # the teacher latents of the student rows: constants of the student epochs, computed once (own kernels) instead of in each of the 20 steps
-            for _ in range(self.num_learning_epochs):
+            for _ in range(self._step_reps or self.num_learning_epochs):
                 for step in steps:
                     step()
         n = self.num_learning_epochs * nmb
