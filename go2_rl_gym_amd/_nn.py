@@ -10,12 +10,13 @@ import torch.nn as nn
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 NN_LIB = os.path.join(_HERE, "libgo2nn_hip.so")
-GO2NN_MAX_LAYERS, GO2NN_MAX_WIDTH, GO2NN_ABI_VERSION, GO2NN_MAX_GROUP = 6, 512, 5, 2
+GO2NN_MAX_LAYERS, GO2NN_MAX_WIDTH, GO2NN_ABI_VERSION, GO2NN_MAX_GROUP = 6, 512, 6, 2
 _cached = None
 
 
 class Go2nnSumJob(C.Structure):
-    _fields_ = [("part", C.c_void_p), ("out", C.c_void_p), ("nrows", C.c_int32), ("ncols", C.c_int32), ("acc", C.c_void_p), ("nacc", C.c_int32), ("pad_", C.c_int32)]
+    _fields_ = [("part", C.c_void_p), ("out", C.c_void_p), ("nrows", C.c_int32), ("ncols", C.c_int32), ("acc", C.c_void_p), ("nacc", C.c_int32), ("pad_", C.c_int32),
+                ("out_w", C.c_int32), ("out_ld", C.c_int32)]          # ABI 6: out_w > 0: the sums go out as rows of out_w floats with pitch out_ld
 
 
 class Go2nnFwdJob(C.Structure):
@@ -25,11 +26,12 @@ class Go2nnFwdJob(C.Structure):
 
 class Go2nnBwdInJob(C.Structure):
     _fields_ = [("gz", C.c_void_p), ("w", C.c_void_p), ("y_prev", C.c_void_p), ("gz_prev", C.c_void_p), ("workspace", C.c_void_p),
-                ("M", C.c_int32), ("C", C.c_int32), ("Kin", C.c_int32), ("plain", C.c_int32), ("w_split", C.c_void_p), ("ld", C.c_int32)]          # ABI 5: plain 1 = gz W only; ld = pitch of y_prev / gz_prev (0: Kin)
+                ("M", C.c_int32), ("C", C.c_int32), ("Kin", C.c_int32), ("plain", C.c_int32), ("w_split", C.c_void_p), ("ld", C.c_int32),          # ABI 5: plain 1 = gz W only; ld = pitch of y_prev / gz_prev (0: Kin)
+                ("Kx", C.c_int32), ("x_in", C.c_void_p), ("dw_workspace", C.c_void_p), ("ldx", C.c_int32)]          # ABI 6: x_in [M, Kx] = input of the layer below: its weight gradient's partials -> dw_workspace; gz_prev may be None
 
 
 class Go2nnBwdWJob(C.Structure):
-    _fields_ = [("gz", C.c_void_p), ("x", C.c_void_p), ("workspace", C.c_void_p), ("M", C.c_int32), ("C", C.c_int32), ("Kin", C.c_int32), ("split", C.c_int32)]
+    _fields_ = [("gz", C.c_void_p), ("x", C.c_void_p), ("workspace", C.c_void_p), ("M", C.c_int32), ("C", C.c_int32), ("Kin", C.c_int32), ("split", C.c_int32), ("ldx", C.c_int32)]          # ABI 6: ldx = pitch of x (0: Kin)
 
 
 class Go2nnSplitJob(C.Structure):
@@ -76,6 +78,7 @@ def bind(path):
     lib.go2nn_linear_elu_forward_group.argtypes = [C.POINTER(Go2nnFwdJob), C.c_int32, C.c_void_p]
     lib.go2nn_linear_backward_input_group_rows.argtypes = [C.c_int32] * 3
     lib.go2nn_linear_backward_input_group.argtypes = [C.POINTER(Go2nnBwdInJob), C.c_int32, C.c_void_p]
+    lib.go2nn_linear_backward_input_fused_rows.argtypes = [C.c_int32]
     lib.go2nn_linear_backward_weight_group_rows.argtypes = [C.POINTER(Go2nnBwdWJob), C.c_int32]
     lib.go2nn_linear_backward_weight_group.argtypes = [C.POINTER(Go2nnBwdWJob), C.c_int32, C.c_void_p]
     lib.go2nn_split_weights_bytes.restype = C.c_int64

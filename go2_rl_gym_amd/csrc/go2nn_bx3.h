@@ -42,6 +42,7 @@ struct Bx3Prob {
   const float* A; const unsigned char* B; float* C; const float* bias; const float* Y; float* part;
   int M, N, K, lda, ldc, nbm, nbn, c_vec, nkt;
   const float* Bf; int ldb;          // weight-gradient mode: the second operand is an activation matrix too (fp32, [rows][N])
+  float* wpart; int kx;              // EPI_DELU_WG: Bf [M][ldb] = the input x of the layer below (kx <= 64 columns), wpart [nbm][N][kx] = per-row-tile partials of its weight gradient; C may be NULL
 };
 struct Bx3Args { Bx3Prob p[2]; int ntiles0, ntiles; long long* stamps; int wg_M, wg_rows; };          // wg_*: the mini-batch's rows and the rows of one slice (weight-gradient mode)
 struct Bx3SplitJob { const float* w; unsigned char* img; int N, K; };          // img: forward image, then the transposed one
@@ -116,6 +117,7 @@ template <int TM> struct Bx3Frags {
 template <int TM, int EPI, bool WG = false>
 __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
   static_assert(!WG || (TM == 2 && EPI == EPI_STORE), "weight-gradient mode: 128 x 128 tiles, plain store");
+  static_assert(EPI != EPI_DELU_WG || (TM == 2 && !WG), "input gradient + the weight gradient below: 128-row tiles");
   constexpr int BM = 64 * TM, BN = 128, BK = BX3_BK, TN = 2;
   constexpr int AP = BM * 32, BP = 4096, BOFF = 3 * AP, STAGE = 3 * AP + 3 * BP, LOOP_LDS = 2 * STAGE, EPI_LDS = 4 * 32 * 32 * TN * 4;
   using SA = G3Stage<BM, true, BK>;
@@ -344,6 +346,127 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
   __syncthreads();          // every wave is done with the stages: the epilogue turns tiles through the same LDS
   G3_T(3);
 
+  if constexpr (EPI == EPI_DELU_WG) {
+    // ---- input gradient whose tile stays on the chip: Gp = (G W) * elu'(Yp) in the ACCUMULATORS' layout (acc[a][b][r] = row (r & 3) + 8 (r >> 2) + 4 gk of the wave's
+    // 32-row tile a, column i of its 32-column tile b), its column sums, and the weight gradient of the layer below  dWp [N, kx] = Gp^T X  of the workgroup's 128 rows:
+    // with the contraction index = the row, a lane's accumulator registers 8 kb .. 8 kb + 7 ARE an A fragment of v_mfma_f32_32x32x16_bf16 (m = column i of Gp, the lane's
+    // 8 k values = rows {0..3, 8..11} + 4 gk + 16 kb — the order inside a contraction is free as long as X is gathered in the same one).  Gp goes to HBM only if C is set.
+    const int rw = row0 + wm * 64, cw = col0 + wn * 64;
+    const int kx = g.kx;
+    const bool two = kx > 32;
+    float xv[2][2][8];
+    auto issue_x = [&](auto q_c, float (&x)[2][8]) __attribute__((always_inline)) {
+      constexpr int A_ = decltype(q_c)::value >> 1, KB = decltype(q_c)::value & 1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float* q = g.Bf + (size_t)gm_opaque(min(rw + A_ * 32 + 16 * KB + (e & 3) + 8 * (e >> 2) + 4 * gk, g.M - 1)) * g.ldb;
+        x[0][e] = q[min(i, kx - 1)];
+        if (two) x[1][e] = q[min(32 + i, kx - 1)];
+      }
+    };
+    issue_x(G3Int<0>{}, xv[0]);
+    float cs[2] = {0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      float y[2][16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float* q = g.Y + (size_t)gm_opaque(min(rw + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * gk, g.M - 1)) * g.ldc;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) y[b][r] = q[min(cw + b * 32 + i, g.N - 1)];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool in = rw + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * gk < g.M;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const float v = gm_keep(acc[a][b][r] * (y[b][r] > 0.f ? 1.f : y[b][r] + 1.f), in);
+          acc[a][b][r] = v; cs[b] += v;
+        }
+      }
+    }
+    // column sums: one partial row per 64 data rows = this wave's rows (the other row half gk is the lane 32 away)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float t2 = cs[b] + __shfl_xor(cs[b], 32);
+      const int c = cw + b * 32 + i;
+      if (gk == 0 && c < g.N && (bm * 2 + wm) * 64 < g.M) g.part[(size_t)(bm * 2 + wm) * g.N + c] = t2;
+    }
+    if (g.C) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rw + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * gk;
+#pragma unroll
+          for (int b = 0; b < 2; ++b) { const int c = cw + b * 32 + i; if (row < g.M && c < g.N) g.C[(size_t)row * g.ldc + c] = acc[a][b][r]; }
+        }
+    }
+    f32x16 o[2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[b][jt][r] = 0.f;
+    g3_for<0, 4>([&](auto q_c) __attribute__((always_inline)) {
+      constexpr int Q = decltype(q_c)::value, A_ = Q >> 1, KB = Q & 1;
+      if constexpr (Q + 1 < 4) issue_x(G3Int<Q + 1>{}, xv[(Q + 1) & 1]);
+      u32x4 gp[2][3], xp[2][3];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        u32x2 h0, m0_, l0, h1, m1, l1;
+        bx3_split4(f32x4{acc[A_][b][8 * KB], acc[A_][b][8 * KB + 1], acc[A_][b][8 * KB + 2], acc[A_][b][8 * KB + 3]}, h0, m0_, l0);
+        bx3_split4(f32x4{acc[A_][b][8 * KB + 4], acc[A_][b][8 * KB + 5], acc[A_][b][8 * KB + 6], acc[A_][b][8 * KB + 7]}, h1, m1, l1);
+        gp[b][0] = u32x4{h0[0], h0[1], h1[0], h1[1]}; gp[b][1] = u32x4{m0_[0], m0_[1], m1[0], m1[1]}; gp[b][2] = u32x4{l0[0], l0[1], l1[0], l1[1]};
+      }
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        if (jt == 1 && !two) break;
+        const float (&x)[8] = xv[Q & 1][jt];
+        const bool in = jt * 32 + i < kx;
+        u32x2 h0, m0_, l0, h1, m1, l1;
+        bx3_split4(f32x4{gm_keep(x[0], in), gm_keep(x[1], in), gm_keep(x[2], in), gm_keep(x[3], in)}, h0, m0_, l0);
+        bx3_split4(f32x4{gm_keep(x[4], in), gm_keep(x[5], in), gm_keep(x[6], in), gm_keep(x[7], in)}, h1, m1, l1);
+        xp[jt][0] = u32x4{h0[0], h0[1], h1[0], h1[1]}; xp[jt][1] = u32x4{m0_[0], m0_[1], m1[0], m1[1]}; xp[jt][2] = u32x4{l0[0], l0[1], l1[0], l1[1]};
+      }
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};          // the six terms of the main loop, small ones first (0 hi, 1 mid, 2 lo)
+#pragma unroll
+      for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) {
+            if (jt == 1 && !two) continue;
+            o[b][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, gp[b][PA[t6]]), __builtin_bit_cast(bf16x8, xp[jt][PB[t6]]), o[b][jt], 0, 0, 0);
+          }
+    });
+    // the two row halves of the workgroup (waves wm = 0, 1) are added through LDS (fixed order), then ONE partial tile [128 columns of Gp][kx] per workgroup
+    float* ex = reinterpret_cast<float*>(lds) + wn * (64 * 64);
+    if (wm == 1) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ex[((b * 2 + jt) * 16 + r) * 64 + lane] = o[b][jt][r];
+    }
+    __syncthreads();
+    if (wm == 0) {
+      float* const wp = g.wpart + (size_t)bm * g.N * kx;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+          if (jt == 1 && !two) continue;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = cw + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * gk, j = jt * 32 + i;
+            if (c < g.N && j < kx) wp[(size_t)c * kx + j] = o[b][jt][r] + ex[((b * 2 + jt) * 16 + r) * 64 + lane];
+          }
+        }
+    }
+  } else {
   // epilogue: go2nn_gemm3_kernel's (every wave turns its tile, 32 rows at a time, through its LDS quarter; 16-byte row accesses)
   g3_for<(TM == 2 ? 1 : 0), TM>([&](auto a_c) __attribute__((always_inline)) { load_y(a_c); });
   {
@@ -403,6 +526,7 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
           if ((bm * TM + q) * 64 < g.M) g.part[(size_t)(bm * TM + q) * g.N + col0 + tid] = shs[(2 * q) * BN + tid] + shs[(2 * q + 1) * BN + tid];
       }
     }
+  }
   }
 #ifdef GM3_STAMPS
   G3_T(4);

@@ -23,7 +23,8 @@
 
 #define GM_BK 32
 #define GM_THREADS 256
-enum { EPI_STORE = 0, EPI_BIAS_ELU = 1, EPI_DELU_COLSUM = 2, EPI_BIAS = 3 };          // EPI_BIAS: a Linear without activation (the encoders' last layer; grouped kernels only)
+enum { EPI_STORE = 0, EPI_BIAS_ELU = 1, EPI_DELU_COLSUM = 2, EPI_BIAS = 3, EPI_DELU_WG = 4 };          // EPI_BIAS: a Linear without activation (the encoders' last layer; grouped kernels only)
+// EPI_DELU_WG (go2nn_bx3_kernel only): EPI_DELU_COLSUM whose tile never leaves the chip — the weight gradient of the layer BELOW is formed from it in the epilogue
 
 struct GemmArgs {
   const float *A, *B; float* C;

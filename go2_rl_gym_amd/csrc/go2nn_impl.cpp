@@ -24,6 +24,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <vector>
 
 #include "../../include/go2nn.h"
 
@@ -501,13 +502,14 @@ int go2nn_policy_act_latent(const Go2nnMlp* actor, const float* actor_packed, co
 
 int go2nn_sum_rows(const Go2nnSumJob* jobs, int32_t njobs, void* stream) {
   if (!jobs || njobs <= 0 || njobs > GO2NN_MAX_SUM_JOBS) FAIL(GO2NN_EINVAL, "sum rows: 1..%d jobs", GO2NN_MAX_SUM_JOBS);
-  for (int j = 0; j < njobs; ++j) if (!jobs[j].part || !jobs[j].out || jobs[j].nrows <= 0 || jobs[j].ncols <= 0) FAIL(GO2NN_EINVAL, "sum rows: bad job %d", j);
+  for (int j = 0; j < njobs; ++j) if (!jobs[j].part || !jobs[j].out || jobs[j].nrows <= 0 || jobs[j].ncols <= 0 || jobs[j].out_w < 0 ||
+                                      (jobs[j].out_w > 0 && (jobs[j].out_ld < jobs[j].out_w || jobs[j].ncols % jobs[j].out_w))) FAIL(GO2NN_EINVAL, "sum rows: bad job %d", j);
 #ifdef GO2_EMU
   (void)stream;
   for (int j = 0; j < njobs; ++j) for (int c = 0; c < jobs[j].ncols; ++c) {
     float s = 0.f;
     for (int r = 0; r < jobs[j].nrows; ++r) s += jobs[j].part[(int64_t)r * jobs[j].ncols + c];
-    jobs[j].out[c] = s;
+    jobs[j].out[jobs[j].out_w > 0 ? (int64_t)(c / jobs[j].out_w) * jobs[j].out_ld + c % jobs[j].out_w : c] = s;
     if (jobs[j].acc && c < jobs[j].nacc) jobs[j].acc[c] += s;
   }
 #else
@@ -515,6 +517,7 @@ int go2nn_sum_rows(const Go2nnSumJob* jobs, int32_t njobs, void* stream) {
   a.njobs = njobs; a.first_block[0] = 0;
   for (int j = 0; j < njobs; ++j) {
     a.part[j] = jobs[j].part; a.out[j] = jobs[j].out; a.nrows[j] = jobs[j].nrows; a.ncols[j] = jobs[j].ncols; a.acc[j] = jobs[j].acc; a.nacc[j] = jobs[j].acc ? jobs[j].nacc : 0;
+    a.out_w[j] = jobs[j].out_w; a.out_ld[j] = jobs[j].out_ld;
     a.first_block[j + 1] = a.first_block[j] + (jobs[j].nrows <= 32 ? (jobs[j].ncols + 255) / 256 : (jobs[j].ncols + 15) / 16);
   }
   hipLaunchKernelGGL(go2nn_sum_rows_kernel, dim3(a.first_block[njobs]), dim3(256), 0, (hipStream_t)stream, a);
@@ -839,13 +842,38 @@ int32_t go2nn_linear_backward_input_group_rows(int32_t M, int32_t C, int32_t Kin
 #endif
 }
 
+int32_t go2nn_linear_backward_input_fused_rows(int32_t M) {
+  if (M <= 0) FAIL(GO2NN_EINVAL, "linear backward: bad shape");
+#ifdef GO2_EMU
+  return 1;
+#else
+  return cdiv(M, 128);
+#endif
+}
+
 int go2nn_linear_backward_input_group(const Go2nnBwdInJob* jobs, int32_t njobs, void* stream) {
   if (!jobs || njobs < 1 || njobs > GO2NN_MAX_GROUP) FAIL(GO2NN_EINVAL, "input-gradient group: 1..%d jobs", GO2NN_MAX_GROUP);
   const int plain = jobs[0].plain;
   if (plain != 0 && plain != 1) FAIL(GO2NN_EINVAL, "input-gradient group: plain 0 or 1");
-  for (int j = 0; j < njobs; ++j) if (jobs[j].plain != plain || !jobs[j].gz || !jobs[j].w || !jobs[j].gz_prev || (!plain && (!jobs[j].y_prev || !jobs[j].workspace)) || !lin_check(jobs[j].M, jobs[j].C, jobs[j].Kin) ||
+  const bool fused = jobs[0].x_in != nullptr;          // ABI 6: + the weight gradient of the layer below
+  for (int j = 0; j < njobs; ++j) if (jobs[j].plain != plain || !jobs[j].gz || !jobs[j].w || (!jobs[j].gz_prev && !fused) || (!plain && (!jobs[j].y_prev || !jobs[j].workspace)) || !lin_check(jobs[j].M, jobs[j].C, jobs[j].Kin) ||
                                       (jobs[j].ld != 0 && jobs[j].ld < jobs[j].Kin)) FAIL(GO2NN_EINVAL, "input-gradient group: bad job %d", j);
+  if (fused) for (int j = 0; j < njobs; ++j) if (!jobs[j].x_in || !jobs[j].dw_workspace || jobs[j].Kx < 1 || jobs[j].Kx > 64 || plain || jobs[j].ld || !jobs[j].w_split || jobs[j].C < 4 || (jobs[j].ldx != 0 && jobs[j].ldx < jobs[j].Kx))
+    FAIL(GO2NN_EINVAL, "input-gradient group with x_in: every job with x_in [M, 1..64], dw_workspace and w_split, plain 0, ld 0 (job %d)", j);
+  if (!fused) for (int j = 0; j < njobs; ++j) if (jobs[j].x_in) FAIL(GO2NN_EINVAL, "input-gradient group: x_in on every job of a group or on none");
 #ifdef GO2_EMU
+  if (fused) {
+    for (int j = 0; j < njobs; ++j) {
+      const Go2nnBwdInJob& q = jobs[j];
+      std::vector<float> gp((size_t)q.M * q.Kin);
+      const int rc = go2nn_linear_backward_input(q.gz, q.w, q.y_prev, gp.data(), nullptr, q.workspace, q.M, q.C, q.Kin, stream); if (rc) return rc;
+      if (q.gz_prev) memcpy(q.gz_prev, gp.data(), gp.size() * sizeof(float));
+      std::vector<float> xd;          // (a column block of a wider input: made dense for the single-network call)
+      if (q.ldx && q.ldx != q.Kx) { xd.resize((size_t)q.M * q.Kx); for (int m = 0; m < q.M; ++m) memcpy(&xd[(size_t)m * q.Kx], q.x_in + (size_t)m * q.ldx, q.Kx * sizeof(float)); }
+      const int rc2 = go2nn_linear_backward_weight(gp.data(), xd.empty() ? q.x_in : xd.data(), q.dw_workspace, q.dw_workspace, q.M, q.Kin, q.Kx, stream); if (rc2) return rc2;
+    }
+    return 0;
+  }
   for (int j = 0; j < njobs; ++j) {
     if (!plain && !jobs[j].ld) { const int rc = go2nn_linear_backward_input(jobs[j].gz, jobs[j].w, jobs[j].y_prev, jobs[j].gz_prev, nullptr, jobs[j].workspace, jobs[j].M, jobs[j].C, jobs[j].Kin, stream); if (rc) return rc; continue; }
     const Go2nnBwdInJob& q = jobs[j];
@@ -862,9 +890,10 @@ int go2nn_linear_backward_input_group(const Go2nnBwdInJob* jobs, int32_t njobs, 
 #else
   if (jobs[0].w_split && jobs[njobs - 1].w_split && jobs[0].C >= 4 && jobs[njobs - 1].C >= 4) {          // split-operand kernel: A = gz [M,C], B = the transposed image (rows k, contraction c)
     Bx3Args a; memset(&a, 0, sizeof(a));
-    const int tm = bx3_tm(jobs[0].M, jobs[0].Kin, njobs == 2 ? jobs[1].Kin : 0, 2);          // (192-row tiles measured equal for the input gradient: 100.4 against 99.5 us; not instantiated)
+    const int tm = fused ? 2 : bx3_tm(jobs[0].M, jobs[0].Kin, njobs == 2 ? jobs[1].Kin : 0, 2);          // (192-row tiles measured equal for the input gradient: 100.4 against 99.5 us; not instantiated)
     for (int j = 0; j < njobs; ++j) {
       Bx3Prob& g = a.p[j]; const Go2nnBwdInJob& q = jobs[j];
+      g.Bf = q.x_in; g.ldb = q.ldx ? q.ldx : q.Kx; g.kx = q.Kx; g.wpart = q.dw_workspace;
       g.A = q.gz; g.B = (const unsigned char*)q.w_split + bx3_image_bytes(q.C, q.Kin); g.C = q.gz_prev; g.Y = q.y_prev; g.part = q.workspace;
       g.M = q.M; g.N = q.Kin; g.K = q.C; g.lda = q.C; g.ldc = q.ld ? q.ld : q.Kin;
       g.nbm = cdiv(q.M, 64 * tm); g.nbn = cdiv(q.Kin, 128); g.nkt = cdiv(q.C, BX3_BK); g.c_vec = (q.Kin % 4 == 0) && (g.ldc % 4 == 0) && aligned16(q.gz_prev) && (plain || aligned16(q.y_prev));
@@ -872,6 +901,11 @@ int go2nn_linear_backward_input_group(const Go2nnBwdInJob* jobs, int32_t njobs, 
     }
     a.ntiles = njobs == 2 ? a.ntiles0 + a.ntiles : a.ntiles0;
     GM3_SET_STAMPS(a);
+    if (fused) {
+      hipLaunchKernelGGL((go2nn_bx3_kernel<2, EPI_DELU_WG>), dim3(a.ntiles), dim3(256), 0, (hipStream_t)stream, a);
+      HIPCHK(hipGetLastError());
+      return 0;
+    }
     return plain ? bx3_launch<EPI_STORE>(tm, a, (hipStream_t)stream) : bx3_launch<EPI_DELU_COLSUM>(tm, a, (hipStream_t)stream);
   }
   int tm, tn, bk; gemm3_tile(jobs[0].Kin, &tm, &tn, &bk);
@@ -922,17 +956,22 @@ int go2nn_linear_backward_weight_group(const Go2nnBwdWJob* jobs, int32_t njobs, 
   int ta, tn, tiles_of[GO2NN_MAX_GROUP], nsplit, rows;
   const int tiles = wgrad3_group_shape(jobs, njobs, &ta, &tn, tiles_of, &nsplit, &rows);
   if (!tiles) FAIL(GO2NN_EINVAL, "weight-gradient group: 1..%d jobs with one M, C >= 2, Kin >= 4", GO2NN_MAX_GROUP);
-  for (int j = 0; j < njobs; ++j) if (!jobs[j].gz || !jobs[j].x || !jobs[j].workspace) FAIL(GO2NN_EINVAL, "weight-gradient group: bad job %d", j);
+  for (int j = 0; j < njobs; ++j) if (!jobs[j].gz || !jobs[j].x || !jobs[j].workspace || (jobs[j].ldx != 0 && jobs[j].ldx < jobs[j].Kin)) FAIL(GO2NN_EINVAL, "weight-gradient group: bad job %d", j);
 #ifdef GO2_EMU
-  for (int j = 0; j < njobs; ++j) { const int rc = go2nn_linear_backward_weight(jobs[j].gz, jobs[j].x, jobs[j].workspace, jobs[j].workspace, jobs[j].M, jobs[j].C, jobs[j].Kin, stream); if (rc) return rc; }
+  for (int j = 0; j < njobs; ++j) {
+    const Go2nnBwdWJob& q = jobs[j];
+    std::vector<float> xd;
+    if (q.ldx && q.ldx != q.Kin) { xd.resize((size_t)q.M * q.Kin); for (int m = 0; m < q.M; ++m) memcpy(&xd[(size_t)m * q.Kin], q.x + (size_t)m * q.ldx, q.Kin * sizeof(float)); }
+    const int rc = go2nn_linear_backward_weight(q.gz, xd.empty() ? q.x : xd.data(), q.workspace, q.workspace, q.M, q.C, q.Kin, stream); if (rc) return rc; }
   return 0;
 #else
+  for (int j = 0; j < njobs; ++j) if (jobs[j].ldx && jobs[j].ldx != jobs[j].Kin && ta != 9) FAIL(GO2NN_EINVAL, "weight-gradient group: a pitched x (ldx) on the split-operand kernel only (C in whole 128-row tiles, >= 8 tiles)");
   WgArgs a; memset(&a, 0, sizeof(a));
   if (ta == 9) {
     Bx3Args b; memset(&b, 0, sizeof(b));
     for (int j = 0; j < njobs; ++j) {
       Bx3Prob& g = b.p[j]; const Go2nnBwdWJob& q = jobs[j];
-      g.A = q.gz; g.lda = q.C; g.Bf = q.x; g.ldb = q.Kin; g.C = q.workspace; g.ldc = q.Kin; g.M = q.C; g.N = q.Kin; g.K = rows;
+      g.A = q.gz; g.lda = q.C; g.Bf = q.x; g.ldb = q.ldx ? q.ldx : q.Kin; g.C = q.workspace; g.ldc = q.Kin; g.M = q.C; g.N = q.Kin; g.K = rows;
       g.nbm = q.C / 128; g.nbn = cdiv(q.Kin, 128); g.c_vec = aligned16(q.workspace) && (q.Kin % 4 == 0);
     }
     b.ntiles0 = tiles_of[0]; b.ntiles = tiles; b.wg_M = jobs[0].M; b.wg_rows = rows;

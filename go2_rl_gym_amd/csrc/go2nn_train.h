@@ -100,6 +100,7 @@ __global__ void __launch_bounds__(HB_THREADS) go2nn_head_bwd_kernel(const float*
 struct SumRowsArgs {
   const float* part[SR_MAX_JOBS]; float* out[SR_MAX_JOBS]; float* acc[SR_MAX_JOBS];
   int nrows[SR_MAX_JOBS], ncols[SR_MAX_JOBS], nacc[SR_MAX_JOBS], first_block[SR_MAX_JOBS + 1];      // blocks [first_block[j], first_block[j+1]) belong to job j
+  int out_w[SR_MAX_JOBS], out_ld[SR_MAX_JOBS];          // out_w > 0: sum c goes to out[(c / out_w) * out_ld + c % out_w]
   int njobs;
 };
 __global__ void __launch_bounds__(256) go2nn_sum_rows_kernel(const SumRowsArgs a) {
@@ -108,6 +109,8 @@ __global__ void __launch_bounds__(256) go2nn_sum_rows_kernel(const SumRowsArgs a
   while (j + 1 < a.njobs && (int)blockIdx.x >= a.first_block[j + 1]) ++j;
   const float* __restrict__ part = a.part[j]; float* __restrict__ out = a.out[j];
   const int nrows = a.nrows[j], ncols = a.ncols[j], blk = blockIdx.x - a.first_block[j];
+  const int ow = a.out_w[j], old_ = a.out_ld[j];
+  auto oidx = [&](int c) { return ow > 0 ? (size_t)(c / ow) * old_ + (c % ow) : (size_t)c; };
   if (nrows <= 32) {
     const int c = blk * 256 + threadIdx.x;
     if (c < ncols) {
@@ -119,7 +122,7 @@ __global__ void __launch_bounds__(256) go2nn_sum_rows_kernel(const SumRowsArgs a
 #pragma unroll
         for (int u = 0; u < 8; ++u) if (r0 + u < nrows) s += v[u];
       }
-      out[c] = s;
+      out[oidx(c)] = s;
       if (a.acc[j] && c < a.nacc[j]) a.acc[j][c] += s;          // (one thread per column: no race)
     }
     return;
@@ -143,7 +146,7 @@ __global__ void __launch_bounds__(256) go2nn_sum_rows_kernel(const SumRowsArgs a
     for (int wd = 8; wd >= 1; wd >>= 1)
 #pragma unroll
       for (int i = 0; i < wd; ++i) t[i] += t[i + wd];
-    out[c] = t[0];
+    out[oidx(c)] = t[0];
     if (a.acc[j] && c < a.nacc[j]) a.acc[j][c] += t[0];
   }
 }

@@ -24,6 +24,7 @@ _NN = None
 # The hidden layers' products on the bf16 matrix pipe with fp32 operands (include/go2nn.h ABI 4: every fp32 value split exactly into three bf16 planes, six MFMA terms,
 # fp32 accumulation — as close to float64 as the fp32-MFMA kernels, tests/test_gpu_mlp_tail.py).  0: the fp32-MFMA kernels.
 _SPLIT = os.environ.get("GO2_GEMM_SPLIT", "1") == "1"
+_WG_BELOW = os.environ.get("GO2_WGRAD_BELOW", "1") == "1"      # tools (A/B): 0 = the first layer's weight gradient as a launch of its own (round 5)
 _OWN_FORWARD = False       # inside own_forward(): Linear / ELU stacks evaluated WITHOUT gradient also run on the library's kernels (see FusedSequential.forward)
 
 
@@ -112,15 +113,24 @@ class _Launch:
         self.check(self.nn.go2nn_linear_elu_forward_group(arr, len(jobs), self.stream), "go2nn_linear_elu_forward_group")
         return ys
 
-    def wgrad(self, jobs, sink=None, tag=None):
+    def wgrad(self, jobs, sink=None, tag=None, lead=None):
         """jobs: [(gz [M, C], x [M, Kin], Linear)] with one M: the layers' weight gradients (row-slice partials now, .grad = their sum after finish()).
-        sink: a dict that receives the gradient tensors under (tag, "w") instead of the parameters' .grad (inside an autograd node)"""
+        sink: a dict that receives the gradient tensors under (tag, "w") instead of the parameters' .grad (inside an autograd node).
+        lead: [(x0, dw)] per job — only the first x0 columns of x (whole 128-column tiles; pitch Kin) into columns [0, x0) of the given dw [C, Kin]: the other columns'
+        gradient came out of the layer above's input-gradient launch (bwd_in(below=...))"""
         from ..._nn import Go2nnBwdWJob
-        arr = (Go2nnBwdWJob * len(jobs))(*[Go2nnBwdWJob(gz.data_ptr(), x.data_ptr(), None, gz.shape[0], m.out_features, m.in_features, 1 if _SPLIT else 0) for gz, x, m in jobs])
+        arr = (Go2nnBwdWJob * len(jobs))(*[Go2nnBwdWJob(gz.data_ptr(), x.data_ptr(), None, gz.shape[0], m.out_features, m.in_features if lead is None else lead[j][0], 1 if _SPLIT else 0,
+                                                        0 if lead is None else m.in_features) for j, (gz, x, m) in enumerate(jobs)])
         rows = self.nn.go2nn_linear_backward_weight_group_rows(arr, len(jobs))
         if rows <= 0:
             raise RuntimeError("go2nn_linear_backward_weight_group_rows: %s" % self.nn.go2nn_last_error().decode())
         for j, (gz, x, m) in enumerate(jobs):
+            if lead is not None:
+                x0, dw = lead[j]
+                wk = self.new(rows * m.out_features * x0)
+                arr[j].workspace = wk.data_ptr()
+                self.sums.append((wk, dw, rows, m.out_features * x0, None, 0, (0, x0, m.in_features)))
+                continue
             n = m.out_features * m.in_features
             wk, dw = self.new(rows * n), torch.empty_like(m.weight)
             arr[j].workspace = wk.data_ptr()
@@ -131,23 +141,63 @@ class _Launch:
                 sink[(tag, "w")] = dw
         self.check(self.nn.go2nn_linear_backward_weight_group(arr, len(jobs), self.stream), "go2nn_linear_backward_weight_group")
 
-    def bwd_in(self, jobs, plain=False):
-        """jobs: [(gz [M, C], Linear, y_prev [M, Kin] or None, image)] -> ([gz_prev [M, Kin]], [gb_prev [Kin]] (valid after finish(); None when plain))"""
+    def bwd_in(self, jobs, plain=False, below=None, sink=None, tag=None):
+        """jobs: [(gz [M, C], Linear, y_prev [M, Kin] or None, image)] -> ([gz_prev [M, Kin]], [gb_prev [Kin]] (valid after finish(); None when plain)).
+        below: [(x [M, K0], Linear K0 -> Kin, x0, keep)] per job — the layer whose ELU output y_prev is: the weight gradient of its input columns [x0, K0) (at most 64)
+        comes out of the same launch (include/go2nn.h ABI 6, Go2nnBwdInJob.x_in), formed from the gz_prev tile while it is on the chip; keep False: gz_prev is not
+        written at all (-> None).  -> additionally [dw [Kin, K0]] per job: complete after finish() when x0 == 0, else columns [0, x0) are the caller's (wgrad(lead=...))."""
         from ..._nn import Go2nnBwdInJob
-        arr, outs, gbs = (Go2nnBwdInJob * len(jobs))(), [], []
+        arr, outs, gbs, dws = (Go2nnBwdInJob * len(jobs))(), [], [], []
         for j, (gz, m, yp, img) in enumerate(jobs):
             M, Co, Ki = gz.shape[0], m.out_features, m.in_features
-            o = self.new(M, Ki)
+            o = self.new(M, Ki) if below is None or below[j][3] else None
             wk = gb = None
             if not plain:
                 r = self.nn.go2nn_linear_backward_input_group_rows(M, Co, Ki)
                 wk, gb = self.new(r * Ki), self.new(Ki)
                 self.sums.append((wk, gb, r, Ki))
-            arr[j] = Go2nnBwdInJob(gz.data_ptr(), m.weight.data_ptr(), yp.data_ptr() if yp is not None else None, o.data_ptr(), wk.data_ptr() if wk is not None else None,
-                                   M, Co, Ki, 1 if plain else 0, img.data_ptr() if img is not None else None)
+            arr[j] = Go2nnBwdInJob(gz.data_ptr(), m.weight.data_ptr(), yp.data_ptr() if yp is not None else None, o.data_ptr() if o is not None else None,
+                                   wk.data_ptr() if wk is not None else None, M, Co, Ki, 1 if plain else 0, img.data_ptr() if img is not None else None)
+            if below is not None:
+                x, mb, x0, _ = below[j]
+                K0 = mb.in_features
+                kx = K0 - x0
+                rows = self.nn.go2nn_linear_backward_input_fused_rows(M)
+                if rows <= 0:
+                    raise RuntimeError("go2nn_linear_backward_input_fused_rows: %s" % self.nn.go2nn_last_error().decode())
+                dwk, dw = self.new(rows * Ki * kx), torch.empty_like(mb.weight)
+                arr[j].Kx, arr[j].x_in, arr[j].dw_workspace, arr[j].ldx = kx, x.data_ptr() + 4 * x0, dwk.data_ptr(), K0
+                self.sums.append((dwk, dw, rows, Ki * kx, None, 0, (4 * x0, kx, K0)))
+                dws.append(dw)
+                if sink is None:
+                    mb.weight.grad = dw
+                else:
+                    sink[(tag, "w")] = dw
             outs.append(o); gbs.append(gb)
         self.check(self.nn.go2nn_linear_backward_input_group(arr, len(jobs), self.stream), "go2nn_linear_backward_input_group")
-        return outs, gbs
+        return (outs, gbs) if below is None else (outs, gbs, dws)
+
+    def below_plan(self, chains, need_gz0):
+        """[x0] per chain when the first layers' weight gradients (their input columns [x0, K0)) can come out of the second layers' input-gradient launch, else None:
+        split-operand kernels, dense inputs, K0 <= 64 (x0 = 0: everything) or K0 = whole 128-column tiles + at most 64 columns (the 263-wide critic input: x0 = 256 —
+        the tiles go to the weight-gradient kernel without padding, which needs C in whole 128-row tiles and 8 tiles in its group)"""
+        if not (_SPLIT and _WG_BELOW) or len(chains[0]["lins"]) < 2:
+            return None
+        plan, t128 = [], 0
+        dev = self.nn.go2nn_is_device_library() != 0          # (the host build takes any shape: the tile conditions are the device kernels')
+        for c in chains:
+            m0, x = c["lins"][0], c["acts"][0]
+            K0 = m0.in_features
+            if c["imgs"][1] is None or c["lins"][1].out_features < 4 or not x.is_contiguous() or x.dim() != 2 or x.shape[1] != K0:
+                return None
+            x0 = 0 if K0 <= 64 else K0 - K0 % 128
+            if not 1 <= K0 - x0 <= 64:
+                return None
+            if x0 and dev and m0.out_features % 128:
+                return None
+            t128 += (m0.out_features // 128) * (x0 // 128)
+            plan.append(x0)
+        return plan if (t128 == 0 or t128 >= 8 or not dev) else None
 
     def bwd_in_blocks(self, do, w, y, imgs):
         """The E heads of a grouped layer (GroupedHeads: Conv1d(groups = E)) back into the shared matrix they read: do [E, M, C] (expert-major, dense), w [E, C, Kin],
@@ -172,10 +222,13 @@ class _Launch:
             self.check(self.nn.go2nn_linear_backward_input_group(arr, n, self.stream), "go2nn_linear_backward_input_group (pitched)")
         return gz, gb
 
-    def chain_backward(self, chains, sink=None):
+    def chain_backward(self, chains, sink=None, need_gz0=True):
         """chains: 1 or 2 dicts {lins, acts, gz, gb, imgs} of equally many layers and one M: gz / gb = the gradient at lins[-1]'s output and its column sums;
-        acts[l] = the input of lins[l] (acts[l > 0] an ELU output).  Sets .grad of every weight and bias; -> the gradients at lins[0]'s pre-activation."""
+        acts[l] = the input of lins[l] (acts[l > 0] an ELU output).  Sets .grad of every weight and bias; -> the gradients at lins[0]'s pre-activation
+        (need_gz0 False, or one flag per chain: the caller does not read them — where the first layer's weight gradient comes out of the second layer's input-gradient
+        launch whole (an input of at most 64 columns) they then never exist in HBM and the entry is None)."""
         n = len(chains[0]["lins"])
+        need = list(need_gz0) if isinstance(need_gz0, (list, tuple)) else [need_gz0] * len(chains)
         gz, gb = [c["gz"] for c in chains], [c["gb"] for c in chains]
         for l in range(n - 1, -1, -1):
             self.wgrad([(gz[j], c["acts"][l], c["lins"][l]) for j, c in enumerate(chains)], sink, l)
@@ -185,19 +238,33 @@ class _Launch:
                 else:
                     sink[(l, "b")] = gb[j]
             if l > 0:
-                gz, gb = self.bwd_in([(gz[j], c["lins"][l], c["acts"][l], c["imgs"][l]) for j, c in enumerate(chains)])
+                jobs = [(gz[j], c["lins"][l], c["acts"][l], c["imgs"][l]) for j, c in enumerate(chains)]
+                plan = self.below_plan(chains, need) if l == 1 else None
+                if plan is not None:
+                    gz, gb, dws = self.bwd_in(jobs, below=[(c["acts"][0], c["lins"][0], plan[j], need[j] or plan[j] > 0) for j, c in enumerate(chains)], sink=sink, tag=0)
+                    for j, c in enumerate(chains):
+                        if sink is None:
+                            c["lins"][0].bias.grad = gb[j]
+                        else:
+                            sink[(0, "b")] = gb[j]
+                    wide = [j for j in range(len(chains)) if plan[j] > 0]
+                    if wide:
+                        self.wgrad([(gz[j], chains[j]["acts"][0], chains[j]["lins"][0]) for j in wide], lead=[(plan[j], dws[j]) for j in wide])
+                    return [g if nd else None for g, nd in zip(gz, need)]
+                gz, gb = self.bwd_in(jobs)
         return gz
 
     def finish(self):
         from ..._nn import Go2nnSumJob
         for k in range(0, len(self.sums), 32):
             chunk = self.sums[k:k + 32]
-            arr = (Go2nnSumJob * len(chunk))(*[Go2nnSumJob(t[0].data_ptr(), t[1].data_ptr(), t[2], t[3], t[4].data_ptr() if len(t) > 4 and t[4] is not None else None,
-                                                           t[5] if len(t) > 4 and t[4] is not None else 0, 0) for t in chunk])
+            arr = (Go2nnSumJob * len(chunk))()
+            for i, t in enumerate(chunk):          # (part, out, rows, columns[, acc, nacc[, (byte offset into out, out_w, out_ld)]])
+                acc = t[4] if len(t) > 4 else None
+                off, ow, old = t[6] if len(t) > 6 else (0, 0, 0)
+                arr[i] = Go2nnSumJob(t[0].data_ptr(), t[1].data_ptr() + off, t[2], t[3], acc.data_ptr() if acc is not None else None, t[5] if acc is not None else 0, 0, ow, old)
             self.check(self.nn.go2nn_sum_rows(arr, len(chunk), self.stream), "go2nn_sum_rows")
         self.sums = []
-
-
 
 
 def _narrow(N, K):
@@ -262,11 +329,11 @@ class _FusedMLP(torch.autograd.Function):
             _check(_NN.go2nn_head_backward(p(gout), p(y), p(w_out), p(gz), None, p(wk), B, Cn, K, k.stream), "go2nn_head_backward", _NN)
             k.sums.append((wk, sums, _NN.go2nn_head_backward_rows(B, Cn, K), (Cn + 1) * K + Cn))
             grads[(H, "w")], grads[(H, "b")] = sums[:Cn * K].view(Cn, K), sums[(Cn + 1) * K:]
-            gz0 = k.chain_backward([{"lins": lins[:H], "acts": acts, "gz": gz, "gb": sums[Cn * K:(Cn + 1) * K], "imgs": ctx.imgs}], sink=grads)
+            gz0 = k.chain_backward([{"lins": lins[:H], "acts": acts, "gz": gz, "gb": sums[Cn * K:(Cn + 1) * K], "imgs": ctx.imgs}], sink=grads, need_gz0=ctx.needs_input_grad[0])
         else:
             gb = k.new(gout.shape[1])
             k.sums.append((gout, gb, B, gout.shape[1]))          # the output layer's bias gradient: column sums of gout (go2nn_sum_rows' tall shape)
-            gz0 = k.chain_backward([{"lins": lins, "acts": acts, "gz": gout, "gb": gb, "imgs": ctx.imgs}], sink=grads)
+            gz0 = k.chain_backward([{"lins": lins, "acts": acts, "gz": gout, "gb": gb, "imgs": ctx.imgs}], sink=grads, need_gz0=ctx.needs_input_grad[0])
         gx = _input_grad(k, gz0[0], lins[0], ctx.imgs[0]) if ctx.needs_input_grad[0] else None
         k.finish()
         out = []
@@ -307,7 +374,7 @@ class _FusedChain(torch.autograd.Function):
             raise RuntimeError("go2sim_elu_backward_bias failed: %s" % _LIB.go2sim_last_error().decode())
         lins = [_LinearView(w, None) for w in ws]
         grads = {}
-        gz0 = k.chain_backward([{"lins": lins, "acts": acts, "gz": gz, "gb": gb, "imgs": ctx.imgs}], sink=grads)
+        gz0 = k.chain_backward([{"lins": lins, "acts": acts, "gz": gz, "gb": gb, "imgs": ctx.imgs}], sink=grads, need_gz0=ctx.needs_input_grad[0])
         gx = _input_grad(k, gz0[0], lins[0], ctx.imgs[0]) if ctx.needs_input_grad[0] else None
         k.finish()
         out = []
@@ -353,7 +420,7 @@ class _FusedChainHeads(torch.autograd.Function):
         gz, gb = k.bwd_in_blocks(do, w3, y, himgs)
         lins = [_LinearView(w, None) for w in ws]
         grads = {}
-        gz0 = k.chain_backward([{"lins": lins, "acts": acts, "gz": gz, "gb": gb, "imgs": ctx.imgs}], sink=grads)
+        gz0 = k.chain_backward([{"lins": lins, "acts": acts, "gz": gz, "gb": gb, "imgs": ctx.imgs}], sink=grads, need_gz0=ctx.needs_input_grad[0])
         gx = _input_grad(k, gz0[0], lins[0], ctx.imgs[0]) if ctx.needs_input_grad[0] else None
         k.finish()
         out = []
@@ -455,7 +522,7 @@ def ppo_pair_applicable(ac, xa, xc):
     return pl is not None and ac.std.dim() == 1 and ac.std.shape[0] == pl[0][-1].out_features and ac.std.requires_grad
 
 
-def pair_grads(k, la, lc, xa, xc, std, batch, clip, vcoef, ecoef, use_clipped_value_loss, surrogate_split=0, acc=None, imgs=None):
+def pair_grads(k, la, lc, xa, xc, std, batch, clip, vcoef, ecoef, use_clipped_value_loss, surrogate_split=0, acc=None, imgs=None, need_gz0=True):
     """Forward of two MLPs with grouped hidden layers, go2nn_ppo_heads, backward of the hidden layers; the reductions are queued on `k` (the caller finishes).
     batch: actions, old values, advantages, returns, old log-probs, old mu, old sigma.  imgs: (actor images, critic images) of the hidden layers when the caller split
     them together with other networks' weights.  Sets .grad of every parameter of both networks and of std.
@@ -491,7 +558,7 @@ def pair_grads(k, la, lc, xa, xc, std, batch, clip, vcoef, ecoef, use_clipped_va
     la[H].weight.grad, gb_a, la[H].bias.grad = tot[o:o + A * K].view(A, K), tot[o + A * K:o + (A + 1) * K], tot[o + (A + 1) * K:o + (A + 1) * K + A]
     o += (A + 1) * K + A
     lc[H].weight.grad, gb_c, lc[H].bias.grad = tot[o:o + K].view(1, K), tot[o + K:o + 2 * K], tot[o + 2 * K:o + 2 * K + 1]
-    gz1 = k.chain_backward([{"lins": la[:H], "acts": acts[0], "gz": gz[0], "gb": gb_a, "imgs": ia}, {"lins": lc[:H], "acts": acts[1], "gz": gz[1], "gb": gb_c, "imgs": ic}])
+    gz1 = k.chain_backward([{"lins": la[:H], "acts": acts[0], "gz": gz[0], "gb": gb_a, "imgs": ia}, {"lins": lc[:H], "acts": acts[1], "gz": gz[1], "gb": gb_c, "imgs": ic}], need_gz0=need_gz0)
     return tot, gz1
 
 
@@ -502,6 +569,6 @@ def ppo_pair_grads(ac, xa, xc, actions, old_values, adv, returns, old_logp, old_
     la, lc = pair_lins(ac.actor, ac.critic)
     k = _Launch(xa.device)
     with torch.no_grad():
-        tot, _ = pair_grads(k, la, lc, xa, xc, ac.std, (actions, old_values, adv, returns, old_logp, old_mu, old_sigma), clip, vcoef, ecoef, use_clipped_value_loss, 0, acc)
+        tot, _ = pair_grads(k, la, lc, xa, xc, ac.std, (actions, old_values, adv, returns, old_logp, old_mu, old_sigma), clip, vcoef, ecoef, use_clipped_value_loss, 0, acc, need_gz0=False)
         k.finish()
     return tot[:4]

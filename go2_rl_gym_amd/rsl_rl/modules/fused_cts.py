@@ -137,7 +137,7 @@ def cts_policy_grads(plan, model, ain, cin, priv_t, batch, n_t, clip, vcoef, eco
         dz, zpart, gb_z = k.new(n_t, L), k.new(r * L), k.new(L)
         k.check(nn_.go2nn_l2norm_backward(_p(g_in), g_in.stride(0), _p(ain), ain.stride(0), _p(inv), _p(dz), _p(zpart), n_t, L, k.stream), "go2nn_l2norm_backward")
         k.sums.append((zpart, gb_z, r, L))
-        k.chain_backward([{"lins": te, "acts": eacts, "gz": dz, "gb": gb_z, "imgs": ie}])
+        k.chain_backward([{"lins": te, "acts": eacts, "gz": dz, "gb": gb_z, "imgs": ie}], need_gz0=False)
         k.finish()
     return tot[:4]
 
@@ -162,7 +162,7 @@ def cts_student_grads(plan, model, hist_s, priv_s, acc=None):
         dz, part, tot = k.new(n, L), k.new(r * (L + 4)), k.new(L + 4)          # [loss, 0, 0, 0 | the last bias gradient]
         k.check(nn_.go2nn_latent_mse(_p(sacts[-1]), _p(tx), _p(dz), _p(part), n, L, 1.0, k.stream), "go2nn_latent_mse")
         k.sums.append((part, tot, r, L + 4, acc, 1))
-        k.chain_backward([{"lins": st, "acts": sacts, "gz": dz, "gb": tot[4:], "imgs": is_}])
+        k.chain_backward([{"lins": st, "acts": sacts, "gz": dz, "gb": tot[4:], "imgs": is_}], need_gz0=False)
         k.finish()
     return tot[:1]
 

@@ -21,8 +21,9 @@
 extern "C" {
 #endif
 
-#define GO2NN_ABI_VERSION 5      /* 2: + the learner-side kernels (go2nn_head_backward, go2nn_linear_*); 3: + the grouped (actor + critic) layer calls; 4: + split-operand (3 x bf16) products;
-                                    5: + the CTS pieces: layers without activation, plain input gradients, the latent normaliser forward / backward, the split surrogate, two-segment policy inputs */
+#define GO2NN_ABI_VERSION 6      /* 2: + the learner-side kernels (go2nn_head_backward, go2nn_linear_*); 3: + the grouped (actor + critic) layer calls; 4: + split-operand (3 x bf16) products;
+                                    5: + the CTS pieces: layers without activation, plain input gradients, the latent normaliser forward / backward, the split surrogate, two-segment policy inputs;
+                                    6: + Go2nnBwdInJob.x_in: the weight gradient of the layer below out of the input gradient's epilogue (its gz_prev never goes to HBM) */
 #define GO2NN_MAX_LAYERS 6
 #define GO2NN_MAX_WIDTH 512      /* widest layer input / output (LDS holds two 32-row activation tiles of this width) */
 #define GO2NN_EINVAL (-22)
@@ -95,7 +96,9 @@ int go2nn_policy_act_latent(const Go2nnMlp* actor, const float* actor_packed, co
  * go2nn_head_backward (sums == NULL) and go2nn_linear_backward_input (gb_prev == NULL) then leave their per-workgroup partial rows in `workspace` —
  * go2nn_*_rows rows of (C + 1) K + C resp. Kin columns — and the caller finishes all of a backward pass's reductions (and the row splits of its
  * weight gradients) with one go2nn_sum_rows call, off the chain of dependent GEMMs. */
-typedef struct Go2nnSumJob { const float* part; float* out; int32_t nrows, ncols; float* acc; int32_t nacc, pad_; } Go2nnSumJob;      /* ABI 4: acc != NULL: acc[c] += out[c] for c < nacc (a running sum over launches, e.g. the update's mean losses) */
+typedef struct Go2nnSumJob { const float* part; float* out; int32_t nrows, ncols; float* acc; int32_t nacc, pad_; int32_t out_w, out_ld; } Go2nnSumJob;      /* ABI 4: acc != NULL: acc[c] += out[c] for c < nacc (a running sum over launches, e.g. the update's mean losses) */
+/* ABI 6: out_w > 0: the sums are a [ncols / out_w, out_w] matrix written with row pitch out_ld — a column block of a wider matrix (a weight gradient assembled from
+ * two launches' partials: Go2nnBwdInJob.x_in, Go2nnBwdWJob.ldx); 0: dense */
 #define GO2NN_MAX_SUM_JOBS 32      /* (ABI 5: was 16 — a CTS policy step finishes 19 reductions in one launch) */
 int go2nn_sum_rows(const Go2nnSumJob* jobs, int32_t njobs, void* stream);
 int32_t go2nn_head_backward_rows(int32_t B, int32_t C, int32_t K);
@@ -140,11 +143,22 @@ int go2nn_linear_backward_weight(const float* gz, const float* x, float* dw, flo
  *                       write the matching block of its gradient, ELU' and bias partials in the epilogue, with no transposing copy in between; the job's
  *                       workspace stays dense (rows x Kin) */
 typedef struct Go2nnFwdJob { const float *x, *w, *b; float* y; int32_t M, K, N; int32_t act; const void* w_split; } Go2nnFwdJob;
-typedef struct Go2nnBwdInJob { const float *gz, *w, *y_prev; float *gz_prev, *workspace; int32_t M, C, Kin; int32_t plain; const void* w_split; int32_t ld; } Go2nnBwdInJob;
-typedef struct Go2nnBwdWJob { const float *gz, *x; float* workspace; int32_t M, C, Kin; int32_t split; } Go2nnBwdWJob;
+ /* ABI 6 (appended fields; NULL / 0 keep the ABI 5 meaning).  Every job of a group alike; split-operand kernels only (w_split set), plain 0, ld 0.
+ *   Go2nnBwdInJob.x_in  the input x [M, Kx] (dense, 1 <= Kx <= 64) of the layer BELOW — the one whose ELU output is y_prev.  The job then ALSO leaves that layer's weight
+ *                       gradient  dW_prev [Kin, Kx] = gz_prev^T x_in  as go2nn_linear_backward_input_fused_rows(M) partial rows of Kin * Kx columns in `dw_workspace`
+ *                       (finished by go2nn_sum_rows), formed from the gz_prev tile while it is still in the accumulators: autograd's mm(gz_prev.t(), x) (ppo.py:173
+ *                       loss.backward() through the FIRST Linear of actor_critic.py:50-75) without gz_prev's round trip through HBM.  gz_prev may then be NULL (PPO: nothing
+ *                       else reads the gradient at the first layer's pre-activation); `workspace` keeps its meaning and its row count.
+ *   Go2nnBwdInJob.ldx   row pitch of x_in in floats, 0 = Kx: x_in may be a column block of a wider input — a 263-wide critic input leaves its last 7 columns' weight
+ *                       gradient here and its first 256 = two whole 128-column tiles to go2nn_linear_backward_weight_group (Go2nnBwdWJob.ldx), which would otherwise pad
+ *                       263 to 384 columns */
+typedef struct Go2nnBwdInJob { const float *gz, *w, *y_prev; float *gz_prev, *workspace; int32_t M, C, Kin; int32_t plain; const void* w_split; int32_t ld;
+                               int32_t Kx; const float* x_in; float* dw_workspace; int32_t ldx; } Go2nnBwdInJob;
+typedef struct Go2nnBwdWJob { const float *gz, *x; float* workspace; int32_t M, C, Kin; int32_t split; int32_t ldx; } Go2nnBwdWJob;      /* ABI 6: ldx = row pitch of x, 0 = Kin (split-operand kernel only) */
 int go2nn_linear_elu_forward_group(const Go2nnFwdJob* jobs, int32_t njobs, void* stream);
 int32_t go2nn_linear_backward_input_group_rows(int32_t M, int32_t C, int32_t Kin);
 int go2nn_linear_backward_input_group(const Go2nnBwdInJob* jobs, int32_t njobs, void* stream);
+int32_t go2nn_linear_backward_input_fused_rows(int32_t M);          /* ABI 6: partial rows of dw_workspace */
 int32_t go2nn_linear_backward_weight_group_rows(const Go2nnBwdWJob* jobs, int32_t njobs);
 int go2nn_linear_backward_weight_group(const Go2nnBwdWJob* jobs, int32_t njobs, void* stream);
 

@@ -91,6 +91,23 @@ def test_linear_group_split_operands_on_gpu(M, s0, s1):
         assert torch.equal(u, v)
 
 
+from test_mlp_tail import check_wgrad_below  # noqa: E402
+
+
+@pytest.mark.parametrize("M,s,kx0,kx1,keep_gz", [(24576, (256, 512), 45, 48, False), (24576, (256, 512), 45, 48, True), (6144, (256, 512), 48, 45, False), (70, (96, 40), 45, 48, True),
+                                                 (1000, (37, 70), 64, 7, False), (4099, (8, 33), 33, 32, True), (777, (64, 300), 1, 45, False), (128, (16, 128), 32, 64, False)])
+def test_wgrad_below_on_gpu(M, s, kx0, kx1, keep_gz):
+    """include/go2nn.h ABI 6: the first layer's weight gradient out of the second layer's input-gradient launch (the gradient at the first layer's pre-activation never
+    leaves the chip) at the update's shape (24576 x 256 -> 512, inputs 45 / 48 wide) and at ragged ones (rows that do not fill a tile, Kx = 1 / 7 / 32 / 33 / 64, ragged
+    contraction, columns beyond the last tile); against float64 within the bounds of the separate launches; bit-reproducible from launch to launch"""
+    lib = _nn.load_nn()
+    a = check_wgrad_below(lib, M, s, kx0, kx1, keep_gz, device="cuda:0")
+    b = check_wgrad_below(lib, M, s, kx0, kx1, keep_gz, device="cuda:0")
+    torch.cuda.synchronize()
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
 @pytest.mark.parametrize("M,s0,s1", [(6144, (512, 256), (512, 256)), (6144, (256, 128), (256, 128)), (3072, (45, 512), (263, 512))])
 def test_split_operand_error_is_the_fp32_kernels_error(M, s0, s1):
     """What "same float64 error" means, as numbers.  On the same inputs the rms deviation from the float64 result of every PRODUCT (forward, input gradient, weight

@@ -298,6 +298,73 @@ def test_linear_group_matches_torch(M, s0, s1):
     check_linear_group(load_nn_emu(), M, s0, s1, split=True)          # (the host build reads the fp32 weights: the call path and the struct layout)
 
 
+# ---- ABI 6: the weight gradient of the layer below out of the input gradient's epilogue (Go2nnBwdInJob.x_in; go2_rl_gym_amd/csrc/go2nn_bx3.h EPI_DELU_WG) -----------
+BELOW_SHAPES = [(70, (96, 40), 45, 48, True), (130, (37, 70), 64, 7, False), (257, (8, 33), 33, 32, True), (128, (64, 128), 1, 45, False)]      # M, (C, Kin), Kx job 0, Kx job 1, also store gz_prev
+
+
+def check_wgrad_below(lib, M, s, kx0, kx1, keep_gz, device="cpu"):
+    """two jobs of one input-gradient launch that also leave dW_below = gz_prev^T x_in: against float64 torch, bounds of check_linear_group; gz_prev optional"""
+    from go2_rl_gym_amd._nn import Go2nnBwdInJob, Go2nnSplitJob, Go2nnSumJob
+    C_, Kin = s
+    g = torch.Generator().manual_seed(M * 5 + C_ * 3 + Kin + kx0)
+    nan = lambda *shape: torch.full(shape, float("nan"), device=device)
+    p = lambda t: t.data_ptr()
+    jobs = []
+    for kx in (kx0, kx1):
+        w = (torch.randn(C_, Kin, generator=g) / np.sqrt(C_)).to(device)
+        gz, yp = torch.randn(M, C_, generator=g).to(device), torch.nn.functional.elu(torch.randn(M, Kin, generator=g)).to(device)
+        xw = torch.randn(M, kx + (5 if len(jobs) else 0), generator=g).to(device)          # job 1: x_in is columns [3, 3 + kx) of a wider matrix (Go2nnBwdInJob.ldx)
+        x = xw[:, 3:3 + kx] if len(jobs) else xw
+        n = lib.go2nn_split_weights_bytes(C_, Kin)
+        assert n > 0, lib.go2nn_last_error().decode()
+        jobs.append(dict(kx=kx, w=w, gz=gz, yp=yp, x=x, img=torch.full((int(n),), 0xff, dtype=torch.uint8, device=device), gzp=nan(M, Kin) if keep_gz else None, gbp=nan(Kin), dw=nan(Kin, kx)))
+    st = _stream(jobs[0]["x"])
+    sj = (Go2nnSplitJob * 2)(*[Go2nnSplitJob(p(j["w"]), p(j["img"]), C_, Kin) for j in jobs])
+    assert lib.go2nn_split_weights(sj, 2, st) == 0, lib.go2nn_last_error().decode()
+    ij, sums, keep = (Go2nnBwdInJob * 2)(), [], []
+    rows = lib.go2nn_linear_backward_input_fused_rows(M)
+    r = lib.go2nn_linear_backward_input_group_rows(M, C_, Kin)
+    assert rows > 0 and r > 0
+    for k, j in enumerate(jobs):
+        ws, dws = nan(r * Kin), nan(rows * Kin * j["kx"]); keep += [ws, dws]
+        ij[k] = Go2nnBwdInJob(p(j["gz"]), p(j["w"]), p(j["yp"]), p(j["gzp"]) if keep_gz else None, p(ws), M, C_, Kin, 0, p(j["img"]), 0, j["kx"], p(j["x"]), p(dws), j["x"].stride(0) if k else 0)
+        sums += [(ws, j["gbp"], r, Kin), (dws, j["dw"], rows, Kin * j["kx"])]
+    assert lib.go2nn_linear_backward_input_group(ij, 2, st) == 0, lib.go2nn_last_error().decode()
+    arr = (Go2nnSumJob * len(sums))(*[Go2nnSumJob(t[0].data_ptr(), t[1].data_ptr(), t[2], t[3]) for t in sums])
+    assert lib.go2nn_sum_rows(arr, len(sums), st) == 0
+    out = []
+    for j in jobs:
+        yp = j["yp"]
+        r_gzp = j["gz"].double().mm(j["w"].double()) * torch.where(yp > 0, torch.ones_like(yp), yp + 1.0).double()
+        if keep_gz:
+            np.testing.assert_allclose(j["gzp"].cpu().double().numpy(), r_gzp.cpu().numpy(), atol=3e-6 * np.sqrt(C_) + 2e-6, rtol=2e-6)
+            out.append(j["gzp"])
+        np.testing.assert_allclose(j["gbp"].cpu().double().numpy(), r_gzp.sum(0).cpu().numpy(), atol=4e-6 * np.sqrt(M * C_) + 1e-5, rtol=2e-5)
+        np.testing.assert_allclose(j["dw"].cpu().double().numpy(), r_gzp.t().mm(j["x"].double()).cpu().numpy(), atol=4e-6 * np.sqrt(M * C_) + 1e-5, rtol=2e-5)
+        out += [j["gbp"], j["dw"]]
+    return out
+
+
+@pytest.mark.parametrize("M,s,kx0,kx1,keep_gz", BELOW_SHAPES)
+def test_wgrad_below_matches_torch(M, s, kx0, kx1, keep_gz):
+    check_wgrad_below(load_nn_emu(), M, s, kx0, kx1, keep_gz)
+
+
+def test_wgrad_below_refuses_bad_arguments():
+    from go2_rl_gym_amd._nn import Go2nnBwdInJob
+    lib = load_nn_emu()
+    t = torch.zeros(4096)
+    p = t.data_ptr()
+    ok = lambda **kw: Go2nnBwdInJob(**{**dict(gz=p, w=p, y_prev=p, gz_prev=None, workspace=p, M=8, C=8, Kin=8, plain=0, w_split=p, ld=0, Kx=4, x_in=p, dw_workspace=p), **kw})
+    one = lambda j: lib.go2nn_linear_backward_input_group((Go2nnBwdInJob * 1)(j), 1, None)
+    assert one(ok()) == 0
+    for bad in (dict(Kx=65), dict(Kx=0), dict(dw_workspace=None), dict(w_split=None), dict(plain=1), dict(ld=16)):
+        assert one(ok(**bad)) < 0, bad
+    assert lib.go2nn_linear_backward_input_group((Go2nnBwdInJob * 2)(ok(), ok(x_in=None, gz_prev=p)), 2, None) < 0          # x_in on every job or on none
+    assert one(ok(x_in=None)) < 0          # no gz_prev without x_in
+    assert lib.go2nn_linear_backward_input_fused_rows(0) < 0
+
+
 def test_group_calls_refuse_bad_arguments():
     from go2_rl_gym_amd._nn import Go2nnBwdWJob, Go2nnFwdJob
     lib = load_nn_emu()
