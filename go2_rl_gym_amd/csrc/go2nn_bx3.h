@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
   const int bm = t / g.nbn, bn = t - bm * g.nbn;
   const int row0 = bm * BM, col0 = bn * BN;
   const int nk = WG ? (ga.wg_rows + BK - 1) / BK : g.nkt;
-  const int m0 = slice * ga.wg_rows, mend = min(ga.wg_M, m0 + ga.wg_rows);          // (weight-gradient mode)
+  const int m0 = slice * ga.wg_rows;          // (weight-gradient mode: first row of the slice)
   float* const Cout = g.C + (WG ? (size_t)slice * g.M * g.N : 0);
 
 #ifdef GM3_STAMPS
@@ -181,27 +181,40 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
   // A: DA staging sets — the loads of tile kt + DA are issued at the top of tile kt (HBM latency); B: one set (L2 hits: re-issued as soon as it is committed)
   constexpr int DA = BX3_DA(TM);
   f32x4 ba[DA][WG ? 4 : SA::P]; u32x4 bb[3];          // (weight-gradient mode: a set is 8 values of G's column and 8 of X's)
-  // weight-gradient staging: thread -> (column tid % 128 of the tile, contraction half tid / 128)
+  // weight-gradient staging: thread -> (column tid % 128 of the tile, contraction half tid / 128).  Buffer loads (round 6): the descriptor of a k-tile starts at its
+  // first row and ends with the matrix, so rows beyond M read as zero and a column beyond Kin gets an offset that is out of range — no clamps, no selects, and the
+  // per-lane offsets of the 8 rows are loop invariants (the address arithmetic and the edge masks were half of the kernel's 6.3 VALU instructions per MFMA)
   const int scol = tid & 127, skg = tid >> 7;
-  const float* const wg_a = g.A + min(row0 + scol, g.M - 1);                              // G [rows][C]: output row = column of G
-  const float* const wg_b = WG ? g.Bf + min(col0 + scol, g.N - 1) : nullptr;              // X [rows][Kin]
+  unsigned voa[WG ? 8 : 1], vob[WG ? 8 : 1];
+  if constexpr (WG) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      voa[j] = (unsigned)(((skg * 8 + j) * g.lda + row0 + scol) * 4);                                        // G [rows][C]: output row = column of G (C in whole tiles)
+      vob[j] = col0 + scol < g.N ? (unsigned)(((skg * 8 + j) * g.ldb + col0 + scol) * 4) : 0x7ffffff0u;      // X [rows][Kin]
+    }
+  }
+  auto wg_rsrc = [&](const float* base, int ld, int mrow) __attribute__((always_inline)) {
+    const long long left = (long long)(ga.wg_M - mrow) * ld * 4;
+    const float* p0 = base + (size_t)mrow * ld;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)p0), hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)p0 >> 32));
+    const unsigned nb = __builtin_amdgcn_readfirstlane(left > 0 ? (unsigned)(left < 0x7fffffe0ll ? left : 0x7fffffe0ll) : 0u);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uintptr_t)hi << 32) | lo), 0, nb, 0x00020000);
+  };
   auto issue_wg = [&](int kt, f32x4 (&w)[WG ? 4 : SA::P]) __attribute__((always_inline)) {
     if constexpr (WG) {
+      const int mrow = m0 + kt * BK;
+      const auto ra = wg_rsrc(g.A, g.lda, mrow), rb = wg_rsrc(g.Bf, g.ldb, mrow);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const size_t m = (size_t)gm_opaque(min(m0 + kt * BK + skg * 8 + j, ga.wg_M - 1));
-        w[j >> 2][j & 3] = wg_a[m * g.lda]; w[2 + (j >> 2)][j & 3] = wg_b[m * g.ldb];
+        w[j >> 2][j & 3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, voa[j], 0, 0));
+        w[2 + (j >> 2)][j & 3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, vob[j], 0, 0));
       }
     }
   };
   auto commit_wg = [&](int stage, int kt, const f32x4 (&w)[WG ? 4 : SA::P]) __attribute__((always_inline)) {
     if constexpr (WG) {
       unsigned char* st = lds + stage * STAGE + scol * 32 + ((skg ^ ((scol >> 3) & 1)) << 4);
-      f32x4 a0 = w[0], a1 = w[1];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {          // rows beyond the slice contribute nothing: zero on G's side
-        a0[j] = m0 + kt * BK + skg * 8 + j < mend ? a0[j] : 0.f; a1[j] = m0 + kt * BK + skg * 8 + 4 + j < mend ? a1[j] : 0.f;
-      }
+      const f32x4 a0 = w[0], a1 = w[1];          // (rows beyond M were read as zero; a slice is whole k-tiles, so the loop never reaches into the next one)
       u32x2 h0, m0_, l0, h1, m1, l1;
       bx3_split4(a0, h0, m0_, l0); bx3_split4(a1, h1, m1, l1);
       *reinterpret_cast<u32x4*>(st) = u32x4{h0[0], h0[1], h1[0], h1[1]};
