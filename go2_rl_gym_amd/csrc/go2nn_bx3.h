@@ -90,6 +90,7 @@ __global__ void __launch_bounds__(256) go2nn_bx3_split_kernel(const Bx3SplitArgs
   *reinterpret_cast<u32x4*>(img + 8192) = u32x4{l0[0], l0[1], l1[0], l1[1]};
 }
 
+__device__ __forceinline__ int lane_pos_x(int i, int gk) { return i * 2 + gk; }          // EPI_DELU_WG: position of lane (i, gk)'s 16 bytes inside a 1 KB fragment block of X
 // ---- forward / input gradient ---------------------------------------------------------------------------------------------------------------------------
 // k-tiles of 16 (one MFMA k-block), two LDS stages, two staging register sets (the loads of tile kt + 2 are issued at the top of tile kt).  One k-tile, per wave:
 //     top      global loads of tile kt + 2
@@ -177,6 +178,22 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
     }
   };
 
+  // EPI_DELU_WG: the input x [128 rows of the workgroup][kx] of the layer below, 8 rows at one column per thread and 32-row tile (the epilogue's B fragments)
+  const int kx = EPI == EPI_DELU_WG ? g.kx : 0;
+  const bool two = kx > 32;
+  const int xj = tid & 31, xjt = (tid >> 5) & 1, xhk = (tid >> 6) & 1, xkb = tid >> 7;
+  float xv[EPI == EPI_DELU_WG ? 4 : 1][8];
+  auto issue_xv = [&]() __attribute__((always_inline)) {
+    if constexpr (EPI == EPI_DELU_WG) {
+      if (xjt == 0 || two) {
+        const float* const xq = g.Bf + min(xjt * 32 + xj, kx - 1);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xv[rt][e] = xq[(size_t)gm_opaque(min(row0 + rt * 32 + 16 * xkb + (e & 3) + 8 * (e >> 2) + 4 * xhk, g.M - 1)) * g.ldb];
+      }
+    }
+  };
   SA sa; sa.init(g.A, g.lda, row0, g.M, WG ? 4 : g.K, tid);
   // A: DA staging sets — the loads of tile kt + DA are issued at the top of tile kt (HBM latency); B: one set (L2 hits: re-issued as soon as it is committed)
   constexpr int DA = BX3_DA(TM);
@@ -333,6 +350,7 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
       if constexpr (WG) issue_wg(min(D_, nkp - 1), ba[D_]); else sa.issue(min(D_, nkp - 1) * BK, ba[D_]); });
     // (BEHIND the first tiles' loads: vmcnt counts in order, in front of them the Y loads stood between the first tile and its commit — prologue 9.6 k instead of 4.9 k ticks)
     if constexpr (TM == 2) load_y(G3Int<0>{});          // (64-row tiles: 32 more registers would cost the third workgroup per CU; 192-row tiles have none to spare)
+    issue_xv();
     if constexpr (WG) commit_wg(0, 0, ba[0]); else commit(I0, 0, 0, ba[0]);
     if (nkp > 1) issue_b(1);
     __syncthreads();
@@ -343,6 +361,7 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
     for (int kt = 0; kt < nkp; kt += G)
       g3_for<0, G>([&](auto j_c) __attribute__((always_inline)) { constexpr int J = decltype(j_c)::value; if (kt + J < nkp) tile(G3Int<J & 1>{}, G3Int<J % DA>{}, kt + J + 1 < nkp, kt + J); });
   } else if constexpr (TM == 2) {
+    issue_xv();
     load_y(G3Int<0>{});          // (a contraction shorter than one k-tile — the 8-wide latent of the toy CTS networks — has no pipelined loop: the first slab's ELU outputs are requested here.
   }                              //  Round 5: found by the CTS student step at K = 8, where the slab was read uninitialised)
   if constexpr (!WG) if (ragged) {
@@ -364,40 +383,40 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
     // 32-row tile a, column i of its 32-column tile b), its column sums, and the weight gradient of the layer below  dWp [N, kx] = Gp^T X  of the workgroup's 128 rows:
     // with the contraction index = the row, a lane's accumulator registers 8 kb .. 8 kb + 7 ARE an A fragment of v_mfma_f32_32x32x16_bf16 (m = column i of Gp, the lane's
     // 8 k values = rows {0..3, 8..11} + 4 gk + 16 kb — the order inside a contraction is free as long as X is gathered in the same one).  Gp goes to HBM only if C is set.
+#if defined(GM3_STAMPS) && defined(WG_T3)          /* tools only: G3_T(3) / G3_T(5) at phase points WG_T3 / WG_T5 of this epilogue (1: X in LDS, 2: ELU' + sums + stores issued, 3: MFMAs done) */
+#define WG_STAMP(n) do { if (WG_T3 == (n)) G3_T(3); if (WG_T5 == (n)) G3_T(5); } while (0)
+#else
+#define WG_STAMP(n) do { } while (0)
+#endif
     const int rw = row0 + wm * 64, cw = col0 + wn * 64;
-    const int kx = g.kx;
-    const bool two = kx > 32;
-    float xv[2][2][8];
-    auto issue_x = [&](auto q_c, float (&x)[2][8]) __attribute__((always_inline)) {
-      constexpr int A_ = decltype(q_c)::value >> 1, KB = decltype(q_c)::value & 1;
+    // X [128 rows of the workgroup][kx] -> LDS as B fragments, once per workgroup (the loop's stages are free: the barrier above): item = (32-row tile rt, k-block kb,
+    // row half hk, column tile jt, column j) = the 8 rows {0..3, 8..11} + 4 hk + 16 kb of tile rt at one column = 16 bytes per plane at
+    //   [plane][rt][kb][jt][j][hk]  — a wave's fragment read (lane (i, gk) -> j = i, hk = gk) is 1 KB contiguous.  Thread -> (j, jt, hk, kb) = bits of tid, rt = 0 .. 3.
+    // X's loads were issued in front of the k-loop (issue_xv: mostly L2 hits — the four column tiles of a row tile read the same rows); the ELU outputs Y of both
+    // 32-row tiles are requested here, all before the first use: ONE exposed latency.
+    const bool xon = xjt == 0 || two;
+    float y[2][2][16];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float* q = g.Bf + (size_t)gm_opaque(min(rw + A_ * 32 + 16 * KB + (e & 3) + 8 * (e >> 2) + 4 * gk, g.M - 1)) * g.ldb;
-        x[0][e] = q[min(i, kx - 1)];
-        if (two) x[1][e] = q[min(32 + i, kx - 1)];
-      }
-    };
-    issue_x(G3Int<0>{}, xv[0]);
-    float cs[2] = {0.f, 0.f};
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      float y[2][16];
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float* q = g.Y + (size_t)gm_opaque(min(rw + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * gk, g.M - 1)) * g.ldc;
 #pragma unroll
-        for (int b = 0; b < 2; ++b) y[b][r] = q[min(cw + b * 32 + i, g.N - 1)];
+        for (int b = 0; b < 2; ++b) y[a][b][r] = q[min(cw + b * 32 + i, g.N - 1)];
       }
+    WG_STAMP(1);
+    float cs[2] = {0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const bool in = rw + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * gk < g.M;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          const float v = gm_keep(acc[a][b][r] * (y[b][r] > 0.f ? 1.f : y[b][r] + 1.f), in);
+          const float v = gm_keep(acc[a][b][r] * (y[a][b][r] > 0.f ? 1.f : y[a][b][r] + 1.f), in);
           acc[a][b][r] = v; cs[b] += v;
         }
       }
-    }
     // column sums: one partial row per 64 data rows = this wave's rows (the other row half gk is the lane 32 away)
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -405,16 +424,44 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
       const int c = cw + b * 32 + i;
       if (gk == 0 && c < g.N && (bm * 2 + wm) * 64 < g.M) g.part[(size_t)(bm * 2 + wm) * g.N + c] = t2;
     }
-    if (g.C) {
+    if (g.C) {          // (workgroup-uniform) Gp is wanted in HBM too: every wave turns its tiles, 32 rows at a time, through its LDS quarter for 16-byte row stores (the plain epilogue's way)
+      float* wl = reinterpret_cast<float*>(lds) + wave * (32 * CT);
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < 2; ++a) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rw + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * gk;
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-          for (int b = 0; b < 2; ++b) { const int c = cw + b * 32 + i; if (row < g.M && c < g.N) g.C[(size_t)row * g.ldc + c] = acc[a][b][r]; }
+          for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * gk, cc = b * 32 + i;
+            wl[row * CT + (cc ^ (gk << 5 & (CT - 1)))] = acc[a][b][r];
+          }
+#pragma unroll
+        for (int n = 0; n < NI; ++n) {
+          const int lrow = lr + n * RPI, row = rw + a * 32 + lrow;
+          const float4 v = *reinterpret_cast<const float4*>(wl + lrow * CT + (lc ^ ((lrow >> 2 & 1) << 5 & (CT - 1))));
+          if (row < g.M) {
+            float* o = g.C + (size_t)row * g.ldc + col;
+            if (cv) *reinterpret_cast<float4*>(o) = v;
+            else { if (col < g.N) o[0] = v.x; if (col + 1 < g.N) o[1] = v.y; if (col + 2 < g.N) o[2] = v.z; if (col + 3 < g.N) o[3] = v.w; }
+          }
         }
+      }
+      __syncthreads();          // the quarters are read: X's fragments go to the same memory
     }
+    if (xon) {
+      const bool in = xjt * 32 + xj < kx;
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        u32x2 h0, m0_, l0, h1, m1, l1;
+        bx3_split4(f32x4{gm_keep(xv[rt][0], in), gm_keep(xv[rt][1], in), gm_keep(xv[rt][2], in), gm_keep(xv[rt][3], in)}, h0, m0_, l0);
+        bx3_split4(f32x4{gm_keep(xv[rt][4], in), gm_keep(xv[rt][5], in), gm_keep(xv[rt][6], in), gm_keep(xv[rt][7], in)}, h1, m1, l1);
+        unsigned char* d = lds + ((((rt * 2 + xkb) * 2 + xjt) * 32 + xj) * 2 + xhk) * 16;
+        *reinterpret_cast<u32x4*>(d) = u32x4{h0[0], h0[1], h1[0], h1[1]};
+        *reinterpret_cast<u32x4*>(d + 16384) = u32x4{m0_[0], m0_[1], m1[0], m1[1]};
+        *reinterpret_cast<u32x4*>(d + 32768) = u32x4{l0[0], l0[1], l1[0], l1[1]};
+      }
+    }
+    WG_STAMP(2);
     f32x16 o[2][2];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
@@ -422,10 +469,17 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
       for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[b][jt][r] = 0.f;
+    __syncthreads();          // X's fragments are in LDS
+    const unsigned xfrag = lbase + (unsigned)(lane_pos_x(i, gk) * 16);
     g3_for<0, 4>([&](auto q_c) __attribute__((always_inline)) {
       constexpr int Q = decltype(q_c)::value, A_ = Q >> 1, KB = Q & 1;
-      if constexpr (Q + 1 < 4) issue_x(G3Int<Q + 1>{}, xv[(Q + 1) & 1]);
       u32x4 gp[2][3], xp[2][3];
+      const unsigned xa = xfrag + (unsigned)((((wm * 2 + A_) * 2 + KB) * 2) * 1024);
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        if (jt == 1 && !two) break;
+        g3_for<0, 3>([&](auto p_c) __attribute__((always_inline)) { constexpr int P = decltype(p_c)::value; bx3_dsr128<P * 16384>(xp[jt][P], xa + jt * 1024); });
+      }
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         u32x2 h0, m0_, l0, h1, m1, l1;
@@ -433,16 +487,11 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
         bx3_split4(f32x4{acc[A_][b][8 * KB + 4], acc[A_][b][8 * KB + 5], acc[A_][b][8 * KB + 6], acc[A_][b][8 * KB + 7]}, h1, m1, l1);
         gp[b][0] = u32x4{h0[0], h0[1], h1[0], h1[1]}; gp[b][1] = u32x4{m0_[0], m0_[1], m1[0], m1[1]}; gp[b][2] = u32x4{l0[0], l0[1], l1[0], l1[1]};
       }
+      g3_wait_lgkm<0>();
 #pragma unroll
-      for (int jt = 0; jt < 2; ++jt) {
-        if (jt == 1 && !two) break;
-        const float (&x)[8] = xv[Q & 1][jt];
-        const bool in = jt * 32 + i < kx;
-        u32x2 h0, m0_, l0, h1, m1, l1;
-        bx3_split4(f32x4{gm_keep(x[0], in), gm_keep(x[1], in), gm_keep(x[2], in), gm_keep(x[3], in)}, h0, m0_, l0);
-        bx3_split4(f32x4{gm_keep(x[4], in), gm_keep(x[5], in), gm_keep(x[6], in), gm_keep(x[7], in)}, h1, m1, l1);
-        xp[jt][0] = u32x4{h0[0], h0[1], h1[0], h1[1]}; xp[jt][1] = u32x4{m0_[0], m0_[1], m1[0], m1[1]}; xp[jt][2] = u32x4{l0[0], l0[1], l1[0], l1[1]};
-      }
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) g3_opaque(xp[jt][p]);
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};          // the six terms of the main loop, small ones first (0 hi, 1 mid, 2 lo)
 #pragma unroll
       for (int t6 = 0; t6 < 6; ++t6)
@@ -454,6 +503,8 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
             o[b][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, gp[b][PA[t6]]), __builtin_bit_cast(bf16x8, xp[jt][PB[t6]]), o[b][jt], 0, 0, 0);
           }
     });
+    WG_STAMP(3);
+    __syncthreads();          // every wave is done with X's fragments: the exchange below reuses the memory
     // the two row halves of the workgroup (waves wm = 0, 1) are added through LDS (fixed order), then ONE partial tile [128 columns of Gp][kx] per workgroup
     float* ex = reinterpret_cast<float*>(lds) + wn * (64 * 64);
     if (wm == 1) {
@@ -543,7 +594,7 @@ __global__ void __launch_bounds__(256, 2) go2nn_bx3_kernel(const Bx3Args ga) {
   }
 #ifdef GM3_STAMPS
   G3_T(4);
-  if (ga.stamps && (tid & 63) == 0) { long long* o = ga.stamps + ((size_t)blockIdx.x * 4 + wave) * 8; o[0] = st_[0]; o[1] = st_[1]; o[2] = st_[2]; o[3] = st_[3]; o[4] = st_[4]; o[5] = wall_clock64(); o[6] = wall0_; }
+  if (ga.stamps && (tid & 63) == 0) { long long* o = ga.stamps + ((size_t)blockIdx.x * 4 + wave) * 8; o[0] = st_[0]; o[1] = st_[1]; o[2] = st_[2]; o[3] = st_[3]; o[4] = st_[4]; o[5] = wall_clock64(); o[6] = wall0_; o[7] = st_[5]; }
 #endif
 }
 #endif  // !GO2_EMU

@@ -192,16 +192,22 @@ int main(int argc, char** argv) {
     }
     const int wrows = L.bw_g_rows(wj, 2);
     for (int j = 0; j < 2; ++j) { ly[j].ws_w.alloc((size_t)wrows * ly[j].N * ly[j].K, false); wj[j].workspace = ly[j].ws_w.d; }
+    Buf xin[2], dwk[2];          // BELOW=1 (round 6, ABI 6): the input gradient also leaves the weight gradient of the layer below (inputs 45 wide / the last 7 of 263 columns)
+    if (getenv("BELOW") && atoi(getenv("BELOW")) && kind == 'i') {
+      const int kx[2] = {45, 7}, ld[2] = {45, 263};
+      for (int j = 0; j < 2; ++j) { xin[j].alloc((size_t)M * ld[j]); dwk[j].alloc((size_t)((M + 127) / 128) * ly[j].K * kx[j], false);
+        ij[j].Kx = kx[j]; ij[j].x_in = xin[j].d + (ld[j] - kx[j]); ij[j].dw_workspace = dwk[j].d; ij[j].ldx = ld[j]; if (j == 0) ij[j].gz_prev = nullptr; }
+    }
     for (int it = 0; it < iters; ++it) { if (kind == 'f') L.fwd_g(fj, 2, nullptr); else if (kind == 'i') L.bin_g(ij, 2, nullptr); else L.bw_g(wj, 2, nullptr); }
     CK(hipDeviceSynchronize());
     typedef void (*stamps_fn)(long long*);
     stamps_fn setst = (stamps_fn)dlsym(L.h, "go2nn_debug_gemm3_stamps");
-    if (setst && kind != 'w') {      // -DGM3_STAMPS build: per-wave shader-clock stamps of one more launch
+    if (setst) {      // -DGM3_STAMPS build: per-wave shader-clock stamps of one more launch
       const int njobs = argc > 7 ? atoi(argv[7]) : 2;
       const size_t nwg = 16384; long long* d; CK(hipMalloc(&d, nwg * 4 * 8 * 8)); CK(hipMemset(d, 0, nwg * 4 * 8 * 8));
       if (getenv("G3_COLD") && atoi(getenv("G3_COLD"))) { if (!g_flush) CK(hipMalloc(&g_flush, 640u << 20)); CK(hipMemsetAsync(g_flush, 1, 640u << 20, nullptr)); }
       setst(d);
-      if (kind == 'f') L.fwd_g(fj + (2 - njobs), njobs, nullptr); else L.bin_g(ij + (2 - njobs), njobs, nullptr);
+      if (kind == 'f') L.fwd_g(fj + (2 - njobs), njobs, nullptr); else if (kind == 'i') L.bin_g(ij + (2 - njobs), njobs, nullptr); else L.bw_g(wj, 2, nullptr);
       CK(hipDeviceSynchronize()); setst(nullptr);
       std::vector<long long> h(nwg * 4 * 8); CK(hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost));
       long long t0 = -1, wall0 = -1, wall1 = 0; size_t n = 0; double s_pro = 0, s_loop = 0, s_bar = 0, s_epi = 0, s_tot = 0; long long first_end = -1, last_end = 0, last_start = 0;
@@ -212,6 +218,8 @@ int main(int argc, char** argv) {
       std::sort(starts.begin(), starts.end()); std::sort(ends.begin(), ends.end());
       { double fsum = 0; size_t fn = 0; for (size_t w = 0; w < nwg * 4; ++w) { const long long* o = &h[w * 8]; if (!o[4] || !o[6] || o[5] <= o[6]) continue; fsum += (double)(o[4] - o[0]) / ((o[5] - o[6]) / 100.0); ++fn; }
         if (fn) printf("   shader clock over the waves' lifetimes: %.0f MHz (mean of %zu waves)\n", fsum / fn, fn); }
+      { double s5 = 0, s3 = 0; size_t n5 = 0; for (size_t w = 0; w < nwg * 4; ++w) { const long long* o = &h[w * 8]; if (!o[4] || !o[7]) continue; s5 += o[7] - o[2]; s3 += o[3] - o[2]; ++n5; }
+        if (n5) printf("   movable stamps (fused epilogue): loop end -> T3 %.0f, loop end -> T5 %.0f ticks (mean of %zu waves)\n", s3 / n5, s5 / n5, n5); }
       printf("stamps %c layer %d, %d job(s): %zu waves; per wave mean ticks: prologue %.0f, k-loop %.0f, barrier %.0f, epilogue %.0f, total %.0f\n", kind, layer, njobs, n, s_pro / n, s_loop / n, s_bar / n, s_epi / n, s_tot / n);
       printf("   wave starts p0/p50/p90/p100 = %lld / %lld / %lld / %lld ticks after the first; ends p0/p10/p50/p100 = %lld / %lld / %lld / %lld;  wall span of the end stamps %.2f us (100 MHz clock)\n",
              starts[0], starts[n / 2], starts[n * 9 / 10], starts[n - 1], ends[0], ends[n / 10], ends[n / 2], ends[n - 1], (wall1 - wall0) / 100.0);
