@@ -156,8 +156,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly (`python bench.py --gpus N`): become the launcher — one rank per GPU under torch.distributed.run, as the driver's own command line does;
+        # rank 0's JSON line is this process's stdout
+        import socket
+        import subprocess
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, stdout=_STDOUT, stderr=sys.stderr).returncode)
     if a.gpus > 1 and world != a.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, a.gpus, world))
+        raise SystemExit("--gpus %d under a launcher with WORLD_SIZE=%d: start it with --nproc-per-node %d (or plainly: bench.py launches its own ranks)" % (a.gpus, world, a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product has no CPU path)")
     backend = os.environ.get("GO2_DIST_BACKEND", "nccl")

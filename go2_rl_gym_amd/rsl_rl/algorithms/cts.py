@@ -563,7 +563,10 @@ class CTS(_RolloutHeads):
 
     def graphs_captured(self):
         """True iff every policy / student mini-batch step is being replayed from a HIP graph."""
-        return bool(self.use_graphs and self._capture and all_captured(self._steps))
+        # (ADVICE r5: the update head and the teacher-latent step are `optional` CapturedSteps — a failed capture keeps them eager even under GO2_STRICT_GRAPHS — and
+        #  count here once they exist and had their warm-up calls)
+        heads = [h for h in (getattr(self, "_head_step", None), getattr(self, "_tlat_step", None)) if h is not None and h.calls > 0]          # (calls > 0: in use)
+        return bool(self.use_graphs and self._capture and all_captured(self._steps) and all(h.graph is not None for h in heads))
 
     def update(self):
         self._pk_packed = False          # the optimizer steps below change the parameters: the next rollout re-packs

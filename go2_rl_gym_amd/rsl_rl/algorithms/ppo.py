@@ -548,7 +548,10 @@ class PPO(_RolloutHeads):
     def graphs_captured(self):
         """True iff every mini-batch step of the update is being replayed from a HIP graph (bench.py reports it and refuses to quote a
         number from a silently degraded run)."""
-        return bool(self.use_graphs and self._capture and all_captured(self._graph))
+        # (ADVICE r5: the permutation step is a CapturedStep too — `optional`, a failed capture keeps it eager even under GO2_STRICT_GRAPHS — and counts here: a run
+        #  whose update replays but whose permutation fell back to ten eager launches does not report "update": true)
+        head = getattr(self, "_permute", None)
+        return bool(self.use_graphs and self._capture and all_captured(self._graph) and (head is None or head.calls == 0 or head.graph is not None))
 
     def update(self):
         self._pk_packed = False          # the optimizer steps below change the parameters: the next rollout re-packs

@@ -82,8 +82,11 @@ class ActorCriticCTS(nn.Module):
         self.history[dones > 0] = 0.0
 
     def load_state_dict(self, *a, **k):
-        self._history_dirty = True          # (whatever comes with a checkpoint: no assumption about the buffer)
-        return super().load_state_dict(*a, **k)
+        out = super().load_state_dict(*a, **k)
+        # whatever comes with a checkpoint: the buffer is looked at once (one host read at load time) — a training checkpoint carries zeros, and a resumed run then
+        # takes the same two launches per env step fewer that a fresh one does (resumed and fresh benchmarks differed silently)
+        self._history_dirty = bool(self.history.abs().sum().item() != 0.0)
+        return out
 
     def forward(self):
         raise NotImplementedError

@@ -401,7 +401,11 @@ class _FusedChainHeads(torch.autograd.Function):
         y = acts[-1]
         B, hid = y.shape[0], y.shape[1] // E
         w3 = hw.view(E, -1, hid)                                                        # [E, out, hidden]
-        outs = torch.bmm(y.view(B, E, hid).transpose(0, 1), w3.transpose(1, 2))         # [E, B, out]
+        wt, nout = w3.transpose(1, 2), w3.shape[1]
+        if nout < 32 and y.is_cuda:          # (a strided-batched product with fewer than 32 output columns is ~100x slower on ROCm 7 — GroupedHeads._heads pads too)
+            outs = torch.bmm(y.view(B, E, hid).transpose(0, 1), torch.nn.functional.pad(wt, (0, 32 - nout)))[..., :nout].contiguous()
+        else:
+            outs = torch.bmm(y.view(B, E, hid).transpose(0, 1), wt)         # [E, B, out]
         ctx.save_for_backward(*acts, *ws, hw)
         ctx.n, ctx.imgs, ctx.E = len(ws), imgs, E
         return outs

@@ -232,6 +232,13 @@ class OnPolicyRunner:
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
                 ev[0].record()
             with torch.inference_mode():
+                #  what the captured rollout contains was decided by host-side state at capture time: the CTS module's deployment-side history being
+                # all zeros lets process_env_step skip its reset.  If that flag has changed since (act_inference on the live runner, a checkpoint loaded), the graph
+                # is dropped and captured again from the next eager rollouts
+                sig = bool(getattr(getattr(self.alg, "model", None), "_history_dirty", False))
+                if self._rollout_graph is not None and sig != getattr(self, "_rollout_graph_sig", sig):
+                    self._rollout_graph, self._returns_graph, self._eager_rollouts = None, None, 0
+                self._rollout_graph_sig = sig
                 if self._rollout_graph is not None:
                     self._rollout_graph.replay()                       # 24 x (policy, env step kernel, storage) in ONE launch
                     self.env.lib.go2sim_notify_replayed(self.env.handle, T)

@@ -155,6 +155,51 @@ def test_one_iteration_matches_reference(kind, fixture, fused, monkeypatch, tmp_
     assert [len(x["params"]) for x in ck["optimizer2_state_dict"]["param_groups"]] == list(g["optimizer2_groups"])
 
 
+@pytest.mark.parametrize("kind,fixture", [("CTS", "cts_iteration.npz"), ("MoECTS", "moe_cts_iteration.npz")])
+def test_update_head_composes_teacher_first_and_advances_the_counter(kind, fixture, monkeypatch, tmp_path):
+    """The graph-mode update's HEAD on the host builds with torch.randperm left alone (the goldens above replace randperm, so they never reach
+    CTS._update_head): the keyed device-side permutation (go2sim_cts_minibatch_indices) under the algorithm's own key -> every mini-batch of the gathered rollout is
+    [teacher rows | student rows] (rollout_storage_cts.py:152-160), every sample is used exactly once, the gathered buffers are the storage's rows in that order, and
+    the key's counter advances by one per update (a second head draws another permutation)."""
+    from helpers import load_nn_emu
+    from go2_rl_gym_amd.rsl_rl.modules import fused as fmod
+    g = dict(np.load(os.path.join(G, fixture)))
+    T, N = g["rew"].shape
+    env = ScriptedEnv(g, load_oracle())
+    monkeypatch.setattr(fmod, "_LIB", load_oracle()); monkeypatch.setattr(fmod, "_NN", load_nn_emu())
+    torch.manual_seed(5)
+    runner = OnPolicyRunnerCTS(env, _train_cfg(kind, T), log_dir=str(tmp_path), device="cpu", use_graphs="uncaptured")
+    alg = runner.alg
+    alg.fused_loss = alg.fused_rollout = True
+    alg.nn_lib = load_nn_emu()
+    assert alg.use_graphs and alg._own_plan() is not None
+    heads = []
+    real_head = alg._update_head
+
+    def head():
+        real_head()
+        st = alg.storage
+        heads.append((alg._order.clone(), {k: alg._perm[k].clone() for k in ("ain", "act", "adv")}, {k: v.clone() for k, v in st.flat().items() if k in ("obs", "act", "adv")}))
+    alg._update_head = head
+    runner.writer = TagRecorder()
+    runner.learn(1, init_at_random_ep_len=False)
+    assert len(heads) == 1 and int(alg._shuffle_key[1]) == 1
+    order, perm, flat = heads[0]
+    nmb, n_t = alg.num_mini_batches, alg._teacher_rows()
+    mb = order.numel() // nmb
+    assert sorted(order.tolist()) == list(range(T * N))                                  # every sample once (nmb divides both populations in the fixture)
+    teacher = set(alg.teacher_env_idxs.tolist())
+    for i in range(nmb):
+        envs = (order[i * mb:(i + 1) * mb] % N).tolist()                                 # flattened [T, N] storage: index = t N + env
+        assert all(e in teacher for e in envs[:n_t]) and not any(e in teacher for e in envs[n_t:]), i
+    for k in ("act", "adv"):
+        np.testing.assert_array_equal(perm[k].reshape(order.numel(), -1).numpy(), flat[k][order].reshape(order.numel(), -1).numpy())
+    L = alg._plan.L
+    np.testing.assert_array_equal(perm["ain"][:, L:].numpy(), flat["obs"][order].numpy())          # (the observations land behind the latent's columns of the actor's input matrix)
+    alg._update_head()                                                                    # the next update's head: counter 2, another permutation
+    assert int(alg._shuffle_key[1]) == 2 and not torch.equal(heads[1][0], order) and sorted(heads[1][0].tolist()) == list(range(T * N))
+
+
 def test_history_ring_kernel_contract():
     """go2sim_history_push (oracle and the host build of the HIP source) == zero-on-done, shift, append (on_policy_runner_cts.py:155-156)."""
     rng = np.random.default_rng(0)

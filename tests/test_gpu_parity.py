@@ -304,16 +304,28 @@ def test_cts_kernels_on_gpu(hip):
     assert abs(np.abs(res["hip"][0][split:]).mean() / np.abs(res["hip"][0][:split]).mean() - 3.0) < 0.5
 
 
-@pytest.mark.parametrize("task", ["go2_flat_cts", "go2_cts", "go2_moe_cts", "go2_moe_ng_cts", "go2_ac_moe_cts", "go2_dual_moe_cts", "go2_mcp_cts"])
-def test_cts_training_graph_vs_eager_on_gpu(hip, task):
-    """CTS / MoE-CTS through the product path, HIP-graph mode against eager mode from the same seeds (the eager arithmetic is
-    pinned to the reference in tests/test_cts_golden.py)."""
+
+
+@pytest.mark.parametrize("task", ["go2_flat_cts", "go2_cts", "go2_moe_cts"])
+def test_cts_training_graph_vs_eager_on_gpu(hip, task, monkeypatch):
+    """CTS / MoE-CTS through the product path: HIP-graph mode (the no-autograd mini-batch steps, the keyed device-side permutation, the captured rollout) against eager
+    mode (autograd over the same kernels) fed the SAME mini-batch permutations and the SAME exploration noise, so the two runs differ by rounding only and the weights
+    after 5 iterations (100 policy + 100 student Adam steps) are held to a bound a dropped or reordered launch breaks by orders of magnitude:
+      * permutations: the eager arm's storage.mini_batch_indices asks go2sim_cts_minibatch_indices (the kernel graph mode's update head launches) under the key
+        graph mode derives from torch.manual_seed — same (seed, counter) sequence, so also a check of the counter's advance per update;
+      * noise: both arms' modules hand out rows of one pre-drawn [T, N, A] buffer, refilled from a CPU generator before every iteration (a static address: the
+        captured rollout reads the refreshed values on replay).
+    (Round 5 bounded the median weight gap of two differently-shuffled, differently-perturbed runs by 7e-3 — a statistic that could not tell an arithmetic change
+    from noise.)  The eager arithmetic is pinned to the reference in tests/test_cts_golden.py, graph mode's in tests/test_gpu_update_golden.py."""
+    import ctypes as C
     import torch
     from go2_rl_gym_amd.envs import task_registry  # noqa: F401
+    from go2_rl_gym_amd.rsl_rl.modules.actor_critic_cts import ActorCriticCTS
     from go2_rl_gym_amd.utils import get_args
+    N, ITERS = 512, 5
     out = {}
     for mode in (False, True):
-        args = get_args(["--task", task, "--num_envs", "512", "--headless", "--seed", "3"])
+        args = get_args(["--task", task, "--num_envs", str(N), "--headless", "--seed", "3"])
         env, _ = task_registry.make_env(task, args)
         torch.manual_seed(3)
         _, train_cfg = task_registry.get_cfgs(task)
@@ -323,24 +335,68 @@ def test_cts_training_graph_vs_eager_on_gpu(hip, task):
             runner, _ = task_registry.make_alg_runner(env, task, args, train_cfg=train_cfg, log_root=None, use_graphs=mode)
         finally:
             train_cfg.algorithm.schedule = sched0
-        assert runner.use_graphs == mode and runner.alg.use_graphs == mode and (runner.alg.fused_loss or task == "go2_mcp_cts")
+        alg = runner.alg
+        assert runner.use_graphs == mode and alg.use_graphs == mode and alg.fused_loss
+        T, A = alg.storage.num_transitions_per_env, alg.storage.actions.shape[-1]
+        gen, buf, calls = torch.Generator().manual_seed(17), torch.zeros(T, N, A, device=alg.device), [0]
+
+        def noise(self_, like, buf=buf, calls=calls, T=T):
+            row = buf[calls[0] % T]; calls[0] += 1
+            assert row.shape == like.shape
+            return row
+        monkeypatch.setattr(ActorCriticCTS, "_noise", noise)
+        if not mode:
+            st = alg.storage
+            key = torch.tensor([int((torch.initial_seed() * 0x9E3779B1 + 0x7F4A7C15) & 0x7FFFFFFF), 0, 0, 0], dtype=torch.int32, device=alg.device)          # _RolloutHeads._make_shuffle_key
+            order = torch.empty(N * T, dtype=torch.int64, device=alg.device)
+
+            def keyed(nmb, st=st, key=key, order=order, T=T):
+                nt, ns = st.teacher_num_envs * T, st.student_num_envs * T
+                rc = hip.go2sim_cts_minibatch_indices(C.c_void_p(order.data_ptr()), nmb, nt, ns, C.c_void_p(st.ref2mine.data_ptr()), C.c_void_p(key.data_ptr()),
+                                                      C.c_void_p(torch.cuda.current_stream(alg.device).cuda_stream))
+                assert rc == 0, hip.go2sim_last_error().decode()
+                rows = (nt // nmb + ns // nmb)
+                return [order[i * rows:(i + 1) * rows].clone() for i in range(nmb)]
+            st.mini_batch_indices = keyed
         env.common_step_counter = 0
-        runner.learn(5, init_at_random_ep_len=True)
+        first = None
+        for it in range(ITERS):
+            buf.copy_(torch.randn(buf.shape, generator=gen))
+            runner.learn(1, init_at_random_ep_len=(it == 0))
+            if it == 0:
+                first = {n: p.detach().cpu().numpy().copy() for n, p in alg.model.named_parameters()}
         torch.cuda.synchronize()
+        assert calls[0] % T == 0 and calls[0] >= T
         if mode:
-            assert runner._rollout_graph is not None and all(s.graph is not None for grp in runner.alg._steps for s in grp)
-        out[mode] = (runner.alg.learning_rate, torch.cat([p.detach().reshape(-1) for p in runner.alg.model.parameters()]).cpu().numpy(),
-                     env.common_step_counter, float(env.rew_buf.mean()), runner.history.abs().mean().item())
+            assert runner._rollout_graph is not None and all(s.graph is not None for grp in alg._steps for s in grp)
+            assert alg._head_step.graph is not None                                   # the keyed permutation + gather ran as a graph, not through the eager fall-back
+            assert int(alg._shuffle_key[1]) == ITERS                                   # one counter step per update
+        else:
+            assert int(key[1]) == ITERS
+        out[mode] = (alg.learning_rate, torch.cat([p.detach().reshape(-1) for p in alg.model.parameters()]).cpu().numpy(),
+                     env.common_step_counter, float(env.rew_buf.mean()), runner.history.abs().mean().item(), {n: p.detach().cpu().numpy().copy() for n, p in alg.model.named_parameters()}, first)
         env.close()
-    assert out[True][2] == out[False][2] == 5 * 24
+    assert out[True][2] == out[False][2] == ITERS * 24
     assert np.isfinite(out[True][1]).all() and out[True][4] > 0
     assert abs(out[True][0] - 1e-3) < 1e-9 and abs(out[False][0] - 1e-3) < 1e-9
     d = np.abs(out[True][1] - out[False][1])
-    # same data distribution, different noise AND different mini-batch permutations (graph mode: the keyed device-side shuffle; eager: torch.randperm): the weights stay
-    # close after 100 fixed-rate Adam steps of 1e-3 each (round 5: 5e-3 -> 7e-3, the MoE run measured 5.0e-3 once both the permutation and the noise differ; the
-    # ARITHMETIC of graph mode is pinned to the reference's by tests/test_gpu_update_golden.py, not here)
-    assert np.median(d) < 7e-3, np.median(d)
-    assert abs(out[True][3] - out[False][3]) < 0.05
+    print("[graph vs eager %s] weight gap median %.2e p99 %.2e max %.2e, reward %.4f / %.4f" % (task, np.median(d), np.quantile(d, 0.99), d.max(), out[True][3], out[False][3]))
+    # (1) after the FIRST iteration — same weights, same noise, same permutation, the same rollout kernels: the two arms have seen the same data, what differs is
+    # the update's formulation (explicit launches against autograd over the same GEMM kernels), i.e. summation orders.  20 + 20 Adam steps of 1e-3: a launch that is
+    # dropped, doubled or fed another mini-batch moves the weights it touches by ~1e-3 PER STEP; every parameter tensor is held on its own so that one layer's launch
+    # cannot hide among a million other weights.  (Graphs are not captured yet in iteration 1: the warm-up calls run the same launches through Python.)
+    per1 = {n: float(np.abs(out[True][6][n] - out[False][6][n]).max()) for n in out[True][6]}
+    print("   after iteration 1, largest gap per tensor: max %.1e (%s)" % (max(per1.values()), max(per1, key=per1.get)))
+    assert max(per1.values()) < (1e-3 if task == "go2_moe_cts" else 2e-4), per1          # measured: 5.5e-5 / 4.9e-5 / 2.9e-4 (the MoE student: softmax gate + load-balance term)
+    # (2) after 5 iterations (100 + 100 steps, the last three replayed from HIP graphs): the rounding differences have been fed back through the simulator for 120 env
+    # steps (contacts make the trajectories of the two arms drift apart: rough terrain more than the plane), so this bound is looser — measured (round 6) medians 1.4e-4
+    # (plane) / 6.3e-4 (rough) over all weights, 7e-4 / 2.7e-3 for the worst tensor; a replay that reads stale memory or skips a launch is off by 1e-2 and more
+    per = {n: float(np.median(np.abs(out[True][5][n] - out[False][5][n]))) for n in out[True][5]}
+    print("   after iteration %d, median gap per tensor: max %.1e (%s)" % (ITERS, max(per.values()), max(per, key=per.get)))
+    rough = task != "go2_flat_cts"
+    assert np.median(d) < (2e-3 if rough else 5e-4) and np.quantile(d, 0.99) < (2e-2 if rough else 6e-3), (np.median(d), np.quantile(d, 0.99), d.max())
+    assert max(per.values()) < (8e-3 if rough else 2.5e-3), per
+    assert abs(out[True][3] - out[False][3]) < 0.02
 
 
 @pytest.mark.parametrize("terrain", ["plane", "heightfield"])
@@ -755,8 +811,10 @@ def test_fused_clip_adam_matches_torch_on_gpu(hip):
     assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
 
 
-def test_two_rank_bench_rehearsal_on_one_gpu(hip):
-    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank), rehearsed on the ONE GPU of a test
+@pytest.mark.parametrize("launch", ["torchrun", "plain"])
+def test_two_rank_bench_rehearsal_on_one_gpu(hip, launch):
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank) and started PLAINLY (`python bench.py --gpus 2`: bench.py
+    then launches its own ranks — the driver's N = 1 command line has no launcher in front of it), rehearsed on the ONE GPU of a test
     box: GO2_DIST_BACKEND=gloo lets both ranks share cuda:0 (RCCL refuses two ranks on one device).  Exercises on the real library what a
     node would: env shards at env_offset 0 / N of 2N, the policy broadcast, the advantage-statistics all-reduce, the two captured halves of
     every mini-batch step with the eager gradient all-reduce between them, the barrier / MAX-over-ranks timing and the single JSON line."""
@@ -766,8 +824,10 @@ def test_two_rank_bench_rehearsal_on_one_gpu(hip):
     import sys
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, GO2_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "3", "--num-envs", "1024"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)] if launch == "torchrun" else [sys.executable]
+    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "3", "--num-envs", "1024"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
