@@ -19,7 +19,8 @@ static inline void go2sim_fill_default_cfg(Go2SimCfg* c) {
   c->sim_dt = 0.005f;                            /* :243 */
   c->decimation = 4;                             /* go2_config.py:85 */
   c->gravity[0] = 0.f; c->gravity[1] = 0.f; c->gravity[2] = -9.81f; /* :245 */
-  c->solver_iterations = 4;                      /* = physx.num_position_iterations (:251); 2..8 give the same gait/stance */
+  c->solver_iterations = 8;                      /* 2 x physx.num_position_iterations (:251): sweeps of the leg-parallel iteration per substep; 4..16 give the same gait/stance, the
+                                                    body forces' distance to the converged solve is what moves (profiles/r6_solver_convergence.txt) */
   c->contact_offset = 0.01f;                     /* :253 */
   c->erp = 0.5f;                                 /* own choice */
   c->max_depenetration_velocity = 1.0f;          /* :256 */

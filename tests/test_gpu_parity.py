@@ -121,7 +121,8 @@ def test_heightfield_one_step_parity_vs_oracle(hip, mesh_type):
         np.testing.assert_array_equal(np.asarray(so.terrain_levels), np.asarray(sd.terrain_levels))
         # the height scan is taken at the pose each library integrated to (1e-5 apart): a point within that of a cell boundary may read the
         # neighbouring cell; the index arithmetic itself is pinned bit-exactly by the golden sequences (test_golden_sequence_on_gpu)
-        assert (np.abs(np.asarray(so.measured_heights) - np.asarray(sd.measured_heights)) > 1e-6).sum() <= 2
+        # (<= 2 of the 14960 samples of a step until round 5; with 8 solver sweeps the two integrated poses are a little further apart — up to 4 samples seen)
+        assert (np.abs(np.asarray(so.measured_heights) - np.asarray(sd.measured_heights)) > 1e-6).sum() <= 6
     # a facet edge / stair face under a sphere makes the step ill-conditioned in fp32 for ANY evaluation order: the kernel's error stays
     # within 3x of the fp32 oracle's own error against the fp64 oracle on the same inputs (median, 99th percentile, far tail)
     check_relative_to_conditioning(err, cond, floors)
@@ -306,6 +307,9 @@ def test_cts_kernels_on_gpu(hip):
 
 
 
+GAP1_MED = 2e-6          # measured (round 6): 2.2e-8 / 1.1e-7 / 1.9e-8 — a tensor whose launch is dropped or fed other rows sits at ~1e-3 after one step
+
+
 @pytest.mark.parametrize("task", ["go2_flat_cts", "go2_cts", "go2_moe_cts"])
 def test_cts_training_graph_vs_eager_on_gpu(hip, task, monkeypatch):
     """CTS / MoE-CTS through the product path: HIP-graph mode (the no-autograd mini-batch steps, the keyed device-side permutation, the captured rollout) against eager
@@ -385,17 +389,19 @@ def test_cts_training_graph_vs_eager_on_gpu(hip, task, monkeypatch):
     # the update's formulation (explicit launches against autograd over the same GEMM kernels), i.e. summation orders.  20 + 20 Adam steps of 1e-3: a launch that is
     # dropped, doubled or fed another mini-batch moves the weights it touches by ~1e-3 PER STEP; every parameter tensor is held on its own so that one layer's launch
     # cannot hide among a million other weights.  (Graphs are not captured yet in iteration 1: the warm-up calls run the same launches through Python.)
+    # (Adam turns the SIGN of a near-zero gradient into a full +-1e-3 step, so single weights can sit an order of magnitude above the rest: the median of a tensor is
+    #  the sharp statistic, its largest element the loose one)
     per1 = {n: float(np.abs(out[True][6][n] - out[False][6][n]).max()) for n in out[True][6]}
-    print("   after iteration 1, largest gap per tensor: max %.1e (%s)" % (max(per1.values()), max(per1, key=per1.get)))
-    assert max(per1.values()) < (1e-3 if task == "go2_moe_cts" else 2e-4), per1          # measured: 5.5e-5 / 4.9e-5 / 2.9e-4 (the MoE student: softmax gate + load-balance term)
+    med1 = {n: float(np.median(np.abs(out[True][6][n] - out[False][6][n]))) for n in out[True][6]}
+    print("   after iteration 1, per tensor: largest median gap %.1e (%s), largest element gap %.1e (%s)" % (max(med1.values()), max(med1, key=med1.get), max(per1.values()), max(per1, key=per1.get)))
+    assert max(med1.values()) < GAP1_MED and max(per1.values()) < 2e-3, (med1, per1)
     # (2) after 5 iterations (100 + 100 steps, the last three replayed from HIP graphs): the rounding differences have been fed back through the simulator for 120 env
-    # steps (contacts make the trajectories of the two arms drift apart: rough terrain more than the plane), so this bound is looser — measured (round 6) medians 1.4e-4
-    # (plane) / 6.3e-4 (rough) over all weights, 7e-4 / 2.7e-3 for the worst tensor; a replay that reads stale memory or skips a launch is off by 1e-2 and more
+    # steps (contacts make the trajectories of the two arms drift apart: rough terrain more than the plane), so this bound is looser — measured (round 6) medians 3.0e-4
+    # (plane) / 6.4e-4 / 7.7e-4 (rough) over all weights, 1.1e-3 / 2.4e-3 / 3.1e-3 for the worst tensor; a replay that reads stale memory or skips a launch is off by 1e-2 and more
     per = {n: float(np.median(np.abs(out[True][5][n] - out[False][5][n]))) for n in out[True][5]}
     print("   after iteration %d, median gap per tensor: max %.1e (%s)" % (ITERS, max(per.values()), max(per, key=per.get)))
-    rough = task != "go2_flat_cts"
-    assert np.median(d) < (2e-3 if rough else 5e-4) and np.quantile(d, 0.99) < (2e-2 if rough else 6e-3), (np.median(d), np.quantile(d, 0.99), d.max())
-    assert max(per.values()) < (8e-3 if rough else 2.5e-3), per
+    assert np.median(d) < 2e-3 and np.quantile(d, 0.99) < 2e-2, (np.median(d), np.quantile(d, 0.99), d.max())
+    assert max(per.values()) < 8e-3, per
     assert abs(out[True][3] - out[False][3]) < 0.02
 
 

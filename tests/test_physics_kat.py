@@ -145,6 +145,9 @@ def test_coulomb_friction_cone(which):
             ft, fn = np.hypot(f[..., 0], f[..., 1]), f[..., 2]
             assert (fn >= -1e-3).all()
             worst = max(worst, float((ft - 1.0 * fn).max()))
+        # (an env whose robot tipped over in the window is out of the displacement statements like one that was reset: env 1 of this seed walks off and falls on the
+        #  gentle slope with ANY sweep count 4 .. 64 — with 4, 12, 16 or 64 sweeps its reset falls inside the 100 steps, with 6 or 8 one step behind them)
+        was_reset |= np.asarray(s.root_states)[:, 2] < 0.2
         out[tan_t] = (np.asarray(s.root_states)[:, 0] - x0, worst, was_reset)
         s.close()
     assert out[0.2][1] < 0.05 and out[1.8][1] < 0.05, (out[0.2][1], out[1.8][1])         # cone respected (N; forces are impulse / 5 ms)
@@ -271,18 +274,20 @@ def solver_convergence_table(steps=60, N=64, iters=(4, 16, 64, 256), top=1024, s
     return {k: {m: np.concatenate(v) for m, v in d.items()} for k, d in acc.items()}
 
 
-def test_four_sweeps_against_the_converged_solve_fp64():
-    """How far the shipped 4-sweep solve (= physx.num_position_iterations of the reference's config) is from its own fixed point, and that
+def test_shipped_sweeps_against_the_converged_solve_fp64():
+    """How far the shipped 8-sweep solve (2 per physx.num_position_iteration of the reference's config; 4 until round 5) is from its own fixed point, and that
     the iteration HAS one: 256 sweeps reproduce 1024 to 1e-4 (99 % of env-steps), the error shrinks monotonically with the sweep count, and
-    at 4 sweeps the median env-step is within 5 mm/s (base), 0.1 rad/s (joints), 2 % (forces) of the converged step.  The table is kept in
-    profiles/r3_solver_convergence.txt (tools/solver_convergence.py) and quoted in DESIGN.md 4."""
-    t = solver_convergence_table(steps=30, N=32)
+    at 8 sweeps the median env-step is within 0.2 mm/s (base), 3e-3 rad/s (joints), 0.05 % (forces) of the converged step, 90 % of the env-steps within 8 % in the body
+    forces (VERDICT r5's bar; the 4-sweep solve was at 13 %).  The table is kept in profiles/r6_solver_convergence.txt (tools/solver_convergence.py) and quoted in DESIGN.md 4."""
+    from go2_rl_gym_amd.envs.base.legged_robot_config import LeggedRobotCfg
+    assert LeggedRobotCfg.sim.solver.iterations == 8 == HostSim(load_oracle(), num_envs=1).cfg.solver_iterations          # config and go2sim_default_config agree
+    t = solver_convergence_table(steps=30, N=32, iters=(8, 4, 16, 64, 256))
     q = lambda k, m, p: float(np.quantile(t[k][m], p))
     assert q(256, "base_twist", 0.99) < 1e-3 and q(256, "joint_rates", 0.99) < 1e-2 and q(256, "forces_rel", 0.99) < 1e-3
     for m in ("base_twist", "joint_rates", "forces_rel"):
-        assert q(4, m, 0.9) > q(16, m, 0.9) >= q(64, m, 0.9) >= q(256, m, 0.9), m
-    assert q(4, "base_twist", 0.5) < 5e-3 and q(4, "joint_rates", 0.5) < 0.1 and q(4, "forces_rel", 0.5) < 0.02
-    assert q(4, "base_twist", 0.9) < 5e-2 and q(4, "joint_rates", 0.9) < 0.6 and q(4, "forces_rel", 0.9) < 0.1
+        assert q(4, m, 0.9) > q(8, m, 0.9) > q(16, m, 0.9) >= q(64, m, 0.9) >= q(256, m, 0.9), m
+    assert q(8, "base_twist", 0.5) < 5e-4 and q(8, "joint_rates", 0.5) < 1e-2 and q(8, "forces_rel", 0.5) < 2e-3
+    assert q(8, "base_twist", 0.9) < 4e-2 and q(8, "joint_rates", 0.9) < 0.25 and q(8, "forces_rel", 0.9) < 0.08
 
 
 def _standing(lib, n, **kw):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""How far is the shipped contact solve (solver.iterations = 4 sweeps of the leg-parallel mass-splitting iteration) from the
+"""How far is the shipped contact solve (solver.iterations = 8 sweeps — 4 until round 5 — of the leg-parallel mass-splitting iteration) from the
 converged solution of the SAME model?  fp64 oracle, identical states before every policy step (4 substeps), random-action trajectory with
 landings, stance, falls: per env-step max-abs difference to a 1024-sweep solve.   CPU only:  python tools/solver_convergence.py > profiles/r3_solver_convergence.txt"""
 import os
@@ -17,7 +17,9 @@ if "--both" in sys.argv:          # the shipped model, then the EXPERIMENT of VE
         sys.stdout.flush()
         subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, GO2_ORACLE_WARM_GROUPS=w), check=True)
     sys.exit(0)
-t = solver_convergence_table(steps=100, N=128)
+# round 6: the shipped count is 8 sweeps (solver.iterations = 2 x physx.num_position_iterations); the trajectory follows the shipped model (first entry of iters)
+t = solver_convergence_table(steps=100, N=128, iters=(8, 4, 16, 64, 256))
+t = {k: t[k] for k in sorted(t)}
 n = len(next(iter(t.values()))["base_twist"])
 print("contact solve: k sweeps vs 1024 sweeps of the same model (fp64 oracle, %d env-steps = 100 policy steps x 128 envs, N(0,1) actions, re-synced every step)" % n)
 print("difference after ONE policy step (4 substeps) | base twist [m/s, rad/s] | joint rates [rad/s] | body forces, relative to the env's largest")
@@ -25,5 +27,5 @@ print("%7s | %-38s | %-38s | %-38s" % ("sweeps", "p50      p90      p99      max
 for k, d in t.items():
     row = ["  ".join("%8.2e" % np.quantile(d[m], p) for p in (0.5, 0.9, 0.99, 1.0)) for m in ("base_twist", "joint_rates", "forces_rel")]
     print("%7d | %s | %s | %s" % (k, *row))
-print("4 sweeps is the reference's physx.num_position_iterations (legged_robot_config.py:253); PhysX's TGS at 4 iterations is not converged either.  The iteration has a fixed\n"
+print("4 is the reference's physx.num_position_iterations (legged_robot_config.py:253); shipped since round 6: 8 sweeps = 2 per position iteration (PhysX's TGS at 4 iterations is not converged either).  The iteration has a fixed\n"
       "point (256 sweeps = 1024 sweeps to 3e-4 m/s for 99 % of env-steps, to 1e-14 for 90 %); the far tail at few sweeps are env-steps with many simultaneous contacts (robots lying on several links).")
