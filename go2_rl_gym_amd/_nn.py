@@ -93,6 +93,7 @@ def bind(path):
     lib.go2nn_latent_mse.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]
     lib.go2nn_moe_usage.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.go2nn_moe_mix_loss.argtypes = [C.c_void_p] * 7 + [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.go2nn_moe_mix_forward.argtypes = [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_void_p]
     if lib.go2nn_abi_version() != GO2NN_ABI_VERSION:
         raise RuntimeError("%s: ABI version %d, expected %d" % (path, lib.go2nn_abi_version(), GO2NN_ABI_VERSION))
     return lib
@@ -251,6 +252,25 @@ class PolicyKernelCTS:
         if self.enc_s is not None:
             ios.append(Go2nnMlpIO(history.data_ptr(), None, self.si.data_ptr(), latent.data_ptr(), history.shape[1], 0, history.shape[1], self.si.numel(), L, 1))
         self._rows(self._nets, ios)
+
+    def moe_mix_ok(self, model):
+        """the student encoder is a soft mixture whose tail go2nn_moe_mix_forward covers: E <= 16 experts, an L2 normaliser, the latent width the CTS kernels take"""
+        enc = getattr(model, "student_moe_encoder", None)
+        from .rsl_rl.modules.actor_critic_moe_cts import ActorCriticMoECTS
+        from .rsl_rl.modules.utils import L2Norm
+        return (enc is not None and getattr(type(model), "student_moe_parts", None) is ActorCriticMoECTS.student_moe_parts and hasattr(enc, "moe") and isinstance(getattr(enc, "norm_layer", None), L2Norm) and enc.moe.experts.expert_num <= 16
+                and enc.moe.experts.output_dim == self.L)
+
+    def moe_mix(self, logits, outs, bias, latent):
+        """latent[student envs] <- normalise(sum_e softmax(logits)_e (outs[e] + bias[e])): logits [n, E], outs [E, n, L] (expert-major, no bias), bias [E * L]"""
+        E, n, L = outs.shape
+        for t in (logits, outs, bias, latent):
+            assert t.is_contiguous() and t.dtype == torch.float32
+        assert logits.shape == (n, E) and L == self.L and n == self.si.numel()
+        p = lambda t: C.c_void_p(t.data_ptr())
+        rc = self.lib.go2nn_moe_mix_forward(p(logits), p(outs), p(bias.detach()), p(self.si), p(latent), latent.shape[1], n, E, L, 1, self.enc_t._stream())
+        if rc != 0:
+            raise RuntimeError("go2nn_moe_mix_forward failed: %s" % self.lib.go2nn_last_error().decode())
 
     def value(self, latent, privileged_obs):
         """critic([latent | privileged obs]) -> [N, 1] (the bootstrap value of compute_returns), one launch on the packed weights"""

@@ -202,4 +202,35 @@ __global__ void __launch_bounds__(256) go2nn_moe_mix_kernel(const float* __restr
     prow[0] = s / ((float)n * (float)L); prow[1] = lb; prow[2] = prow[3] = 0.f;
   }
 }
+// The same mixture FORWARD only (the rollout's student rows, CTS.act: rsl_rl/rsl_rl/algorithms/cts.py:112-149 -> modules/utils.py:96-152): softmax gate, weighted sum of the
+// expert outputs (+ their bias), L2 normaliser, and the result scattered to the env-ordered latent — in place of softmax, a broadcast product, two reductions, a clamp,
+// a division and an index_copy (8 launches of ~5 us each on [n, 8] / [n, 32] tensors, 24 times per iteration).  rows: optional destination row of source row r.
+template <int ME>
+__global__ void __launch_bounds__(256) go2nn_moe_mix_forward_kernel(const float* __restrict__ logits, const float* __restrict__ outs, const float* __restrict__ bias,
+                                                                    const int* __restrict__ rows, float* __restrict__ z, int ldz, int n, int E, int L, long long sr, long long se) {
+  const int LP = L >> 2, RL = 256 / LP, cq = threadIdx.x % LP, rl = threadIdx.x / LP, c = cq * 4;
+  const int r0 = blockIdx.x * CTS_ROWS_PER_WG, r1 = min(n, r0 + CTS_ROWS_PER_WG);
+  float4 bq[ME];
+#pragma unroll
+  for (int e = 0; e < ME; ++e) bq[e] = (bias && e < E) ? *reinterpret_cast<const float4*>(bias + (size_t)e * L + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int rb = r0; rb < r1; rb += RL) {
+    const int r = rb + rl, rc = min(r, r1 - 1);
+    float w[ME]; float4 o[ME];
+    float mx = -3.4e38f, sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < ME; ++e) {
+      w[e] = e < E ? logits[(size_t)rc * E + e] : -3.4e38f; mx = fmaxf(mx, w[e]);
+      o[e] = e < E ? *reinterpret_cast<const float4*>(outs + (size_t)rc * sr + (size_t)e * se + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      o[e].x += bq[e].x; o[e].y += bq[e].y; o[e].z += bq[e].z; o[e].w += bq[e].w;
+    }
+#pragma unroll
+    for (int e = 0; e < ME; ++e) { w[e] = e < E ? expf(w[e] - mx) : 0.f; sum += w[e]; }
+    const float isum = 1.f / sum;
+    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int e = 0; e < ME; ++e) { w[e] *= isum; y.x = fmaf(w[e], o[e].x, y.x); y.y = fmaf(w[e], o[e].y, y.y); y.z = fmaf(w[e], o[e].z, y.z); y.w = fmaf(w[e], o[e].w, y.w); }
+    const float inv = 1.f / fmaxf(sqrtf(cts_group_sum(y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w, LP)), CTS_EPS);
+    if (r < r1) *reinterpret_cast<float4*>(z + (size_t)(rows ? rows[r] : r) * ldz + c) = make_float4(y.x * inv, y.y * inv, y.z * inv, y.w * inv);
+  }
+}
 #endif  // !GO2_EMU

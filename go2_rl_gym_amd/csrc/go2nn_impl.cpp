@@ -1199,4 +1199,28 @@ int go2nn_moe_mix_loss(const float* logits, const float* outs, const float* t_ha
   return 0;
 }
 
+int go2nn_moe_mix_forward(const float* logits, const float* outs, const float* bias, const int32_t* rows, float* z, int32_t ldz, int32_t n, int32_t E, int32_t L,
+                          int32_t expert_major, void* stream) {
+  if (!logits || !outs || !z || !cts_ok(n, L) || E < 1 || E > 16 || ldz < L || (ldz & 3) || ((uintptr_t)z & 15)) FAIL(GO2NN_EINVAL, "moe mix forward: bad argument (1 <= E <= 16, ldz >= L a multiple of 4)");
+  const long long sr = expert_major ? L : (long long)E * L, se = expert_major ? (long long)n * L : L;
+#ifdef GO2_EMU
+  (void)stream;
+  for (int r = 0; r < n; ++r) {
+    float w[16], y[128], mx = -3.4e38f, sum = 0.f, ss = 0.f;
+    for (int e = 0; e < E; ++e) mx = fmaxf(mx, logits[(size_t)r * E + e]);
+    for (int e = 0; e < E; ++e) { w[e] = expf(logits[(size_t)r * E + e] - mx); sum += w[e]; }
+    for (int e = 0; e < E; ++e) w[e] /= sum;
+    for (int c = 0; c < L; ++c) { y[c] = 0.f; for (int e = 0; e < E; ++e) y[c] = fmaf(w[e], outs[(size_t)r * sr + (size_t)e * se + c] + (bias ? bias[(size_t)e * L + c] : 0.f), y[c]); ss += y[c] * y[c]; }
+    const float inv = 1.f / fmaxf(sqrtf(ss), CTS_EPS);
+    float* o = z + (size_t)(rows ? rows[r] : r) * ldz;
+    for (int c = 0; c < L; ++c) o[c] = y[c] * inv;
+  }
+#else
+  if (E <= 8) hipLaunchKernelGGL(go2nn_moe_mix_forward_kernel<8>, dim3(cts_rows(n)), dim3(256), 0, (hipStream_t)stream, logits, outs, bias, rows, z, ldz, n, E, L, sr, se);
+  else        hipLaunchKernelGGL(go2nn_moe_mix_forward_kernel<16>, dim3(cts_rows(n)), dim3(256), 0, (hipStream_t)stream, logits, outs, bias, rows, z, ldz, n, E, L, sr, se);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
+}
+
 }  // extern "C"

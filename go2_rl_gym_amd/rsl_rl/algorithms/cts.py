@@ -134,6 +134,7 @@ class CTS(_RolloutHeads):
         if pk is not None and all(x.is_contiguous() and x.dtype == torch.float32 for x in (obs, privileged_obs, history)):
             # two launches (include/go2nn.h ABI 5): both encoders on their env subsets -> the env-ordered latent; actor + critic + sampling head on [latent | obs] / [latent | priv]
             if s == 0 or not self._pk_packed:
+                self._img_cache = {}
                 pk.pack()                  # the parameters only change in update(): once per rollout (inside the captured rollout graph too)
                 self._pk_packed = True
                 self._pk_recorded = self._pk_recorded or s == 0
@@ -218,8 +219,17 @@ class CTS(_RolloutHeads):
         latent = self._latent_buf
         if pk.enc_s is None:
             from ..modules.fused import own_forward
-            with torch.no_grad(), own_forward():
-                latent.index_copy_(0, self.student_env_idxs, self.model.student_latent(history[self.student_env_idxs])[0])
+            if self._img_cache is None:
+                self._img_cache = {}
+            with torch.no_grad(), own_forward(images=self._img_cache):          # (the split weight images: once per rollout — act() empties the cache at step 0)
+                hs = history[self.student_env_idxs]
+                parts = getattr(self.model, "student_moe_parts", None)
+                if parts is not None and pk.moe_mix_ok(self.model):
+                    # the soft mixture's tail (softmax gate, weighted sum + bias, normaliser, scatter to the env-ordered latent) as ONE launch (include/go2nn.h ABI 6)
+                    logits, outs, bias = parts(hs)
+                    pk.moe_mix(logits, outs, bias, latent)
+                else:
+                    latent.index_copy_(0, self.student_env_idxs, self.model.student_latent(hs)[0])
         pk.latents(privileged_obs, history, latent)
         return latent
 
@@ -570,6 +580,7 @@ class CTS(_RolloutHeads):
 
     def update(self):
         self._pk_packed = False          # the optimizer steps below change the parameters: the next rollout re-packs
+        self._img_cache = None
         out = self._update_graphs() if self.use_graphs else self._update_eager()
         self.storage.clear()
         return out

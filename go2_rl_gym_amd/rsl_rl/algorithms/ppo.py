@@ -64,6 +64,7 @@ _PLAIN = (_AC._noise, _ACC._noise)          # the modules' own _noise functions 
 class _RolloutHeads:
     """Shared pieces of the PPO-family algorithms: two-stream actor/critic evaluation and the per-step rollout heads."""
     _eps_all = None
+    _img_cache = None           # split weight images of the networks a rollout evaluates as torch modules on the library's kernels (modules/fused.py:own_forward(images=...)); emptied with _pk_packed
     _pk_packed = False          # the policy kernel's packed weights are those of the current parameters (they change in update() only)
     _pk_recorded = False        # the rollout last RUN THROUGH PYTHON (eager, or while being captured) packed at its first step: what a replay of that capture does too
 

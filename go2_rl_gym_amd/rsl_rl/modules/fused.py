@@ -25,6 +25,7 @@ _NN = None
 # fp32 accumulation — as close to float64 as the fp32-MFMA kernels, tests/test_gpu_mlp_tail.py).  0: the fp32-MFMA kernels.
 _SPLIT = os.environ.get("GO2_GEMM_SPLIT", "1") == "1"
 _WG_BELOW = os.environ.get("GO2_WGRAD_BELOW", "1") == "1"      # tools (A/B): 0 = the first layer's weight gradient as a launch of its own (round 5)
+_IMAGES = None             # own_forward(images=...): the caller's cache of split weight images, by weight address
 _OWN_FORWARD = False       # inside own_forward(): Linear / ELU stacks evaluated WITHOUT gradient also run on the library's kernels (see FusedSequential.forward)
 
 
@@ -48,13 +49,19 @@ class own_forward:
     """with own_forward(): Linear / ELU stacks evaluated under torch.no_grad() run on the library's kernels too (the update's once-per-update student latents, the
     rollout's MoE student encoder) — opt-in, so that a test's torch-module reference never silently becomes the kernels it is the reference for"""
 
+    def __init__(self, images=None):
+        """images: a dict the caller owns — the split images of the layers' weights are kept in it across calls (the 24 steps of a rollout evaluate the same
+        parameters: one go2nn_split_weights launch per network and ROLLOUT instead of per step); the caller empties it whenever the parameters may have changed"""
+        self.images = images
+
     def __enter__(self):
-        global _OWN_FORWARD
-        self._was, _OWN_FORWARD = _OWN_FORWARD, True
+        global _OWN_FORWARD, _IMAGES
+        self._was, _OWN_FORWARD = (_OWN_FORWARD, _IMAGES), True
+        _IMAGES = self.images
 
     def __exit__(self, *exc):
-        global _OWN_FORWARD
-        _OWN_FORWARD = self._was
+        global _OWN_FORWARD, _IMAGES
+        _OWN_FORWARD, _IMAGES = self._was
         return False
 
 
@@ -92,13 +99,19 @@ class _Launch:
         if not _SPLIT:
             return [None] * len(lins)
         imgs, jobs = [], []
+        cache = _IMAGES if (_OWN_FORWARD and not torch.is_grad_enabled()) else None
         for m in lins:
             N, K = m.weight.shape
+            if cache is not None and m.weight.data_ptr() in cache:
+                imgs.append(cache[m.weight.data_ptr()])
+                continue
             n = self.nn.go2nn_split_weights_bytes(N, K)
             if n <= 0:
                 raise RuntimeError("go2nn_split_weights_bytes: %s" % self.nn.go2nn_last_error().decode())
             imgs.append(torch.empty(int(n), device=self.dev, dtype=torch.uint8))
             jobs.append(Go2nnSplitJob(m.weight.data_ptr(), imgs[-1].data_ptr(), N, K))
+            if cache is not None:
+                cache[m.weight.data_ptr()] = imgs[-1]
         for k in range(0, len(jobs), 16):
             chunk = jobs[k:k + 16]
             self.check(self.nn.go2nn_split_weights((Go2nnSplitJob * len(chunk))(*chunk), len(chunk), self.stream), "go2nn_split_weights")

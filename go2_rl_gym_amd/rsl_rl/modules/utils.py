@@ -78,7 +78,7 @@ class GroupedHeads(nn.Module):
         w = self.weight.view(self.groups, self.cout, self.cin).transpose(1, 2)   # [E, hidden, out]
         if not with_bias:                                               # (the fused loss head of the student step adds the bias itself: a plain batched product here)
             if self.cout < 32 and x.is_cuda:                            # (the same narrow-output trap as below — a latent of 4 / 8 / 16 columns)
-                return torch.bmm(xe, F.pad(w, (0, 32 - self.cout)))[..., :self.cout]
+                return torch.bmm(xe, F.pad(w, (0, 32 - self.cout)))[..., :self.cout].contiguous()          # (dense [E, B, out]: what the fused heads read)
             return torch.bmm(xe, w)
         b = self.bias.view(self.groups, 1, self.cout)
         if self.cout < 32 and x.is_cuda:

@@ -228,6 +228,11 @@ int go2nn_latent_mse(const float* z_s, const float* z_t, float* dz_s, float* par
 int go2nn_moe_usage(const float* logits, float* partials, int32_t n, int32_t E, void* stream);
 int go2nn_moe_mix_loss(const float* logits, const float* outs, const float* t_hat, const float* usage_sum, float* d_logits, float* d_outs, float* partials,
                        int32_t n, int32_t E, int32_t L, float lb_coef, int32_t expert_major, const float* bias, float* dbias_partials, void* stream);
+/* ABI 6: the mixture FORWARD only — the student rows of a rollout step (rsl_rl/rsl_rl/algorithms/cts.py:112-149: CTS.act evaluates the student encoder without gradient):
+ *   z[rows ? rows[r] : r][0 .. L) = normalise(sum_e softmax(logits[r])_e (outs[r, e] + bias[e]))     z has row pitch ldz (a multiple of 4, 16-byte aligned rows)
+ * one launch in place of softmax, a broadcast product, a sum, the normaliser's four element-wise / reduction kernels and the index_copy into the env-ordered latent. */
+int go2nn_moe_mix_forward(const float* logits, const float* outs, const float* bias, const int32_t* rows, float* z, int32_t ldz, int32_t n, int32_t E, int32_t L,
+                          int32_t expert_major, void* stream);
 /* expert_major 1: outs / d_outs are [E, n, L] (the batched GEMM's own layout: no transposing copies either way).  bias (optional, [E, L]): the expert heads' output bias,
  * added to outs here — autograd then differentiates a plain batched product — with its gradient left as go2nn_l2norm_backward_rows(n) partial rows of E L columns in
  * dbias_partials (a 77 us torch reduction otherwise). */

@@ -287,3 +287,34 @@ def moe_head_vs_autograd(nn_lib, sim_lib, device, n=150, E=8, L=32, coef=0.01, e
 def test_moe_loss_head_matches_autograd(n, E, L, coef):
     moe_head_vs_autograd(load_nn_emu(), load_oracle(), "cpu", n, E, L, coef)
     moe_head_vs_autograd(load_nn_emu(), load_oracle(), "cpu", n, E, L, coef, expert_major=True)
+
+
+def moe_mix_forward_vs_torch(nn_lib, device, n=150, E=8, L=32, N=400):
+    """go2nn_moe_mix_forward (include/go2nn.h ABI 6: the rollout's student rows — softmax gate, weighted sum of the expert outputs + bias, normaliser, scatter into the
+    env-ordered latent) against the reference's formulation (modules/utils.py:96-152 MoE.forward + the normaliser, float64 torch): both expert layouts, with and
+    without a row map, rows it does not own left untouched"""
+    g = torch.Generator().manual_seed(n * 13 + E + L)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream) if device != "cpu" else None
+    logits, outs, bias = (torch.randn(n, E, generator=g) * 2).to(device), torch.randn(n, E, L, generator=g).to(device), (torch.randn(E, L, generator=g) * 0.3).to(device)
+    if n > 2:
+        outs[n // 2] = 0.0          # (with b = None below: a zero mixture, the eps branch of the normaliser)
+    rows = torch.randperm(N, generator=g)[:n].to(torch.int32).to(device)
+    want = lambda b: torch.nn.functional.normalize(torch.sum(torch.softmax(logits.double().cpu(), -1).unsqueeze(-1) * (outs.double().cpu() + (b.double().cpu() if b is not None else 0.0)), dim=1), p=2.0, dim=-1)
+    for em in (0, 1):
+        o = outs.transpose(0, 1).contiguous() if em else outs
+        for b in (bias, None):
+            z = torch.full((N, L + 4), 7.0, device=device)
+            assert nn_lib.go2nn_moe_mix_forward(P(logits), P(o), P(b), P(rows), P(z), L + 4, n, E, L, em, stream) == 0, nn_lib.go2nn_last_error()
+            np.testing.assert_allclose(z[rows.long(), :L].cpu().numpy(), want(b).numpy(), atol=3e-7)
+            mask = torch.ones(N, dtype=torch.bool); mask[rows.long().cpu()] = False
+            assert (z[:, L:] == 7.0).all() and (z[mask.to(device)] == 7.0).all()
+            d = torch.full((n, L), 7.0, device=device)
+            assert nn_lib.go2nn_moe_mix_forward(P(logits), P(o), P(b), None, P(d), L, n, E, L, em, stream) == 0
+            np.testing.assert_allclose(d.cpu().numpy(), want(b).numpy(), atol=3e-7)
+    t = torch.zeros(64, device=device)
+    assert nn_lib.go2nn_moe_mix_forward(P(t), P(t), None, None, P(t), 8, 2, 17, 8, 0, stream) < 0 and nn_lib.go2nn_moe_mix_forward(P(t), P(t), None, None, P(t), 6, 2, 4, 8, 0, stream) < 0
+
+
+@pytest.mark.parametrize("n,E,L", [(150, 8, 32), (1, 4, 8), (67, 16, 4), (300, 3, 128)])
+def test_moe_mix_forward_matches_torch(n, E, L):
+    moe_mix_forward_vs_torch(load_nn_emu(), "cpu", n, E, L)

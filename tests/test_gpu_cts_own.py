@@ -69,3 +69,12 @@ def test_moe_loss_head_on_gpu(n, E, L, coef):
     torch.cuda.synchronize()
     for u, v in zip(a, b):
         assert torch.equal(u, v)
+
+
+from test_cts_own import moe_mix_forward_vs_torch  # noqa: E402
+
+
+@pytest.mark.parametrize("n,E,L", [(256, 8, 32), (1, 4, 8), (67, 16, 4), (2048, 8, 32), (300, 3, 128)])
+def test_moe_mix_forward_on_gpu(n, E, L):
+    """the rollout's mixture tail (go2nn_moe_mix_forward_kernel) against float64 torch at the student-row counts of 1024 and 8192 envs and at ragged ones"""
+    moe_mix_forward_vs_torch(_nn.load_nn(), "cuda:0", n, E, L, N=max(400, 4 * n))
