@@ -70,11 +70,10 @@ def _latent_ok(L):
 def cts_plan(model):
     """-> CtsPlan when the no-autograd mini-batch applies to `model`, else None (the algorithm then keeps the autograd formulation): the library pair is loaded, the
     heads are the base class's ([latent | obs] -> actor MLP, [latent | privileged obs] -> critic MLP, one std per action), every network is Linear / ELU with an
-    L2-normalised latent, actor and critic share their hidden widths, and the split-operand kernels are on (the plain input gradient of a 77-wide layer exists only there)."""
+    L2-normalised latent, actor and critic share their hidden widths.  (Round 6: also with GO2_GEMM_SPLIT=0, the fp32-MFMA A/B arithmetic — the one product those kernels do
+    not have, the plain input gradient of a layer whose width is not a multiple of 4 ([latent | obs] = 77), is then a vendor mm: _plain_input_grad.)"""
     from .actor_critic_cts import ActorCriticCTS
     if not (fused._LIB is not None and fused._NN is not None and isinstance(model, ActorCriticCTS)):
-        return None
-    if not (fused._SPLIT or fused._NN.go2nn_is_device_library() == 0):
         return None
     t = type(model)
     if any(getattr(t, n) is not getattr(ActorCriticCTS, n) for n in ("policy_mean", "value", "policy_dist", "latents", "evaluate_joint")) or model.state_dependent_std:
@@ -120,6 +119,14 @@ def latent_concat(k, z, dst_a, dst_b, inv=None):
             "go2nn_latent_concat")
 
 
+def _plain_input_grad(k, gz0, lin0, img0):
+    """d loss / d x = gz0 W0 of a network's first layer: the split-operand kernel (any width), or — fp32-MFMA arithmetic (GO2_GEMM_SPLIT=0, A/B runs) and a width that is
+    not a multiple of 4 — the vendor's mm, as modules/fused.py:_input_grad does for the autograd nodes"""
+    if img0 is not None or (lin0.in_features % 4 == 0 and lin0.out_features >= 4):
+        return k.bwd_in([(gz0, lin0, None, img0)], plain=True)[0][0]
+    return gz0.mm(lin0.weight)
+
+
 def cts_policy_grads(plan, model, ain, cin, priv_t, batch, n_t, clip, vcoef, ecoef, use_clipped_value_loss, acc=None):
     """One CTS policy mini-batch gradient (cts.py:180-250 + loss.backward()).
     ain [B, L + obs], cin [B, L + priv]: the actor's / critic's input matrices, rows [0, n_t) teacher samples, the rest student samples; columns [L, ...) hold obs /
@@ -144,7 +151,7 @@ def cts_policy_grads(plan, model, ain, cin, priv_t, batch, n_t, clip, vcoef, eco
         # actor + critic: grouped hidden layers, heads + PPO loss with the split surrogate, backward down to the first layers' pre-activations
         tot, gz1 = fused.pair_grads(k, la, lc, ain, cin, model.std, batch, clip, vcoef, ecoef, use_clipped_value_loss, surrogate_split=n_t, acc=acc, imgs=(ia, ic))
         # into the teacher encoder: d loss / d [latent | obs] of the actor on the teacher rows (the critic sees latent.detach()), through the normaliser
-        g_in = k.bwd_in([(gz1[0][:n_t], la[0], None, ia[0])], plain=True)[0][0]
+        g_in = _plain_input_grad(k, gz1[0][:n_t], la[0], ia[0])
         r = nn_.go2nn_l2norm_backward_rows(n_t)
         dz, zpart, gb_z = k.new(n_t, L), k.new(r * L), k.new(L)
         k.check(nn_.go2nn_l2norm_backward(_p(g_in), g_in.stride(0), _p(ain), ain.stride(0), _p(inv), _p(dz), _p(zpart), n_t, L, k.stream), "go2nn_l2norm_backward")
