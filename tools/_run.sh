@@ -1,7 +1,3 @@
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
-cd $R
-python -m pytest tests -m gpu -q 2>&1 | grep "passed\|failed\|FAILED" 
-python bench.py --steps 30 --warmup 10 --no-cpu-baseline 2>/dev/null | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"collection_only": [0-9.]*' | tr '\n' ' '; echo
-python bench.py --steps 30 --warmup 10 --no-cpu-baseline 2>/dev/null | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"collection_only": [0-9.]*' | tr '\n' ' '; echo
-python bench.py --task go2_moe_cts --num-envs 1024 --steps 30 --warmup 10 --no-cpu-baseline 2>/dev/null | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' | tr '\n' ' '; echo
+cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_gpu_parity.py -q -s -k "cts_training_graph_vs_eager" 2>&1 | grep -v Warning | grep "graph vs eager\|after iteration\|Error\|passed\|failed\|^E " | cut -c1-600 | head -30
