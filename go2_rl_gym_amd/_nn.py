@@ -261,14 +261,15 @@ class PolicyKernelCTS:
         return (enc is not None and getattr(type(model), "student_moe_parts", None) is ActorCriticMoECTS.student_moe_parts and hasattr(enc, "moe") and isinstance(getattr(enc, "norm_layer", None), L2Norm) and enc.moe.experts.expert_num <= 16
                 and enc.moe.experts.output_dim == self.L)
 
-    def moe_mix(self, logits, outs, bias, latent):
-        """latent[student envs] <- normalise(sum_e softmax(logits)_e (outs[e] + bias[e])): logits [n, E], outs [E, n, L] (expert-major, no bias), bias [E * L]"""
+    def moe_mix(self, logits, outs, bias, latent, rows=True):
+        """latent[student envs] <- normalise(sum_e softmax(logits)_e (outs[e] + bias[e])): logits [n, E], outs [E, n, L] (expert-major, no bias), bias [E * L].
+        rows False: latent is [n, L], row r <- source row r (the update's student rows)"""
         E, n, L = outs.shape
         for t in (logits, outs, bias, latent):
             assert t.is_contiguous() and t.dtype == torch.float32
-        assert logits.shape == (n, E) and L == self.L and n == self.si.numel()
+        assert logits.shape == (n, E) and L == self.L and (n == self.si.numel() if rows else latent.shape[0] == n)
         p = lambda t: C.c_void_p(t.data_ptr())
-        rc = self.lib.go2nn_moe_mix_forward(p(logits), p(outs), p(bias.detach()), p(self.si), p(latent), latent.shape[1], n, E, L, 1, self.enc_t._stream())
+        rc = self.lib.go2nn_moe_mix_forward(p(logits), p(outs), p(bias.detach()), p(self.si) if rows else None, p(latent), latent.shape[1], n, E, L, 1, self.enc_t._stream())
         if rc != 0:
             raise RuntimeError("go2nn_moe_mix_forward failed: %s" % self.lib.go2nn_last_error().decode())
 
