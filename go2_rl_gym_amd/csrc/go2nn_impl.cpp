@@ -518,7 +518,7 @@ int go2nn_sum_rows(const Go2nnSumJob* jobs, int32_t njobs, void* stream) {
   for (int j = 0; j < njobs; ++j) {
     a.part[j] = jobs[j].part; a.out[j] = jobs[j].out; a.nrows[j] = jobs[j].nrows; a.ncols[j] = jobs[j].ncols; a.acc[j] = jobs[j].acc; a.nacc[j] = jobs[j].acc ? jobs[j].nacc : 0;
     a.out_w[j] = jobs[j].out_w; a.out_ld[j] = jobs[j].out_ld;
-    a.first_block[j + 1] = a.first_block[j] + (jobs[j].nrows <= 32 ? (jobs[j].ncols + 255) / 256 : (jobs[j].ncols + 15) / 16);
+    a.first_block[j + 1] = a.first_block[j] + (jobs[j].nrows <= 32 ? (jobs[j].ncols + 255) / 256 : (jobs[j].ncols + 31) / 32);
   }
   hipLaunchKernelGGL(go2nn_sum_rows_kernel, dim3(a.first_block[njobs]), dim3(256), 0, (hipStream_t)stream, a);
   HIPCHK(hipGetLastError());

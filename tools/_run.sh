@@ -1,12 +1,4 @@
 export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
-DBG_DUMP=/tmp/mix python -m pytest tests/test_gpu_parity.py -q -k "cts_training_graph_vs_eager and moe" > /dev/null 2>&1
-DBG_MIX_TORCH=1 DBG_DUMP=/tmp/tor python -m pytest tests/test_gpu_parity.py -q -k "cts_training_graph_vs_eager and moe" > /dev/null 2>&1
-python - <<'PY'
-import numpy as np
-for mode in (0, 1):
-    a, b = np.load("/tmp/mix_%d.npz" % mode), np.load("/tmp/tor_%d.npz" % mode)
-    d = {k: float(np.median(np.abs(a[k] - b[k]))) for k in a.files}
-    k = max(d, key=d.get)
-    print("arm %s: kernel-mix rollout vs torch-mix rollout, weights after iteration 1: largest per-tensor median gap %.2e (%s); actor.network.0.weight %.2e" % ("graph" if mode else "eager", d[k], k, d.get("actor.network.0.weight", -1)))
-PY
+R=$GRAFT_REPO_ROOT; cd $R
+for rep in 1 2; do for v in 8 4; do echo "min tiles $v: $(GO2NN_WG_MIN_TILES=$v python bench.py --steps 30 --warmup 10 --no-cpu-baseline 2>/dev/null | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' | tr '\n' ' ')"; done; done
+GO2NN_WG_MIN_TILES=4 python -m pytest tests/test_gpu_mlp_tail.py -q -k "ppo_heads_path or linear_group_split" 2>&1 | grep "passed\|failed"
