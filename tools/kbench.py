@@ -59,7 +59,7 @@ if __name__ == "__main__":
     run_split(label="measure_heights=0", measure_heights=0)
     run_split(label="add_noise=0", add_noise=0)
     run_split(label="no DR/push/delay", push_robots=0, randomize_action_delay=0, add_noise=0, measure_heights=0)
-    run("default (4 PGS sweeps, 4 substeps)")
+    run("default (8 PGS sweeps, 4 substeps)")
     run("no PGS sweeps", solver_iterations=0)
     run("4 PGS sweeps", solver_iterations=4)
     run("8 PGS sweeps", solver_iterations=8)
