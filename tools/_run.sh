@@ -1,4 +1,4 @@
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; cd $R
-for rep in 1 2; do for v in 8 4; do echo "min tiles $v: $(GO2NN_WG_MIN_TILES=$v python bench.py --steps 30 --warmup 10 --no-cpu-baseline 2>/dev/null | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' | tr '\n' ' ')"; done; done
-GO2NN_WG_MIN_TILES=4 python -m pytest tests/test_gpu_mlp_tail.py -q -k "ppo_heads_path or linear_group_split" 2>&1 | grep "passed\|failed"
+cd $GRAFT_REPO_ROOT
+echo "== MIX"; DBG_DUMP=/tmp/mix python -m pytest tests/test_gpu_parity.py -q -s -k "cts_training_graph_vs_eager and moe" 2>&1 | grep "DBG policy\|Error\|passed\|failed" | cut -c1-400
+echo "== MIX_TORCH"; DBG_MIX_TORCH=1 DBG_DUMP=/tmp/tor python -m pytest tests/test_gpu_parity.py -q -s -k "cts_training_graph_vs_eager and moe" 2>&1 | grep "DBG policy\|Error\|passed\|failed" | cut -c1-400
