@@ -211,7 +211,8 @@ struct LegPhys {
   //     (terrain_utils triangles (0,3,1),(0,2,3)); gap = (c.z - h) n.z - r;
   //   * with hf_walls (mesh_type 'trimesh'): the vertical faces on the cell's four edges — a face stands where the NEIGHBOUR cell's heights
   //     along the common edge exceed this cell's (go2sim.h hf_cells); closest point on the face (bottom .. top at the foot of the
-  //     perpendicular) gives a horizontal normal beside the face and a slanted one over its top edge.
+  //     perpendicular) gives a horizontal normal beside the face and a slanted one over its top edge;
+  //   * and the vertical edge at the nearest cell corner where the DIAGONAL neighbour cell is higher (round 6).
   template <class LT>
   GO2_HD void contact_query(const LT& L, const GO2_AS1 Go2Cell* cells, V3 c, float r, float* gap, V3* n) const {
     if (L.terrain_mode == 0) { *gap = c.z - r; *n = v3(0, 0, 1); return; }
@@ -221,17 +222,12 @@ struct LegPhys {
     i = i < 0 ? 0 : (i > L.hf_rows - 2 ? L.hf_rows - 2 : i); j = j < 0 ? 0 : (j > L.hf_cols - 2 ? L.hf_cols - 2 : j);
     const float uu = fminf(fmaxf(fx - i, 0.f), 1.f), vv = fminf(fmaxf(fy - j, 0.f), 1.f);
     const int nc = L.hf_cols - 1;
-    const Go2Cell q = cells[i * nc + j];
-    // (with hf_walls) the four neighbour cells are loaded TOGETHER with the cell itself, before any of them is looked at (indices clamped
-    // into the grid: a neighbour outside it is the cell itself and is ignored below) — issued where they are tested, each behind its branch
-    // and behind the facet arithmetic, a query waits for several L2 round trips in a row instead of one
-    const int rows2 = L.hf_rows - 2, cols2 = L.hf_cols - 2;
-    Go2Cell bxm = q, bxp = q, bym = q, byp = q;
-    if (L.hf_walls) {
-      bxm = cells[(i > 0 ? i - 1 : i) * nc + j]; bxp = cells[(i < rows2 ? i + 1 : i) * nc + j];
-      bym = cells[i * nc + (j > 0 ? j - 1 : j)]; byp = cells[i * nc + (j < cols2 ? j + 1 : j)];
-    }
-    const float h00 = q.h[0] * vs, h10 = q.h[1] * vs, h01 = q.h[2] * vs, h11 = q.h[3] * vs;
+    // (with hf_walls the record of a cell holds its neighbours' heights along the common edges and corners too — go2_tables.h Go2CellW: one 32-byte load per query;
+    // rounds 2-5 fetched the four edge neighbours' cells beside the cell itself, five L2 requests per query)
+    Go2CellW w;
+    if (L.hf_walls) w = ((const GO2_AS1 Go2CellW*)cells)[i * nc + j];
+    else { const Go2Cell q = cells[i * nc + j]; w.h[0] = q.h[0]; w.h[1] = q.h[1]; w.h[2] = q.h[2]; w.h[3] = q.h[3]; }
+    const float h00 = w.h[0] * vs, h10 = w.h[1] * vs, h01 = w.h[2] * vs, h11 = w.h[3] * vs;
     float dx, dy;
     if (uu >= vv) { dx = h10 - h00; dy = h11 - h10; }
     else { dx = h11 - h01; dy = h01 - h00; }
@@ -239,18 +235,30 @@ struct LegPhys {
     const float nx = -dx / hs, ny = -dy / hs, inv = 1.0f / sqrtf(nx * nx + ny * ny + 1.f);
     float g = (c.z - hgt) * inv - r; V3 nn = v3(nx * inv, ny * inv, inv);
     if (L.hf_walls) {
-      // edge k: neighbour cell, this cell's heights at the edge ends (a0, a1), the neighbour's (its corners k0, k1), parameter along the edge,
-      // distance of the centre from the edge, inward direction
-#define GO2_WALL(INGRID, NB, A0, A1, K0, K1, T, D, NX, NY) { \
-        const float bot = (A0) + (T) * ((A1) - (A0)), b0 = (NB).h[K0] * vs, top = b0 + (T) * ((NB).h[K1] * vs - b0); \
-        if ((INGRID) && top - bot > 0.5f * vs) { \
+      // edge k: this cell's heights at the edge ends (a0, a1), the neighbour's (b0, b1), parameter along the edge, distance of the centre from the edge, inward direction
+#define GO2_WALL(NB, A0, A1, T, D, NX, NY) { \
+        const float bot = (A0) + (T) * ((A1) - (A0)), b0 = (NB)[0] * vs, top = b0 + (T) * ((NB)[1] * vs - b0); \
+        if (top - bot > 0.5f * vs) { \
           const float qz = fminf(fmaxf(c.z, bot), top), dz = c.z - qz, dist = sqrtf((D) * (D) + dz * dz), gw = dist - r; \
           if (gw < g) { const float iv = 1.0f / fmaxf(dist, 1e-9f); g = gw; nn = dist > 1e-9f ? v3((NX) * (D) * iv, (NY) * (D) * iv, dz * iv) : v3((NX), (NY), 0.f); } } }
-      GO2_WALL(i > 0, bxm, h00, h01, 1, 3, vv, uu * hs, 1.f, 0.f)
-      GO2_WALL(i < rows2, bxp, h10, h11, 0, 2, vv, (1.f - uu) * hs, -1.f, 0.f)
-      GO2_WALL(j > 0, bym, h00, h10, 2, 3, uu, vv * hs, 0.f, 1.f)
-      GO2_WALL(j < cols2, byp, h01, h11, 0, 1, uu, (1.f - vv) * hs, 0.f, -1.f)
+      GO2_WALL(w.xm, h00, h01, vv, uu * hs, 1.f, 0.f)
+      GO2_WALL(w.xp, h10, h11, vv, (1.f - uu) * hs, -1.f, 0.f)
+      GO2_WALL(w.ym, h00, h10, uu, vv * hs, 0.f, 1.f)
+      GO2_WALL(w.yp, h01, h11, uu, (1.f - vv) * hs, 0.f, -1.f)
 #undef GO2_WALL
+      // the vertical EDGE at the nearest cell corner, where the diagonal neighbour stands higher there than this cell (outside corner of a stair ring
+      // or a block): neither of the four faces above needs to exist for it.  Radii < hscale / 2: no other corner's edge can be penetrated from here.
+      {
+        const bool px = uu >= 0.5f, py = vv >= 0.5f;
+        const float bot = px ? (py ? h11 : h10) : (py ? h01 : h00);
+        const float top = (px ? (py ? w.dg[3] : w.dg[1]) : (py ? w.dg[2] : w.dg[0])) * vs;
+        if (top - bot > 0.5f * vs) {
+          const float ex = (px ? 1.f - uu : uu) * hs, ey = (py ? 1.f - vv : vv) * hs;
+          const float qz = fminf(fmaxf(c.z, bot), top), dz = c.z - qz, dist = sqrtf(ex * ex + ey * ey + dz * dz), gw = dist - r;
+          if (gw < g) { const float iv = 1.0f / fmaxf(dist, 1e-9f), sx = px ? -1.f : 1.f, sy = py ? -1.f : 1.f;
+            g = gw; nn = dist > 1e-9f ? v3(sx * ex * iv, sy * ey * iv, dz * iv) : v3(sx * 0.70710678f, sy * 0.70710678f, 0.f); }
+        }
+      }
     }
     *gap = g; *n = nn;
   }

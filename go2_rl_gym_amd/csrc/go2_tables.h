@@ -79,6 +79,11 @@ struct Go2RowsLds {
 // the contact surface over one grid cell: heights (vscale units) at the corners (i,j) (i+1,j) (i,j+1) (i+1,j+1) as seen from inside the cell
 // (include/go2sim.h Go2SimCfg.hf_cells); one aligned 8-byte load per contact query
 struct alignas(8) Go2Cell { int16_t h[4]; };
+// With hf_walls (mesh_type 'trimesh') a cell's record also carries what the query needs of its eight neighbours, so that a query is ONE 32-byte load
+// instead of six scattered 8-byte ones: the heights of the four edge neighbours along the common edge (xm: cell (i-1,j) at its corners 1, 3; xp: (i+1,j) at
+// 0, 2; ym: (i,j-1) at 2, 3; yp: (i,j+1) at 0, 1) and of the four diagonal neighbours at the common corner (dg[k]: at this cell's corner k).  A neighbour
+// outside the grid repeats the cell's own heights (no face, no edge).  Built at go2sim_create from hf_cells.
+struct alignas(16) Go2CellW { int16_t h[4]; int16_t xm[2], xp[2], ym[2], yp[2]; int16_t dg[4]; };
 
 // Device/host pointers of every per-env field.  The HIP library stores per-env fields FIELD-MAJOR (SoA):
 // logical [N, a, b] lives at ((b_idx * A + a_idx) * N + env), i.e. C order of the reversed logical dims,

@@ -1199,9 +1199,27 @@ int go2sim_create(const Go2SimCfg* cfg, int device_id, Go2Sim** out) {
         if (cfg->hf_cells) for (int k = 0; k < 4; ++k) q.h[k] = cfg->hf_cells[(i * nc + j) * 4 + k];
         else { const int16_t* h = cfg->hf_samples; const size_t C_ = (size_t)cfg->hf_cols; q.h[0] = h[i * C_ + j]; q.h[1] = h[(i + 1) * C_ + j]; q.h[2] = h[i * C_ + j + 1]; q.h[3] = h[(i + 1) * C_ + j + 1]; }
       }
-      s->d_cells = (Go2Cell*)dev_alloc(s, cells.size() * sizeof(Go2Cell));
-      if (!s->d_cells) { go2sim_destroy(s); FAIL(GO2SIM_ENOMEM, "allocation failed"); }
-      dev_upload(s->d_cells, cells.data(), cells.size() * sizeof(Go2Cell)); p.hf_cells = s->d_cells;
+      if (L.hf_walls) {        // trimesh: a record per cell that carries the neighbours' heights along its edges and at its corners (go2_tables.h Go2CellW)
+        std::vector<Go2CellW> cw(nr * nc);
+        for (long i = 0; i < (long)nr; ++i) for (long j = 0; j < (long)nc; ++j) {
+          Go2CellW& o = cw[i * nc + j]; const Go2Cell& q = cells[i * nc + j];
+          auto nb = [&](long a, long b) -> const Go2Cell* { return (a >= 0 && a < (long)nr && b >= 0 && b < (long)nc) ? &cells[a * nc + b] : nullptr; };
+          for (int k = 0; k < 4; ++k) o.h[k] = q.h[k];
+          const Go2Cell* c;
+          c = nb(i - 1, j); o.xm[0] = c ? c->h[1] : q.h[0]; o.xm[1] = c ? c->h[3] : q.h[2];
+          c = nb(i + 1, j); o.xp[0] = c ? c->h[0] : q.h[1]; o.xp[1] = c ? c->h[2] : q.h[3];
+          c = nb(i, j - 1); o.ym[0] = c ? c->h[2] : q.h[0]; o.ym[1] = c ? c->h[3] : q.h[1];
+          c = nb(i, j + 1); o.yp[0] = c ? c->h[0] : q.h[2]; o.yp[1] = c ? c->h[1] : q.h[3];
+          for (int k = 0; k < 4; ++k) { c = nb(i + ((k & 1) ? 1 : -1), j + ((k & 2) ? 1 : -1)); o.dg[k] = c ? c->h[3 - k] : q.h[k]; }
+        }
+        s->d_cells = (Go2Cell*)dev_alloc(s, cw.size() * sizeof(Go2CellW));
+        if (!s->d_cells) { go2sim_destroy(s); FAIL(GO2SIM_ENOMEM, "allocation failed"); }
+        dev_upload(s->d_cells, cw.data(), cw.size() * sizeof(Go2CellW)); p.hf_cells = s->d_cells;
+      } else {
+        s->d_cells = (Go2Cell*)dev_alloc(s, cells.size() * sizeof(Go2Cell));
+        if (!s->d_cells) { go2sim_destroy(s); FAIL(GO2SIM_ENOMEM, "allocation failed"); }
+        dev_upload(s->d_cells, cells.data(), cells.size() * sizeof(Go2Cell)); p.hf_cells = s->d_cells;
+      }
       // the candidate cull's view of the map (go2_lane.h phaseC): per GO2_TOP_CELL^2 block the highest cell corner within GO2_TOP_REACH
       // cells around it (separable running maximum), and the smallest facet n_z of the whole map
       const int B = GO2_TOP_CELL, R = GO2_TOP_REACH; const int tr = (int)((nr + B - 1) / B), tc = (int)((nc + B - 1) / B);

@@ -215,8 +215,9 @@ class LeggedRobotCfg(BaseConfig):
             contact_collection = 2
 
         class solver:                      # parameters of this build's own contact solver
-            iterations = 8                 # sweeps per substep = 2 per physx.num_position_iteration (round 6: at 4 the body forces' p90 gap to this model's own converged
-                                           # solve was 13 %, at 8 it is 3.8 % — profiles/r6_solver_convergence.txt; +5 us of the step kernel on the plane, +15 us on rough terrain)
+            iterations = 8                 # sweeps per substep = 2 per physx.num_position_iteration (round 6).  Against this model's own converged solve the body forces after one
+                                           # policy step are within p90 = 13 % at 4 sweeps, 9.6 % at 5, 6.6 % at 6, 5.2 % at 7, 3.8 % at 8 (profiles/r6_solver_convergence.txt); a sweep costs
+                                           # 2.2 us of the step kernel on the plane, 3.7 us on rough terrain (profiles/r6_kbench*.txt)
             erp = 0.5
             cfm = 1e-3
             joint_limit_margin = 0.05

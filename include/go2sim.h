@@ -140,7 +140,8 @@ typedef struct Go2SimCfg {
                                * convert_heightfield_to_trimesh builds with terrain.slope_treshold (legged_gym/utils/terrain.py:46-49,
                                * legged_robot.py:1127-1141): 1-cell ramps become flat cells ending in a vertical face, i.e. neighbouring cells
                                * that disagree on their common edge (go2_rl_gym_amd/utils/terrain.py:displaced_cell_heights). */
-  int32_t  hf_walls;          /* 1: the contact query also tests the vertical faces between disagreeing neighbour cells (set with hf_cells) */
+  int32_t  hf_walls;          /* 1: the contact query also tests the vertical faces between disagreeing neighbour cells and the vertical edge at the nearest cell
+                               * corner where the diagonal-neighbour cell stands higher (outside corners of stair rings and blocks) (set with hf_cells) */
   int32_t  terrain_num_levels, terrain_num_types; /* 10 x 20 */
   const float* terrain_origins; /* HOST [levels][types][3]; NULL for plane */
   const int32_t* terrain_type_id; /* HOST [types] -> terrain kind 0..8 (terrain.cols2id); NULL for plane */

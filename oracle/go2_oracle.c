@@ -384,7 +384,8 @@ static void aba(const Go2Sim* s, const Kin* k, const R* qd, const R* tau, R* acc
  * cell by cell (s->cells: heights at the corners (i,j) (i+1,j) (i,j+1) (i+1,j+1) as seen from inside the cell, go2sim.h hf_cells); the
  * contact is the deepest of the facet under the centre (two triangles per cell split along (i,j)-(i+1,j+1), the diagonal
  * isaacgym.terrain_utils.convert_heightfield_to_trimesh uses) and, with hf_walls, the vertical faces that stand on the cell's edges where
- * the neighbouring cell's edge is higher (mesh_type 'trimesh' with slope_treshold, legged_robot.py:1127-1141). */
+ * the neighbouring cell's edge is higher, and the vertical edge at the nearest cell corner where the DIAGONAL neighbour is higher (mesh_type
+ * 'trimesh' with slope_treshold, legged_robot.py:1127-1141). */
 static R clampR(R x, R lo, R hi) { return x < lo ? lo : (x > hi ? hi : x); }
 static void wall_face(const Go2Sim* s, int inside, int ni, int nj, R a0, R a1, int k0, int k1, R t, R d, R nx, R ny, const R* c, R r, R* g, R* n) {
   if (!inside) return;
@@ -417,6 +418,20 @@ static void contact_query(const Go2Sim* s, const R* c, R r, R* gap, R* n) {
     wall_face(s, i < rows-2, i+1, j,   h10, h11, 0, 2, v, (1-u)*hs, -1, 0, c, r, &g, n);
     wall_face(s, j > 0,      i,   j-1, h00, h10, 2, 3, u, v*hs,     0, 1, c, r, &g, n);
     wall_face(s, j < cols-2, i,   j+1, h01, h11, 0, 1, u, (1-v)*hs, 0, -1, c, r, &g, n);
+    /* the vertical EDGE at the cell corner nearest to the centre: where the diagonal-neighbour cell stands higher at that corner than this
+     * cell (the outside corner of a stair ring or of a block, terrain.py:44-49 -> legged_robot.py:1127-1141), the segment from this cell's
+     * height to the diagonal cell's belongs to the mesh although neither of this cell's four faces needs to exist.  Radii are < hscale / 2,
+     * so a sphere centred in this cell cannot penetrate the edge at any other corner. */
+    int di = u >= RC(0.5) ? 1 : -1, dj = v >= RC(0.5) ? 1 : -1, ii = i+di, jj = j+dj;
+    if (ii >= 0 && ii <= rows-2 && jj >= 0 && jj <= cols-2) {
+      int kc = (di > 0 ? 1 : 0) + (dj > 0 ? 2 : 0);
+      R bot = q[kc]*vs, top = s->cells[((size_t)ii*nc + jj)*4 + (3-kc)]*vs;
+      if (top - bot > RC(0.5)*vs) {
+        R ex = (di > 0 ? 1-u : u)*hs, ey = (dj > 0 ? 1-v : v)*hs;
+        R qz = clampR(c[2], bot, top), dz = c[2]-qz, dist = SQRT(ex*ex + ey*ey + dz*dz), gw = dist - r;
+        if (gw < g) { g = gw; if (dist > RC(1e-9)) { n[0] = -di*ex/dist; n[1] = -dj*ey/dist; n[2] = dz/dist; } else { n[0]=-di*RC(0.70710678118654752); n[1]=-dj*RC(0.70710678118654752); n[2]=0; } }
+      }
+    }
   }
   *gap = g;
 }

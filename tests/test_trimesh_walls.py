@@ -240,3 +240,115 @@ def test_calf_lying_across_a_nosing_between_its_end_spheres_reports_a_calf_force
     assert abs(gaps[2] + 0.004) < 2e-4, gaps                           # the mid sample is 4 mm into the edge
     assert f[1] > 1.0, f                                               # ... and the calf body reports it
     assert others == 0.0, others                                       # nothing else of the robot touches anything
+
+
+# --- the outside corner of a block: the vertical edge that belongs to the DIAGONAL-neighbour cell (round 6, VERDICT r3-r5 item "contact geometry") -------------------
+CORNER = np.array([6.0, 3.0])
+
+
+def block_world(mesh_type="trimesh"):
+    """The 12 m x 6 m map with ONE block: 15 cm up for x >= 6 m AND y >= 3 m.  From the quadrant x < 6, y < 3 the block shows no face of the
+    centre's own cell — only its vertical edge at (6, 3): what a stair ring or a discrete obstacle shows to a foot that arrives diagonally."""
+    from go2_rl_gym_amd.utils.terrain import displaced_cell_heights
+    rows, cols = 161, 101
+    hf = np.zeros((rows, cols), np.int16)
+    ki, kj = int(round((CORNER[0] + BORDER) / HS)), int(round((CORNER[1] + BORDER) / HS))
+    hf[ki:, kj:] = int(round(STEP_H / VS))
+    ov = dict(terrain_mode=1, hf_rows=rows, hf_cols=cols, hf_hscale=HS, hf_vscale=VS, hf_border=BORDER, hf_samples=np.ascontiguousarray(hf),
+              terrain_origins=np.zeros((1, 1, 3), np.float32), terrain_type_id=np.zeros(1, np.int32), terrain_num_levels=1, terrain_num_types=1,
+              terrain_curriculum=0, max_init_terrain_level=0, measure_heights=1)
+    if mesh_type == "trimesh":
+        ov.update(hf_cells=np.ascontiguousarray(displaced_cell_heights(hf, HS, VS, 0.75)), hf_walls=1)
+    return hf, ov
+
+
+def corner_queries(lib, sim, query=query):
+    """-> (got, expected) rows [gap, nx, ny, nz] of the contact query around the block's outside corner."""
+    r = 0.022
+    _, ov = block_world()
+    s = sim(lib, num_envs=1, **ov)
+    pts, exp = [], []
+    for a, b in ((0.01, 0.01), (0.02, 0.005), (0.004, 0.03), (0.03, 0.03)):
+        d = np.hypot(a, b)
+        pts.append([CORNER[0] - a, CORNER[1] - b, 0.05, r]); exp.append([d - r, -a / d, -b / d, 0.0])            # beside the edge: horizontal, diagonal normal
+        dz = 0.01; d3 = np.sqrt(a * a + b * b + dz * dz)
+        pts.append([CORNER[0] - a, CORNER[1] - b, STEP_H + dz, r]); exp.append([d3 - r, -a / d3, -b / d3, dz / d3])   # over its top end: all three components
+    # away from the corner the lower level and the faces are what they were: on the tread, and beside the face x = 6 at y > 3
+    pts.append([CORNER[0] - 0.08, CORNER[1] - 0.08, 0.05, r]); exp.append([0.05 - r, 0, 0, 1])
+    pts.append([CORNER[0] - 0.03, CORNER[1] + 0.5, 0.05, r]); exp.append([0.03 - r, -1, 0, 0])
+    pts.append([CORNER[0] + 0.5, CORNER[1] - 0.03, 0.05, r]); exp.append([0.03 - r, 0, -1, 0])
+    got = query(lib, s, pts)
+    s.close()
+    return got, np.array(exp)
+
+
+@pytest.mark.parametrize("which", ["oracle", "lane_emulation"])
+def test_outside_corner_of_a_block_is_a_vertical_edge(which):
+    lib = {"oracle": load_oracle, "lane_emulation": load_emu}[which]()
+    got, exp = corner_queries(lib, HostSim)
+    np.testing.assert_allclose(got, exp, atol=3e-5)
+
+
+def test_corner_query_equals_exact_distance_to_the_displaced_mesh():
+    """Around the outside corner the query equals the exact sphere-to-mesh distance of the reference's displaced trimesh (brute force over its triangles)."""
+    from go2_rl_gym_amd.utils.terrain import convert_heightfield_to_trimesh
+    lib = load_oracle()
+    hf, ov = block_world()
+    s = HostSim(lib, num_envs=1, **ov)
+    verts, tris = convert_heightfield_to_trimesh(hf, HS, VS, 0.75)
+    verts = verts.astype(np.float64) - [BORDER, BORDER, 0.0]
+    near = np.nonzero((np.abs(verts[tris][:, :, 0] - CORNER[0]).min(1) < 0.35) & (np.abs(verts[tris][:, :, 1] - CORNER[1]).min(1) < 0.35))[0]
+    rng = np.random.default_rng(5)
+    r, pts, exact = 0.022, [], []
+    for _ in range(80):
+        x, y = CORNER - rng.uniform(0.001, 0.045, 2)                # the quadrant in front of the edge, inside the diagonal cell
+        c = np.array([x, y, rng.uniform(0.03, STEP_H + 0.04)])
+        d, n = _closest_on_triangles(verts, tris[near], c)
+        pts.append([x, y, c[2], r]); exact.append([d - r, *n])
+    got, exact = query(lib, s, pts), np.array(exact)
+    assert np.abs(got[:, 0] - exact[:, 0]).max() < 1e-4
+    assert np.abs(got[:, 1:] - exact[:, 1:]).max() < 5e-3
+    s.close()
+
+
+def foot_pressed_into_corner(lib, sim, steps=10, **kw):
+    """Robot standing on the lower level, teleported so that its FL foot sphere starts 1 cm inside the block's vertical edge along the diagonal; zero
+    actions.  -> (the foot's horizontal offset from the corner after the first env step, the contact forces on the FL foot in the steps after it, the offset and
+    height of the foot after `steps` steps)."""
+    _, ov = block_world()
+    s = sim(lib, num_envs=1, push_robots=0, add_noise=0, randomize_action_delay=0, **ov, **kw)
+    s.inject(np.full((1, lib.abi.GO2_NUM_UNIFORMS), 0.5, np.float32)); s.reset_all()
+    root = np.asarray(s.root_states).copy(); root[:, 3:7] = [0, 0, 0, 1]; root[:, 7:] = 0; root[:, 0] = 3.0; root[:, 1] = 1.0; root[:, 2] = 0.33
+    s.root_states[:] = root
+    zero = np.zeros((1, 12), np.float32)
+    for _ in range(25):
+        s.step(zero)
+    off = np.asarray(s.rigid_body_states)[0, FL_FOOT_B, :2] - np.asarray(s.root_states)[0, :2]
+    root = np.asarray(s.root_states).copy(); root[:, 7:] = 0
+    inside = (0.022 - 0.010) / np.sqrt(2.0)                               # centre 12 mm from the edge along the diagonal: 1 cm deep
+    root[0, :2] = CORNER - inside - off
+    s.root_states[:] = root
+    d = np.asarray(s.dof_state).copy(); d[:, :, 1] = 0; s.dof_state[:] = d
+    s.step(zero)
+    first = np.asarray(s.rigid_body_states)[0, FL_FOOT_B, :2] - CORNER
+    forces = []
+    for _ in range(steps - 1):
+        s.step(zero)
+        forces.append(np.asarray(s.contact_forces, np.float64)[0, FL_FOOT_B].copy())
+    foot = np.asarray(s.rigid_body_states)[0, FL_FOOT_B, :3].copy()
+    s.close()
+    return first, np.array(forces), foot[:2] - CORNER, foot[2]
+
+
+@pytest.mark.parametrize("which", ["oracle", "lane_emulation"])
+def test_foot_pressed_into_an_outside_corner_is_pushed_out_along_the_diagonal(which):
+    """Known-answer behaviour: the edge answers with a force that has BOTH horizontal components (no face of the foot's own cell exists there; before
+    round 6 the foot stayed where it was put, 1 cm inside the block's corner, with no horizontal force at all): one env step moves the foot out in x
+    AND y until it touches the edge, and there it keeps reporting a force that points away from the corner in both."""
+    lib = {"oracle": load_oracle, "lane_emulation": load_emu}[which]()
+    first, forces, off, z = foot_pressed_into_corner(lib, HostSim)
+    start = -(0.022 - 0.010) / np.sqrt(2.0)
+    assert first[0] < start - 0.002 and first[1] < start - 0.002 and np.hypot(*first) > 0.022 - 0.003, first      # depenetrated along both axes within one step
+    assert (forces[:, 0] < -1.0).all() and (forces[:, 1] < -1.0).all(), forces
+    assert off[0] < 0 and off[1] < 0 and abs(np.hypot(*off) - 0.022) < 0.003, off           # resting against the edge ...
+    assert abs(z - 0.022) < 0.006, z                                                          # ... on the lower level

@@ -62,6 +62,7 @@ if __name__ == "__main__":
     run("default (8 PGS sweeps, 4 substeps)")
     run("no PGS sweeps", solver_iterations=0)
     run("4 PGS sweeps", solver_iterations=4)
+    run("6 PGS sweeps", solver_iterations=6)
     run("8 PGS sweeps", solver_iterations=8)
     run("16 PGS sweeps", solver_iterations=16)
     run("1 substep", decimation=1)

@@ -18,7 +18,7 @@ if "--both" in sys.argv:          # the shipped model, then the EXPERIMENT of VE
         subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, GO2_ORACLE_WARM_GROUPS=w), check=True)
     sys.exit(0)
 # round 6: the shipped count is 8 sweeps (solver.iterations = 2 x physx.num_position_iterations); the trajectory follows the shipped model (first entry of iters)
-t = solver_convergence_table(steps=100, N=128, iters=(8, 4, 16, 64, 256))
+t = solver_convergence_table(steps=100, N=128, iters=(8, 4, 5, 6, 7, 16, 64, 256))
 t = {k: t[k] for k in sorted(t)}
 n = len(next(iter(t.values()))["base_twist"])
 print("contact solve: k sweeps vs 1024 sweeps of the same model (fp64 oracle, %d env-steps = 100 policy steps x 128 envs, N(0,1) actions, re-synced every step)" % n)
