@@ -5,6 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/${1:-final}; mkdir -p $O
 cd $R
 python __graft_entry__.py > $O/build.log 2>&1
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log
 timeout 1500 python -m pytest tests -q -m gpu -s -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log
 timeout 400 python bench.py > $O/bench.json 2> $O/bench.err
 GO2_GEMM_SPLIT=0 timeout 200 python bench.py --no-cpu-baseline > $O/bench_fp32_mfma_gemms.json 2> /dev/null
