@@ -28,6 +28,6 @@ while done < iters:
     txt = buf.getvalue()
     last = txt[txt.rfind("Learning iteration"):]
     pick = lambda key: (re.findall(key + r"\s*(-?[\d.]+)", last) or ["nan"])[-1]
-    names = ("Mean reward:", "Mean teacher reward:", "Mean student reward:", "Mean episode length:", "Mean teacher episode length:", "Mean student episode length:", "Mean episode rew_tracking_lin_vel:", "Mean episode rew_tracking_ang_vel:", "Mean action noise std:", "Computation:")
+    names = ("Mean reward:", "Mean teacher reward:", "Mean student reward:", "Mean episode length:", "Mean teacher episode length:", "Mean student episode length:", "Mean episode rew_tracking_lin_vel:", "Mean episode rew_tracking_ang_vel:", "Mean episode terrain_level_all:", "Mean episode terrain_level_stairs_up:", "Mean action noise std:", "Computation:")
     print("it %4d | " % done + " | ".join("%s %s" % (n.replace("Mean ", "").replace("episode ", "").rstrip(":"), pick(re.escape(n))) for n in names if pick(re.escape(n)) != "nan"), flush=True)
 env.close()
