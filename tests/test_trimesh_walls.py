@@ -352,3 +352,45 @@ def test_foot_pressed_into_an_outside_corner_is_pushed_out_along_the_diagonal(wh
     assert (forces[:, 0] < -1.0).all() and (forces[:, 1] < -1.0).all(), forces
     assert off[0] < 0 and off[1] < 0 and abs(np.hypot(*off) - 0.022) < 0.003, off           # resting against the edge ...
     assert abs(z - 0.022) < 0.006, z                                                          # ... on the lower level
+
+
+def test_query_against_exact_distance_on_discrete_obstacles():
+    """Blocks of random height (the 'obstacles' column of the curriculum map): near their faces, edges and corners the query's gap equals the exact sphere-to-mesh distance
+    of the reference's displaced trimesh for > 90 % of the spheres (measured 93.0 %; 92.0 % before the corner edge of round 6, stairs 99.7 -> 100 %) and never reports a contact
+    more than 5 mm deeper than the mesh has it.  What is left are the cells AT a block's corner, where the slope correction leaves a triangular face (three corners of the
+    neighbour cell up, one down): the query takes the foot of the perpendicular at the sphere's own position along the edge, which is exact for a rectangular face only,
+    and over-estimates the gap to a triangular one."""
+    from go2_rl_gym_amd.utils.terrain import SubTerrain, convert_heightfield_to_trimesh, discrete_obstacles_terrain, displaced_cell_heights
+    lib = load_oracle()
+    t = SubTerrain("t", width=60, length=60, vertical_scale=VS, horizontal_scale=HS)
+    state = np.random.get_state(); np.random.seed(4)
+    try:
+        discrete_obstacles_terrain(t, max_height=0.2, min_size=1.0, max_size=2.0, num_rects=20, platform_size=3.0)
+    finally:
+        np.random.set_state(state)
+    hf = np.ascontiguousarray(t.height_field_raw)
+    cells = displaced_cell_heights(hf, HS, VS, 0.75)
+    ov = dict(terrain_mode=1, hf_rows=60, hf_cols=60, hf_hscale=HS, hf_vscale=VS, hf_border=0.0, hf_samples=hf,
+              terrain_origins=np.zeros((1, 1, 3), np.float32), terrain_type_id=np.zeros(1, np.int32), terrain_num_levels=1, terrain_num_types=1,
+              terrain_curriculum=0, max_init_terrain_level=0, hf_cells=np.ascontiguousarray(cells), hf_walls=1)
+    s = HostSim(lib, num_envs=1, **ov)
+    verts, tris = convert_heightfield_to_trimesh(hf, HS, VS, 0.75)
+    verts = verts.astype(np.float64); tv = verts[tris]
+    rng = np.random.default_rng(1)
+    r, pts, exact = 0.03, [], []
+    while len(pts) < 200:
+        x, y = rng.uniform(0.6, 5.3, 2)
+        i, j = int(x / HS), int(y / HS)
+        zlo, ztop = cells[i, j].max() * VS, hf[max(i - 1, 0):i + 3, max(j - 1, 0):j + 3].max() * VS
+        if ztop - zlo < 0.02:
+            continue                                               # only spheres beside something higher than their own cell
+        c = np.array([x, y, rng.uniform(zlo + 0.005, ztop + 0.06)])
+        near = np.nonzero((np.abs(tv[:, :, 0] - x).min(1) < 0.35) & (np.abs(tv[:, :, 1] - y).min(1) < 0.35))[0]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            d, n = _closest_on_triangles(verts, tris[near], c)
+        if d < 0.08:
+            pts.append([x, y, c[2], r]); exact.append(d - r)
+    got, exact = query(lib, s, pts)[:, 0], np.array(exact)
+    s.close()
+    assert (np.abs(got - exact) < 2e-3).mean() > 0.90, (np.abs(got - exact) < 2e-3).mean()
+    assert (exact - got).max() < 5e-3, (exact - got).max()
