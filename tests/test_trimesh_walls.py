@@ -357,9 +357,9 @@ def test_foot_pressed_into_an_outside_corner_is_pushed_out_along_the_diagonal(wh
 def test_query_against_exact_distance_on_discrete_obstacles():
     """Blocks of random height (the 'obstacles' column of the curriculum map): near their faces, edges and corners the query's gap equals the exact sphere-to-mesh distance
     of the reference's displaced trimesh for > 90 % of the spheres (measured 93.0 %; 92.0 % before the corner edge of round 6, stairs 99.7 -> 100 %) and never reports a contact
-    more than 5 mm deeper than the mesh has it.  What is left are the cells AT a block's corner, where the slope correction leaves a triangular face (three corners of the
-    neighbour cell up, one down): the query takes the foot of the perpendicular at the sphere's own position along the edge, which is exact for a rectangular face only,
-    and over-estimates the gap to a triangular one."""
+    more than 5 mm deeper than the mesh has it.  What is left sits AT the blocks' corners, where the slope correction moves a vertex in x AND y and leaves slanted triangles across a
+    cell that "four corner heights per cell + vertical faces on the cell's edges" cannot hold (treating the faces there as the exact trapezoids / triangles between the two cells'
+    edge lines was tried in the oracle, round 6: 93.0 -> 93.3 %, not kept); the query then over-estimates the gap, i.e. the contact starts a little later than on the mesh."""
     from go2_rl_gym_amd.utils.terrain import SubTerrain, convert_heightfield_to_trimesh, discrete_obstacles_terrain, displaced_cell_heights
     lib = load_oracle()
     t = SubTerrain("t", width=60, length=60, vertical_scale=VS, horizontal_scale=HS)
