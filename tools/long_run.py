@@ -2,7 +2,7 @@
 """A training run over the reference's own horizon (go2_config.py: max_iterations = 150000) on one MI355X, then the trained student policy next to the policy the
 reference ships (trained for 150 k iterations in Isaac Gym; tests/golden/pretrained_go2_cts_150k.npz) under the walking protocol of tests/test_export.py:
 1 m/s forward command, plane and rough curriculum map, 80 robots, 8 s.
-   python tools/long_run.py [task] [iterations] [every] [seed]      -> stdout; the final checkpoint goes to gpurun_out/long_run_<task>.pt"""
+   python tools/long_run.py [task] [iterations] [every] [seed] [wall budget, s]      -> stdout; the final checkpoint goes to gpurun_out/long_run_<task>.pt"""
 import contextlib
 import io
 import math
@@ -24,6 +24,7 @@ task = sys.argv[1] if len(sys.argv) > 1 else "go2_cts"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 150000
 every = int(sys.argv[3]) if len(sys.argv) > 3 else 5000
 seed = sys.argv[4] if len(sys.argv) > 4 else "1"
+budget = float(sys.argv[5]) if len(sys.argv) > 5 else float("inf")          # wall seconds for the training part (a gpurun call is limited to 60 minutes): stop at the next checkpoint line past it
 args = get_args(["--task", task, "--num_envs", "4096", "--headless", "--seed", seed])
 env_cfg, train_cfg = task_registry.get_cfgs(task)
 env_cfg.seed = train_cfg.seed = int(seed)
@@ -52,6 +53,8 @@ while done < iters:
           + " | wall %.0f s | weights finite: %s" % (time.time() - t0, finite), flush=True)
     if not finite:
         print("STOP: non-finite weights"); break
+    if time.time() - t0 > budget:
+        print("(wall budget of %.0f s reached: stopping the training here)" % budget, flush=True); break
 wall = time.time() - t0
 print("trained %d iterations = %.3g env-steps in %.1f s wall (%.2f M env-steps/s including logging and the curve's parsing)" % (done, done * 24 * 4096.0, wall, done * 24 * 4096 / wall / 1e6), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
