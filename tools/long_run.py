@@ -61,6 +61,8 @@ os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 ck = os.path.join(ROOT, "gpurun_out", "long_run_%s.pt" % task)
 torch.save({k: v.detach().cpu() for k, v in runner.alg.model.state_dict().items()}, ck)
 sd = {k: v.detach().cpu() for k, v in runner.alg.model.state_dict().items()}
+import copy
+model_cpu = copy.deepcopy(runner.alg.model).cpu()
 env.close()
 
 # ---- the walking protocol (tests/test_export.py:run_pretrained_walk) for both policies on the HIP simulator --------------------------------------------------------
@@ -90,11 +92,14 @@ def walk(m, sim, seconds=8.0):
     return float(np.mean(speeds)), zmin, resets
 
 
-if task in ("go2_cts", "go2_flat_cts"):
+if True:
     ref, _ = pretrained_policy()
-    ours = ActorCriticCTS(45, 263, 12, 1, 5)
-    missing, unexpected = ours.load_state_dict(sd, strict=False)
-    assert not unexpected, unexpected
+    if task in ("go2_cts", "go2_flat_cts"):
+        ours = ActorCriticCTS(45, 263, 12, 1, 5)
+        missing, unexpected = ours.load_state_dict(sd, strict=False)
+        assert not unexpected, unexpected
+    else:
+        ours = model_cpu          # (a plain ActorCritic: act_inference(obs) = the actor's mean)
     hip = load_hip()
     for terrain in ("plane", "rough curriculum map"):
         for name, m in (("the reference's shipped policy (150 k iterations in Isaac Gym)", ref), ("the policy trained here (%d iterations)" % done, ours)):
