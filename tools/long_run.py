@@ -34,6 +34,7 @@ logdir = tempfile.mkdtemp()
 runner, _ = task_registry.make_alg_runner(env, None, args, train_cfg=train_cfg, log_root=logdir)
 env.common_step_counter = 0
 env.update_reward_curriculum(force_update=True)
+model = runner.alg.model if hasattr(runner.alg, "model") else runner.alg.actor_critic          # (CTS family / PPO)
 print("task %s, %d iterations of 24 x 4096 env-steps, seed %s" % (task, iters, seed), flush=True)
 done, t0 = 0, time.time()
 names = ("Mean reward:", "Mean teacher reward:", "Mean student reward:", "Mean episode length:", "Mean teacher episode length:", "Mean student episode length:",
@@ -48,7 +49,7 @@ while done < iters:
     last = txt[txt.rfind("Learning iteration"):]
     pick = lambda key: (re.findall(key + r"\s*(-?[\d.]+|nan|inf)", last) or ["-"])[-1]
     vals = {k: pick(re.escape(k)) for k in names}
-    finite = all(torch.isfinite(p).all().item() for p in runner.alg.model.parameters())
+    finite = all(torch.isfinite(p).all().item() for p in model.parameters())
     print("it %6d | " % done + " | ".join("%s %s" % (k.replace("Mean ", "").replace("episode ", "").rstrip(":"), v) for k, v in vals.items() if v != "-")
           + " | wall %.0f s | weights finite: %s" % (time.time() - t0, finite), flush=True)
     if not finite:
@@ -59,10 +60,10 @@ wall = time.time() - t0
 print("trained %d iterations = %.3g env-steps in %.1f s wall (%.2f M env-steps/s including logging and the curve's parsing)" % (done, done * 24 * 4096.0, wall, done * 24 * 4096 / wall / 1e6), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 ck = os.path.join(ROOT, "gpurun_out", "long_run_%s.pt" % task)
-torch.save({k: v.detach().cpu() for k, v in runner.alg.model.state_dict().items()}, ck)
-sd = {k: v.detach().cpu() for k, v in runner.alg.model.state_dict().items()}
+torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, ck)
+sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
 import copy
-model_cpu = copy.deepcopy(runner.alg.model).cpu()
+model_cpu = copy.deepcopy(model).cpu()
 env.close()
 
 # ---- the walking protocol (tests/test_export.py:run_pretrained_walk) for both policies on the HIP simulator --------------------------------------------------------
