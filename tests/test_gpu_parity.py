@@ -789,6 +789,12 @@ def test_trimesh_walls_on_gpu(hip):
         return do.cpu().numpy()
     got, exp = tw.corner_queries(hip, DeviceSim, query=device_query)
     np.testing.assert_allclose(got, exp, atol=3e-5)
+    # the device's one-record-per-cell query against the oracle's direct neighbour reads on a map of independent random cells (grid borders included)
+    ov_r, pts_r = tw.random_cells_world()
+    so_r, sd_r = HostSim(load_oracle(), num_envs=1, **ov_r), DeviceSim(hip, num_envs=1, **ov_r)
+    want_r, got_r = tw.query(load_oracle(), so_r, pts_r), device_query(hip, sd_r, pts_r)
+    so_r.close(); sd_r.close()
+    tw.check_against_oracle_on_random_cells(got_r, want_r)
     first, forces, off, z = tw.foot_pressed_into_corner(hip, DeviceSim)
     first_o, forces_o, off_o, z_o = tw.foot_pressed_into_corner(load_oracle(), HostSim)
     assert (forces[:, 0] < -1.0).all() and (forces[:, 1] < -1.0).all() and abs(np.hypot(*off) - 0.022) < 0.003, (forces, off)

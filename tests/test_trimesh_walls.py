@@ -394,3 +394,37 @@ def test_query_against_exact_distance_on_discrete_obstacles():
     s.close()
     assert (np.abs(got - exact) < 2e-3).mean() > 0.90, (np.abs(got - exact) < 2e-3).mean()
     assert (exact - got).max() < 5e-3, (exact - got).max()
+
+
+def random_cells_world(n=4000):
+    """A map of INDEPENDENT random cells (every edge and every corner disagrees somewhere, which no terrain generator produces), half of them flat at 0, and spheres
+    everywhere including the outermost cells, where a neighbour does not exist.  -> (config overrides, query points)"""
+    rows, cols = 24, 19
+    rng = np.random.default_rng(11)
+    hf = rng.integers(-30, 30, (rows, cols)).astype(np.int16)
+    cells = rng.integers(-40, 40, (rows - 1, cols - 1, 4)).astype(np.int16)
+    cells[rng.random((rows - 1, cols - 1)) < 0.5] = 0
+    ov = dict(terrain_mode=1, hf_rows=rows, hf_cols=cols, hf_hscale=HS, hf_vscale=VS, hf_border=0.3, hf_samples=np.ascontiguousarray(hf),
+              terrain_origins=np.zeros((1, 1, 3), np.float32), terrain_type_id=np.zeros(1, np.int32), terrain_num_levels=1, terrain_num_types=1,
+              terrain_curriculum=0, max_init_terrain_level=0, hf_cells=np.ascontiguousarray(cells), hf_walls=1)
+    pts = np.stack([rng.uniform(-0.35, (rows - 1) * HS - 0.25, n), rng.uniform(-0.35, (cols - 1) * HS - 0.25, n), rng.uniform(-0.25, 0.3, n), rng.uniform(0.0, 0.046, n)], 1).astype(np.float32)
+    return ov, pts
+
+
+def check_against_oracle_on_random_cells(got, want):
+    d = np.abs(got - want).max(1)
+    # (fp32 on both sides: a centre within rounding of a cell boundary, of the facets' diagonal or of u = 0.5 may be assigned to the other side)
+    assert np.quantile(d, 0.995) < 2e-5 and (d > 1e-3).mean() < 3e-3, (float(np.quantile(d, 0.995)), float((d > 1e-3).mean()))
+    assert ((np.abs(want[:, 1]) > 0.1) & (np.abs(want[:, 2]) > 0.1) & (want[:, 3] < 0.9)).sum() > 50       # corner edges were hit
+    assert (want[:, 3] < 0.5).mean() > 0.1                                                                 # and faces
+
+
+def test_cell_records_equal_direct_neighbour_reads_on_random_maps():
+    """The HIP code answers a query from ONE 32-byte record per cell (own corners + the neighbours' heights along the edges and at the corners, built at go2sim_create;
+    go2_tables.h Go2CellW), the oracle reads the neighbour cells themselves: on random cells the two answer alike (lane emulation here, the device in
+    tests/test_gpu_parity.py::test_trimesh_walls_on_gpu)."""
+    ov, pts = random_cells_world()
+    so, se = HostSim(load_oracle(), num_envs=1, **ov), HostSim(load_emu(), num_envs=1, **ov)
+    want, got = query(load_oracle(), so, pts), query(load_emu(), se, pts)
+    so.close(); se.close()
+    check_against_oracle_on_random_cells(got, want)
